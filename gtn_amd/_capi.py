@@ -1,0 +1,143 @@
+"""ctypes binding of the C ABI declared in include/gtn_amd.h.
+
+`load(path)` returns a ctypes library object with every entry point of the
+header typed.  The product library is gtn_amd/lib/libgtn_amd.so (HIP, gfx950);
+the parity tests also load oracle/_ref/libgtn_ref.so -- the unmodified
+reference behind the same ABI -- through this same function.
+"""
+import ctypes as C
+import os
+
+c_graph = C.c_void_p
+c_graph_p = C.POINTER(C.c_void_p)
+c_i32_p = C.POINTER(C.c_int)
+c_i64_p = C.POINTER(C.c_int64)
+c_u8_p = C.POINTER(C.c_uint8)
+c_f32_p = C.POINTER(C.c_float)
+
+GRAD_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, c_graph_p, C.c_int, c_graph)
+CTX_FREE = C.CFUNCTYPE(None, C.c_void_p)
+
+OK, INVALID_ARGUMENT, LOGIC_ERROR, RUNTIME_ERROR, OUT_OF_RANGE, DEVICE_ERROR = range(6)
+
+# name -> argtypes (restype is c_int status unless listed in _RESTYPE)
+_SIGS = {
+    "gtnx_set_device": [C.c_int],
+    "gtnx_set_stream": [C.c_void_p],
+    "gtnx_synchronize": [],
+    "gtnx_memory_stats": [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "gtnx_empty_cache": [],
+    "gtnx_graph_create": [C.c_int, c_graph_p],
+    "gtnx_graph_copy": [c_graph, c_graph_p],
+    "gtnx_graph_deep_copy": [c_graph, c_graph_p],
+    "gtnx_graph_destroy": [c_graph],
+    "gtnx_graph_add_node": [c_graph, C.c_int, C.c_int, c_i32_p],
+    "gtnx_graph_add_arc": [c_graph, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_i32_p],
+    "gtnx_graph_add_nodes": [c_graph, C.c_int, C.c_void_p, C.c_void_p],
+    "gtnx_graph_add_arcs": [c_graph, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gtnx_graph_num_nodes": [c_graph, c_i64_p],
+    "gtnx_graph_num_arcs": [c_graph, c_i64_p],
+    "gtnx_graph_num_start": [c_graph, c_i64_p],
+    "gtnx_graph_num_accept": [c_graph, c_i64_p],
+    "gtnx_graph_item": [c_graph, c_f32_p],
+    "gtnx_graph_arc_sort": [c_graph, C.c_int],
+    "gtnx_graph_mark_arc_sorted": [c_graph, C.c_int],
+    "gtnx_graph_ilabel_sorted": [c_graph, c_i32_p],
+    "gtnx_graph_olabel_sorted": [c_graph, c_i32_p],
+    "gtnx_graph_weights": [c_graph, C.c_int, C.POINTER(c_f32_p)],
+    "gtnx_graph_get_weights": [c_graph, C.c_void_p],
+    "gtnx_graph_set_weights": [c_graph, C.c_void_p],
+    "gtnx_graph_set_weights_device": [c_graph, C.c_void_p],
+    "gtnx_graph_weights_device": [c_graph, C.POINTER(C.c_void_p)],
+    "gtnx_graph_labels_to_array": [c_graph, C.c_void_p, C.c_int],
+    "gtnx_graph_get_start": [c_graph, C.c_void_p],
+    "gtnx_graph_get_accept": [c_graph, C.c_void_p],
+    "gtnx_graph_is_start": [c_graph, C.c_int, c_i32_p],
+    "gtnx_graph_is_accept": [c_graph, C.c_int, c_i32_p],
+    "gtnx_graph_make_accept": [c_graph, C.c_int],
+    "gtnx_graph_num_out": [c_graph, C.c_int, c_i64_p],
+    "gtnx_graph_num_in": [c_graph, C.c_int, c_i64_p],
+    "gtnx_graph_get_out": [c_graph, C.c_int, C.c_void_p],
+    "gtnx_graph_get_in": [c_graph, C.c_int, C.c_void_p],
+    "gtnx_graph_get_arcs": [c_graph, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "gtnx_graph_get_arc": [c_graph, C.c_int, c_i32_p, c_i32_p, c_i32_p, c_i32_p, c_f32_p],
+    "gtnx_graph_set_weight": [c_graph, C.c_int, C.c_float],
+    "gtnx_graph_calc_grad": [c_graph, c_i32_p],
+    "gtnx_graph_set_calc_grad": [c_graph, C.c_int],
+    "gtnx_graph_is_grad_available": [c_graph, c_i32_p],
+    "gtnx_graph_grad": [c_graph, c_graph_p],
+    "gtnx_graph_zero_grad": [c_graph],
+    "gtnx_graph_add_grad": [c_graph, C.c_void_p, C.c_int64],
+    "gtnx_graph_add_grad_graph": [c_graph, c_graph],
+    "gtnx_graph_id": [c_graph, C.POINTER(C.c_size_t)],
+    "gtnx_graph_create_op": [c_graph_p, C.c_int, GRAD_FN, C.c_void_p, CTX_FREE, c_graph_p],
+    "gtnx_graph_num_inputs": [c_graph, c_i64_p],
+    "gtnx_scalar_graph": [C.c_float, C.c_int, c_graph_p],
+    "gtnx_linear_graph": [C.c_int, C.c_int, C.c_int, c_graph_p],
+    "gtnx_linear_graph_n": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_graph_p],
+    "gtnx_negate": [c_graph, c_graph_p],
+    "gtnx_add": [c_graph, c_graph, c_graph_p],
+    "gtnx_subtract": [c_graph, c_graph, c_graph_p],
+    "gtnx_compose": [c_graph, c_graph, c_graph_p],
+    "gtnx_intersect": [c_graph, c_graph, c_graph_p],
+    "gtnx_forward_score": [c_graph, c_graph_p],
+    "gtnx_viterbi_score": [c_graph, c_graph_p],
+    "gtnx_viterbi_path": [c_graph, c_graph_p],
+    "gtnx_negate_n": [c_graph_p, C.c_int, c_graph_p],
+    "gtnx_add_n": [c_graph_p, C.c_int, c_graph_p, C.c_int, c_graph_p],
+    "gtnx_subtract_n": [c_graph_p, C.c_int, c_graph_p, C.c_int, c_graph_p],
+    "gtnx_compose_n": [c_graph_p, C.c_int, c_graph_p, C.c_int, c_graph_p],
+    "gtnx_intersect_n": [c_graph_p, C.c_int, c_graph_p, C.c_int, c_graph_p],
+    "gtnx_forward_score_n": [c_graph_p, C.c_int, c_graph_p],
+    "gtnx_viterbi_score_n": [c_graph_p, C.c_int, c_graph_p],
+    "gtnx_viterbi_path_n": [c_graph_p, C.c_int, c_graph_p],
+    "gtnx_items_n": [c_graph_p, C.c_int, C.c_void_p],
+    "gtnx_items_device_n": [c_graph_p, C.c_int, C.c_void_p],
+    "gtnx_grads_device_n": [c_graph_p, C.c_int, C.c_void_p, C.c_void_p],
+    "gtnx_backward": [c_graph, C.c_int],
+    "gtnx_backward_with_grad": [c_graph, c_graph, C.c_int],
+    "gtnx_backward_n": [c_graph_p, C.c_int, C.c_int],
+    "gtnx_equal": [c_graph, c_graph, c_i32_p],
+    "gtnx_isomorphic": [c_graph, c_graph, c_i32_p],
+    "gtnx_prof_enable": [C.c_int],
+    "gtnx_prof_reset": [],
+    "gtnx_prof_get": [C.c_char_p, C.POINTER(C.c_double), c_i64_p, C.POINTER(C.c_double)],
+    "gtnx_prof_names": [C.c_char_p, C.c_size_t],
+}
+
+_RESTYPE = {
+    "gtnx_last_error": (C.c_char_p, []),
+    "gtnx_version": (C.c_char_p, []),
+    "gtnx_backend": (C.c_char_p, []),
+    "gtnx_device_count": (C.c_int, []),
+}
+
+ALL_SYMBOLS = sorted(list(_SIGS) + list(_RESTYPE))
+
+
+def default_library_path():
+    env = os.environ.get("GTN_AMD_LIB")
+    if env:
+        return env
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgtn_amd.so")
+
+
+def load(path=None):
+    path = path or default_library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"gtn_amd: native library not found at {path}. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL if hasattr(C, "RTLD_GLOBAL") else 0)
+    for name, args in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    for name, (res, args) in _RESTYPE.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    lib._path = path
+    return lib

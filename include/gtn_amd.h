@@ -1,0 +1,194 @@
+/*
+ * gtn_amd.h -- C ABI of the MI355X-native WFST engine (libgtn_amd.so).
+ *
+ * The reference (facebookresearch/gtn) has no FFI layer of its own: its
+ * language binding (bindings/python/gtn/_*.cpp, pybind11) binds the public C++
+ * API of libgtn directly.  This header is therefore the C restatement of that
+ * public API for the hot path, one entry point per reference member/function,
+ * each citing what it replaces.  Everything crossing the boundary is a plain
+ * pointer, an integer or an opaque handle; no C++/HIP/torch types.
+ *
+ * Conventions
+ *  - every call returns gtnx_status_t; GTNX_OK == 0.  On failure the message is
+ *    available (thread-local) from gtnx_last_error().  Status codes map 1:1 to
+ *    the exception types the reference throws (see below); the header-only C++
+ *    shim in include/gtn/ rethrows them.
+ *  - gtnx_graph_t is an owning reference to a graph *value handle* with the
+ *    reference's aliasing semantics (gtn/graph.h:461-464): gtnx_graph_copy()
+ *    aliases structure, weights and grad; gtnx_graph_deep_copy() detaches.
+ *  - the "_n" forms take arrays of n handles and run ONE batched device launch
+ *    per kernel for the whole array.  They are the device analogue of the
+ *    reference's batch entry points: the std::vector<Graph> overloads of the
+ *    Python binding (bindings/python/gtn/_functions.cpp:84-135) which call
+ *    parallelMap (gtn/parallel/parallel_map.h:153-188).  An input array of
+ *    length 1 is broadcast, as parallelMap does (parallel_map.h:77-89).
+ *  - device pointers are raw HIP device addresses (e.g. torch.Tensor.data_ptr()
+ *    on a ROCm tensor); a stream is a hipStream_t passed as void*.
+ */
+#ifndef GTN_AMD_H
+#define GTN_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int gtnx_status_t;
+#define GTNX_OK 0
+#define GTNX_INVALID_ARGUMENT 1 /* std::invalid_argument  (shortest.cpp:149-152, autograd.cpp:43-45, graph.cpp:70-73) */
+#define GTNX_LOGIC_ERROR 2      /* std::logic_error       (graph.cpp:82-95, functions.cpp:19-21,33-35,49-51) */
+#define GTNX_RUNTIME_ERROR 3    /* std::runtime_error     (parallel_map.h:85-88) */
+#define GTNX_OUT_OF_RANGE 4     /* std::out_of_range      (bad node / arc index; the reference only asserts) */
+#define GTNX_DEVICE_ERROR 5     /* HIP failure or no usable gfx950 device; std::runtime_error in the C++ shim */
+
+typedef struct gtnx_graph_s* gtnx_graph_t;
+
+#define GTNX_EPSILON (-1) /* gtn/graph.h:21 */
+
+/* ------------------------------------------------------------------ runtime */
+const char* gtnx_last_error(void);
+const char* gtnx_version(void);
+/* "hip:gfx950" for libgtn_amd.so; the reference-backed test shim
+ * (oracle/_ref/libgtn_ref.so) answers "reference-cpu". */
+const char* gtnx_backend(void);
+int gtnx_device_count(void);                /* 0 when no GPU is visible */
+gtnx_status_t gtnx_set_device(int device);  /* hipSetDevice for this process */
+gtnx_status_t gtnx_set_stream(void* hip_stream); /* NULL = the engine's own stream */
+gtnx_status_t gtnx_synchronize(void);
+/* bytes currently held by the engine's device arena pool / bytes in use */
+gtnx_status_t gtnx_memory_stats(uint64_t* reserved, uint64_t* in_use);
+gtnx_status_t gtnx_empty_cache(void);
+
+/* ------------------------------------------------------------------ Graph
+ * class Graph, gtn/graph.h:75-415 */
+gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out);          /* graph.h:89  */
+gtnx_status_t gtnx_graph_copy(gtnx_graph_t g, gtnx_graph_t* out);           /* copy-ctor: alias */
+gtnx_status_t gtnx_graph_deep_copy(gtnx_graph_t g, gtnx_graph_t* out);      /* graph.h:150 */
+gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g);
+gtnx_status_t gtnx_graph_add_node(gtnx_graph_t g, int start, int accept, int* id);      /* graph.h:97 */
+gtnx_status_t gtnx_graph_add_arc(gtnx_graph_t g, int src, int dst, int ilabel,
+                                 int olabel, float weight, int* id);                    /* graph.h:118-123 */
+/* bulk forms of the two above (same order semantics as n successive calls) */
+gtnx_status_t gtnx_graph_add_nodes(gtnx_graph_t g, int n, const uint8_t* start,
+                                   const uint8_t* accept);
+gtnx_status_t gtnx_graph_add_arcs(gtnx_graph_t g, int n, const int* src,
+                                  const int* dst, const int* ilabel,
+                                  const int* olabel, const float* weight /* NULL = 0 */);
+gtnx_status_t gtnx_graph_num_nodes(gtnx_graph_t g, int64_t* out);   /* graph.h:130 */
+gtnx_status_t gtnx_graph_num_arcs(gtnx_graph_t g, int64_t* out);    /* graph.h:126 */
+gtnx_status_t gtnx_graph_num_start(gtnx_graph_t g, int64_t* out);   /* graph.h:134 */
+gtnx_status_t gtnx_graph_num_accept(gtnx_graph_t g, int64_t* out);  /* graph.h:138 */
+gtnx_status_t gtnx_graph_item(gtnx_graph_t g, float* out);          /* graph.h:143; sync point */
+gtnx_status_t gtnx_graph_arc_sort(gtnx_graph_t g, int olabel);      /* graph.h:158 */
+gtnx_status_t gtnx_graph_mark_arc_sorted(gtnx_graph_t g, int olabel); /* graph.h:166 */
+gtnx_status_t gtnx_graph_ilabel_sorted(gtnx_graph_t g, int* out);   /* graph.h:178 */
+gtnx_status_t gtnx_graph_olabel_sorted(gtnx_graph_t g, int* out);   /* graph.h:186 */
+/* weights(): a pointer into the live host buffer of numArcs floats (graph.h:194-204).
+ * Forces a device->host sync when the weights were produced on the GPU; the
+ * non-const form marks the host copy authoritative. */
+gtnx_status_t gtnx_graph_weights(gtnx_graph_t g, int mutable_, float** out);
+gtnx_status_t gtnx_graph_get_weights(gtnx_graph_t g, float* out);   /* copy-out of the above */
+gtnx_status_t gtnx_graph_set_weights(gtnx_graph_t g, const float* host_weights); /* graph.h:210 */
+/* the same copy from a DEVICE buffer of numArcs floats (no host round-trip;
+ * replaces pytorch_loss.py:53-61's inputs.cpu() + set_weights(data_ptr)) */
+gtnx_status_t gtnx_graph_set_weights_device(gtnx_graph_t g, const void* device_weights);
+/* device address of the weight buffer (numArcs floats), uploading if needed */
+gtnx_status_t gtnx_graph_weights_device(gtnx_graph_t g, void** out);
+gtnx_status_t gtnx_graph_labels_to_array(gtnx_graph_t g, int* out, int ilabel); /* graph.h:219 */
+/* node accessors, graph.h:330-376 */
+gtnx_status_t gtnx_graph_get_start(gtnx_graph_t g, int* out);   /* numStart ints  */
+gtnx_status_t gtnx_graph_get_accept(gtnx_graph_t g, int* out);  /* numAccept ints */
+gtnx_status_t gtnx_graph_is_start(gtnx_graph_t g, int node, int* out);
+gtnx_status_t gtnx_graph_is_accept(gtnx_graph_t g, int node, int* out);
+gtnx_status_t gtnx_graph_make_accept(gtnx_graph_t g, int node);
+gtnx_status_t gtnx_graph_num_out(gtnx_graph_t g, int node, int64_t* out);
+gtnx_status_t gtnx_graph_num_in(gtnx_graph_t g, int node, int64_t* out);
+gtnx_status_t gtnx_graph_get_out(gtnx_graph_t g, int node, int* out); /* numOut arc ids, list order */
+gtnx_status_t gtnx_graph_get_in(gtnx_graph_t g, int node, int* out);  /* numIn arc ids, list order  */
+/* arc accessors, graph.h:384-414 (bulk; any pointer may be NULL) */
+gtnx_status_t gtnx_graph_get_arcs(gtnx_graph_t g, int* src, int* dst, int* ilabel, int* olabel);
+gtnx_status_t gtnx_graph_get_arc(gtnx_graph_t g, int arc, int* src, int* dst,
+                                 int* ilabel, int* olabel, float* weight);
+gtnx_status_t gtnx_graph_set_weight(gtnx_graph_t g, int arc, float weight);
+/* autograd members, graph.h:244-321 */
+gtnx_status_t gtnx_graph_calc_grad(gtnx_graph_t g, int* out);
+gtnx_status_t gtnx_graph_set_calc_grad(gtnx_graph_t g, int calc_grad);
+gtnx_status_t gtnx_graph_is_grad_available(gtnx_graph_t g, int* out);
+gtnx_status_t gtnx_graph_grad(gtnx_graph_t g, gtnx_graph_t* out);  /* new handle aliasing the grad graph */
+gtnx_status_t gtnx_graph_zero_grad(gtnx_graph_t g);
+gtnx_status_t gtnx_graph_add_grad(gtnx_graph_t g, const float* host_grad, int64_t n); /* graph.h:244-250 */
+gtnx_status_t gtnx_graph_add_grad_graph(gtnx_graph_t g, gtnx_graph_t other);           /* graph.h:256 */
+gtnx_status_t gtnx_graph_id(gtnx_graph_t g, uintptr_t* out);                            /* graph.h:281 */
+/* Graph(GradFunc, inputs), graph.h:76-78: a user-defined differentiable op.
+ * grad_fn(ctx, inputs, n_inputs, deltas) is called by gtnx_backward on the host;
+ * ctx_free(ctx) when the op is released (either may be NULL). */
+typedef gtnx_status_t (*gtnx_grad_fn)(void* ctx, gtnx_graph_t* inputs, int n_inputs, gtnx_graph_t deltas);
+gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n_inputs, gtnx_grad_fn grad_fn,
+                                   void* ctx, void (*ctx_free)(void*), gtnx_graph_t* out);
+gtnx_status_t gtnx_graph_num_inputs(gtnx_graph_t g, int64_t* out);                      /* graph.h:303 */
+
+/* ------------------------------------------------------------------ creations
+ * gtn/creations.h:25,32 */
+gtnx_status_t gtnx_scalar_graph(float value, int calc_grad, gtnx_graph_t* out);
+gtnx_status_t gtnx_linear_graph(int M, int N, int calc_grad, gtnx_graph_t* out);
+/* B linear graphs whose weights are COPIED from one contiguous device tensor
+ * [B][M][N] (the (B,T,C) emissions of pytorch_loss.py:46-71), one launch. */
+gtnx_status_t gtnx_linear_graph_n(int B, int M, int N, int calc_grad,
+                                  const void* device_weights, gtnx_graph_t* out /* B handles */);
+
+/* ------------------------------------------------------------------ functions
+ * gtn/functions.h:19-152.  Single-graph forms, then batched forms. */
+gtnx_status_t gtnx_negate(gtnx_graph_t g, gtnx_graph_t* out);                   /* functions.cpp:18-30 */
+gtnx_status_t gtnx_add(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out);      /* functions.cpp:32-46 */
+gtnx_status_t gtnx_subtract(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out); /* functions.cpp:48-64 */
+gtnx_status_t gtnx_compose(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out);  /* functions.cpp:225-237 */
+gtnx_status_t gtnx_intersect(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out);/* functions.cpp:239-251 */
+gtnx_status_t gtnx_forward_score(gtnx_graph_t g, gtnx_graph_t* out);            /* functions.cpp:320-322 */
+gtnx_status_t gtnx_viterbi_score(gtnx_graph_t g, gtnx_graph_t* out);            /* functions.cpp:324-326 */
+gtnx_status_t gtnx_viterbi_path(gtnx_graph_t g, gtnx_graph_t* out);             /* functions.cpp:328-330 */
+
+gtnx_status_t gtnx_negate_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out);
+gtnx_status_t gtnx_add_n(const gtnx_graph_t* a, int na, const gtnx_graph_t* b, int nb, gtnx_graph_t* out);
+gtnx_status_t gtnx_subtract_n(const gtnx_graph_t* a, int na, const gtnx_graph_t* b, int nb, gtnx_graph_t* out);
+gtnx_status_t gtnx_compose_n(const gtnx_graph_t* a, int na, const gtnx_graph_t* b, int nb, gtnx_graph_t* out);
+gtnx_status_t gtnx_intersect_n(const gtnx_graph_t* a, int na, const gtnx_graph_t* b, int nb, gtnx_graph_t* out);
+gtnx_status_t gtnx_forward_score_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out);
+gtnx_status_t gtnx_viterbi_score_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out);
+gtnx_status_t gtnx_viterbi_path_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out);
+/* item() of n single-arc graphs with one device->host copy (batched graph.h:143) */
+gtnx_status_t gtnx_items_n(const gtnx_graph_t* g, int n, float* out);
+/* the same, written to a DEVICE buffer of n floats without a host sync */
+gtnx_status_t gtnx_items_device_n(const gtnx_graph_t* g, int n, void* device_out);
+/* grad().weights() of n graphs gathered into ONE device buffer, graph i at
+ * byte offset offsets[i]*4 (replaces pytorch_loss.py:94-102's per-sample
+ * weights_to_numpy + torch.from_numpy + .to(device)) */
+gtnx_status_t gtnx_grads_device_n(const gtnx_graph_t* g, int n, void* device_out, const int64_t* offsets);
+
+/* ------------------------------------------------------------------ autograd
+ * gtn/autograd.h:27,37 */
+gtnx_status_t gtnx_backward(gtnx_graph_t g, int retain_graph);
+gtnx_status_t gtnx_backward_with_grad(gtnx_graph_t g, gtnx_graph_t grad, int retain_graph);
+gtnx_status_t gtnx_backward_n(const gtnx_graph_t* g, int n, int retain_graph);
+
+/* ------------------------------------------------------------------ utils
+ * gtn/utils.h:23-60 (test fixtures of the parity suite; host-side) */
+gtnx_status_t gtnx_equal(gtnx_graph_t a, gtnx_graph_t b, int* out);
+gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out);
+
+/* ------------------------------------------------------------------ profiling
+ * hipEvent timing of the engine's own kernel launches on the launch stream
+ * (what bench.py's roofline leg reads).  name is a kernel family, e.g.
+ * "forward_score", "compose", "forward_score_grad", "linear_forward". */
+gtnx_status_t gtnx_prof_enable(int on);
+gtnx_status_t gtnx_prof_reset(void);
+gtnx_status_t gtnx_prof_get(const char* name, double* total_ms, int64_t* launches,
+                            double* algorithmic_bytes);
+/* names, '\n'-separated, of the families seen since the last reset */
+gtnx_status_t gtnx_prof_names(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GTN_AMD_H */

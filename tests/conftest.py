@@ -1,0 +1,43 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the product library must exist for any test that imports gtn_amd; build it
+    # (hipcc cross-compiles gfx950 without a GPU) if a fresh checkout lacks it.
+    lib = os.path.join(ROOT, "gtn_amd", "lib", "libgtn_amd.so")
+    orc = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(orc)):
+        import __graft_entry__
+        __graft_entry__.build()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def gtn():
+    """the product: gtn_amd bound to libgtn_amd.so (HIP).  Fails loudly when the
+    library is missing; device ops raise without a GPU."""
+    import gtn_amd
+    assert gtn_amd.backend().startswith("hip"), gtn_amd.backend()
+    return gtn_amd
+
+
+def has_gpu():
+    try:
+        import gtn_amd
+        return gtn_amd.device_count() > 0
+    except Exception:
+        return False

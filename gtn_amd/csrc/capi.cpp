@@ -1,0 +1,527 @@
+// capi.cpp -- the extern "C" boundary declared in include/gtn_amd.h.
+// Thin: argument checks, handle <-> Graph, exception -> status mapping.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ops.h"
+
+#define GTNX_API extern "C" __attribute__((visibility("default")))
+
+using namespace gtnx;
+
+namespace {
+thread_local std::string g_err;
+
+gtnx_status_t fail(gtnx_status_t s, const std::string& m) {
+  g_err = m;
+  return s;
+}
+
+template <class F>
+gtnx_status_t guard(F&& f) {
+  try {
+    f();
+    return GTNX_OK;
+  } catch (const Error& e) {
+    return fail(e.status, e.what());
+  } catch (const std::bad_alloc&) {
+    return fail(GTNX_RUNTIME_ERROR, "out of host memory");
+  } catch (const std::exception& e) {
+    return fail(GTNX_RUNTIME_ERROR, e.what());
+  }
+}
+
+inline Graph& G(gtnx_graph_t h) {
+  if (!h) throw_invalid("null graph handle");
+  return *reinterpret_cast<Graph*>(h);
+}
+inline gtnx_graph_t H(Graph g) { return reinterpret_cast<gtnx_graph_t>(new Graph(std::move(g))); }
+
+std::vector<Graph> vec(const gtnx_graph_t* a, int n) {
+  std::vector<Graph> v;
+  v.reserve(n > 0 ? n : 0);
+  for (int i = 0; i < n; ++i) v.push_back(G(a[i]));
+  return v;
+}
+void put(std::vector<Graph>& r, gtnx_graph_t* out) {
+  for (size_t i = 0; i < r.size(); ++i) out[i] = H(std::move(r[i]));
+}
+void check_node(Graph& g, int n) {
+  if (n < 0 || n >= g.num_nodes()) throw_range("node index out of range");
+}
+void check_arc(Graph& g, int a) {
+  if (a < 0 || a >= g.num_arcs()) throw_range("arc index out of range");
+}
+} // namespace
+
+// ------------------------------------------------------------------ runtime
+GTNX_API const char* gtnx_last_error(void) { return g_err.c_str(); }
+GTNX_API const char* gtnx_version(void) { return "0.1.0"; }
+GTNX_API const char* gtnx_backend(void) { return "hip:gfx950"; }
+GTNX_API int gtnx_device_count(void) { return Runtime::device_count(); }
+GTNX_API gtnx_status_t gtnx_set_device(int d) {
+  return guard([&] {
+    if (Runtime::initialized())
+      Runtime::get().set_device(d);
+    else {
+      HIP_CHECK(hipSetDevice(d));
+      (void)Runtime::get();
+    }
+  });
+}
+GTNX_API gtnx_status_t gtnx_set_stream(void* s) {
+  return guard([&] { Runtime::get().set_stream(static_cast<hipStream_t>(s)); });
+}
+GTNX_API gtnx_status_t gtnx_synchronize(void) {
+  return guard([&] {
+    if (Runtime::initialized()) Runtime::get().sync();
+  });
+}
+GTNX_API gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
+  return guard([&] {
+    if (r) *r = 0;
+    if (u) *u = 0;
+    if (Runtime::initialized()) Runtime::get().stats(r, u);
+  });
+}
+GTNX_API gtnx_status_t gtnx_empty_cache(void) {
+  return guard([&] {
+    if (Runtime::initialized()) Runtime::get().empty_cache();
+  });
+}
+
+// ------------------------------------------------------------------ Graph
+GTNX_API gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out) {
+  return guard([&] { *out = H(Graph(calc_grad != 0)); });
+}
+GTNX_API gtnx_status_t gtnx_graph_copy(gtnx_graph_t g, gtnx_graph_t* out) {
+  return guard([&] { *out = H(G(g)); });
+}
+GTNX_API gtnx_status_t gtnx_graph_deep_copy(gtnx_graph_t g, gtnx_graph_t* out) {
+  return guard([&] { *out = H(Graph::deep_copy(G(g))); });
+}
+GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
+  return guard([&] { delete reinterpret_cast<Graph*>(g); });
+}
+GTNX_API gtnx_status_t gtnx_graph_add_node(gtnx_graph_t g, int s, int a, int* id) {
+  return guard([&] {
+    int i = G(g).add_node(s != 0, a != 0);
+    if (id) *id = i;
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_add_arc(gtnx_graph_t g, int src, int dst, int il, int ol, float w, int* id) {
+  return guard([&] {
+    int i = G(g).add_arc(src, dst, il, ol, w);
+    if (id) *id = i;
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_add_nodes(gtnx_graph_t g, int n, const uint8_t* s, const uint8_t* a) {
+  return guard([&] {
+    Graph& gr = G(g);
+    for (int i = 0; i < n; ++i) gr.add_node(s && s[i], a && a[i]);
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_add_arcs(gtnx_graph_t g, int n, const int* src, const int* dst, const int* il,
+                                           const int* ol, const float* w) {
+  return guard([&] {
+    Graph& gr = G(g);
+    for (int i = 0; i < n; ++i) gr.add_arc(src[i], dst[i], il[i], ol[i], w ? w[i] : 0.0f);
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_nodes(gtnx_graph_t g, int64_t* out) {
+  return guard([&] { *out = G(g).num_nodes(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_arcs(gtnx_graph_t g, int64_t* out) {
+  return guard([&] { *out = G(g).num_arcs(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_start(gtnx_graph_t g, int64_t* out) {
+  return guard([&] { *out = G(g).num_start(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_accept(gtnx_graph_t g, int64_t* out) {
+  return guard([&] { *out = G(g).num_accept(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_inputs(gtnx_graph_t g, int64_t* out) {
+  return guard([&] { *out = int64_t(G(g).g->inputs.size()); });
+}
+GTNX_API gtnx_status_t gtnx_graph_item(gtnx_graph_t g, float* out) {
+  return guard([&] { *out = G(g).item(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_arc_sort(gtnx_graph_t g, int ol) {
+  return guard([&] { G(g).arc_sort(ol != 0); });
+}
+GTNX_API gtnx_status_t gtnx_graph_mark_arc_sorted(gtnx_graph_t g, int ol) {
+  return guard([&] {
+    Structure& s = *G(g).s;
+    bool& flag = ol ? s.olabel_sorted : s.ilabel_sorted;
+    if (!flag) {
+      flag = true;
+      s.dev_valid = s.kind == KIND_LINEAR ? s.dev_valid : false;  // flags live in the device view
+    }
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_ilabel_sorted(gtnx_graph_t g, int* out) {
+  return guard([&] { *out = G(g).s->ilabel_sorted; });
+}
+GTNX_API gtnx_status_t gtnx_graph_olabel_sorted(gtnx_graph_t g, int* out) {
+  return guard([&] { *out = G(g).s->olabel_sorted; });
+}
+GTNX_API gtnx_status_t gtnx_graph_weights(gtnx_graph_t g, int mut, float** out) {
+  return guard([&] { *out = const_cast<float*>(G(g).weights_host(mut != 0)); });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_weights(gtnx_graph_t g, float* out) {
+  return guard([&] {
+    Graph& gr = G(g);
+    const float* p = gr.weights_host(false);
+    std::memcpy(out, p, sizeof(float) * size_t(gr.num_arcs()));
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_set_weights(gtnx_graph_t g, const float* w) {
+  return guard([&] { G(g).set_weights_host(w); });
+}
+GTNX_API gtnx_status_t gtnx_graph_set_weights_device(gtnx_graph_t g, const void* w) {
+  return guard([&] { G(g).set_weights_device(w); });
+}
+GTNX_API gtnx_status_t gtnx_graph_weights_device(gtnx_graph_t g, void** out) {
+  return guard([&] {
+    Graph& gr = G(g);
+    std::vector<Weights*> v{gr.w.get()};
+    ensure_weights_device_batch(v);
+    *out = gr.w->dev;
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_labels_to_array(gtnx_graph_t g, int* out, int il) {
+  return guard([&] {
+    Structure& s = *G(g).s;
+    if (s.kind == KIND_LINEAR) {
+      for (int64_t a = 0; a < s.A; ++a) out[a] = int(a % s.C);
+      return;
+    }
+    s.ensure_host();
+    std::memcpy(out, (il ? s.il : s.ol).data(), sizeof(int) * size_t(s.A));
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_start(gtnx_graph_t g, int* out) {
+  return guard([&] {
+    Structure& s = *G(g).s;
+    if (s.kind == KIND_LINEAR) {
+      out[0] = 0;
+      return;
+    }
+    s.ensure_host();
+    std::memcpy(out, s.start.data(), sizeof(int) * s.start.size());
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_accept(gtnx_graph_t g, int* out) {
+  return guard([&] {
+    Structure& s = *G(g).s;
+    if (s.kind == KIND_LINEAR) {
+      if (s.M > 0) out[0] = s.M;
+      return;
+    }
+    s.ensure_host();
+    std::memcpy(out, s.accept.data(), sizeof(int) * s.accept.size());
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_is_start(gtnx_graph_t g, int n, int* out) {
+  return guard([&] {
+    Graph& gr = G(g);
+    check_node(gr, n);
+    Structure& s = *gr.s;
+    if (s.kind == KIND_LINEAR) {
+      *out = n == 0;
+      return;
+    }
+    s.ensure_host();
+    *out = (s.nflags[n] & NF_START) != 0;
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_is_accept(gtnx_graph_t g, int n, int* out) {
+  return guard([&] {
+    Graph& gr = G(g);
+    check_node(gr, n);
+    Structure& s = *gr.s;
+    if (s.kind == KIND_LINEAR) {
+      *out = s.M > 0 && n == s.M;
+      return;
+    }
+    s.ensure_host();
+    *out = (s.nflags[n] & NF_ACCEPT) != 0;
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_make_accept(gtnx_graph_t g, int n) {
+  return guard([&] {
+    Graph& gr = G(g);
+    check_node(gr, n);
+    Structure& s = *gr.s;
+    s.materialize();
+    s.ensure_host();
+    if (!(s.nflags[n] & NF_ACCEPT)) {  // graph.h:346-352 (sort flags are not touched)
+      s.accept.push_back(n);
+      s.nflags[n] |= NF_ACCEPT;
+      s.dev_valid = false;
+      s.dev_mem.reset();
+      s.sched.reset();
+    }
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_out(gtnx_graph_t g, int n, int64_t* out) {
+  return guard([&] {
+    check_node(G(g), n);
+    *out = G(g).s->num_out(n);
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_num_in(gtnx_graph_t g, int n, int64_t* out) {
+  return guard([&] {
+    check_node(G(g), n);
+    *out = G(g).s->num_in(n);
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_out(gtnx_graph_t g, int n, int* out) {
+  return guard([&] {
+    check_node(G(g), n);
+    Structure& s = *G(g).s;
+    if (s.kind == KIND_LINEAR) {
+      if (n < s.M)
+        for (int c = 0; c < s.C; ++c) out[c] = n * s.C + c;
+      return;
+    }
+    s.ensure_csr();
+    std::memcpy(out, s.out_list.data() + s.out_off[n], sizeof(int) * size_t(s.out_off[n + 1] - s.out_off[n]));
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_in(gtnx_graph_t g, int n, int* out) {
+  return guard([&] {
+    check_node(G(g), n);
+    Structure& s = *G(g).s;
+    if (s.kind == KIND_LINEAR) {
+      if (n > 0)
+        for (int c = 0; c < s.C; ++c) out[c] = (n - 1) * s.C + c;
+      return;
+    }
+    s.ensure_csr();
+    std::memcpy(out, s.in_list.data() + s.in_off[n], sizeof(int) * size_t(s.in_off[n + 1] - s.in_off[n]));
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_arcs(gtnx_graph_t g, int* src, int* dst, int* il, int* ol) {
+  return guard([&] {
+    Structure& s = *G(g).s;
+    if (s.kind == KIND_LINEAR) {
+      for (int64_t a = 0; a < s.A; ++a) {
+        if (src) src[a] = int(a / s.C);
+        if (dst) dst[a] = int(a / s.C) + 1;
+        if (il) il[a] = int(a % s.C);
+        if (ol) ol[a] = int(a % s.C);
+      }
+      return;
+    }
+    s.ensure_host();
+    size_t b = sizeof(int) * size_t(s.A);
+    if (src) std::memcpy(src, s.src.data(), b);
+    if (dst) std::memcpy(dst, s.dst.data(), b);
+    if (il) std::memcpy(il, s.il.data(), b);
+    if (ol) std::memcpy(ol, s.ol.data(), b);
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_get_arc(gtnx_graph_t g, int a, int* src, int* dst, int* il, int* ol, float* w) {
+  return guard([&] {
+    Graph& gr = G(g);
+    check_arc(gr, a);
+    Structure& s = *gr.s;
+    if (s.kind == KIND_LINEAR) {
+      if (src) *src = a / s.C;
+      if (dst) *dst = a / s.C + 1;
+      if (il) *il = a % s.C;
+      if (ol) *ol = a % s.C;
+    } else {
+      s.ensure_host();
+      if (src) *src = s.src[a];
+      if (dst) *dst = s.dst[a];
+      if (il) *il = s.il[a];
+      if (ol) *ol = s.ol[a];
+    }
+    if (w) *w = gr.weights_host(false)[a];
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_set_weight(gtnx_graph_t g, int a, float w) {
+  return guard([&] {
+    Graph& gr = G(g);
+    check_arc(gr, a);
+    gr.w->ensure_host();
+    gr.w->host[a] = w;
+    gr.w->dev_valid = false;
+    gr.w->version++;
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_calc_grad(gtnx_graph_t g, int* out) {
+  return guard([&] { *out = G(g).calc_grad(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_set_calc_grad(gtnx_graph_t g, int c) {
+  return guard([&] { G(g).set_calc_grad(c != 0); });
+}
+GTNX_API gtnx_status_t gtnx_graph_is_grad_available(gtnx_graph_t g, int* out) {
+  return guard([&] { *out = G(g).is_grad_available(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_grad(gtnx_graph_t g, gtnx_graph_t* out) {
+  return guard([&] { *out = H(G(g).grad()); });
+}
+GTNX_API gtnx_status_t gtnx_graph_zero_grad(gtnx_graph_t g) {
+  return guard([&] { G(g).zero_grad(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_add_grad(gtnx_graph_t g, const float* v, int64_t n) {
+  return guard([&] { G(g).add_grad_host(v, n); });
+}
+GTNX_API gtnx_status_t gtnx_graph_add_grad_graph(gtnx_graph_t g, gtnx_graph_t o) {
+  return guard([&] {
+    Graph& other = G(o);
+    Graph& gr = G(g);
+    if (!gr.calc_grad()) return;
+    if (other.num_arcs() != gr.num_arcs()) throw_logic("[Graph::addGrad] Invalid grad size.");
+    if (other.w->dev_valid && !other.w->host_escaped)
+      gr.add_grad_device(other.w->dev_mem, other.w->dev, false);
+    else
+      gr.add_grad_host(other.weights_host(false), other.num_arcs());
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_id(gtnx_graph_t g, uintptr_t* out) {
+  return guard([&] { *out = G(g).id(); });
+}
+GTNX_API gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n, gtnx_grad_fn fn, void* ctx,
+                                            void (*ctx_free)(void*), gtnx_graph_t* out) {
+  return guard([&] {
+    auto v = vec(inputs, n);
+    *out = H(make_user_op(v, fn, ctx, ctx_free));
+  });
+}
+
+// ------------------------------------------------------------------ creations
+GTNX_API gtnx_status_t gtnx_scalar_graph(float v, int cg, gtnx_graph_t* out) {
+  return guard([&] { *out = H(make_scalar_graph(v, cg != 0)); });
+}
+GTNX_API gtnx_status_t gtnx_linear_graph(int M, int N, int cg, gtnx_graph_t* out) {
+  return guard([&] { *out = H(make_linear_graph(M, N, cg != 0)); });
+}
+GTNX_API gtnx_status_t gtnx_linear_graph_n(int B, int M, int N, int cg, const void* dev, gtnx_graph_t* out) {
+  return guard([&] {
+    auto r = make_linear_graphs_device(B, M, N, cg != 0, dev);
+    put(r, out);
+  });
+}
+
+// ------------------------------------------------------------------ functions
+#define UNARY_FN(name, expr)                                                \
+  GTNX_API gtnx_status_t name(gtnx_graph_t g, gtnx_graph_t* out) {          \
+    return guard([&] {                                                      \
+      std::vector<Graph> v{G(g)};                                           \
+      auto r = expr;                                                        \
+      *out = H(std::move(r[0]));                                            \
+    });                                                                     \
+  }                                                                         \
+  GTNX_API gtnx_status_t name##_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out) { \
+    return guard([&] {                                                      \
+      auto v = vec(g, n);                                                   \
+      auto r = expr;                                                        \
+      put(r, out);                                                          \
+    });                                                                     \
+  }
+#define BINARY_FN(name, expr)                                                           \
+  GTNX_API gtnx_status_t name(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out) {      \
+    return guard([&] {                                                                  \
+      std::vector<Graph> va{G(a)}, vb{G(b)};                                            \
+      auto r = expr;                                                                    \
+      *out = H(std::move(r[0]));                                                        \
+    });                                                                                 \
+  }                                                                                     \
+  GTNX_API gtnx_status_t name##_n(const gtnx_graph_t* a, int na, const gtnx_graph_t* b, \
+                                  int nb, gtnx_graph_t* out) {                          \
+    return guard([&] {                                                                  \
+      auto va = vec(a, na);                                                             \
+      auto vb = vec(b, nb);                                                             \
+      auto r = expr;                                                                    \
+      put(r, out);                                                                      \
+    });                                                                                 \
+  }
+
+namespace {
+std::vector<Graph> g_empty;
+}
+UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty))
+BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb))
+BINARY_FN(gtnx_subtract, op_scalar(SK_SUBTRACT, va, vb))
+BINARY_FN(gtnx_compose, op_compose(va, vb, false))
+BINARY_FN(gtnx_intersect, op_compose(va, vb, true))
+UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false))
+UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true))
+UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v))
+
+GTNX_API gtnx_status_t gtnx_items_n(const gtnx_graph_t* g, int n, float* out) {
+  return guard([&] {
+    auto v = vec(g, n);
+    items_host(v, out);
+  });
+}
+GTNX_API gtnx_status_t gtnx_items_device_n(const gtnx_graph_t* g, int n, void* out) {
+  return guard([&] {
+    auto v = vec(g, n);
+    items_device(v, out);
+  });
+}
+GTNX_API gtnx_status_t gtnx_grads_device_n(const gtnx_graph_t* g, int n, void* out, const int64_t* offsets) {
+  return guard([&] {
+    auto v = vec(g, n);
+    grads_device(v, out, offsets);
+  });
+}
+
+// ------------------------------------------------------------------ autograd
+GTNX_API gtnx_status_t gtnx_backward(gtnx_graph_t g, int retain) {
+  return guard([&] {
+    std::vector<Graph> v{G(g)};
+    op_backward(v, nullptr, retain != 0);
+  });
+}
+GTNX_API gtnx_status_t gtnx_backward_with_grad(gtnx_graph_t g, gtnx_graph_t grad, int retain) {
+  return guard([&] {
+    std::vector<Graph> v{G(g)};
+    op_backward(v, &G(grad), retain != 0);
+  });
+}
+GTNX_API gtnx_status_t gtnx_backward_n(const gtnx_graph_t* g, int n, int retain) {
+  return guard([&] {
+    auto v = vec(g, n);
+    op_backward(v, nullptr, retain != 0);
+  });
+}
+
+// ------------------------------------------------------------------ utils
+GTNX_API gtnx_status_t gtnx_equal(gtnx_graph_t a, gtnx_graph_t b, int* out) {
+  return guard([&] { *out = graphs_equal(G(a), G(b)); });
+}
+GTNX_API gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out) {
+  return guard([&] { *out = graphs_isomorphic(G(a), G(b)); });
+}
+
+// ------------------------------------------------------------------ profiling
+GTNX_API gtnx_status_t gtnx_prof_enable(int on) {
+  return guard([&] { Runtime::get().prof_enable(on != 0); });
+}
+GTNX_API gtnx_status_t gtnx_prof_reset(void) {
+  return guard([&] { Runtime::get().prof_reset(); });
+}
+GTNX_API gtnx_status_t gtnx_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {
+  return guard([&] {
+    ProfEntry e = Runtime::get().prof_get(name);
+    if (ms) *ms = e.total_ms;
+    if (n) *n = e.launches;
+    if (bytes) *bytes = e.bytes;
+  });
+}
+GTNX_API gtnx_status_t gtnx_prof_names(char* buf, size_t cap) {
+  return guard([&] {
+    std::string s = Runtime::get().prof_names();
+    if (cap) {
+      std::strncpy(buf, s.c_str(), cap - 1);
+      buf[cap - 1] = 0;
+    }
+  });
+}

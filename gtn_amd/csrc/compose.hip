@@ -1,0 +1,569 @@
+// compose.hip -- WFST composition / intersection on the GPU.
+//
+// Replaces gtn/functions/compose.cpp:377-522 (detail::compose), :64-104
+// (findReachable), :108-208 (node/arc emission incl. epsilon handling), the three
+// matchers (:211-374) and the gradient scatter (:496-518).
+//
+// Contract kept bit-exact with the reference: the composed graph's NODE IDS are
+// the reference's BFS discovery order and its ARC IDS the reference's emission
+// order (grouped by source node in id order; within a node: matcher order, then
+// first-graph epsilon arcs, then second-graph epsilon arcs).  That holds because
+//   * the reference's FIFO pops nodes in id order, so arcs are src-sorted, and
+//   * a node's id is the rank of the first arc (in arc order) that reaches it,
+// both of which a level-synchronous BFS reproduces with prefix sums.
+//
+// Execution model: ONE persistent workgroup per (g1, g2) pair; a batch is one
+// launch of B workgroups.  Phase B marks co-reachable state pairs by a backward
+// frontier BFS over the dense N1*N2 `state` table in HBM (atomic test-and-set,
+// frontier queue appended through an LDS cursor).  Phase F expands the forward
+// frontier level by level: each lane owns one frontier node, counts its valid
+// matches, a workgroup prefix sum assigns arc slots, lanes emit the SoA arc
+// fields (coalesced per field), first-touch ownership of new state pairs is
+// resolved with atomicMax "claims" + a second prefix sum, then destinations are
+// patched.  A second, fully parallel pass builds the in-arc CSR (with src ids
+// and weights permuted into row order for the forward-score kernel).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "kernels.h"
+
+namespace gtnx {
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int ST_UNREACH = INT_MIN;
+constexpr int ST_REACH = INT_MIN + 1;
+constexpr int EPS = -1;
+
+__device__ __forceinline__ int claim_of(int r) { return -2 - r; }
+
+// `state` is touched by L2 atomics; read/write it L1-bypassing so a lane never
+// sees a line cached before another lane's atomic (MI355X: sc1 loads/stores).
+__device__ __forceinline__ int ld_state(const int* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_state(int* p, int v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- graph accessors (explicit SoA/CSR or implicit linear chain) -------------
+struct Adj {
+  int n;
+  int base;
+  const int* list;
+};
+__device__ __forceinline__ Adj out_adj(const DGraph& g, int node) {
+  Adj a;
+  if (g.kind == KIND_LINEAR) {
+    a.n = node < g.M ? g.C : 0;
+    a.base = node * g.C;
+    a.list = nullptr;
+  } else {
+    a.base = g.out_off[node];
+    a.n = g.out_off[node + 1] - a.base;
+    a.list = g.out_list;
+  }
+  return a;
+}
+__device__ __forceinline__ Adj in_adj(const DGraph& g, int node) {
+  Adj a;
+  if (g.kind == KIND_LINEAR) {
+    a.n = node > 0 ? g.C : 0;
+    a.base = (node - 1) * g.C;
+    a.list = nullptr;
+  } else {
+    a.base = g.in_off[node];
+    a.n = g.in_off[node + 1] - a.base;
+    a.list = g.in_list;
+  }
+  return a;
+}
+__device__ __forceinline__ int adj_arc(const Adj& a, int k) { return a.list ? a.list[a.base + k] : a.base + k; }
+__device__ __forceinline__ int g_il(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc % g.C : g.il[arc]; }
+__device__ __forceinline__ int g_ol(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc % g.C : g.ol[arc]; }
+__device__ __forceinline__ int g_src(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc / g.C : g.src[arc]; }
+__device__ __forceinline__ int g_dst(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc / g.C + 1 : g.dst[arc]; }
+__device__ __forceinline__ bool g_start(const DGraph& g, int n) {
+  return g.kind == KIND_LINEAR ? n == 0 : (g.nflags[n] & NF_START) != 0;
+}
+__device__ __forceinline__ bool g_accept(const DGraph& g, int n) {
+  return g.kind == KIND_LINEAR ? (g.M > 0 && n == g.M) : (g.nflags[n] & NF_ACCEPT) != 0;
+}
+__device__ __forceinline__ int g_start_at(const DGraph& g, int k) { return g.kind == KIND_LINEAR ? 0 : g.start_list[k]; }
+__device__ __forceinline__ int g_accept_at(const DGraph& g, int k) { return g.kind == KIND_LINEAR ? g.M : g.accept_list[k]; }
+
+// ---- matcher: calls f(i, j) for every pair of arcs (i of g1, j of g2) leaving
+// (use_in: entering) the node pair with olabel1(i) == ilabel2(j), in the
+// reference's order: "for q in query list: for s in the equal-label run of the
+// search list" (compose.cpp:211-374; roles per matcher as in functions.cpp:225-251).
+template <class F>
+__device__ __forceinline__ void enum_matches(const ComposeArgs& a, int n1, int n2, bool use_in, F&& f) {
+  const Adj l1 = use_in ? in_adj(a.g1, n1) : out_adj(a.g1, n1);
+  const Adj l2 = use_in ? in_adj(a.g2, n2) : out_adj(a.g2, n2);
+  bool search_g1, sorted;
+  switch (a.matcher) {
+    case MATCH_UNSORTED: search_g1 = false; sorted = false; break;
+    case MATCH_SINGLY_G1: search_g1 = true; sorted = true; break;
+    case MATCH_SINGLY_G2: search_g1 = false; sorted = true; break;
+    default: search_g1 = l1.n > l2.n; sorted = true; break;  // compose.cpp:319
+  }
+  const DGraph& gs = search_g1 ? a.g1 : a.g2;
+  const Adj q = search_g1 ? l2 : l1;
+  const Adj s = search_g1 ? l1 : l2;
+  for (int qi = 0; qi < q.n; ++qi) {
+    const int qa = adj_arc(q, qi);
+    const int ql = search_g1 ? g_il(a.g2, qa) : g_ol(a.g1, qa);
+    if (!use_in && ql == EPS) continue;  // direct eps:eps matches are skipped (compose.cpp:425-428)
+    if (gs.kind == KIND_LINEAR) {
+      if (ql >= 0 && ql < gs.C) {
+        const int sa = s.base + ql;
+        if (s.n > 0) {
+          if (search_g1) f(sa, qa); else f(qa, sa);
+        }
+      }
+    } else if (sorted) {
+      int lo = 0, hi = s.n;
+      while (lo < hi) {  // std::lower_bound
+        const int mid = (lo + hi) >> 1;
+        const int sk = search_g1 ? gs.ol[adj_arc(s, mid)] : gs.il[adj_arc(s, mid)];
+        if (sk < ql) lo = mid + 1; else hi = mid;
+      }
+      for (int k = lo; k < s.n; ++k) {
+        const int sa = adj_arc(s, k);
+        const int sk = search_g1 ? gs.ol[sa] : gs.il[sa];
+        if (sk != ql) break;
+        if (search_g1) f(sa, qa); else f(qa, sa);
+      }
+    } else {
+      for (int k = 0; k < s.n; ++k) {
+        const int sa = adj_arc(s, k);
+        const int sk = search_g1 ? gs.ol[sa] : gs.il[sa];
+        if (sk == ql) {
+          if (search_g1) f(sa, qa); else f(qa, sa);
+        }
+      }
+    }
+  }
+}
+
+// epsilon arcs of one side's list: g1 arcs with olabel eps / g2 arcs with ilabel eps
+template <class F>
+__device__ __forceinline__ void enum_eps(const DGraph& g, const Adj& l, bool second, F&& f) {
+  if (g.kind == KIND_LINEAR) return;
+  const bool sorted = second ? (g.flags & 1) : (g.flags & 2);
+  for (int k = 0; k < l.n; ++k) {
+    const int arc = adj_arc(l, k);
+    const int label = second ? g.il[arc] : g.ol[arc];
+    if (label != EPS) {
+      if (sorted) break;  // eps sorts first (compose.cpp:36-41, 169-176)
+      continue;
+    }
+    f(arc);
+  }
+}
+__device__ __forceinline__ bool has_eps(const DGraph& g, const Adj& l, bool second) {
+  bool r = false;
+  enum_eps(g, l, second, [&](int) { r = true; });
+  return r;
+}
+
+// ---- workgroup exclusive scan (wave64 shuffles + one LDS hop) -------------------
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  __syncthreads();  // protect sh from a previous use
+  if (lane == 63) sh[wave] = x;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    const int s = sh[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + x - v;
+}
+
+// ================================================================================
+// the composition kernel
+// ================================================================================
+__global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __restrict__ args) {
+  const ComposeArgs a = args[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int N1 = a.g1.N, N2 = a.g2.N;
+  __shared__ int sh_scan[8];
+  __shared__ int sh_tail;
+  __shared__ int sh_flag[2];
+
+  if (tid == 0) {
+    sh_tail = 0;
+    sh_flag[0] = 1;  // layered
+    sh_flag[1] = 0;  // overflow
+  }
+  __syncthreads();
+  if (N1 == 0 || N2 == 0) {
+    if (tid == 0) {
+      ComposeOut o{};
+      o.layered = 1;
+      *a.out = o;
+      a.out_off[0] = 0;
+      a.level_off[0] = 0;
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ phase B
+  // compose.cpp:64-104 -- `state` was pre-filled with ST_UNREACH
+  {
+    const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
+    const int seeds = na1 * na2;
+    for (int t = tid; t < seeds; t += kBlock) {
+      const int f = g_accept_at(a.g1, t / na2), s = g_accept_at(a.g2, t % na2);
+      const int idx = f + N1 * s;
+      st_state(a.state + idx, ST_REACH);
+      a.queue[t] = idx;
+    }
+    if (tid == 0) sh_tail = seeds;
+    __syncthreads();
+    int lo = 0, hi = seeds;
+    auto mark = [&](int u1, int u2) {
+      const int idx = u1 + N1 * u2;
+      if (ld_state(a.state + idx) == ST_UNREACH &&
+          atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH) {
+        const int pos = atomicAdd(&sh_tail, 1);
+        a.queue[pos] = idx;
+      }
+    };
+    while (lo < hi) {
+      for (int f = lo + tid; f < hi; f += kBlock) {
+        const int idx = a.queue[f];
+        const int n1 = idx % N1, n2 = idx / N1;
+        enum_matches(a, n1, n2, true, [&](int i, int j) { mark(g_src(a.g1, i), g_src(a.g2, j)); });
+        enum_eps(a.g1, in_adj(a.g1, n1), false, [&](int i) { mark(a.g1.src[i], n2); });
+        enum_eps(a.g2, in_adj(a.g2, n2), true, [&](int j) { mark(n1, a.g2.src[j]); });
+      }
+      __syncthreads();
+      lo = hi;
+      hi = sh_tail;
+      __syncthreads();
+    }
+  }
+
+  // ------------------------------------------------------------------ phase F
+  int nn = 0, na = 0;
+  {
+    // start pairs in (s1 outer, s2 inner) order (compose.cpp:392-401)
+    const int ns1 = a.g1.n_start, ns2 = a.g2.n_start;
+    const int seeds = ns1 * ns2;
+    for (int t0 = 0; t0 < seeds; t0 += kBlock) {
+      const int t = t0 + tid;
+      int idx = 0, ok = 0, s1 = 0, s2 = 0;
+      if (t < seeds) {
+        s1 = g_start_at(a.g1, t / ns2);
+        s2 = g_start_at(a.g2, t % ns2);
+        idx = s1 + N1 * s2;
+        ok = ld_state(a.state + idx) == ST_REACH;
+      }
+      int tot;
+      const int off = block_excl_scan(ok, sh_scan, tot);
+      if (ok) {
+        const int id = nn + off;
+        if (id < a.Ncap) {
+          a.pair_of[id] = idx;
+          a.nflags[id] = uint8_t(NF_START | ((g_accept(a.g1, s1) && g_accept(a.g2, s2)) ? NF_ACCEPT : 0));
+          st_state(a.state + idx, id);
+        } else {
+          sh_flag[1] = 1;
+        }
+      }
+      nn += tot;
+    }
+    __syncthreads();
+  }
+
+  int lo = 0, hi = nn, L = 0;
+  while (lo < hi && !sh_flag[1]) {
+    if (tid == 0) a.level_off[L] = lo;
+    for (int c0 = lo; c0 < hi; c0 += kBlock) {
+      const int node = c0 + tid;
+      const bool live = node < hi;
+      int n1 = 0, n2 = 0;
+      bool eps1_ok = false, eps2_ok = false;
+      Adj o1{}, o2{};
+      int cnt = 0;
+      if (live) {
+        const int pr = a.pair_of[node];
+        n1 = pr % N1;
+        n2 = pr / N1;
+        o1 = out_adj(a.g1, n1);
+        o2 = out_adj(a.g2, n2);
+        // epsilon_matched <=> some (i, j) with olabel1(i) == ilabel2(j) == eps
+        const bool em = has_eps(a.g1, o1, false) && has_eps(a.g2, o2, true);
+        const bool acc1 = g_accept(a.g1, n1), acc2 = g_accept(a.g2, n2);
+        eps1_ok = !em || acc2 || !acc1;  // compose.cpp:461
+        eps2_ok = !em || acc1;           // compose.cpp:476
+        enum_matches(a, n1, n2, false, [&](int i, int j) {
+          const int idx = g_dst(a.g1, i) + N1 * g_dst(a.g2, j);
+          cnt += ld_state(a.state + idx) != ST_UNREACH;
+        });
+        if (eps1_ok)
+          enum_eps(a.g1, o1, false, [&](int i) { cnt += ld_state(a.state + a.g1.dst[i] + N1 * n2) != ST_UNREACH; });
+        if (eps2_ok)
+          enum_eps(a.g2, o2, true, [&](int j) { cnt += ld_state(a.state + n1 + N1 * a.g2.dst[j]) != ST_UNREACH; });
+      }
+      int total;
+      const int off = block_excl_scan(cnt, sh_scan, total);
+      if (na + total > a.Acap) {
+        if (tid == 0) sh_flag[1] = 1;
+        __syncthreads();
+        break;
+      }
+      if (live) {
+        a.out_off[node] = na + off;
+        int r = off;
+        auto emit = [&](int idx, int il, int ol, float w, int i, int j) {
+          const int cur = ld_state(a.state + idx);
+          if (cur == ST_UNREACH) return;
+          const int ai = na + r;
+          a.src[ai] = node;
+          a.dst[ai] = idx;  // patched to the node id below
+          a.il[ai] = il;
+          a.ol[ai] = ol;
+          a.w[ai] = w;
+          a.gi1[ai] = i;
+          a.gi2[ai] = j;
+          if (cur < 0) atomicMax(a.state + idx, claim_of(r));
+          ++r;
+        };
+        enum_matches(a, n1, n2, false, [&](int i, int j) {
+          emit(g_dst(a.g1, i) + N1 * g_dst(a.g2, j), g_il(a.g1, i), g_ol(a.g2, j), a.g1.w[i] + a.g2.w[j], i, j);
+        });
+        if (eps1_ok)
+          enum_eps(a.g1, o1, false, [&](int i) { emit(a.g1.dst[i] + N1 * n2, a.g1.il[i], EPS, a.g1.w[i], i, -1); });
+        if (eps2_ok)
+          enum_eps(a.g2, o2, true, [&](int j) { emit(n1 + N1 * a.g2.dst[j], EPS, a.g2.ol[j], a.g2.w[j], -1, j); });
+      }
+      __syncthreads();
+      // ---- first-touch ownership -> new node ids in arc order
+      int newn = 0;
+      for (int r0 = 0; r0 < total; r0 += kBlock) {
+        const int r = r0 + tid;
+        int own = 0, idx = 0;
+        if (r < total) {
+          idx = a.dst[na + r];
+          own = ld_state(a.state + idx) == claim_of(r);
+        }
+        int t2;
+        const int rank = block_excl_scan(own, sh_scan, t2);
+        int id = -1;
+        if (own) {
+          id = nn + newn + rank;
+          if (id < a.Ncap) {
+            const int d1 = idx % N1, d2 = idx / N1;
+            a.pair_of[id] = idx;
+            a.nflags[id] = uint8_t(((g_start(a.g1, d1) && g_start(a.g2, d2)) ? NF_START : 0) |
+                                   ((g_accept(a.g1, d1) && g_accept(a.g2, d2)) ? NF_ACCEPT : 0));
+          } else {
+            sh_flag[1] = 1;
+            id = -1;
+          }
+        }
+        if (r < total) a.in_list[na + r] = id;  // scratch: in_list is built later
+        newn += t2;
+      }
+      __syncthreads();  // every ownership test has read its claim
+      for (int r = tid; r < total; r += kBlock) {
+        const int id = a.in_list[na + r];
+        if (id >= 0) st_state(a.state + a.dst[na + r], id);
+      }
+      __syncthreads();
+      int lay = 1;
+      for (int r = tid; r < total; r += kBlock) {
+        const int id = ld_state(a.state + a.dst[na + r]);
+        a.dst[na + r] = id;
+        if (id < hi) lay = 0;
+      }
+      if (!lay) sh_flag[0] = 0;
+      na += total;
+      nn += newn;
+      __syncthreads();
+    }
+    if (sh_flag[1]) break;
+    lo = hi;
+    hi = nn;
+    ++L;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.level_off[L] = nn;
+    a.out_off[nn < a.Ncap + 1 ? nn : a.Ncap] = na;
+    ComposeOut o{};
+    o.N = nn;
+    o.A = na;
+    o.L = L;
+    o.layered = sh_flag[0];
+    o.overflow = sh_flag[1];
+    *a.out = o;
+  }
+}
+
+// ================================================================================
+// in-arc CSR (transpose) + ordered start/accept lists: three fully parallel passes
+// ================================================================================
+constexpr int kChunk = 2048;  // nodes per scan chunk
+
+__global__ void tr_count_kernel(const ComposeArgs* __restrict__ args) {
+  const ComposeArgs a = args[blockIdx.y];
+  const int A = a.out->A;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < A; k += gridDim.x * blockDim.x)
+    atomicAdd(a.in_cursor + a.dst[k], 1);
+}
+
+// per chunk: sums of (in-degree, start flag, accept flag) -> in_off scratch tail
+__global__ __launch_bounds__(kBlock) void tr_chunk_sum_kernel(const ComposeArgs* __restrict__ args, int3* __restrict__ sums,
+                                                              int chunks_per_graph) {
+  const ComposeArgs a = args[blockIdx.y];
+  const int N = a.out->N;
+  const int c = blockIdx.x;
+  if (c * kChunk >= N && c > 0) return;
+  int d = 0, s = 0, ac = 0;
+  for (int n = c * kChunk + threadIdx.x; n < min(N, (c + 1) * kChunk); n += kBlock) {
+    d += a.in_cursor[n];
+    const uint8_t f = a.nflags[n];
+    s += (f & NF_START) != 0;
+    ac += (f & NF_ACCEPT) != 0;
+  }
+  __shared__ int sh[3][kBlock];
+  sh[0][threadIdx.x] = d;
+  sh[1][threadIdx.x] = s;
+  sh[2][threadIdx.x] = ac;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + o];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + o];
+      sh[2][threadIdx.x] += sh[2][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[(size_t)blockIdx.y * chunks_per_graph + c] = make_int3(sh[0][0], sh[1][0], sh[2][0]);
+}
+
+// one lane per graph turns chunk sums into chunk offsets (chunks are few)
+__global__ void tr_chunk_scan_kernel(const ComposeArgs* __restrict__ args, int3* __restrict__ sums, int n, int chunks_per_graph) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n) return;
+  const ComposeArgs a = args[g];
+  const int N = a.out->N;
+  const int nc = (N + kChunk - 1) / kChunk;
+  int3 run = make_int3(0, 0, 0);
+  for (int c = 0; c < nc; ++c) {
+    const int3 v = sums[(size_t)g * chunks_per_graph + c];
+    sums[(size_t)g * chunks_per_graph + c] = run;
+    run.x += v.x;
+    run.y += v.y;
+    run.z += v.z;
+  }
+  a.in_off[N] = run.x;
+  a.counts[0] = run.y;
+  a.counts[1] = run.z;
+}
+
+__global__ __launch_bounds__(kBlock) void tr_offsets_kernel(const ComposeArgs* __restrict__ args, const int3* __restrict__ sums,
+                                                            int chunks_per_graph) {
+  const ComposeArgs a = args[blockIdx.y];
+  const int N = a.out->N;
+  const int c = blockIdx.x;
+  if (c * kChunk >= N) return;
+  __shared__ int sh_scan[8];
+  int3 run = sums[(size_t)blockIdx.y * chunks_per_graph + c];
+  for (int n0 = c * kChunk; n0 < min(N, (c + 1) * kChunk); n0 += kBlock) {
+    const int n = n0 + threadIdx.x;
+    int d = 0, s = 0, ac = 0;
+    if (n < N) {
+      d = a.in_cursor[n];
+      const uint8_t f = a.nflags[n];
+      s = (f & NF_START) != 0;
+      ac = (f & NF_ACCEPT) != 0;
+    }
+    int td, ts, ta;
+    const int od = block_excl_scan(d, sh_scan, td);
+    const int os = block_excl_scan(s, sh_scan, ts);
+    const int oa = block_excl_scan(ac, sh_scan, ta);
+    if (n < N) {
+      a.in_off[n] = run.x + od;
+      a.in_cursor[n] = run.x + od;
+      if (s) a.start_list[run.y + os] = n;
+      if (ac) a.accept_list[run.z + oa] = n;
+    }
+    run.x += td;
+    run.y += ts;
+    run.z += ta;
+  }
+}
+
+__global__ void tr_scatter_kernel(const ComposeArgs* __restrict__ args) {
+  const ComposeArgs a = args[blockIdx.y];
+  const int A = a.out->A;
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < A; k += gridDim.x * blockDim.x) {
+    const int pos = atomicAdd(a.in_cursor + a.dst[k], 1);
+    a.in_list[pos] = k;
+    a.in_src[pos] = a.src[k];
+    a.in_w[pos] = a.w[k];
+  }
+}
+
+// ================================================================================
+// gradient scatter (compose.cpp:496-518)
+// ================================================================================
+__global__ void compose_grad_kernel(const ComposeGradArgs* __restrict__ args) {
+  const ComposeGradArgs a = args[blockIdx.y];
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.A; k += gridDim.x * blockDim.x) {
+    const float d = a.delta[k];
+    const int i = a.gi1[k], j = a.gi2[k];
+    if (a.grad1 && i >= 0) atomicAdd(a.grad1 + i, d);
+    if (a.grad2 && j >= 0) atomicAdd(a.grad2 + j, d);
+  }
+}
+
+int grid_x(int n, int cap) {
+  int g = (n + kBlock - 1) / kBlock;
+  return g < 1 ? 1 : (g > cap ? cap : g);
+}
+
+} // namespace
+
+void launch_compose(const ComposeArgs* d_args, int n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(compose_kernel, dim3(n), dim3(kBlock), 0, st, d_args);
+}
+
+size_t compose_transpose_scratch_bytes(int n, int maxNcap) {
+  const size_t chunks = size_t(maxNcap + kChunk - 1) / kChunk + 1;
+  return sizeof(int3) * chunks * size_t(n > 0 ? n : 1);
+}
+
+void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int maxNcap, void* scratch,
+                              hipStream_t st) {
+  if (n <= 0) return;
+  const int chunks = (maxNcap + kChunk - 1) / kChunk + 1;
+  int3* g_sums = static_cast<int3*>(scratch);
+  hipLaunchKernelGGL(tr_count_kernel, dim3(grid_x(maxAcap, 2048), n), dim3(kBlock), 0, st, d_args);
+  hipLaunchKernelGGL(tr_chunk_sum_kernel, dim3(chunks, n), dim3(kBlock), 0, st, d_args, g_sums, chunks);
+  hipLaunchKernelGGL(tr_chunk_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_args, g_sums, n, chunks);
+  hipLaunchKernelGGL(tr_offsets_kernel, dim3(chunks, n), dim3(kBlock), 0, st, d_args, (const int3*)g_sums, chunks);
+  hipLaunchKernelGGL(tr_scatter_kernel, dim3(grid_x(maxAcap, 2048), n), dim3(kBlock), 0, st, d_args);
+}
+
+void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st) {
+  if (n <= 0 || maxA <= 0) return;
+  hipLaunchKernelGGL(compose_grad_kernel, dim3(grid_x(maxA, 2048), n), dim3(kBlock), 0, st, d_args);
+}
+
+} // namespace gtnx

@@ -1,0 +1,781 @@
+// graph.cpp -- host graph model, HBM residency and level scheduling.
+#include "graph.h"
+
+#include <algorithm>
+#include <cstring>
+#include <list>
+#include <map>
+#include <queue>
+
+namespace gtnx {
+
+// ======================================================================
+// Structure
+// ======================================================================
+void Structure::touch() {
+  dev_valid = false;
+  dev_mem.reset();
+  sched.reset();
+  csr_valid = false;
+  ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65
+}
+
+void Structure::materialize() {
+  if (kind != KIND_LINEAR) return;
+  // creations.cpp:20-33: node m -> m+1, arc id m*N+n, label n
+  src.resize(A);
+  dst.resize(A);
+  il.resize(A);
+  ol.resize(A);
+  for (int64_t a = 0; a < A; ++a) {
+    src[a] = int(a / C);
+    dst[a] = int(a / C) + 1;
+    il[a] = ol[a] = int(a % C);
+  }
+  nflags.assign(N, 0);
+  nflags[0] |= NF_START;
+  start.assign(1, 0);
+  accept.clear();
+  if (M > 0) {
+    nflags[M] |= NF_ACCEPT;
+    accept.assign(1, M);
+  }
+  kind = KIND_EXPLICIT;
+  host_valid = true;
+  csr_valid = false;
+  dev_valid = false;
+  dev_mem.reset();
+  sched.reset();
+}
+
+void Structure::ensure_host() {
+  if (kind == KIND_LINEAR || host_valid) return;
+  // device-built (composition result): pull the SoA arrays once
+  Runtime& rt = Runtime::get();
+  src.resize(A);
+  dst.resize(A);
+  il.resize(A);
+  ol.resize(A);
+  nflags.resize(N);
+  size_t ab = sizeof(int) * size_t(A);
+  if (A) {
+    HIP_CHECK(hipMemcpyAsync(src.data(), dview.src, ab, hipMemcpyDeviceToHost, rt.stream()));
+    HIP_CHECK(hipMemcpyAsync(dst.data(), dview.dst, ab, hipMemcpyDeviceToHost, rt.stream()));
+    HIP_CHECK(hipMemcpyAsync(il.data(), dview.il, ab, hipMemcpyDeviceToHost, rt.stream()));
+    HIP_CHECK(hipMemcpyAsync(ol.data(), dview.ol, ab, hipMemcpyDeviceToHost, rt.stream()));
+  }
+  if (N) HIP_CHECK(hipMemcpyAsync(nflags.data(), dview.nflags, size_t(N), hipMemcpyDeviceToHost, rt.stream()));
+  rt.sync();
+  start.clear();
+  accept.clear();
+  for (int n = 0; n < N; ++n) {
+    if (nflags[n] & NF_START) start.push_back(n);
+    if (nflags[n] & NF_ACCEPT) accept.push_back(n);
+  }
+  host_valid = true;
+  csr_valid = false;
+}
+
+void Structure::ensure_csr() {
+  if (kind == KIND_LINEAR) materialize();
+  ensure_host();
+  if (csr_valid) return;
+  // lists in arc-id order == the push_back order of graph.cpp:62-63
+  in_off.assign(N + 1, 0);
+  out_off.assign(N + 1, 0);
+  for (int64_t a = 0; a < A; ++a) {
+    out_off[src[a] + 1]++;
+    in_off[dst[a] + 1]++;
+  }
+  for (int64_t n = 0; n < N; ++n) {
+    out_off[n + 1] += out_off[n];
+    in_off[n + 1] += in_off[n];
+  }
+  in_list.resize(A);
+  out_list.resize(A);
+  std::vector<int> ci(in_off.begin(), in_off.end() - 1), co(out_off.begin(), out_off.end() - 1);
+  for (int64_t a = 0; a < A; ++a) {
+    out_list[co[src[a]]++] = int(a);
+    in_list[ci[dst[a]]++] = int(a);
+  }
+  csr_valid = true;
+}
+
+int Structure::num_in(int n) {
+  if (kind == KIND_LINEAR) return n == 0 ? 0 : C;
+  ensure_csr();
+  return in_off[n + 1] - in_off[n];
+}
+int Structure::num_out(int n) {
+  if (kind == KIND_LINEAR) return n == M ? 0 : C;
+  ensure_csr();
+  return out_off[n + 1] - out_off[n];
+}
+
+// ======================================================================
+// Weights
+// ======================================================================
+void Weights::ensure_host() {
+  if (host_valid) return;
+  host.resize(n);
+  if (n) Runtime::get().d2h_sync(host.data(), dev, sizeof(float) * size_t(n));
+  host_valid = true;
+}
+
+// ======================================================================
+// Graph
+// ======================================================================
+Graph::Graph(bool calc_grad)
+    : s(std::make_shared<Structure>()), w(std::make_shared<Weights>()), g(std::make_shared<GradState>()) {
+  g->calc_grad = calc_grad;
+}
+
+Graph Graph::make_result(bool calc_grad) { return Graph(calc_grad); }
+
+int Graph::add_node(bool start, bool accept) {
+  s->materialize();
+  s->ensure_host();
+  int idx = int(s->N);
+  s->nflags.push_back(uint8_t((start ? NF_START : 0) | (accept ? NF_ACCEPT : 0)));
+  if (start) s->start.push_back(idx);
+  if (accept) s->accept.push_back(idx);
+  s->N++;
+  s->touch();
+  return idx;
+}
+
+int Graph::add_arc(int src, int dst, int il, int ol, float wt) {
+  s->materialize();
+  s->ensure_host();
+  if (src < 0 || src >= s->N || dst < 0 || dst >= s->N) throw_range("[Graph::addArc] node index out of range");
+  if (il < GTNX_EPSILON || ol < GTNX_EPSILON) throw_invalid("[Graph::addArc] labels must be >= epsilon");  // graph.cpp:57
+  w->ensure_host();
+  int idx = int(s->A);
+  s->src.push_back(src);
+  s->dst.push_back(dst);
+  s->il.push_back(il);
+  s->ol.push_back(ol);
+  w->host.push_back(wt);
+  w->n = int64_t(w->host.size());
+  w->dev_valid = false;
+  w->version++;
+  s->A++;
+  s->touch();
+  return idx;
+}
+
+int64_t Graph::num_start() {
+  if (s->kind == KIND_LINEAR) return 1;
+  s->ensure_host();
+  return int64_t(s->start.size());
+}
+int64_t Graph::num_accept() {
+  if (s->kind == KIND_LINEAR) return s->M > 0 ? 1 : 0;
+  s->ensure_host();
+  return int64_t(s->accept.size());
+}
+
+float Graph::item() {
+  if (s->A != 1)  // graph.cpp:70-73
+    throw_invalid("[Graph::item] Cannot convert Graph with more than 1 arc to a scalar.");
+  w->ensure_host();
+  return w->host[0];
+}
+
+void Graph::arc_sort(bool olabel) {
+  // graph.cpp:162-177
+  if ((olabel && s->olabel_sorted) || (!olabel && s->ilabel_sorted)) return;
+  s->ensure_csr();
+  const std::vector<int>& key = olabel ? s->ol : s->il;
+  auto cmp = [&key](int a, int b) { return key[a] < key[b]; };
+  for (int64_t n = 0; n < s->N; ++n) {
+    std::sort(s->in_list.begin() + s->in_off[n], s->in_list.begin() + s->in_off[n + 1], cmp);
+    std::sort(s->out_list.begin() + s->out_off[n], s->out_list.begin() + s->out_off[n + 1], cmp);
+  }
+  s->dev_valid = false;
+  s->dev_mem.reset();
+  s->sched.reset();
+  s->olabel_sorted = olabel;
+  s->ilabel_sorted = !olabel;
+}
+
+Graph Graph::deep_copy(const Graph& srcg) {
+  // graph.cpp:152-160: structure + weights copied, not on the tape, sort flags dropped
+  Graph out(srcg.g->calc_grad);
+  Structure& a = *srcg.s;
+  if (a.kind == KIND_LINEAR) {
+    out.s->kind = KIND_LINEAR;
+    out.s->N = a.N;
+    out.s->A = a.A;
+    out.s->M = a.M;
+    out.s->C = a.C;
+    // the reference's deepCopy does not carry the sort flags; a linear graph
+    // stays implicitly sorted only while flagged, so materialise the copy
+    out.s->materialize();
+  } else {
+    a.ensure_host();
+    out.s->N = a.N;
+    out.s->A = a.A;
+    out.s->src = a.src;
+    out.s->dst = a.dst;
+    out.s->il = a.il;
+    out.s->ol = a.ol;
+    out.s->nflags = a.nflags;
+    out.s->start = a.start;
+    out.s->accept = a.accept;
+    // adjacency lists are copied too (deepCopy copies the Node vectors)
+    if (a.csr_valid) {
+      out.s->in_off = a.in_off;
+      out.s->in_list = a.in_list;
+      out.s->out_off = a.out_off;
+      out.s->out_list = a.out_list;
+      out.s->csr_valid = true;
+    }
+  }
+  srcg.w->ensure_host();
+  out.w->host = srcg.w->host;
+  out.w->n = srcg.w->n;
+  return out;
+}
+
+const float* Graph::weights_host(bool mut) {
+  if (!w) throw_logic("[Graph::weights] graph has no weights");
+  w->ensure_host();
+  if (mut) {
+    w->host_escaped = true;
+    w->dev_valid = false;
+    w->version++;
+  }
+  return w->host.data();
+}
+
+void Graph::set_weights_host(const float* p) {
+  // graph.cpp:179-181
+  w->host.assign(p, p + s->A);
+  w->n = s->A;
+  w->host_valid = true;
+  w->dev_valid = false;
+  w->version++;
+}
+
+void Graph::set_weights_device(const void* p) {
+  Runtime& rt = Runtime::get();
+  int64_t n = s->A;
+  if (!w->dev || w->n != n || !w->dev_mem || w->dev_mem.use_count() > 1) {
+    w->dev_mem = rt.alloc(sizeof(float) * size_t(n));
+    w->dev = w->dev_mem->as<float>();
+  }
+  w->n = n;
+  rt.d2d(w->dev, p, sizeof(float) * size_t(n));
+  w->dev_valid = true;
+  w->host_valid = false;
+  w->host_escaped = false;
+  w->version++;
+}
+
+Graph& Graph::grad() {
+  // graph.cpp:81-89
+  if (!g->calc_grad) throw_logic("[Graph::grad] Gradient calculation disabled.");
+  if (!g->grad) throw_logic("[Graph::grad] Gradient not calculated yet.");
+  return *g->grad;
+}
+
+void Graph::set_calc_grad(bool c) {
+  // graph.cpp:131-138
+  g->calc_grad = c;
+  if (!c) {
+    g->op.reset();
+    g->has_grad_fn = false;
+    g->inputs.clear();
+    g->grad.reset();
+  }
+}
+
+static void make_grad_graph(Graph& self) {
+  self.g->grad = std::make_unique<Graph>(false);
+  self.g->grad->s = self.s;  // shares the structure (graph.cpp:102-103)
+}
+
+void Graph::add_grad_host(const float* v, int64_t n) {
+  if (!calc_grad()) return;
+  if (n != s->A) throw_logic("[Graph::addGrad] Invalid grad size.");  // graph.cpp:93-95
+  std::lock_guard<std::mutex> lk(s->grad_lock);
+  if (is_grad_available()) {
+    Weights& gw = *g->grad->w;
+    gw.ensure_host();
+    for (int64_t i = 0; i < n; ++i) gw.host[i] += v[i];
+    gw.dev_valid = false;
+  } else {
+    make_grad_graph(*this);
+    Weights& gw = *g->grad->w;
+    gw.host.assign(v, v + n);
+    gw.n = n;
+  }
+}
+
+void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
+  if (!calc_grad()) return;
+  Runtime& rt = Runtime::get();
+  int64_t n = s->A;
+  std::lock_guard<std::mutex> lk(s->grad_lock);
+  if (!is_grad_available()) {
+    make_grad_graph(*this);
+    Weights& gw = *g->grad->w;
+    gw.n = n;
+    gw.host_valid = false;
+    if (adopt) {
+      gw.dev_mem = owner;
+      gw.dev = dev;
+    } else {
+      gw.dev_mem = rt.alloc(sizeof(float) * size_t(n));
+      gw.dev = gw.dev_mem->as<float>();
+      rt.d2d(gw.dev, dev, sizeof(float) * size_t(n));
+    }
+    gw.dev_valid = true;
+    return;
+  }
+  Weights& gw = *g->grad->w;
+  if (!gw.dev_valid) {
+    std::vector<Weights*> v{&gw};
+    ensure_weights_device_batch(v);
+  }
+  AxpyArgs a{gw.dev, dev, n, 1.0f};
+  PinnedMemP pin = rt.alloc_pinned(sizeof(AxpyArgs));
+  *pin->as<AxpyArgs>() = a;
+  DevMemP d = rt.alloc(sizeof(AxpyArgs));
+  rt.h2d(d->ptr, pin->ptr, sizeof(AxpyArgs));
+  launch_axpy_batch(d->as<AxpyArgs>(), 1, n, 0, rt.stream());
+  gw.host_valid = false;
+}
+
+// ======================================================================
+// residency: one staging buffer + one copy per batch
+// ======================================================================
+namespace {
+struct Packer {
+  // lays out blobs at 256-byte aligned offsets inside one allocation
+  size_t total = 0;
+  size_t add(size_t bytes) {
+    size_t off = total;
+    total = align_up(total + bytes, 256);
+    return off;
+  }
+};
+} // namespace
+
+void ensure_device_batch(const std::vector<Structure*>& ss) {
+  Runtime& rt = Runtime::get();
+  std::vector<Structure*> todo;
+  for (Structure* s : ss) {
+    if (s->kind == KIND_LINEAR) {
+      DGraph& v = s->dview;
+      std::memset(&v, 0, sizeof(v));
+      v.kind = KIND_LINEAR;
+      v.N = int(s->N);
+      v.A = int(s->A);
+      v.M = s->M;
+      v.C = s->C;
+      v.n_start = 1;
+      v.n_accept = s->M > 0 ? 1 : 0;
+      v.flags = 3;
+      s->dev_valid = true;
+      continue;
+    }
+    if (!s->dev_valid && std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
+  }
+  if (todo.empty()) return;
+  struct Off {
+    size_t src, dst, il, ol, nf, st, ac, oo, ol_, io, il_;
+  };
+  Packer pk;
+  std::vector<Off> offs(todo.size());
+  for (size_t i = 0; i < todo.size(); ++i) {
+    Structure* s = todo[i];
+    s->ensure_csr();
+    size_t A = size_t(s->A), N = size_t(s->N);
+    Off& o = offs[i];
+    o.src = pk.add(4 * A);
+    o.dst = pk.add(4 * A);
+    o.il = pk.add(4 * A);
+    o.ol = pk.add(4 * A);
+    o.nf = pk.add(N);
+    o.st = pk.add(4 * s->start.size());
+    o.ac = pk.add(4 * s->accept.size());
+    o.oo = pk.add(4 * (N + 1));
+    o.ol_ = pk.add(4 * A);
+    o.io = pk.add(4 * (N + 1));
+    o.il_ = pk.add(4 * A);
+  }
+  PinnedMemP pin = rt.alloc_pinned(pk.total);
+  DevMemP dev = rt.alloc(pk.total);
+  char* hb = pin->as<char>();
+  char* db = dev->as<char>();
+  for (size_t i = 0; i < todo.size(); ++i) {
+    Structure* s = todo[i];
+    size_t A = size_t(s->A), N = size_t(s->N);
+    const Off& o = offs[i];
+    std::memcpy(hb + o.src, s->src.data(), 4 * A);
+    std::memcpy(hb + o.dst, s->dst.data(), 4 * A);
+    std::memcpy(hb + o.il, s->il.data(), 4 * A);
+    std::memcpy(hb + o.ol, s->ol.data(), 4 * A);
+    std::memcpy(hb + o.nf, s->nflags.data(), N);
+    std::memcpy(hb + o.st, s->start.data(), 4 * s->start.size());
+    std::memcpy(hb + o.ac, s->accept.data(), 4 * s->accept.size());
+    std::memcpy(hb + o.oo, s->out_off.data(), 4 * (N + 1));
+    std::memcpy(hb + o.ol_, s->out_list.data(), 4 * A);
+    std::memcpy(hb + o.io, s->in_off.data(), 4 * (N + 1));
+    std::memcpy(hb + o.il_, s->in_list.data(), 4 * A);
+    DGraph& v = s->dview;
+    std::memset(&v, 0, sizeof(v));
+    v.kind = KIND_EXPLICIT;
+    v.N = int(N);
+    v.A = int(A);
+    v.n_start = int(s->start.size());
+    v.n_accept = int(s->accept.size());
+    v.flags = (s->ilabel_sorted ? 1 : 0) | (s->olabel_sorted ? 2 : 0);
+    v.src = reinterpret_cast<const int*>(db + o.src);
+    v.dst = reinterpret_cast<const int*>(db + o.dst);
+    v.il = reinterpret_cast<const int*>(db + o.il);
+    v.ol = reinterpret_cast<const int*>(db + o.ol);
+    v.nflags = reinterpret_cast<const uint8_t*>(db + o.nf);
+    v.start_list = reinterpret_cast<const int*>(db + o.st);
+    v.accept_list = reinterpret_cast<const int*>(db + o.ac);
+    v.out_off = reinterpret_cast<const int*>(db + o.oo);
+    v.out_list = reinterpret_cast<const int*>(db + o.ol_);
+    v.in_off = reinterpret_cast<const int*>(db + o.io);
+    v.in_list = reinterpret_cast<const int*>(db + o.il_);
+    s->dev_mem = dev;
+    s->dev_valid = true;
+  }
+  rt.h2d(dev->ptr, pin->ptr, pk.total);
+}
+
+void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
+  Runtime& rt = Runtime::get();
+  std::vector<Weights*> todo;
+  for (Weights* w : ws) {
+    bool stale = !w->dev_valid || w->host_escaped;
+    if (stale && std::find(todo.begin(), todo.end(), w) == todo.end()) todo.push_back(w);
+  }
+  if (todo.empty()) return;
+  Packer pk;
+  std::vector<size_t> offs(todo.size());
+  for (size_t i = 0; i < todo.size(); ++i) {
+    if (!todo[i]->host_valid) throw_logic("weights valid on neither host nor device");
+    offs[i] = pk.add(4 * size_t(todo[i]->n));
+  }
+  PinnedMemP pin = rt.alloc_pinned(pk.total);
+  DevMemP dev = rt.alloc(pk.total);
+  for (size_t i = 0; i < todo.size(); ++i) {
+    Weights* w = todo[i];
+    std::memcpy(pin->as<char>(offs[i]), w->host.data(), 4 * size_t(w->n));
+    w->dev_mem = dev;
+    w->dev = dev->as<float>(offs[i]);
+    w->dev_valid = true;
+  }
+  rt.h2d(dev->ptr, pin->ptr, pk.total);
+}
+
+DGraph device_view(Graph& gr) {
+  DGraph v = gr.s->dview;
+  v.w = gr.w ? gr.w->dev : nullptr;
+  return v;
+}
+
+// ======================================================================
+// level schedule (host pre-pass for host-built structures)
+// Replays the reference's Kahn FIFO (shortest.cpp:96-145) on the structure only,
+// so positions == the reference's processing order; levels are the dependency
+// depth, which the FIFO order is sorted by.
+// ======================================================================
+namespace {
+struct HostSched {
+  bool error = false;
+  int P = 0, L = 0;
+  std::vector<int> level_off, row_off, in_srcpos, in_arc, in_rank, acc_pos, out_off, out_dstpos, out_arc;
+  std::vector<uint8_t> pflags;
+  int max_width = 0;
+  bool all_written = false;
+};
+
+void build_host_schedule(Structure& s, HostSched& h, bool need_rank) {
+  s.ensure_csr();
+  const int N = int(s.N);
+  std::vector<int> deg(N), order, pos(N, -1), level(N, 0);
+  order.reserve(N);
+  for (int n = 0; n < N; ++n) deg[n] = s.in_off[n + 1] - s.in_off[n];
+  size_t head = 0;
+  for (int n : s.start)
+    if (deg[n] == 0) order.push_back(n);
+  while (head < order.size()) {
+    int n = order[head];
+    pos[n] = int(head);
+    ++head;
+    for (int k = s.out_off[n]; k < s.out_off[n + 1]; ++k) {
+      int d = s.dst[s.out_list[k]];
+      level[d] = std::max(level[d], level[n] + 1);
+      if (--deg[d] == 0) order.push_back(d);
+    }
+  }
+  h.P = int(order.size());
+  for (int n : s.accept)
+    if (pos[n] < 0) h.error = true;  // shortest.cpp:149-152
+  // levels (FIFO order is level-sorted)
+  h.level_off.clear();
+  int cur = -1;
+  for (int p = 0; p < h.P; ++p) {
+    int lv = level[order[p]];
+    while (cur < lv) {
+      h.level_off.push_back(p);
+      ++cur;
+    }
+  }
+  h.L = int(h.level_off.size());
+  h.level_off.push_back(h.P);
+  for (int l = 0; l < h.L; ++l) h.max_width = std::max(h.max_width, h.level_off[l + 1] - h.level_off[l]);
+  // reverse-Kahn "processed" flags (shortest.cpp:45-53, 76-78): a node's arcs get
+  // gradients only if it is popped from the reverse queue
+  std::vector<int> odeg(N);
+  std::vector<uint8_t> proc(N, 0);
+  std::vector<int> rq;
+  for (int n = 0; n < N; ++n) odeg[n] = s.out_off[n + 1] - s.out_off[n];
+  for (int n : s.accept)
+    if (odeg[n] == 0) rq.push_back(n);
+  for (size_t i = 0; i < rq.size(); ++i) {
+    int n = rq[i];
+    proc[n] = 1;
+    for (int k = s.in_off[n]; k < s.in_off[n + 1]; ++k) {
+      int u = s.src[s.in_list[k]];
+      if (--odeg[u] == 0) rq.push_back(u);
+    }
+  }
+  // rows
+  h.row_off.assign(h.P + 1, 0);
+  h.out_off.assign(h.P + 1, 0);
+  h.pflags.assign(h.P, 0);
+  std::vector<int> out_index_of_arc;  // push rank: index in the position-ordered out CSR
+  if (need_rank) out_index_of_arc.assign(size_t(s.A), 0);
+  for (int p = 0; p < h.P; ++p) {
+    int n = order[p];
+    h.pflags[p] = s.nflags[n];
+    h.row_off[p + 1] = h.row_off[p] + (s.in_off[n + 1] - s.in_off[n]);
+  }
+  h.in_srcpos.resize(h.row_off[h.P]);
+  h.in_arc.resize(h.row_off[h.P]);
+  for (int p = 0; p < h.P; ++p) {
+    int n = order[p], o = h.row_off[p];
+    for (int k = s.in_off[n]; k < s.in_off[n + 1]; ++k, ++o) {
+      int a = s.in_list[k];
+      h.in_arc[o] = a;
+      h.in_srcpos[o] = pos[s.src[a]];  // >= 0: all predecessors of a scheduled node are scheduled
+    }
+  }
+  bool all = (h.P == N);
+  int64_t written = 0;
+  for (int p = 0; p < h.P; ++p) {
+    int n = order[p];
+    int cnt = 0;
+    for (int k = s.out_off[n]; k < s.out_off[n + 1]; ++k) {
+      int d = s.dst[s.out_list[k]];
+      if (pos[d] >= 0 && proc[d]) ++cnt;
+    }
+    h.out_off[p + 1] = h.out_off[p] + cnt;
+  }
+  h.out_dstpos.resize(h.out_off[h.P]);
+  h.out_arc.resize(h.out_off[h.P]);
+  {
+    int rank = 0;
+    for (int p = 0; p < h.P; ++p) {
+      int n = order[p], o = h.out_off[p];
+      for (int k = s.out_off[n]; k < s.out_off[n + 1]; ++k, ++rank) {
+        int a = s.out_list[k];
+        if (need_rank) out_index_of_arc[a] = rank;
+        int d = s.dst[a];
+        if (pos[d] >= 0 && proc[d]) {
+          h.out_dstpos[o] = pos[d];
+          h.out_arc[o] = a;
+          ++o;
+          ++written;
+        }
+      }
+    }
+  }
+  h.all_written = all && written == s.A;
+  if (need_rank) {
+    h.in_rank.resize(h.in_arc.size());
+    for (size_t i = 0; i < h.in_arc.size(); ++i) h.in_rank[i] = out_index_of_arc[h.in_arc[i]];
+  }
+  h.acc_pos.resize(s.accept.size());
+  for (size_t k = 0; k < s.accept.size(); ++k) h.acc_pos[k] = pos[s.accept[k]];
+}
+} // namespace
+
+void ensure_schedule_batch(const std::vector<Structure*>& ss, bool need_rank) {
+  Runtime& rt = Runtime::get();
+  std::vector<Structure*> todo;
+  for (Structure* s : ss) {
+    if (s->kind == KIND_LINEAR) continue;
+    if (s->sched && (!need_rank || s->sched->has_rank || (s->sched->view.flags & SCHED_TIE_BY_ARC))) continue;
+    if (std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
+  }
+  if (todo.empty()) return;
+  std::vector<HostSched> hs(todo.size());
+  struct Off {
+    size_t lv, ro, sp, ia, ir, pf, ap, oo, od, oa;
+  };
+  std::vector<Off> offs(todo.size());
+  Packer pk;
+  for (size_t i = 0; i < todo.size(); ++i) {
+    build_host_schedule(*todo[i], hs[i], need_rank);
+    HostSched& h = hs[i];
+    Off& o = offs[i];
+    o.lv = pk.add(4 * h.level_off.size());
+    o.ro = pk.add(4 * h.row_off.size());
+    o.sp = pk.add(4 * h.in_srcpos.size());
+    o.ia = pk.add(4 * h.in_arc.size());
+    o.ir = pk.add(4 * h.in_rank.size());
+    o.pf = pk.add(h.pflags.size());
+    o.ap = pk.add(4 * h.acc_pos.size());
+    o.oo = pk.add(4 * h.out_off.size());
+    o.od = pk.add(4 * h.out_dstpos.size());
+    o.oa = pk.add(4 * h.out_arc.size());
+  }
+  PinnedMemP pin = rt.alloc_pinned(pk.total);
+  DevMemP dev = rt.alloc(pk.total);
+  char* hb = pin->as<char>();
+  char* db = dev->as<char>();
+  auto put = [&](size_t off, const void* p, size_t bytes) {
+    if (bytes) std::memcpy(hb + off, p, bytes);
+  };
+  for (size_t i = 0; i < todo.size(); ++i) {
+    HostSched& h = hs[i];
+    const Off& o = offs[i];
+    put(o.lv, h.level_off.data(), 4 * h.level_off.size());
+    put(o.ro, h.row_off.data(), 4 * h.row_off.size());
+    put(o.sp, h.in_srcpos.data(), 4 * h.in_srcpos.size());
+    put(o.ia, h.in_arc.data(), 4 * h.in_arc.size());
+    put(o.ir, h.in_rank.data(), 4 * h.in_rank.size());
+    put(o.pf, h.pflags.data(), h.pflags.size());
+    put(o.ap, h.acc_pos.data(), 4 * h.acc_pos.size());
+    put(o.oo, h.out_off.data(), 4 * h.out_off.size());
+    put(o.od, h.out_dstpos.data(), 4 * h.out_dstpos.size());
+    put(o.oa, h.out_arc.data(), 4 * h.out_arc.size());
+    auto sc = std::make_shared<Schedule>();
+    sc->error = h.error;
+    sc->mem = dev;
+    sc->max_level_width = h.max_width;
+    sc->n_in = int64_t(h.in_arc.size());
+    sc->n_out = int64_t(h.out_arc.size());
+    sc->all_written = h.all_written;
+    sc->has_rank = need_rank;
+    DSched& v = sc->view;
+    v.P = h.P;
+    v.L = h.L;
+    v.n_accept = int(h.acc_pos.size());
+    v.flags = 0;
+    v.level_off = reinterpret_cast<const int*>(db + o.lv);
+    v.row_off = reinterpret_cast<const int*>(db + o.ro);
+    v.in_srcpos = reinterpret_cast<const int*>(db + o.sp);
+    v.in_arc = reinterpret_cast<const int*>(db + o.ia);
+    v.in_rank = need_rank ? reinterpret_cast<const int*>(db + o.ir) : nullptr;
+    v.in_w = nullptr;
+    v.pflags = reinterpret_cast<const uint8_t*>(db + o.pf);
+    v.acc_pos = reinterpret_cast<const int*>(db + o.ap);
+    v.out_off = reinterpret_cast<const int*>(db + o.oo);
+    v.out_dstpos = reinterpret_cast<const int*>(db + o.od);
+    v.out_arc = reinterpret_cast<const int*>(db + o.oa);
+    todo[i]->sched = sc;
+  }
+  rt.h2d(dev->ptr, pin->ptr, pk.total);
+}
+
+// ======================================================================
+// equal / isomorphic (host fixtures of the parity suite)
+// ======================================================================
+namespace {
+struct HostView {
+  Structure* s;
+  const float* w;
+};
+HostView host_view(Graph& g) {
+  g.s->ensure_csr();
+  g.w->ensure_host();
+  return {g.s.get(), g.w->host.data()};
+}
+} // namespace
+
+bool graphs_equal(Graph& a, Graph& b) {
+  // utils.cpp:45-77: same node ids, per-node multiset of out arcs, arc order ignored
+  if (a.num_nodes() != b.num_nodes() || a.num_start() != b.num_start() ||
+      a.num_accept() != b.num_accept() || a.num_arcs() != b.num_arcs())
+    return false;
+  HostView x = host_view(a), y = host_view(b);
+  for (int n = 0; n < x.s->N; ++n) {
+    if (x.s->num_in(n) != y.s->num_in(n) || x.s->num_out(n) != y.s->num_out(n) ||
+        x.s->nflags[n] != y.s->nflags[n])
+      return false;
+    std::list<int> bout(y.s->out_list.begin() + y.s->out_off[n], y.s->out_list.begin() + y.s->out_off[n + 1]);
+    for (int k = x.s->out_off[n]; k < x.s->out_off[n + 1]; ++k) {
+      int a1 = x.s->out_list[k];
+      auto it = bout.begin();
+      for (; it != bout.end(); ++it) {
+        int a2 = *it;
+        if (x.s->dst[a1] == y.s->dst[a2] && x.s->src[a1] == y.s->src[a2] && x.s->il[a1] == y.s->il[a2] &&
+            x.s->ol[a1] == y.s->ol[a2] && x.w[a1] == y.w[a2])
+          break;
+      }
+      if (it == bout.end()) return false;
+      bout.erase(it);
+    }
+  }
+  return true;
+}
+
+namespace {
+bool iso_rec(HostView& x, HostView& y, int n1, int n2, std::map<std::pair<int, int>, int>& visited) {
+  // utils.cpp:79-123
+  auto ins = visited.insert({{n1, n2}, n1});
+  if (!ins.second) return ins.first->second >= 0;
+  if (x.s->num_in(n1) != y.s->num_in(n2) || x.s->num_out(n1) != y.s->num_out(n2) ||
+      x.s->nflags[n1] != y.s->nflags[n2]) {
+    ins.first->second = -1;
+    return false;
+  }
+  std::list<int> bout(y.s->out_list.begin() + y.s->out_off[n2], y.s->out_list.begin() + y.s->out_off[n2 + 1]);
+  for (int k = x.s->out_off[n1]; k < x.s->out_off[n1 + 1]; ++k) {
+    int a1 = x.s->out_list[k];
+    auto it = bout.begin();
+    for (; it != bout.end(); ++it) {
+      int a2 = *it;
+      if (x.s->il[a1] != y.s->il[a2] || x.s->ol[a1] != y.s->ol[a2] || x.w[a1] != y.w[a2]) continue;
+      if (iso_rec(x, y, x.s->dst[a1], y.s->dst[a2], visited)) break;
+    }
+    if (it == bout.end()) {
+      visited[{n1, n2}] = -1;
+      return false;
+    }
+    bout.erase(it);
+  }
+  return true;
+}
+} // namespace
+
+bool graphs_isomorphic(Graph& a, Graph& b) {
+  // utils.cpp:125-150
+  if (a.num_nodes() != b.num_nodes() || a.num_start() != b.num_start() ||
+      a.num_accept() != b.num_accept() || a.num_arcs() != b.num_arcs())
+    return false;
+  HostView x = host_view(a), y = host_view(b);
+  std::map<std::pair<int, int>, int> visited;
+  std::list<int> s2(y.s->start.begin(), y.s->start.end());
+  for (int s1 : x.s->start) {
+    auto it = s2.begin();
+    for (; it != s2.end(); ++it)
+      if (iso_rec(x, y, s1, *it, visited)) break;
+    if (it == s2.end()) return false;
+    s2.erase(it);
+  }
+  return true;
+}
+
+} // namespace gtnx

@@ -1,0 +1,135 @@
+// graph.h -- host-side graph value handle of the engine.
+//
+// Mirrors the three shared pieces of the reference's gtn::Graph
+// (gtn/graph.h:439-464: SharedGraph / weights / SharedGrad) so copies alias and
+// deepCopy detaches exactly as there, but each piece is dual-resident:
+//   Structure : host SoA mirror (for graphs built with addNode/addArc or when a
+//               device-built graph is inspected) + SoA/CSR buffers in HBM
+//   Weights   : host vector + device buffer (possibly a slice of a batch arena)
+//   GradState : autograd tape node (producing op, inputs, grad graph)
+#pragma once
+
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "kernels.h"
+#include "runtime.h"
+
+namespace gtnx {
+
+struct Graph;
+struct OpRecord;
+
+// cached level schedule for shortest distance (see kernels.h: DSched)
+struct Schedule {
+  bool error = false;  // an accept node is never reached: cycle / self-loop / disconnected
+  DevMemP mem;
+  DSched view{};
+  int max_level_width = 0;
+  int64_t n_in = 0, n_out = 0;
+  bool all_written = false;  // every arc gets a gradient (no memset needed)
+  bool has_rank = false;
+  // view.in_w (weights permuted into row order, emitted by compose) is only
+  // valid for this weights object at this version
+  const void* in_w_of = nullptr;
+  uint64_t in_w_version = 0;
+  const float* in_w = nullptr;
+};
+
+struct Structure {
+  int kind = KIND_EXPLICIT;
+  int64_t N = 0, A = 0;
+  int M = 0, C = 0;  // KIND_LINEAR
+  bool ilabel_sorted = false, olabel_sorted = false;
+
+  // ---- host mirror (arc-id order SoA + lazily built CSR in reference list order)
+  bool host_valid = true;
+  std::vector<int> src, dst, il, ol;
+  std::vector<uint8_t> nflags;
+  std::vector<int> start, accept;
+  bool csr_valid = false;
+  std::vector<int> in_off, in_list, out_off, out_list;
+
+  // ---- device mirror
+  bool dev_valid = false;
+  DevMemP dev_mem;  // owner (may be shared by a whole batch)
+  DGraph dview{};   // pointers into dev_mem (w unset)
+
+  std::shared_ptr<Schedule> sched;  // valid while the structure is unchanged
+  std::mutex grad_lock;             // graph.h:450
+
+  void materialize();  // LINEAR -> EXPLICIT host arrays
+  void ensure_host();  // download a device-built structure
+  void ensure_csr();
+  void touch();        // structural mutation: drop device mirror, schedule, sort flags
+  int num_in(int n);
+  int num_out(int n);
+};
+
+struct Weights {
+  int64_t n = 0;
+  std::vector<float> host;
+  bool host_valid = true;
+  bool host_escaped = false;  // a mutable host pointer was handed out (Graph::weights())
+  uint64_t version = 0;       // bumped on every mutation
+  DevMemP dev_mem;
+  float* dev = nullptr;
+  bool dev_valid = false;
+  void ensure_host();
+};
+
+struct GradState {
+  bool calc_grad = true;
+  std::shared_ptr<OpRecord> op;  // producing op; nullptr for leaves
+  int op_idx = 0;
+  bool has_grad_fn = false;      // mirrors `gradFunc != nullptr`
+  std::vector<Graph> inputs;
+  std::unique_ptr<Graph> grad;
+};
+
+struct Graph {
+  std::shared_ptr<Structure> s;
+  std::shared_ptr<Weights> w;
+  std::shared_ptr<GradState> g;
+
+  explicit Graph(bool calc_grad = true);
+  static Graph make_result(bool calc_grad);  // fresh pieces, for op outputs
+
+  // graph.cpp:33-67
+  int add_node(bool start, bool accept);
+  int add_arc(int src, int dst, int il, int ol, float w);
+  int64_t num_nodes() const { return s->N; }
+  int64_t num_arcs() const { return s->A; }
+  int64_t num_start();
+  int64_t num_accept();
+  float item();
+  void arc_sort(bool olabel);
+  static Graph deep_copy(const Graph& src);
+  const float* weights_host(bool mut);
+  void set_weights_host(const float* p);
+  void set_weights_device(const void* p);
+  bool calc_grad() const { return g->calc_grad; }
+  bool is_grad_available() const { return g->grad != nullptr; }
+  Graph& grad();
+  void set_calc_grad(bool c);
+  void zero_grad() { g->grad.reset(); }
+  uintptr_t id() const { return reinterpret_cast<uintptr_t>(g.get()); }
+
+  // addGrad (graph.cpp:91-129).  `owner`/`dev` is a device vector of numArcs
+  // floats; when `adopt` the buffer becomes the grad without a copy.
+  void add_grad_host(const float* v, int64_t n);
+  void add_grad_device(const DevMemP& owner, float* dev, bool adopt);
+};
+
+// ---- batched residency helpers (ONE staging copy for a whole batch)
+void ensure_device_batch(const std::vector<Structure*>& ss);
+void ensure_weights_device_batch(const std::vector<Weights*>& ws);
+void ensure_schedule_batch(const std::vector<Structure*>& ss, bool need_rank);
+DGraph device_view(Graph& g);  // structure view + weight pointer (after the ensure_* calls)
+
+bool graphs_equal(Graph& a, Graph& b);       // gtn/utils.cpp:45-77
+bool graphs_isomorphic(Graph& a, Graph& b);  // gtn/utils.cpp:79-150
+
+} // namespace gtnx

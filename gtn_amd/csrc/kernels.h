@@ -1,0 +1,221 @@
+// kernels.h -- device-side views (PODs laid out in HBM) and the launch entry
+// points of the HIP kernels.  Everything here is plain data + free functions so
+// the host runtime (graph.cpp / ops.cpp) never sees kernel internals.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace gtnx {
+
+enum : int { KIND_EXPLICIT = 0, KIND_LINEAR = 1 };
+enum : int { NF_START = 1, NF_ACCEPT = 2 };
+
+// ---------------------------------------------------------------------------
+// Structure-of-arrays view of one graph in HBM (replaces gtn/graph.h:58-73's
+// AoS Arc + per-node std::vector<int> in/out).  Arc arrays are in arc-id (API)
+// order.  Adjacency is CSR over arc ids: out_list[out_off[n] .. out_off[n+1])
+// is Graph::out(n) in the reference's list order, likewise in_*.
+// KIND_LINEAR (gtn/creations.cpp:20-33) stores nothing but (M, C): arc a is
+// (a / C) -> (a / C + 1) with label a % C; only the weight tensor is material.
+// ---------------------------------------------------------------------------
+struct DGraph {
+  int kind;
+  int N, A;
+  int M, C;
+  int n_start, n_accept;
+  int flags;  // bit0 ilabelSorted, bit1 olabelSorted
+  const int* src;
+  const int* dst;
+  const int* il;
+  const int* ol;
+  const uint8_t* nflags;
+  const int* start_list;
+  const int* accept_list;
+  const int* out_off;
+  const int* out_list;  // nullptr => identity (arcs already grouped by src in id order)
+  const int* in_off;
+  const int* in_list;
+  const float* w;  // weights, arc-id order (filled per op; not part of the structure)
+};
+
+// ---------------------------------------------------------------------------
+// Level schedule of a DAG for shortest distance, in *position space*: nodes
+// renumbered by their place in the reference's Kahn FIFO order
+// (gtn/functions/shortest.cpp:96-145), grouped into dependency levels.
+//   rows   : row_off[p] .. row_off[p+1] index in_srcpos/in_arc  (in-arcs of p)
+//   in_w   : optional weights permuted into row order (compose emits it)
+//   out_*  : the transposed rows for the backward sweep
+// Device-built layered products have position == node id and out_arc == nullptr
+// (arc k is the k-th out entry).
+// ---------------------------------------------------------------------------
+struct DSched {
+  int P;  // scheduled nodes
+  int L;  // levels
+  int n_accept;
+  int flags;  // bit0: tie-break by arc id (rows unordered); bit1: out rows are identity
+  const int* level_off;  // [L+1]
+  const int* row_off;    // [P+1]
+  const int* in_srcpos;  // [Ain]
+  const int* in_arc;     // [Ain] arc ids
+  const int* in_rank;    // [Ain] push rank for viterbiPath ties (nullptr => arc id)
+  const float* in_w;     // [Ain] or nullptr
+  const uint8_t* pflags; // [P] NF_START | NF_ACCEPT by position
+  const int* acc_pos;    // [n_accept] position of accept()[k]
+  const int* out_off;    // [P+1]
+  const int* out_dstpos; // [Aout]
+  const int* out_arc;    // [Aout] or nullptr (identity)
+};
+enum : int { SCHED_TIE_BY_ARC = 1, SCHED_OUT_IDENTITY = 2 };
+
+// per-graph result of the forward sweep (kept for the backward sweep)
+struct SdResult {
+  float score;      // shortest.cpp:159
+  float max_final;  // maxScoresCache.back()
+  int argmax_final; // position of the arg-max accept node (tropical), -1 if none
+  int pad;
+};
+
+// one shortest-distance problem
+struct SdArgs {
+  DSched s;
+  const float* w;   // arc-id order weights
+  float* scores;    // [P]
+  int* argmax;      // [P] tropical only (arc id, -1 = the start node's virtual 0)
+  SdResult* result; // [1]
+  float* out_score; // [1] the scalar graph's weight
+  // backward
+  const float* delta;  // [1] upstream gradient of the scalar
+  float* node_grad;    // [P]
+  float* arc_grad;     // [A] arc-id order
+};
+
+enum : int { SD_LOG = 0, SD_TROPICAL = 1, SD_PATH = 2 };
+
+void launch_sd_forward(const SdArgs* d_args, int n, int mode, int max_level_width,
+                       int avg_in_degree_x16, hipStream_t st);
+void launch_sd_backward(const SdArgs* d_args, int n, int mode, int max_level_width,
+                        hipStream_t st);
+
+// viterbiPath pointer chase (shortest.cpp:239-245): writes path arc ids first-arc-first
+struct PathArgs {
+  DSched s;
+  DGraph g;
+  const int* argmax;       // back-pointers by position (arc id / -1)
+  const SdResult* result;
+  int* path_arcs;          // [cap]
+  int* path_il;            // [cap]
+  int* path_ol;            // [cap]
+  float* path_w;           // [cap]
+  int* path_len;           // [2]: length, has_node
+  int cap;
+};
+void launch_path_chase(const PathArgs* d_args, int n, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// linear-chain emissions graphs: forwardScore / viterbiScore and their grads
+// are row reductions over the [M][C] weight tensor (no graph traversal).
+// ---------------------------------------------------------------------------
+struct LinArgs {
+  const float* w;   // [M][C]
+  int M, C;
+  float* out_score; // [1]
+  float* partial;   // [splits]
+  const float* delta;
+  float* grad;      // [M][C]
+};
+void launch_linear_forward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
+void launch_linear_backward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// composition (gtn/functions/compose.cpp:377-522)
+// ---------------------------------------------------------------------------
+enum : int { MATCH_UNSORTED = 0, MATCH_SINGLY_G1 = 1, MATCH_SINGLY_G2 = 2, MATCH_DOUBLY = 3 };
+
+struct ComposeOut {
+  int N, A, L;
+  int layered;   // every arc goes from BFS level k to k+1
+  int overflow;  // capacity exceeded (host bound was wrong) -- never expected
+  int pad[3];
+};
+
+struct ComposeArgs {
+  DGraph g1, g2;
+  int matcher;
+  int Ncap, Acap;
+  int* state;     // [N1*N2] pair -> INT_MIN unreachable / R / claim / node id
+  int* queue;     // [N1*N2] backward-BFS queue of pair ids
+  // outputs (SoA, arc-id order)
+  int* src;
+  int* dst;
+  int* il;
+  int* ol;
+  float* w;
+  int* gi1;       // gradInfo.first  (compose.cpp:443-446)
+  int* gi2;       // gradInfo.second
+  uint8_t* nflags;
+  int* pair_of;   // [Ncap] composed node -> pair id
+  int* out_off;   // [Ncap+1]
+  int* level_off; // [Ncap+2]
+  // in-CSR (filled by the transpose kernels)
+  int* in_off;    // [Ncap+1]
+  int* in_cursor; // [Ncap]
+  int* in_list;   // [Acap]
+  int* in_src;    // [Acap]
+  float* in_w;    // [Acap]
+  int* start_list;  // [Ncap]
+  int* accept_list; // [Ncap]
+  int* counts;      // [2] n_start, n_accept
+  ComposeOut* out;
+};
+void launch_compose(const ComposeArgs* d_args, int n, hipStream_t st);
+size_t compose_transpose_scratch_bytes(int n, int maxNcap);
+void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int maxNcap, void* scratch,
+                              hipStream_t st);
+
+struct ComposeGradArgs {
+  const float* delta; // [A] grads of the composed arcs
+  const int* gi1;
+  const int* gi2;
+  int A;
+  int A1, A2;
+  float* grad1; // nullptr when input 0 has calcGrad = false
+  float* grad2;
+};
+void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st);
+
+// ---------------------------------------------------------------------------
+// small elementwise helpers
+// ---------------------------------------------------------------------------
+void launch_fill_i32(int* p, int v, size_t n, hipStream_t st);
+void launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
+// out[i] = sa * a[i] + sb * b[i]  over n scalars held at arbitrary addresses
+struct ScalarArgs {
+  const float* a;
+  const float* b; // may be nullptr
+  float* out;
+};
+void launch_scalar_combine(const ScalarArgs* d_args, int n, float sa, float sb, hipStream_t st);
+// dst[i] += src[i] for a batch of vectors (atomic when dst's may repeat)
+struct AxpyArgs {
+  float* dst;
+  const float* src;
+  int64_t n;
+  float scale;
+};
+void launch_axpy_batch(const AxpyArgs* d_args, int n, int64_t maxn, int atomic, hipStream_t st);
+// gather n scalars at arbitrary addresses into a dense array
+void launch_gather_scalars(const float* const* d_ptrs, float* out, int n, hipStream_t st);
+// viterbiPath grad: grad[arcs[a]] += delta[a]
+struct ScatterArgs {
+  const int* idx;
+  const float* delta;
+  float* grad;
+  int n;
+};
+void launch_scatter_add(const ScatterArgs* d_args, int n, int maxn, hipStream_t st);
+// materialise a KIND_LINEAR graph's arc arrays
+void launch_linear_materialize(int M, int C, int* src, int* dst, int* il, int* ol, hipStream_t st);
+
+} // namespace gtnx

@@ -1,0 +1,237 @@
+// misc.hip -- linear-chain (emissions) kernels and small batched helpers.
+//
+// forwardScore / viterbiScore of linearGraph(M, C) (gtn/creations.cpp:20-33) is
+//   score = sum_t reduce_c w[t][c]      (reduce = log-sum-exp | max)
+// because node t+1's only predecessor is node t (shortest.cpp:118-137 applied to
+// a chain).  So the emissions normaliser of a CTC/ASG loss is a pure streaming
+// row reduction over the [M][C] weight tensor: one wave64 per row, float4
+// loads, shuffle reductions; HBM traffic = 4*M*C bytes (+ the same again to
+// write the gradient in the backward kernel).
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "kernels.h"
+
+namespace gtnx {
+namespace {
+
+#define NEG_INF (-__builtin_huge_valf())
+#define POS_INF (__builtin_huge_valf())
+constexpr int kBlock = 256;
+constexpr int kSplits = 8;  // row chunks per graph => n*8 workgroups
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// row reduce with one wave; returns (lse or max) and, for tropical, the first arg-max
+template <bool TROPICAL>
+__device__ __forceinline__ float row_reduce(const float* __restrict__ row, int C, int lane, int* argmax) {
+  float mx = NEG_INF;
+  int am = INT_MAX;
+  for (int c = lane; c < C; c += 64) {
+    const float v = row[c];
+    if (v > mx) {
+      mx = v;
+      am = c;
+    }
+  }
+  if (TROPICAL) {
+    // first max in label order (in-arcs are label-ascending, strict '>')
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(mx, o, 64);
+      const int a2 = __shfl_xor(am, o, 64);
+      if (v2 > mx || (v2 == mx && a2 < am)) {
+        mx = v2;
+        am = a2;
+      }
+    }
+    if (argmax) *argmax = (mx > NEG_INF) ? am : -1;
+    return C > 0 ? mx : NEG_INF;
+  }
+  mx = wave_max(mx);
+  if (C == 0) return NEG_INF;
+  if (mx == POS_INF || mx == NEG_INF) return mx;
+  float sum = 0.0f;
+  for (int c = lane; c < C; c += 64) sum += expf(row[c] - mx);
+  sum = wave_sum(sum);
+  return mx + log1pf(sum - 1.0f);
+}
+
+template <bool TROPICAL>
+__global__ __launch_bounds__(kBlock) void linear_forward_kernel(const LinArgs* __restrict__ args) {
+  const LinArgs a = args[blockIdx.x / kSplits];
+  const int split = blockIdx.x % kSplits;
+  const int rows_per = (a.M + kSplits - 1) / kSplits;
+  const int r0 = split * rows_per, r1 = min(a.M, r0 + rows_per);
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  float acc = 0.0f;
+  for (int r = r0 + wave; r < r1; r += kBlock / 64)
+    acc += row_reduce<TROPICAL>(a.w + (size_t)r * a.C, a.C, lane, nullptr);
+  __shared__ float sh[kBlock / 64];
+  if (lane == 0) sh[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+    a.partial[split] = t;
+  }
+}
+
+__global__ void linear_finish_kernel(const LinArgs* __restrict__ args, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const LinArgs a = args[i];
+  float t;
+  if (a.M == 0) {
+    t = NEG_INF;  // start node is not accepting: empty accept reduction
+  } else {
+    t = 0.0f;
+    for (int s = 0; s < kSplits; ++s) t += a.partial[s];
+  }
+  *a.out_score = t;
+}
+
+template <bool TROPICAL>
+__global__ __launch_bounds__(kBlock) void linear_backward_kernel(const LinArgs* __restrict__ args) {
+  const LinArgs a = args[blockIdx.x / kSplits];
+  const int split = blockIdx.x % kSplits;
+  const int rows_per = (a.M + kSplits - 1) / kSplits;
+  const int r0 = split * rows_per, r1 = min(a.M, r0 + rows_per);
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const float delta = *a.delta;
+  for (int r = r0 + wave; r < r1; r += kBlock / 64) {
+    const float* row = a.w + (size_t)r * a.C;
+    float* grow = a.grad + (size_t)r * a.C;
+    int am = -1;
+    const float red = row_reduce<TROPICAL>(row, a.C, lane, &am);
+    for (int c = lane; c < a.C; c += 64) {
+      float g;
+      if (TROPICAL)
+        g = (c == am) ? 1.0f : 0.0f;
+      else
+        g = expf(row[c] - red);  // exp(score[t] + w - score[t+1])
+      grow[c] = g * delta;
+    }
+  }
+}
+
+__global__ void fill_i32_kernel(int* p, int v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+__global__ void fill_f32_kernel(float* p, float v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+__global__ void scalar_combine_kernel(const ScalarArgs* __restrict__ args, int n, float sa, float sb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ScalarArgs a = args[i];
+  float v = sa * (*a.a);
+  if (a.b) v += sb * (*a.b);
+  *a.out = v;
+}
+
+__global__ void axpy_batch_kernel(const AxpyArgs* __restrict__ args, int atomic) {
+  const AxpyArgs a = args[blockIdx.y];
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < a.n; i += stride) {
+    if (atomic == 2)
+      a.dst[i] = a.scale * a.src[i];  // copy mode
+    else if (atomic)
+      atomicAdd(a.dst + i, a.scale * a.src[i]);
+    else
+      a.dst[i] += a.scale * a.src[i];
+  }
+}
+
+__global__ void gather_scalars_kernel(const float* const* __restrict__ ptrs, float* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = *ptrs[i];
+}
+
+__global__ void scatter_add_kernel(const ScatterArgs* __restrict__ args) {
+  const ScatterArgs a = args[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += gridDim.x * blockDim.x)
+    atomicAdd(a.grad + a.idx[i], a.delta[i]);
+}
+
+__global__ void linear_materialize_kernel(int M, int C, int* src, int* dst, int* il, int* ol) {
+  const size_t A = (size_t)M * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < A; i += stride) {
+    const int m = int(i / C), c = int(i % C);
+    src[i] = m;
+    dst[i] = m + 1;
+    il[i] = c;
+    ol[i] = c;
+  }
+}
+
+int grid_for(size_t n, int block = 256, int cap = 4096) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return int(g);
+}
+
+} // namespace
+
+void launch_linear_forward(const LinArgs* d, int n, int tropical, int /*maxM*/, hipStream_t st) {
+  if (n <= 0) return;
+  if (tropical)
+    hipLaunchKernelGGL(linear_forward_kernel<true>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
+  else
+    hipLaunchKernelGGL(linear_forward_kernel<false>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
+  hipLaunchKernelGGL(linear_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d, n);
+}
+
+void launch_linear_backward(const LinArgs* d, int n, int tropical, int /*maxM*/, hipStream_t st) {
+  if (n <= 0) return;
+  if (tropical)
+    hipLaunchKernelGGL(linear_backward_kernel<true>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
+  else
+    hipLaunchKernelGGL(linear_backward_kernel<false>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
+}
+
+void launch_fill_i32(int* p, int v, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
+}
+void launch_fill_f32(float* p, float v, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
+}
+void launch_scalar_combine(const ScalarArgs* d, int n, float sa, float sb, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(scalar_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, n, sa, sb);
+}
+void launch_axpy_batch(const AxpyArgs* d, int n, int64_t maxn, int atomic, hipStream_t st) {
+  if (n <= 0 || maxn <= 0) return;
+  hipLaunchKernelGGL(axpy_batch_kernel, dim3(grid_for((size_t)maxn, 256, 1024), n), dim3(256), 0, st, d, atomic);
+}
+void launch_gather_scalars(const float* const* d_ptrs, float* out, int n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(gather_scalars_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_ptrs, out, n);
+}
+void launch_scatter_add(const ScatterArgs* d, int n, int maxn, hipStream_t st) {
+  if (n <= 0 || maxn <= 0) return;
+  hipLaunchKernelGGL(scatter_add_kernel, dim3(grid_for((size_t)maxn, 256, 256), n), dim3(256), 0, st, d);
+}
+void launch_linear_materialize(int M, int C, int* src, int* dst, int* il, int* ol, hipStream_t st) {
+  const size_t A = (size_t)M * C;
+  if (A) hipLaunchKernelGGL(linear_materialize_kernel, dim3(grid_for(A)), dim3(256), 0, st, M, C, src, dst, il, ol);
+}
+
+} // namespace gtnx

@@ -1,0 +1,1103 @@
+// ops.cpp -- batched graph functions + batch-level autograd (see ops.h)
+#include "ops.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace gtnx {
+
+namespace {
+std::atomic<uint64_t> g_seq{1};
+
+const float NEG_INF_F = -__builtin_huge_valf();
+
+// ---- the constant structure of a scalar result (functions.cpp:26-28, shortest.cpp:183-186)
+void init_scalar_structure(Graph& g) {
+  Structure& s = *g.s;
+  s.N = 2;
+  s.A = 1;
+  s.nflags = {NF_START, NF_ACCEPT};
+  s.start = {0};
+  s.accept = {1};
+  s.src = {0};
+  s.dst = {1};
+  s.il = {0};
+  s.ol = {0};
+  s.host_valid = true;
+}
+
+// result graph on the tape: calcGrad = any(inputs) (graph.cpp:16-27)
+Graph make_output(const std::shared_ptr<OpRecord>& op, int idx, std::vector<Graph> inputs) {
+  bool cg = false;
+  for (auto& i : inputs) cg |= i.calc_grad();
+  Graph out(cg);
+  if (cg) {
+    out.g->op = op;
+    out.g->op_idx = idx;
+    out.g->has_grad_fn = true;
+    out.g->inputs = std::move(inputs);
+  }
+  return out;
+}
+
+template <class T>
+const T& bcast(const std::vector<T>& v, size_t n, size_t i) {
+  if (v.size() == n) return v[i];
+  if (v.size() == 1) return v[0];
+  // parallel_map.h:85-88
+  throw_runtime("parallelMap getIdxOrBroadcast got invalid size or unbroadcastable vector");
+}
+
+void set_dev_weights(Graph& g, const DevMemP& owner, float* ptr, int64_t n) {
+  Weights& w = *g.w;
+  w.n = n;
+  w.dev_mem = owner;
+  w.dev = ptr;
+  w.dev_valid = true;
+  w.host_valid = false;
+  w.version++;
+}
+
+float* grad_dev_ptr(Graph& out) {
+  // the incoming delta of an output graph, resident on the device
+  Graph& gr = out.grad();
+  if (!gr.w->dev_valid || gr.w->host_escaped) {
+    std::vector<Weights*> v{gr.w.get()};
+    ensure_weights_device_batch(v);
+  }
+  return gr.w->dev;
+}
+} // namespace
+
+// ======================================================================
+// GradSink
+// ======================================================================
+void GradSink::flush() {
+  if (items.empty()) return;
+  Runtime& rt = Runtime::get();
+  std::vector<AxpyArgs> ax;
+  std::unordered_set<float*> seen;
+  bool dup = false;
+  int64_t maxn = 0;
+  for (auto& it : items) {
+    Graph& g = it.g;
+    if (!g.is_grad_available()) {
+      g.add_grad_device(it.owner, it.ptr, /*adopt=*/true);
+      continue;
+    }
+    Weights& gw = *g.g->grad->w;
+    if (!gw.dev_valid || gw.host_escaped) {
+      std::vector<Weights*> v{&gw};
+      ensure_weights_device_batch(v);
+    }
+    gw.host_valid = false;
+    gw.version++;
+    if (!seen.insert(gw.dev).second) dup = true;
+    ax.push_back({gw.dev, it.ptr, g.num_arcs(), 1.0f});
+    maxn = std::max<int64_t>(maxn, g.num_arcs());
+  }
+  if (!ax.empty()) {
+    DevMemP d = upload_vec(ax);
+    launch_axpy_batch(d->as<AxpyArgs>(), int(ax.size()), maxn, dup ? 1 : 0, rt.stream());
+  }
+  items.clear();
+}
+
+// ======================================================================
+// creations
+// ======================================================================
+Graph make_scalar_graph(float v, bool calc_grad) {
+  // creations.cpp:12-18 (labels are epsilon here, unlike op results)
+  Graph g(calc_grad);
+  init_scalar_structure(g);
+  g.s->il = {GTNX_EPSILON};
+  g.s->ol = {GTNX_EPSILON};
+  g.w->host = {v};
+  g.w->n = 1;
+  return g;
+}
+
+Graph make_linear_graph(int M, int N, bool calc_grad) {
+  if (M < 0 || N < 0) throw_invalid("[gtn::linearGraph] negative size");
+  Graph g(calc_grad);
+  Structure& s = *g.s;
+  s.kind = KIND_LINEAR;
+  s.M = M;
+  s.C = N;
+  s.N = int64_t(M) + 1;
+  s.A = int64_t(M) * N;
+  s.ilabel_sorted = s.olabel_sorted = true;  // creations.cpp:30-31
+  s.host_valid = true;                       // implicit
+  g.w->host.assign(size_t(s.A), 0.0f);
+  g.w->n = s.A;
+  return g;
+}
+
+std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev) {
+  Runtime& rt = Runtime::get();
+  std::vector<Graph> out;
+  out.reserve(B);
+  const int64_t A = int64_t(M) * N;
+  DevMemP arena = rt.alloc(sizeof(float) * size_t(A) * size_t(B > 0 ? B : 1));
+  if (dev && A && B) rt.d2d(arena->ptr, dev, sizeof(float) * size_t(A) * size_t(B));
+  for (int b = 0; b < B; ++b) {
+    Graph g(calc_grad);
+    Structure& s = *g.s;
+    s.kind = KIND_LINEAR;
+    s.M = M;
+    s.C = N;
+    s.N = int64_t(M) + 1;
+    s.A = A;
+    s.ilabel_sorted = s.olabel_sorted = true;
+    set_dev_weights(g, arena, arena->as<float>() + size_t(b) * size_t(A), A);
+    out.push_back(std::move(g));
+  }
+  return out;
+}
+
+// ======================================================================
+// scalar ops (functions.cpp:18-64)
+// ======================================================================
+namespace {
+struct ScalarOp : OpRecord {
+  ScalarKind kind;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    const int n = int(ms.size());
+    DevMemP buf = rt.alloc(sizeof(float) * 2 * size_t(n));
+    float* b0 = buf->as<float>();
+    float* b1 = b0 + n;
+    std::vector<ScalarArgs> a0, a1;
+    GradSink sink;
+    for (int m = 0; m < n; ++m) {
+      Graph& out = ms[m].out;
+      float* d = grad_dev_ptr(out);
+      a0.push_back({d, nullptr, b0 + m});
+      sink.add(out.g->inputs[0], buf, b0 + m);
+      if (kind != SK_NEGATE) {
+        // subtract only feeds input 1 when it wants a gradient (functions.cpp:55-57)
+        a1.push_back({d, nullptr, b1 + m});
+        sink.add(out.g->inputs[1], buf, b1 + m);
+      }
+    }
+    DevMemP d0 = upload_vec(a0);
+    launch_scalar_combine(d0->as<ScalarArgs>(), n, kind == SK_NEGATE ? -1.0f : 1.0f, 0.0f, rt.stream());
+    if (!a1.empty()) {
+      DevMemP d1 = upload_vec(a1);
+      launch_scalar_combine(d1->as<ScalarArgs>(), int(a1.size()), kind == SK_SUBTRACT ? -1.0f : 1.0f, 0.0f,
+                            rt.stream());
+    }
+    sink.flush();
+  }
+};
+} // namespace
+
+std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Graph>& b) {
+  static const char* msg1[] = {"[gtn::negate] input must have only one arc",
+                               "[gtn::add] inputs must have only one arc",
+                               "[gtn::subtract] inputs must have only one arc"};
+  const bool binary = k != SK_NEGATE;
+  const size_t n = binary ? std::max(a.size(), b.size()) : a.size();
+  std::vector<Graph> outs;
+  if (n == 0) return outs;
+  Runtime& rt = Runtime::get();
+  std::vector<Weights*> ws;
+  for (size_t i = 0; i < n; ++i) {
+    const Graph& x = bcast(a, n, i);
+    if (x.num_arcs() != 1) throw_logic(msg1[k]);
+    ws.push_back(x.w.get());
+    if (binary) {
+      const Graph& y = bcast(b, n, i);
+      if (y.num_arcs() != 1) throw_logic(msg1[k]);
+      ws.push_back(y.w.get());
+    }
+  }
+  ensure_weights_device_batch(ws);
+  auto op = std::make_shared<ScalarOp>();
+  op->kind = k;
+  op->seq = g_seq++;
+  DevMemP res = rt.alloc(sizeof(float) * n);
+  std::vector<ScalarArgs> args(n);
+  for (size_t i = 0; i < n; ++i) {
+    const Graph& x = bcast(a, n, i);
+    std::vector<Graph> ins{x};
+    args[i].a = x.w->dev;
+    args[i].b = nullptr;
+    if (binary) {
+      const Graph& y = bcast(b, n, i);
+      ins.push_back(y);
+      args[i].b = y.w->dev;
+    }
+    args[i].out = res->as<float>() + i;
+    Graph out = make_output(op, int(i), std::move(ins));
+    init_scalar_structure(out);
+    set_dev_weights(out, res, res->as<float>() + i, 1);
+    outs.push_back(std::move(out));
+  }
+  DevMemP d = upload_vec(args);
+  launch_scalar_combine(d->as<ScalarArgs>(), int(n), k == SK_NEGATE ? -1.0f : 1.0f,
+                        k == SK_SUBTRACT ? -1.0f : 1.0f, rt.stream());
+  return outs;
+}
+
+// ======================================================================
+// shortest distance: forwardScore / viterbiScore (functions.cpp:320-326)
+// ======================================================================
+namespace {
+
+// effective schedule view for this call: in_w only while it still matches the weights
+DSched sched_view(Graph& g) {
+  Schedule& sc = *g.s->sched;
+  DSched v = sc.view;
+  v.in_w = (sc.in_w && sc.in_w_of == g.w.get() && sc.in_w_version == g.w->version) ? sc.in_w : nullptr;
+  return v;
+}
+
+struct LinearSdOp : OpRecord {
+  bool tropical;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    const int n = int(ms.size());
+    std::vector<Weights*> ws;
+    size_t total = 0;
+    for (auto& m : ms) {
+      Graph& in = m.out.g->inputs[0];
+      ws.push_back(in.w.get());
+      total += size_t(in.num_arcs());
+    }
+    ensure_weights_device_batch(ws);
+    DevMemP grads = rt.alloc(sizeof(float) * (total ? total : 1));
+    std::vector<LinArgs> args(n);
+    GradSink sink;
+    size_t off = 0;
+    int maxM = 0;
+    double bytes = 0;
+    for (int i = 0; i < n; ++i) {
+      Graph& in = ms[i].out.g->inputs[0];
+      LinArgs& a = args[i];
+      a.w = in.w->dev;
+      a.M = in.s->M;
+      a.C = in.s->C;
+      a.out_score = nullptr;
+      a.partial = nullptr;
+      a.delta = grad_dev_ptr(ms[i].out);
+      a.grad = grads->as<float>() + off;
+      sink.add(in, grads, a.grad);
+      off += size_t(in.num_arcs());
+      maxM = std::max(maxM, a.M);
+      bytes += 8.0 * double(in.num_arcs());
+    }
+    DevMemP d = upload_vec(args);
+    {
+      GTNX_PROF("linear_forward_grad", bytes);
+      launch_linear_backward(d->as<LinArgs>(), n, tropical ? 1 : 0, maxM, rt.stream());
+    }
+    sink.flush();
+  }
+};
+
+struct SdOp : OpRecord {
+  int mode;
+  DevMemP arena;  // scores / argmax / results of the whole batch
+  struct Saved {
+    std::shared_ptr<Schedule> sched;
+    float* scores;
+    int* argmax;
+    SdResult* result;
+  };
+  std::vector<Saved> saved;
+
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    const int n = int(ms.size());
+    std::vector<Weights*> ws;
+    for (auto& m : ms) ws.push_back(m.out.g->inputs[0].w.get());
+    ensure_weights_device_batch(ws);
+    // one arena: arc grads (A) + node grads (P) per member
+    size_t bytes = 0;
+    std::vector<size_t> off_a(n), off_n(n);
+    bool need_zero = false;
+    for (int i = 0; i < n; ++i) {
+      Graph& in = ms[i].out.g->inputs[0];
+      const Saved& sv = saved[ms[i].idx];
+      off_a[i] = bytes;
+      bytes = align_up(bytes + 4 * size_t(in.num_arcs()), 256);
+      off_n[i] = bytes;
+      bytes = align_up(bytes + 4 * size_t(sv.sched->view.P), 256);
+      need_zero |= !sv.sched->all_written;
+    }
+    DevMemP g = need_zero ? rt.alloc_zero(bytes) : rt.alloc(bytes ? bytes : 1);
+    std::vector<SdArgs> args(n);
+    GradSink sink;
+    int64_t tot_out = 0, tot_p = 0;
+    double alg = 0;
+    for (int i = 0; i < n; ++i) {
+      Graph& in = ms[i].out.g->inputs[0];
+      const Saved& sv = saved[ms[i].idx];
+      SdArgs& a = args[i];
+      a.s = sv.sched->view;
+      a.s.in_w = nullptr;
+      a.w = in.w->dev;
+      a.scores = sv.scores;
+      a.argmax = sv.argmax;
+      a.result = sv.result;
+      a.out_score = nullptr;
+      a.delta = grad_dev_ptr(ms[i].out);
+      a.arc_grad = g->as<float>(off_a[i]);
+      a.node_grad = g->as<float>(off_n[i]);
+      sink.add(in, g, a.arc_grad);
+      tot_out += sv.sched->n_out;
+      tot_p += sv.sched->view.P;
+      alg += 12.0 * double(in.num_arcs()) + 12.0 * double(sv.sched->view.P);
+    }
+    DevMemP d = upload_vec(args);
+    {
+      GTNX_PROF(mode == SD_LOG ? "forward_score_grad" : "viterbi_score_grad", alg);
+      launch_sd_backward(d->as<SdArgs>(), n, mode, int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream());
+    }
+    sink.flush();
+  }
+};
+
+} // namespace
+
+std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+  const size_t n = gs.size();
+  std::vector<Graph> outs(n, Graph(false));
+  if (n == 0) return outs;
+  Runtime& rt = Runtime::get();
+  std::vector<int> lin, exp;
+  for (size_t i = 0; i < n; ++i) (gs[i].s->kind == KIND_LINEAR ? lin : exp).push_back(int(i));
+  std::vector<Weights*> ws;
+  for (auto& g : gs) ws.push_back(g.w.get());
+  ensure_weights_device_batch(ws);
+
+  // ---- linear-chain members: streaming row reductions
+  if (!lin.empty()) {
+    const int m = int(lin.size());
+    auto op = std::make_shared<LinearSdOp>();
+    op->tropical = tropical;
+    op->seq = g_seq++;
+    DevMemP res = rt.alloc(sizeof(float) * size_t(m) * 9);
+    float* scal = res->as<float>();
+    float* partial = scal + m;
+    std::vector<LinArgs> args(m);
+    int maxM = 0;
+    double bytes = 0;
+    for (int k = 0; k < m; ++k) {
+      Graph& g = gs[lin[k]];
+      LinArgs& a = args[k];
+      a.w = g.w->dev;
+      a.M = g.s->M;
+      a.C = g.s->C;
+      a.out_score = scal + k;
+      a.partial = partial + size_t(k) * 8;
+      a.delta = nullptr;
+      a.grad = nullptr;
+      maxM = std::max(maxM, a.M);
+      bytes += 4.0 * double(g.num_arcs());
+      Graph out = make_output(op, k, {g});
+      init_scalar_structure(out);
+      set_dev_weights(out, res, scal + k, 1);
+      outs[lin[k]] = std::move(out);
+    }
+    DevMemP d = upload_vec(args);
+    GTNX_PROF("linear_forward", bytes);
+    launch_linear_forward(d->as<LinArgs>(), m, tropical ? 1 : 0, maxM, rt.stream());
+  }
+
+  // ---- general DAGs: level-scheduled persistent kernel
+  if (!exp.empty()) {
+    const int m = int(exp.size());
+    std::vector<Structure*> ss;
+    for (int i : exp) ss.push_back(gs[i].s.get());
+    ensure_schedule_batch(ss, false);
+    for (int i : exp)
+      if (gs[i].s->sched->error) throw_invalid(kCycleMsg);  // shortest.cpp:149-152
+    auto op = std::make_shared<SdOp>();
+    op->mode = tropical ? SD_TROPICAL : SD_LOG;
+    op->seq = g_seq++;
+    size_t bytes = 0;
+    std::vector<size_t> off_s(m), off_a(m), off_r(m);
+    for (int k = 0; k < m; ++k) {
+      const int P = gs[exp[k]].s->sched->view.P;
+      off_s[k] = bytes;
+      bytes = align_up(bytes + 4 * size_t(P), 256);
+      off_a[k] = bytes;
+      if (tropical) bytes = align_up(bytes + 4 * size_t(P), 256);
+      off_r[k] = bytes;
+      bytes += 256;
+    }
+    size_t off_out = bytes;
+    bytes += 4 * size_t(m);
+    DevMemP arena = rt.alloc(bytes);
+    op->arena = arena;
+    op->saved.resize(m);
+    std::vector<SdArgs> args(m);
+    int64_t tot_in = 0, tot_p = 0;
+    int maxw = 0;
+    double alg = 0;
+    for (int k = 0; k < m; ++k) {
+      Graph& g = gs[exp[k]];
+      Schedule& sc = *g.s->sched;
+      SdArgs& a = args[k];
+      a.s = sched_view(g);
+      a.w = g.w->dev;
+      a.scores = arena->as<float>(off_s[k]);
+      a.argmax = tropical ? arena->as<int>(off_a[k]) : nullptr;
+      a.result = arena->as<SdResult>(off_r[k]);
+      a.out_score = arena->as<float>(off_out) + k;
+      a.delta = nullptr;
+      a.node_grad = nullptr;
+      a.arc_grad = nullptr;
+      op->saved[k] = {g.s->sched, a.scores, a.argmax, a.result};
+      tot_in += sc.n_in;
+      tot_p += sc.view.P;
+      maxw = std::max(maxw, sc.max_level_width);
+      alg += 8.0 * double(g.num_arcs()) + 8.0 * double(g.num_nodes());
+      Graph out = make_output(op, k, {g});
+      init_scalar_structure(out);
+      set_dev_weights(out, arena, a.out_score, 1);
+      outs[exp[k]] = std::move(out);
+    }
+    DevMemP d = upload_vec(args);
+    GTNX_PROF(tropical ? "viterbi_score" : "forward_score", alg);
+    launch_sd_forward(d->as<SdArgs>(), m, op->mode, maxw, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
+  }
+  return outs;
+}
+
+// ======================================================================
+// viterbiPath (functions.cpp:328-330, shortest.cpp:190-272)
+// ======================================================================
+namespace {
+struct PathOp : OpRecord {
+  // per member: the path's arc ids in the order the reference's gradFunc indexes
+  // them (last-arc-first, shortest.cpp:240-245 & 262-268)
+  std::vector<std::vector<int>> arcs_rev;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    const int n = int(ms.size());
+    size_t tot_idx = 0, tot_grad = 0;
+    for (auto& m : ms) {
+      tot_idx += arcs_rev[m.idx].size();
+      tot_grad += size_t(m.out.g->inputs[0].num_arcs());
+    }
+    std::vector<int> idx_host;
+    idx_host.reserve(tot_idx);
+    DevMemP grads = rt.alloc_zero(sizeof(float) * (tot_grad ? tot_grad : 1));
+    std::vector<ScatterArgs> args(n);
+    std::vector<size_t> ioff(n);
+    for (int i = 0; i < n; ++i) {
+      ioff[i] = idx_host.size();
+      const auto& v = arcs_rev[ms[i].idx];
+      idx_host.insert(idx_host.end(), v.begin(), v.end());
+    }
+    DevMemP didx = upload_vec(idx_host);
+    GradSink sink;
+    size_t goff = 0;
+    int maxn = 0;
+    for (int i = 0; i < n; ++i) {
+      Graph& in = ms[i].out.g->inputs[0];
+      ScatterArgs& a = args[i];
+      a.idx = didx->as<int>() + ioff[i];
+      a.n = int(arcs_rev[ms[i].idx].size());
+      a.delta = a.n ? grad_dev_ptr(ms[i].out) : nullptr;
+      a.grad = grads->as<float>() + goff;
+      sink.add(in, grads, a.grad);
+      goff += size_t(in.num_arcs());
+      maxn = std::max(maxn, a.n);
+    }
+    DevMemP d = upload_vec(args);
+    launch_scatter_add(d->as<ScatterArgs>(), n, maxn, rt.stream());
+    sink.flush();
+  }
+};
+} // namespace
+
+std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
+  const size_t n = gs.size();
+  std::vector<Graph> outs;
+  if (n == 0) return outs;
+  Runtime& rt = Runtime::get();
+  for (auto& g : gs) g.s->materialize();  // TODO(linear fast path): row arg-max needs no graph
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  for (auto& g : gs) {
+    ss.push_back(g.s.get());
+    ws.push_back(g.w.get());
+  }
+  ensure_device_batch(ss);
+  ensure_weights_device_batch(ws);
+  ensure_schedule_batch(ss, true);
+  for (auto& g : gs)
+    if (g.s->sched->error) throw_invalid(kCycleMsg);  // shortest.cpp:229-232
+  const int m = int(n);
+  size_t bytes = 0;
+  std::vector<size_t> off_s(m), off_a(m), off_r(m), off_p(m);
+  std::vector<int> cap(m);
+  for (int k = 0; k < m; ++k) {
+    const DSched& v = gs[k].s->sched->view;
+    cap[k] = std::max(v.L, 1);
+    off_s[k] = bytes;
+    bytes = align_up(bytes + 4 * size_t(v.P), 256);
+    off_a[k] = bytes;
+    bytes = align_up(bytes + 4 * size_t(v.P), 256);
+    off_r[k] = bytes;
+    bytes += 256;
+    off_p[k] = bytes;
+    bytes = align_up(bytes + 16 * size_t(cap[k]) + 8, 256);
+  }
+  DevMemP arena = rt.alloc(bytes);
+  std::vector<SdArgs> args(m);
+  std::vector<PathArgs> pargs(m);
+  int64_t tot_in = 0, tot_p = 0;
+  for (int k = 0; k < m; ++k) {
+    Graph& g = gs[k];
+    SdArgs& a = args[k];
+    a.s = sched_view(g);
+    a.w = g.w->dev;
+    a.scores = arena->as<float>(off_s[k]);
+    a.argmax = arena->as<int>(off_a[k]);
+    a.result = arena->as<SdResult>(off_r[k]);
+    a.out_score = nullptr;
+    a.delta = nullptr;
+    a.node_grad = nullptr;
+    a.arc_grad = nullptr;
+    PathArgs& p = pargs[k];
+    p.s = a.s;
+    p.g = device_view(g);
+    p.argmax = a.argmax;
+    p.result = a.result;
+    char* pb = arena->as<char>(off_p[k]);
+    p.path_len = reinterpret_cast<int*>(pb);
+    p.path_arcs = reinterpret_cast<int*>(pb + 8);
+    p.path_il = p.path_arcs + cap[k];
+    p.path_ol = p.path_il + cap[k];
+    p.path_w = reinterpret_cast<float*>(p.path_ol + cap[k]);
+    p.cap = cap[k];
+    tot_in += g.s->sched->n_in;
+    tot_p += a.s.P;
+  }
+  DevMemP d = upload_vec(args);
+  DevMemP dp = upload_vec(pargs);
+  {
+    GTNX_PROF("viterbi_path", 0.0);
+    launch_sd_forward(d->as<SdArgs>(), m, SD_PATH, 0, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
+    launch_path_chase(dp->as<PathArgs>(), m, rt.stream());
+  }
+  // the path is at most L arcs: bring it to the host and build the chain graph there
+  std::vector<char> host(bytes);
+  rt.d2h_sync(host.data(), arena->ptr, bytes);
+  auto op = std::make_shared<PathOp>();
+  op->seq = g_seq++;
+  op->arcs_rev.resize(m);
+  for (int k = 0; k < m; ++k) {
+    const char* pb = host.data() + off_p[k];
+    const int* pl = reinterpret_cast<const int*>(pb);
+    const int len = pl[0], has_node = pl[1];
+    const int* arcs = reinterpret_cast<const int*>(pb + 8);
+    const int* il = arcs + cap[k];
+    const int* ol = il + cap[k];
+    const float* w = reinterpret_cast<const float*>(ol + cap[k]);
+    Graph out = make_output(op, k, {gs[k]});
+    // shortest.cpp:248-260
+    if (has_node) out.add_node(true, len == 0);
+    for (int i = 0; i < len; ++i) {
+      out.add_node(false, i == len - 1);
+      out.add_arc(i, i + 1, il[i], ol[i], w[i]);
+    }
+    op->arcs_rev[k].assign(arcs, arcs + len);
+    std::reverse(op->arcs_rev[k].begin(), op->arcs_rev[k].end());
+    outs.push_back(std::move(out));
+  }
+  return outs;
+}
+
+// ======================================================================
+// compose / intersect (functions.cpp:225-251, compose.cpp:377-522)
+// ======================================================================
+namespace {
+
+struct ComposeOp : OpRecord {
+  DevMemP arena;
+  struct Saved {
+    const int* gi1;
+    const int* gi2;
+    int A;
+  };
+  std::vector<Saved> saved;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    const int n = int(ms.size());
+    size_t bytes = 0;
+    std::vector<size_t> o1(n), o2(n);
+    for (int i = 0; i < n; ++i) {
+      auto& ins = ms[i].out.g->inputs;
+      o1[i] = bytes;
+      if (ins[0].calc_grad()) bytes = align_up(bytes + 4 * size_t(ins[0].num_arcs()), 256);
+      o2[i] = bytes;
+      if (ins[1].calc_grad()) bytes = align_up(bytes + 4 * size_t(ins[1].num_arcs()), 256);
+    }
+    DevMemP g = rt.alloc_zero(bytes ? bytes : 1);
+    std::vector<ComposeGradArgs> args(n);
+    GradSink sink;
+    int maxA = 0;
+    double alg = 0;
+    for (int i = 0; i < n; ++i) {
+      auto& ins = ms[i].out.g->inputs;
+      const Saved& sv = saved[ms[i].idx];
+      ComposeGradArgs& a = args[i];
+      a.A = sv.A;
+      a.gi1 = sv.gi1;
+      a.gi2 = sv.gi2;
+      a.delta = sv.A ? grad_dev_ptr(ms[i].out) : nullptr;
+      a.A1 = int(ins[0].num_arcs());
+      a.A2 = int(ins[1].num_arcs());
+      a.grad1 = ins[0].calc_grad() ? g->as<float>(o1[i]) : nullptr;
+      a.grad2 = ins[1].calc_grad() ? g->as<float>(o2[i]) : nullptr;
+      if (a.grad1) sink.add(ins[0], g, a.grad1);
+      if (a.grad2) sink.add(ins[1], g, a.grad2);
+      maxA = std::max(maxA, sv.A);
+      alg += 12.0 * sv.A + 4.0 * (a.A1 + a.A2);
+    }
+    DevMemP d = upload_vec(args);
+    {
+      GTNX_PROF("compose_grad", alg);
+      launch_compose_grad(d->as<ComposeGradArgs>(), n, maxA, rt.stream());
+    }
+    sink.flush();
+  }
+};
+
+// label histogram of the labels compose matches on (olabel of g1 / ilabel of g2)
+struct LabelHist {
+  bool linear = false;
+  int M = 0, C = 0;
+  std::unordered_map<int, int64_t> cnt;
+  int64_t eps = 0;
+};
+void label_hist(Structure& s, bool use_olabel, LabelHist& h) {
+  if (s.kind == KIND_LINEAR) {
+    h.linear = true;
+    h.M = s.M;
+    h.C = s.C;
+    return;
+  }
+  s.ensure_host();
+  const std::vector<int>& lab = use_olabel ? s.ol : s.il;
+  for (int l : lab) {
+    if (l == GTNX_EPSILON)
+      h.eps++;
+    else
+      h.cnt[l]++;
+  }
+}
+int64_t match_bound(const LabelHist& a, const LabelHist& b) {
+  // sum over non-eps labels of cnt_a[l] * cnt_b[l]
+  int64_t t = 0;
+  if (a.linear && b.linear) return int64_t(std::min(a.C, b.C)) * a.M * b.M;
+  const LabelHist& e = a.linear ? b : a;  // explicit side (or a)
+  const LabelHist& o = a.linear ? a : b;
+  for (auto& kv : e.cnt) {
+    int64_t c2;
+    if (o.linear)
+      c2 = (kv.first >= 0 && kv.first < o.C) ? o.M : 0;
+    else {
+      auto it = o.cnt.find(kv.first);
+      c2 = it == o.cnt.end() ? 0 : it->second;
+    }
+    t += kv.second * c2;
+  }
+  return t;
+}
+} // namespace
+
+std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect) {
+  const size_t n = std::max(av.size(), bv.size());
+  std::vector<Graph> outs;
+  if (n == 0) return outs;
+  Runtime& rt = Runtime::get();
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  for (size_t i = 0; i < n; ++i) {
+    Graph& a = const_cast<Graph&>(bcast(av, n, i));
+    Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+    ss.push_back(a.s.get());
+    ss.push_back(b.s.get());
+    ws.push_back(a.w.get());
+    ws.push_back(b.w.get());
+  }
+  ensure_device_batch(ss);
+  ensure_weights_device_batch(ws);
+
+  // ---- capacities from label histograms (exact upper bound on matches)
+  std::unordered_map<Structure*, LabelHist> h1, h2;
+  struct Cap {
+    int64_t N1, N2, Ncap, Acap, pairs;
+  };
+  std::vector<Cap> caps(n);
+  for (size_t i = 0; i < n; ++i) {
+    Structure& s1 = *bcast(av, n, i).s;
+    Structure& s2 = *bcast(bv, n, i).s;
+    if (!h1.count(&s1)) label_hist(s1, true, h1[&s1]);
+    if (!h2.count(&s2)) label_hist(s2, false, h2[&s2]);
+    const LabelHist& x = h1[&s1];
+    const LabelHist& y = h2[&s2];
+    Cap& c = caps[i];
+    c.N1 = s1.N;
+    c.N2 = s2.N;
+    c.pairs = c.N1 * c.N2;
+    c.Acap = match_bound(x, y) + x.eps * c.N2 + y.eps * c.N1;
+    const int64_t starts = (s1.kind == KIND_LINEAR ? 1 : int64_t(s1.start.size())) *
+                           (s2.kind == KIND_LINEAR ? 1 : int64_t(s2.start.size()));
+    c.Ncap = std::min<int64_t>(c.pairs, c.Acap + starts);
+    if (c.pairs > (int64_t(1) << 30) || c.Acap > (int64_t(1) << 30))
+      throw_runtime("[gtn::compose] composed graph too large for 32-bit indices");
+  }
+
+  // ---- arenas.  Scratch is laid out by kind (all `state` tables contiguous,
+  // all in-degree cursors contiguous) so ONE fill and ONE memset initialise the
+  // whole batch; result headers (sizes) are contiguous so ONE copy returns them.
+  struct Off {
+    size_t state, queue, pair_of, in_cursor;
+    size_t src, dst, il, ol, w, gi1, gi2, nf, out_off, level_off, in_off, in_list, in_src, in_w, sl, al;
+  };
+  std::vector<Off> offs(n);
+  size_t st_b = 0, cu_b = 0, sc_b = 0, rb = 0;
+  auto add = [](size_t& tot, size_t bytes) {
+    size_t o = tot;
+    tot = align_up(tot + bytes, 256);
+    return o;
+  };
+  const size_t hdr_out = add(rb, sizeof(ComposeOut) * n);
+  const size_t hdr_cnt = add(rb, 8 * n);
+  int64_t maxA = 0, maxN = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const Cap& c = caps[i];
+    Off& o = offs[i];
+    const size_t A = size_t(c.Acap), N = size_t(c.Ncap), P = size_t(c.pairs);
+    o.state = add(st_b, 4 * P);
+    o.in_cursor = add(cu_b, 4 * N);
+    o.queue = add(sc_b, 4 * P);
+    o.pair_of = add(sc_b, 4 * N);
+    o.src = add(rb, 4 * A);
+    o.dst = add(rb, 4 * A);
+    o.il = add(rb, 4 * A);
+    o.ol = add(rb, 4 * A);
+    o.w = add(rb, 4 * A);
+    o.gi1 = add(rb, 4 * A);
+    o.gi2 = add(rb, 4 * A);
+    o.nf = add(rb, N);
+    o.out_off = add(rb, 4 * (N + 1));
+    o.level_off = add(rb, 4 * (N + 2));
+    o.in_off = add(rb, 4 * (N + 1));
+    o.in_list = add(rb, 4 * A);
+    o.in_src = add(rb, 4 * A);
+    o.in_w = add(rb, 4 * A);
+    o.sl = add(rb, 4 * N);
+    o.al = add(rb, 4 * N);
+    maxA = std::max(maxA, c.Acap);
+    maxN = std::max(maxN, c.Ncap);
+  }
+  DevMemP st_mem = rt.alloc(st_b ? st_b : 1);
+  DevMemP cu_mem = rt.alloc(cu_b ? cu_b : 1);
+  DevMemP sc_mem = rt.alloc(sc_b ? sc_b : 1);
+  DevMemP res = rt.alloc(rb ? rb : 1);
+  launch_fill_i32(st_mem->as<int>(), INT32_MIN, st_b / 4, rt.stream());
+  HIP_CHECK(hipMemsetAsync(cu_mem->ptr, 0, cu_b ? cu_b : 1, rt.stream()));
+  std::vector<ComposeArgs> args(n);
+  for (size_t i = 0; i < n; ++i) {
+    const Cap& c = caps[i];
+    const Off& o = offs[i];
+    Graph& a = const_cast<Graph&>(bcast(av, n, i));
+    Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+    ComposeArgs& x = args[i];
+    x.g1 = device_view(a);
+    x.g2 = device_view(b);
+    // matcher dispatch, functions.cpp:225-251
+    const bool s1 = intersect ? (a.s->ilabel_sorted || a.s->olabel_sorted) : a.s->olabel_sorted;
+    const bool s2 = intersect ? (b.s->ilabel_sorted || b.s->olabel_sorted) : b.s->ilabel_sorted;
+    x.matcher = (s1 && s2) ? MATCH_DOUBLY : (s1 ? MATCH_SINGLY_G1 : (s2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
+    x.Ncap = int(c.Ncap);
+    x.Acap = int(c.Acap);
+    char* rp = res->as<char>();
+    x.state = st_mem->as<int>(o.state);
+    x.in_cursor = cu_mem->as<int>(o.in_cursor);
+    x.queue = sc_mem->as<int>(o.queue);
+    x.pair_of = sc_mem->as<int>(o.pair_of);
+    x.src = reinterpret_cast<int*>(rp + o.src);
+    x.dst = reinterpret_cast<int*>(rp + o.dst);
+    x.il = reinterpret_cast<int*>(rp + o.il);
+    x.ol = reinterpret_cast<int*>(rp + o.ol);
+    x.w = reinterpret_cast<float*>(rp + o.w);
+    x.gi1 = reinterpret_cast<int*>(rp + o.gi1);
+    x.gi2 = reinterpret_cast<int*>(rp + o.gi2);
+    x.nflags = reinterpret_cast<uint8_t*>(rp + o.nf);
+    x.out_off = reinterpret_cast<int*>(rp + o.out_off);
+    x.level_off = reinterpret_cast<int*>(rp + o.level_off);
+    x.in_off = reinterpret_cast<int*>(rp + o.in_off);
+    x.in_list = reinterpret_cast<int*>(rp + o.in_list);
+    x.in_src = reinterpret_cast<int*>(rp + o.in_src);
+    x.in_w = reinterpret_cast<float*>(rp + o.in_w);
+    x.start_list = reinterpret_cast<int*>(rp + o.sl);
+    x.accept_list = reinterpret_cast<int*>(rp + o.al);
+    x.counts = reinterpret_cast<int*>(rp + hdr_cnt) + 2 * i;
+    x.out = reinterpret_cast<ComposeOut*>(rp + hdr_out) + i;
+  }
+  DevMemP dargs = upload_vec(args);
+  DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(n), int(maxN)));
+  {
+    double alg = 0;
+    for (size_t i = 0; i < n; ++i) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
+    GTNX_PROF(intersect ? "intersect" : "compose", alg);
+    launch_compose(dargs->as<ComposeArgs>(), int(n), rt.stream());
+  }
+  {
+    GTNX_PROF("compose_transpose", 0.0);
+    launch_compose_transpose(dargs->as<ComposeArgs>(), int(n), int(maxA), int(maxN), tscratch->ptr, rt.stream());
+  }
+  // ---- sizes back to the host: the contiguous header block, one copy, one sync
+  std::vector<char> hdr(hdr_cnt + 8 * n);
+  rt.d2h_sync(hdr.data(), res->ptr, hdr.size());
+  const ComposeOut* res_out = reinterpret_cast<const ComposeOut*>(hdr.data() + hdr_out);
+  const int* res_counts = reinterpret_cast<const int*>(hdr.data() + hdr_cnt);
+
+  auto op = std::make_shared<ComposeOp>();
+  op->seq = g_seq++;
+  op->arena = res;
+  op->saved.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    const ComposeOut& co = res_out[i];
+    if (co.overflow) throw_runtime("[gtn::compose] internal capacity bound exceeded");
+    const ComposeArgs& x = args[i];
+    Graph& a = const_cast<Graph&>(bcast(av, n, i));
+    Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+    Graph out = make_output(op, int(i), {a, b});
+    Structure& s = *out.s;
+    s.kind = KIND_EXPLICIT;
+    s.N = co.N;
+    s.A = co.A;
+    s.host_valid = false;
+    s.dev_valid = true;
+    s.dev_mem = res;
+    DGraph& v = s.dview;
+    std::memset(&v, 0, sizeof(v));
+    v.kind = KIND_EXPLICIT;
+    v.N = co.N;
+    v.A = co.A;
+    v.n_start = res_counts[2 * i];
+    v.n_accept = res_counts[2 * i + 1];
+    v.flags = 0;
+    v.src = x.src;
+    v.dst = x.dst;
+    v.il = x.il;
+    v.ol = x.ol;
+    v.nflags = x.nflags;
+    v.start_list = x.start_list;
+    v.accept_list = x.accept_list;
+    v.out_off = x.out_off;
+    v.out_list = nullptr;  // arcs are grouped by source in id order
+    v.in_off = x.in_off;
+    v.in_list = x.in_list;
+    set_dev_weights(out, res, x.w, co.A);
+    if (co.layered) {
+      auto sc = std::make_shared<Schedule>();
+      sc->mem = res;
+      sc->n_in = co.A;
+      sc->n_out = co.A;
+      sc->all_written = true;
+      sc->has_rank = true;  // rank == arc id for src-sorted arcs
+      sc->max_level_width = 0;
+      DSched& d = sc->view;
+      d.P = co.N;
+      d.L = co.L;
+      d.n_accept = v.n_accept;
+      d.flags = SCHED_TIE_BY_ARC | SCHED_OUT_IDENTITY;
+      d.level_off = x.level_off;
+      d.row_off = x.in_off;
+      d.in_srcpos = x.in_src;
+      d.in_arc = x.in_list;
+      d.in_rank = nullptr;
+      d.in_w = nullptr;
+      d.pflags = x.nflags;
+      d.acc_pos = x.accept_list;
+      d.out_off = x.out_off;
+      d.out_dstpos = x.dst;
+      d.out_arc = nullptr;
+      sc->in_w = x.in_w;
+      sc->in_w_of = out.w.get();
+      sc->in_w_version = out.w->version;
+      s.sched = sc;
+    }
+    op->saved[i] = {x.gi1, x.gi2, co.A};
+    outs.push_back(std::move(out));
+  }
+  return outs;
+}
+
+// ======================================================================
+// user-defined ops (Graph(GradFunc, inputs), graph.h:76-78)
+// ======================================================================
+namespace {
+struct UserOp : OpRecord {
+  gtnx_grad_fn fn;
+  void* ctx;
+  void (*ctx_free)(void*);
+  ~UserOp() override {
+    if (ctx_free) ctx_free(ctx);
+  }
+  void backward(std::vector<Member>& ms) override {
+    for (auto& m : ms) {
+      std::vector<gtnx_graph_t> hs;
+      for (auto& in : m.out.g->inputs) hs.push_back(reinterpret_cast<gtnx_graph_t>(&in));
+      gtnx_status_t st = fn(ctx, hs.data(), int(hs.size()), reinterpret_cast<gtnx_graph_t>(&m.out.grad()));
+      if (st != GTNX_OK) throw Error(st, std::string("user gradFunc failed: ") + gtnx_last_error());
+    }
+  }
+};
+} // namespace
+
+Graph make_user_op(std::vector<Graph>& inputs, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*)) {
+  auto op = std::make_shared<UserOp>();
+  op->fn = fn;
+  op->ctx = ctx;
+  op->ctx_free = ctx_free;
+  op->seq = g_seq++;
+  Graph out = make_output(op, 0, inputs);
+  if (!fn) out.g->has_grad_fn = false;
+  return out;
+}
+
+// ======================================================================
+// backward (autograd.cpp:17-67)
+// ======================================================================
+void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
+  Runtime& rt = Runtime::get();
+  // ---- seed (autograd.cpp:57-67)
+  if (grad) {
+    for (auto& r : roots) {
+      if (!r.calc_grad()) continue;
+      if (grad->num_arcs() != r.num_arcs()) throw_logic("[Graph::addGrad] Invalid grad size.");
+      std::vector<Weights*> v{grad->w.get()};
+      ensure_weights_device_batch(v);
+      r.add_grad_device(grad->w->dev_mem, grad->w->dev, /*adopt=*/false);
+    }
+  } else {
+    size_t tot = 0;
+    for (auto& r : roots) tot += size_t(r.num_arcs());
+    DevMemP ones = rt.alloc(sizeof(float) * (tot ? tot : 1));
+    launch_fill_f32(ones->as<float>(), 1.0f, tot, rt.stream());
+    GradSink sink;
+    size_t off = 0;
+    for (auto& r : roots) {
+      sink.add(r, ones, ones->as<float>() + off);
+      off += size_t(r.num_arcs());
+    }
+    sink.flush();
+  }
+  // ---- collect the tape: reachable graphs grouped by producing record
+  std::unordered_set<GradState*> seen;
+  std::map<uint64_t, std::pair<std::shared_ptr<OpRecord>, std::vector<Member>>, std::greater<uint64_t>> tape;
+  std::vector<Graph> stack(roots.begin(), roots.end());
+  while (!stack.empty()) {
+    Graph g = stack.back();
+    stack.pop_back();
+    if (!seen.insert(g.g.get()).second) continue;
+    for (auto& in : g.g->inputs) stack.push_back(in);
+    if (g.g->has_grad_fn) {
+      if (!g.g->op || g.g->inputs.empty())  // autograd.cpp:42-45
+        throw_invalid("[autograd::backward] Cannot Backward twice without retaining the graph.");
+      auto& slot = tape[g.g->op->seq];
+      slot.first = g.g->op;
+      slot.second.push_back({g.g->op_idx, g});
+    }
+  }
+  // ---- reverse sweep: creation order is a topological order
+  for (auto& kv : tape) {
+    auto& members = kv.second.second;
+    std::sort(members.begin(), members.end(), [](const Member& a, const Member& b) { return a.idx < b.idx; });
+    for (auto& m : members) (void)m.out.grad();  // throws "Gradient not calculated yet." like autograd.cpp:46
+    kv.second.first->backward(members);
+    if (!retain) {
+      for (auto& m : members) {
+        m.out.g->inputs.clear();  // autograd.cpp:47-50
+        m.out.g->op.reset();      // drop the saved forward state with the tape
+      }
+    }
+  }
+}
+
+// ======================================================================
+// batched item() / grad gathering
+// ======================================================================
+void items_host(std::vector<Graph>& gs, float* out) {
+  const size_t n = gs.size();
+  if (n == 0) return;
+  std::vector<const float*> ptrs;
+  std::vector<size_t> which;
+  for (size_t i = 0; i < n; ++i) {
+    if (gs[i].num_arcs() != 1)
+      throw_invalid("[Graph::item] Cannot convert Graph with more than 1 arc to a scalar.");
+    Weights& w = *gs[i].w;
+    if (w.host_valid) {
+      out[i] = w.host[0];
+    } else {
+      ptrs.push_back(w.dev);
+      which.push_back(i);
+    }
+  }
+  if (ptrs.empty()) return;
+  Runtime& rt = Runtime::get();
+  DevMemP dp = upload_vec(ptrs);
+  DevMemP dense = rt.alloc(sizeof(float) * ptrs.size());
+  launch_gather_scalars(dp->as<const float*>(), dense->as<float>(), int(ptrs.size()), rt.stream());
+  std::vector<float> host(ptrs.size());
+  rt.d2h_sync(host.data(), dense->ptr, sizeof(float) * ptrs.size());
+  for (size_t k = 0; k < which.size(); ++k) {
+    out[which[k]] = host[k];
+    Weights& w = *gs[which[k]].w;
+    w.host.assign(1, host[k]);
+    w.host_valid = true;
+  }
+}
+
+void items_device(std::vector<Graph>& gs, void* dev_out) {
+  const size_t n = gs.size();
+  if (n == 0) return;
+  std::vector<Weights*> ws;
+  for (auto& g : gs) {
+    if (g.num_arcs() != 1)
+      throw_invalid("[Graph::item] Cannot convert Graph with more than 1 arc to a scalar.");
+    ws.push_back(g.w.get());
+  }
+  ensure_weights_device_batch(ws);
+  std::vector<const float*> ptrs;
+  for (auto& g : gs) ptrs.push_back(g.w->dev);
+  Runtime& rt = Runtime::get();
+  DevMemP dp = upload_vec(ptrs);
+  launch_gather_scalars(dp->as<const float*>(), static_cast<float*>(dev_out), int(n), rt.stream());
+}
+
+void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets) {
+  const size_t n = gs.size();
+  if (n == 0) return;
+  Runtime& rt = Runtime::get();
+  std::vector<Weights*> ws;
+  for (auto& g : gs) ws.push_back(g.grad().w.get());
+  ensure_weights_device_batch(ws);
+  std::vector<AxpyArgs> ax(n);
+  int64_t maxn = 0;
+  for (size_t i = 0; i < n; ++i) {
+    ax[i] = {static_cast<float*>(dev_out) + offsets[i], gs[i].g->grad->w->dev, gs[i].num_arcs(), 1.0f};
+    maxn = std::max(maxn, gs[i].num_arcs());
+  }
+  DevMemP d = upload_vec(ax);
+  launch_axpy_batch(d->as<AxpyArgs>(), int(n), maxn, /*copy mode*/ 2, rt.stream());
+}
+
+} // namespace gtnx

@@ -1,0 +1,79 @@
+// ops.h -- batched graph functions and the batch-level autograd tape.
+//
+// Every function takes vectors of graphs and runs ONE launch per kernel family
+// for the whole vector (a single graph is a batch of one).  This replaces the
+// reference's per-utterance parallelMap over CPU threads
+// (gtn/parallel/parallel_map.h:153-188) with batch-of-graphs kernels.
+//
+// Autograd (gtn/autograd.cpp:17-67): each batched call creates one OpRecord with
+// a global sequence number; outputs remember (record, index).  backward() walks
+// the inputs() DAG from the roots, groups reachable outputs by record and runs
+// the records in decreasing sequence order -- creation order is a topological
+// order, so this is the reference's reverse tape sweep with one batched kernel
+// per record instead of one gradFunc call per graph.
+#pragma once
+
+#include <cstring>
+#include <vector>
+
+#include "graph.h"
+
+namespace gtnx {
+
+struct Member {
+  int idx;    // index inside the producing batch
+  Graph out;  // the output graph (its g->grad is the incoming delta)
+};
+
+struct OpRecord {
+  uint64_t seq = 0;
+  virtual void backward(std::vector<Member>& members) = 0;
+  virtual ~OpRecord() {}
+};
+
+// accumulates addGrad calls of one backward step and flushes them with at most
+// one batched accumulate launch (first gradient of a graph is adopted in place)
+struct GradSink {
+  struct Item {
+    Graph g;
+    DevMemP owner;
+    float* ptr;
+  };
+  std::vector<Item> items;
+  void add(const Graph& g, const DevMemP& owner, float* ptr) {
+    if (g.calc_grad()) items.push_back({g, owner, ptr});
+  }
+  void flush();
+};
+
+enum ScalarKind { SK_NEGATE = 0, SK_ADD = 1, SK_SUBTRACT = 2 };
+
+std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Graph>& b);
+std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical);
+std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs);
+std::vector<Graph> op_compose(std::vector<Graph>& a, std::vector<Graph>& b, bool intersect);
+void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain);
+
+Graph make_scalar_graph(float v, bool calc_grad);
+Graph make_linear_graph(int M, int N, bool calc_grad);
+std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev);
+Graph make_user_op(std::vector<Graph>& inputs, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*));
+
+void items_host(std::vector<Graph>& gs, float* out);
+void items_device(std::vector<Graph>& gs, void* dev_out);
+void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets);
+
+template <class T>
+DevMemP upload_vec(const std::vector<T>& v) {
+  Runtime& rt = Runtime::get();
+  size_t bytes = sizeof(T) * v.size();
+  DevMemP d = rt.alloc(bytes ? bytes : 1);
+  if (bytes) {
+    PinnedMemP p = rt.alloc_pinned(bytes);
+    std::memcpy(p->ptr, v.data(), bytes);
+    rt.h2d(d->ptr, p->ptr, bytes);
+  }
+  return d;
+}
+
+} // namespace gtnx

@@ -1,0 +1,265 @@
+// runtime.cpp -- see runtime.h
+#include "runtime.h"
+
+#include <cstring>
+
+namespace gtnx {
+
+namespace {
+Runtime* g_rt = nullptr;
+std::mutex g_rt_mu;
+
+size_t round_size(size_t b) {
+  if (b < 512) return 512;
+  if (b < (1u << 20)) return align_up(b, 512);
+  return align_up(b, size_t(2) << 20);  // 2 MiB granules for arenas
+}
+} // namespace
+
+DevMem::~DevMem() {
+  if (ptr && g_rt) g_rt->release_dev(ptr, bytes);
+}
+PinnedMem::~PinnedMem() {
+  if (ptr && g_rt) g_rt->release_pinned(ptr, bytes);
+}
+
+int Runtime::device_count() {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+bool Runtime::initialized() { return g_rt != nullptr; }
+
+Runtime& Runtime::get() {
+  std::lock_guard<std::mutex> lk(g_rt_mu);
+  if (!g_rt) {
+    if (device_count() <= 0)
+      throw_device(
+          "gtn_amd: no HIP device visible -- this engine runs its graph functions on an "
+          "MI355X (gfx950) only and has no CPU fallback");
+    g_rt = new Runtime();
+  }
+  return *g_rt;
+}
+
+Runtime::Runtime() {
+  HIP_CHECK(hipGetDevice(&device_));
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device_));
+  cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+  stream_ = own_stream_;
+}
+
+void Runtime::set_device(int d) {
+  sync();
+  HIP_CHECK(hipSetDevice(d));
+  if (d != device_) {
+    // pools belong to the previous device: drop them
+    empty_cache();
+    device_ = d;
+    HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
+    stream_ = own_stream_;
+  }
+}
+
+void Runtime::set_stream(hipStream_t s) {
+  sync();  // everything queued so far completes before buffers are reused on another stream
+  stream_ = s ? s : own_stream_;
+}
+
+void Runtime::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+
+DevMemP Runtime::alloc(size_t bytes) {
+  size_t sz = round_size(bytes ? bytes : 1);
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = free_dev_.lower_bound(sz);
+    // accept a cached block up to 1.5x the request (big arenas) / exact class (small)
+    if (it != free_dev_.end() && it->first <= sz + sz / 2) {
+      p = it->second;
+      sz = it->first;
+      free_dev_.erase(it);
+    }
+  }
+  if (!p) {
+    hipError_t e = hipMalloc(&p, sz);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      empty_cache();
+      HIP_CHECK(hipMalloc(&p, sz));
+    }
+    std::lock_guard<std::mutex> lk(mu_);
+    reserved_ += sz;
+  }
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    in_use_ += sz;
+  }
+  auto m = std::make_shared<DevMem>();
+  m->ptr = p;
+  m->bytes = sz;
+  return m;
+}
+
+DevMemP Runtime::alloc_zero(size_t bytes) {
+  DevMemP m = alloc(bytes);
+  HIP_CHECK(hipMemsetAsync(m->ptr, 0, bytes ? bytes : 1, stream_));
+  return m;
+}
+
+void Runtime::release_dev(void* p, size_t bytes) {
+  // single in-order stream: a block freed on the host after its last kernel was
+  // ENQUEUED can be handed to a later launch on the same stream safely.
+  std::lock_guard<std::mutex> lk(mu_);
+  free_dev_.emplace(bytes, p);
+  in_use_ -= bytes;
+}
+
+PinnedMemP Runtime::alloc_pinned(size_t bytes) {
+  size_t sz = round_size(bytes ? bytes : 1);
+  void* p = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    // recycle blocks whose release event has completed
+    for (size_t i = 0; i < pending_pinned_.size();) {
+      if (hipEventQuery(pending_pinned_[i].ev) == hipSuccess) {
+        free_pinned_.emplace(pending_pinned_[i].bytes, pending_pinned_[i].ptr);
+        ev_pool_.push_back(pending_pinned_[i].ev);
+        pending_pinned_[i] = pending_pinned_.back();
+        pending_pinned_.pop_back();
+      } else {
+        (void)hipGetLastError();
+        ++i;
+      }
+    }
+    auto it = free_pinned_.lower_bound(sz);
+    if (it != free_pinned_.end() && it->first <= sz * 2) {
+      p = it->second;
+      sz = it->first;
+      free_pinned_.erase(it);
+    }
+  }
+  if (!p) HIP_CHECK(hipHostMalloc(&p, sz, hipHostMallocDefault));
+  auto m = std::make_shared<PinnedMem>();
+  m->ptr = p;
+  m->bytes = sz;
+  return m;
+}
+
+void Runtime::release_pinned(void* p, size_t bytes) {
+  std::lock_guard<std::mutex> lk(mu_);
+  hipEvent_t ev;
+  if (!ev_pool_.empty()) {
+    ev = ev_pool_.back();
+    ev_pool_.pop_back();
+  } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream_);
+    free_pinned_.emplace(bytes, p);
+    return;
+  }
+  (void)hipEventRecord(ev, stream_);
+  pending_pinned_.push_back({p, bytes, ev});
+}
+
+void Runtime::empty_cache() {
+  (void)hipStreamSynchronize(stream_);
+  std::lock_guard<std::mutex> lk(mu_);
+  for (auto& kv : free_dev_) {
+    (void)hipFree(kv.second);
+    reserved_ -= kv.first;
+  }
+  free_dev_.clear();
+  for (auto& kv : free_pinned_) (void)hipHostFree(kv.second);
+  free_pinned_.clear();
+}
+
+void Runtime::stats(uint64_t* reserved, uint64_t* in_use) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (reserved) *reserved = reserved_;
+  if (in_use) *in_use = in_use_;
+}
+
+void Runtime::h2d(void* dst, const void* src, size_t bytes) {
+  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
+}
+void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
+  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
+  sync();
+}
+void Runtime::d2d(void* dst, const void* src, size_t bytes) {
+  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_));
+}
+
+// ---------------------------------------------------------------- profiler
+void Runtime::prof_enable(bool on) {
+  if (!on) collect_prof();
+  prof_on_ = on;
+}
+void Runtime::prof_reset() {
+  collect_prof();
+  prof_.clear();
+}
+
+Runtime::Scope::Scope(Runtime* r, const char* name, double bytes) : rt(r), idx(-1) {
+  if (!rt->prof_on_) return;
+  ProfRec rec;
+  rec.name = name;
+  rec.bytes = bytes;
+  auto get_ev = [&]() {
+    hipEvent_t e;
+    HIP_CHECK(hipEventCreate(&e));
+    return e;
+  };
+  rec.a = get_ev();
+  rec.b = get_ev();
+  HIP_CHECK(hipEventRecord(rec.a, rt->stream_));
+  idx = (int)rt->prof_recs_.size();
+  rt->prof_recs_.push_back(rec);
+}
+Runtime::Scope::~Scope() {
+  if (idx >= 0) (void)hipEventRecord(rt->prof_recs_[idx].b, rt->stream_);
+}
+
+void Runtime::collect_prof() {
+  if (prof_recs_.empty()) return;
+  (void)hipStreamSynchronize(stream_);
+  for (auto& r : prof_recs_) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& e = prof_[r.name];
+      e.total_ms += ms;
+      e.launches += 1;
+      e.bytes += r.bytes;
+    } else {
+      (void)hipGetLastError();
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  prof_recs_.clear();
+}
+
+ProfEntry Runtime::prof_get(const std::string& name) {
+  collect_prof();
+  auto it = prof_.find(name);
+  return it == prof_.end() ? ProfEntry{} : it->second;
+}
+
+std::string Runtime::prof_names() {
+  collect_prof();
+  std::string s;
+  for (auto& kv : prof_) {
+    if (!s.empty()) s += "\n";
+    s += kv.first;
+  }
+  return s;
+}
+
+} // namespace gtnx

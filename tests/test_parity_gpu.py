@@ -1,0 +1,295 @@
+"""Parity of the HIP engine (through the C ABI) against
+ (1) the known answers of the reference's own tests,
+ (2) tests/golden/golden.json (outputs of the unmodified reference), and
+ (3) the pinned C oracle on seeded inputs.
+Integer results (node ids, labels, paths, one-hot grads) must match bit-exact;
+log-semiring floats within 1e-4 relative (BASELINE.json north_star)."""
+import math
+
+import numpy as np
+import pytest
+
+import graphgen as gg
+from oracle_lib import OGraph, ctc_loss
+
+pytestmark = pytest.mark.gpu
+INF = float("inf")
+RTOL = 1e-4
+
+
+def G(gtn, start, accept, arcs):
+    N = max([a[0] for a in arcs] + [a[1] for a in arcs] + start + accept + [-1]) + 1
+    g = gtn.Graph()
+    for n in range(N):
+        g.add_node(n in start, n in accept)
+    for a in arcs:
+        g.add_arc(*a)
+    return g
+
+
+COMPLEX = ([0, 1], [3, 4], [(0, 1, 0, 0, 2), (0, 2, 1, 1, 1), (1, 2, 0, 0, 2), (2, 3, 0, 0, 1),
+                            (2, 3, 1, 1, 1), (1, 4, 0, 0, 2), (2, 4, 1, 1, 3), (3, 4, 0, 0, 2)])
+SIMPLE = ([0], [2], [(0, 1, 0, 0, 1), (0, 1, 1, 1, 2), (0, 1, 2, 2, 3), (1, 2, 0, 0, 1),
+                     (1, 2, 1, 1, 2), (1, 2, 2, 2, 3)])
+
+
+def close(a, b, rtol=RTOL, atol=1e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return a.shape == b.shape and np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+# ---- test/functions_test.cpp:22-36, 231-453 ---------------------------------------------
+def test_scalar_ops(gtn):
+    g1, g2 = gtn.scalar_graph(3.0), gtn.scalar_graph(4.0)
+    assert gtn.negate(g1).item() == -3.0
+    assert gtn.add(g1, g2).item() == 7.0
+    assert gtn.subtract(g2, g1).item() == 1.0
+    with pytest.raises(RuntimeError):
+        gtn.negate(G(gtn, *SIMPLE))
+
+
+def test_forward_known_answers(gtn):
+    fs = lambda g: gtn.forward_score(g).item()
+    assert fs(gtn.Graph()) == -INF
+    for arcs in ([(0, 0, 1, 1, 0)],):
+        with pytest.raises(ValueError):
+            gtn.forward_score(G(gtn, [0], [0], arcs))
+    for arcs in ([(0, 1, 0, 0, 0), (1, 2, 0, 0, 0), (1, 1, 0, 0, 0)],
+                 [(0, 1, 0, 0, 0), (1, 2, 0, 0, 0), (2, 2, 0, 0, 0)],
+                 [(0, 1, 0, 0, 0), (1, 2, 0, 0, 0), (2, 0, 0, 0, 0)],
+                 [(0, 2, 0, 0, 0), (1, 2, 0, 0, 0)]):
+        with pytest.raises(ValueError, match="cycle"):
+            gtn.forward_score(G(gtn, [0], [2], arcs))
+    assert fs(G(gtn, [0], [1], [(0, 1, 0, 0, -INF), (0, 1, 1, 1, -INF)])) == -INF
+    assert fs(G(gtn, [0], [1], [(0, 1, 0, 0, INF), (0, 1, 1, 1, 0)])) == INF
+    assert fs(G(gtn, [0], [0], [])) == 0.0
+    assert fs(G(gtn, *SIMPLE)) == pytest.approx(6.8152, rel=1e-4)
+    e = math.log(math.exp(1) + math.exp(-5 + 2) + math.exp(2))
+    assert fs(G(gtn, [0, 1], [2], [(0, 1, 0, 0, -5), (0, 2, 0, 0, 1), (1, 2, 0, 0, 2)])) == pytest.approx(e, rel=1e-5)
+    e = math.log(2 * math.exp(2) + math.exp(4))
+    assert fs(G(gtn, [0], [1, 2], [(0, 1, 0, 0, 2), (0, 2, 0, 0, 2), (1, 2, 0, 0, 2)])) == pytest.approx(e, rel=1e-5)
+    assert fs(G(gtn, [0], [2], [(0, 1, 0, 0, 2), (0, 2, 0, 0, 2)])) == 2.0
+    assert fs(G(gtn, *COMPLEX)) == pytest.approx(8.36931, rel=1e-5)
+
+
+def test_viterbi_known_answers(gtn):
+    vs = lambda g: gtn.viterbi_score(g).item()
+    assert vs(gtn.Graph()) == -INF
+    assert vs(G(gtn, *SIMPLE)) == 6.0
+    assert vs(G(gtn, [0, 1], [2], [(0, 1, 0, 0, -5), (0, 2, 0, 0, 1), (1, 2, 0, 0, 2)])) == 2.0
+    assert vs(G(gtn, [0], [1, 2], [(0, 1, 0, 0, 2), (0, 2, 0, 0, 2), (1, 2, 0, 0, 2)])) == 4.0
+    assert vs(G(gtn, *COMPLEX)) == 7.0
+    p = gtn.viterbi_path(G(gtn, *SIMPLE))
+    assert p.labels_to_list() == [2, 2] and p.weights_to_list() == [3.0, 3.0]
+    assert gtn.viterbi_path(gtn.Graph()).num_nodes() == 0
+    single = G(gtn, [0], [0], [])
+    assert gtn.equal(gtn.viterbi_path(single), single)
+
+
+# ---- test/autograd_test.cpp:270-517 -------------------------------------------------------
+def test_grad_known_answers(gtn):
+    def fgrad(g, fn=None):
+        gtn.backward((fn or gtn.forward_score)(g))
+        return g.grad().weights_to_numpy()
+    g = G(gtn, [0, 1], [2], [(0, 1, 0, 0, -5), (0, 2, 0, 0, 1), (1, 2, 0, 0, 2)])
+    den = 1 / (math.exp(-3) + math.exp(1) + math.exp(2))
+    assert close(fgrad(g), [den * math.exp(-3), den * math.exp(1), den * (math.exp(-3) + math.exp(2))], 1e-5)
+    g = G(gtn, [0], [1, 2], [(0, 1, 0, 0, 2), (0, 2, 0, 0, 2), (1, 2, 0, 0, 2)])
+    den = 1 / (2 * math.exp(2) + math.exp(4))
+    assert close(fgrad(g), [den * (math.exp(2) + math.exp(4)), den * math.exp(2), den * math.exp(4)], 1e-5)
+    assert close(fgrad(G(gtn, [0], [2], [(0, 1, 0, 0, 2), (0, 2, 0, 0, 2)])), [0, 1])
+    assert np.isnan(fgrad(G(gtn, [0], [1], [(0, 1, 0, 0, -INF), (0, 1, 1, 1, -INF)]))).all()
+    assert close(fgrad(G(gtn, [0], [1], [(0, 1, 0, 0, -INF), (0, 1, 1, 1, 1.0)])), [0, 1])
+    assert np.isnan(fgrad(G(gtn, [0], [1], [(0, 1, 0, 0, INF), (0, 1, 1, 1, INF)]))).all()
+    assert np.isnan(fgrad(G(gtn, [0], [1], [(0, 1, 0, 0, INF), (0, 1, 1, 1, 1.0)]))).all()
+    vs = gtn.viterbi_score
+    assert fgrad(G(gtn, *SIMPLE), vs).tolist() == [0, 0, 1, 0, 0, 1]
+    assert fgrad(G(gtn, [0, 1], [2], [(0, 1, 0, 0, -5), (0, 2, 0, 0, 1), (1, 2, 0, 0, 2)]), vs).tolist() == [0, 0, 1]
+    assert fgrad(G(gtn, [0], [1, 2], [(0, 1, 0, 0, 2), (0, 2, 0, 0, 2), (1, 2, 0, 0, 2)]), vs).tolist() == [1, 0, 1]
+    assert fgrad(G(gtn, *COMPLEX), vs).tolist() in ([1, 0, 1, 0, 0, 0, 1, 0], [1, 0, 1, 0, 1, 0, 0, 1])
+    g = G(gtn, [0, 1], [3, 4], [(0, 1, 0, 0, 2), (0, 2, 1, 1, 1), (1, 2, 0, 0, 2), (2, 3, 0, 0, 1),
+                                (2, 3, 1, 1, 3), (1, 4, 0, 0, 2), (2, 4, 1, 1, 3), (3, 4, 0, 0, 2)])
+    assert fgrad(g, gtn.viterbi_path).tolist() == [1, 0, 1, 0, 1, 0, 0, 1]   # :482-496
+    # backward twice without retain (autograd.cpp:42-45)
+    g = G(gtn, *SIMPLE)
+    s = gtn.forward_score(g)
+    gtn.backward(s)
+    with pytest.raises(ValueError, match="Backward twice"):
+        gtn.backward(s)
+    s = gtn.forward_score(g)
+    g.zero_grad()
+    gtn.backward(s, True)
+    gtn.backward(s, True)
+    assert close(g.grad().weights_to_numpy(), 2 * fgrad(G(gtn, *SIMPLE)), 1e-5)
+
+
+# ---- test/criterion_test.cpp:56-180 -------------------------------------------------------------
+def test_ctc_criterion_known_answers(gtn):
+    def ctc_graph(target, blank):
+        d = gg.ctc_target_graph(target, blank)
+        d["sort"] = None
+        return gg.to_api(gtn, d)
+    with np.errstate(divide="ignore"):
+        em = np.log(np.array([1.0, 0.0, 0.0, 1.0, 1.0, 0.0], np.float32))
+    e = gtn.linear_graph(3, 2)
+    e.set_weights(em)
+    assert gtn.forward_score(gtn.compose(ctc_graph([0, 0], 1), e)).item() == 0.0
+    assert gtn.forward_score(e).item() == 0.0
+    T, N = 3, 4
+    e = gtn.linear_graph(T, N)
+    e.set_weights(np.zeros(T * N, np.float32))
+    loss = gtn.subtract(gtn.forward_score(gtn.compose(ctc_graph([1, 2], N - 1), e)), gtn.forward_score(e))
+    assert -loss.item() == pytest.approx(-math.log(0.25 ** 3 * 5), rel=1e-5)
+    em = np.array([0.633766, 0.221185, 0.0917319, 0.0129757, 0.0142857, 0.0260553,
+                   0.111121, 0.588392, 0.278779, 0.0055756, 0.00569609, 0.010436,
+                   0.0357786, 0.633813, 0.321418, 0.00249248, 0.00272882, 0.0037688,
+                   0.0663296, 0.643849, 0.280111, 0.00283995, 0.0035545, 0.00331533,
+                   0.458235, 0.396634, 0.123377, 0.00648837, 0.00903441, 0.00623107], np.float32)
+    expected_grad = np.array([-0.366234, 0.221185, 0.0917319, 0.0129757, 0.0142857, 0.0260553,
+                              0.111121, -0.411608, 0.278779, 0.0055756, 0.00569609, 0.010436,
+                              0.0357786, 0.633813, -0.678582, 0.00249248, 0.00272882, 0.0037688,
+                              0.0663296, -0.356151, 0.280111, 0.00283995, 0.0035545, 0.00331533,
+                              -0.541765, 0.396634, 0.123377, 0.00648837, 0.00903441, 0.00623107], np.float32)
+    e = gtn.linear_graph(5, 6)
+    e.set_weights(np.log(em))
+    z = gtn.forward_score(e)
+    assert abs(z.item()) < 1e-5
+    loss = gtn.subtract(z, gtn.forward_score(gtn.compose(ctc_graph([0, 1, 2, 1, 0], 5), e)))
+    assert loss.item() == pytest.approx(3.34211, rel=1e-5)
+    gtn.backward(loss)
+    np.testing.assert_allclose(e.grad().weights_to_numpy(), expected_grad, atol=1e-5)
+
+
+# ---- golden fixtures ----------------------------------------------------------------------
+def test_golden_shortest(gtn, golden):
+    for c in golden["shortest"]:
+        d = c["graph"]
+        for key, fn in (("forward", gtn.forward_score), ("viterbi", gtn.viterbi_score)):
+            g = gg.to_api(gtn, d)
+            if c[key] == "error":
+                with pytest.raises(ValueError):
+                    fn(g)
+                continue
+            s = fn(g)
+            assert close(s.item(), c[key]), (c["name"], key, s.item(), c[key])
+            if key + "_grad" in c and g.num_arcs():
+                gtn.backward(s)
+                gr = g.grad().weights_to_numpy()
+                if key == "viterbi":
+                    assert gr.tolist() == c[key + "_grad"], (c["name"], key)
+                else:
+                    assert close(gr, c[key + "_grad"], RTOL, 1e-6), (c["name"], key)
+        g = gg.to_api(gtn, d)
+        if c["path"] == "error":
+            with pytest.raises(ValueError):
+                gtn.viterbi_path(g)
+        else:
+            p = gtn.viterbi_path(g)
+            got = gg.from_api(p)
+            for k in ("start", "accept", "src", "dst", "il", "ol", "w"):
+                assert got[k] == c["path"][k], (c["name"], k)
+            if "path_grad" in c and g.num_arcs():
+                gtn.backward(p)
+                assert g.grad().weights_to_list() == c["path_grad"], c["name"]
+
+
+def sorted_arcs(d):
+    return sorted(zip(d["src"], d["dst"], d["il"], d["ol"], d["w"]))
+
+
+def test_golden_compose(gtn, golden):
+    n_exact = 0
+    for c in golden["compose"]:
+        fn = gtn.compose if c["mode"] == "compose" else gtn.intersect
+        g1, g2 = gg.to_api(gtn, c["g1"]), gg.to_api(gtn, c["g2"])
+        out = fn(g1, g2)
+        d, e = gg.from_api(out), c["out"]
+        assert d["start"] == e["start"] and d["accept"] == e["accept"], c["name"]
+        assert sorted_arcs(d) == sorted_arcs(e), c["name"]          # == gtn::equal
+        same = (d["src"], d["dst"], d["il"], d["ol"]) == (e["src"], e["dst"], e["il"], e["ol"])
+        n_exact += same
+        if "grad1" in c and same:
+            gtn.backward(out)
+            assert g1.grad().weights_to_list() == c["grad1"], c["name"]
+            assert g2.grad().weights_to_list() == c["grad2"], c["name"]
+        g1, g2 = gg.to_api(gtn, c["g1"]), gg.to_api(gtn, c["g2"])
+        if c["forward"] == "error":
+            with pytest.raises(ValueError):
+                gtn.forward_score(fn(g1, g2))
+        else:
+            s = gtn.forward_score(fn(g1, g2))
+            assert close(s.item(), c["forward"]), c["name"]
+            if "fgrad1" in c:
+                gtn.backward(s)
+                assert close(g1.grad().weights_to_numpy(), c["fgrad1"], RTOL, 1e-6), c["name"]
+                assert close(g2.grad().weights_to_numpy(), c["fgrad2"], RTOL, 1e-6), c["name"]
+    # arc ORDER may differ from the reference only where std::sort's unspecified
+    # order among equal labels shows through
+    assert n_exact >= 0.9 * len(golden["compose"])
+
+
+def test_golden_ctc(gtn, golden):
+    for c in golden["ctc"]:
+        T, C = c["T"], c["C"]
+        em = np.array(c["emissions"], np.float32)
+        ctc = gg.to_api(gtn, gg.ctc_target_graph(c["target"]))
+        e = gtn.linear_graph(T, C)
+        e.set_weights(em)
+        comp = gtn.intersect(ctc, e)
+        assert (comp.num_nodes(), comp.num_arcs()) == (c["comp_nodes"], c["comp_arcs"])
+        loss = gtn.subtract(gtn.forward_score(e), gtn.forward_score(comp))
+        assert loss.item() == pytest.approx(c["loss"], rel=RTOL), c["name"]
+        gtn.backward(loss)
+        np.testing.assert_allclose(e.grad().weights_to_numpy(), c["grad"], rtol=RTOL, atol=1e-6)
+        vit = gtn.viterbi_path(gtn.intersect(ctc, e))
+        assert vit.labels_to_list() == c["viterbi_labels"], c["name"]
+
+
+# ---- batched hot path vs the oracle on seeded inputs -----------------------------------------
+@pytest.mark.parametrize("B,T,C,U", [(1, 100, 28, 20), (6, 150, 32, 20), (4, 300, 64, 30)])
+def test_batched_ctc_vs_oracle(gtn, B, T, C, U):
+    import torch
+    em, tg = gg.ctc_inputs(99 + B, B, T, C, U)
+    dev = torch.from_numpy(em).cuda()
+    ems = gtn.linear_graph_n(B, T, C, dev)
+    ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    comp = gtn.intersect(ctcs, ems)
+    loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))
+    gtn.backward(loss)
+    got = gtn.items(loss)
+    out = torch.empty(B, T, C, device="cuda")
+    gtn.grads_to_device(ems, out, [b * T * C for b in range(B)])
+    gtn.synchronize()
+    grads = out.cpu().numpy()
+    for b in range(B):
+        want, wgrad = ctc_loss(em[b], tg[b])
+        assert got[b] == pytest.approx(want, rel=RTOL)
+        # float32 scores reach ~T*8 here, so one ulp of the running score is
+        # ~T*1e-6 relative in every gradient (both in the reference and here)
+        np.testing.assert_allclose(grads[b], wgrad, rtol=5e-4, atol=2e-6)
+        oc = OGraph.from_dict(gg.ctc_target_graph(tg[b].tolist())).compose(OGraph.linear(T, C, em[b]), "intersect")
+        assert (comp[b].num_nodes(), comp[b].num_arcs()) == (oc.N, oc.A)
+    # composed structure identical to the oracle's (node ids and arc order)
+    d, e = gg.from_api(comp[0]), oc if B == 1 else OGraph.from_dict(gg.ctc_target_graph(tg[0].tolist())).compose(OGraph.linear(T, C, em[0]), "intersect")
+    e = e.to_dict()
+    for k in ("start", "accept", "src", "dst", "il", "ol"):
+        assert d[k] == e[k], k
+    np.testing.assert_allclose(d["w"], e["w"], rtol=1e-6)
+
+
+def test_linear_forward_c2(gtn):
+    """BASELINE config 2: forwardScore on a batch of linear-chain emission graphs"""
+    import torch
+    B, T, C = 256, 150, 32
+    rng = np.random.default_rng(5)
+    em = (rng.random((B, T, C), dtype=np.float32) * 10 - 5)
+    ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+    got = gtn.items(gtn.forward_score(ems))
+    vit = gtn.items(gtn.viterbi_score(ems))
+    x = em.astype(np.float64)
+    m = x.max(-1, keepdims=True)
+    want = (m[..., 0] + np.log(np.exp(x - m).sum(-1))).sum(-1)
+    np.testing.assert_allclose(got, want, rtol=1e-5)
+    np.testing.assert_allclose(vit, x.max(-1).sum(-1), rtol=1e-5)
+    for b in (0, 17):
+        assert got[b] == pytest.approx(OGraph.linear(T, C, em[b]).shortest_distance(), rel=1e-5)

@@ -507,9 +507,9 @@ void build_host_schedule(Structure& s, HostSched& h, bool need_rank) {
   size_t head = 0;
   for (int n : s.start)
     if (deg[n] == 0) order.push_back(n);
+  const size_t n_seed = order.size();
   while (head < order.size()) {
     int n = order[head];
-    pos[n] = int(head);
     ++head;
     for (int k = s.out_off[n]; k < s.out_off[n + 1]; ++k) {
       int d = s.dst[s.out_list[k]];
@@ -517,9 +517,30 @@ void build_host_schedule(Structure& s, HostSched& h, bool need_rank) {
       if (--deg[d] == 0) order.push_back(d);
     }
   }
+  // shortest.cpp:148-152: an accept node the queue never reached is an error only
+  // if it still waits on a predecessor; a non-start accept node WITHOUT in-arcs is
+  // never queued but keeps its zero-initialised score (shortest.cpp:89) and takes
+  // part in the final reduction with 0.0.  Schedule those at level 0, flagged.
+  std::vector<uint8_t> scheduled(N, 0);
+  for (int n : order) scheduled[n] = 1;
+  std::vector<int> orphans;
+  for (int n : s.accept) {
+    if (scheduled[n]) continue;
+    if (deg[n] > 0)
+      h.error = true;
+    else
+      orphans.push_back(n);
+  }
+  std::vector<uint8_t> orphan_flag(N, 0);
+  if (!orphans.empty()) {
+    for (int n : orphans) {
+      orphan_flag[n] = 1;
+      level[n] = 0;
+    }
+    order.insert(order.begin() + n_seed, orphans.begin(), orphans.end());
+  }
+  for (size_t p = 0; p < order.size(); ++p) pos[order[p]] = int(p);
   h.P = int(order.size());
-  for (int n : s.accept)
-    if (pos[n] < 0) h.error = true;  // shortest.cpp:149-152
   // levels (FIFO order is level-sorted)
   h.level_off.clear();
   int cur = -1;
@@ -557,7 +578,7 @@ void build_host_schedule(Structure& s, HostSched& h, bool need_rank) {
   if (need_rank) out_index_of_arc.assign(size_t(s.A), 0);
   for (int p = 0; p < h.P; ++p) {
     int n = order[p];
-    h.pflags[p] = s.nflags[n];
+    h.pflags[p] = uint8_t(s.nflags[n] | (orphan_flag[n] ? NF_ORPHAN : 0));
     h.row_off[p + 1] = h.row_off[p] + (s.in_off[n + 1] - s.in_off[n]);
   }
   h.in_srcpos.resize(h.row_off[h.P]);

@@ -10,7 +10,7 @@
 namespace gtnx {
 
 enum : int { KIND_EXPLICIT = 0, KIND_LINEAR = 1 };
-enum : int { NF_START = 1, NF_ACCEPT = 2 };
+enum : int { NF_START = 1, NF_ACCEPT = 2, NF_ORPHAN = 4 /* unqueued accept node: score 0.0 */ };
 
 // ---------------------------------------------------------------------------
 // Structure-of-arrays view of one graph in HBM (replaces gtn/graph.h:58-73's

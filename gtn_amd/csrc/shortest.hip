@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_kernel(const SdArgs* __rest
         // tropical: the max; path mode keeps -inf for unreachable nodes (:196)
         out = (cnt == 0) ? NEG_INF : mx;
       }
+      if (MODE != SD_PATH && (s.pflags[p] & NF_ORPHAN)) out = 0.0f;  // shortest.cpp:89 zero-init
       if (sub == 0) {
         scores[p] = out;
         if (MODE != SD_LOG) a.argmax[p] = best;

@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- CTC forward+backward losses/sec (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic utterances,
+everything benchmarks/ctc.cpp:150-165 does per utterance: build the CTC target
+graph, wrap the [T, C] emissions as a linear graph, intersect, two forwardScores,
+subtract, backward (emission gradients populated).  Emissions are resident in HBM
+when the timed region starts (the PyTorch use-case); inputs follow the reference
+generator (uniform [-5, 5) emissions, uniform targets in [1, C-1], blank 0),
+seeded.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver under torch.distributed.run, one rank per GPU;
+utterances are independent, so each rank owns B utterances (weak scaling) and the
+only collective is an all_gather of the B scalar losses over RCCL.
+
+Prints ONE JSON line (see the contract in the task statement), including
+  roofline     -- forwardScore kernel: algorithmic bytes (8A + 8N per graph) /
+                  hipEvent-timed launch duration vs the 8 TB/s HBM3E peak
+  cpu_baseline -- the unmodified reference's parallelMap CTC pattern on all host
+                  cores (oracle/_ref) on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def ctc_arrays(target, blank=0):
+    """arc/node arrays of benchmarks/ctc.cpp:40-58's ctcGraph, vectorised"""
+    U = len(target)
+    L = 2 * U + 1
+    l = np.arange(L)
+    idx = (l - 1) // 2
+    label = np.where(l % 2 == 1, target[np.clip(idx, 0, U - 1)], blank).astype(np.int32)
+    prev = target[np.clip(idx - 1, 0, U - 1)]
+    has_step = l > 0
+    has_skip = (l % 2 == 1) & (l > 1) & (label != prev)
+    n_arcs = 1 + has_step.astype(np.int64) + has_skip.astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(n_arcs)])
+    A = int(off[-1])
+    src = np.empty(A, np.int32)
+    dst = np.empty(A, np.int32)
+    lab = np.empty(A, np.int32)
+    src[off[:-1]] = l
+    dst[off[:-1]] = l
+    lab[off[:-1]] = label
+    s = off[:-1][has_step] + 1
+    src[s] = l[has_step] - 1
+    dst[s] = l[has_step]
+    lab[s] = label[has_step]
+    k = off[:-1][has_skip] + 2
+    src[k] = l[has_skip] - 2
+    dst[k] = l[has_skip]
+    lab[k] = label[has_skip]
+    start = (l == 0).astype(np.uint8)
+    accept = ((l == L - 1) | (l == L - 2)).astype(np.uint8)
+    return start, accept, src, dst, lab
+
+
+def build_ctc_graphs(gtn, targets):
+    out = []
+    for t in targets:
+        st, ac, s, d, lab = ctc_arrays(t)
+        g = gtn.Graph()
+        g.add_nodes(st, ac)
+        g.add_arcs(s, d, lab)
+        g.arc_sort()
+        out.append(g)
+    return out
+
+
+def cpu_baseline(B, T, Cn, U, seed):
+    """reference CPU path timed on this host (rank 0, N=1 only), bounded sample"""
+    import graphgen as gg
+    cores = os.cpu_count() or 1
+    path = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
+    if os.path.exists(path):
+        lib = C.CDLL(path)
+        lib.ref_ctc_batch.restype = C.c_double
+        lib.ref_ctc_batch.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]
+        nb = int(min(B, max(cores * 2, 8)))
+        em, tg = gg.ctc_inputs(seed, nb, T, Cn, U)
+        losses = np.zeros(nb, np.float32)
+        thr = C.c_int()
+        t0 = time.time()
+        sec = lib.ref_ctc_batch(em.ctypes.data, tg.ctypes.data, nb, T, Cn, U, 0, 1, losses.ctypes.data, None,
+                                C.byref(thr))
+        iters = 1
+        # aim at ~10-20 s of CPU work in total
+        extra = int(min(20, max(0, 12.0 / max(sec, 1e-3) - 1)))
+        if extra > 0:
+            sec = lib.ref_ctc_batch(em.ctypes.data, tg.ctypes.data, nb, T, Cn, U, 0, extra, losses.ctypes.data,
+                                    None, C.byref(thr))
+            iters = extra
+        return {"value": nb / sec, "unit": "losses/s", "cores": int(thr.value), "kind": "reference",
+                "sample": f"{iters} iteration(s) of parallelMap(fwd)+parallelMap(bwd) over {nb} utterances "
+                          f"(T={T}, C={Cn}, U={U}), {time.time() - t0:.1f}s wall; host has {cores} logical cores"}
+    from oracle_lib import ctc_loss
+    em, tg = gg.ctc_inputs(seed, 4, T, Cn, U)
+    t0 = time.time()
+    for b in range(4):
+        ctc_loss(em[b], tg[b])
+    sec = time.time() - t0
+    return {"value": 4 / sec, "unit": "losses/s", "cores": 1, "kind": "port",
+            "sample": f"4 utterances (T={T}, C={Cn}, U={U}) through the scalar C oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=512, help="utterances per GPU (C3: 512)")
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--C", type=int, default=256)
+    ap.add_argument("--U", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gtn_amd as gtn
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        gtn.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    B, T, Cn, U = args.batch, args.T, args.C, args.U
+
+    import graphgen as gg
+    em, tg = gg.ctc_inputs(1234 + rank, B, T, Cn, U)
+    stream = torch.cuda.Stream(device=dev)
+    gtn.set_stream(stream.cuda_stream)
+    with torch.cuda.stream(stream):
+        em_dev = torch.from_numpy(em).to(dev)
+        loss_dev = torch.empty(B, dtype=torch.float32, device=dev)
+        gathered = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        with torch.cuda.stream(stream):
+            ctcs = build_ctc_graphs(gtn, tg)
+            ems = gtn.linear_graph_n(B, T, Cn, em_dev)
+            comp = gtn.intersect(ctcs, ems)
+            loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))
+            gtn.backward(loss)
+            gtn.items_to_device(loss, loss_dev)
+            if world > 1:
+                dist.all_gather(gathered, loss_dev)
+        return ems, comp
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    gtn.prof_reset()
+    gtn.prof_enable(True)
+    t0 = time.perf_counter()
+    keep = None
+    for _ in range(args.steps):
+        keep = step()
+    fence()
+    dt = time.perf_counter() - t0
+    gtn.prof_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    ems, comp = keep
+    prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+    fs = prof.get("forward_score", {"total_ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
+    roof = None
+    if fs["launches"]:
+        ms = fs["total_ms"] / fs["launches"]
+        gbs = fs["algorithmic_bytes"] / fs["launches"] / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "sd_forward_kernel<LOG> (forwardScore over the composed lattices)",
+                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                "traffic": None, "ms_per_launch": ms,
+                "algorithmic_bytes_per_launch": fs["algorithmic_bytes"] / fs["launches"]}
+    if rank == 0:
+        n_nodes, n_arcs = comp[0].num_nodes(), comp[0].num_arcs()
+        losses = loss_dev.cpu().numpy()
+        out = {
+            "metric": "CTC forward+backward losses/sec (T=1000, C=256)" if (T, Cn) == (1000, 256)
+            else f"CTC forward+backward losses/sec (T={T}, C={Cn})",
+            "value": world * B * args.steps / dt,
+            "unit": "losses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE config C3: compose(ctc_target, emissions)+forwardScore CTC loss "
+                                   f"fwd+bwd, T={T}, C={Cn}, U={U}, batch={B} per GPU",
+                       "global_batch": world * B, "composed_nodes": n_nodes, "composed_arcs": n_arcs,
+                       "parallelism": f"dp{world} (utterance sharding, all_gather of losses)"},
+            "roofline": roof,
+            "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
+            "loss_mean": float(np.mean(losses)),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -228,6 +228,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234)
         print(json.dumps(out))
+    # orderly teardown: drop every graph, return pooled memory, then let HIP exit
+    del keep, ems, comp
+    gtn.set_stream(None)
+    gtn.synchronize()
+    gtn.empty_cache()
     if world > 1:
         dist.destroy_process_group()
 

@@ -289,8 +289,11 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   }
 
   int lo = 0, hi = nn, L = 0;
+  int max_width = 0, max_level_arcs = 0;
   while (lo < hi && !sh_flag[1]) {
     if (tid == 0) a.level_off[L] = lo;
+    const int na_level = na;
+    max_width = max(max_width, hi - lo);
     for (int c0 = lo; c0 < hi; c0 += kBlock) {
       const int node = c0 + tid;
       const bool live = node < hi;
@@ -396,6 +399,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       __syncthreads();
     }
     if (sh_flag[1]) break;
+    max_level_arcs = max(max_level_arcs, na - na_level);
     lo = hi;
     hi = nn;
     ++L;
@@ -410,6 +414,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     o.L = L;
     o.layered = sh_flag[0];
     o.overflow = sh_flag[1];
+    o.max_width = max_width;
+    o.max_level_arcs = max_level_arcs;
     *a.out = o;
   }
 }
@@ -523,14 +529,69 @@ __global__ void tr_scatter_kernel(const ComposeArgs* __restrict__ args) {
 // ================================================================================
 // gradient scatter (compose.cpp:496-518)
 // ================================================================================
-__global__ void compose_grad_kernel(const ComposeGradArgs* __restrict__ args) {
+// Each workgroup owns a contiguous chunk of composed arcs.  Composed arcs are
+// emitted in BFS order, so the input arcs a chunk refers to are clustered (for
+// CTC: one or two target-graph nodes' arcs and a handful of emission frames).
+// When the chunk's index range fits, contributions are first summed in an LDS
+// window (ds_add_f32) and flushed with ONE global atomic per touched input arc;
+// otherwise it falls back to direct global atomics.  This removes the heavy
+// same-address contention (hundreds of composed arcs per blank-label emission).
+constexpr int kGradChunk = 4096;
+constexpr int kGradWin = 4096;
+
+__global__ __launch_bounds__(kBlock) void compose_grad_kernel(const ComposeGradArgs* __restrict__ args) {
   const ComposeGradArgs a = args[blockIdx.y];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < a.A; k += gridDim.x * blockDim.x) {
+  const int k0 = blockIdx.x * kGradChunk;
+  if (k0 >= a.A) return;
+  const int k1 = min(a.A, k0 + kGradChunk);
+  const int tid = threadIdx.x;
+  __shared__ float win1[kGradWin];
+  __shared__ float win2[kGradWin];
+  __shared__ int red[4][kBlock];
+  int mn1 = INT_MAX, mx1 = -1, mn2 = INT_MAX, mx2 = -1;
+  for (int k = k0 + tid; k < k1; k += kBlock) {
+    const int i = a.gi1[k], j = a.gi2[k];
+    if (i >= 0) { mn1 = min(mn1, i); mx1 = max(mx1, i); }
+    if (j >= 0) { mn2 = min(mn2, j); mx2 = max(mx2, j); }
+  }
+  red[0][tid] = mn1; red[1][tid] = mx1; red[2][tid] = mn2; red[3][tid] = mx2;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      red[0][tid] = min(red[0][tid], red[0][tid + o]);
+      red[1][tid] = max(red[1][tid], red[1][tid + o]);
+      red[2][tid] = min(red[2][tid], red[2][tid + o]);
+      red[3][tid] = max(red[3][tid], red[3][tid + o]);
+    }
+    __syncthreads();
+  }
+  mn1 = red[0][0]; mx1 = red[1][0]; mn2 = red[2][0]; mx2 = red[3][0];
+  const bool lds1 = a.grad1 && mx1 >= 0 && (mx1 - mn1) < kGradWin;
+  const bool lds2 = a.grad2 && mx2 >= 0 && (mx2 - mn2) < kGradWin;
+  if (lds1) for (int x = tid; x <= mx1 - mn1; x += kBlock) win1[x] = 0.0f;
+  if (lds2) for (int x = tid; x <= mx2 - mn2; x += kBlock) win2[x] = 0.0f;
+  __syncthreads();
+  for (int k = k0 + tid; k < k1; k += kBlock) {
     const float d = a.delta[k];
     const int i = a.gi1[k], j = a.gi2[k];
-    if (a.grad1 && i >= 0) atomicAdd(a.grad1 + i, d);
-    if (a.grad2 && j >= 0) atomicAdd(a.grad2 + j, d);
+    if (a.grad1 && i >= 0) {
+      if (lds1) atomicAdd(&win1[i - mn1], d); else atomicAdd(a.grad1 + i, d);
+    }
+    if (a.grad2 && j >= 0) {
+      if (lds2) atomicAdd(&win2[j - mn2], d); else atomicAdd(a.grad2 + j, d);
+    }
   }
+  __syncthreads();
+  if (lds1)
+    for (int x = tid; x <= mx1 - mn1; x += kBlock) {
+      const float v = win1[x];
+      if (v != 0.0f) atomicAdd(a.grad1 + mn1 + x, v);
+    }
+  if (lds2)
+    for (int x = tid; x <= mx2 - mn2; x += kBlock) {
+      const float v = win2[x];
+      if (v != 0.0f) atomicAdd(a.grad2 + mn2 + x, v);
+    }
 }
 
 int grid_x(int n, int cap) {
@@ -563,7 +624,7 @@ void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int
 
 void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st) {
   if (n <= 0 || maxA <= 0) return;
-  hipLaunchKernelGGL(compose_grad_kernel, dim3(grid_x(maxA, 2048), n), dim3(kBlock), 0, st, d_args);
+  hipLaunchKernelGGL(compose_grad_kernel, dim3((maxA + kGradChunk - 1) / kGradChunk, n), dim3(kBlock), 0, st, d_args);
 }
 
 } // namespace gtnx

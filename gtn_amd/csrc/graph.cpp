@@ -495,6 +495,7 @@ struct HostSched {
   std::vector<int> level_off, row_off, in_srcpos, in_arc, in_rank, acc_pos, out_off, out_dstpos, out_arc;
   std::vector<uint8_t> pflags;
   int max_width = 0;
+  int max_level_arcs = 0, max_reach = 0;
   bool all_written = false;
 };
 
@@ -591,6 +592,13 @@ void build_host_schedule(Structure& s, HostSched& h, bool need_rank) {
       h.in_srcpos[o] = pos[s.src[a]];  // >= 0: all predecessors of a scheduled node are scheduled
     }
   }
+  for (int l = 0; l < h.L; ++l) {
+    const int lo = h.level_off[l], hi = h.level_off[l + 1];
+    h.max_level_arcs = std::max(h.max_level_arcs, h.row_off[hi] - h.row_off[lo]);
+    int mn = lo;
+    for (int k = h.row_off[lo]; k < h.row_off[hi]; ++k) mn = std::min(mn, h.in_srcpos[k]);
+    h.max_reach = std::max(h.max_reach, hi - mn);
+  }
   bool all = (h.P == N);
   int64_t written = 0;
   for (int p = 0; p < h.P; ++p) {
@@ -685,6 +693,8 @@ void ensure_schedule_batch(const std::vector<Structure*>& ss, bool need_rank) {
     sc->error = h.error;
     sc->mem = dev;
     sc->max_level_width = h.max_width;
+    sc->max_level_arcs = h.max_level_arcs;
+    sc->max_reach = h.max_reach;
     sc->n_in = int64_t(h.in_arc.size());
     sc->n_out = int64_t(h.out_arc.size());
     sc->all_written = h.all_written;

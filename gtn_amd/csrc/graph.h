@@ -28,6 +28,8 @@ struct Schedule {
   DevMemP mem;
   DSched view{};
   int max_level_width = 0;
+  int max_level_arcs = 0;  // most in-arcs entering one level
+  int max_reach = 0;       // max over levels of (last position + 1 - min source position)
   int64_t n_in = 0, n_out = 0;
   bool all_written = false;  // every arc gets a gradient (no memset needed)
   bool has_rank = false;

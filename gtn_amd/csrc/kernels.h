@@ -93,7 +93,13 @@ struct SdArgs {
 
 enum : int { SD_LOG = 0, SD_TROPICAL = 1, SD_PATH = 2 };
 
-void launch_sd_forward(const SdArgs* d_args, int n, int mode, int max_level_width,
+// narrow != 0 (2: every graph carries row-ordered weights in_w) selects the LDS-ring kernel for deep, narrow lattices (every graph
+// of the batch must satisfy: level arcs <= sd_narrow_tmp_cap(), per-level reach
+// <= sd_narrow_ring()); only the log semiring has it so far.
+int sd_narrow_ring();
+int sd_narrow_tmp_cap();
+int sd_narrow_node_cap();
+void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
                        int avg_in_degree_x16, hipStream_t st);
 void launch_sd_backward(const SdArgs* d_args, int n, int mode, int max_level_width,
                         hipStream_t st);
@@ -137,7 +143,9 @@ struct ComposeOut {
   int N, A, L;
   int layered;   // every arc goes from BFS level k to k+1
   int overflow;  // capacity exceeded (host bound was wrong) -- never expected
-  int pad[3];
+  int max_width;       // widest BFS level (nodes)
+  int max_level_arcs;  // most arcs emitted by one level
+  int pad;
 };
 
 struct ComposeArgs {

@@ -441,6 +441,16 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     int64_t tot_in = 0, tot_p = 0;
     int maxw = 0;
     double alg = 0;
+    // deep & narrow lattices take the LDS-ring kernel (whole batch must qualify)
+    bool narrow = !tropical;
+    int64_t tot_levels = 0;
+    for (int k = 0; k < m; ++k) {
+      Schedule& sc = *gs[exp[k]].s->sched;
+      narrow = narrow && sc.max_level_arcs <= sd_narrow_tmp_cap() && sc.max_level_width <= sd_narrow_node_cap() &&
+               sc.max_reach <= sd_narrow_ring();
+      tot_levels += sc.view.L;
+    }
+    narrow = narrow && tot_levels >= 32 * int64_t(m);
     for (int k = 0; k < m; ++k) {
       Graph& g = gs[exp[k]];
       Schedule& sc = *g.s->sched;
@@ -466,7 +476,10 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     }
     DevMemP d = upload_vec(args);
     GTNX_PROF(tropical ? "viterbi_score" : "forward_score", alg);
-    launch_sd_forward(d->as<SdArgs>(), m, op->mode, maxw, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
+    bool all_inw = true;
+    for (auto& a : args) all_inw = all_inw && a.s.in_w != nullptr;
+    launch_sd_forward(d->as<SdArgs>(), m, op->mode, narrow ? (all_inw ? 2 : 1) : 0,
+                      int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
   }
   return outs;
 }
@@ -912,7 +925,9 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
       sc->n_out = co.A;
       sc->all_written = true;
       sc->has_rank = true;  // rank == arc id for src-sorted arcs
-      sc->max_level_width = 0;
+      sc->max_level_width = co.max_width;
+      sc->max_level_arcs = co.max_level_arcs;
+      sc->max_reach = 2 * co.max_width;  // in-arcs come from the previous level only
       DSched& d = sc->view;
       d.P = co.N;
       d.L = co.L;

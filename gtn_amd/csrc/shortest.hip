@@ -196,6 +196,218 @@ __global__ __launch_bounds__(kBlock) void sd_forward_kernel(const SdArgs* __rest
 }
 
 // --------------------------------------------------------------------------
+// forward sweep, "narrow lattice" specialisation (log semiring).
+//
+// CTC-like products are DEEP and NARROW: T ~ 1000-2000 dependency levels of only
+// ~180 nodes / ~450 arcs.  The generic kernel above pays ~4 dependent global
+// round trips per level; with T levels that latency, not bandwidth, bounds it
+// (measured 10% of HBM peak).  Here the per-level critical path touches LDS only:
+//   * scores of the active frontier live in an LDS ring indexed by position;
+//   * the CSR rows are streamed through LDS in CHUNKS of consecutive levels
+//     (<= kCA arcs, <= kCN nodes), double buffered: while chunk c is reduced
+//     out of LDS, chunk c+1's (src position, weight) pairs, row offsets and
+//     node flags are in flight from HBM into registers (coalesced, issued a
+//     whole chunk ahead) and land in the other LDS buffer at the chunk switch;
+//   * inside a chunk there is NO global memory instruction at all, so the only
+//     wait per level is lgkmcnt + one s_barrier; finished scores are flushed to
+//     HBM once per chunk (for the backward pass), coalesced.
+// One lane reduces one node (rows are short: mean in-degree 2.5).
+// Eligibility (host): per-level arcs <= kCA, nodes <= kCN, reach <= kRing.
+// HBM traffic is exactly the algorithmic 8A + 8N bytes.
+// --------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains
+// vmcnt (gfx950 counts loads and stores on one counter), which would stall every
+// level on the staged loads of the NEXT chunk.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+constexpr int kRing = 4096;  // floats; power of two
+constexpr int kCA = 2048;    // arcs per chunk (and per level)
+constexpr int kCN = 1024;    // nodes per chunk (and per level)
+constexpr int kTab = 256;    // levels per offset-table refill
+constexpr int kJA = kCA / kBlock, kJN = kCN / kBlock;
+
+template <bool HAS_INW>
+__global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs* __restrict__ args) {
+  const SdArgs a = args[blockIdx.x];
+  const DSched s = a.s;
+  const int tid = threadIdx.x;
+  __shared__ float ring[kRing];
+  __shared__ int arc_sp[2][kCA];
+  __shared__ float arc_w[2][kCA];
+  __shared__ int node_off[2][kCN + kBlock];
+  __shared__ uint8_t node_fl[2][kCN];
+  __shared__ int tab_node[kTab + 2];
+  __shared__ int tab_arc[kTab + 2];
+  float* __restrict__ scores = a.scores;
+  const int* __restrict__ in_srcpos = s.in_srcpos;
+  const int* __restrict__ row_off = s.row_off;
+  const uint8_t* __restrict__ pflags = s.pflags;
+  const int last_node = s.P > 0 ? s.P - 1 : 0;
+
+  // staging registers of the chunk in flight
+  int st_sp[kJA];
+  float st_w[kJA];
+  int st_off[kJN + 1];
+  int st_fl[kJN];
+
+  // chunk = levels [c, e) of the current table window; ranges from the tables
+  auto chunk_end = [&](int c, int nl) {
+    int e = c + 1;  // a level always fits (eligibility)
+    while (e < nl && tab_arc[e + 1] - tab_arc[c] <= kCA && tab_node[e + 1] - tab_node[c] <= kCN) ++e;
+    return e;
+  };
+  // unconditional, index-clamped loads: straight-line code, coalesced
+  auto stage_load = [&](int a0, int a1, int n0) {
+    const int ahi = max(a1 - 1, 0);
+#pragma unroll
+    for (int j = 0; j < kJA; ++j) {
+      const int k = min(a0 + tid + j * kBlock, ahi);
+      st_sp[j] = in_srcpos[k];
+      st_w[j] = HAS_INW ? s.in_w[k] : a.w[s.in_arc[k]];
+    }
+#pragma unroll
+    for (int j = 0; j < kJN + 1; ++j) st_off[j] = row_off[min(n0 + tid + j * kBlock, last_node + 1)];
+#pragma unroll
+    for (int j = 0; j < kJN; ++j) st_fl[j] = pflags[min(n0 + tid + j * kBlock, last_node)];
+  };
+  auto stage_write = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < kJA; ++j) {
+      arc_sp[b][tid + j * kBlock] = st_sp[j];
+      arc_w[b][tid + j * kBlock] = st_w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kJN + 1; ++j) node_off[b][tid + j * kBlock] = st_off[j];
+#pragma unroll
+    for (int j = 0; j < kJN; ++j) node_fl[b][tid + j * kBlock] = uint8_t(st_fl[j]);
+  };
+
+  for (int l0 = 0; l0 < s.L; l0 += kTab) {
+    const int nl = min(kTab, s.L - l0);
+    __syncthreads();
+    for (int i = tid; i <= nl; i += kBlock) {
+      const int n = s.level_off[l0 + i];
+      tab_node[i] = n;
+      tab_arc[i] = row_off[n];
+    }
+    __syncthreads();
+    // prologue of the window: chunk 0 -> LDS buffer 0, chunk 1 -> registers
+    int c = 0, e = chunk_end(0, nl), b = 0;
+    stage_load(tab_arc[c], tab_arc[e], tab_node[c]);
+    stage_write(0);
+    int e2 = e < nl ? chunk_end(e, nl) : e;
+    if (e < nl) stage_load(tab_arc[e], tab_arc[e2], tab_node[e]);
+    __syncthreads();
+    while (c < nl) {
+      const int a0 = tab_arc[c], n0 = tab_node[c];
+      // ---- reduce the chunk's levels out of LDS (no global memory traffic here)
+      for (int i = c; i < e; ++i) {
+        const int nlo = tab_node[i], nhi = tab_node[i + 1];
+        for (int p = nlo + tid; p < nhi; p += kBlock) {
+          const int r0 = node_off[b][p - n0] - a0, r1 = node_off[b][p - n0 + 1] - a0;
+          const int fl = node_fl[b][p - n0];
+          const bool is_start = (fl & NF_START) != 0;
+          const int deg = r1 - r0;
+          float mx = NEG_INF, sum = 0.0f;
+          if (deg <= 4) {
+            // short row (the common case): 4 independent LDS gathers in flight,
+            // values kept in registers for the single-pass max / sum-exp
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = min(r0 + j, kCA - 1);
+              const float x = ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k];
+              v[j] = j < deg ? x : NEG_INF;
+              mx = fmaxf(mx, v[j]);
+            }
+            if (is_start && 0.0f > mx) mx = 0.0f;
+            if (mx != POS_INF && mx != NEG_INF) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) sum += __expf(v[j] - mx);
+              if (is_start) sum += __expf(0.0f - mx);
+            }
+          } else {
+            for (int k = r0; k < r1; ++k) mx = fmaxf(mx, ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k]);
+            if (is_start && 0.0f > mx) mx = 0.0f;
+            if (mx != POS_INF && mx != NEG_INF) {
+              for (int k = r0; k < r1; ++k) sum += __expf(ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k] - mx);
+              if (is_start) sum += __expf(0.0f - mx);
+            }
+          }
+          const int cnt = deg + (is_start ? 1 : 0);
+          // max + log(sum of exp(. - max)); sum >= 1, so the plain log is as
+          // accurate in absolute terms as the reference's log1p(sum - 1)
+          float out = (cnt == 0) ? NEG_INF : ((mx == POS_INF || mx == NEG_INF) ? mx : mx + __logf(sum));
+          if (fl & NF_ORPHAN) out = 0.0f;
+          // the slot being overwritten belongs to position p - kRing, which no
+          // later level reads (reach <= kRing); same-level lanes read other slots
+          ring[p & (kRing - 1)] = out;
+        }
+        lds_barrier();
+      }
+      // ---- chunk switch: flush finished scores, land the staged chunk, refill
+      const int n1 = tab_node[e];
+      for (int p = n0 + tid; p < n1; p += kBlock) scores[p] = ring[p & (kRing - 1)];
+      c = e;
+      e = e2;
+      b ^= 1;
+      if (c < nl) {
+        stage_write(b);  // waits for the loads issued one chunk ago
+        e2 = e < nl ? chunk_end(e, nl) : e;
+        if (e < nl) stage_load(tab_arc[e], tab_arc[e2], tab_node[e]);
+      }
+      lds_barrier();
+    }
+  }
+  __syncthreads();  // scores[] stores visible before the accept reduction reads them
+
+  // ---- accept reduction (identical to the generic kernel)
+  __shared__ float sh_v[kBlock];
+  __shared__ int sh_k[kBlock];
+  float mx = NEG_INF;
+  int bestk = INT_MAX;
+  for (int k = tid; k < s.n_accept; k += kBlock) {
+    const float v = scores[s.acc_pos[k]];
+    if (v > mx) { mx = v; bestk = k; }
+  }
+  sh_v[tid] = mx;
+  sh_k[tid] = bestk;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      const float v2 = sh_v[tid + o];
+      const int k2 = sh_k[tid + o];
+      if (v2 > sh_v[tid] || (v2 == sh_v[tid] && k2 < sh_k[tid])) { sh_v[tid] = v2; sh_k[tid] = k2; }
+    }
+    __syncthreads();
+  }
+  mx = sh_v[0];
+  bestk = sh_k[0];
+  __syncthreads();
+  float sum = 0.0f;
+  if (s.n_accept > 0 && mx != POS_INF && mx != NEG_INF)
+    for (int k = tid; k < s.n_accept; k += kBlock) sum += expf(scores[s.acc_pos[k]] - mx);
+  sh_v[tid] = sum;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) sh_v[tid] += sh_v[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const float out = finish_lse(mx, sh_v[0], s.n_accept);
+    SdResult r;
+    r.score = out;
+    r.max_final = mx;
+    r.argmax_final = (bestk == INT_MAX || !(mx > NEG_INF)) ? -1 : s.acc_pos[bestk];
+    r.pad = 0;
+    *a.result = r;
+    if (a.out_score) *a.out_score = out;
+  }
+}
+
+// --------------------------------------------------------------------------
 // backward sweep (pull form over the transposed rows; no atomics):
 //   nodeGrad[u] = acceptTerm(u) + sum over out-arcs a = (u -> v) of g_a
 //   g_a (log)      = nodeGrad[v] * exp(score[u] + w_a - score[v])
@@ -310,9 +522,20 @@ int pick_group(int avg_deg_x16) {
 
 } // namespace
 
-void launch_sd_forward(const SdArgs* d_args, int n, int mode, int /*max_level_width*/,
+int sd_narrow_ring() { return kRing; }
+int sd_narrow_tmp_cap() { return kCA; }
+int sd_narrow_node_cap() { return kCN; }
+
+void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
                        int avg_in_degree_x16, hipStream_t st) {
   if (n <= 0) return;
+  if (narrow && mode == SD_LOG) {
+    if (narrow == 2)
+      hipLaunchKernelGGL(sd_forward_narrow_kernel<true>, dim3(n), dim3(kBlock), 0, st, d_args);
+    else
+      hipLaunchKernelGGL(sd_forward_narrow_kernel<false>, dim3(n), dim3(kBlock), 0, st, d_args);
+    return;
+  }
   const int g = pick_group(avg_in_degree_x16);
   if (mode == SD_LOG)
     launch_fwd_mode<SD_LOG>(d_args, n, g, st);

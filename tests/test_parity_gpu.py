@@ -303,3 +303,34 @@ def test_linear_forward_c2(gtn):
     np.testing.assert_allclose(vit, x.max(-1).sum(-1), rtol=1e-5)
     for b in (0, 17):
         assert got[b] == pytest.approx(OGraph.linear(T, C, em[b]).shortest_distance(), rel=1e-5)
+
+
+def test_deep_narrow_dags_vs_oracle(gtn):
+    """host-built deep, narrow DAGs take the LDS-ring forward kernel (weights
+    gathered through in_arc); wide ones the generic kernel.  Both vs the oracle."""
+    rng = np.random.default_rng(11)
+    graphs, dicts = [], []
+    for L, W in ((300, 6), (120, 40), (64, 3), (40, 200)):
+        # layered DAG with skip arcs: node ids level-major
+        lv = [list(range(i * W, (i + 1) * W)) for i in range(L)]
+        src, dst = [], []
+        for i in range(1, L):
+            for n in lv[i]:
+                for _ in range(1 + int(rng.integers(0, 3))):
+                    back = 1 + int(rng.integers(0, min(i, 3)))
+                    src.append(int(rng.choice(lv[i - back])))
+                    dst.append(n)
+        N, A = L * W, len(src)
+        d = {"start": [1] * W + [0] * (N - W), "accept": [0] * (N - W) + [1] * W, "src": src, "dst": dst,
+             "il": rng.integers(0, 5, A).tolist(), "ol": rng.integers(0, 5, A).tolist(),
+             "w": [float(np.float32(x)) for x in rng.normal(0, 1, A)], "sort": None}
+        dicts.append(d)
+        graphs.append(gg.to_api(gtn, d))
+    fs = gtn.forward_score(graphs)
+    vs = gtn.viterbi_score(graphs)
+    gtn.backward(fs)
+    for d, g, f, v in zip(dicts, graphs, gtn.items(fs), gtn.items(vs)):
+        o = OGraph.from_dict(d)
+        assert f == pytest.approx(o.shortest_distance(), rel=1e-5)
+        assert v == pytest.approx(o.shortest_distance(True), rel=1e-6)
+        assert close(g.grad().weights_to_numpy(), o.shortest_distance_grad(), RTOL, 1e-6)

@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--U", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--python-host", action="store_true",
+                    help="drive the step through the Python interface instead of the C++ one")
     args = ap.parse_args()
 
     import torch
@@ -155,7 +157,29 @@ def main():
         loss_dev = torch.empty(B, dtype=torch.float32, device=dev)
         gathered = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
 
+    native = None
+    if not args.python_host:
+        native = C.CDLL(os.path.join(ROOT, "bench_native", "libgtn_bench.so"))
+        native.gtn_bench_ctc_step.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
+        native.gtn_bench_ctc_step.restype = C.c_int
+        with torch.cuda.stream(stream):
+            grad_dev = torch.empty(B, T, Cn, dtype=torch.float32, device=dev)
+
+    def native_step():
+        # the step as a gtn user's C++ host code (bench_native/ctc_step.cpp): target
+        # graphs built with parallelMap on host threads, graph functions batched
+        with torch.cuda.stream(stream):
+            rc = native.gtn_bench_ctc_step(em_dev.data_ptr(), tg.ctypes.data, B, T, Cn, U, loss_dev.data_ptr(),
+                                           grad_dev.data_ptr())
+            if rc != 0:
+                raise RuntimeError("native step failed: " + gtn._lib.gtnx_last_error().decode())
+            if world > 1:
+                dist.all_gather(gathered, loss_dev)
+        return None
+
     def step():
+        if native is not None:
+            return native_step()
         with torch.cuda.stream(stream):
             ctcs = build_ctc_graphs(gtn, tg)
             ems = gtn.linear_graph_n(B, T, Cn, em_dev)
@@ -189,8 +213,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    ems, comp = keep
     prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+    # composed-lattice size of utterance 0 (one extra untimed intersect)
+    e0 = gtn.linear_graph_n(1, T, Cn, em_dev)
+    comp = gtn.intersect(build_ctc_graphs(gtn, tg[:1]), e0)
+    ems = e0
     fs = prof.get("forward_score", {"total_ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
     roof = None
     if fs["launches"]:
@@ -220,7 +247,8 @@ def main():
             "config": {"workload": f"BASELINE config C3: compose(ctc_target, emissions)+forwardScore CTC loss "
                                    f"fwd+bwd, T={T}, C={Cn}, U={U}, batch={B} per GPU",
                        "global_batch": world * B, "composed_nodes": n_nodes, "composed_arcs": n_arcs,
-                       "parallelism": f"dp{world} (utterance sharding, all_gather of losses)"},
+                       "parallelism": f"dp{world} (utterance sharding, all_gather of losses)",
+                       "host": "python (gtn_amd/api.py)" if native is None else "C++ (include/gtn/, bench_native/ctc_step.cpp)"},
             "roofline": roof,
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
             "loss_mean": float(np.mean(losses)),
@@ -229,7 +257,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234)
         print(json.dumps(out))
     # orderly teardown: drop every graph, return pooled memory, then let HIP exit
-    del keep, ems, comp
+    del keep, ems, comp, e0
     gtn.set_stream(None)
     gtn.synchronize()
     gtn.empty_cache()

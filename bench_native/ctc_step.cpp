@@ -1,0 +1,57 @@
+// ctc_step.cpp -- the benchmark step of benchmarks/ctc.cpp:136-168 written against
+// the drop-in C++ API (include/gtn/), i.e. what a gtn user's host code looks like
+// on this engine: target graphs are built on host threads with parallelMap, the
+// graph functions run batched on the GPU through their vector overloads.
+// Built into bench_native/libgtn_bench.so and driven by bench.py over ctypes.
+#include <vector>
+
+#include "gtn/gtn.h"
+
+using namespace gtn;
+
+namespace {
+// benchmarks/ctc.cpp:40-58
+Graph ctcGraph(const std::vector<int>& target) {
+  int blank = 0;
+  size_t L = 2 * target.size() + 1;
+  Graph ctc;
+  for (size_t l = 0; l < L; l++) {
+    size_t idx = (l - 1) / 2;
+    ctc.addNode(l == 0, l == L - 1 || l == L - 2);
+    int label = l % 2 ? target[idx] : blank;
+    ctc.addArc(l, l, label);
+    if (l > 0) ctc.addArc(l - 1, l, label);
+    if (l % 2 && l > 1 && label != target[idx - 1]) ctc.addArc(l - 2, l, label);
+  }
+  ctc.arcSort();
+  return ctc;
+}
+} // namespace
+
+// emissions: DEVICE [B][T][C]; targets: host [B][U]; loss_dev: DEVICE [B];
+// grad_dev: DEVICE [B][T][C] or null.  Returns 0 or a gtnx status.
+extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const void* emissions, const int* targets,
+                                                                         int B, int T, int C, int U, void* loss_dev,
+                                                                         void* grad_dev) {
+  try {
+    std::vector<std::vector<int>> tg(B);
+    for (int b = 0; b < B; ++b) tg[b].assign(targets + (size_t)b * U, targets + (size_t)(b + 1) * U);
+    // fwd of benchmarks/ctc.cpp:150-158, batched
+    auto ctcs = parallelMap(ctcGraph, tg);
+    auto ems = linearGraphs(B, T, C, emissions);  // linearGraph + setWeights, one copy
+    auto losses = subtract(forwardScore(ems), forwardScore(intersect(ctcs, ems)));
+    // bwd of benchmarks/ctc.cpp:160
+    backward(losses);
+    auto h = detail::handles(losses);
+    detail::check(gtnx_items_device_n(h.data(), B, loss_dev));
+    if (grad_dev) {
+      auto he = detail::handles(ems);
+      std::vector<int64_t> off(B);
+      for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
+      detail::check(gtnx_grads_device_n(he.data(), B, grad_dev, off.data()));
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    return -1;
+  }
+}

@@ -302,49 +302,81 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     __syncthreads();
     while (c < nl) {
       const int a0 = tab_arc[c], n0 = tab_node[c];
-      // ---- reduce the chunk's levels out of LDS (no global memory traffic here)
-      for (int i = c; i < e; ++i) {
-        const int nlo = tab_node[i], nhi = tab_node[i + 1];
-        for (int p = nlo + tid; p < nhi; p += kBlock) {
-          const int r0 = node_off[b][p - n0] - a0, r1 = node_off[b][p - n0 + 1] - a0;
-          const int fl = node_fl[b][p - n0];
-          const bool is_start = (fl & NF_START) != 0;
-          const int deg = r1 - r0;
-          float mx = NEG_INF, sum = 0.0f;
-          if (deg <= 4) {
-            // short row (the common case): 4 independent LDS gathers in flight,
-            // values kept in registers for the single-pass max / sum-exp
-            float v[4];
+      // ---- reduce the chunk's levels out of LDS (no global memory traffic here).
+      // Everything that does not depend on the scores (row bounds, flags, source
+      // positions, weights) of level i+1 is read from LDS into registers BEFORE
+      // level i's barrier, so a level's critical path is: ring gather -> max /
+      // exp / log -> ring write -> barrier.
+      int q_p = 0, q_r0 = 0, q_deg = 0, q_fl = 0, q_nhi = 0;
+      int q_sp[4];
+      float q_w[4];
+      auto preload = [&](int i) {
+        const int nlo = tab_node[i];
+        q_nhi = tab_node[i + 1];
+        q_p = nlo + tid;
+        const int pc = max(min(q_p, q_nhi - 1), n0) - n0;
+        q_r0 = node_off[b][pc] - a0;
+        q_deg = node_off[b][pc + 1] - a0 - q_r0;
+        q_fl = node_fl[b][pc];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int k = min(r0 + j, kCA - 1);
-              const float x = ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k];
-              v[j] = j < deg ? x : NEG_INF;
-              mx = fmaxf(mx, v[j]);
-            }
-            if (is_start && 0.0f > mx) mx = 0.0f;
-            if (mx != POS_INF && mx != NEG_INF) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) sum += __expf(v[j] - mx);
-              if (is_start) sum += __expf(0.0f - mx);
-            }
-          } else {
-            for (int k = r0; k < r1; ++k) mx = fmaxf(mx, ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k]);
-            if (is_start && 0.0f > mx) mx = 0.0f;
-            if (mx != POS_INF && mx != NEG_INF) {
-              for (int k = r0; k < r1; ++k) sum += __expf(ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k] - mx);
-              if (is_start) sum += __expf(0.0f - mx);
-            }
-          }
-          const int cnt = deg + (is_start ? 1 : 0);
-          // max + log(sum of exp(. - max)); sum >= 1, so the plain log is as
-          // accurate in absolute terms as the reference's log1p(sum - 1)
-          float out = (cnt == 0) ? NEG_INF : ((mx == POS_INF || mx == NEG_INF) ? mx : mx + __logf(sum));
-          if (fl & NF_ORPHAN) out = 0.0f;
-          // the slot being overwritten belongs to position p - kRing, which no
-          // later level reads (reach <= kRing); same-level lanes read other slots
-          ring[p & (kRing - 1)] = out;
+        for (int j = 0; j < 4; ++j) {
+          const int k = min(q_r0 + j, kCA - 1);
+          q_sp[j] = arc_sp[b][k];
+          q_w[j] = arc_w[b][k];
         }
+      };
+      auto node_update = [&](int p, int r0, int deg, int fl, const int* sp4, const float* w4) {
+        const bool is_start = (fl & NF_START) != 0;
+        float mx = NEG_INF, sum = 0.0f;
+        if (deg <= 4) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = ring[sp4[j] & (kRing - 1)] + w4[j];
+            v[j] = j < deg ? x : NEG_INF;
+            mx = fmaxf(mx, v[j]);
+          }
+          if (is_start && 0.0f > mx) mx = 0.0f;
+          if (mx != POS_INF && mx != NEG_INF) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum += __expf(v[j] - mx);
+            if (is_start) sum += __expf(0.0f - mx);
+          }
+        } else {
+          const int r1 = r0 + deg;
+          for (int k = r0; k < r1; ++k) mx = fmaxf(mx, ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k]);
+          if (is_start && 0.0f > mx) mx = 0.0f;
+          if (mx != POS_INF && mx != NEG_INF) {
+            for (int k = r0; k < r1; ++k) sum += __expf(ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k] - mx);
+            if (is_start) sum += __expf(0.0f - mx);
+          }
+        }
+        const int cnt = deg + (is_start ? 1 : 0);
+        // max + log(sum of exp(. - max)); sum >= 1, so the plain log is as
+        // accurate in absolute terms as the reference's log1p(sum - 1)
+        float out = (cnt == 0) ? NEG_INF : ((mx == POS_INF || mx == NEG_INF) ? mx : mx + __logf(sum));
+        if (fl & NF_ORPHAN) out = 0.0f;
+        // the slot being overwritten belongs to position p - kRing, which no
+        // later level reads (reach <= kRing); same-level lanes read other slots
+        ring[p & (kRing - 1)] = out;
+      };
+      preload(c);
+      for (int i = c; i < e; ++i) {
+        const int nhi = q_nhi;
+        if (q_p < nhi) node_update(q_p, q_r0, q_deg, q_fl, q_sp, q_w);
+        for (int p = q_p + kBlock; p < nhi; p += kBlock) {  // levels wider than the workgroup
+          const int r0 = node_off[b][p - n0] - a0, deg = node_off[b][p - n0 + 1] - a0 - r0;
+          int sp4[4];
+          float w4[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int k = min(r0 + j, kCA - 1);
+            sp4[j] = arc_sp[b][k];
+            w4[j] = arc_w[b][k];
+          }
+          node_update(p, r0, deg, node_fl[b][p - n0], sp4, w4);
+        }
+        if (i + 1 < e) preload(i + 1);
         lds_barrier();
       }
       // ---- chunk switch: flush finished scores, land the staged chunk, refill

@@ -1,0 +1,79 @@
+// gtn/functions.h -- reference gtn/functions.h:19-152 for the hot path, plus the
+// batched (std::vector<Graph>) overloads the reference exposes through its Python
+// binding (bindings/python/gtn/_functions.cpp:84-135).  A vector call is ONE
+// batched device launch per kernel family.
+#pragma once
+
+#include <vector>
+
+#include "gtn/graph.h"
+
+namespace gtn {
+namespace detail {
+inline std::vector<gtnx_graph_t> handles(const std::vector<Graph>& v) {
+  std::vector<gtnx_graph_t> h;
+  h.reserve(v.size());
+  for (auto& g : v) h.push_back(g.handle());
+  return h;
+}
+inline std::vector<Graph> adopt(std::vector<gtnx_graph_t>& h) {
+  std::vector<Graph> out;
+  out.reserve(h.size());
+  for (auto x : h) out.push_back(Graph::fromHandle(x));
+  return out;
+}
+template <class F>
+Graph unary(F f, const Graph& g) {
+  gtnx_graph_t out;
+  check(f(g.handle(), &out));
+  return Graph::fromHandle(out);
+}
+template <class F>
+Graph binary(F f, const Graph& a, const Graph& b) {
+  gtnx_graph_t out;
+  check(f(a.handle(), b.handle(), &out));
+  return Graph::fromHandle(out);
+}
+template <class F>
+std::vector<Graph> unaryN(F f, const std::vector<Graph>& g) {
+  auto h = handles(g);
+  std::vector<gtnx_graph_t> out(h.size());
+  if (!h.empty()) check(f(h.data(), (int)h.size(), out.data()));
+  return adopt(out);
+}
+template <class F>
+std::vector<Graph> binaryN(F f, const std::vector<Graph>& a, const std::vector<Graph>& b) {
+  auto ha = handles(a), hb = handles(b);
+  std::vector<gtnx_graph_t> out(std::max(ha.size(), hb.size()));
+  if (!out.empty()) check(f(ha.data(), (int)ha.size(), hb.data(), (int)hb.size(), out.data()));
+  return adopt(out);
+}
+} // namespace detail
+
+inline Graph negate(const Graph& g) { return detail::unary(&gtnx_negate, g); }
+inline Graph add(const Graph& g1, const Graph& g2) { return detail::binary(&gtnx_add, g1, g2); }
+inline Graph subtract(const Graph& g1, const Graph& g2) { return detail::binary(&gtnx_subtract, g1, g2); }
+inline Graph compose(const Graph& g1, const Graph& g2) { return detail::binary(&gtnx_compose, g1, g2); }
+inline Graph intersect(const Graph& g1, const Graph& g2) { return detail::binary(&gtnx_intersect, g1, g2); }
+inline Graph forwardScore(const Graph& g) { return detail::unary(&gtnx_forward_score, g); }
+inline Graph viterbiScore(const Graph& g) { return detail::unary(&gtnx_viterbi_score, g); }
+inline Graph viterbiPath(const Graph& g) { return detail::unary(&gtnx_viterbi_path, g); }
+
+inline std::vector<Graph> negate(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_negate_n, g); }
+inline std::vector<Graph> add(const std::vector<Graph>& a, const std::vector<Graph>& b) {
+  return detail::binaryN(&gtnx_add_n, a, b);
+}
+inline std::vector<Graph> subtract(const std::vector<Graph>& a, const std::vector<Graph>& b) {
+  return detail::binaryN(&gtnx_subtract_n, a, b);
+}
+inline std::vector<Graph> compose(const std::vector<Graph>& a, const std::vector<Graph>& b) {
+  return detail::binaryN(&gtnx_compose_n, a, b);
+}
+inline std::vector<Graph> intersect(const std::vector<Graph>& a, const std::vector<Graph>& b) {
+  return detail::binaryN(&gtnx_intersect_n, a, b);
+}
+inline std::vector<Graph> forwardScore(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_forward_score_n, g); }
+inline std::vector<Graph> viterbiScore(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_viterbi_score_n, g); }
+inline std::vector<Graph> viterbiPath(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_viterbi_path_n, g); }
+
+} // namespace gtn

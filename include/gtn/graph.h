@@ -1,0 +1,265 @@
+// gtn/graph.h -- drop-in replacement for the reference's gtn/graph.h:75-415.
+// Header-only shim over the C ABI of libgtn_amd.so (include/gtn_amd.h): same class,
+// same members, same exception types and messages; the storage and every graph
+// function live on the MI355X behind the ABI.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "gtn_amd.h"
+
+namespace gtn {
+
+/** The index of the epsilon label (reference gtn/graph.h:21). */
+constexpr int epsilon{-1};
+
+namespace detail {
+inline void check(gtnx_status_t st) {
+  if (st == GTNX_OK) return;
+  const std::string msg = gtnx_last_error();
+  switch (st) {
+    case GTNX_INVALID_ARGUMENT: throw std::invalid_argument(msg);
+    case GTNX_LOGIC_ERROR: throw std::logic_error(msg);
+    case GTNX_OUT_OF_RANGE: throw std::out_of_range(msg);
+    default: throw std::runtime_error(msg);
+  }
+}
+} // namespace detail
+
+class Graph {
+ public:
+  using GradFunc = std::function<void(std::vector<Graph>& inputs, Graph& deltas)>;
+
+  /** Graph(GradFunc, inputs), reference graph.h:78 */
+  Graph(GradFunc gradFunc, std::vector<Graph> inputs) {
+    std::vector<gtnx_graph_t> hs;
+    for (auto& g : inputs) hs.push_back(g.h_);
+    auto* ctx = gradFunc ? new GradFunc(std::move(gradFunc)) : nullptr;
+    detail::check(gtnx_graph_create_op(hs.data(), static_cast<int>(hs.size()), ctx ? &Graph::trampoline : nullptr,
+                                       ctx, ctx ? &Graph::freeCtx : nullptr, &h_));
+  }
+  /** Graph(bool calcGrad = true), reference graph.h:89 */
+  Graph(bool calcGrad = true) { detail::check(gtnx_graph_create(calcGrad ? 1 : 0, &h_)); }
+  Graph(const Graph& o) { detail::check(gtnx_graph_copy(o.h_, &h_)); }  // aliases, like the reference
+  Graph(Graph&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  Graph& operator=(const Graph& o) {
+    if (this != &o) {
+      gtnx_graph_t n;
+      detail::check(gtnx_graph_copy(o.h_, &n));
+      reset();
+      h_ = n;
+    }
+    return *this;
+  }
+  Graph& operator=(Graph&& o) noexcept {
+    if (this != &o) {
+      reset();
+      h_ = o.h_;
+      o.h_ = nullptr;
+    }
+    return *this;
+  }
+  ~Graph() { reset(); }
+
+  int addNode(bool start = false, bool accept = false) {
+    int id;
+    detail::check(gtnx_graph_add_node(h_, start, accept, &id));
+    return id;
+  }
+  size_t addArc(size_t srcNode, size_t dstNode, int label) { return addArc(srcNode, dstNode, label, label); }
+  size_t addArc(size_t srcNode, size_t dstNode, int ilabel, int olabel, float weight = 0.0) {
+    int id;
+    detail::check(gtnx_graph_add_arc(h_, static_cast<int>(srcNode), static_cast<int>(dstNode), ilabel, olabel,
+                                     weight, &id));
+    return static_cast<size_t>(id);
+  }
+  size_t numArcs() const { return count(&gtnx_graph_num_arcs); }
+  size_t numNodes() const { return count(&gtnx_graph_num_nodes); }
+  size_t numStart() const { return count(&gtnx_graph_num_start); }
+  size_t numAccept() const { return count(&gtnx_graph_num_accept); }
+  float item() const {
+    float v;
+    detail::check(gtnx_graph_item(h_, &v));
+    return v;
+  }
+  static Graph deepCopy(const Graph& src) {
+    gtnx_graph_t n;
+    detail::check(gtnx_graph_deep_copy(src.h_, &n));
+    return Graph(n);
+  }
+  void arcSort(bool olabel = false) { detail::check(gtnx_graph_arc_sort(h_, olabel)); }
+  void markArcSorted(bool olabel = false) { detail::check(gtnx_graph_mark_arc_sorted(h_, olabel)); }
+  bool ilabelSorted() const {
+    int v;
+    detail::check(gtnx_graph_ilabel_sorted(h_, &v));
+    return v != 0;
+  }
+  bool olabelSorted() const {
+    int v;
+    detail::check(gtnx_graph_olabel_sorted(h_, &v));
+    return v != 0;
+  }
+  float* weights() {
+    float* p;
+    detail::check(gtnx_graph_weights(h_, 1, &p));
+    return p;
+  }
+  const float* weights() const {
+    float* p;
+    detail::check(gtnx_graph_weights(h_, 0, &p));
+    return p;
+  }
+  void setWeights(const float* weights) { detail::check(gtnx_graph_set_weights(h_, weights)); }
+  /** extension: copy numArcs floats from a DEVICE buffer (no host round trip) */
+  void setWeightsDevice(const void* deviceWeights) { detail::check(gtnx_graph_set_weights_device(h_, deviceWeights)); }
+  void labelsToArray(int* out, bool ilabel = true) { detail::check(gtnx_graph_labels_to_array(h_, out, ilabel)); }
+  std::vector<int> labelsToVector(bool ilabel = true) {
+    std::vector<int> out(numArcs());
+    labelsToArray(out.data(), ilabel);
+    return out;
+  }
+
+  void addGrad(std::vector<float>&& other) { detail::check(gtnx_graph_add_grad(h_, other.data(), (int64_t)other.size())); }
+  void addGrad(const std::vector<float>& other) {
+    detail::check(gtnx_graph_add_grad(h_, other.data(), (int64_t)other.size()));
+  }
+  void addGrad(const Graph& other) { detail::check(gtnx_graph_add_grad_graph(h_, other.h_)); }
+  bool calcGrad() const {
+    int v;
+    detail::check(gtnx_graph_calc_grad(h_, &v));
+    return v != 0;
+  }
+  bool isGradAvailable() const {
+    int v;
+    detail::check(gtnx_graph_is_grad_available(h_, &v));
+    return v != 0;
+  }
+  Graph& grad() { return const_cast<Graph&>(static_cast<const Graph&>(*this).grad()); }
+  const Graph& grad() const {
+    gtnx_graph_t n;
+    detail::check(gtnx_graph_grad(h_, &n));
+    grad_.reset(new Graph(n));
+    return *grad_;
+  }
+  void setCalcGrad(bool calcGrad) { detail::check(gtnx_graph_set_calc_grad(h_, calcGrad)); }
+  void zeroGrad() { detail::check(gtnx_graph_zero_grad(h_)); }
+  std::uintptr_t id() {
+    std::uintptr_t v;
+    detail::check(gtnx_graph_id(h_, &v));
+    return v;
+  }
+
+  const std::vector<int>& start() const {
+    cacheA_.resize(numStart());
+    detail::check(gtnx_graph_get_start(h_, cacheA_.data()));
+    return cacheA_;
+  }
+  const std::vector<int>& accept() const {
+    cacheB_.resize(numAccept());
+    detail::check(gtnx_graph_get_accept(h_, cacheB_.data()));
+    return cacheB_;
+  }
+  bool isStart(size_t i) const {
+    int v;
+    detail::check(gtnx_graph_is_start(h_, (int)i, &v));
+    return v != 0;
+  }
+  bool isAccept(size_t i) const {
+    int v;
+    detail::check(gtnx_graph_is_accept(h_, (int)i, &v));
+    return v != 0;
+  }
+  void makeAccept(size_t i) { detail::check(gtnx_graph_make_accept(h_, (int)i)); }
+  size_t numOut(size_t i) const {
+    int64_t v;
+    detail::check(gtnx_graph_num_out(h_, (int)i, &v));
+    return (size_t)v;
+  }
+  const std::vector<int>& out(size_t i) const {
+    cacheC_.resize(numOut(i));
+    detail::check(gtnx_graph_get_out(h_, (int)i, cacheC_.data()));
+    return cacheC_;
+  }
+  int out(size_t i, size_t j) const { return out(i)[j]; }
+  size_t numIn(size_t i) const {
+    int64_t v;
+    detail::check(gtnx_graph_num_in(h_, (int)i, &v));
+    return (size_t)v;
+  }
+  const std::vector<int>& in(size_t i) const {
+    cacheD_.resize(numIn(i));
+    detail::check(gtnx_graph_get_in(h_, (int)i, cacheD_.data()));
+    return cacheD_;
+  }
+  size_t in(size_t i, size_t j) const { return (size_t)in(i)[j]; }
+
+  int srcNode(size_t i) const { return arcField(i, 0); }
+  int dstNode(size_t i) const { return arcField(i, 1); }
+  int label(size_t i) const { return arcField(i, 2); }
+  int ilabel(size_t i) const { return arcField(i, 2); }
+  int olabel(size_t i) const { return arcField(i, 3); }
+  float weight(size_t i) const {
+    float w;
+    detail::check(gtnx_graph_get_arc(h_, (int)i, nullptr, nullptr, nullptr, nullptr, &w));
+    return w;
+  }
+  void setWeight(size_t i, float weight) { detail::check(gtnx_graph_set_weight(h_, (int)i, weight)); }
+
+  /** the C-ABI handle (for the batched free functions) */
+  gtnx_graph_t handle() const { return h_; }
+  /** adopt a handle returned by the C ABI */
+  static Graph fromHandle(gtnx_graph_t h) { return Graph(h); }
+
+ private:
+  size_t addArc(size_t srcNode, size_t dstNode, int label, float) = delete;   // reference graph.h:419-420
+  size_t addArc(size_t srcNode, size_t dstNode, int label, double) = delete;
+  explicit Graph(gtnx_graph_t h) : h_(h) {}
+  void reset() {
+    if (h_) gtnx_graph_destroy(h_);
+    h_ = nullptr;
+  }
+  size_t count(gtnx_status_t (*fn)(gtnx_graph_t, int64_t*)) const {
+    int64_t v;
+    detail::check(fn(h_, &v));
+    return (size_t)v;
+  }
+  int arcField(size_t i, int which) const {
+    int v[4];
+    detail::check(gtnx_graph_get_arc(h_, (int)i, &v[0], &v[1], &v[2], &v[3], nullptr));
+    return v[which];
+  }
+  static gtnx_status_t trampoline(void* ctx, gtnx_graph_t* inputs, int n, gtnx_graph_t deltas) {
+    try {
+      std::vector<Graph> ins;
+      for (int i = 0; i < n; ++i) {
+        gtnx_graph_t c;
+        detail::check(gtnx_graph_copy(inputs[i], &c));
+        ins.push_back(Graph(c));
+      }
+      gtnx_graph_t dc;
+      detail::check(gtnx_graph_copy(deltas, &dc));
+      Graph d(dc);
+      (*static_cast<GradFunc*>(ctx))(ins, d);
+      return GTNX_OK;
+    } catch (const std::invalid_argument&) {
+      return GTNX_INVALID_ARGUMENT;
+    } catch (const std::logic_error&) {
+      return GTNX_LOGIC_ERROR;
+    } catch (...) {
+      return GTNX_RUNTIME_ERROR;
+    }
+  }
+  static void freeCtx(void* ctx) { delete static_cast<GradFunc*>(ctx); }
+
+  gtnx_graph_t h_{nullptr};
+  mutable std::unique_ptr<Graph> grad_;
+  mutable std::vector<int> cacheA_, cacheB_, cacheC_, cacheD_;
+};
+
+} // namespace gtn

@@ -208,10 +208,8 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     gtn.prof_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from gtn_amd.distributed import max_over_ranks
+    dt = max_over_ranks(dt, dev)
 
     prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
     # composed-lattice size of utterance 0 (one extra untimed intersect)

@@ -1,0 +1,47 @@
+"""Utterance sharding across ranks (one process per GPU).
+
+A batch of independent utterance graphs shards embarrassingly: rank r owns a
+contiguous block of utterances, runs the whole loss locally, and the only
+exchange is an all_gather of the per-utterance scalar losses (RCCL over xGMI on
+GPUs; gloo in the CPU tests).  No gradient collective is needed for CTC: the
+emission gradients stay on the rank that owns the utterances.  (The ASG variant's
+shared transition-graph gradient would add one all_reduce of C*C + C floats.)
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """contiguous block [lo, hi) of rank `rank`; blocks differ by at most one item"""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_losses(local_losses, n_items=None):
+    """all_gather of the ranks' loss vectors -> one tensor in utterance order.
+    Ragged shards (n_items not divisible by world) are padded to the longest."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_losses
+    world = dist.get_world_size()
+    if n_items is None:
+        n_items = local_losses.numel() * world
+    longest = -(-n_items // world)
+    pad = local_losses.new_zeros(longest)
+    pad[: local_losses.numel()] = local_losses
+    parts = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(parts, pad)
+    out = []
+    for r in range(world):
+        lo, hi = shard_range(n_items, r, world)
+        out.append(parts[r][: hi - lo])
+    return torch.cat(out)
+
+
+def max_over_ranks(seconds, device=None):
+    """the step time the contract reports: slowest rank"""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -194,34 +194,71 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int
 // ================================================================================
 // the composition kernel
 // ================================================================================
+// LDS working set of the fast paths (ints): a per-chunk claim hash (keys / first
+// arc rank / assigned id), the next frontier's pair ids, and per-level in-degree
+// counters + cursors for the fused in-arc CSR.
+constexpr int KC = 4;      // candidates cached per lane (registers)
+constexpr int HC = 2048;   // claim-hash slots per chunk (<= HC/2 arcs per chunk)
+constexpr int FC = 1024;   // frontier pairs kept in LDS per level
+constexpr int WC = 2048;   // new nodes per level whose in-rows are built in LDS
+constexpr int BQ = 2048;   // backward-BFS frontier pairs kept in LDS per level
+
+struct Cand {
+  int idx[KC], i[KC], j[KC];
+  int n;
+  __device__ __forceinline__ void push(int id, int ai, int aj) {
+    // select chain instead of dynamic indexing keeps everything in registers
+    if (n == 0) { idx[0] = id; i[0] = ai; j[0] = aj; }
+    else if (n == 1) { idx[1] = id; i[1] = ai; j[1] = aj; }
+    else if (n == 2) { idx[2] = id; i[2] = ai; j[2] = aj; }
+    else if (n == 3) { idx[3] = id; i[3] = ai; j[3] = aj; }
+    ++n;
+  }
+};
+
 __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __restrict__ args) {
   const ComposeArgs a = args[blockIdx.x];
   const int tid = threadIdx.x;
   const int N1 = a.g1.N, N2 = a.g2.N;
   __shared__ int sh_scan[8];
   __shared__ int sh_tail;
-  __shared__ int sh_flag[2];
+  __shared__ int sh_flag[4];
+  __shared__ int hkeys[HC];
+  __shared__ int hvals[HC];
+  __shared__ int hids[HC];
+  __shared__ int front[2][FC];   // also the backward queue (2 x BQ/2 ... see below)
+  __shared__ int incnt[WC];
+  __shared__ int incur[WC];
 
   if (tid == 0) {
     sh_tail = 0;
     sh_flag[0] = 1;  // layered
     sh_flag[1] = 0;  // overflow
+    sh_flag[2] = 1;  // in-CSR built in-kernel is valid
+    sh_flag[3] = 0;
   }
   __syncthreads();
   if (N1 == 0 || N2 == 0) {
     if (tid == 0) {
       ComposeOut o{};
       o.layered = 1;
+      o.csr_built = 1;
       *a.out = o;
       a.out_off[0] = 0;
       a.level_off[0] = 0;
+      a.in_off[0] = 0;
+      a.counts[0] = a.counts[1] = 0;
     }
     return;
   }
 
   // ------------------------------------------------------------------ phase B
-  // compose.cpp:64-104 -- `state` was pre-filled with ST_UNREACH
+  // compose.cpp:64-104 -- `state` was pre-filled with ST_UNREACH.  The frontier
+  // queue of a level lives in LDS (hkeys/hvals double as the two queue buffers)
+  // when it fits, else in HBM; a lane gathers its (<= KC) predecessor pairs
+  // first, then issues their state loads together and CASes the unreached ones.
   {
+    auto bq = [&](int b) -> int* { return b ? hvals : hkeys; };
     const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
     const int seeds = na1 * na2;
     for (int t = tid; t < seeds; t += kBlock) {
@@ -229,29 +266,48 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       const int idx = f + N1 * s;
       st_state(a.state + idx, ST_REACH);
       a.queue[t] = idx;
+      if (t < BQ) bq(0)[t] = idx;
     }
     if (tid == 0) sh_tail = seeds;
     __syncthreads();
-    int lo = 0, hi = seeds;
-    auto mark = [&](int u1, int u2) {
-      const int idx = u1 + N1 * u2;
-      if (ld_state(a.state + idx) == ST_UNREACH &&
-          atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH) {
+    int lo = 0, hi = seeds, cur = 0;
+    auto mark = [&](int idx, int nxt) {
+      if (atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH) {
         const int pos = atomicAdd(&sh_tail, 1);
         a.queue[pos] = idx;
+        if (pos - hi < BQ) bq(nxt)[pos - hi] = idx;
       }
     };
     while (lo < hi) {
+      const bool in_lds = (hi - lo) <= BQ;
       for (int f = lo + tid; f < hi; f += kBlock) {
-        const int idx = a.queue[f];
+        const int idx = in_lds ? bq(cur)[f - lo] : a.queue[f];
         const int n1 = idx % N1, n2 = idx / N1;
-        enum_matches(a, n1, n2, true, [&](int i, int j) { mark(g_src(a.g1, i), g_src(a.g2, j)); });
-        enum_eps(a.g1, in_adj(a.g1, n1), false, [&](int i) { mark(a.g1.src[i], n2); });
-        enum_eps(a.g2, in_adj(a.g2, n2), true, [&](int j) { mark(n1, a.g2.src[j]); });
+        Cand c;
+        c.n = 0;
+        enum_matches(a, n1, n2, true, [&](int i, int j) { c.push(g_src(a.g1, i) + N1 * g_src(a.g2, j), 0, 0); });
+        enum_eps(a.g1, in_adj(a.g1, n1), false, [&](int i) { c.push(a.g1.src[i] + N1 * n2, 0, 0); });
+        enum_eps(a.g2, in_adj(a.g2, n2), true, [&](int j) { c.push(n1 + N1 * a.g2.src[j], 0, 0); });
+        if (c.n <= KC) {
+          int st[KC];
+#pragma unroll
+          for (int m = 0; m < KC; ++m) st[m] = m < c.n ? ld_state(a.state + c.idx[m]) : 0;
+#pragma unroll
+          for (int m = 0; m < KC; ++m)
+            if (m < c.n && st[m] == ST_UNREACH) mark(c.idx[m], cur ^ 1);
+        } else {
+          auto slow = [&](int id) {
+            if (ld_state(a.state + id) == ST_UNREACH) mark(id, cur ^ 1);
+          };
+          enum_matches(a, n1, n2, true, [&](int i, int j) { slow(g_src(a.g1, i) + N1 * g_src(a.g2, j)); });
+          enum_eps(a.g1, in_adj(a.g1, n1), false, [&](int i) { slow(a.g1.src[i] + N1 * n2); });
+          enum_eps(a.g2, in_adj(a.g2, n2), true, [&](int j) { slow(n1 + N1 * a.g2.src[j]); });
+        }
       }
       __syncthreads();
       lo = hi;
       hi = sh_tail;
+      cur ^= 1;
       __syncthreads();
     }
   }
@@ -278,6 +334,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         if (id < a.Ncap) {
           a.pair_of[id] = idx;
           a.nflags[id] = uint8_t(NF_START | ((g_accept(a.g1, s1) && g_accept(a.g2, s2)) ? NF_ACCEPT : 0));
+          a.in_off[id] = 0;  // level 0 has no in-arcs in a layered product
+          if (id < FC) front[0][id] = idx;
           st_state(a.state + idx, id);
         } else {
           sh_flag[1] = 1;
@@ -285,24 +343,37 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       }
       nn += tot;
     }
+    for (int x = tid; x < WC; x += kBlock) incnt[x] = 0;
     __syncthreads();
   }
 
-  int lo = 0, hi = nn, L = 0;
+  int lo = 0, hi = nn, L = 0, fcur = 0;
   int max_width = 0, max_level_arcs = 0;
   while (lo < hi && !sh_flag[1]) {
     if (tid == 0) a.level_off[L] = lo;
     const int na_level = na;
     max_width = max(max_width, hi - lo);
+    const bool front_in_lds = (hi - lo) <= FC;
+    const bool single_chunk = (hi - lo) <= kBlock;
+    // registers of this lane's emitted arcs (fast path), kept for the fused in-CSR
+    int my_dst[KC], my_ai[KC];
+    float my_w[KC];
+    bool fast_level = true;
     for (int c0 = lo; c0 < hi; c0 += kBlock) {
       const int node = c0 + tid;
       const bool live = node < hi;
       int n1 = 0, n2 = 0;
       bool eps1_ok = false, eps2_ok = false;
       Adj o1{}, o2{};
-      int cnt = 0;
+      Cand c;
+      c.n = 0;
+      // clear the claim hash (ordered before its use by the scan's barriers)
+      for (int x = tid; x < HC; x += kBlock) {
+        hkeys[x] = -1;
+        hvals[x] = INT_MAX;
+      }
       if (live) {
-        const int pr = a.pair_of[node];
+        const int pr = front_in_lds ? front[fcur][node - lo] : a.pair_of[node];
         n1 = pr % N1;
         n2 = pr / N1;
         o1 = out_adj(a.g1, n1);
@@ -312,9 +383,22 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         const bool acc1 = g_accept(a.g1, n1), acc2 = g_accept(a.g2, n2);
         eps1_ok = !em || acc2 || !acc1;  // compose.cpp:461
         eps2_ok = !em || acc1;           // compose.cpp:476
+        enum_matches(a, n1, n2, false, [&](int i, int j) { c.push(g_dst(a.g1, i) + N1 * g_dst(a.g2, j), i, j); });
+        if (eps1_ok) enum_eps(a.g1, o1, false, [&](int i) { c.push(a.g1.dst[i] + N1 * n2, i, -1); });
+        if (eps2_ok) enum_eps(a.g2, o2, true, [&](int j) { c.push(n1 + N1 * a.g2.dst[j], -1, j); });
+      }
+      // state of the cached candidates: independent loads, one round trip
+      int st[KC];
+#pragma unroll
+      for (int m = 0; m < KC; ++m) st[m] = (m < c.n && m < KC) ? ld_state(a.state + c.idx[m]) : ST_UNREACH;
+      int cnt = 0;
+      if (c.n <= KC) {
+#pragma unroll
+        for (int m = 0; m < KC; ++m) cnt += st[m] != ST_UNREACH;
+      } else {
+        // wide node (more than KC candidates): count by re-enumeration
         enum_matches(a, n1, n2, false, [&](int i, int j) {
-          const int idx = g_dst(a.g1, i) + N1 * g_dst(a.g2, j);
-          cnt += ld_state(a.state + idx) != ST_UNREACH;
+          cnt += ld_state(a.state + g_dst(a.g1, i) + N1 * g_dst(a.g2, j)) != ST_UNREACH;
         });
         if (eps1_ok)
           enum_eps(a.g1, o1, false, [&](int i) { cnt += ld_state(a.state + a.g1.dst[i] + N1 * n2) != ST_UNREACH; });
@@ -323,91 +407,242 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       }
       int total;
       const int off = block_excl_scan(cnt, sh_scan, total);
+      const bool fast = !__syncthreads_or(c.n > KC) && total <= HC / 2;
       if (na + total > a.Acap) {
         if (tid == 0) sh_flag[1] = 1;
         __syncthreads();
         break;
       }
-      if (live) {
-        a.out_off[node] = na + off;
-        int r = off;
-        auto emit = [&](int idx, int il, int ol, float w, int i, int j) {
-          const int cur = ld_state(a.state + idx);
-          if (cur == ST_UNREACH) return;
-          const int ai = na + r;
-          a.src[ai] = node;
-          a.dst[ai] = idx;  // patched to the node id below
-          a.il[ai] = il;
-          a.ol[ai] = ol;
-          a.w[ai] = w;
-          a.gi1[ai] = i;
-          a.gi2[ai] = j;
-          if (cur < 0) atomicMax(a.state + idx, claim_of(r));
-          ++r;
-        };
-        enum_matches(a, n1, n2, false, [&](int i, int j) {
-          emit(g_dst(a.g1, i) + N1 * g_dst(a.g2, j), g_il(a.g1, i), g_ol(a.g2, j), a.g1.w[i] + a.g2.w[j], i, j);
-        });
-        if (eps1_ok)
-          enum_eps(a.g1, o1, false, [&](int i) { emit(a.g1.dst[i] + N1 * n2, a.g1.il[i], EPS, a.g1.w[i], i, -1); });
-        if (eps2_ok)
-          enum_eps(a.g2, o2, true, [&](int j) { emit(n1 + N1 * a.g2.dst[j], EPS, a.g2.ol[j], a.g2.w[j], -1, j); });
-      }
-      __syncthreads();
-      // ---- first-touch ownership -> new node ids in arc order
+      if (live) a.out_off[node] = na + off;
       int newn = 0;
-      for (int r0 = 0; r0 < total; r0 += kBlock) {
-        const int r = r0 + tid;
-        int own = 0, idx = 0;
-        if (r < total) {
-          idx = a.dst[na + r];
-          own = ld_state(a.state + idx) == claim_of(r);
-        }
-        int t2;
-        const int rank = block_excl_scan(own, sh_scan, t2);
-        int id = -1;
-        if (own) {
-          id = nn + newn + rank;
-          if (id < a.Ncap) {
-            const int d1 = idx % N1, d2 = idx / N1;
-            a.pair_of[id] = idx;
-            a.nflags[id] = uint8_t(((g_start(a.g1, d1) && g_start(a.g2, d2)) ? NF_START : 0) |
-                                   ((g_accept(a.g1, d1) && g_accept(a.g2, d2)) ? NF_ACCEPT : 0));
-          } else {
-            sh_flag[1] = 1;
-            id = -1;
+      if (fast) {
+        // ---------------- fast chunk: claims / ids through the LDS hash
+        int slot[KC], rr[KC];
+        int k = 0;
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+          slot[m] = -1;
+          rr[m] = -1;
+          if (m < c.n && st[m] != ST_UNREACH) {
+            const int r = off + k++;
+            const int ai = na + r;
+            const int i = c.i[m], j = c.j[m];
+            float w;
+            int il, ol;
+            if (i >= 0 && j >= 0) {
+              il = g_il(a.g1, i); ol = g_ol(a.g2, j); w = a.g1.w[i] + a.g2.w[j];
+            } else if (j < 0) {
+              il = a.g1.il[i]; ol = EPS; w = a.g1.w[i];
+            } else {
+              il = EPS; ol = a.g2.ol[j]; w = a.g2.w[j];
+            }
+            a.src[ai] = node;
+            a.il[ai] = il;
+            a.ol[ai] = ol;
+            a.w[ai] = w;
+            a.gi1[ai] = i;
+            a.gi2[ai] = j;
+            rr[m] = r;
+            my_w[m] = w;
+            if (st[m] < 0) {  // co-reachable, not discovered yet: claim by smallest arc rank
+              unsigned h = (unsigned(c.idx[m]) * 2654435761u) >> 21;  // HC = 2^11
+              while (true) {
+                const int old = atomicCAS(&hkeys[h], -1, c.idx[m]);
+                if (old == -1 || old == c.idx[m]) break;
+                h = (h + 1) & (HC - 1);
+              }
+              atomicMin(&hvals[h], r);
+              slot[m] = int(h);
+            }
           }
         }
-        if (r < total) a.in_list[na + r] = id;  // scratch: in_list is built later
-        newn += t2;
+        __syncthreads();
+        int nown = 0;
+        bool own[KC];
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+          own[m] = slot[m] >= 0 && hvals[slot[m]] == rr[m];
+          nown += own[m];
+        }
+        int t2;
+        int rank = block_excl_scan(nown, sh_scan, t2);
+        newn = t2;
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+          if (own[m]) {
+            const int id = nn + rank++;
+            if (id < a.Ncap) {
+              const int idx = c.idx[m];
+              const int d1 = idx % N1, d2 = idx / N1;
+              hids[slot[m]] = id;
+              a.pair_of[id] = idx;
+              a.nflags[id] = uint8_t(((g_start(a.g1, d1) && g_start(a.g2, d2)) ? NF_START : 0) |
+                                     ((g_accept(a.g1, d1) && g_accept(a.g2, d2)) ? NF_ACCEPT : 0));
+              if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
+              st_state(a.state + idx, id);
+            } else {
+              hids[slot[m]] = 0;
+              sh_flag[1] = 1;
+            }
+          }
+        }
+        __syncthreads();
+        int lay = 1, csr_ok = 1;
+#pragma unroll
+        for (int m = 0; m < KC; ++m) {
+          my_dst[m] = -1;
+          my_ai[m] = -1;
+          if (rr[m] >= 0) {
+            const int id = slot[m] >= 0 ? hids[slot[m]] : st[m];
+            a.dst[na + rr[m]] = id;
+            if (id < hi) lay = 0;
+            else if (id - hi < WC) atomicAdd(&incnt[id - hi], 1);
+            else csr_ok = 0;
+            my_dst[m] = id;
+            my_ai[m] = na + rr[m];
+          }
+        }
+        if (!lay) sh_flag[0] = 0;
+        if (!lay || !csr_ok) sh_flag[2] = 0;
+      } else {
+        // ---------------- general chunk: claims through the global state table
+        fast_level = false;
+        if (live) {
+          int r = off;
+          auto emit = [&](int idx, int il, int ol, float w, int i, int j) {
+            const int cur = ld_state(a.state + idx);
+            if (cur == ST_UNREACH) return;
+            const int ai = na + r;
+            a.src[ai] = node;
+            a.dst[ai] = idx;  // patched to the node id below
+            a.il[ai] = il;
+            a.ol[ai] = ol;
+            a.w[ai] = w;
+            a.gi1[ai] = i;
+            a.gi2[ai] = j;
+            if (cur < 0) atomicMax(a.state + idx, claim_of(r));
+            ++r;
+          };
+          enum_matches(a, n1, n2, false, [&](int i, int j) {
+            emit(g_dst(a.g1, i) + N1 * g_dst(a.g2, j), g_il(a.g1, i), g_ol(a.g2, j), a.g1.w[i] + a.g2.w[j], i, j);
+          });
+          if (eps1_ok)
+            enum_eps(a.g1, o1, false, [&](int i) { emit(a.g1.dst[i] + N1 * n2, a.g1.il[i], EPS, a.g1.w[i], i, -1); });
+          if (eps2_ok)
+            enum_eps(a.g2, o2, true, [&](int j) { emit(n1 + N1 * a.g2.dst[j], EPS, a.g2.ol[j], a.g2.w[j], -1, j); });
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < total; r0 += kBlock) {
+          const int r = r0 + tid;
+          int own = 0, idx = 0;
+          if (r < total) {
+            idx = a.dst[na + r];
+            own = ld_state(a.state + idx) == claim_of(r);
+          }
+          int t2;
+          const int rank = block_excl_scan(own, sh_scan, t2);
+          int id = -1;
+          if (own) {
+            id = nn + newn + rank;
+            if (id < a.Ncap) {
+              const int d1 = idx % N1, d2 = idx / N1;
+              a.pair_of[id] = idx;
+              a.nflags[id] = uint8_t(((g_start(a.g1, d1) && g_start(a.g2, d2)) ? NF_START : 0) |
+                                     ((g_accept(a.g1, d1) && g_accept(a.g2, d2)) ? NF_ACCEPT : 0));
+              if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
+            } else {
+              sh_flag[1] = 1;
+              id = -1;
+            }
+          }
+          if (r < total) a.in_list[na + r] = id;  // scratch: in_list is built later
+          newn += t2;
+        }
+        __syncthreads();  // every ownership test has read its claim
+        for (int r = tid; r < total; r += kBlock) {
+          const int id = a.in_list[na + r];
+          if (id >= 0) st_state(a.state + a.dst[na + r], id);
+        }
+        __syncthreads();
+        int lay = 1, csr_ok = 1;
+        for (int r = tid; r < total; r += kBlock) {
+          const int id = ld_state(a.state + a.dst[na + r]);
+          a.dst[na + r] = id;
+          if (id < hi) lay = 0;
+          else if (id - hi < WC) atomicAdd(&incnt[id - hi], 1);
+          else csr_ok = 0;
+        }
+        if (!lay) sh_flag[0] = 0;
+        if (!lay || !csr_ok) sh_flag[2] = 0;
       }
-      __syncthreads();  // every ownership test has read its claim
-      for (int r = tid; r < total; r += kBlock) {
-        const int id = a.in_list[na + r];
-        if (id >= 0) st_state(a.state + a.dst[na + r], id);
-      }
-      __syncthreads();
-      int lay = 1;
-      for (int r = tid; r < total; r += kBlock) {
-        const int id = ld_state(a.state + a.dst[na + r]);
-        a.dst[na + r] = id;
-        if (id < hi) lay = 0;
-      }
-      if (!lay) sh_flag[0] = 0;
       na += total;
       nn += newn;
       __syncthreads();
     }
     if (sh_flag[1]) break;
+    // ---- fused in-arc CSR of the next level: rows of nodes [hi, nn) are exactly
+    // the arcs [na_level, na) when the product is layered.  Counts were taken in
+    // LDS above; one scan gives the row offsets, then arcs are placed (from
+    // registers when the level was a single fast chunk, else re-read from HBM).
+    {
+      const int W = nn - hi;
+      if (sh_flag[2] && W <= WC) {
+        constexpr int PER = WC / kBlock;
+        int loc[PER];
+        int sum = 0;
+#pragma unroll
+        for (int x = 0; x < PER; ++x) {
+          loc[x] = incnt[tid * PER + x];
+          sum += loc[x];
+        }
+        int tot;
+        int run = block_excl_scan(sum, sh_scan, tot);
+#pragma unroll
+        for (int x = 0; x < PER; ++x) {
+          const int nidx = tid * PER + x;
+          if (nidx < W) a.in_off[hi + nidx] = na_level + run;
+          incur[nidx] = na_level + run;
+          run += loc[x];
+          incnt[nidx] = 0;
+        }
+        __syncthreads();
+        if (single_chunk && fast_level) {
+#pragma unroll
+          for (int m = 0; m < KC; ++m) {
+            if (my_ai[m] >= 0) {
+              const int pos = atomicAdd(&incur[my_dst[m] - hi], 1);
+              a.in_list[pos] = my_ai[m];
+              a.in_src[pos] = lo + tid;
+              a.in_w[pos] = my_w[m];
+            }
+          }
+        } else {
+          for (int k = na_level + tid; k < na; k += kBlock) {
+            const int pos = atomicAdd(&incur[a.dst[k] - hi], 1);
+            a.in_list[pos] = k;
+            a.in_src[pos] = a.src[k];
+            a.in_w[pos] = a.w[k];
+          }
+        }
+      } else {
+        if (tid == 0) sh_flag[2] = 0;
+        for (int x = tid; x < WC; x += kBlock) incnt[x] = 0;
+      }
+    }
     max_level_arcs = max(max_level_arcs, na - na_level);
     lo = hi;
     hi = nn;
+    fcur ^= 1;
     ++L;
+    __syncthreads();
   }
   __syncthreads();
+  // ordered start / accept lists when the in-kernel CSR is valid: done by the
+  // (cheap, parallel) list kernel afterwards -- see tr_lists_kernel.
   if (tid == 0) {
     a.level_off[L] = nn;
     a.out_off[nn < a.Ncap + 1 ? nn : a.Ncap] = na;
+    a.in_off[nn < a.Ncap + 1 ? nn : a.Ncap] = na;
     ComposeOut o{};
     o.N = nn;
     o.A = na;
@@ -416,6 +651,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     o.overflow = sh_flag[1];
     o.max_width = max_width;
     o.max_level_arcs = max_level_arcs;
+    o.csr_built = sh_flag[2] && sh_flag[0];
     *a.out = o;
   }
 }
@@ -427,6 +663,7 @@ constexpr int kChunk = 2048;  // nodes per scan chunk
 
 __global__ void tr_count_kernel(const ComposeArgs* __restrict__ args) {
   const ComposeArgs a = args[blockIdx.y];
+  if (a.out->csr_built) return;  // rows were built inside compose_kernel
   const int A = a.out->A;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < A; k += gridDim.x * blockDim.x)
     atomicAdd(a.in_cursor + a.dst[k], 1);
@@ -477,7 +714,7 @@ __global__ void tr_chunk_scan_kernel(const ComposeArgs* __restrict__ args, int3*
     run.y += v.y;
     run.z += v.z;
   }
-  a.in_off[N] = run.x;
+  if (!a.out->csr_built) a.in_off[N] = run.x;
   a.counts[0] = run.y;
   a.counts[1] = run.z;
 }
@@ -504,8 +741,10 @@ __global__ __launch_bounds__(kBlock) void tr_offsets_kernel(const ComposeArgs* _
     const int os = block_excl_scan(s, sh_scan, ts);
     const int oa = block_excl_scan(ac, sh_scan, ta);
     if (n < N) {
-      a.in_off[n] = run.x + od;
-      a.in_cursor[n] = run.x + od;
+      if (!a.out->csr_built) {
+        a.in_off[n] = run.x + od;
+        a.in_cursor[n] = run.x + od;
+      }
       if (s) a.start_list[run.y + os] = n;
       if (ac) a.accept_list[run.z + oa] = n;
     }
@@ -517,6 +756,7 @@ __global__ __launch_bounds__(kBlock) void tr_offsets_kernel(const ComposeArgs* _
 
 __global__ void tr_scatter_kernel(const ComposeArgs* __restrict__ args) {
   const ComposeArgs a = args[blockIdx.y];
+  if (a.out->csr_built) return;
   const int A = a.out->A;
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < A; k += gridDim.x * blockDim.x) {
     const int pos = atomicAdd(a.in_cursor + a.dst[k], 1);

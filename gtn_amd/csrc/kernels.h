@@ -145,7 +145,7 @@ struct ComposeOut {
   int overflow;  // capacity exceeded (host bound was wrong) -- never expected
   int max_width;       // widest BFS level (nodes)
   int max_level_arcs;  // most arcs emitted by one level
-  int pad;
+  int csr_built;       // in_off / in_list / in_src / in_w were built inside compose_kernel
 };
 
 struct ComposeArgs {

@@ -51,3 +51,19 @@ def load_txt(text):
 
 
 __version__ = _lib.gtnx_version().decode()
+
+
+def _shutdown():
+    # orderly teardown before the HIP runtime's own exit handlers run: finish
+    # queued work and hand pooled device / pinned memory back
+    try:
+        _lib.gtnx_set_stream(None)
+        _lib.gtnx_synchronize()
+        _lib.gtnx_empty_cache()
+    except Exception:
+        pass
+
+
+import atexit as _atexit  # noqa: E402
+
+_atexit.register(_shutdown)

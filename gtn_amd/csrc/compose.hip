@@ -48,128 +48,186 @@ __device__ __forceinline__ void st_state(int* p, int v) {
 }
 
 // ---- graph accessors (explicit SoA/CSR or implicit linear chain) -------------
+// An adjacency entry is fetched as ONE record {ilabel, olabel, other node, arc id}:
+// host-built graphs carry packed 16-byte records in list order (out_rec / in_rec),
+// so walking a node's arcs is "offsets, then independent 16 B loads" -- a
+// dependent-load chain of depth 2 instead of list -> label -> node (depth 4),
+// which is what bounds a BFS level (every hop is an L1/L2 round trip).
+struct Rec {
+  int il, ol, node, arc;
+};
 struct Adj {
   int n;
   int base;
-  const int* list;
+  int node;
 };
+template <bool LIN>
 __device__ __forceinline__ Adj out_adj(const DGraph& g, int node) {
   Adj a;
-  if (g.kind == KIND_LINEAR) {
+  a.node = node;
+  if (LIN) {
     a.n = node < g.M ? g.C : 0;
     a.base = node * g.C;
-    a.list = nullptr;
   } else {
     a.base = g.out_off[node];
     a.n = g.out_off[node + 1] - a.base;
-    a.list = g.out_list;
   }
   return a;
 }
+template <bool LIN>
 __device__ __forceinline__ Adj in_adj(const DGraph& g, int node) {
   Adj a;
-  if (g.kind == KIND_LINEAR) {
+  a.node = node;
+  if (LIN) {
     a.n = node > 0 ? g.C : 0;
     a.base = (node - 1) * g.C;
-    a.list = nullptr;
   } else {
     a.base = g.in_off[node];
     a.n = g.in_off[node + 1] - a.base;
-    a.list = g.in_list;
   }
   return a;
 }
-__device__ __forceinline__ int adj_arc(const Adj& a, int k) { return a.list ? a.list[a.base + k] : a.base + k; }
-__device__ __forceinline__ int g_il(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc % g.C : g.il[arc]; }
-__device__ __forceinline__ int g_ol(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc % g.C : g.ol[arc]; }
-__device__ __forceinline__ int g_src(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc / g.C : g.src[arc]; }
-__device__ __forceinline__ int g_dst(const DGraph& g, int arc) { return g.kind == KIND_LINEAR ? arc / g.C + 1 : g.dst[arc]; }
-__device__ __forceinline__ bool g_start(const DGraph& g, int n) {
-  return g.kind == KIND_LINEAR ? n == 0 : (g.nflags[n] & NF_START) != 0;
-}
-__device__ __forceinline__ bool g_accept(const DGraph& g, int n) {
-  return g.kind == KIND_LINEAR ? (g.M > 0 && n == g.M) : (g.nflags[n] & NF_ACCEPT) != 0;
-}
-__device__ __forceinline__ int g_start_at(const DGraph& g, int k) { return g.kind == KIND_LINEAR ? 0 : g.start_list[k]; }
-__device__ __forceinline__ int g_accept_at(const DGraph& g, int k) { return g.kind == KIND_LINEAR ? g.M : g.accept_list[k]; }
-
-// ---- matcher: calls f(i, j) for every pair of arcs (i of g1, j of g2) leaving
-// (use_in: entering) the node pair with olabel1(i) == ilabel2(j), in the
-// reference's order: "for q in query list: for s in the equal-label run of the
-// search list" (compose.cpp:211-374; roles per matcher as in functions.cpp:225-251).
-template <class F>
-__device__ __forceinline__ void enum_matches(const ComposeArgs& a, int n1, int n2, bool use_in, F&& f) {
-  const Adj l1 = use_in ? in_adj(a.g1, n1) : out_adj(a.g1, n1);
-  const Adj l2 = use_in ? in_adj(a.g2, n2) : out_adj(a.g2, n2);
-  bool search_g1, sorted;
-  switch (a.matcher) {
-    case MATCH_UNSORTED: search_g1 = false; sorted = false; break;
-    case MATCH_SINGLY_G1: search_g1 = true; sorted = true; break;
-    case MATCH_SINGLY_G2: search_g1 = false; sorted = true; break;
-    default: search_g1 = l1.n > l2.n; sorted = true; break;  // compose.cpp:319
+template <bool IN, bool LIN>
+__device__ __forceinline__ Rec adj_rec(const DGraph& g, const Adj& a, int k) {
+  Rec r;
+  if (LIN) {
+    r.il = r.ol = k;
+    r.arc = a.base + k;
+    r.node = IN ? a.node - 1 : a.node + 1;
+    return r;
   }
-  const DGraph& gs = search_g1 ? a.g1 : a.g2;
-  const Adj q = search_g1 ? l2 : l1;
-  const Adj s = search_g1 ? l1 : l2;
-  for (int qi = 0; qi < q.n; ++qi) {
-    const int qa = adj_arc(q, qi);
-    const int ql = search_g1 ? g_il(a.g2, qa) : g_ol(a.g1, qa);
-    if (!use_in && ql == EPS) continue;  // direct eps:eps matches are skipped (compose.cpp:425-428)
-    if (gs.kind == KIND_LINEAR) {
-      if (ql >= 0 && ql < gs.C) {
-        const int sa = s.base + ql;
-        if (s.n > 0) {
-          if (search_g1) f(sa, qa); else f(qa, sa);
-        }
+  const GTNX_G int4* recs = IN ? g.in_rec : g.out_rec;
+  if (recs) {
+    const int4 v = recs[a.base + k];
+    r.il = v.x; r.ol = v.y; r.node = v.z; r.arc = v.w;
+    return r;
+  }
+  const GTNX_G int* list = IN ? g.in_list : g.out_list;
+  r.arc = list ? list[a.base + k] : a.base + k;
+  r.il = g.il[r.arc];
+  r.ol = g.ol[r.arc];
+  r.node = IN ? g.src[r.arc] : g.dst[r.arc];
+  return r;
+}
+template <bool LIN>
+__device__ __forceinline__ bool g_start(const DGraph& g, int n) {
+  return LIN ? n == 0 : (g.nflags[n] & NF_START) != 0;
+}
+template <bool LIN>
+__device__ __forceinline__ bool g_accept(const DGraph& g, int n) {
+  return LIN ? (g.M > 0 && n == g.M) : (g.nflags[n] & NF_ACCEPT) != 0;
+}
+template <bool LIN>
+__device__ __forceinline__ int g_start_at(const DGraph& g, int k) { return LIN ? 0 : g.start_list[k]; }
+template <bool LIN>
+__device__ __forceinline__ int g_accept_at(const DGraph& g, int k) { return LIN ? g.M : g.accept_list[k]; }
+
+// ---- matcher: calls f(r1, r2) for every pair of arcs (r1 of g1, r2 of g2) leaving
+// (IN: entering) the node pair with olabel1 == ilabel2, in the reference's order:
+// "for q in query list: for s in the equal-label run of the search list"
+// (compose.cpp:211-374; roles per matcher as in functions.cpp:225-251).
+template <bool IN, int MATCH, bool L1, bool L2, bool SG1, class F>
+__device__ __forceinline__ void enum_matches_role(const ComposeArgs& a, const Adj& l1, const Adj& l2, F&& f) {
+  // SG1: the search side is g1 (query = g2); all roles resolved at compile time
+  constexpr bool sorted = MATCH != MATCH_UNSORTED;
+  constexpr bool LQ = SG1 ? L2 : L1, LS = SG1 ? L1 : L2;
+  const DGraph& gq = SG1 ? a.g2 : a.g1;
+  const DGraph& gs = SG1 ? a.g1 : a.g2;
+  const Adj q = SG1 ? l2 : l1;
+  const Adj s = SG1 ? l1 : l2;
+  auto one_query = [&](const Rec& qr) {
+    const int ql = SG1 ? qr.il : qr.ol;
+    if (!IN && ql == EPS) return;  // direct eps:eps matches are skipped (compose.cpp:425-428)
+    if (LS) {
+      if (ql >= 0 && ql < gs.C && s.n > 0) {
+        const Rec sr = adj_rec<IN, true>(gs, s, ql);
+        if (SG1) f(sr, qr); else f(qr, sr);
       }
     } else if (sorted) {
       int lo = 0, hi = s.n;
       while (lo < hi) {  // std::lower_bound
         const int mid = (lo + hi) >> 1;
-        const int sk = search_g1 ? gs.ol[adj_arc(s, mid)] : gs.il[adj_arc(s, mid)];
-        if (sk < ql) lo = mid + 1; else hi = mid;
+        const Rec m = adj_rec<IN, false>(gs, s, mid);
+        if ((SG1 ? m.ol : m.il) < ql) lo = mid + 1; else hi = mid;
       }
       for (int k = lo; k < s.n; ++k) {
-        const int sa = adj_arc(s, k);
-        const int sk = search_g1 ? gs.ol[sa] : gs.il[sa];
-        if (sk != ql) break;
-        if (search_g1) f(sa, qa); else f(qa, sa);
+        const Rec sr = adj_rec<IN, false>(gs, s, k);
+        if ((SG1 ? sr.ol : sr.il) != ql) break;
+        if (SG1) f(sr, qr); else f(qr, sr);
       }
     } else {
       for (int k = 0; k < s.n; ++k) {
-        const int sa = adj_arc(s, k);
-        const int sk = search_g1 ? gs.ol[sa] : gs.il[sa];
-        if (sk == ql) {
-          if (search_g1) f(sa, qa); else f(qa, sa);
+        const Rec sr = adj_rec<IN, false>(gs, s, k);
+        if ((SG1 ? sr.ol : sr.il) == ql) {
+          if (SG1) f(sr, qr); else f(qr, sr);
         }
       }
     }
+  };
+  // the first four query records are fetched together (independent loads)
+  Rec q4[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < q.n) q4[k] = adj_rec<IN, LQ>(gq, q, k);
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (k < q.n) one_query(q4[k]);
+  for (int k = 4; k < q.n; ++k) one_query(adj_rec<IN, LQ>(gq, q, k));
+}
+
+template <bool IN, int MATCH, bool L1, bool L2, class F>
+__device__ __forceinline__ void enum_matches(const ComposeArgs& a, int n1, int n2, F&& f) {
+  const Adj l1 = IN ? in_adj<L1>(a.g1, n1) : out_adj<L1>(a.g1, n1);
+  const Adj l2 = IN ? in_adj<L2>(a.g2, n2) : out_adj<L2>(a.g2, n2);
+  if (MATCH == MATCH_SINGLY_G1) {
+    enum_matches_role<IN, MATCH, L1, L2, true>(a, l1, l2, f);
+  } else if (MATCH == MATCH_DOUBLY) {
+    if (l1.n > l2.n)  // compose.cpp:319
+      enum_matches_role<IN, MATCH, L1, L2, true>(a, l1, l2, f);
+    else
+      enum_matches_role<IN, MATCH, L1, L2, false>(a, l1, l2, f);
+  } else {
+    enum_matches_role<IN, MATCH, L1, L2, false>(a, l1, l2, f);
   }
 }
 
 // epsilon arcs of one side's list: g1 arcs with olabel eps / g2 arcs with ilabel eps
-template <class F>
+template <bool IN, bool LIN, class F>
 __device__ __forceinline__ void enum_eps(const DGraph& g, const Adj& l, bool second, F&& f) {
-  if (g.kind == KIND_LINEAR) return;
+  if (LIN) return;
   const bool sorted = second ? (g.flags & 1) : (g.flags & 2);
   for (int k = 0; k < l.n; ++k) {
-    const int arc = adj_arc(l, k);
-    const int label = second ? g.il[arc] : g.ol[arc];
-    if (label != EPS) {
+    const Rec r = adj_rec<IN, false>(g, l, k);
+    if ((second ? r.il : r.ol) != EPS) {
       if (sorted) break;  // eps sorts first (compose.cpp:36-41, 169-176)
       continue;
     }
-    f(arc);
+    f(r);
   }
 }
+template <bool LIN>
 __device__ __forceinline__ bool has_eps(const DGraph& g, const Adj& l, bool second) {
+  if (LIN || l.n == 0) return false;
+  const bool sorted = second ? (g.flags & 1) : (g.flags & 2);
+  if (sorted) {  // eps (-1) sorts first: one record decides
+    const Rec r = adj_rec<false, false>(g, l, 0);
+    return (second ? r.il : r.ol) == EPS;
+  }
   bool r = false;
-  enum_eps(g, l, second, [&](int) { r = true; });
+  enum_eps<false, false>(g, l, second, [&](const Rec&) { r = true; });
   return r;
 }
 
 // ---- workgroup exclusive scan (wave64 shuffles + one LDS hop) -------------------
-__device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int& total) {
+// Workgroup barrier ordering LDS traffic only (see shortest.hip): __syncthreads()
+// also drains vmcnt, i.e. waits for every global store issued so far -- a full
+// HBM round trip per barrier in a kernel that stores at every BFS level.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wg_barrier(bool lds_only) {
+  if (lds_only) lds_barrier(); else __syncthreads();
+}
+
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int& total, bool lds_only = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int x = v;
 #pragma unroll
@@ -177,9 +235,9 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int
     const int y = __shfl_up(x, o, 64);
     if (lane >= o) x += y;
   }
-  __syncthreads();  // protect sh from a previous use
+  wg_barrier(lds_only);  // protect sh from a previous use
   if (lane == 63) sh[wave] = x;
-  __syncthreads();
+  wg_barrier(lds_only);
   int base = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < kBlock / 64; ++w) {
@@ -198,24 +256,30 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int
 // arc rank / assigned id), the next frontier's pair ids, and per-level in-degree
 // counters + cursors for the fused in-arc CSR.
 constexpr int KC = 4;      // candidates cached per lane (registers)
-constexpr int HC = 2048;   // claim-hash slots per chunk (<= HC/2 arcs per chunk)
-constexpr int FC = 1024;   // frontier pairs kept in LDS per level
-constexpr int WC = 2048;   // new nodes per level whose in-rows are built in LDS
-constexpr int BQ = 2048;   // backward-BFS frontier pairs kept in LDS per level
+constexpr int HC = 1024;   // claim-hash slots per chunk (<= 3/4 HC arcs per chunk)
+constexpr int HC_LOG2 = 10;
+constexpr int FC = 512;    // frontier pairs kept in LDS per level
+constexpr int WC = 1024;   // new nodes per level whose in-rows are built in LDS
+constexpr int BQ = HC;     // backward-BFS frontier pairs kept in LDS per level
+// When the pair table is small (2 * N1*N2 bits fit the dynamic LDS request) the
+// co-reachability bitmap and a "discovered" bitmap live in LDS for the whole
+// kernel: phase B then runs without any HBM traffic on its critical path and
+// phase F consults HBM `state` only for pairs discovered in an earlier level.
+constexpr int kMaxBitmapBytes = 2 * 26624;  // both bitmaps; keeps 2 workgroups per CU
 
 struct Cand {
-  int idx[KC], i[KC], j[KC];
+  int idx[KC], i[KC], j[KC], il[KC], ol[KC];
   int n;
-  __device__ __forceinline__ void push(int id, int ai, int aj) {
+  __device__ __forceinline__ void push(int id, int ai, int aj, int l_in = 0, int l_out = 0) {
     // select chain instead of dynamic indexing keeps everything in registers
-    if (n == 0) { idx[0] = id; i[0] = ai; j[0] = aj; }
-    else if (n == 1) { idx[1] = id; i[1] = ai; j[1] = aj; }
-    else if (n == 2) { idx[2] = id; i[2] = ai; j[2] = aj; }
-    else if (n == 3) { idx[3] = id; i[3] = ai; j[3] = aj; }
+#pragma unroll
+    for (int m = 0; m < KC; ++m)
+      if (n == m) { idx[m] = id; i[m] = ai; j[m] = aj; il[m] = l_in; ol[m] = l_out; }
     ++n;
   }
 };
 
+template <int MATCH, bool L1, bool L2>
 __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __restrict__ args) {
   const ComposeArgs a = args[blockIdx.x];
   const int tid = threadIdx.x;
@@ -229,13 +293,18 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   __shared__ int front[2][FC];   // also the backward queue (2 x BQ/2 ... see below)
   __shared__ int incnt[WC];
   __shared__ int incur[WC];
+  extern __shared__ __attribute__((aligned(16))) unsigned dyn_bits[];
+  const int nwords = (N1 * N2 + 31) >> 5;
+  const bool lds_state = a.lds_state != 0;
+  unsigned* reach_bits = dyn_bits;
+  unsigned* disc_bits = dyn_bits + nwords;
 
   if (tid == 0) {
     sh_tail = 0;
     sh_flag[0] = 1;  // layered
     sh_flag[1] = 0;  // overflow
     sh_flag[2] = 1;  // in-CSR built in-kernel is valid
-    sh_flag[3] = 0;
+    sh_flag[3] = 0;  // per-chunk: bit0 wide node, bit1 discovered-pair lookup
   }
   __syncthreads();
   if (N1 == 0 || N2 == 0) {
@@ -261,57 +330,97 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     auto bq = [&](int b) -> int* { return b ? hvals : hkeys; };
     const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
     const int seeds = na1 * na2;
+    if (lds_state) {
+      for (int x = tid; x < 2 * nwords; x += kBlock) dyn_bits[x] = 0u;
+      __syncthreads();
+    }
     for (int t = tid; t < seeds; t += kBlock) {
-      const int f = g_accept_at(a.g1, t / na2), s = g_accept_at(a.g2, t % na2);
+      const int f = g_accept_at<L1>(a.g1, t / na2), s = g_accept_at<L2>(a.g2, t % na2);
       const int idx = f + N1 * s;
-      st_state(a.state + idx, ST_REACH);
-      a.queue[t] = idx;
-      if (t < BQ) bq(0)[t] = idx;
+      if (lds_state) atomicOr(&reach_bits[idx >> 5], 1u << (idx & 31));
+      else st_state(a.state + idx, ST_REACH);
+      if (t < BQ) bq(0)[t] = idx; else a.queue[t] = idx;
     }
     if (tid == 0) sh_tail = seeds;
     __syncthreads();
     int lo = 0, hi = seeds, cur = 0;
     auto mark = [&](int idx, int nxt) {
-      if (atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH) {
+      const bool fresh = lds_state ? !(atomicOr(&reach_bits[idx >> 5], 1u << (idx & 31)) & (1u << (idx & 31)))
+                                   : atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH;
+      if (fresh) {
         const int pos = atomicAdd(&sh_tail, 1);
-        a.queue[pos] = idx;
-        if (pos - hi < BQ) bq(nxt)[pos - hi] = idx;
+        if (pos - hi < BQ) bq(nxt)[pos - hi] = idx; else a.queue[pos] = idx;
       }
     };
+#ifdef GTNX_TIMING
+    long long t_enum = 0, t_mark = 0, t_bar = 0, t0, t1; int nlev = 0;
+#endif
     while (lo < hi) {
-      const bool in_lds = (hi - lo) <= BQ;
+#ifdef GTNX_TIMING
+      t0 = wall_clock64(); ++nlev;
+#endif
       for (int f = lo + tid; f < hi; f += kBlock) {
-        const int idx = in_lds ? bq(cur)[f - lo] : a.queue[f];
+        const int idx = (f - lo) < BQ ? bq(cur)[f - lo] : a.queue[f];
         const int n1 = idx % N1, n2 = idx / N1;
         Cand c;
         c.n = 0;
-        enum_matches(a, n1, n2, true, [&](int i, int j) { c.push(g_src(a.g1, i) + N1 * g_src(a.g2, j), 0, 0); });
-        enum_eps(a.g1, in_adj(a.g1, n1), false, [&](int i) { c.push(a.g1.src[i] + N1 * n2, 0, 0); });
-        enum_eps(a.g2, in_adj(a.g2, n2), true, [&](int j) { c.push(n1 + N1 * a.g2.src[j], 0, 0); });
+        enum_matches<true, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) { c.push(r1.node + N1 * r2.node, 0, 0); });
+        enum_eps<true, L1>(a.g1, in_adj<L1>(a.g1, n1), false, [&](const Rec& r) { c.push(r.node + N1 * n2, 0, 0); });
+        enum_eps<true, L2>(a.g2, in_adj<L2>(a.g2, n2), true, [&](const Rec& r) { c.push(n1 + N1 * r.node, 0, 0); });
+#ifdef GTNX_TIMING
+        t1 = wall_clock64(); t_enum += t1 - t0; t0 = t1;
+#endif
         if (c.n <= KC) {
           int st[KC];
 #pragma unroll
-          for (int m = 0; m < KC; ++m) st[m] = m < c.n ? ld_state(a.state + c.idx[m]) : 0;
+          for (int m = 0; m < KC; ++m) {
+            if (m >= c.n) st[m] = 0;
+            else if (lds_state) st[m] = ((reach_bits[c.idx[m] >> 5] >> (c.idx[m] & 31)) & 1u) ? 0 : ST_UNREACH;
+            else st[m] = ld_state(a.state + c.idx[m]);
+          }
 #pragma unroll
           for (int m = 0; m < KC; ++m)
             if (m < c.n && st[m] == ST_UNREACH) mark(c.idx[m], cur ^ 1);
         } else {
           auto slow = [&](int id) {
-            if (ld_state(a.state + id) == ST_UNREACH) mark(id, cur ^ 1);
+            const bool un = lds_state ? !((reach_bits[id >> 5] >> (id & 31)) & 1u)
+                                      : ld_state(a.state + id) == ST_UNREACH;
+            if (un) mark(id, cur ^ 1);
           };
-          enum_matches(a, n1, n2, true, [&](int i, int j) { slow(g_src(a.g1, i) + N1 * g_src(a.g2, j)); });
-          enum_eps(a.g1, in_adj(a.g1, n1), false, [&](int i) { slow(a.g1.src[i] + N1 * n2); });
-          enum_eps(a.g2, in_adj(a.g2, n2), true, [&](int j) { slow(n1 + N1 * a.g2.src[j]); });
+          enum_matches<true, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) { slow(r1.node + N1 * r2.node); });
+          enum_eps<true, L1>(a.g1, in_adj<L1>(a.g1, n1), false, [&](const Rec& r) { slow(r.node + N1 * n2); });
+          enum_eps<true, L2>(a.g2, in_adj<L2>(a.g2, n2), true, [&](const Rec& r) { slow(n1 + N1 * r.node); });
         }
       }
-      __syncthreads();
+#ifdef GTNX_TIMING
+      t1 = wall_clock64(); t_mark += t1 - t0; t0 = t1;
+#endif
+      // LDS-only barrier when nothing this level communicated through HBM
+      wg_barrier(lds_state);
       lo = hi;
       hi = sh_tail;
       cur ^= 1;
-      __syncthreads();
+      wg_barrier(lds_state && (hi - lo) <= BQ);
+#ifdef GTNX_TIMING
+      t1 = wall_clock64(); t_bar += t1 - t0;
+#endif
     }
+#ifdef GTNX_TIMING
+    if (blockIdx.x == 0 && tid == 0)
+      printf("B-phase: levels %d  enum %lld  mark %lld  barrier %lld (100MHz ticks)\n", nlev, t_enum, t_mark, t_bar);
+#endif
   }
 
+  if (lds_state) {
+    // publish the co-reachability table for the general (HBM) code paths of phase F
+    for (int x = tid; x < N1 * N2; x += kBlock)
+      a.state[x] = ((reach_bits[x >> 5] >> (x & 31)) & 1u) ? ST_REACH : ST_UNREACH;
+    __syncthreads();
+  }
+  if (a.matcher & 0x100) {  // debug: stop after phase B (timing experiments only)
+    if (tid == 0) { ComposeOut o{}; o.layered = 1; o.csr_built = 1; *a.out = o; a.counts[0] = a.counts[1] = 0; }
+    return;
+  }
   // ------------------------------------------------------------------ phase F
   int nn = 0, na = 0;
   {
@@ -322,8 +431,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       const int t = t0 + tid;
       int idx = 0, ok = 0, s1 = 0, s2 = 0;
       if (t < seeds) {
-        s1 = g_start_at(a.g1, t / ns2);
-        s2 = g_start_at(a.g2, t % ns2);
+        s1 = g_start_at<L1>(a.g1, t / ns2);
+        s2 = g_start_at<L2>(a.g2, t % ns2);
         idx = s1 + N1 * s2;
         ok = ld_state(a.state + idx) == ST_REACH;
       }
@@ -333,9 +442,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         const int id = nn + off;
         if (id < a.Ncap) {
           a.pair_of[id] = idx;
-          a.nflags[id] = uint8_t(NF_START | ((g_accept(a.g1, s1) && g_accept(a.g2, s2)) ? NF_ACCEPT : 0));
+          a.nflags[id] = uint8_t(NF_START | ((g_accept<L1>(a.g1, s1) && g_accept<L2>(a.g2, s2)) ? NF_ACCEPT : 0));
           a.in_off[id] = 0;  // level 0 has no in-arcs in a layered product
           if (id < FC) front[0][id] = idx;
+          if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
           st_state(a.state + idx, id);
         } else {
           sh_flag[1] = 1;
@@ -376,38 +486,66 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         const int pr = front_in_lds ? front[fcur][node - lo] : a.pair_of[node];
         n1 = pr % N1;
         n2 = pr / N1;
-        o1 = out_adj(a.g1, n1);
-        o2 = out_adj(a.g2, n2);
+        o1 = out_adj<L1>(a.g1, n1);
+        o2 = out_adj<L2>(a.g2, n2);
         // epsilon_matched <=> some (i, j) with olabel1(i) == ilabel2(j) == eps
-        const bool em = has_eps(a.g1, o1, false) && has_eps(a.g2, o2, true);
-        const bool acc1 = g_accept(a.g1, n1), acc2 = g_accept(a.g2, n2);
+        const bool em = has_eps<L1>(a.g1, o1, false) && has_eps<L2>(a.g2, o2, true);
+        const bool acc1 = g_accept<L1>(a.g1, n1), acc2 = g_accept<L2>(a.g2, n2);
         eps1_ok = !em || acc2 || !acc1;  // compose.cpp:461
         eps2_ok = !em || acc1;           // compose.cpp:476
-        enum_matches(a, n1, n2, false, [&](int i, int j) { c.push(g_dst(a.g1, i) + N1 * g_dst(a.g2, j), i, j); });
-        if (eps1_ok) enum_eps(a.g1, o1, false, [&](int i) { c.push(a.g1.dst[i] + N1 * n2, i, -1); });
-        if (eps2_ok) enum_eps(a.g2, o2, true, [&](int j) { c.push(n1 + N1 * a.g2.dst[j], -1, j); });
+        enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
+          c.push(r1.node + N1 * r2.node, r1.arc, r2.arc, r1.il, r2.ol);
+        });
+        if (eps1_ok) enum_eps<false, L1>(a.g1, o1, false, [&](const Rec& r) { c.push(r.node + N1 * n2, r.arc, -1, r.il, EPS); });
+        if (eps2_ok) enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { c.push(n1 + N1 * r.node, -1, r.arc, EPS, r.ol); });
       }
-      // state of the cached candidates: independent loads, one round trip
+      // state of the cached candidates.  With the bitmaps in LDS no HBM access is
+      // needed unless a candidate pair was already discovered (non-layered arcs or
+      // an earlier chunk of this level): then -- and only then -- the workgroup
+      // drains its stores (full barrier) and reads the id from the HBM table.
       int st[KC];
+      bool hit = false;
 #pragma unroll
-      for (int m = 0; m < KC; ++m) st[m] = (m < c.n && m < KC) ? ld_state(a.state + c.idx[m]) : ST_UNREACH;
+      for (int m = 0; m < KC; ++m) {
+        if (m >= c.n) {
+          st[m] = ST_UNREACH;
+        } else if (lds_state) {
+          const unsigned bit = 1u << (c.idx[m] & 31);
+          const int wd = c.idx[m] >> 5;
+          st[m] = !(reach_bits[wd] & bit) ? ST_UNREACH : ((disc_bits[wd] & bit) ? 0 : ST_REACH);
+          hit = hit || st[m] == 0;
+        } else {
+          st[m] = ld_state(a.state + c.idx[m]);
+        }
+      }
+      if (c.n > KC) atomicOr(&sh_flag[3], 1);
+      if (hit) atomicOr(&sh_flag[3], 2);
+      wg_barrier(lds_state);
+      const int chunk_flags = sh_flag[3];
+      if (chunk_flags & 2) {
+        __syncthreads();  // every earlier st_state() of this workgroup has landed
+#pragma unroll
+        for (int m = 0; m < KC; ++m)
+          if (m < c.n && st[m] == 0) st[m] = ld_state(a.state + c.idx[m]);
+      }
       int cnt = 0;
       if (c.n <= KC) {
 #pragma unroll
         for (int m = 0; m < KC; ++m) cnt += st[m] != ST_UNREACH;
       } else {
-        // wide node (more than KC candidates): count by re-enumeration
-        enum_matches(a, n1, n2, false, [&](int i, int j) {
-          cnt += ld_state(a.state + g_dst(a.g1, i) + N1 * g_dst(a.g2, j)) != ST_UNREACH;
+        // wide node (more than KC candidates): count by re-enumeration (HBM table)
+        enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
+          cnt += ld_state(a.state + r1.node + N1 * r2.node) != ST_UNREACH;
         });
         if (eps1_ok)
-          enum_eps(a.g1, o1, false, [&](int i) { cnt += ld_state(a.state + a.g1.dst[i] + N1 * n2) != ST_UNREACH; });
+          enum_eps<false, L1>(a.g1, o1, false, [&](const Rec& r) { cnt += ld_state(a.state + r.node + N1 * n2) != ST_UNREACH; });
         if (eps2_ok)
-          enum_eps(a.g2, o2, true, [&](int j) { cnt += ld_state(a.state + n1 + N1 * a.g2.dst[j]) != ST_UNREACH; });
+          enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { cnt += ld_state(a.state + n1 + N1 * r.node) != ST_UNREACH; });
       }
       int total;
-      const int off = block_excl_scan(cnt, sh_scan, total);
-      const bool fast = !__syncthreads_or(c.n > KC) && total <= HC / 2;
+      const int off = block_excl_scan(cnt, sh_scan, total, lds_state);
+      const bool fast = !(chunk_flags & 1) && total <= (HC * 3) / 4;
+      if (!fast) __syncthreads();  // the general path below goes through HBM
       if (na + total > a.Acap) {
         if (tid == 0) sh_flag[1] = 1;
         __syncthreads();
@@ -427,15 +565,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             const int r = off + k++;
             const int ai = na + r;
             const int i = c.i[m], j = c.j[m];
-            float w;
-            int il, ol;
-            if (i >= 0 && j >= 0) {
-              il = g_il(a.g1, i); ol = g_ol(a.g2, j); w = a.g1.w[i] + a.g2.w[j];
-            } else if (j < 0) {
-              il = a.g1.il[i]; ol = EPS; w = a.g1.w[i];
-            } else {
-              il = EPS; ol = a.g2.ol[j]; w = a.g2.w[j];
-            }
+            const int il = c.il[m], ol = c.ol[m];
+            const float w = (i >= 0 ? a.g1.w[i] : 0.0f) + (j >= 0 ? a.g2.w[j] : 0.0f);
             a.src[ai] = node;
             a.il[ai] = il;
             a.ol[ai] = ol;
@@ -445,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             rr[m] = r;
             my_w[m] = w;
             if (st[m] < 0) {  // co-reachable, not discovered yet: claim by smallest arc rank
-              unsigned h = (unsigned(c.idx[m]) * 2654435761u) >> 21;  // HC = 2^11
+              unsigned h = (unsigned(c.idx[m]) * 2654435761u) >> (32 - HC_LOG2);
               while (true) {
                 const int old = atomicCAS(&hkeys[h], -1, c.idx[m]);
                 if (old == -1 || old == c.idx[m]) break;
@@ -456,7 +587,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             }
           }
         }
-        __syncthreads();
+        wg_barrier(lds_state);
         int nown = 0;
         bool own[KC];
 #pragma unroll
@@ -465,7 +596,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           nown += own[m];
         }
         int t2;
-        int rank = block_excl_scan(nown, sh_scan, t2);
+        int rank = block_excl_scan(nown, sh_scan, t2, lds_state);
         newn = t2;
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
@@ -476,9 +607,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
               const int d1 = idx % N1, d2 = idx / N1;
               hids[slot[m]] = id;
               a.pair_of[id] = idx;
-              a.nflags[id] = uint8_t(((g_start(a.g1, d1) && g_start(a.g2, d2)) ? NF_START : 0) |
-                                     ((g_accept(a.g1, d1) && g_accept(a.g2, d2)) ? NF_ACCEPT : 0));
+              a.nflags[id] = uint8_t(((g_start<L1>(a.g1, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
+                                     ((g_accept<L1>(a.g1, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
               if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
+              if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
               st_state(a.state + idx, id);
             } else {
               hids[slot[m]] = 0;
@@ -486,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             }
           }
         }
-        __syncthreads();
+        wg_barrier(lds_state);
         int lay = 1, csr_ok = 1;
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
@@ -523,13 +655,13 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             if (cur < 0) atomicMax(a.state + idx, claim_of(r));
             ++r;
           };
-          enum_matches(a, n1, n2, false, [&](int i, int j) {
-            emit(g_dst(a.g1, i) + N1 * g_dst(a.g2, j), g_il(a.g1, i), g_ol(a.g2, j), a.g1.w[i] + a.g2.w[j], i, j);
+          enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
+            emit(r1.node + N1 * r2.node, r1.il, r2.ol, a.g1.w[r1.arc] + a.g2.w[r2.arc], r1.arc, r2.arc);
           });
           if (eps1_ok)
-            enum_eps(a.g1, o1, false, [&](int i) { emit(a.g1.dst[i] + N1 * n2, a.g1.il[i], EPS, a.g1.w[i], i, -1); });
+            enum_eps<false, L1>(a.g1, o1, false, [&](const Rec& r) { emit(r.node + N1 * n2, r.il, EPS, a.g1.w[r.arc], r.arc, -1); });
           if (eps2_ok)
-            enum_eps(a.g2, o2, true, [&](int j) { emit(n1 + N1 * a.g2.dst[j], EPS, a.g2.ol[j], a.g2.w[j], -1, j); });
+            enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { emit(n1 + N1 * r.node, EPS, r.ol, a.g2.w[r.arc], -1, r.arc); });
         }
         __syncthreads();
         for (int r0 = 0; r0 < total; r0 += kBlock) {
@@ -547,9 +679,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             if (id < a.Ncap) {
               const int d1 = idx % N1, d2 = idx / N1;
               a.pair_of[id] = idx;
-              a.nflags[id] = uint8_t(((g_start(a.g1, d1) && g_start(a.g2, d2)) ? NF_START : 0) |
-                                     ((g_accept(a.g1, d1) && g_accept(a.g2, d2)) ? NF_ACCEPT : 0));
+              a.nflags[id] = uint8_t(((g_start<L1>(a.g1, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
+                                     ((g_accept<L1>(a.g1, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
               if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
+              if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
             } else {
               sh_flag[1] = 1;
               id = -1;
@@ -577,7 +710,9 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       }
       na += total;
       nn += newn;
-      __syncthreads();
+      if (tid == 0) sh_flag[3] = 0;
+      // a later chunk of the SAME level may look up ids this chunk stored in HBM
+      wg_barrier(lds_state && single_chunk && fast);
     }
     if (sh_flag[1]) break;
     // ---- fused in-arc CSR of the next level: rows of nodes [hi, nn) are exactly
@@ -596,7 +731,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           sum += loc[x];
         }
         int tot;
-        int run = block_excl_scan(sum, sh_scan, tot);
+        int run = block_excl_scan(sum, sh_scan, tot, lds_state);
 #pragma unroll
         for (int x = 0; x < PER; ++x) {
           const int nidx = tid * PER + x;
@@ -605,8 +740,9 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           run += loc[x];
           incnt[nidx] = 0;
         }
-        __syncthreads();
-        if (single_chunk && fast_level) {
+        const bool from_regs = single_chunk && fast_level;
+        wg_barrier(lds_state && from_regs);  // the re-read path needs this level's stores
+        if (from_regs) {
 #pragma unroll
           for (int m = 0; m < KC; ++m) {
             if (my_ai[m] >= 0) {
@@ -634,7 +770,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     hi = nn;
     fcur ^= 1;
     ++L;
-    __syncthreads();
+    // next level reads its frontier from LDS when it fits, else pair_of in HBM
+    wg_barrier(lds_state && (hi - lo) <= FC);
   }
   __syncthreads();
   // ordered start / accept lists when the in-kernel CSR is valid: done by the
@@ -841,8 +978,41 @@ int grid_x(int n, int cap) {
 
 } // namespace
 
-void launch_compose(const ComposeArgs* d_args, int n, hipStream_t st) {
-  if (n > 0) hipLaunchKernelGGL(compose_kernel, dim3(n), dim3(kBlock), 0, st, d_args);
+int compose_max_bitmap_bytes() { return kMaxBitmapBytes; }
+
+namespace {
+template <int MATCH, bool L1, bool L2>
+void launch_compose_t(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
+  static int max_set = 0;
+  if (dyn > max_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+    max_set = dyn;
+  }
+  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2>), dim3(n), dim3(kBlock), dyn, st, d_args);
+}
+template <int MATCH>
+void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, hipStream_t st) {
+  if (lin1 && lin2) launch_compose_t<MATCH, true, true>(d, n, dyn, st);
+  else if (lin1) launch_compose_t<MATCH, true, false>(d, n, dyn, st);
+  else if (lin2) launch_compose_t<MATCH, false, true>(d, n, dyn, st);
+  else launch_compose_t<MATCH, false, false>(d, n, dyn, st);
+}
+} // namespace
+
+// One instantiation per (matcher, g1 linear?, g2 linear?): every role / kind
+// branch of the matcher folds at compile time, which keeps the per-level code
+// path a few hundred instructions (the all-in-one kernel was ~40k lines of ISA
+// and instruction-cache bound).  All graphs of a launch share the triple.
+void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
+                    hipStream_t st) {
+  if (n <= 0) return;
+  switch (matcher) {
+    case MATCH_UNSORTED: launch_compose_m<MATCH_UNSORTED>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
+    case MATCH_SINGLY_G1: launch_compose_m<MATCH_SINGLY_G1>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
+    case MATCH_SINGLY_G2: launch_compose_m<MATCH_SINGLY_G2>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
+    default: launch_compose_m<MATCH_DOUBLY>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
+  }
 }
 
 size_t compose_transpose_scratch_bytes(int n, int maxNcap) {

@@ -385,7 +385,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
   }
   if (todo.empty()) return;
   struct Off {
-    size_t src, dst, il, ol, nf, st, ac, oo, ol_, io, il_;
+    size_t src, dst, il, ol, nf, st, ac, oo, ol_, io, il_, orec, irec;
   };
   Packer pk;
   std::vector<Off> offs(todo.size());
@@ -405,6 +405,8 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     o.ol_ = pk.add(4 * A);
     o.io = pk.add(4 * (N + 1));
     o.il_ = pk.add(4 * A);
+    o.orec = pk.add(16 * A);
+    o.irec = pk.add(16 * A);
   }
   PinnedMemP pin = rt.alloc_pinned(pk.total);
   DevMemP dev = rt.alloc(pk.total);
@@ -425,6 +427,15 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     std::memcpy(hb + o.ol_, s->out_list.data(), 4 * A);
     std::memcpy(hb + o.io, s->in_off.data(), 4 * (N + 1));
     std::memcpy(hb + o.il_, s->in_list.data(), 4 * A);
+    {
+      int* orec = reinterpret_cast<int*>(hb + o.orec);
+      int* irec = reinterpret_cast<int*>(hb + o.irec);
+      for (size_t k = 0; k < A; ++k) {
+        const int ao = s->out_list[k], ai = s->in_list[k];
+        orec[4 * k + 0] = s->il[ao]; orec[4 * k + 1] = s->ol[ao]; orec[4 * k + 2] = s->dst[ao]; orec[4 * k + 3] = ao;
+        irec[4 * k + 0] = s->il[ai]; irec[4 * k + 1] = s->ol[ai]; irec[4 * k + 2] = s->src[ai]; irec[4 * k + 3] = ai;
+      }
+    }
     DGraph& v = s->dview;
     std::memset(&v, 0, sizeof(v));
     v.kind = KIND_EXPLICIT;
@@ -444,6 +455,8 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     v.out_list = reinterpret_cast<const int*>(db + o.ol_);
     v.in_off = reinterpret_cast<const int*>(db + o.io);
     v.in_list = reinterpret_cast<const int*>(db + o.il_);
+    v.out_rec = reinterpret_cast<const int4*>(db + o.orec);
+    v.in_rec = reinterpret_cast<const int4*>(db + o.irec);
     s->dev_mem = dev;
     s->dev_valid = true;
   }

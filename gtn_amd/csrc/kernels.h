@@ -9,6 +9,18 @@
 
 namespace gtnx {
 
+// Pointers inside the argument structs are loaded from memory, so the compiler
+// would treat them as generic ("flat") addresses: flat_load/flat_store, which
+// are slower and -- worse -- tick lgkmcnt as well as vmcnt, so an LDS-only
+// barrier (s_waitcnt lgkmcnt(0); s_barrier) would still wait for every HBM
+// access in flight.  In device code the members are therefore typed as GLOBAL
+// (address space 1) pointers; the host sees ordinary pointers of the same size.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GTNX_G __attribute__((address_space(1)))
+#else
+#define GTNX_G
+#endif
+
 enum : int { KIND_EXPLICIT = 0, KIND_LINEAR = 1 };
 enum : int { NF_START = 1, NF_ACCEPT = 2, NF_ORPHAN = 4 /* unqueued accept node: score 0.0 */ };
 
@@ -26,18 +38,22 @@ struct DGraph {
   int M, C;
   int n_start, n_accept;
   int flags;  // bit0 ilabelSorted, bit1 olabelSorted
-  const int* src;
-  const int* dst;
-  const int* il;
-  const int* ol;
-  const uint8_t* nflags;
-  const int* start_list;
-  const int* accept_list;
-  const int* out_off;
-  const int* out_list;  // nullptr => identity (arcs already grouped by src in id order)
-  const int* in_off;
-  const int* in_list;
-  const float* w;  // weights, arc-id order (filled per op; not part of the structure)
+  const GTNX_G int* src;
+  const GTNX_G int* dst;
+  const GTNX_G int* il;
+  const GTNX_G int* ol;
+  const GTNX_G uint8_t* nflags;
+  const GTNX_G int* start_list;
+  const GTNX_G int* accept_list;
+  const GTNX_G int* out_off;
+  const GTNX_G int* out_list;  // nullptr => identity (arcs already grouped by src in id order)
+  const GTNX_G int* in_off;
+  const GTNX_G int* in_list;
+  // packed adjacency records in list order: {ilabel, olabel, dst (out) / src (in), arc id};
+  // present for host-built graphs, nullptr for device-built ones
+  const GTNX_G int4* out_rec;
+  const GTNX_G int4* in_rec;
+  const GTNX_G float* w;  // weights, arc-id order (filled per op; not part of the structure)
 };
 
 // ---------------------------------------------------------------------------
@@ -55,17 +71,17 @@ struct DSched {
   int L;  // levels
   int n_accept;
   int flags;  // bit0: tie-break by arc id (rows unordered); bit1: out rows are identity
-  const int* level_off;  // [L+1]
-  const int* row_off;    // [P+1]
-  const int* in_srcpos;  // [Ain]
-  const int* in_arc;     // [Ain] arc ids
-  const int* in_rank;    // [Ain] push rank for viterbiPath ties (nullptr => arc id)
-  const float* in_w;     // [Ain] or nullptr
-  const uint8_t* pflags; // [P] NF_START | NF_ACCEPT by position
-  const int* acc_pos;    // [n_accept] position of accept()[k]
-  const int* out_off;    // [P+1]
-  const int* out_dstpos; // [Aout]
-  const int* out_arc;    // [Aout] or nullptr (identity)
+  const GTNX_G int* level_off;  // [L+1]
+  const GTNX_G int* row_off;    // [P+1]
+  const GTNX_G int* in_srcpos;  // [Ain]
+  const GTNX_G int* in_arc;     // [Ain] arc ids
+  const GTNX_G int* in_rank;    // [Ain] push rank for viterbiPath ties (nullptr => arc id)
+  const GTNX_G float* in_w;     // [Ain] or nullptr
+  const GTNX_G uint8_t* pflags; // [P] NF_START | NF_ACCEPT by position
+  const GTNX_G int* acc_pos;    // [n_accept] position of accept()[k]
+  const GTNX_G int* out_off;    // [P+1]
+  const GTNX_G int* out_dstpos; // [Aout]
+  const GTNX_G int* out_arc;    // [Aout] or nullptr (identity)
 };
 enum : int { SCHED_TIE_BY_ARC = 1, SCHED_OUT_IDENTITY = 2 };
 
@@ -80,15 +96,15 @@ struct SdResult {
 // one shortest-distance problem
 struct SdArgs {
   DSched s;
-  const float* w;   // arc-id order weights
-  float* scores;    // [P]
-  int* argmax;      // [P] tropical only (arc id, -1 = the start node's virtual 0)
-  SdResult* result; // [1]
-  float* out_score; // [1] the scalar graph's weight
+  const GTNX_G float* w;   // arc-id order weights
+  GTNX_G float* scores;    // [P]
+  GTNX_G int* argmax;      // [P] tropical only (arc id, -1 = the start node's virtual 0)
+  GTNX_G SdResult* result; // [1]
+  GTNX_G float* out_score; // [1] the scalar graph's weight
   // backward
-  const float* delta;  // [1] upstream gradient of the scalar
-  float* node_grad;    // [P]
-  float* arc_grad;     // [A] arc-id order
+  const GTNX_G float* delta;  // [1] upstream gradient of the scalar
+  GTNX_G float* node_grad;    // [P]
+  GTNX_G float* arc_grad;     // [A] arc-id order
 };
 
 enum : int { SD_LOG = 0, SD_TROPICAL = 1, SD_PATH = 2 };
@@ -108,13 +124,13 @@ void launch_sd_backward(const SdArgs* d_args, int n, int mode, int max_level_wid
 struct PathArgs {
   DSched s;
   DGraph g;
-  const int* argmax;       // back-pointers by position (arc id / -1)
-  const SdResult* result;
-  int* path_arcs;          // [cap]
-  int* path_il;            // [cap]
-  int* path_ol;            // [cap]
-  float* path_w;           // [cap]
-  int* path_len;           // [2]: length, has_node
+  const GTNX_G int* argmax;       // back-pointers by position (arc id / -1)
+  const GTNX_G SdResult* result;
+  GTNX_G int* path_arcs;          // [cap]
+  GTNX_G int* path_il;            // [cap]
+  GTNX_G int* path_ol;            // [cap]
+  GTNX_G float* path_w;           // [cap]
+  GTNX_G int* path_len;           // [2]: length, has_node
   int cap;
 };
 void launch_path_chase(const PathArgs* d_args, int n, hipStream_t st);
@@ -124,12 +140,12 @@ void launch_path_chase(const PathArgs* d_args, int n, hipStream_t st);
 // are row reductions over the [M][C] weight tensor (no graph traversal).
 // ---------------------------------------------------------------------------
 struct LinArgs {
-  const float* w;   // [M][C]
+  const GTNX_G float* w;   // [M][C]
   int M, C;
-  float* out_score; // [1]
-  float* partial;   // [splits]
-  const float* delta;
-  float* grad;      // [M][C]
+  GTNX_G float* out_score; // [1]
+  GTNX_G float* partial;   // [splits]
+  const GTNX_G float* delta;
+  GTNX_G float* grad;      // [M][C]
 };
 void launch_linear_forward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
 void launch_linear_backward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
@@ -151,45 +167,51 @@ struct ComposeOut {
 struct ComposeArgs {
   DGraph g1, g2;
   int matcher;
+  int lds_state;  // co-reachability / discovered bitmaps live in LDS
   int Ncap, Acap;
-  int* state;     // [N1*N2] pair -> INT_MIN unreachable / R / claim / node id
-  int* queue;     // [N1*N2] backward-BFS queue of pair ids
+  GTNX_G int* state;     // [N1*N2] pair -> INT_MIN unreachable / R / claim / node id
+  GTNX_G int* queue;     // [N1*N2] backward-BFS queue of pair ids
   // outputs (SoA, arc-id order)
-  int* src;
-  int* dst;
-  int* il;
-  int* ol;
-  float* w;
-  int* gi1;       // gradInfo.first  (compose.cpp:443-446)
-  int* gi2;       // gradInfo.second
-  uint8_t* nflags;
-  int* pair_of;   // [Ncap] composed node -> pair id
-  int* out_off;   // [Ncap+1]
-  int* level_off; // [Ncap+2]
+  GTNX_G int* src;
+  GTNX_G int* dst;
+  GTNX_G int* il;
+  GTNX_G int* ol;
+  GTNX_G float* w;
+  GTNX_G int* gi1;       // gradInfo.first  (compose.cpp:443-446)
+  GTNX_G int* gi2;       // gradInfo.second
+  GTNX_G uint8_t* nflags;
+  GTNX_G int* pair_of;   // [Ncap] composed node -> pair id
+  GTNX_G int* out_off;   // [Ncap+1]
+  GTNX_G int* level_off; // [Ncap+2]
   // in-CSR (filled by the transpose kernels)
-  int* in_off;    // [Ncap+1]
-  int* in_cursor; // [Ncap]
-  int* in_list;   // [Acap]
-  int* in_src;    // [Acap]
-  float* in_w;    // [Acap]
-  int* start_list;  // [Ncap]
-  int* accept_list; // [Ncap]
-  int* counts;      // [2] n_start, n_accept
-  ComposeOut* out;
+  GTNX_G int* in_off;    // [Ncap+1]
+  GTNX_G int* in_cursor; // [Ncap]
+  GTNX_G int* in_list;   // [Acap]
+  GTNX_G int* in_src;    // [Acap]
+  GTNX_G float* in_w;    // [Acap]
+  GTNX_G int* start_list;  // [Ncap]
+  GTNX_G int* accept_list; // [Ncap]
+  GTNX_G int* counts;      // [2] n_start, n_accept
+  GTNX_G ComposeOut* out;
 };
-void launch_compose(const ComposeArgs* d_args, int n, hipStream_t st);
+// dyn_lds_bytes: 2 bitmaps of N1*N2 bits for the largest pair table of the batch
+// when every graph has lds_state set, else 0
+int compose_max_bitmap_bytes();
+// all n problems share (matcher, g1 is linear, g2 is linear)
+void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
+                    hipStream_t st);
 size_t compose_transpose_scratch_bytes(int n, int maxNcap);
 void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int maxNcap, void* scratch,
                               hipStream_t st);
 
 struct ComposeGradArgs {
-  const float* delta; // [A] grads of the composed arcs
-  const int* gi1;
-  const int* gi2;
+  const GTNX_G float* delta; // [A] grads of the composed arcs
+  const GTNX_G int* gi1;
+  const GTNX_G int* gi2;
   int A;
   int A1, A2;
-  float* grad1; // nullptr when input 0 has calcGrad = false
-  float* grad2;
+  GTNX_G float* grad1; // nullptr when input 0 has calcGrad = false
+  GTNX_G float* grad2;
 };
 void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st);
 
@@ -200,15 +222,15 @@ void launch_fill_i32(int* p, int v, size_t n, hipStream_t st);
 void launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
 // out[i] = sa * a[i] + sb * b[i]  over n scalars held at arbitrary addresses
 struct ScalarArgs {
-  const float* a;
-  const float* b; // may be nullptr
-  float* out;
+  const GTNX_G float* a;
+  const GTNX_G float* b; // may be nullptr
+  GTNX_G float* out;
 };
 void launch_scalar_combine(const ScalarArgs* d_args, int n, float sa, float sb, hipStream_t st);
 // dst[i] += src[i] for a batch of vectors (atomic when dst's may repeat)
 struct AxpyArgs {
-  float* dst;
-  const float* src;
+  GTNX_G float* dst;
+  const GTNX_G float* src;
   int64_t n;
   float scale;
 };
@@ -217,9 +239,9 @@ void launch_axpy_batch(const AxpyArgs* d_args, int n, int64_t maxn, int atomic, 
 void launch_gather_scalars(const float* const* d_ptrs, float* out, int n, hipStream_t st);
 // viterbiPath grad: grad[arcs[a]] += delta[a]
 struct ScatterArgs {
-  const int* idx;
-  const float* delta;
-  float* grad;
+  const GTNX_G int* idx;
+  const GTNX_G float* delta;
+  GTNX_G float* grad;
   int n;
 };
 void launch_scatter_add(const ScatterArgs* d_args, int n, int maxn, hipStream_t st);

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -821,7 +822,13 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   DevMemP cu_mem = rt.alloc(cu_b ? cu_b : 1);
   DevMemP sc_mem = rt.alloc(sc_b ? sc_b : 1);
   DevMemP res = rt.alloc(rb ? rb : 1);
-  launch_fill_i32(st_mem->as<int>(), INT32_MIN, st_b / 4, rt.stream());
+  // small pair tables keep their bitmaps in LDS (whole batch must qualify, the
+  // dynamic LDS request is per launch); the HBM table is then written by the kernel
+  size_t max_pairs = 0;
+  for (size_t i = 0; i < n; ++i) max_pairs = std::max(max_pairs, size_t(caps[i].pairs));
+  const int bitmap_bytes = int(2 * 4 * ((max_pairs + 31) / 32));
+  const bool lds_state = bitmap_bytes <= compose_max_bitmap_bytes();
+  if (!lds_state) launch_fill_i32(st_mem->as<int>(), INT32_MIN, st_b / 4, rt.stream());
   HIP_CHECK(hipMemsetAsync(cu_mem->ptr, 0, cu_b ? cu_b : 1, rt.stream()));
   std::vector<ComposeArgs> args(n);
   for (size_t i = 0; i < n; ++i) {
@@ -836,6 +843,8 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     const bool s1 = intersect ? (a.s->ilabel_sorted || a.s->olabel_sorted) : a.s->olabel_sorted;
     const bool s2 = intersect ? (b.s->ilabel_sorted || b.s->olabel_sorted) : b.s->ilabel_sorted;
     x.matcher = (s1 && s2) ? MATCH_DOUBLY : (s1 ? MATCH_SINGLY_G1 : (s2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
+    if (getenv("GTNX_COMPOSE_DEBUG_B")) x.matcher |= 0x100;
+    x.lds_state = lds_state ? 1 : 0;
     x.Ncap = int(c.Ncap);
     x.Acap = int(c.Acap);
     char* rp = res->as<char>();
@@ -862,13 +871,29 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     x.counts = reinterpret_cast<int*>(rp + hdr_cnt) + 2 * i;
     x.out = reinterpret_cast<ComposeOut*>(rp + hdr_out) + i;
   }
-  DevMemP dargs = upload_vec(args);
+  // group the batch by kernel instantiation: (matcher, g1 linear, g2 linear)
+  auto key_of = [&](size_t i) {
+    return ((args[i].matcher & 0xff) << 2) | ((args[i].g1.kind == KIND_LINEAR) << 1) | (args[i].g2.kind == KIND_LINEAR);
+  };
+  std::vector<size_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
+  std::vector<ComposeArgs> sorted_args(n);
+  for (size_t i = 0; i < n; ++i) sorted_args[i] = args[order[i]];
+  DevMemP dargs = upload_vec(sorted_args);
   DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(n), int(maxN)));
   {
     double alg = 0;
     for (size_t i = 0; i < n; ++i) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
     GTNX_PROF(intersect ? "intersect" : "compose", alg);
-    launch_compose(dargs->as<ComposeArgs>(), int(n), rt.stream());
+    for (size_t g0 = 0; g0 < n;) {
+      size_t g1 = g0;
+      while (g1 < n && key_of(order[g1]) == key_of(order[g0])) ++g1;
+      const int key = key_of(order[g0]);
+      launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
+                     lds_state ? bitmap_bytes : 0, rt.stream());
+      g0 = g1;
+    }
   }
   {
     GTNX_PROF("compose_transpose", 0.0);

@@ -96,17 +96,10 @@ __device__ __forceinline__ Rec adj_rec(const DGraph& g, const Adj& a, int k) {
     r.node = IN ? a.node - 1 : a.node + 1;
     return r;
   }
-  const GTNX_G int4* recs = IN ? g.in_rec : g.out_rec;
-  if (recs) {
-    const int4 v = recs[a.base + k];
-    r.il = v.x; r.ol = v.y; r.node = v.z; r.arc = v.w;
-    return r;
-  }
-  const GTNX_G int* list = IN ? g.in_list : g.out_list;
-  r.arc = list ? list[a.base + k] : a.base + k;
-  r.il = g.il[r.arc];
-  r.ol = g.ol[r.arc];
-  r.node = IN ? g.src[r.arc] : g.dst[r.arc];
+  // every explicit graph entering compose carries records (host-built: made at
+  // upload; device-built: build_records_kernel below), so this is one 16 B load
+  const int4 v = (IN ? g.in_rec : g.out_rec)[a.base + k];
+  r.il = v.x; r.ol = v.y; r.node = v.z; r.arc = v.w;
   return r;
 }
 template <bool LIN>
@@ -279,7 +272,12 @@ struct Cand {
   }
 };
 
-template <int MATCH, bool L1, bool L2>
+// FAST: the compact variant -- LDS bitmaps required, every cold path (nodes with
+// more than KC candidates, chunks too large for the claim hash) compiled OUT; on
+// meeting one it sets ComposeOut::overflow = 2 and leaves, and the host re-runs
+// that pair with the general variant.  Keeping the cold code out of the hot
+// kernel matters: the BFS inner loop is instruction-fetch sensitive.
+template <int MATCH, bool L1, bool L2, bool FAST>
 __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __restrict__ args) {
   const ComposeArgs a = args[blockIdx.x];
   const int tid = threadIdx.x;
@@ -295,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   __shared__ int incur[WC];
   extern __shared__ __attribute__((aligned(16))) unsigned dyn_bits[];
   const int nwords = (N1 * N2 + 31) >> 5;
-  const bool lds_state = a.lds_state != 0;
+  const bool lds_state = FAST ? true : (a.lds_state != 0);
   unsigned* reach_bits = dyn_bits;
   unsigned* disc_bits = dyn_bits + nwords;
 
@@ -381,6 +379,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
 #pragma unroll
           for (int m = 0; m < KC; ++m)
             if (m < c.n && st[m] == ST_UNREACH) mark(c.idx[m], cur ^ 1);
+        } else if (FAST) {
+          sh_flag[1] = 2;  // hand this pair to the general kernel
         } else {
           auto slow = [&](int id) {
             const bool un = lds_state ? !((reach_bits[id >> 5] >> (id & 31)) & 1u)
@@ -411,6 +411,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
 #endif
   }
 
+  if (FAST && sh_flag[1]) {
+    if (tid == 0) { ComposeOut o{}; o.overflow = 2; *a.out = o; a.counts[0] = a.counts[1] = 0; }
+    return;
+  }
   if (lds_state) {
     // publish the co-reachability table for the general (HBM) code paths of phase F
     for (int x = tid; x < N1 * N2; x += kBlock)
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       if (c.n <= KC) {
 #pragma unroll
         for (int m = 0; m < KC; ++m) cnt += st[m] != ST_UNREACH;
-      } else {
+      } else if (!FAST) {
         // wide node (more than KC candidates): count by re-enumeration (HBM table)
         enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
           cnt += ld_state(a.state + r1.node + N1 * r2.node) != ST_UNREACH;
@@ -545,6 +549,11 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       int total;
       const int off = block_excl_scan(cnt, sh_scan, total, lds_state);
       const bool fast = !(chunk_flags & 1) && total <= (HC * 3) / 4;
+      if (FAST && !fast) {
+        if (tid == 0) sh_flag[1] = 2;
+        lds_barrier();
+        break;
+      }
       if (!fast) __syncthreads();  // the general path below goes through HBM
       if (na + total > a.Acap) {
         if (tid == 0) sh_flag[1] = 1;
@@ -636,7 +645,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         }
         if (!lay) sh_flag[0] = 0;
         if (!lay || !csr_ok) sh_flag[2] = 0;
-      } else {
+      } else if (!FAST) {
         // ---------------- general chunk: claims through the global state table
         fast_level = false;
         if (live) {
@@ -971,6 +980,16 @@ __global__ __launch_bounds__(kBlock) void compose_grad_kernel(const ComposeGradA
     }
 }
 
+// packed adjacency records for a device-built graph that is used as a compose input
+__global__ void build_records_kernel(DGraph g, int4* out_rec, int4* in_rec) {
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.A; k += gridDim.x * blockDim.x) {
+    const int ao = g.out_list ? g.out_list[k] : k;
+    out_rec[k] = make_int4(g.il[ao], g.ol[ao], g.dst[ao], ao);
+    const int ai = g.in_list[k];
+    in_rec[k] = make_int4(g.il[ai], g.ol[ai], g.src[ai], ai);
+  }
+}
+
 int grid_x(int n, int cap) {
   int g = (n + kBlock - 1) / kBlock;
   return g < 1 ? 1 : (g > cap ? cap : g);
@@ -981,22 +1000,27 @@ int grid_x(int n, int cap) {
 int compose_max_bitmap_bytes() { return kMaxBitmapBytes; }
 
 namespace {
-template <int MATCH, bool L1, bool L2>
+template <int MATCH, bool L1, bool L2, bool FAST>
 void launch_compose_t(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
   static int max_set = 0;
   if (dyn > max_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2, FAST>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
     max_set = dyn;
   }
-  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2>), dim3(n), dim3(kBlock), dyn, st, d_args);
+  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST>), dim3(n), dim3(kBlock), dyn, st, d_args);
+}
+template <int MATCH, bool FAST>
+void launch_compose_f(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, hipStream_t st) {
+  if (lin1 && lin2) launch_compose_t<MATCH, true, true, FAST>(d, n, dyn, st);
+  else if (lin1) launch_compose_t<MATCH, true, false, FAST>(d, n, dyn, st);
+  else if (lin2) launch_compose_t<MATCH, false, true, FAST>(d, n, dyn, st);
+  else launch_compose_t<MATCH, false, false, FAST>(d, n, dyn, st);
 }
 template <int MATCH>
-void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, hipStream_t st) {
-  if (lin1 && lin2) launch_compose_t<MATCH, true, true>(d, n, dyn, st);
-  else if (lin1) launch_compose_t<MATCH, true, false>(d, n, dyn, st);
-  else if (lin2) launch_compose_t<MATCH, false, true>(d, n, dyn, st);
-  else launch_compose_t<MATCH, false, false>(d, n, dyn, st);
+void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, int fast, hipStream_t st) {
+  if (fast) launch_compose_f<MATCH, true>(d, n, lin1, lin2, dyn, st);
+  else launch_compose_f<MATCH, false>(d, n, lin1, lin2, dyn, st);
 }
 } // namespace
 
@@ -1005,13 +1029,13 @@ void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, 
 // path a few hundred instructions (the all-in-one kernel was ~40k lines of ISA
 // and instruction-cache bound).  All graphs of a launch share the triple.
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
-                    hipStream_t st) {
+                    int fast, hipStream_t st) {
   if (n <= 0) return;
   switch (matcher) {
-    case MATCH_UNSORTED: launch_compose_m<MATCH_UNSORTED>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
-    case MATCH_SINGLY_G1: launch_compose_m<MATCH_SINGLY_G1>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
-    case MATCH_SINGLY_G2: launch_compose_m<MATCH_SINGLY_G2>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
-    default: launch_compose_m<MATCH_DOUBLY>(d_args, n, lin1, lin2, dyn_lds_bytes, st); break;
+    case MATCH_UNSORTED: launch_compose_m<MATCH_UNSORTED>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
+    case MATCH_SINGLY_G1: launch_compose_m<MATCH_SINGLY_G1>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
+    case MATCH_SINGLY_G2: launch_compose_m<MATCH_SINGLY_G2>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
+    default: launch_compose_m<MATCH_DOUBLY>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
   }
 }
 
@@ -1030,6 +1054,12 @@ void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int
   hipLaunchKernelGGL(tr_chunk_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_args, g_sums, n, chunks);
   hipLaunchKernelGGL(tr_offsets_kernel, dim3(chunks, n), dim3(kBlock), 0, st, d_args, (const int3*)g_sums, chunks);
   hipLaunchKernelGGL(tr_scatter_kernel, dim3(grid_x(maxAcap, 2048), n), dim3(kBlock), 0, st, d_args);
+}
+
+void launch_build_records(const DGraph& g, void* out_rec, void* in_rec, hipStream_t st) {
+  if (g.A <= 0) return;
+  hipLaunchKernelGGL(build_records_kernel, dim3(grid_x(g.A, 1024)), dim3(kBlock), 0, st, g,
+                     static_cast<int4*>(out_rec), static_cast<int4*>(in_rec));
 }
 
 void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st) {

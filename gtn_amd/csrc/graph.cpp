@@ -15,6 +15,7 @@ namespace gtnx {
 void Structure::touch() {
   dev_valid = false;
   dev_mem.reset();
+  rec_mem.reset();
   sched.reset();
   csr_valid = false;
   ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65

@@ -58,6 +58,7 @@ struct Structure {
   bool dev_valid = false;
   DevMemP dev_mem;  // owner (may be shared by a whole batch)
   DGraph dview{};   // pointers into dev_mem (w unset)
+  DevMemP rec_mem;  // packed adjacency records of a device-built structure (made on demand)
 
   std::shared_ptr<Schedule> sched;  // valid while the structure is unchanged
   std::mutex grad_lock;             // graph.h:450

@@ -198,11 +198,16 @@ struct ComposeArgs {
 // when every graph has lds_state set, else 0
 int compose_max_bitmap_bytes();
 // all n problems share (matcher, g1 is linear, g2 is linear)
+// fast != 0: the compact LDS-only variant (needs dyn_lds_bytes > 0); pairs it cannot
+// handle come back with ComposeOut::overflow == 2 and must be re-run with fast = 0
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
-                    hipStream_t st);
+                    int fast, hipStream_t st);
 size_t compose_transpose_scratch_bytes(int n, int maxNcap);
 void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int maxNcap, void* scratch,
                               hipStream_t st);
+
+// out_rec / in_rec (16 B * A each) for a device-built explicit graph
+void launch_build_records(const DGraph& g, void* out_rec, void* in_rec, hipStream_t st);
 
 struct ComposeGradArgs {
   const GTNX_G float* delta; // [A] grads of the composed arcs

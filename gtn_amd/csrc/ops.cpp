@@ -748,6 +748,17 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   }
   ensure_device_batch(ss);
   ensure_weights_device_batch(ws);
+  // device-built inputs (results of an earlier compose) get their packed
+  // adjacency records now; host-built ones got them at upload
+  for (Structure* st : ss) {
+    if (st->kind != KIND_EXPLICIT || st->dview.out_rec || st->A == 0) continue;
+    st->rec_mem = rt.alloc(32 * size_t(st->A));
+    int4* orec = st->rec_mem->as<int4>();
+    int4* irec = orec + st->A;
+    launch_build_records(st->dview, orec, irec, rt.stream());
+    st->dview.out_rec = orec;
+    st->dview.in_rec = irec;
+  }
 
   // ---- capacities from label histograms (exact upper bound on matches)
   std::unordered_map<Structure*, LabelHist> h1, h2;
@@ -871,39 +882,52 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     x.counts = reinterpret_cast<int*>(rp + hdr_cnt) + 2 * i;
     x.out = reinterpret_cast<ComposeOut*>(rp + hdr_out) + i;
   }
-  // group the batch by kernel instantiation: (matcher, g1 linear, g2 linear)
+  // Launch groups share a kernel instantiation: (matcher, g1 linear, g2 linear).
+  // First pass: the compact LDS-only variant when the pair tables fit; pairs it
+  // hands back (overflow == 2: a node with many candidates, an oversized chunk)
+  // are re-run with the general variant.
   auto key_of = [&](size_t i) {
     return ((args[i].matcher & 0xff) << 2) | ((args[i].g1.kind == KIND_LINEAR) << 1) | (args[i].g2.kind == KIND_LINEAR);
   };
-  std::vector<size_t> order(n);
-  for (size_t i = 0; i < n; ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
-  std::vector<ComposeArgs> sorted_args(n);
-  for (size_t i = 0; i < n; ++i) sorted_args[i] = args[order[i]];
-  DevMemP dargs = upload_vec(sorted_args);
-  DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(n), int(maxN)));
-  {
-    double alg = 0;
-    for (size_t i = 0; i < n; ++i) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
-    GTNX_PROF(intersect ? "intersect" : "compose", alg);
-    for (size_t g0 = 0; g0 < n;) {
-      size_t g1 = g0;
-      while (g1 < n && key_of(order[g1]) == key_of(order[g0])) ++g1;
-      const int key = key_of(order[g0]);
-      launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
-                     lds_state ? bitmap_bytes : 0, rt.stream());
-      g0 = g1;
-    }
-  }
-  {
-    GTNX_PROF("compose_transpose", 0.0);
-    launch_compose_transpose(dargs->as<ComposeArgs>(), int(n), int(maxA), int(maxN), tscratch->ptr, rt.stream());
-  }
-  // ---- sizes back to the host: the contiguous header block, one copy, one sync
   std::vector<char> hdr(hdr_cnt + 8 * n);
-  rt.d2h_sync(hdr.data(), res->ptr, hdr.size());
   const ComposeOut* res_out = reinterpret_cast<const ComposeOut*>(hdr.data() + hdr_out);
   const int* res_counts = reinterpret_cast<const int*>(hdr.data() + hdr_cnt);
+  double alg = 0;
+  for (size_t i = 0; i < n; ++i) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
+  auto run = [&](std::vector<size_t> order, bool fast) {
+    const size_t m = order.size();
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
+    std::vector<ComposeArgs> sorted_args(m);
+    for (size_t i = 0; i < m; ++i) sorted_args[i] = args[order[i]];
+    DevMemP dargs = upload_vec(sorted_args);
+    DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(m), int(maxN)));
+    {
+      GTNX_PROF(intersect ? "intersect" : "compose", alg);
+      for (size_t g0 = 0; g0 < m;) {
+        size_t g1 = g0;
+        while (g1 < m && key_of(order[g1]) == key_of(order[g0])) ++g1;
+        const int key = key_of(order[g0]);
+        launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
+                       lds_state ? bitmap_bytes : 0, fast ? 1 : 0, rt.stream());
+        g0 = g1;
+      }
+    }
+    {
+      GTNX_PROF("compose_transpose", 0.0);
+      launch_compose_transpose(dargs->as<ComposeArgs>(), int(m), int(maxA), int(maxN), tscratch->ptr, rt.stream());
+    }
+    // sizes back to the host: the contiguous header block, one copy, one sync
+    rt.d2h_sync(hdr.data(), res->ptr, hdr.size());
+  };
+  {
+    std::vector<size_t> all(n);
+    for (size_t i = 0; i < n; ++i) all[i] = i;
+    run(all, lds_state);
+    std::vector<size_t> redo;
+    for (size_t i = 0; i < n; ++i)
+      if (res_out[i].overflow == 2) redo.push_back(i);
+    if (!redo.empty()) run(redo, false);
+  }
 
   auto op = std::make_shared<ComposeOp>();
   op->seq = g_seq++;

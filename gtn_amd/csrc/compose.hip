@@ -61,8 +61,20 @@ struct Adj {
   int base;
   int node;
 };
-template <bool LIN>
-__device__ __forceinline__ Adj out_adj(const DGraph& g, int node) {
+// LDS-resident copy of a small explicit graph's adjacency for the current phase
+// (in-lists during phase B, out-lists during phase F): same member names as
+// DGraph so the accessors below are generic over both.
+#define GTNX_L __attribute__((address_space(3)))
+struct LGraph {
+  int N, A, M, C, flags;
+  const GTNX_L int* in_off;
+  const GTNX_L int* out_off;
+  const GTNX_L gtnx_i4* in_rec;
+  const GTNX_L gtnx_i4* out_rec;
+  const GTNX_L uint8_t* nflags;
+};
+template <bool LIN, class G>
+__device__ __forceinline__ Adj out_adj(const G& g, int node) {
   Adj a;
   a.node = node;
   if (LIN) {
@@ -74,8 +86,8 @@ __device__ __forceinline__ Adj out_adj(const DGraph& g, int node) {
   }
   return a;
 }
-template <bool LIN>
-__device__ __forceinline__ Adj in_adj(const DGraph& g, int node) {
+template <bool LIN, class G>
+__device__ __forceinline__ Adj in_adj(const G& g, int node) {
   Adj a;
   a.node = node;
   if (LIN) {
@@ -87,8 +99,8 @@ __device__ __forceinline__ Adj in_adj(const DGraph& g, int node) {
   }
   return a;
 }
-template <bool IN, bool LIN>
-__device__ __forceinline__ Rec adj_rec(const DGraph& g, const Adj& a, int k) {
+template <bool IN, bool LIN, class G>
+__device__ __forceinline__ Rec adj_rec(const G& g, const Adj& a, int k) {
   Rec r;
   if (LIN) {
     r.il = r.ol = k;
@@ -98,16 +110,16 @@ __device__ __forceinline__ Rec adj_rec(const DGraph& g, const Adj& a, int k) {
   }
   // every explicit graph entering compose carries records (host-built: made at
   // upload; device-built: build_records_kernel below), so this is one 16 B load
-  const int4 v = (IN ? g.in_rec : g.out_rec)[a.base + k];
+  const gtnx_i4 v = (IN ? g.in_rec : g.out_rec)[a.base + k];
   r.il = v.x; r.ol = v.y; r.node = v.z; r.arc = v.w;
   return r;
 }
-template <bool LIN>
-__device__ __forceinline__ bool g_start(const DGraph& g, int n) {
+template <bool LIN, class G>
+__device__ __forceinline__ bool g_start(const G& g, int n) {
   return LIN ? n == 0 : (g.nflags[n] & NF_START) != 0;
 }
-template <bool LIN>
-__device__ __forceinline__ bool g_accept(const DGraph& g, int n) {
+template <bool LIN, class G>
+__device__ __forceinline__ bool g_accept(const G& g, int n) {
   return LIN ? (g.M > 0 && n == g.M) : (g.nflags[n] & NF_ACCEPT) != 0;
 }
 template <bool LIN>
@@ -119,15 +131,10 @@ __device__ __forceinline__ int g_accept_at(const DGraph& g, int k) { return LIN 
 // (IN: entering) the node pair with olabel1 == ilabel2, in the reference's order:
 // "for q in query list: for s in the equal-label run of the search list"
 // (compose.cpp:211-374; roles per matcher as in functions.cpp:225-251).
-template <bool IN, int MATCH, bool L1, bool L2, bool SG1, class F>
-__device__ __forceinline__ void enum_matches_role(const ComposeArgs& a, const Adj& l1, const Adj& l2, F&& f) {
+template <bool IN, int MATCH, bool LQ, bool LS, bool SG1, class GQ, class GS, class F>
+__device__ __forceinline__ void enum_matches_role(const GQ& gq, const GS& gs, const Adj& q, const Adj& s, F&& f) {
   // SG1: the search side is g1 (query = g2); all roles resolved at compile time
   constexpr bool sorted = MATCH != MATCH_UNSORTED;
-  constexpr bool LQ = SG1 ? L2 : L1, LS = SG1 ? L1 : L2;
-  const DGraph& gq = SG1 ? a.g2 : a.g1;
-  const DGraph& gs = SG1 ? a.g1 : a.g2;
-  const Adj q = SG1 ? l2 : l1;
-  const Adj s = SG1 ? l1 : l2;
   auto one_query = [&](const Rec& qr) {
     const int ql = SG1 ? qr.il : qr.ol;
     if (!IN && ql == EPS) return;  // direct eps:eps matches are skipped (compose.cpp:425-428)
@@ -168,25 +175,25 @@ __device__ __forceinline__ void enum_matches_role(const ComposeArgs& a, const Ad
   for (int k = 4; k < q.n; ++k) one_query(adj_rec<IN, LQ>(gq, q, k));
 }
 
-template <bool IN, int MATCH, bool L1, bool L2, class F>
-__device__ __forceinline__ void enum_matches(const ComposeArgs& a, int n1, int n2, F&& f) {
-  const Adj l1 = IN ? in_adj<L1>(a.g1, n1) : out_adj<L1>(a.g1, n1);
-  const Adj l2 = IN ? in_adj<L2>(a.g2, n2) : out_adj<L2>(a.g2, n2);
+template <bool IN, int MATCH, bool L1, bool L2, class G1, class G2, class F>
+__device__ __forceinline__ void enum_matches(const G1& g1, const G2& g2, int n1, int n2, F&& f) {
+  const Adj l1 = IN ? in_adj<L1>(g1, n1) : out_adj<L1>(g1, n1);
+  const Adj l2 = IN ? in_adj<L2>(g2, n2) : out_adj<L2>(g2, n2);
   if (MATCH == MATCH_SINGLY_G1) {
-    enum_matches_role<IN, MATCH, L1, L2, true>(a, l1, l2, f);
+    enum_matches_role<IN, MATCH, L2, L1, true>(g2, g1, l2, l1, f);
   } else if (MATCH == MATCH_DOUBLY) {
     if (l1.n > l2.n)  // compose.cpp:319
-      enum_matches_role<IN, MATCH, L1, L2, true>(a, l1, l2, f);
+      enum_matches_role<IN, MATCH, L2, L1, true>(g2, g1, l2, l1, f);
     else
-      enum_matches_role<IN, MATCH, L1, L2, false>(a, l1, l2, f);
+      enum_matches_role<IN, MATCH, L1, L2, false>(g1, g2, l1, l2, f);
   } else {
-    enum_matches_role<IN, MATCH, L1, L2, false>(a, l1, l2, f);
+    enum_matches_role<IN, MATCH, L1, L2, false>(g1, g2, l1, l2, f);
   }
 }
 
 // epsilon arcs of one side's list: g1 arcs with olabel eps / g2 arcs with ilabel eps
-template <bool IN, bool LIN, class F>
-__device__ __forceinline__ void enum_eps(const DGraph& g, const Adj& l, bool second, F&& f) {
+template <bool IN, bool LIN, class G, class F>
+__device__ __forceinline__ void enum_eps(const G& g, const Adj& l, bool second, F&& f) {
   if (LIN) return;
   const bool sorted = second ? (g.flags & 1) : (g.flags & 2);
   for (int k = 0; k < l.n; ++k) {
@@ -198,8 +205,8 @@ __device__ __forceinline__ void enum_eps(const DGraph& g, const Adj& l, bool sec
     f(r);
   }
 }
-template <bool LIN>
-__device__ __forceinline__ bool has_eps(const DGraph& g, const Adj& l, bool second) {
+template <bool LIN, class G>
+__device__ __forceinline__ bool has_eps(const G& g, const Adj& l, bool second) {
   if (LIN || l.n == 0) return false;
   const bool sorted = second ? (g.flags & 1) : (g.flags & 2);
   if (sorted) {  // eps (-1) sorts first: one record decides
@@ -251,8 +258,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int
 constexpr int KC = 4;      // candidates cached per lane (registers)
 constexpr int HC = 1024;   // claim-hash slots per chunk (<= 3/4 HC arcs per chunk)
 constexpr int HC_LOG2 = 10;
-constexpr int FC = 512;    // frontier pairs kept in LDS per level
-constexpr int WC = 1024;   // new nodes per level whose in-rows are built in LDS
+constexpr int FC = 256;    // frontier pairs kept in LDS per level
+constexpr int WC = 512;    // new nodes per level whose in-rows are built in LDS
 constexpr int BQ = HC;     // backward-BFS frontier pairs kept in LDS per level
 // When the pair table is small (2 * N1*N2 bits fit the dynamic LDS request) the
 // co-reachability bitmap and a "discovered" bitmap live in LDS for the whole
@@ -277,7 +284,17 @@ struct Cand {
 // meeting one it sets ComposeOut::overflow = 2 and leaves, and the host re-runs
 // that pair with the general variant.  Keeping the cold code out of the hot
 // kernel matters: the BFS inner loop is instruction-fetch sensitive.
-template <int MATCH, bool L1, bool L2, bool FAST>
+template <bool C>
+struct SelView {
+  __device__ static __forceinline__ const LGraph& get(const LGraph& l, const DGraph&) { return l; }
+};
+template <>
+struct SelView<false> {
+  __device__ static __forceinline__ const DGraph& get(const LGraph&, const DGraph& d) { return d; }
+};
+
+// C1: g1 (explicit, small) has its adjacency of the current phase cached in LDS
+template <int MATCH, bool L1, bool L2, bool FAST, bool C1>
 __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __restrict__ args) {
   const ComposeArgs a = args[blockIdx.x];
   const int tid = threadIdx.x;
@@ -296,6 +313,26 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   const bool lds_state = FAST ? true : (a.lds_state != 0);
   unsigned* reach_bits = dyn_bits;
   unsigned* disc_bits = dyn_bits + nwords;
+  // ---- optional LDS cache of g1: offsets, records (16 B aligned), node flags
+  const int A1 = a.g1.A;
+  int* c_off = reinterpret_cast<int*>(dyn_bits + ((2 * nwords + 3) & ~3));
+  gtnx_i4* c_rec = reinterpret_cast<gtnx_i4*>(c_off + ((N1 + 1 + 3) & ~3));
+  uint8_t* c_fl = reinterpret_cast<uint8_t*>(c_rec + A1);
+  LGraph lg;
+  lg.N = N1; lg.A = A1; lg.M = a.g1.M; lg.C = a.g1.C; lg.flags = a.g1.flags;
+  lg.in_off = lg.out_off = (const GTNX_L int*)c_off;
+  lg.in_rec = lg.out_rec = (const GTNX_L gtnx_i4*)c_rec;
+  lg.nflags = (const GTNX_L uint8_t*)c_fl;
+  const auto& g1v = SelView<C1>::get(lg, a.g1);
+  auto cache_g1 = [&](bool in_lists) {
+    if (!C1) return;
+    const GTNX_G int* off = in_lists ? a.g1.in_off : a.g1.out_off;
+    const GTNX_G gtnx_i4* rec = in_lists ? a.g1.in_rec : a.g1.out_rec;
+    for (int x = tid; x <= N1; x += kBlock) c_off[x] = off[x];
+    for (int x = tid; x < A1; x += kBlock) c_rec[x] = rec[x];
+    for (int x = tid; x < N1; x += kBlock) c_fl[x] = a.g1.nflags[x];
+    __syncthreads();
+  };
 
   if (tid == 0) {
     sh_tail = 0;
@@ -332,6 +369,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       for (int x = tid; x < 2 * nwords; x += kBlock) dyn_bits[x] = 0u;
       __syncthreads();
     }
+    cache_g1(true);
     for (int t = tid; t < seeds; t += kBlock) {
       const int f = g_accept_at<L1>(a.g1, t / na2), s = g_accept_at<L2>(a.g2, t % na2);
       const int idx = f + N1 * s;
@@ -351,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       }
     };
 #ifdef GTNX_TIMING
-    long long t_enum = 0, t_mark = 0, t_bar = 0, t0, t1; int nlev = 0;
+    long long t_enum = 0, t_mark = 0, t_bar = 0, t_q = 0, t0, t1; int nlev = 0;
 #endif
     while (lo < hi) {
 #ifdef GTNX_TIMING
@@ -360,10 +398,14 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       for (int f = lo + tid; f < hi; f += kBlock) {
         const int idx = (f - lo) < BQ ? bq(cur)[f - lo] : a.queue[f];
         const int n1 = idx % N1, n2 = idx / N1;
+#ifdef GTNX_TIMING
+        asm volatile("" :: "v"(n1), "v"(n2));
+        t1 = wall_clock64(); t_q += t1 - t0; t0 = t1;
+#endif
         Cand c;
         c.n = 0;
-        enum_matches<true, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) { c.push(r1.node + N1 * r2.node, 0, 0); });
-        enum_eps<true, L1>(a.g1, in_adj<L1>(a.g1, n1), false, [&](const Rec& r) { c.push(r.node + N1 * n2, 0, 0); });
+        enum_matches<true, MATCH, L1, L2>(g1v, a.g2, n1, n2, [&](const Rec& r1, const Rec& r2) { c.push(r1.node + N1 * r2.node, 0, 0); });
+        enum_eps<true, L1>(g1v, in_adj<L1>(g1v, n1), false, [&](const Rec& r) { c.push(r.node + N1 * n2, 0, 0); });
         enum_eps<true, L2>(a.g2, in_adj<L2>(a.g2, n2), true, [&](const Rec& r) { c.push(n1 + N1 * r.node, 0, 0); });
 #ifdef GTNX_TIMING
         t1 = wall_clock64(); t_enum += t1 - t0; t0 = t1;
@@ -387,8 +429,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
                                       : ld_state(a.state + id) == ST_UNREACH;
             if (un) mark(id, cur ^ 1);
           };
-          enum_matches<true, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) { slow(r1.node + N1 * r2.node); });
-          enum_eps<true, L1>(a.g1, in_adj<L1>(a.g1, n1), false, [&](const Rec& r) { slow(r.node + N1 * n2); });
+          enum_matches<true, MATCH, L1, L2>(g1v, a.g2, n1, n2, [&](const Rec& r1, const Rec& r2) { slow(r1.node + N1 * r2.node); });
+          enum_eps<true, L1>(g1v, in_adj<L1>(g1v, n1), false, [&](const Rec& r) { slow(r.node + N1 * n2); });
           enum_eps<true, L2>(a.g2, in_adj<L2>(a.g2, n2), true, [&](const Rec& r) { slow(n1 + N1 * r.node); });
         }
       }
@@ -407,7 +449,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     }
 #ifdef GTNX_TIMING
     if (blockIdx.x == 0 && tid == 0)
-      printf("B-phase: levels %d  enum %lld  mark %lld  barrier %lld (100MHz ticks)\n", nlev, t_enum, t_mark, t_bar);
+      printf("B-phase: levels %d  queue+divmod %lld enum %lld  mark %lld  barrier %lld (100MHz ticks)\n", nlev, t_q, t_enum, t_mark, t_bar);
 #endif
   }
 
@@ -426,6 +468,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     return;
   }
   // ------------------------------------------------------------------ phase F
+  cache_g1(false);
   int nn = 0, na = 0;
   {
     // start pairs in (s1 outer, s2 inner) order (compose.cpp:392-401)
@@ -446,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         const int id = nn + off;
         if (id < a.Ncap) {
           a.pair_of[id] = idx;
-          a.nflags[id] = uint8_t(NF_START | ((g_accept<L1>(a.g1, s1) && g_accept<L2>(a.g2, s2)) ? NF_ACCEPT : 0));
+          a.nflags[id] = uint8_t(NF_START | ((g_accept<L1>(g1v, s1) && g_accept<L2>(a.g2, s2)) ? NF_ACCEPT : 0));
           a.in_off[id] = 0;  // level 0 has no in-arcs in a layered product
           if (id < FC) front[0][id] = idx;
           if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
@@ -490,17 +533,17 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         const int pr = front_in_lds ? front[fcur][node - lo] : a.pair_of[node];
         n1 = pr % N1;
         n2 = pr / N1;
-        o1 = out_adj<L1>(a.g1, n1);
+        o1 = out_adj<L1>(g1v, n1);
         o2 = out_adj<L2>(a.g2, n2);
         // epsilon_matched <=> some (i, j) with olabel1(i) == ilabel2(j) == eps
-        const bool em = has_eps<L1>(a.g1, o1, false) && has_eps<L2>(a.g2, o2, true);
-        const bool acc1 = g_accept<L1>(a.g1, n1), acc2 = g_accept<L2>(a.g2, n2);
+        const bool em = has_eps<L1>(g1v, o1, false) && has_eps<L2>(a.g2, o2, true);
+        const bool acc1 = g_accept<L1>(g1v, n1), acc2 = g_accept<L2>(a.g2, n2);
         eps1_ok = !em || acc2 || !acc1;  // compose.cpp:461
         eps2_ok = !em || acc1;           // compose.cpp:476
-        enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
+        enum_matches<false, MATCH, L1, L2>(g1v, a.g2, n1, n2, [&](const Rec& r1, const Rec& r2) {
           c.push(r1.node + N1 * r2.node, r1.arc, r2.arc, r1.il, r2.ol);
         });
-        if (eps1_ok) enum_eps<false, L1>(a.g1, o1, false, [&](const Rec& r) { c.push(r.node + N1 * n2, r.arc, -1, r.il, EPS); });
+        if (eps1_ok) enum_eps<false, L1>(g1v, o1, false, [&](const Rec& r) { c.push(r.node + N1 * n2, r.arc, -1, r.il, EPS); });
         if (eps2_ok) enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { c.push(n1 + N1 * r.node, -1, r.arc, EPS, r.ol); });
       }
       // state of the cached candidates.  With the bitmaps in LDS no HBM access is
@@ -538,11 +581,11 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         for (int m = 0; m < KC; ++m) cnt += st[m] != ST_UNREACH;
       } else if (!FAST) {
         // wide node (more than KC candidates): count by re-enumeration (HBM table)
-        enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
+        enum_matches<false, MATCH, L1, L2>(g1v, a.g2, n1, n2, [&](const Rec& r1, const Rec& r2) {
           cnt += ld_state(a.state + r1.node + N1 * r2.node) != ST_UNREACH;
         });
         if (eps1_ok)
-          enum_eps<false, L1>(a.g1, o1, false, [&](const Rec& r) { cnt += ld_state(a.state + r.node + N1 * n2) != ST_UNREACH; });
+          enum_eps<false, L1>(g1v, o1, false, [&](const Rec& r) { cnt += ld_state(a.state + r.node + N1 * n2) != ST_UNREACH; });
         if (eps2_ok)
           enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { cnt += ld_state(a.state + n1 + N1 * r.node) != ST_UNREACH; });
       }
@@ -616,8 +659,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
               const int d1 = idx % N1, d2 = idx / N1;
               hids[slot[m]] = id;
               a.pair_of[id] = idx;
-              a.nflags[id] = uint8_t(((g_start<L1>(a.g1, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
-                                     ((g_accept<L1>(a.g1, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
+              a.nflags[id] = uint8_t(((g_start<L1>(g1v, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
+                                     ((g_accept<L1>(g1v, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
               if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
               if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
               st_state(a.state + idx, id);
@@ -664,11 +707,11 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             if (cur < 0) atomicMax(a.state + idx, claim_of(r));
             ++r;
           };
-          enum_matches<false, MATCH, L1, L2>(a, n1, n2, [&](const Rec& r1, const Rec& r2) {
+          enum_matches<false, MATCH, L1, L2>(g1v, a.g2, n1, n2, [&](const Rec& r1, const Rec& r2) {
             emit(r1.node + N1 * r2.node, r1.il, r2.ol, a.g1.w[r1.arc] + a.g2.w[r2.arc], r1.arc, r2.arc);
           });
           if (eps1_ok)
-            enum_eps<false, L1>(a.g1, o1, false, [&](const Rec& r) { emit(r.node + N1 * n2, r.il, EPS, a.g1.w[r.arc], r.arc, -1); });
+            enum_eps<false, L1>(g1v, o1, false, [&](const Rec& r) { emit(r.node + N1 * n2, r.il, EPS, a.g1.w[r.arc], r.arc, -1); });
           if (eps2_ok)
             enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { emit(n1 + N1 * r.node, EPS, r.ol, a.g2.w[r.arc], -1, r.arc); });
         }
@@ -688,8 +731,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             if (id < a.Ncap) {
               const int d1 = idx % N1, d2 = idx / N1;
               a.pair_of[id] = idx;
-              a.nflags[id] = uint8_t(((g_start<L1>(a.g1, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
-                                     ((g_accept<L1>(a.g1, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
+              a.nflags[id] = uint8_t(((g_start<L1>(g1v, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
+                                     ((g_accept<L1>(g1v, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
               if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
               if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
             } else {
@@ -981,12 +1024,12 @@ __global__ __launch_bounds__(kBlock) void compose_grad_kernel(const ComposeGradA
 }
 
 // packed adjacency records for a device-built graph that is used as a compose input
-__global__ void build_records_kernel(DGraph g, int4* out_rec, int4* in_rec) {
+__global__ void build_records_kernel(DGraph g, gtnx_i4* out_rec, gtnx_i4* in_rec) {
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < g.A; k += gridDim.x * blockDim.x) {
     const int ao = g.out_list ? g.out_list[k] : k;
-    out_rec[k] = make_int4(g.il[ao], g.ol[ao], g.dst[ao], ao);
+    out_rec[k] = gtnx_i4{g.il[ao], g.ol[ao], g.dst[ao], ao};
     const int ai = g.in_list[k];
-    in_rec[k] = make_int4(g.il[ai], g.ol[ai], g.src[ai], ai);
+    in_rec[k] = gtnx_i4{g.il[ai], g.ol[ai], g.src[ai], ai};
   }
 }
 
@@ -1000,27 +1043,32 @@ int grid_x(int n, int cap) {
 int compose_max_bitmap_bytes() { return kMaxBitmapBytes; }
 
 namespace {
-template <int MATCH, bool L1, bool L2, bool FAST>
+template <int MATCH, bool L1, bool L2, bool FAST, bool C1>
 void launch_compose_t(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
   static int max_set = 0;
   if (dyn > max_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2, FAST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2, FAST, C1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
     max_set = dyn;
   }
-  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST>), dim3(n), dim3(kBlock), dyn, st, d_args);
+  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST, C1>), dim3(n), dim3(kBlock), dyn, st, d_args);
 }
 template <int MATCH, bool FAST>
-void launch_compose_f(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, hipStream_t st) {
-  if (lin1 && lin2) launch_compose_t<MATCH, true, true, FAST>(d, n, dyn, st);
-  else if (lin1) launch_compose_t<MATCH, true, false, FAST>(d, n, dyn, st);
-  else if (lin2) launch_compose_t<MATCH, false, true, FAST>(d, n, dyn, st);
-  else launch_compose_t<MATCH, false, false, FAST>(d, n, dyn, st);
+void launch_compose_f(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, int cache1, hipStream_t st) {
+  if (lin1 && lin2) launch_compose_t<MATCH, true, true, FAST, false>(d, n, dyn, st);
+  else if (lin1) launch_compose_t<MATCH, true, false, FAST, false>(d, n, dyn, st);
+  else if (lin2) {
+    if (FAST && cache1) launch_compose_t<MATCH, false, true, FAST, FAST>(d, n, dyn, st);
+    else launch_compose_t<MATCH, false, true, FAST, false>(d, n, dyn, st);
+  } else {
+    if (FAST && cache1) launch_compose_t<MATCH, false, false, FAST, FAST>(d, n, dyn, st);
+    else launch_compose_t<MATCH, false, false, FAST, false>(d, n, dyn, st);
+  }
 }
 template <int MATCH>
-void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, int fast, hipStream_t st) {
-  if (fast) launch_compose_f<MATCH, true>(d, n, lin1, lin2, dyn, st);
-  else launch_compose_f<MATCH, false>(d, n, lin1, lin2, dyn, st);
+void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, int fast, int cache1, hipStream_t st) {
+  if (fast) launch_compose_f<MATCH, true>(d, n, lin1, lin2, dyn, cache1, st);
+  else launch_compose_f<MATCH, false>(d, n, lin1, lin2, dyn, 0, st);
 }
 } // namespace
 
@@ -1028,14 +1076,19 @@ void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, 
 // branch of the matcher folds at compile time, which keeps the per-level code
 // path a few hundred instructions (the all-in-one kernel was ~40k lines of ISA
 // and instruction-cache bound).  All graphs of a launch share the triple.
+size_t compose_g1_cache_bytes(int N1, int A1) {
+  return 16 + 4 * size_t((N1 + 1 + 3) & ~3) + 16 * size_t(A1) + size_t((N1 + 15) & ~15);
+}
+int compose_lds_budget() { return 80 * 1024 - 19 * 1024; }  // dynamic bytes that keep 2 workgroups per CU
+
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
-                    int fast, hipStream_t st) {
+                    int fast, int cache1, hipStream_t st) {
   if (n <= 0) return;
   switch (matcher) {
-    case MATCH_UNSORTED: launch_compose_m<MATCH_UNSORTED>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
-    case MATCH_SINGLY_G1: launch_compose_m<MATCH_SINGLY_G1>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
-    case MATCH_SINGLY_G2: launch_compose_m<MATCH_SINGLY_G2>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
-    default: launch_compose_m<MATCH_DOUBLY>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, st); break;
+    case MATCH_UNSORTED: launch_compose_m<MATCH_UNSORTED>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, cache1, st); break;
+    case MATCH_SINGLY_G1: launch_compose_m<MATCH_SINGLY_G1>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, cache1, st); break;
+    case MATCH_SINGLY_G2: launch_compose_m<MATCH_SINGLY_G2>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, cache1, st); break;
+    default: launch_compose_m<MATCH_DOUBLY>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, cache1, st); break;
   }
 }
 
@@ -1059,7 +1112,7 @@ void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int
 void launch_build_records(const DGraph& g, void* out_rec, void* in_rec, hipStream_t st) {
   if (g.A <= 0) return;
   hipLaunchKernelGGL(build_records_kernel, dim3(grid_x(g.A, 1024)), dim3(kBlock), 0, st, g,
-                     static_cast<int4*>(out_rec), static_cast<int4*>(in_rec));
+                     static_cast<gtnx_i4*>(out_rec), static_cast<gtnx_i4*>(in_rec));
 }
 
 void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st) {

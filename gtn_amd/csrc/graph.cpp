@@ -456,8 +456,8 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     v.out_list = reinterpret_cast<const int*>(db + o.ol_);
     v.in_off = reinterpret_cast<const int*>(db + o.io);
     v.in_list = reinterpret_cast<const int*>(db + o.il_);
-    v.out_rec = reinterpret_cast<const int4*>(db + o.orec);
-    v.in_rec = reinterpret_cast<const int4*>(db + o.irec);
+    v.out_rec = reinterpret_cast<const gtnx_i4*>(db + o.orec);
+    v.in_rec = reinterpret_cast<const gtnx_i4*>(db + o.irec);
     s->dev_mem = dev;
     s->dev_valid = true;
   }

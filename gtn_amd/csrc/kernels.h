@@ -21,6 +21,9 @@ namespace gtnx {
 #define GTNX_G
 #endif
 
+// 16-byte adjacency record as a builtin vector (loadable from any address space)
+typedef int gtnx_i4 __attribute__((ext_vector_type(4)));
+
 enum : int { KIND_EXPLICIT = 0, KIND_LINEAR = 1 };
 enum : int { NF_START = 1, NF_ACCEPT = 2, NF_ORPHAN = 4 /* unqueued accept node: score 0.0 */ };
 
@@ -51,8 +54,8 @@ struct DGraph {
   const GTNX_G int* in_list;
   // packed adjacency records in list order: {ilabel, olabel, dst (out) / src (in), arc id};
   // present for host-built graphs, nullptr for device-built ones
-  const GTNX_G int4* out_rec;
-  const GTNX_G int4* in_rec;
+  const GTNX_G gtnx_i4* out_rec;
+  const GTNX_G gtnx_i4* in_rec;
   const GTNX_G float* w;  // weights, arc-id order (filled per op; not part of the structure)
 };
 
@@ -200,8 +203,12 @@ int compose_max_bitmap_bytes();
 // all n problems share (matcher, g1 is linear, g2 is linear)
 // fast != 0: the compact LDS-only variant (needs dyn_lds_bytes > 0); pairs it cannot
 // handle come back with ComposeOut::overflow == 2 and must be re-run with fast = 0
+// cache1 != 0 (fast only): g1's adjacency is cached in LDS; dyn_lds_bytes then
+// covers the bitmaps plus compose_g1_cache_bytes() of the largest g1
+size_t compose_g1_cache_bytes(int N1, int A1);
+int compose_lds_budget();
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
-                    int fast, hipStream_t st);
+                    int fast, int cache1, hipStream_t st);
 size_t compose_transpose_scratch_bytes(int n, int maxNcap);
 void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int maxNcap, void* scratch,
                               hipStream_t st);

@@ -753,8 +753,8 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   for (Structure* st : ss) {
     if (st->kind != KIND_EXPLICIT || st->dview.out_rec || st->A == 0) continue;
     st->rec_mem = rt.alloc(32 * size_t(st->A));
-    int4* orec = st->rec_mem->as<int4>();
-    int4* irec = orec + st->A;
+    gtnx_i4* orec = st->rec_mem->as<gtnx_i4>();
+    gtnx_i4* irec = orec + st->A;
     launch_build_records(st->dview, orec, irec, rt.stream());
     st->dview.out_rec = orec;
     st->dview.in_rec = irec;
@@ -839,6 +839,14 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   for (size_t i = 0; i < n; ++i) max_pairs = std::max(max_pairs, size_t(caps[i].pairs));
   const int bitmap_bytes = int(2 * 4 * ((max_pairs + 31) / 32));
   const bool lds_state = bitmap_bytes <= compose_max_bitmap_bytes();
+  // ... and, when it still fits, g1's adjacency records as well
+  size_t g1_cache = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const Structure& s1 = *bcast(av, n, i).s;
+    if (s1.kind == KIND_EXPLICIT) g1_cache = std::max(g1_cache, compose_g1_cache_bytes(int(s1.N), int(s1.A)));
+  }
+  const bool cache1 = lds_state && g1_cache > 0 && bitmap_bytes + int(g1_cache) <= compose_lds_budget();
+  const int dyn_fast = bitmap_bytes + (cache1 ? int(g1_cache) : 0);
   if (!lds_state) launch_fill_i32(st_mem->as<int>(), INT32_MIN, st_b / 4, rt.stream());
   HIP_CHECK(hipMemsetAsync(cu_mem->ptr, 0, cu_b ? cu_b : 1, rt.stream()));
   std::vector<ComposeArgs> args(n);
@@ -908,7 +916,8 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
         while (g1 < m && key_of(order[g1]) == key_of(order[g0])) ++g1;
         const int key = key_of(order[g0]);
         launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
-                       lds_state ? bitmap_bytes : 0, fast ? 1 : 0, rt.stream());
+                       lds_state ? (fast ? dyn_fast : bitmap_bytes) : 0, fast ? 1 : 0, (fast && cache1) ? 1 : 0,
+                       rt.stream());
         g0 = g1;
       }
     }

@@ -120,8 +120,10 @@ int sd_narrow_tmp_cap();
 int sd_narrow_node_cap();
 void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
                        int avg_in_degree_x16, hipStream_t st);
-void launch_sd_backward(const SdArgs* d_args, int n, int mode, int max_level_width,
-                        hipStream_t st);
+int sd_narrow_ring_backward();
+// narrow != 0: LDS-ring kernel (log semiring, identity out rows, eligibility as forward
+// with reach <= sd_narrow_ring_backward())
+void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st);
 
 // viterbiPath pointer chase (shortest.cpp:239-245): writes path arc ids first-arc-first
 struct PathArgs {

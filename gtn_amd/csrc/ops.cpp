@@ -358,7 +358,17 @@ struct SdOp : OpRecord {
     DevMemP d = upload_vec(args);
     {
       GTNX_PROF(mode == SD_LOG ? "forward_score_grad" : "viterbi_score_grad", alg);
-      launch_sd_backward(d->as<SdArgs>(), n, mode, int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream());
+      bool narrow = mode == SD_LOG;
+      int64_t tot_levels = 0;
+      for (int i = 0; i < n; ++i) {
+        const Schedule& sc = *saved[ms[i].idx].sched;
+        narrow = narrow && (sc.view.flags & SCHED_OUT_IDENTITY) && sc.max_level_arcs <= sd_narrow_tmp_cap() &&
+                 sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring_backward();
+        tot_levels += sc.view.L;
+      }
+      narrow = narrow && tot_levels >= 32 * int64_t(n);
+      launch_sd_backward(d->as<SdArgs>(), n, mode, narrow ? 1 : 0, int(tot_p ? (tot_out * 16) / tot_p : 0),
+                         rt.stream());
     }
     sink.flush();
   }

@@ -492,6 +492,149 @@ __global__ __launch_bounds__(kBlock) void sd_backward_kernel(const SdArgs* __res
 }
 
 // --------------------------------------------------------------------------
+// backward sweep, narrow-lattice specialisation (log semiring, identity out rows:
+// the layered products compose emits, where arc k is the k-th out entry).
+// Mirror image of sd_forward_narrow_kernel: levels are walked last to first, the
+// out rows (dst position, weight), row offsets, flags and the chunk's forward
+// scores are staged through LDS in double-buffered chunks, node gradients and
+// scores of the active frontier live in two LDS rings, and inside a chunk the only
+// global instructions are the fire-and-forget arc-gradient stores.
+// HBM traffic: 12A + 12N (dst, weight, arc-grad per arc; offset, score, flag per node).
+// --------------------------------------------------------------------------
+constexpr int kRingB = 2048;
+
+__global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs* __restrict__ args) {
+  const SdArgs a = args[blockIdx.x];
+  const DSched s = a.s;
+  const int tid = threadIdx.x;
+  __shared__ float sc_ring[kRingB];
+  __shared__ float ng_ring[kRingB];
+  __shared__ int arc_dst[2][kCA];
+  __shared__ float arc_w[2][kCA];
+  __shared__ int node_off[2][kCN + kBlock];
+  __shared__ uint8_t node_fl[2][kCN];
+  __shared__ int tab_node[kTab + 2];
+  __shared__ int tab_arc[kTab + 2];
+  const GTNX_G int* __restrict__ out_off = s.out_off;
+  const GTNX_G int* __restrict__ out_dst = s.out_dstpos;
+  const GTNX_G uint8_t* __restrict__ pflags = s.pflags;
+  const GTNX_G float* __restrict__ scores = a.scores;
+  const int last_node = s.P > 0 ? s.P - 1 : 0;
+  const SdResult res = *a.result;
+  const float delta = *a.delta;
+  const float denom = expf(res.score - res.max_final);
+
+  int st_dst[kJA];
+  float st_w[kJA];
+  int st_off[kJN + 1];
+  int st_fl[kJN];
+  float st_sc[kJN];
+
+  // chunk = levels [c, e) of the current window, chosen downwards from e
+  auto chunk_begin = [&](int e) {
+    int c = e - 1;
+    while (c > 0 && tab_arc[e] - tab_arc[c - 1] <= kCA && tab_node[e] - tab_node[c - 1] <= kCN) --c;
+    return c;
+  };
+  auto stage_load = [&](int a0, int a1, int n0, int n1) {
+    const int ahi = max(a1 - 1, 0);
+#pragma unroll
+    for (int j = 0; j < kJA; ++j) {
+      const int k = min(a0 + tid + j * kBlock, ahi);
+      st_dst[j] = out_dst[k];
+      st_w[j] = a.w[k];
+    }
+#pragma unroll
+    for (int j = 0; j < kJN + 1; ++j) st_off[j] = out_off[min(n0 + tid + j * kBlock, last_node + 1)];
+#pragma unroll
+    for (int j = 0; j < kJN; ++j) {
+      const int p = min(n0 + tid + j * kBlock, last_node);
+      st_fl[j] = pflags[p];
+      st_sc[j] = scores[p];
+    }
+  };
+  auto stage_write = [&](int b, int n0, int n1) {
+#pragma unroll
+    for (int j = 0; j < kJA; ++j) {
+      arc_dst[b][tid + j * kBlock] = st_dst[j];
+      arc_w[b][tid + j * kBlock] = st_w[j];
+    }
+#pragma unroll
+    for (int j = 0; j < kJN + 1; ++j) node_off[b][tid + j * kBlock] = st_off[j];
+#pragma unroll
+    for (int j = 0; j < kJN; ++j) {
+      node_fl[b][tid + j * kBlock] = uint8_t(st_fl[j]);
+      const int p = n0 + tid + j * kBlock;
+      if (p < n1) sc_ring[p & (kRingB - 1)] = st_sc[j];
+    }
+  };
+
+  const int nwin = (s.L + kTab - 1) / kTab;
+  for (int wi = nwin - 1; wi >= 0; --wi) {
+    const int l0 = wi * kTab;
+    const int nl = min(kTab, s.L - l0);
+    __syncthreads();
+    for (int i = tid; i <= nl; i += kBlock) {
+      const int n = s.level_off[l0 + i];
+      tab_node[i] = n;
+      tab_arc[i] = out_off[n];
+    }
+    __syncthreads();
+    int e = nl, c = chunk_begin(nl), b = 0;
+    stage_load(tab_arc[c], tab_arc[e], tab_node[c], tab_node[e]);
+    stage_write(0, tab_node[c], tab_node[e]);
+    int c2 = c > 0 ? chunk_begin(c) : 0;
+    if (c > 0) stage_load(tab_arc[c2], tab_arc[c], tab_node[c2], tab_node[c]);
+    __syncthreads();
+    while (e > 0) {
+      const int a0 = tab_arc[c], n0 = tab_node[c];
+      for (int i = e - 1; i >= c; --i) {
+        const int nlo = tab_node[i], nhi = tab_node[i + 1];
+        for (int p = nlo + tid; p < nhi; p += kBlock) {
+          const int r0 = node_off[b][p - n0] - a0;
+          const int deg = node_off[b][p - n0 + 1] - a0 - r0;
+          const int fl = node_fl[b][p - n0];
+          const float su = sc_ring[p & (kRingB - 1)];
+          float acc = 0.0f;
+          if (deg <= 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int k = min(r0 + j, kCA - 1);
+              const int v = arc_dst[b][k];
+              const float g = ng_ring[v & (kRingB - 1)] * __expf(su + arc_w[b][k] - sc_ring[v & (kRingB - 1)]);
+              if (j < deg) {
+                a.arc_grad[a0 + k] = g * delta;
+                acc += g;
+              }
+            }
+          } else {
+            for (int k = r0; k < r0 + deg; ++k) {
+              const int v = arc_dst[b][k];
+              const float g = ng_ring[v & (kRingB - 1)] * __expf(su + arc_w[b][k] - sc_ring[v & (kRingB - 1)]);
+              a.arc_grad[a0 + k] = g * delta;
+              acc += g;
+            }
+          }
+          if (fl & NF_ACCEPT) acc += expf(su - res.max_final) / denom;  // shortest.cpp:49-60
+          ng_ring[p & (kRingB - 1)] = acc;
+        }
+        lds_barrier();
+      }
+      // ---- chunk switch (downwards)
+      e = c;
+      c = c2;
+      b ^= 1;
+      if (e > 0) {
+        stage_write(b, tab_node[c], tab_node[e]);
+        c2 = c > 0 ? chunk_begin(c) : 0;
+        if (c > 0) stage_load(tab_arc[c2], tab_arc[c], tab_node[c2], tab_node[c]);
+      }
+      lds_barrier();
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // viterbiPath pointer chase (shortest.cpp:239-260); one lane per graph
 // --------------------------------------------------------------------------
 __global__ void path_chase_kernel(const PathArgs* __restrict__ args, int n) {
@@ -577,8 +720,14 @@ void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
     launch_fwd_mode<SD_PATH>(d_args, n, g, st);
 }
 
-void launch_sd_backward(const SdArgs* d_args, int n, int mode, int avg_out_degree_x16, hipStream_t st) {
+int sd_narrow_ring_backward() { return kRingB; }
+
+void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st) {
   if (n <= 0) return;
+  if (narrow && mode == SD_LOG) {
+    hipLaunchKernelGGL(sd_backward_narrow_kernel, dim3(n), dim3(kBlock), 0, st, d_args);
+    return;
+  }
   const int g = pick_group(avg_out_degree_x16);
   if (mode == SD_LOG)
     launch_bwd_mode<SD_LOG>(d_args, n, g, st);

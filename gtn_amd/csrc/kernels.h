@@ -23,6 +23,7 @@ namespace gtnx {
 
 // 16-byte adjacency record as a builtin vector (loadable from any address space)
 typedef int gtnx_i4 __attribute__((ext_vector_type(4)));
+typedef float gtnx_f4 __attribute__((ext_vector_type(4)));
 
 enum : int { KIND_EXPLICIT = 0, KIND_LINEAR = 1 };
 enum : int { NF_START = 1, NF_ACCEPT = 2, NF_ORPHAN = 4 /* unqueued accept node: score 0.0 */ };
@@ -108,6 +109,7 @@ struct SdArgs {
   const GTNX_G float* delta;  // [1] upstream gradient of the scalar
   GTNX_G float* node_grad;    // [P]
   GTNX_G float* arc_grad;     // [A] arc-id order
+  int chunk_levels;           // narrow kernels: levels per LDS chunk (host: caps / widest level)
 };
 
 enum : int { SD_LOG = 0, SD_TROPICAL = 1, SD_PATH = 2 };

@@ -350,6 +350,8 @@ struct SdOp : OpRecord {
       a.delta = grad_dev_ptr(ms[i].out);
       a.arc_grad = g->as<float>(off_a[i]);
       a.node_grad = g->as<float>(off_n[i]);
+      a.chunk_levels = std::max(1, std::min(sd_narrow_tmp_cap() / std::max(sv.sched->max_level_arcs, 1),
+                                            sd_narrow_node_cap() / std::max(sv.sched->max_level_width, 1)));
       sink.add(in, g, a.arc_grad);
       tot_out += sv.sched->n_out;
       tot_p += sv.sched->view.P;
@@ -437,7 +439,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     for (int k = 0; k < m; ++k) {
       const int P = gs[exp[k]].s->sched->view.P;
       off_s[k] = bytes;
-      bytes = align_up(bytes + 4 * size_t(P), 256);
+      bytes = align_up(bytes + 4 * size_t(P) + 16, 256);  // +16: vector staging may read past the end
       off_a[k] = bytes;
       if (tropical) bytes = align_up(bytes + 4 * size_t(P), 256);
       off_r[k] = bytes;
@@ -475,6 +477,8 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       a.delta = nullptr;
       a.node_grad = nullptr;
       a.arc_grad = nullptr;
+      a.chunk_levels = std::max(1, std::min(sd_narrow_tmp_cap() / std::max(sc.max_level_arcs, 1),
+                                            sd_narrow_node_cap() / std::max(sc.max_level_width, 1)));
       op->saved[k] = {g.s->sched, a.scores, a.argmax, a.result};
       tot_in += sc.n_in;
       tot_p += sc.view.P;
@@ -592,6 +596,7 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     a.delta = nullptr;
     a.node_grad = nullptr;
     a.arc_grad = nullptr;
+    a.chunk_levels = 1;
     PathArgs& p = pargs[k];
     p.s = a.s;
     p.g = device_view(g);
@@ -821,19 +826,19 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     o.queue = add(sc_b, 4 * P);
     o.pair_of = add(sc_b, 4 * N);
     o.src = add(rb, 4 * A);
-    o.dst = add(rb, 4 * A);
+    o.dst = add(rb, 4 * A + 16);
     o.il = add(rb, 4 * A);
     o.ol = add(rb, 4 * A);
-    o.w = add(rb, 4 * A);
+    o.w = add(rb, 4 * A + 16);
     o.gi1 = add(rb, 4 * A);
     o.gi2 = add(rb, 4 * A);
-    o.nf = add(rb, N);
-    o.out_off = add(rb, 4 * (N + 1));
+    o.nf = add(rb, N + 16);
+    o.out_off = add(rb, 4 * (N + 1) + 16);
     o.level_off = add(rb, 4 * (N + 2));
-    o.in_off = add(rb, 4 * (N + 1));
+    o.in_off = add(rb, 4 * (N + 1) + 16);
     o.in_list = add(rb, 4 * A);
-    o.in_src = add(rb, 4 * A);
-    o.in_w = add(rb, 4 * A);
+    o.in_src = add(rb, 4 * A + 16);
+    o.in_w = add(rb, 4 * A + 16);
     o.sl = add(rb, 4 * N);
     o.al = add(rb, 4 * N);
     maxA = std::max(maxA, c.Acap);

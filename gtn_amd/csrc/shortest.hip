@@ -234,10 +234,10 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
   const DSched s = a.s;
   const int tid = threadIdx.x;
   __shared__ float ring[kRing];
-  __shared__ int arc_sp[2][kCA];
-  __shared__ float arc_w[2][kCA];
-  __shared__ int node_off[2][kCN + kBlock];
-  __shared__ uint8_t node_fl[2][kCN];
+  __shared__ __attribute__((aligned(16))) int arc_sp[2][kCA];
+  __shared__ __attribute__((aligned(16))) float arc_w[2][kCA];
+  __shared__ __attribute__((aligned(16))) int node_off[2][kCN + kBlock];
+  __shared__ __attribute__((aligned(16))) uint8_t node_fl[2][kCN];
   __shared__ int tab_node[kTab + 2];
   __shared__ int tab_arc[kTab + 2];
   float* __restrict__ scores = a.scores;
@@ -253,19 +253,39 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
   int st_fl[kJN];
 
   // chunk = levels [c, e) of the current table window; ranges from the tables
-  auto chunk_end = [&](int c, int nl) {
-    int e = c + 1;  // a level always fits (eligibility)
-    while (e < nl && tab_arc[e + 1] - tab_arc[c] <= kCA && tab_node[e + 1] - tab_node[c] <= kCN) ++e;
-    return e;
-  };
-  // unconditional, index-clamped loads: straight-line code, coalesced
+  // a fixed number of levels per chunk, sized by the host from the widest level
+  // (no per-switch scan of the offset tables)
+  const int KL = max(a.chunk_levels, 1);
+  auto chunk_end = [&](int c, int nl) { return min(c + KL, nl); };
+  // Staging loads are unconditional and straight-line.  Row-ordered products
+  // (HAS_INW: the arrays compose emits, padded by 16 B) are staged with 16-byte
+  // vector loads -- 7 memory instructions per chunk instead of 25 -- and land in
+  // LDS with ds_write_b128; host-built schedules use clamped scalar loads.
+  gtnx_i4 v_sp[kJA / 4];
+  gtnx_f4 v_w[kJA / 4];
+  gtnx_i4 v_off;
+  int v_off_last = 0;
+  unsigned v_fl = 0;
   auto stage_load = [&](int a0, int a1, int n0) {
+    if (HAS_INW) {
+#pragma unroll
+      for (int j = 0; j < kJA / 4; ++j) {
+        const int k = a0 + 4 * tid + j * 4 * kBlock;
+        v_sp[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.in_srcpos + k);
+        v_w[j] = *reinterpret_cast<const GTNX_G gtnx_f4*>(s.in_w + k);
+      }
+      const int nb = min(n0 + 4 * tid, last_node + 1);
+      v_off = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.row_off + nb);
+      v_off_last = s.row_off[min(n0 + kCN, last_node + 1)];
+      v_fl = *reinterpret_cast<const GTNX_G unsigned*>(s.pflags + min(n0 + 4 * tid, last_node));
+      return;
+    }
     const int ahi = max(a1 - 1, 0);
 #pragma unroll
     for (int j = 0; j < kJA; ++j) {
       const int k = min(a0 + tid + j * kBlock, ahi);
       st_sp[j] = in_srcpos[k];
-      st_w[j] = HAS_INW ? s.in_w[k] : a.w[s.in_arc[k]];
+      st_w[j] = a.w[s.in_arc[k]];
     }
 #pragma unroll
     for (int j = 0; j < kJN + 1; ++j) st_off[j] = row_off[min(n0 + tid + j * kBlock, last_node + 1)];
@@ -273,6 +293,17 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     for (int j = 0; j < kJN; ++j) st_fl[j] = pflags[min(n0 + tid + j * kBlock, last_node)];
   };
   auto stage_write = [&](int b) {
+    if (HAS_INW) {
+#pragma unroll
+      for (int j = 0; j < kJA / 4; ++j) {
+        *reinterpret_cast<gtnx_i4*>(&arc_sp[b][4 * tid + j * 4 * kBlock]) = v_sp[j];
+        *reinterpret_cast<gtnx_f4*>(&arc_w[b][4 * tid + j * 4 * kBlock]) = v_w[j];
+      }
+      *reinterpret_cast<gtnx_i4*>(&node_off[b][4 * tid]) = v_off;
+      if (tid == 0) node_off[b][kCN] = v_off_last;
+      *reinterpret_cast<unsigned*>(&node_fl[b][4 * tid]) = v_fl;
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < kJA; ++j) {
       arc_sp[b][tid + j * kBlock] = st_sp[j];
@@ -284,6 +315,9 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     for (int j = 0; j < kJN; ++j) node_fl[b][tid + j * kBlock] = uint8_t(st_fl[j]);
   };
 
+#ifdef GTNX_TIMING
+  long long tm_upd = 0, tm_pre = 0, tm_bar = 0, tm_sw = 0, tm_w = 0, tm_l = 0, tm_last = wall_clock64();
+#endif
   for (int l0 = 0; l0 < s.L; l0 += kTab) {
     const int nl = min(kTab, s.L - l0);
     __syncthreads();
@@ -361,9 +395,19 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
         ring[p & (kRing - 1)] = out;
       };
       preload(c);
+#ifdef GTNX_TIMING
+      long long t0 = wall_clock64(), t1;
+      tm_sw += t0 - tm_last;
+#endif
       for (int i = c; i < e; ++i) {
         const int nhi = q_nhi;
+#ifdef GTNX_TIMING
+        t0 = wall_clock64();
+#endif
         if (q_p < nhi) node_update(q_p, q_r0, q_deg, q_fl, q_sp, q_w);
+#ifdef GTNX_TIMING
+        t1 = wall_clock64(); tm_upd += t1 - t0; t0 = t1;
+#endif
         for (int p = q_p + kBlock; p < nhi; p += kBlock) {  // levels wider than the workgroup
           const int r0 = node_off[b][p - n0] - a0, deg = node_off[b][p - n0 + 1] - a0 - r0;
           int sp4[4];
@@ -377,23 +421,48 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
           node_update(p, r0, deg, node_fl[b][p - n0], sp4, w4);
         }
         if (i + 1 < e) preload(i + 1);
+#ifdef GTNX_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        t1 = wall_clock64(); tm_pre += t1 - t0; t0 = t1;
+#endif
         lds_barrier();
+#ifdef GTNX_TIMING
+        t1 = wall_clock64(); tm_bar += t1 - t0; tm_last = t1;
+#endif
       }
-      // ---- chunk switch: flush finished scores, land the staged chunk, refill
+      // ---- chunk switch: land the staged chunk, refill the registers, THEN flush
+      // the finished scores -- the vmcnt(0) in front of stage_write() must only
+      // cover loads issued a whole chunk ago, not stores issued just now
       const int n1 = tab_node[e];
-      for (int p = n0 + tid; p < n1; p += kBlock) scores[p] = ring[p & (kRing - 1)];
+      const int pc = c, pe = e;
       c = e;
       e = e2;
       b ^= 1;
       if (c < nl) {
-        stage_write(b);  // waits for the loads issued one chunk ago
+#ifdef GTNX_TIMING
+        long long u0 = wall_clock64(), u1;
+#endif
+        stage_write(b);
+#ifdef GTNX_TIMING
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        u1 = wall_clock64(); tm_w += u1 - u0; u0 = u1;
+#endif
         e2 = e < nl ? chunk_end(e, nl) : e;
         if (e < nl) stage_load(tab_arc[e], tab_arc[e2], tab_node[e]);
+#ifdef GTNX_TIMING
+        u1 = wall_clock64(); tm_l += u1 - u0;
+#endif
       }
+      (void)pc; (void)pe;
+      for (int p = n0 + tid; p < n1; p += kBlock) scores[p] = ring[p & (kRing - 1)];
       lds_barrier();
     }
   }
   __syncthreads();  // scores[] stores visible before the accept reduction reads them
+#ifdef GTNX_TIMING
+  if (blockIdx.x == 0 && tid == 0)
+    printf("fwd narrow: L %d update %lld preload %lld barrier %lld switch %lld (stage_write %lld, chunk_end+stage_load %lld) (10ns ticks)\n", s.L, tm_upd, tm_pre, tm_bar, tm_sw, tm_w, tm_l);
+#endif
 
   // ---- accept reduction (identical to the generic kernel)
   __shared__ float sh_v[kBlock];
@@ -509,12 +578,13 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
   const int tid = threadIdx.x;
   __shared__ float sc_ring[kRingB];
   __shared__ float ng_ring[kRingB];
-  __shared__ int arc_dst[2][kCA];
-  __shared__ float arc_w[2][kCA];
-  __shared__ int node_off[2][kCN + kBlock];
-  __shared__ uint8_t node_fl[2][kCN];
+  __shared__ __attribute__((aligned(16))) int arc_dst[2][kCA];
+  __shared__ __attribute__((aligned(16))) float arc_w[2][kCA];
+  __shared__ __attribute__((aligned(16))) int node_off[2][kCN + kBlock];
+  __shared__ __attribute__((aligned(16))) uint8_t node_fl[2][kCN];
   __shared__ int tab_node[kTab + 2];
   __shared__ int tab_arc[kTab + 2];
+  __shared__ float g_buf[kCA];  // arc gradients of the chunk, flushed at the switch
   const GTNX_G int* __restrict__ out_off = s.out_off;
   const GTNX_G int* __restrict__ out_dst = s.out_dstpos;
   const GTNX_G uint8_t* __restrict__ pflags = s.pflags;
@@ -524,48 +594,44 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
   const float delta = *a.delta;
   const float denom = expf(res.score - res.max_final);
 
-  int st_dst[kJA];
-  float st_w[kJA];
-  int st_off[kJN + 1];
-  int st_fl[kJN];
-  float st_sc[kJN];
 
   // chunk = levels [c, e) of the current window, chosen downwards from e
-  auto chunk_begin = [&](int e) {
-    int c = e - 1;
-    while (c > 0 && tab_arc[e] - tab_arc[c - 1] <= kCA && tab_node[e] - tab_node[c - 1] <= kCN) --c;
-    return c;
-  };
+  const int KL = max(a.chunk_levels, 1);
+  auto chunk_begin = [&](int e) { return max(e - KL, 0); };
+  // 16-byte vector staging (arrays are compose-emitted and padded)
+  gtnx_i4 v_dst[kJA / 4];
+  gtnx_f4 v_w[kJA / 4];
+  gtnx_i4 v_off;
+  gtnx_f4 v_sc;
+  int v_off_last = 0;
+  unsigned v_fl = 0;
   auto stage_load = [&](int a0, int a1, int n0, int n1) {
-    const int ahi = max(a1 - 1, 0);
 #pragma unroll
-    for (int j = 0; j < kJA; ++j) {
-      const int k = min(a0 + tid + j * kBlock, ahi);
-      st_dst[j] = out_dst[k];
-      st_w[j] = a.w[k];
+    for (int j = 0; j < kJA / 4; ++j) {
+      const int k = a0 + 4 * tid + j * 4 * kBlock;
+      v_dst[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.out_dstpos + k);
+      v_w[j] = *reinterpret_cast<const GTNX_G gtnx_f4*>(a.w + k);
     }
-#pragma unroll
-    for (int j = 0; j < kJN + 1; ++j) st_off[j] = out_off[min(n0 + tid + j * kBlock, last_node + 1)];
-#pragma unroll
-    for (int j = 0; j < kJN; ++j) {
-      const int p = min(n0 + tid + j * kBlock, last_node);
-      st_fl[j] = pflags[p];
-      st_sc[j] = scores[p];
-    }
+    const int nb = min(n0 + 4 * tid, last_node + 1);
+    v_off = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.out_off + nb);
+    v_off_last = s.out_off[min(n0 + kCN, last_node + 1)];
+    const int pb = min(n0 + 4 * tid, last_node);
+    v_fl = *reinterpret_cast<const GTNX_G unsigned*>(s.pflags + pb);
+    v_sc = *reinterpret_cast<const GTNX_G gtnx_f4*>(a.scores + pb);
   };
   auto stage_write = [&](int b, int n0, int n1) {
 #pragma unroll
-    for (int j = 0; j < kJA; ++j) {
-      arc_dst[b][tid + j * kBlock] = st_dst[j];
-      arc_w[b][tid + j * kBlock] = st_w[j];
+    for (int j = 0; j < kJA / 4; ++j) {
+      *reinterpret_cast<gtnx_i4*>(&arc_dst[b][4 * tid + j * 4 * kBlock]) = v_dst[j];
+      *reinterpret_cast<gtnx_f4*>(&arc_w[b][4 * tid + j * 4 * kBlock]) = v_w[j];
     }
+    *reinterpret_cast<gtnx_i4*>(&node_off[b][4 * tid]) = v_off;
+    if (tid == 0) node_off[b][kCN] = v_off_last;
+    *reinterpret_cast<unsigned*>(&node_fl[b][4 * tid]) = v_fl;
 #pragma unroll
-    for (int j = 0; j < kJN + 1; ++j) node_off[b][tid + j * kBlock] = st_off[j];
-#pragma unroll
-    for (int j = 0; j < kJN; ++j) {
-      node_fl[b][tid + j * kBlock] = uint8_t(st_fl[j]);
-      const int p = n0 + tid + j * kBlock;
-      if (p < n1) sc_ring[p & (kRingB - 1)] = st_sc[j];
+    for (int i = 0; i < 4; ++i) {
+      const int p = n0 + 4 * tid + i;
+      if (p < n1) sc_ring[p & (kRingB - 1)] = v_sc[i];
     }
   };
 
@@ -603,7 +669,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
               const int v = arc_dst[b][k];
               const float g = ng_ring[v & (kRingB - 1)] * __expf(su + arc_w[b][k] - sc_ring[v & (kRingB - 1)]);
               if (j < deg) {
-                a.arc_grad[a0 + k] = g * delta;
+                g_buf[k] = g * delta;
                 acc += g;
               }
             }
@@ -611,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
             for (int k = r0; k < r0 + deg; ++k) {
               const int v = arc_dst[b][k];
               const float g = ng_ring[v & (kRingB - 1)] * __expf(su + arc_w[b][k] - sc_ring[v & (kRingB - 1)]);
-              a.arc_grad[a0 + k] = g * delta;
+              g_buf[k] = g * delta;
               acc += g;
             }
           }
@@ -620,7 +686,9 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
         }
         lds_barrier();
       }
-      // ---- chunk switch (downwards)
+      // ---- chunk switch (downwards): land the staged chunk and refill first, then
+      // flush this chunk's arc gradients (stores stay behind the staged loads)
+      const int a1 = tab_arc[e];
       e = c;
       c = c2;
       b ^= 1;
@@ -629,6 +697,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
         c2 = c > 0 ? chunk_begin(c) : 0;
         if (c > 0) stage_load(tab_arc[c2], tab_arc[c], tab_node[c2], tab_node[c]);
       }
+      for (int k = a0 + tid; k < a1; k += kBlock) a.arc_grad[k] = g_buf[k - a0];
       lds_barrier();
     }
   }

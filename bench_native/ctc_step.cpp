@@ -3,6 +3,9 @@
 // on this engine: target graphs are built on host threads with parallelMap, the
 // graph functions run batched on the GPU through their vector overloads.
 // Built into bench_native/libgtn_bench.so and driven by bench.py over ctypes.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "gtn/gtn.h"
@@ -34,14 +37,27 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
                                                                          int B, int T, int C, int U, void* loss_dev,
                                                                          void* grad_dev) {
   try {
+    static const bool timing = std::getenv("GTN_BENCH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto t0 = now();
     std::vector<std::vector<int>> tg(B);
     for (int b = 0; b < B; ++b) tg[b].assign(targets + (size_t)b * U, targets + (size_t)(b + 1) * U);
     // fwd of benchmarks/ctc.cpp:150-158, batched
     auto ctcs = parallelMap(ctcGraph, tg);
+    auto t1 = now();
     auto ems = linearGraphs(B, T, C, emissions);  // linearGraph + setWeights, one copy
-    auto losses = subtract(forwardScore(ems), forwardScore(intersect(ctcs, ems)));
+    auto t2 = now();
+    auto comp = intersect(ctcs, ems);
+    auto t3 = now();
+    auto losses = subtract(forwardScore(ems), forwardScore(comp));
+    auto t4 = now();
     // bwd of benchmarks/ctc.cpp:160
     backward(losses);
+    auto t5 = now();
+    if (timing)
+      std::fprintf(stderr, "host ms: build %.2f linear %.2f intersect %.2f fwd %.2f bwd %.2f\n", ms(t0, t1), ms(t1, t2),
+                   ms(t2, t3), ms(t3, t4), ms(t4, t5));
     auto h = detail::handles(losses);
     detail::check(gtnx_items_device_n(h.data(), B, loss_dev));
     if (grad_dev) {

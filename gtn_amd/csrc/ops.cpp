@@ -703,13 +703,21 @@ struct ComposeOp : OpRecord {
   }
 };
 
-// label histogram of the labels compose matches on (olabel of g1 / ilabel of g2)
+// label histogram of the labels compose matches on (olabel of g1 / ilabel of g2).
+// Dense counts when the labels are small (the usual case), a hash map otherwise.
 struct LabelHist {
   bool linear = false;
   int M = 0, C = 0;
-  std::unordered_map<int, int64_t> cnt;
+  std::vector<int64_t> dense;               // dense[l] for 0 <= l < dense.size()
+  std::unordered_map<int, int64_t> sparse;  // labels >= kDenseMax
   int64_t eps = 0;
+  int64_t count(int l) const {
+    if (l < int(dense.size())) return dense[l];
+    auto it = sparse.find(l);
+    return it == sparse.end() ? 0 : it->second;
+  }
 };
+constexpr int kDenseMax = 1 << 16;
 void label_hist(Structure& s, bool use_olabel, LabelHist& h) {
   if (s.kind == KIND_LINEAR) {
     h.linear = true;
@@ -719,29 +727,29 @@ void label_hist(Structure& s, bool use_olabel, LabelHist& h) {
   }
   s.ensure_host();
   const std::vector<int>& lab = use_olabel ? s.ol : s.il;
+  int mx = -1;
+  for (int l : lab) mx = std::max(mx, l);
+  h.dense.assign(size_t(std::min(mx + 1, kDenseMax)), 0);
   for (int l : lab) {
     if (l == GTNX_EPSILON)
       h.eps++;
+    else if (l < kDenseMax)
+      h.dense[l]++;
     else
-      h.cnt[l]++;
+      h.sparse[l]++;
   }
 }
 int64_t match_bound(const LabelHist& a, const LabelHist& b) {
   // sum over non-eps labels of cnt_a[l] * cnt_b[l]
-  int64_t t = 0;
   if (a.linear && b.linear) return int64_t(std::min(a.C, b.C)) * a.M * b.M;
-  const LabelHist& e = a.linear ? b : a;  // explicit side (or a)
+  const LabelHist& e = a.linear ? b : a;  // an explicit side
   const LabelHist& o = a.linear ? a : b;
-  for (auto& kv : e.cnt) {
-    int64_t c2;
-    if (o.linear)
-      c2 = (kv.first >= 0 && kv.first < o.C) ? o.M : 0;
-    else {
-      auto it = o.cnt.find(kv.first);
-      c2 = it == o.cnt.end() ? 0 : it->second;
-    }
-    t += kv.second * c2;
+  int64_t t = 0;
+  for (size_t l = 0; l < e.dense.size(); ++l) {
+    if (!e.dense[l]) continue;
+    t += e.dense[l] * (o.linear ? ((int(l) < o.C) ? int64_t(o.M) : 0) : o.count(int(l)));
   }
+  for (auto& kv : e.sparse) t += kv.second * (o.linear ? ((kv.first < o.C) ? int64_t(o.M) : 0) : o.count(kv.first));
   return t;
 }
 } // namespace

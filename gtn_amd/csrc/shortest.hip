@@ -344,11 +344,13 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
       int q_p = 0, q_r0 = 0, q_deg = 0, q_fl = 0, q_nhi = 0;
       int q_sp[4];
       float q_w[4];
+      const int n_end = tab_node[e];  // chunk end (uniform)
+      int next_lo = n0;               // level i's first node == level i-1's end: no table read on the chain
       auto preload = [&](int i) {
-        const int nlo = tab_node[i];
-        q_nhi = tab_node[i + 1];
-        q_p = nlo + tid;
-        const int pc = max(min(q_p, q_nhi - 1), n0) - n0;
+        q_nhi = tab_node[i + 1];      // only needed for the bounds test, off the address chain
+        q_p = next_lo + tid;
+        next_lo = q_nhi;
+        const int pc = min(q_p, n_end - 1) - n0;
         q_r0 = node_off[b][pc] - a0;
         q_deg = node_off[b][pc + 1] - a0 - q_r0;
         q_fl = node_fl[b][pc];

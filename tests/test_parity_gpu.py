@@ -334,3 +334,117 @@ def test_deep_narrow_dags_vs_oracle(gtn):
         assert f == pytest.approx(o.shortest_distance(), rel=1e-5)
         assert v == pytest.approx(o.shortest_distance(True), rel=1e-6)
         assert close(g.grad().weights_to_numpy(), o.shortest_distance_grad(), RTOL, 1e-6)
+
+
+# ---- test/criterion_test.cpp:182-345 (ASG loss, shared transition grads, Viterbi decode) ----
+ASG_EMISSIONS = [
+    [-0.4340, -0.0254, 0.3667, 0.4180, -0.3805, -0.1707, 0.1060, 0.3631, -0.1122, -0.3825, -0.0031, -0.3801,
+     0.0443, -0.3795, 0.3194, -0.3130, 0.0094, 0.1560, 0.1252, 0.2877, 0.1997, -0.4554, 0.2774, -0.2526,
+     -0.4001, -0.2402, 0.1295, 0.0172, 0.1805, -0.3299],
+    [0.3298, -0.2259, -0.0959, 0.4909, 0.2996, -0.2543, -0.2863, 0.3239, -0.3988, 0.0732, -0.2107, -0.4739,
+     -0.0906, 0.0480, -0.1301, 0.3975, -0.3317, -0.1967, 0.4372, -0.2006, 0.0094, 0.3281, 0.1873, -0.2945,
+     0.2399, 0.0320, -0.3768, -0.2849, -0.2248, 0.3186],
+    [0.0225, -0.3867, -0.1929, -0.2904, -0.4958, -0.2533, 0.4001, -0.1517, -0.2799, -0.2915, 0.4198, 0.4506,
+     0.1446, -0.4753, -0.0711, 0.2876, -0.1851, -0.1066, 0.2081, -0.1190, -0.3902, -0.1668, 0.1911, -0.2848,
+     -0.3846, 0.1175, 0.1052, 0.2172, -0.0362, 0.3055]]
+ASG_EM_GRADS = [
+    [0.1060, 0.1595, -0.7639, 0.2485, 0.1118, 0.1380, 0.1915, -0.7524, 0.1539, 0.1175, 0.1717, 0.1178,
+     0.1738, 0.1137, 0.2288, 0.1216, 0.1678, -0.8057, 0.1766, -0.7923, 0.1902, 0.0988, 0.2056, 0.1210,
+     0.1212, 0.1422, 0.2059, -0.8160, 0.2166, 0.1300],
+    [0.2029, 0.1164, 0.1325, 0.2383, -0.8032, 0.1131, 0.1414, 0.2602, 0.1263, -0.3441, -0.3009, 0.1172,
+     0.1557, 0.1788, 0.1496, -0.5498, 0.0140, 0.0516, 0.2306, 0.1219, 0.1503, -0.4244, 0.1796, -0.2579,
+     0.2149, 0.1745, 0.1160, 0.1271, 0.1350, -0.7675],
+    [0.2195, 0.1458, 0.1770, -0.8395, 0.1307, 0.1666, 0.2148, 0.1237, -0.6613, -0.1223, 0.2191, 0.2259,
+     0.2002, 0.1077, -0.8386, 0.2310, 0.1440, 0.1557, 0.2197, -0.1466, -0.5742, 0.1510, 0.2160, 0.1342,
+     0.1050, -0.8265, 0.1714, 0.1917, 0.1488, 0.2094]]
+ASG_TRANS_GRAD = [
+    0.3990, 0.3396, 0.3486, 0.3922, 0.3504, 0.3155, 0.3666, 0.0116, -1.6678, 0.3737, 0.3361, -0.7152,
+    0.3468, 0.3163, -1.1583, -0.6803, 0.3216, 0.2722, 0.3694, -0.6688, 0.3047, -0.8531, -0.6571, 0.2870,
+    0.3866, 0.3321, 0.3447, 0.3664, -0.2163, 0.3039, 0.3640, -0.6943, 0.2988, -0.6722, 0.3215, -0.1860]
+
+
+def asg_transitions(gtn, N, weights=None):
+    g = gtn.Graph()
+    g.add_node(True)
+    for i in range(1, N + 1):
+        g.add_node(False, True)
+        g.add_arc(0, i, i - 1)
+    for i in range(N):
+        for j in range(N):
+            g.add_arc(j + 1, i + 1, i, i, 0.0 if weights is None else weights[i * N + j])
+    return g
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_asg_criterion(gtn, batched):
+    T, N = 5, 6
+    targets = [[2, 1, 5, 1, 3], [4, 3, 5], [3, 2, 2, 1]]
+    expected_loss = [7.7417464256287, 6.4200420379639, 8.2780694961548]
+    transitions = asg_transitions(gtn, N)
+    fals, ems = [], []
+    for target, ev in zip(targets, ASG_EMISSIONS):
+        fal = gtn.Graph()
+        fal.add_node(True)
+        for l in range(1, len(target) + 1):
+            fal.add_node(False, l == len(target))
+            fal.add_arc(l - 1, l, target[l - 1])
+            fal.add_arc(l, l, target[l - 1])
+        e = gtn.linear_graph(T, N)
+        e.set_weights(np.array(ev, np.float32))
+        fals.append(fal)
+        ems.append(e)
+    if batched:
+        # the shared transitions graph broadcasts; its gradient accumulates over the batch
+        fcc = gtn.forward_score(gtn.compose(ems, [transitions]))
+        fal = gtn.forward_score(gtn.compose(gtn.compose(fals, [transitions]), ems))
+        losses = gtn.subtract(fcc, fal)
+        gtn.backward(losses)
+        vals = gtn.items(losses)
+    else:
+        vals = []
+        for fal, e in zip(fals, ems):
+            loss = gtn.subtract(gtn.forward_score(gtn.compose(e, transitions)),
+                                gtn.forward_score(gtn.compose(gtn.compose(fal, transitions), e)))
+            vals.append(loss.item())
+            gtn.backward(loss)
+    for b in range(3):
+        assert abs(vals[b] - expected_loss[b]) < 1e-3
+        np.testing.assert_allclose(ems[b].grad().weights_to_numpy(), ASG_EM_GRADS[b], atol=1e-4)
+    np.testing.assert_allclose(transitions.grad().weights_to_numpy()[N:], ASG_TRANS_GRAD, atol=1e-4)
+
+
+def test_asg_viterbi_path(gtn):
+    T, N = 4, 3
+    inp = [0, 0, 7, 5, 4, 3, 5, 8, 5, 5, 4, 3]
+    trans = [0, 2, 0, 0, 0, 2, 2, 0, 0]
+    e = gtn.linear_graph(T, N)
+    e.set_weights(np.array(inp, np.float32))
+    path = gtn.viterbi_path(gtn.compose(e, asg_transitions(gtn, N, trans)))
+    assert path.labels_to_list() == [2, 1, 1, 0]
+
+
+def test_asg_shape_vs_oracle(gtn):
+    """emissions o dense transitions at a size where levels are wide (C=48)"""
+    rng = np.random.default_rng(3)
+    T, N = 40, 48
+    em = rng.normal(0, 1, (T, N)).astype(np.float32)
+    tw = rng.normal(0, 1, N * N).astype(np.float32)
+    trans = asg_transitions(gtn, N, tw)
+    e = gtn.linear_graph(T, N)
+    e.set_weights(em)
+    comp = gtn.compose(e, trans)
+    assert comp.num_arcs() == N * N * (T - 1) + N          # examples/asg.cpp:72-74
+    d = gg.from_api(trans)
+    oc = OGraph.linear(T, N, em).compose(OGraph.from_dict(d))
+    assert (comp.num_nodes(), comp.num_arcs()) == (oc.N, oc.A)
+    fs = gtn.forward_score(comp)
+    assert fs.item() == pytest.approx(oc.shortest_distance(), rel=1e-5)
+    assert gtn.viterbi_score(comp).item() == pytest.approx(oc.shortest_distance(True), rel=1e-6)
+    arcs, _ = oc.shortest_path()
+    od = oc.to_dict()
+    assert gtn.viterbi_path(comp).labels_to_list() == [od["il"][a] for a in arcs]
+    gtn.backward(fs)
+    gc = oc.shortest_distance_grad()
+    g1, g2 = oc.compose_grad(gc, T * N, len(d["src"]))
+    np.testing.assert_allclose(e.grad().weights_to_numpy(), g1, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(trans.grad().weights_to_numpy(), g2, rtol=1e-4, atol=1e-5)

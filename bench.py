@@ -221,9 +221,19 @@ def main():
     if fs["launches"]:
         ms = fs["total_ms"] / fs["launches"]
         gbs = fs["algorithmic_bytes"] / fs["launches"] / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "sd_forward_kernel<LOG> (forwardScore over the composed lattices)",
+        # HBM bytes per launch from the PMC run of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate passes, profiles/r01_v3_c3_pmc_hbm.json).
+        # Calibrated on linear_forward_kernel, whose bytes are known exactly
+        # (B*T*C*4): FETCH_SIZE reads half the fetched KiB on gfx950, WRITE_SIZE is exact.
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_v3_c3_pmc_hbm.json")
+        if (B, T, Cn, U) == (512, 1000, 256, 100) and os.path.exists(pmc):
+            k = json.load(open(pmc)).get("sd_forward_narrow_kernel<true>")
+            if k:
+                traffic = (2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024
+        roof = {"bound": "hbm", "kernel": "sd_forward_narrow_kernel<true> (forwardScore over the composed lattices)",
                 "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": None, "ms_per_launch": ms,
+                "traffic": traffic, "ms_per_launch": ms,
                 "algorithmic_bytes_per_launch": fs["algorithmic_bytes"] / fs["launches"]}
     if rank == 0:
         n_nodes, n_arcs = comp[0].num_nodes(), comp[0].num_arcs()

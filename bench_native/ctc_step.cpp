@@ -48,12 +48,12 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
     auto t1 = now();
     auto ems = linearGraphs(B, T, C, emissions);  // linearGraph + setWeights, one copy
     auto t2 = now();
-    auto comp = intersect(ctcs, ems);
+    auto comp = batched::intersect(ctcs, ems);
     auto t3 = now();
-    auto losses = subtract(forwardScore(ems), forwardScore(comp));
+    auto losses = batched::subtract(batched::forwardScore(ems), batched::forwardScore(comp));
     auto t4 = now();
     // bwd of benchmarks/ctc.cpp:160
-    backward(losses);
+    batched::backward(losses);
     auto t5 = now();
     if (timing)
       std::fprintf(stderr, "host ms: build %.2f linear %.2f intersect %.2f fwd %.2f bwd %.2f\n", ms(t0, t1), ms(t1, t2),

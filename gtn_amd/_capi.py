@@ -72,6 +72,10 @@ _SIGS = {
     "gtnx_graph_id": [c_graph, C.POINTER(C.c_size_t)],
     "gtnx_graph_create_op": [c_graph_p, C.c_int, GRAD_FN, C.c_void_p, CTX_FREE, c_graph_p],
     "gtnx_graph_num_inputs": [c_graph, c_i64_p],
+    "gtnx_graph_get_input": [c_graph, C.c_int, c_graph_p],
+    "gtnx_graph_set_inputs": [c_graph, c_graph_p, C.c_int],
+    "gtnx_graph_set_grad_fn": [c_graph, GRAD_FN, C.c_void_p, CTX_FREE],
+    "gtnx_graph_has_grad_fn": [c_graph, c_i32_p],
     "gtnx_scalar_graph": [C.c_float, C.c_int, c_graph_p],
     "gtnx_linear_graph": [C.c_int, C.c_int, C.c_int, c_graph_p],
     "gtnx_linear_graph_n": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_graph_p],

@@ -394,6 +394,23 @@ GTNX_API gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n, gtnx_gr
   });
 }
 
+GTNX_API gtnx_status_t gtnx_graph_get_input(gtnx_graph_t g, int i, gtnx_graph_t* out) {
+  return guard([&] {
+    auto& ins = G(g).g->inputs;
+    if (i < 0 || size_t(i) >= ins.size()) throw_range("input index out of range");
+    *out = H(ins[size_t(i)]);
+  });
+}
+GTNX_API gtnx_status_t gtnx_graph_set_inputs(gtnx_graph_t g, const gtnx_graph_t* inputs, int n) {
+  return guard([&] { G(g).g->inputs = vec(inputs, n); });
+}
+GTNX_API gtnx_status_t gtnx_graph_set_grad_fn(gtnx_graph_t g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*)) {
+  return guard([&] { set_user_grad_fn(G(g), fn, ctx, ctx_free); });
+}
+GTNX_API gtnx_status_t gtnx_graph_has_grad_fn(gtnx_graph_t g, int* out) {
+  return guard([&] { *out = G(g).g->has_grad_fn ? 1 : 0; });
+}
+
 // ------------------------------------------------------------------ creations
 GTNX_API gtnx_status_t gtnx_scalar_graph(float v, int cg, gtnx_graph_t* out) {
   return guard([&] { *out = H(make_scalar_graph(v, cg != 0)); });

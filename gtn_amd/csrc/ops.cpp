@@ -1069,6 +1069,22 @@ Graph make_user_op(std::vector<Graph>& inputs, gtnx_grad_fn fn, void* ctx, void 
   return out;
 }
 
+void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*)) {
+  // Graph::setGradFunc (graph.h:293-297): a no-op unless the graph wants gradients
+  if (!g.calc_grad()) {
+    if (ctx_free) ctx_free(ctx);
+    return;
+  }
+  auto op = std::make_shared<UserOp>();
+  op->fn = fn;
+  op->ctx = ctx;
+  op->ctx_free = ctx_free;
+  op->seq = g_seq++;
+  g.g->op = op;
+  g.g->op_idx = 0;
+  g.g->has_grad_fn = fn != nullptr;
+}
+
 // ======================================================================
 // backward (autograd.cpp:17-67)
 // ======================================================================

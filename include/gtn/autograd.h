@@ -7,8 +7,10 @@ inline void backward(Graph g, bool retainGraph = false) { detail::check(gtnx_bac
 inline void backward(Graph g, const Graph& grad, bool retainGraph = false) {
   detail::check(gtnx_backward_with_grad(g.handle(), grad.handle(), retainGraph));
 }
+namespace batched {
 inline void backward(const std::vector<Graph>& graphs, bool retainGraph = false) {
   auto h = detail::handles(graphs);
   if (!h.empty()) detail::check(gtnx_backward_n(h.data(), (int)h.size(), retainGraph));
 }
+} // namespace batched
 } // namespace gtn

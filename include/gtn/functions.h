@@ -4,6 +4,7 @@
 // batched device launch per kernel family.
 #pragma once
 
+#include <algorithm>
 #include <vector>
 
 #include "gtn/graph.h"
@@ -59,6 +60,9 @@ inline Graph forwardScore(const Graph& g) { return detail::unary(&gtnx_forward_s
 inline Graph viterbiScore(const Graph& g) { return detail::unary(&gtnx_viterbi_score, g); }
 inline Graph viterbiPath(const Graph& g) { return detail::unary(&gtnx_viterbi_path, g); }
 
+// Batched forms live in gtn::batched so that the plain names stay un-overloaded
+// (reference callers pass them as function pointers, e.g. parallelMap(negate, v)).
+namespace batched {
 inline std::vector<Graph> negate(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_negate_n, g); }
 inline std::vector<Graph> add(const std::vector<Graph>& a, const std::vector<Graph>& b) {
   return detail::binaryN(&gtnx_add_n, a, b);
@@ -75,5 +79,150 @@ inline std::vector<Graph> intersect(const std::vector<Graph>& a, const std::vect
 inline std::vector<Graph> forwardScore(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_forward_score_n, g); }
 inline std::vector<Graph> viterbiScore(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_viterbi_score_n, g); }
 inline std::vector<Graph> viterbiPath(const std::vector<Graph>& g) { return detail::unaryN(&gtnx_viterbi_path_n, g); }
+} // namespace batched
+
+// ---------------------------------------------------------------------------
+// Rational / structural operations (reference gtn/functions.h:45-123).  They are
+// off the hot path (graph-construction utilities run once on tiny
+// graphs), so they are plain host-side constructions over the public Graph API;
+// they exist so reference callers and the reference's own tests compile
+// unchanged.  Gradients are slices / copies of the output's deltas, as there.
+// ---------------------------------------------------------------------------
+enum class Projection { NONE = 0, INPUT = 1, OUTPUT = 2 };
+
+inline Graph clone(const Graph& g, Projection projection = Projection::NONE) {
+  // functions.cpp:66-83
+  Graph out([](std::vector<Graph>& inputs, Graph& deltas) { inputs[0].addGrad(deltas); }, {g});
+  for (size_t n = 0; n < g.numNodes(); ++n) out.addNode(g.isStart(n), g.isAccept(n));
+  for (size_t a = 0; a < g.numArcs(); ++a) {
+    const int il = projection == Projection::OUTPUT ? g.olabel(a) : g.ilabel(a);
+    const int ol = projection == Projection::INPUT ? g.ilabel(a) : g.olabel(a);
+    out.addArc(g.srcNode(a), g.dstNode(a), il, ol, g.weight(a));
+  }
+  return out;
+}
+inline Graph projectInput(const Graph& g) { return clone(g, Projection::INPUT); }
+inline Graph projectOutput(const Graph& g) { return clone(g, Projection::OUTPUT); }
+
+inline Graph concat(const std::vector<Graph>& graphs) {
+  // functions.cpp:97-153: graph i's accept nodes are joined to graph i+1's start
+  // nodes by epsilon arcs, which sit between the two graphs' arcs in arc order
+  auto gradFunc = [](std::vector<Graph>& inputs, Graph& deltas) {
+    const float* grad = deltas.weights();
+    for (size_t i = 0; i < inputs.size(); ++i) {
+      Graph& in = inputs[i];
+      if (in.calcGrad()) in.addGrad(std::vector<float>(grad, grad + in.numArcs()));
+      grad += in.numArcs();
+      if (i > 0) grad += inputs[i - 1].numAccept() * in.numStart();
+    }
+  };
+  Graph out(gradFunc, graphs);
+  if (graphs.empty()) {
+    out.addNode(true, true);  // a^0 accepts the empty string
+    return out;
+  }
+  size_t offset = 0;
+  for (size_t i = 0; i < graphs.size(); ++i) {
+    const Graph& g = graphs[i];
+    for (size_t n = 0; n < g.numNodes(); ++n)
+      out.addNode(i == 0 && g.isStart(n), i + 1 == graphs.size() && g.isAccept(n));
+    for (size_t a = 0; a < g.numArcs(); ++a)
+      out.addArc(offset + g.srcNode(a), offset + g.dstNode(a), g.ilabel(a), g.olabel(a), g.weight(a));
+    if (i > 0) {
+      const Graph& prev = graphs[i - 1];
+      const size_t prevOffset = offset - prev.numNodes();
+      const std::vector<int> accepts = prev.accept();
+      const std::vector<int> starts = g.start();
+      for (int acc : accepts)
+        for (int st : starts) out.addArc(acc + prevOffset, st + offset, epsilon);
+    }
+    offset += g.numNodes();
+  }
+  return out;
+}
+inline Graph concat(const Graph& g1, const Graph& g2) { return concat(std::vector<Graph>{g1, g2}); }
+
+inline Graph closure(const Graph& g) {
+  // functions.cpp:155-186: new start/accept node 0, old graph shifted by one
+  auto gradFunc = [](std::vector<Graph>& inputs, Graph& deltas) {
+    const float* grad = deltas.weights();
+    inputs[0].addGrad(std::vector<float>(grad, grad + inputs[0].numArcs()));
+  };
+  Graph closed(gradFunc, {g});
+  closed.addNode(true, true);
+  for (size_t n = 0; n < g.numNodes(); ++n) closed.addNode();
+  for (size_t a = 0; a < g.numArcs(); ++a)
+    closed.addArc(g.srcNode(a) + 1, g.dstNode(a) + 1, g.ilabel(a), g.olabel(a), g.weight(a));
+  const std::vector<int> starts = g.start();
+  const std::vector<int> accepts = g.accept();
+  for (int s : starts) closed.addArc(0, s + 1, epsilon);
+  for (int a : accepts) closed.addArc(a + 1, 0, epsilon);
+  return closed;
+}
+
+inline Graph union_(const std::vector<Graph>& graphs) {
+  // functions.cpp:188-223
+  auto gradFunc = [](std::vector<Graph>& inputs, Graph& deltas) {
+    const float* grad = deltas.weights();
+    for (auto& in : inputs) {
+      if (in.calcGrad()) in.addGrad(std::vector<float>(grad, grad + in.numArcs()));
+      grad += in.numArcs();
+    }
+  };
+  Graph out(gradFunc, graphs);
+  size_t offset = 0;
+  for (const Graph& g : graphs) {
+    for (size_t n = 0; n < g.numNodes(); ++n) out.addNode(g.isStart(n), g.isAccept(n));
+    for (size_t a = 0; a < g.numArcs(); ++a)
+      out.addArc(offset + g.srcNode(a), offset + g.dstNode(a), g.ilabel(a), g.olabel(a), g.weight(a));
+    offset += g.numNodes();
+  }
+  return out;
+}
+
+inline Graph remove(const Graph& g, int ilabel, int olabel) {
+  // functions.cpp:257-318: contract arcs labelled (ilabel:olabel); no gradient
+  auto gradFunc = [](std::vector<Graph>&, Graph&) {
+    throw std::logic_error("[gtn::remove] gradient compuation not implemented");
+  };
+  auto matches = [&](int a) { return g.ilabel(a) == ilabel && g.olabel(a) == olabel; };
+  const int N = static_cast<int>(g.numNodes());
+  std::vector<int> newId(N, -1);
+  Graph out(gradFunc, {g});
+  for (int n = 0; n < N; ++n) {
+    bool keep = g.isStart(n);
+    if (!keep) {
+      const std::vector<int> ins = g.in(n);
+      for (int a : ins) keep = keep || !matches(a);
+    }
+    if (keep) newId[n] = out.addNode(g.isStart(n));
+  }
+  for (int n = 0; n < N; ++n) {
+    const int cur = newId[n];
+    if (cur < 0) continue;
+    // every node reachable from n through removable arcs folds into n
+    std::vector<int> todo{n};
+    std::vector<char> seen(N, 0);
+    seen[n] = 1;
+    for (size_t k = 0; k < todo.size(); ++k) {
+      const int next = todo[k];
+      if (g.isAccept(next)) out.makeAccept(cur);
+      const std::vector<int> outs = g.out(next);
+      for (int a : outs) {
+        const int dn = g.dstNode(a);
+        if (matches(a)) {
+          if (!seen[dn]) {
+            seen[dn] = 1;
+            todo.push_back(dn);
+          }
+        } else {
+          out.addArc(cur, newId[dn], g.ilabel(a), g.olabel(a));
+        }
+      }
+    }
+  }
+  return out;
+}
+inline Graph remove(const Graph& g, int label = epsilon) { return remove(g, label, label); }
 
 } // namespace gtn

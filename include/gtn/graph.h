@@ -154,6 +154,39 @@ class Graph {
     detail::check(gtnx_graph_id(h_, &v));
     return v;
   }
+  /** non-null iff a gradient function is attached (reference graph.h:286); the
+   *  engine owns the function, so the returned callable only reports presence */
+  GradFunc gradFunc() {
+    int v;
+    detail::check(gtnx_graph_has_grad_fn(h_, &v));
+    if (!v) return nullptr;
+    return [](std::vector<Graph>&, Graph&) {
+      throw std::logic_error("[Graph::gradFunc] engine-owned gradient functions run through gtn::backward");
+    };
+  }
+  void setGradFunc(GradFunc gradFunc) {
+    auto* ctx = gradFunc ? new GradFunc(std::move(gradFunc)) : nullptr;
+    detail::check(gtnx_graph_set_grad_fn(h_, ctx ? &Graph::trampoline : nullptr, ctx, ctx ? &Graph::freeCtx : nullptr));
+  }
+  std::vector<Graph>& inputs() const {
+    int64_t n;
+    detail::check(gtnx_graph_num_inputs(h_, &n));
+    inputs_.clear();
+    for (int64_t i = 0; i < n; ++i) {
+      gtnx_graph_t h;
+      detail::check(gtnx_graph_get_input(h_, (int)i, &h));
+      inputs_.push_back(Graph(h));
+    }
+    return inputs_;
+  }
+  void setInputs(std::vector<Graph> inputs) {
+    std::vector<gtnx_graph_t> hs;
+    for (auto& g : inputs) hs.push_back(g.h_);
+    detail::check(gtnx_graph_set_inputs(h_, hs.data(), (int)hs.size()));
+  }
+  /** reference graph.h:317-321 drops the weights to save memory on the tape; the
+   *  engine keeps device buffers alive through the tape itself, so this aliases */
+  Graph withoutWeights() const { return *this; }
 
   const std::vector<int>& start() const {
     cacheA_.resize(numStart());
@@ -259,6 +292,7 @@ class Graph {
 
   gtnx_graph_t h_{nullptr};
   mutable std::unique_ptr<Graph> grad_;
+  mutable std::vector<Graph> inputs_;
   mutable std::vector<int> cacheA_, cacheB_, cacheC_, cacheD_;
 };
 

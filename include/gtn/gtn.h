@@ -5,4 +5,5 @@
 #include "gtn/functions.h"
 #include "gtn/graph.h"
 #include "gtn/parallel.h"
+#include "gtn/rand.h"
 #include "gtn/utils.h"

@@ -1,8 +1,10 @@
 // gtn/utils.h -- the fixtures of the parity suite from reference gtn/utils.h:23-153:
-// equal, isomorphic, loadTxt, saveTxt, operator<<.
+// equal, isomorphic, load/save (binary), loadTxt/saveTxt, operator<<, draw.
 #pragma once
 
+#include <fstream>
 #include <istream>
+#include <unordered_map>
 #include <ostream>
 #include <sstream>
 #include <string>
@@ -62,19 +64,131 @@ inline Graph loadTxt(std::istream& in) {
 }
 inline Graph loadTxt(std::istream&& in) { return loadTxt(in); }
 
-inline void saveTxt(std::ostream& out, const Graph& g) {
-  auto list = [&](const std::vector<int>& v) {
-    for (size_t i = 0; i < v.size(); ++i) out << (i ? " " : "") << v[i];
+inline Graph loadTxt(const std::string& fileName) {
+  std::ifstream in(fileName);
+  if (!in) throw std::invalid_argument("Couldn't find graph file to load. '" + fileName + "'");
+  return loadTxt(in);
+}
+
+namespace detail {
+/** text writer shared by saveTxt and operator<<; `cap` < 0 prints everything,
+ *  otherwise at most `cap` entries per section (reference utils.cpp:226-262) */
+inline void writeTxt(std::ostream& out, const Graph& g, int cap) {
+  auto ids = [&](const std::vector<int>& v) {
+    for (size_t i = 0; i < v.size(); ++i) {
+      if (cap >= 0 && (int)i >= cap) {
+        out << " ...";
+        break;
+      }
+      out << (i ? " " : "") << v[i];
+    }
     out << "\n";
   };
-  list(g.start());
-  list(g.accept());
-  for (size_t a = 0; a < g.numArcs(); ++a)
+  ids(g.start());
+  ids(g.accept());
+  for (size_t a = 0; a < g.numArcs(); ++a) {
+    if (cap >= 0 && (int)a >= cap) {
+      out << "...\n";
+      break;
+    }
     out << g.srcNode(a) << " " << g.dstNode(a) << " " << g.ilabel(a) << " " << g.olabel(a) << " " << g.weight(a)
         << "\n";
+  }
 }
-inline std::ostream& operator<<(std::ostream& out, const Graph& g) {
+} // namespace detail
+
+inline void saveTxt(std::ostream& out, const Graph& g) { detail::writeTxt(out, g, -1); }
+inline void saveTxt(const std::string& fileName, const Graph& g) {
+  std::ofstream out(fileName);
   saveTxt(out, g);
+}
+/** graphs with more than 20 nodes or arcs print a 10-entry summary (utils.cpp:391-394) */
+inline std::ostream& operator<<(std::ostream& out, const Graph& g) {
+  detail::writeTxt(out, g, std::max(g.numArcs(), g.numNodes()) > 20 ? 10 : -1);
   return out;
+}
+
+/** binary format of reference utils.cpp:150-224: int32 {numNodes, numArcs, numStart,
+ *  numAccept}, start ids, accept ids, numArcs x {src, dst, ilabel, olabel}, weights */
+inline void save(std::ostream& out, const Graph& g) {
+  auto put = [&](const void* p, size_t bytes) { out.write(static_cast<const char*>(p), (std::streamsize)bytes); };
+  const int head[4] = {(int)g.numNodes(), (int)g.numArcs(), (int)g.numStart(), (int)g.numAccept()};
+  put(head, sizeof(head));
+  put(g.start().data(), sizeof(int) * g.start().size());
+  put(g.accept().data(), sizeof(int) * g.accept().size());
+  std::vector<int> rows(size_t(4) * g.numArcs());
+  for (size_t a = 0; a < g.numArcs(); ++a) {
+    rows[4 * a] = g.srcNode(a);
+    rows[4 * a + 1] = g.dstNode(a);
+    rows[4 * a + 2] = g.ilabel(a);
+    rows[4 * a + 3] = g.olabel(a);
+  }
+  put(rows.data(), sizeof(int) * rows.size());
+  if (g.numArcs()) put(g.weights(), sizeof(float) * g.numArcs());
+}
+inline void save(const std::string& fileName, const Graph& g) {
+  std::ofstream out(fileName, std::ios::binary);
+  save(out, g);
+}
+inline Graph load(std::istream& in) {
+  auto get = [&](void* p, size_t bytes) { in.read(static_cast<char*>(p), (std::streamsize)bytes); };
+  int head[4] = {0, 0, 0, 0};
+  get(head, sizeof(head));
+  std::vector<int> start(head[2]), accept(head[3]);
+  get(start.data(), sizeof(int) * start.size());
+  get(accept.data(), sizeof(int) * accept.size());
+  std::vector<uint8_t> isStart(head[0], 0), isAccept(head[0], 0);
+  for (int s : start) isStart.at(s) = 1;
+  for (int a : accept) isAccept.at(a) = 1;
+  Graph g;
+  for (int i = 0; i < head[0]; ++i) g.addNode(isStart[i], isAccept[i]);
+  std::vector<int> rows(size_t(4) * head[1]);
+  get(rows.data(), sizeof(int) * rows.size());
+  for (int a = 0; a < head[1]; ++a) g.addArc(rows[4 * a], rows[4 * a + 1], rows[4 * a + 2], rows[4 * a + 3]);
+  std::vector<float> w(head[1]);
+  get(w.data(), sizeof(float) * w.size());
+  if (head[1]) g.setWeights(w.data());
+  return g;
+}
+inline Graph load(std::istream&& in) { return load(in); }
+inline Graph load(const std::string& fileName) {
+  std::ifstream in(fileName, std::ios::binary);
+  if (!in) throw std::invalid_argument("Couldn't find graph file to load. '" + fileName + "'");
+  return load(in);
+}
+
+using SymbolMap = std::unordered_map<int, std::string>;
+
+/** graphviz dot writer (reference utils.cpp:396-461): start nodes first, accept
+ *  nodes last; labels through the symbol maps, epsilon as "ε" */
+inline void draw(const Graph& g, std::ostream& out, const SymbolMap& isymbols = SymbolMap(),
+                 const SymbolMap& osymbols = SymbolMap()) {
+  auto sym = [](const SymbolMap& m, int label) -> std::string {
+    if (label == epsilon) return "ε";
+    return m.empty() ? std::to_string(label) : m.at(label);
+  };
+  auto node = [&](int n) {
+    out << "  " << n << " [label = \"" << n << "\", shape = " << (g.isAccept(n) ? "doublecircle" : "circle")
+        << ", penwidth = " << (g.isStart(n) ? "2.0" : "1.0") << ", fontsize = 14];\n";
+    for (int a : g.out(n)) {
+      out << "  " << g.srcNode(a) << " -> " << g.dstNode(a) << " [label = \"" << sym(isymbols, g.ilabel(a));
+      if (!osymbols.empty()) out << ":" << sym(osymbols, g.olabel(a));
+      out << "/" << g.weight(a) << "\", fontsize = 14];\n";
+    }
+  };
+  out << "digraph FST {\n  margin = 0;\n  rankdir = LR;\n  label = \"\";\n"
+      << "  center = 1;\n  ranksep = \"0.4\";\n  nodesep = \"0.25\";\n";
+  for (int n : g.start()) node(n);
+  for (size_t n = 0; n < g.numNodes(); ++n)
+    if (!g.isStart(n) && !g.isAccept(n)) node((int)n);
+  for (int n : g.accept())
+    if (!g.isStart(n)) node(n);
+  out << "}";
+}
+inline void draw(const Graph& g, const std::string& filename, const SymbolMap& isymbols = SymbolMap(),
+                 const SymbolMap& osymbols = SymbolMap()) {
+  std::ofstream out(filename);
+  if (!out.is_open()) throw std::runtime_error("Could not open file [" + filename + "]");
+  draw(g, out, isymbols, osymbols);
 }
 } // namespace gtn

@@ -128,6 +128,11 @@ typedef gtnx_status_t (*gtnx_grad_fn)(void* ctx, gtnx_graph_t* inputs, int n_inp
 gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n_inputs, gtnx_grad_fn grad_fn,
                                    void* ctx, void (*ctx_free)(void*), gtnx_graph_t* out);
 gtnx_status_t gtnx_graph_num_inputs(gtnx_graph_t g, int64_t* out);                      /* graph.h:303 */
+gtnx_status_t gtnx_graph_get_input(gtnx_graph_t g, int i, gtnx_graph_t* out);           /* graph.h:303 (new handle) */
+gtnx_status_t gtnx_graph_set_inputs(gtnx_graph_t g, const gtnx_graph_t* inputs, int n); /* graph.h:311 */
+gtnx_status_t gtnx_graph_set_grad_fn(gtnx_graph_t g, gtnx_grad_fn grad_fn, void* ctx,
+                                     void (*ctx_free)(void*));                          /* graph.h:293 */
+gtnx_status_t gtnx_graph_has_grad_fn(gtnx_graph_t g, int* out);                         /* graph.h:286 */
 
 /* ------------------------------------------------------------------ creations
  * gtn/creations.h:25,32 */

@@ -308,6 +308,29 @@ gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n,
   });
 }
 
+gtnx_status_t gtnx_graph_get_input(gtnx_graph_t g, int i, gtnx_graph_t* out) {
+  return guard([&] { *out = H(G(g).inputs().at(i)); });
+}
+gtnx_status_t gtnx_graph_set_inputs(gtnx_graph_t g, const gtnx_graph_t* inputs, int n) {
+  return guard([&] { G(g).setInputs(vec(inputs, n)); });
+}
+gtnx_status_t gtnx_graph_set_grad_fn(gtnx_graph_t g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*)) {
+  return guard([&] {
+    std::shared_ptr<void> holder(ctx, [ctx_free](void* p) { if (ctx_free) ctx_free(p); });
+    Graph::GradFunc gf = nullptr;
+    if (fn) gf = [fn, holder](std::vector<Graph>& ins, Graph& deltas) {
+      std::vector<gtnx_graph_t> hs;
+      for (auto& i : ins) hs.push_back(reinterpret_cast<gtnx_graph_t>(&i));
+      if (fn(holder.get(), hs.data(), (int)hs.size(), reinterpret_cast<gtnx_graph_t>(&deltas)) != GTNX_OK)
+        throw std::runtime_error("grad_fn failed");
+    };
+    G(g).setGradFunc(gf);
+  });
+}
+gtnx_status_t gtnx_graph_has_grad_fn(gtnx_graph_t g, int* out) {
+  return guard([&] { *out = G(g).gradFunc() != nullptr; });
+}
+
 gtnx_status_t gtnx_scalar_graph(float v, int cg, gtnx_graph_t* out) {
   return guard([&] { *out = H(gtn::scalarGraph(v, cg != 0)); });
 }

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   __shared__ int front[2][FC];   // also the backward queue (2 x BQ/2 ... see below)
   __shared__ int incnt[WC];
   __shared__ int incur[WC];
+  __shared__ int sh_rep[2];  // stationarity mismatch flags: [0] phase B sets, [1] phase F frontiers
   extern __shared__ __attribute__((aligned(16))) unsigned dyn_bits[];
   const int nwords = (N1 * N2 + 31) >> 5;
   const bool lds_state = FAST ? true : (a.lds_state != 0);
@@ -334,8 +335,23 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     __syncthreads();
   };
 
+  // ---- stationary-level replication (product with ONE implicit linear chain whose
+  // partner has no epsilon labels): the pair (n, t) only ever steps to (n', t+1) and
+  // the chain offers every label at every t, so both the co-reachable set B[t] and
+  // the ordered forward frontier S[t] are images of a time-invariant map.  Once
+  // B[t-1] == B[t] every earlier B equals it; once S[t+1] == S[t] (same order) under
+  // a constant filter, every later level is the previous one shifted by one time
+  // step -- ids + W, arc ids + Aw, chain arc + C -- and is emitted from registers
+  // for all remaining stationary t at once instead of one BFS level at a time.
+  constexpr bool REP = FAST && (L1 != L2);
+  const bool rep_ok = REP && ((L2 ? a.g1.flags : a.g2.flags) & GF_EPS_FREE);
+  const int tshift = L2 ? N1 : 1;           // pair-id step per time step
+  const int TM = L2 ? a.g2.M : a.g1.M;      // chain length
+  const int CL = L2 ? a.g2.C : a.g1.C;      // chain arcs per time step
+  int tB = -1;                              // B[t] is the stationary set for every t <= tB
   if (tid == 0) {
     sh_tail = 0;
+    sh_rep[0] = sh_rep[1] = 0;
     sh_flag[0] = 1;  // layered
     sh_flag[1] = 0;  // overflow
     sh_flag[2] = 1;  // in-CSR built in-kernel is valid
@@ -386,8 +402,13 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       if (fresh) {
         const int pos = atomicAdd(&sh_tail, 1);
         if (pos - hi < BQ) bq(nxt)[pos - hi] = idx; else a.queue[pos] = idx;
+        if (REP && rep_ok) {  // same partner node one time step later must be in the set
+          const int q = idx + tshift;
+          if (!((reach_bits[q >> 5] >> (q & 31)) & 1u)) sh_rep[0] = 1;
+        }
       }
     };
+    int tau = TM;  // time of the frontier being expanded (rep_ok: one time per level)
 #ifdef GTNX_TIMING
     long long t_enum = 0, t_mark = 0, t_bar = 0, t_q = 0, t0, t1; int nlev = 0;
 #endif
@@ -439,10 +460,38 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
 #endif
       // LDS-only barrier when nothing this level communicated through HBM
       wg_barrier(lds_state);
+      const int prev_w = hi - lo;
+      const bool same = REP && rep_ok && sh_rep[0] == 0;
       lo = hi;
       hi = sh_tail;
       cur ^= 1;
+      if (REP && rep_ok && tid == 0) sh_rep[0] = 0;
       wg_barrier(lds_state && (hi - lo) <= BQ);
+      if (REP && rep_ok) {
+        if (same && hi - lo == prev_w && prev_w > 0 && tau >= 2) {
+          // B[tau-1] == B[tau]: fill every earlier time with the same partner set
+          tB = tau;
+          const int total_bits = N1 * N2;
+          for (int wd = tid; wd < nwords; wd += kBlock) {
+            int p = wd << 5;
+            int tm = L2 ? p / N1 : p % N1, ot = L2 ? p % N1 : p / N1;
+            unsigned v = 0;
+            for (int b = 0; b < 32 && p < total_bits; ++b, ++p) {
+              if (tm <= tau - 2) {
+                const int q = L2 ? ot + N1 * tau : tau + N1 * ot;
+                v |= ((reach_bits[q >> 5] >> (q & 31)) & 1u) << b;
+              }
+              if (L2) { if (++ot == N1) { ot = 0; ++tm; } }
+              else    { if (++tm == N1) { tm = 0; ++ot; } }
+            }
+            // bits of times >= tau-1 in this word were set by the BFS; nobody writes now
+            if (v) reach_bits[wd] |= v;
+          }
+          lds_barrier();
+          break;
+        }
+        --tau;
+      }
 #ifdef GTNX_TIMING
       t1 = wall_clock64(); t_bar += t1 - t0;
 #endif
@@ -505,9 +554,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   }
 
   int lo = 0, hi = nn, L = 0, fcur = 0;
-  int max_width = 0, max_level_arcs = 0;
+  int max_width = 0, max_level_arcs = 0, rep_levels = 0;
   while (lo < hi && !sh_flag[1]) {
-    if (tid == 0) a.level_off[L] = lo;
+    if (tid == 0) {
+      a.level_off[L] = lo;
+      if (REP) sh_rep[1] = 0;
+    }
     const int na_level = na;
     max_width = max(max_width, hi - lo);
     const bool front_in_lds = (hi - lo) <= FC;
@@ -515,6 +567,9 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     // registers of this lane's emitted arcs (fast path), kept for the fused in-CSR
     int my_dst[KC], my_ai[KC];
     float my_w[KC];
+    // ... and, for the stationary-level replication, the rest of the arc template
+    int my_i[KC], my_j[KC], my_il[KC], my_ol[KC], my_pos[KC], my_own[KC], my_own_idx[KC];
+    int my_out = 0, newn_level = 0;
     bool fast_level = true;
     for (int c0 = lo; c0 < hi; c0 += kBlock) {
       const int node = c0 + tid;
@@ -604,6 +659,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         break;
       }
       if (live) a.out_off[node] = na + off;
+      if (REP) my_out = na + off;
       int newn = 0;
       if (fast) {
         // ---------------- fast chunk: claims / ids through the LDS hash
@@ -627,6 +683,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             a.gi2[ai] = j;
             rr[m] = r;
             my_w[m] = w;
+            if (REP) { my_i[m] = i; my_j[m] = j; my_il[m] = il; my_ol[m] = ol; }
             if (st[m] < 0) {  // co-reachable, not discovered yet: claim by smallest arc rank
               unsigned h = (unsigned(c.idx[m]) * 2654435761u) >> (32 - HC_LOG2);
               while (true) {
@@ -652,8 +709,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         newn = t2;
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
+          if (REP) { my_own[m] = -1; my_own_idx[m] = 0; }
           if (own[m]) {
             const int id = nn + rank++;
+            if (REP) { my_own[m] = id; my_own_idx[m] = c.idx[m]; }
             if (id < a.Ncap) {
               const int idx = c.idx[m];
               const int d1 = idx % N1, d2 = idx / N1;
@@ -671,6 +730,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           }
         }
         wg_barrier(lds_state);
+        if (REP && rep_ok) {
+          // is the new frontier the old one moved one time step (same order)?
+          if (newn != hi - lo) { if (tid == 0) sh_rep[1] = 1; }
+          else if (tid < newn && tid < FC && front[fcur ^ 1][tid] != front[fcur][tid] + tshift) sh_rep[1] = 1;
+          newn_level = newn;
+        }
         int lay = 1, csr_ok = 1;
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
@@ -773,8 +838,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     // registers when the level was a single fast chunk, else re-read from HBM).
     {
       const int W = nn - hi;
-      if (sh_flag[2] && W <= WC) {
-        constexpr int PER = WC / kBlock;
+      max_level_arcs = max(max_level_arcs, na - na_level);
+      constexpr int PER = WC / kBlock;
+      int my_inoff[PER];
+      const bool csr_level = sh_flag[2] && W <= WC;
+      bool from_regs = false;
+      if (csr_level) {
         int loc[PER];
         int sum = 0;
 #pragma unroll
@@ -788,11 +857,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         for (int x = 0; x < PER; ++x) {
           const int nidx = tid * PER + x;
           if (nidx < W) a.in_off[hi + nidx] = na_level + run;
+          my_inoff[x] = na_level + run;
           incur[nidx] = na_level + run;
           run += loc[x];
           incnt[nidx] = 0;
         }
-        const bool from_regs = single_chunk && fast_level;
+        from_regs = single_chunk && fast_level;
         wg_barrier(lds_state && from_regs);  // the re-read path needs this level's stores
         if (from_regs) {
 #pragma unroll
@@ -802,6 +872,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
               a.in_list[pos] = my_ai[m];
               a.in_src[pos] = lo + tid;
               a.in_w[pos] = my_w[m];
+              if (REP) my_pos[m] = pos;
             }
           }
         } else {
@@ -816,8 +887,89 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         if (tid == 0) sh_flag[2] = 0;
         for (int x = tid; x < WC; x += kBlock) incnt[x] = 0;
       }
+      // ---- stationary-level replication (see the top of the kernel).  Level L
+      // expanded the frontier of time L under the filter B[L+1]; if the frontier
+      // came back unchanged and B is constant up to tB, levels L+1 .. L+K with
+      // K = tB - L - 1 are this level shifted by k time steps.  Every condition
+      // below is workgroup-uniform (shared flags read behind the scan barriers).
+      if (REP && rep_ok) {
+        const int Aw = na - na_level;
+        const int K = tB - L - 1;
+        if (csr_level && from_regs && sh_flag[0] && !sh_flag[1] && sh_rep[1] == 0 && W == hi - lo &&
+            newn_level == W && W > 0 && K >= 2 && nn + (long long)K * W <= a.Ncap &&
+            na + (long long)K * Aw <= a.Acap) {
+          const GTNX_G float* cw = L2 ? a.g2.w : a.g1.w;  // chain weights, one row per time step
+          float wfix[KC];
+          int carc[KC];
+#pragma unroll
+          for (int m = 0; m < KC; ++m) {
+            wfix[m] = 0.0f;
+            carc[m] = 0;
+            if (my_ai[m] >= 0) {
+              wfix[m] = L2 ? a.g1.w[my_i[m]] : a.g2.w[my_j[m]];
+              carc[m] = L2 ? my_j[m] : my_i[m];
+            }
+          }
+          int acc_flag[KC];
+#pragma unroll
+          for (int m = 0; m < KC; ++m) {
+            acc_flag[m] = 0;
+            if (my_own[m] >= 0) {
+              const int ot = L2 ? my_own_idx[m] % N1 : my_own_idx[m] / N1;
+              acc_flag[m] = L2 ? g_accept<L1>(g1v, ot) : g_accept<L2>(a.g2, ot);
+            }
+          }
+          const bool live_src = tid < hi - lo;
+          constexpr int U = 4;
+          for (int k0 = 1; k0 <= K; k0 += U) {
+            float wk[U][KC];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+              for (int m = 0; m < KC; ++m)
+                wk[u][m] = (my_ai[m] >= 0 && k0 + u <= K) ? cw[carc[m] + (k0 + u) * CL] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              const int k = k0 + u;
+              if (k > K) break;
+              const int dn = k * W, da = k * Aw, dc = k * CL;
+#pragma unroll
+              for (int m = 0; m < KC; ++m) {
+                if (my_ai[m] >= 0) {
+                  const int ai = my_ai[m] + da, pos = my_pos[m] + da;
+                  const float w = wfix[m] + wk[u][m];
+                  a.src[ai] = lo + tid + dn;
+                  a.dst[ai] = my_dst[m] + dn;
+                  a.il[ai] = my_il[m];
+                  a.ol[ai] = my_ol[m];
+                  a.w[ai] = w;
+                  a.gi1[ai] = L2 ? my_i[m] : my_i[m] + dc;
+                  a.gi2[ai] = L2 ? my_j[m] + dc : my_j[m];
+                  a.in_list[pos] = ai;
+                  a.in_src[pos] = lo + tid + dn;
+                  a.in_w[pos] = w;
+                }
+                if (my_own[m] >= 0)
+                  a.nflags[my_own[m] + dn] = uint8_t((acc_flag[m] && L + 1 + k == TM) ? NF_ACCEPT : 0);
+              }
+              if (live_src) a.out_off[lo + tid + dn] = my_out + da;
+#pragma unroll
+              for (int x = 0; x < PER; ++x)
+                if (tid * PER + x < W) a.in_off[hi + tid * PER + x + dn] = my_inoff[x] + da;
+            }
+          }
+          for (int k = 1 + tid; k <= K; k += kBlock) a.level_off[L + k] = lo + k * W;
+          // the last replicated level's new nodes are the next frontier
+          if (tid < W) front[fcur ^ 1][tid] += K * tshift;
+          nn += K * W;
+          na += K * Aw;
+          lo += K * W;
+          hi += K * W;
+          L += K;
+          rep_levels += K;
+        }
+      }
     }
-    max_level_arcs = max(max_level_arcs, na - na_level);
     lo = hi;
     hi = nn;
     fcur ^= 1;
@@ -840,6 +992,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     o.overflow = sh_flag[1];
     o.max_width = max_width;
     o.max_level_arcs = max_level_arcs;
+    o.rep_levels = rep_levels;
     o.csr_built = sh_flag[2] && sh_flag[0];
     *a.out = o;
   }

@@ -41,7 +41,7 @@ struct DGraph {
   int N, A;
   int M, C;
   int n_start, n_accept;
-  int flags;  // bit0 ilabelSorted, bit1 olabelSorted
+  int flags;  // bit0 ilabelSorted, bit1 olabelSorted, bit2 GF_EPS_FREE (no epsilon label on any arc)
   const GTNX_G int* src;
   const GTNX_G int* dst;
   const GTNX_G int* il;
@@ -169,7 +169,10 @@ struct ComposeOut {
   int max_width;       // widest BFS level (nodes)
   int max_level_arcs;  // most arcs emitted by one level
   int csr_built;       // in_off / in_list / in_src / in_w were built inside compose_kernel
+  int rep_levels;      // BFS levels emitted by stationary-level replication (not expanded one by one)
 };
+
+constexpr int GF_EPS_FREE = 4;
 
 struct ComposeArgs {
   DGraph g1, g2;

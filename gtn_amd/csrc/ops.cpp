@@ -958,6 +958,9 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     std::vector<size_t> redo;
     for (size_t i = 0; i < n; ++i)
       if (res_out[i].overflow == 2) redo.push_back(i);
+    if (getenv("GTNX_COMPOSE_STATS"))
+      fprintf(stderr, "[gtnx] compose: n=%zu redo=%zu graph0: N=%d A=%d levels=%d replicated=%d\n", n, redo.size(),
+              res_out[0].N, res_out[0].A, res_out[0].L, res_out[0].rep_levels);
     if (!redo.empty()) run(redo, false);
   }
 

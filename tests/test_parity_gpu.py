@@ -473,3 +473,28 @@ def test_torch_ctc_loss_matches_torch_and_oracle(gtn):
         want, wgrad = ctc_loss(lp2.detach().numpy()[b], tg[b].numpy())
         assert float(loss[b]) == pytest.approx(want, rel=1e-4)
         np.testing.assert_allclose(lp.grad[b].cpu().numpy(), wgrad, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("T,C,U", [(120, 20, 8), (260, 12, 40)])
+def test_compose_linear_first_structure_vs_oracle(gtn, T, C, U):
+    """compose(emissions, target): the implicit chain on the LEFT (stationary-level
+    replication with the roles swapped); node ids and arc order as the oracle's"""
+    em, tg = gg.ctc_inputs(5, 1, T, C, U)
+    e = gtn.linear_graph(T, C)
+    e.set_weights(em[0])
+    tgt = gg.ctc_target_graph(tg[0].tolist())
+    ctc = gg.to_api(gtn, tgt)
+    comp = gtn.compose(e, ctc)
+    oc = OGraph.linear(T, C, em[0]).compose(OGraph.from_dict(tgt))
+    assert (comp.num_nodes(), comp.num_arcs()) == (oc.N, oc.A)
+    d, o = gg.from_api(comp), oc.to_dict()
+    for k in ("start", "accept", "src", "dst", "il", "ol"):
+        assert d[k] == o[k], k
+    np.testing.assert_allclose(d["w"], o["w"], rtol=1e-6)
+    fs = gtn.forward_score(comp)
+    assert fs.item() == pytest.approx(oc.shortest_distance(), rel=RTOL)
+    gtn.backward(fs)
+    g1, g2 = oc.compose_grad(oc.shortest_distance_grad(), T * C, len(tgt["src"]))
+    z = abs(float(OGraph.linear(T, C, em[0]).shortest_distance()))
+    np.testing.assert_allclose(e.grad().weights_to_numpy(), g1, rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)
+    np.testing.assert_allclose(ctc.grad().weights_to_numpy(), g2, rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)

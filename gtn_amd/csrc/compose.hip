@@ -308,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   __shared__ int front[2][FC];   // also the backward queue (2 x BQ/2 ... see below)
   __shared__ int incnt[WC];
   __shared__ int incur[WC];
+  __shared__ int sh_lst;     // this chunk created start / accept nodes
   __shared__ int sh_rep[2];  // stationarity mismatch flags: [0] phase B sets, [1] phase F frontiers
   extern __shared__ __attribute__((aligned(16))) unsigned dyn_bits[];
   const int nwords = (N1 * N2 + 31) >> 5;
@@ -352,12 +353,15 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   if (tid == 0) {
     sh_tail = 0;
     sh_rep[0] = sh_rep[1] = 0;
+    sh_lst = 0;
     sh_flag[0] = 1;  // layered
     sh_flag[1] = 0;  // overflow
     sh_flag[2] = 1;  // in-CSR built in-kernel is valid
     sh_flag[3] = 0;  // per-chunk: bit0 wide node, bit1 discovered-pair lookup
   }
   __syncthreads();
+  const long long tk0 = wall_clock64();
+  long long tk_rep = 0;
   if (N1 == 0 || N2 == 0) {
     if (tid == 0) {
       ComposeOut o{};
@@ -517,8 +521,14 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     return;
   }
   // ------------------------------------------------------------------ phase F
+  const long long tk1 = wall_clock64();
   cache_g1(false);
   int nn = 0, na = 0;
+  // ordered start / accept lists are produced here as nodes are numbered (ids rise
+  // with discovery, so appending per level in id order keeps them sorted); only the
+  // general chunk path leaves them to the transpose kernels
+  int ns_tot = 0, na_tot = 0;
+  bool lists_ok = true;
   {
     // start pairs in (s1 outer, s2 inner) order (compose.cpp:392-401)
     const int ns1 = a.g1.n_start, ns2 = a.g2.n_start;
@@ -532,13 +542,17 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         idx = s1 + N1 * s2;
         ok = ld_state(a.state + idx) == ST_REACH;
       }
-      int tot;
+      int tot, tota;
       const int off = block_excl_scan(ok, sh_scan, tot);
+      const int acc0 = ok && g_accept<L1>(g1v, s1) && g_accept<L2>(a.g2, s2);
+      const int offa = block_excl_scan(acc0, sh_scan, tota);
       if (ok) {
         const int id = nn + off;
         if (id < a.Ncap) {
           a.pair_of[id] = idx;
-          a.nflags[id] = uint8_t(NF_START | ((g_accept<L1>(g1v, s1) && g_accept<L2>(a.g2, s2)) ? NF_ACCEPT : 0));
+          a.nflags[id] = uint8_t(NF_START | (acc0 ? NF_ACCEPT : 0));
+          a.start_list[id] = id;
+          if (acc0) a.accept_list[na_tot + offa] = id;
           a.in_off[id] = 0;  // level 0 has no in-arcs in a layered product
           if (id < FC) front[0][id] = idx;
           if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
@@ -548,7 +562,9 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         }
       }
       nn += tot;
+      na_tot += tota;
     }
+    ns_tot = nn;
     for (int x = tid; x < WC; x += kBlock) incnt[x] = 0;
     __syncthreads();
   }
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     int my_dst[KC], my_ai[KC];
     float my_w[KC];
     // ... and, for the stationary-level replication, the rest of the arc template
-    int my_i[KC], my_j[KC], my_il[KC], my_ol[KC], my_pos[KC], my_own[KC], my_own_idx[KC];
+    int my_i[KC], my_j[KC], my_il[KC], my_ol[KC], my_pos[KC], my_own[KC];
     int my_out = 0, newn_level = 0;
     bool fast_level = true;
     for (int c0 = lo; c0 < hi; c0 += kBlock) {
@@ -707,19 +723,28 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         int t2;
         int rank = block_excl_scan(nown, sh_scan, t2, lds_state);
         newn = t2;
+        int own_id[KC], own_fl[KC], n_s = 0, n_a = 0;
 #pragma unroll
         for (int m = 0; m < KC; ++m) {
-          if (REP) { my_own[m] = -1; my_own_idx[m] = 0; }
+          if (REP) my_own[m] = -1;
+          own_id[m] = -1;
+          own_fl[m] = 0;
           if (own[m]) {
             const int id = nn + rank++;
-            if (REP) { my_own[m] = id; my_own_idx[m] = c.idx[m]; }
+            if (REP) my_own[m] = id;
             if (id < a.Ncap) {
               const int idx = c.idx[m];
               const int d1 = idx % N1, d2 = idx / N1;
+              const int fl = ((g_start<L1>(g1v, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
+                             ((g_accept<L1>(g1v, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0);
+              own_id[m] = id;
+              own_fl[m] = fl;
+              n_s += (fl & NF_START) != 0;
+              n_a += (fl & NF_ACCEPT) != 0;
+              if (fl) sh_lst = 1;
               hids[slot[m]] = id;
               a.pair_of[id] = idx;
-              a.nflags[id] = uint8_t(((g_start<L1>(g1v, d1) && g_start<L2>(a.g2, d2)) ? NF_START : 0) |
-                                     ((g_accept<L1>(g1v, d1) && g_accept<L2>(a.g2, d2)) ? NF_ACCEPT : 0));
+              a.nflags[id] = uint8_t(fl);
               if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
               if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
               st_state(a.state + idx, id);
@@ -730,6 +755,19 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           }
         }
         wg_barrier(lds_state);
+        if (sh_lst) {  // workgroup-uniform: some lane numbered a start / accept node
+          int ts, ta;
+          int os = block_excl_scan(n_s, sh_scan, ts, lds_state);
+          int oa = block_excl_scan(n_a, sh_scan, ta, lds_state);
+#pragma unroll
+          for (int m = 0; m < KC; ++m) {
+            if (own_fl[m] & NF_START) a.start_list[ns_tot + os++] = own_id[m];
+            if (own_fl[m] & NF_ACCEPT) a.accept_list[na_tot + oa++] = own_id[m];
+          }
+          ns_tot += ts;
+          na_tot += ta;
+          if (tid == 0) sh_lst = 0;  // every lane read it before the scans' barriers
+        }
         if (REP && rep_ok) {
           // is the new frontier the old one moved one time step (same order)?
           if (newn != hi - lo) { if (tid == 0) sh_rep[1] = 1; }
@@ -756,6 +794,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       } else if (!FAST) {
         // ---------------- general chunk: claims through the global state table
         fast_level = false;
+        lists_ok = false;
         if (live) {
           int r = off;
           auto emit = [&](int idx, int il, int ol, float w, int i, int j) {
@@ -894,10 +933,11 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       // below is workgroup-uniform (shared flags read behind the scan barriers).
       if (REP && rep_ok) {
         const int Aw = na - na_level;
-        const int K = tB - L - 1;
+        const int K = min(tB - L - 1, TM - L - 2);  // new nodes stay before the chain's accept time
         if (csr_level && from_regs && sh_flag[0] && !sh_flag[1] && sh_rep[1] == 0 && W == hi - lo &&
             newn_level == W && W > 0 && K >= 2 && nn + (long long)K * W <= a.Ncap &&
             na + (long long)K * Aw <= a.Acap) {
+          const long long tr0 = wall_clock64();
           const GTNX_G float* cw = L2 ? a.g2.w : a.g1.w;  // chain weights, one row per time step
           float wfix[KC];
           int carc[KC];
@@ -908,15 +948,6 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             if (my_ai[m] >= 0) {
               wfix[m] = L2 ? a.g1.w[my_i[m]] : a.g2.w[my_j[m]];
               carc[m] = L2 ? my_j[m] : my_i[m];
-            }
-          }
-          int acc_flag[KC];
-#pragma unroll
-          for (int m = 0; m < KC; ++m) {
-            acc_flag[m] = 0;
-            if (my_own[m] >= 0) {
-              const int ot = L2 ? my_own_idx[m] % N1 : my_own_idx[m] / N1;
-              acc_flag[m] = L2 ? g_accept<L1>(g1v, ot) : g_accept<L2>(a.g2, ot);
             }
           }
           const bool live_src = tid < hi - lo;
@@ -949,8 +980,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
                   a.in_src[pos] = lo + tid + dn;
                   a.in_w[pos] = w;
                 }
-                if (my_own[m] >= 0)
-                  a.nflags[my_own[m] + dn] = uint8_t((acc_flag[m] && L + 1 + k == TM) ? NF_ACCEPT : 0);
+                if (my_own[m] >= 0) a.nflags[my_own[m] + dn] = 0;  // neither start (t > 0) nor accept (t < TM)
               }
               if (live_src) a.out_off[lo + tid + dn] = my_out + da;
 #pragma unroll
@@ -967,6 +997,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           hi += K * W;
           L += K;
           rep_levels += K;
+          tk_rep += wall_clock64() - tr0;
         }
       }
     }
@@ -993,7 +1024,14 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     o.max_width = max_width;
     o.max_level_arcs = max_level_arcs;
     o.rep_levels = rep_levels;
-    o.csr_built = sh_flag[2] && sh_flag[0];
+    o.t_b = int(tk1 - tk0);
+    o.t_f = int(wall_clock64() - tk1);
+    o.t_rep = int(tk_rep);
+    o.csr_built = sh_flag[2] && sh_flag[0] && lists_ok;
+    if (lists_ok) {
+      a.counts[0] = ns_tot;
+      a.counts[1] = na_tot;
+    }
     *a.out = o;
   }
 }

@@ -170,6 +170,7 @@ struct ComposeOut {
   int max_level_arcs;  // most arcs emitted by one level
   int csr_built;       // in_off / in_list / in_src / in_w were built inside compose_kernel
   int rep_levels;      // BFS levels emitted by stationary-level replication (not expanded one by one)
+  int t_b, t_f, t_rep; // 100 MHz ticks spent in phase B / phase F (total) / replication (diagnostics)
 };
 
 constexpr int GF_EPS_FREE = 4;

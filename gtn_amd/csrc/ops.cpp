@@ -944,12 +944,23 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
         g0 = g1;
       }
     }
-    {
-      GTNX_PROF("compose_transpose", 0.0);
-      launch_compose_transpose(dargs->as<ComposeArgs>(), int(m), int(maxA), int(maxN), tscratch->ptr, rt.stream());
-    }
     // sizes back to the host: the contiguous header block, one copy, one sync
     rt.d2h_sync(hdr.data(), res->ptr, hdr.size());
+    // products whose in-arc CSR / start & accept lists were not produced inside the
+    // compose kernel (non-layered or very wide levels) get them from the parallel
+    // transpose passes; the common layered case never launches them
+    bool need_tr = false;
+    for (size_t i = 0; i < m; ++i) {
+      const ComposeOut& co = res_out[order[i]];
+      need_tr = need_tr || (!co.csr_built && co.overflow == 0);
+    }
+    if (need_tr) {
+      {
+        GTNX_PROF("compose_transpose", 0.0);
+        launch_compose_transpose(dargs->as<ComposeArgs>(), int(m), int(maxA), int(maxN), tscratch->ptr, rt.stream());
+      }
+      rt.d2h_sync(hdr.data(), res->ptr, hdr.size());
+    }
   };
   {
     std::vector<size_t> all(n);
@@ -959,8 +970,9 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     for (size_t i = 0; i < n; ++i)
       if (res_out[i].overflow == 2) redo.push_back(i);
     if (getenv("GTNX_COMPOSE_STATS"))
-      fprintf(stderr, "[gtnx] compose: n=%zu redo=%zu graph0: N=%d A=%d levels=%d replicated=%d\n", n, redo.size(),
-              res_out[0].N, res_out[0].A, res_out[0].L, res_out[0].rep_levels);
+      fprintf(stderr, "[gtnx] compose: n=%zu redo=%zu graph0: N=%d A=%d levels=%d replicated=%d  us: B=%.0f F=%.0f (rep %.0f)\n", n, redo.size(),
+              res_out[0].N, res_out[0].A, res_out[0].L, res_out[0].rep_levels, res_out[0].t_b * 0.01,
+              res_out[0].t_f * 0.01, res_out[0].t_rep * 0.01);
     if (!redo.empty()) run(redo, false);
   }
 

@@ -402,7 +402,10 @@ GTNX_API gtnx_status_t gtnx_graph_get_input(gtnx_graph_t g, int i, gtnx_graph_t*
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_set_inputs(gtnx_graph_t g, const gtnx_graph_t* inputs, int n) {
-  return guard([&] { G(g).g->inputs = vec(inputs, n); });
+  return guard([&] {
+    G(g).g->inputs = vec(inputs, n);
+    for (auto& i : G(g).g->inputs) i.g->n_consumers++;
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_set_grad_fn(gtnx_graph_t g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*)) {
   return guard([&] { set_user_grad_fn(G(g), fn, ctx, ctx_free); });

@@ -38,6 +38,15 @@ struct Schedule {
   const void* in_w_of = nullptr;
   uint64_t in_w_version = 0;
   const float* in_w = nullptr;
+  // Set by compose for a layered product with ONE implicit linear chain (level ==
+  // chain time step): lets forwardScore's backward push the arc gradients straight
+  // into the two compose inputs (see SdOp::backward / sd_backward_narrow_kernel).
+  uint64_t producer_seq = 0;         // seq of the compose record that emitted the structure
+  int chain_side = 0;                // 0: not eligible, 1 / 2: which compose input is the chain
+  int chain_C = 0;                   // chain arcs per time step
+  int64_t fixed_A = 0;               // arcs of the other input
+  const int* gi_fixed = nullptr;     // gradInfo column of the explicit input
+  const int* gi_chain = nullptr;     // gradInfo column of the chain
 };
 
 struct Structure {
@@ -90,6 +99,8 @@ struct GradState {
   bool has_grad_fn = false;      // mirrors `gradFunc != nullptr`
   std::vector<Graph> inputs;
   std::unique_ptr<Graph> grad;
+  int n_consumers = 0;           // op outputs that list this graph as an input
+  bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
 };
 
 struct Graph {

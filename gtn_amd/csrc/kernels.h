@@ -110,6 +110,15 @@ struct SdArgs {
   GTNX_G float* node_grad;    // [P]
   GTNX_G float* arc_grad;     // [A] arc-id order
   int chunk_levels;           // narrow kernels: levels per LDS chunk (host: caps / widest level)
+  // fused compose-gradient scatter (narrow backward only; see sd_narrow_fuse_caps):
+  // arc k of the lattice came from arc gi_fixed[k] of the explicit compose input and
+  // arc gi_chain[k] of the linear chain, whose arcs of level l lie in [l*C, (l+1)*C)
+  const GTNX_G int* gi_fixed;
+  const GTNX_G int* gi_chain;
+  GTNX_G float* grad_fixed;   // [fixed_A] zero-filled by the host; may be null
+  GTNX_G float* grad_chain;   // [T*C]     zero-filled by the host; may be null
+  int chain_C, fixed_A, chain_A;
+  int dbg;  // timing experiments only (GTNX_FUSE_DBG): 1 skip chain sums, 2 skip fixed sums, 4 skip row flush, 8 plain atomics
 };
 
 enum : int { SD_LOG = 0, SD_TROPICAL = 1, SD_PATH = 2 };
@@ -125,7 +134,10 @@ void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
 int sd_narrow_ring_backward();
 // narrow != 0: LDS-ring kernel (log semiring, identity out rows, eligibility as forward
 // with reach <= sd_narrow_ring_backward())
+// narrow == 2: as 1, plus the fused gradient scatter into the compose inputs (every
+// graph must satisfy fixed_A <= cap_fixed and chunk_levels * chain_C <= cap_chain)
 void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st);
+void sd_narrow_fuse_caps(int* cap_fixed, int* cap_chain);
 
 // viterbiPath pointer chase (shortest.cpp:239-245): writes path arc ids first-arc-first
 struct PathArgs {

@@ -41,6 +41,7 @@ Graph make_output(const std::shared_ptr<OpRecord>& op, int idx, std::vector<Grap
     out.g->op_idx = idx;
     out.g->has_grad_fn = true;
     out.g->inputs = std::move(inputs);
+    for (auto& i : out.g->inputs) i.g->n_consumers++;
   }
   return out;
 }
@@ -332,6 +333,51 @@ struct SdOp : OpRecord {
       need_zero |= !sv.sched->all_written;
     }
     DevMemP g = need_zero ? rt.alloc_zero(bytes) : rt.alloc(bytes ? bytes : 1);
+    // narrow-lattice kernel eligibility (whole batch)
+    bool narrow = mode == SD_LOG;
+    {
+      int64_t tot_levels = 0;
+      for (int i = 0; i < n; ++i) {
+        const Schedule& sc = *saved[ms[i].idx].sched;
+        narrow = narrow && (sc.view.flags & SCHED_OUT_IDENTITY) && sc.max_level_arcs <= sd_narrow_tmp_cap() &&
+                 sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring_backward();
+        tot_levels += sc.view.L;
+      }
+      narrow = narrow && tot_levels >= 32 * int64_t(n);
+    }
+    // Fused compose-gradient scatter: when every lattice of the batch is a layered
+    // product with one linear chain, produced by a compose whose ONLY consumer is
+    // this forwardScore and which holds no gradient yet, the kernel sums the arc
+    // gradients into the compose inputs itself and the compose record's own
+    // backward (compose.cpp:496-518) is skipped for these members.  (With a
+    // gradient already present -- a second backward over a retained tape -- the
+    // reference re-scatters the ACCUMULATED delta, so that case stays unfused.)
+    int cap_f = 0, cap_c = 0;
+    sd_narrow_fuse_caps(&cap_f, &cap_c);
+    bool fuse = narrow && !getenv("GTNX_NO_FUSED_SCATTER");
+    for (int i = 0; i < n && fuse; ++i) {
+      Graph& in = ms[i].out.g->inputs[0];
+      const Schedule& sc = *saved[ms[i].idx].sched;
+      fuse = sc.chain_side != 0 && in.g->op && in.g->op->seq == sc.producer_seq && in.g->inputs.size() == 2 &&
+             in.g->n_consumers == 1 && in.calc_grad() && !in.is_grad_available() && sc.fixed_A <= cap_f &&
+             sc.chain_C <= cap_c && in.s->sched.get() == &sc;
+    }
+    DevMemP fg;
+    std::vector<size_t> off_f(n), off_c(n);
+    if (fuse) {
+      size_t fb = 0;
+      for (int i = 0; i < n; ++i) {
+        auto& cin = ms[i].out.g->inputs[0].g->inputs;
+        const Schedule& sc = *saved[ms[i].idx].sched;
+        Graph& fixed = cin[sc.chain_side == 1 ? 1 : 0];
+        Graph& chain = cin[sc.chain_side == 1 ? 0 : 1];
+        off_f[i] = fb;
+        if (fixed.calc_grad()) fb = align_up(fb + 4 * size_t(fixed.num_arcs()), 256);
+        off_c[i] = fb;
+        if (chain.calc_grad()) fb = align_up(fb + 4 * size_t(chain.num_arcs()), 256);
+      }
+      fg = rt.alloc_zero(fb ? fb : 1);
+    }
     std::vector<SdArgs> args(n);
     GradSink sink;
     int64_t tot_out = 0, tot_p = 0;
@@ -340,6 +386,7 @@ struct SdOp : OpRecord {
       Graph& in = ms[i].out.g->inputs[0];
       const Saved& sv = saved[ms[i].idx];
       SdArgs& a = args[i];
+      std::memset(&a, 0, sizeof(a));
       a.s = sv.sched->view;
       a.s.in_w = nullptr;
       a.w = in.w->dev;
@@ -353,6 +400,25 @@ struct SdOp : OpRecord {
       a.chunk_levels = std::max(1, std::min(sd_narrow_tmp_cap() / std::max(sv.sched->max_level_arcs, 1),
                                             sd_narrow_node_cap() / std::max(sv.sched->max_level_width, 1)));
       sink.add(in, g, a.arc_grad);
+      if (fuse) {
+        const Schedule& sc = *sv.sched;
+        auto& cin = in.g->inputs;
+        Graph& fixed = cin[sc.chain_side == 1 ? 1 : 0];
+        Graph& chain = cin[sc.chain_side == 1 ? 0 : 1];
+        a.gi_fixed = sc.gi_fixed;
+        a.gi_chain = sc.gi_chain;
+        a.chain_C = sc.chain_C;
+        a.fixed_A = int(sc.fixed_A);
+        a.chain_A = int(chain.num_arcs());
+        if (const char* e = getenv("GTNX_FUSE_DBG")) a.dbg = atoi(e);
+        a.grad_fixed = fixed.calc_grad() ? fg->as<float>(off_f[i]) : nullptr;
+        a.grad_chain = chain.calc_grad() ? fg->as<float>(off_c[i]) : nullptr;
+        a.chunk_levels = std::max(1, std::min(a.chunk_levels, cap_c / std::max(sc.chain_C, 1)));
+        if (a.grad_fixed) sink.add(fixed, fg, a.grad_fixed);
+        if (a.grad_chain) sink.add(chain, fg, a.grad_chain);
+        in.g->grad_propagated = true;
+        alg += 8.0 * double(in.num_arcs()) + 4.0 * double(fixed.num_arcs() + chain.num_arcs());
+      }
       tot_out += sv.sched->n_out;
       tot_p += sv.sched->view.P;
       alg += 12.0 * double(in.num_arcs()) + 12.0 * double(sv.sched->view.P);
@@ -360,17 +426,8 @@ struct SdOp : OpRecord {
     DevMemP d = upload_vec(args);
     {
       GTNX_PROF(mode == SD_LOG ? "forward_score_grad" : "viterbi_score_grad", alg);
-      bool narrow = mode == SD_LOG;
-      int64_t tot_levels = 0;
-      for (int i = 0; i < n; ++i) {
-        const Schedule& sc = *saved[ms[i].idx].sched;
-        narrow = narrow && (sc.view.flags & SCHED_OUT_IDENTITY) && sc.max_level_arcs <= sd_narrow_tmp_cap() &&
-                 sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring_backward();
-        tot_levels += sc.view.L;
-      }
-      narrow = narrow && tot_levels >= 32 * int64_t(n);
-      launch_sd_backward(d->as<SdArgs>(), n, mode, narrow ? 1 : 0, int(tot_p ? (tot_out * 16) / tot_p : 0),
-                         rt.stream());
+      launch_sd_backward(d->as<SdArgs>(), n, mode, narrow ? (fuse ? 2 : 1) : 0,
+                         int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream());
     }
     sink.flush();
   }
@@ -660,8 +717,15 @@ struct ComposeOp : OpRecord {
     int A;
   };
   std::vector<Saved> saved;
-  void backward(std::vector<Member>& ms) override {
+  void backward(std::vector<Member>& all) override {
     Runtime& rt = Runtime::get();
+    // members whose consumer already scattered their gradient (SdOp::backward, fused)
+    std::vector<Member> ms;
+    for (auto& m : all) {
+      if (m.out.g->grad_propagated) m.out.g->grad_propagated = false;
+      else ms.push_back(m);
+    }
+    if (ms.empty()) return;
     const int n = int(ms.size());
     size_t bytes = 0;
     std::vector<size_t> o1(n), o2(n);
@@ -1043,6 +1107,16 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
       sc->in_w = x.in_w;
       sc->in_w_of = out.w.get();
       sc->in_w_version = out.w->version;
+      // exactly one implicit chain and an epsilon-free partner: level == chain time
+      const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
+      if (l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) && out.calc_grad()) {
+        sc->producer_seq = op->seq;
+        sc->chain_side = l1 ? 1 : 2;
+        sc->chain_C = l1 ? a.s->C : b.s->C;
+        sc->fixed_A = l1 ? b.num_arcs() : a.num_arcs();
+        sc->gi_fixed = l1 ? x.gi2 : x.gi1;
+        sc->gi_chain = l1 ? x.gi1 : x.gi2;
+      }
       s.sched = sc;
     }
     op->saved[i] = {x.gi1, x.gi2, co.A};

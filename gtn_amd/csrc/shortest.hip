@@ -234,12 +234,15 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
   const DSched s = a.s;
   const int tid = threadIdx.x;
   __shared__ float ring[kRing];
-  __shared__ __attribute__((aligned(16))) int arc_sp[2][kCA];
-  __shared__ __attribute__((aligned(16))) float arc_w[2][kCA];
+  // arc_sp holds BYTE offsets into `ring` ((position & (kRing-1)) * 4, applied once at
+  // staging); both arc arrays are padded so a lane may read its 4 row slots unclamped
+  __shared__ __attribute__((aligned(16))) int arc_sp[2][kCA + 4];
+  __shared__ __attribute__((aligned(16))) float arc_w[2][kCA + 4];
   __shared__ __attribute__((aligned(16))) int node_off[2][kCN + kBlock];
   __shared__ __attribute__((aligned(16))) uint8_t node_fl[2][kCN];
   __shared__ int tab_node[kTab + 2];
   __shared__ int tab_arc[kTab + 2];
+  auto ring_at = [&](int byte_off) -> float { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(ring) + byte_off); };
   float* __restrict__ scores = a.scores;
   const int* __restrict__ in_srcpos = s.in_srcpos;
   const int* __restrict__ row_off = s.row_off;
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     if (HAS_INW) {
 #pragma unroll
       for (int j = 0; j < kJA / 4; ++j) {
-        *reinterpret_cast<gtnx_i4*>(&arc_sp[b][4 * tid + j * 4 * kBlock]) = v_sp[j];
+        *reinterpret_cast<gtnx_i4*>(&arc_sp[b][4 * tid + j * 4 * kBlock]) = (v_sp[j] & (kRing - 1)) << 2;
         *reinterpret_cast<gtnx_f4*>(&arc_w[b][4 * tid + j * 4 * kBlock]) = v_w[j];
       }
       *reinterpret_cast<gtnx_i4*>(&node_off[b][4 * tid]) = v_off;
@@ -306,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     }
 #pragma unroll
     for (int j = 0; j < kJA; ++j) {
-      arc_sp[b][tid + j * kBlock] = st_sp[j];
+      arc_sp[b][tid + j * kBlock] = (st_sp[j] & (kRing - 1)) << 2;
       arc_w[b][tid + j * kBlock] = st_w[j];
     }
 #pragma unroll
@@ -354,46 +357,50 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
         q_r0 = node_off[b][pc] - a0;
         q_deg = node_off[b][pc + 1] - a0 - q_r0;
         q_fl = node_fl[b][pc];
+        const int* spb = &arc_sp[b][q_r0];
+        const float* wb = &arc_w[b][q_r0];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int k = min(q_r0 + j, kCA - 1);
-          q_sp[j] = arc_sp[b][k];
-          q_w[j] = arc_w[b][k];
+          q_sp[j] = spb[j];
+          q_w[j] = wb[j];
         }
       };
       auto node_update = [&](int p, int r0, int deg, int fl, const int* sp4, const float* w4) {
-        const bool is_start = (fl & NF_START) != 0;
-        float mx = NEG_INF, sum = 0.0f;
-        if (deg <= 4) {
+        // the slot being overwritten belongs to position p - kRing, which no
+        // later level reads (reach <= kRing); same-level lanes read other slots
+        if (fl == 0 && deg <= 4) {
+          // the common node (no start / orphan flag, at most 4 in-arcs), branch-free.
+          // max + log(sum of exp(. - max)): sum >= 1, so v_log_f32 needs no denormal
+          // scaling and is as accurate in absolute terms as the reference's
+          // log1p(sum - 1); a node without in-arcs (or with a +-inf max) keeps max
           float v[4];
+          float mx = NEG_INF;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const float x = ring[sp4[j] & (kRing - 1)] + w4[j];
+            const float x = ring_at(sp4[j]) + w4[j];
             v[j] = j < deg ? x : NEG_INF;
             mx = fmaxf(mx, v[j]);
           }
-          if (is_start && 0.0f > mx) mx = 0.0f;
-          if (mx != POS_INF && mx != NEG_INF) {
+          const bool fin = fabsf(mx) != POS_INF;
+          const float m2 = fin ? mx : 0.0f;
+          float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum += __expf(v[j] - mx);
-            if (is_start) sum += __expf(0.0f - mx);
-          }
-        } else {
-          const int r1 = r0 + deg;
-          for (int k = r0; k < r1; ++k) mx = fmaxf(mx, ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k]);
-          if (is_start && 0.0f > mx) mx = 0.0f;
-          if (mx != POS_INF && mx != NEG_INF) {
-            for (int k = r0; k < r1; ++k) sum += __expf(ring[arc_sp[b][k] & (kRing - 1)] + arc_w[b][k] - mx);
-            if (is_start) sum += __expf(0.0f - mx);
-          }
+          for (int j = 0; j < 4; ++j) sum += __expf(v[j] - m2);
+          ring[p & (kRing - 1)] = fin ? mx + 0.69314718f * __builtin_amdgcn_logf(sum) : mx;
+          return;
+        }
+        const bool is_start = (fl & NF_START) != 0;
+        float mx = NEG_INF, sum = 0.0f;
+        const int r1 = r0 + deg;
+        for (int k = r0; k < r1; ++k) mx = fmaxf(mx, ring_at(arc_sp[b][k]) + arc_w[b][k]);
+        if (is_start && 0.0f > mx) mx = 0.0f;
+        if (mx != POS_INF && mx != NEG_INF) {
+          for (int k = r0; k < r1; ++k) sum += __expf(ring_at(arc_sp[b][k]) + arc_w[b][k] - mx);
+          if (is_start) sum += __expf(0.0f - mx);
         }
         const int cnt = deg + (is_start ? 1 : 0);
-        // max + log(sum of exp(. - max)); sum >= 1, so the plain log is as
-        // accurate in absolute terms as the reference's log1p(sum - 1)
         float out = (cnt == 0) ? NEG_INF : ((mx == POS_INF || mx == NEG_INF) ? mx : mx + __logf(sum));
         if (fl & NF_ORPHAN) out = 0.0f;
-        // the slot being overwritten belongs to position p - kRing, which no
-        // later level reads (reach <= kRing); same-level lanes read other slots
         ring[p & (kRing - 1)] = out;
       };
       preload(c);
@@ -416,9 +423,8 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
           float w4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const int k = min(r0 + j, kCA - 1);
-            sp4[j] = arc_sp[b][k];
-            w4[j] = arc_w[b][k];
+            sp4[j] = arc_sp[b][r0 + j];
+            w4[j] = arc_w[b][r0 + j];
           }
           node_update(p, r0, deg, node_fl[b][p - n0], sp4, w4);
         }
@@ -571,22 +577,80 @@ __global__ __launch_bounds__(kBlock) void sd_backward_kernel(const SdArgs* __res
 // scores of the active frontier live in two LDS rings, and inside a chunk the only
 // global instructions are the fire-and-forget arc-gradient stores.
 // HBM traffic: 12A + 12N (dst, weight, arc-grad per arc; offset, score, flag per node).
+//
+// FUSE: the lattice is a layered product of an explicit graph with an implicit
+// linear chain (compose.cpp:496-518 would scatter its arc gradients to the two
+// inputs in a second pass).  Here the chunk's arc gradients are instead summed in
+// two LDS windows as they are flushed -- one over the explicit input's arcs (kept
+// for the whole lattice), one over the chain rows of the chunk's levels (arcs that
+// leave level l use chain arcs [l*C, (l+1)*C) only) -- and each chain row is stored
+// exactly once, so the scatter needs no global atomics and no extra kernel.  The
+// gradInfo columns ride in registers alongside the staged chunk (+8A bytes read).
 // --------------------------------------------------------------------------
-constexpr int kRingB = 2048;
+// wave64 sum by DPP row shifts / row broadcasts (VALU speed; no LDS permutes);
+// every lane must be active, the total is returned to all lanes
+#define GTNX_DPP_ADD(x, ctrl, rmask) \
+  x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  GTNX_DPP_ADD(x, 0x111, 0xf);  // row_shr:1
+  GTNX_DPP_ADD(x, 0x112, 0xf);  // row_shr:2
+  GTNX_DPP_ADD(x, 0x114, 0xf);  // row_shr:4
+  GTNX_DPP_ADD(x, 0x118, 0xf);  // row_shr:8   -> lane 15 of each row holds the row sum
+  GTNX_DPP_ADD(x, 0x142, 0xa);  // row_bcast:15 into rows 1, 3
+  GTNX_DPP_ADD(x, 0x143, 0xc);  // row_bcast:31 into rows 2, 3 -> lane 63 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+// win[key] += val for the active lanes of a wave, called from uniform control flow.
+// A histogram-like scatter with a few very hot keys (CTC: the blank emission takes
+// ~45% of a level's arcs) serialises in the LDS atomic unit -- one replay per lane
+// on the same address.  Up to three candidate keys (the first still-unserved
+// lane's) that at least 8 lanes share are therefore summed across the wave and
+// added once; the rest go through plain ds_add_f32.
+__device__ __forceinline__ void lds_add_hot(float* win, int key, float val, bool act) {
+  unsigned long long rem = __ballot(act);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    if (!rem) break;
+    const int sl = __ffsll((long long)rem) - 1;
+    const int hk = __builtin_amdgcn_readlane(key, sl);
+    const bool mine = act && key == hk;
+    const unsigned long long m = __ballot(mine);
+    if (__popcll(m) >= 8) {
+      const float s = wave_sum_dpp(mine ? val : 0.0f);
+      if (int(threadIdx.x & 63) == sl) atomicAdd(&win[hk], s);
+      act = act && !mine;
+    }
+    rem &= ~m;
+  }
+  if (act) atomicAdd(&win[key], val);
+}
 
+constexpr int kRingB = 2048;
+constexpr int kWinF = 1024;  // explicit-input arcs (floats) -- fused scatter
+constexpr int kWinC = 1024;  // chain arcs of one chunk: chunk_levels * C
+
+template <bool FUSE>
 __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs* __restrict__ args) {
   const SdArgs a = args[blockIdx.x];
   const DSched s = a.s;
   const int tid = threadIdx.x;
   __shared__ float sc_ring[kRingB];
   __shared__ float ng_ring[kRingB];
-  __shared__ __attribute__((aligned(16))) int arc_dst[2][kCA];
+  __shared__ __attribute__((aligned(16))) unsigned short arc_dst[2][kCA];  // ring slots of the dst positions
   __shared__ __attribute__((aligned(16))) float arc_w[2][kCA];
   __shared__ __attribute__((aligned(16))) int node_off[2][kCN + kBlock];
   __shared__ __attribute__((aligned(16))) uint8_t node_fl[2][kCN];
   __shared__ int tab_node[kTab + 2];
   __shared__ int tab_arc[kTab + 2];
-  __shared__ float g_buf[kCA];  // arc gradients of the chunk, flushed at the switch
+  __shared__ __attribute__((aligned(16))) float g_buf[kCA];  // arc gradients of the chunk, flushed at the switch
+  __shared__ float win_f[FUSE ? kWinF : 1];
+  __shared__ float win_c[FUSE ? kWinC : 1];
+  if (FUSE) {
+    for (int x = tid; x < kWinF; x += kBlock) win_f[x] = 0.0f;
+    for (int x = tid; x < kWinC; x += kBlock) win_c[x] = 0.0f;
+  }
+  const int CC = a.chain_C;
+  gtnx_i4 gf_cur[kJA / 4], gc_cur[kJA / 4], gf_nxt[kJA / 4], gc_nxt[kJA / 4];
   const GTNX_G int* __restrict__ out_off = s.out_off;
   const GTNX_G int* __restrict__ out_dst = s.out_dstpos;
   const GTNX_G uint8_t* __restrict__ pflags = s.pflags;
@@ -613,6 +677,10 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
       const int k = a0 + 4 * tid + j * 4 * kBlock;
       v_dst[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.out_dstpos + k);
       v_w[j] = *reinterpret_cast<const GTNX_G gtnx_f4*>(a.w + k);
+      if (FUSE) {
+        gf_nxt[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(a.gi_fixed + k);
+        gc_nxt[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(a.gi_chain + k);
+      }
     }
     const int nb = min(n0 + 4 * tid, last_node + 1);
     v_off = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.out_off + nb);
@@ -624,7 +692,10 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
   auto stage_write = [&](int b, int n0, int n1) {
 #pragma unroll
     for (int j = 0; j < kJA / 4; ++j) {
-      *reinterpret_cast<gtnx_i4*>(&arc_dst[b][4 * tid + j * 4 * kBlock]) = v_dst[j];
+      uint2 pk;
+      pk.x = unsigned(v_dst[j].x & (kRingB - 1)) | (unsigned(v_dst[j].y & (kRingB - 1)) << 16);
+      pk.y = unsigned(v_dst[j].z & (kRingB - 1)) | (unsigned(v_dst[j].w & (kRingB - 1)) << 16);
+      *reinterpret_cast<uint2*>(&arc_dst[b][4 * tid + j * 4 * kBlock]) = pk;
       *reinterpret_cast<gtnx_f4*>(&arc_w[b][4 * tid + j * 4 * kBlock]) = v_w[j];
     }
     *reinterpret_cast<gtnx_i4*>(&node_off[b][4 * tid]) = v_off;
@@ -651,6 +722,10 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
     int e = nl, c = chunk_begin(nl), b = 0;
     stage_load(tab_arc[c], tab_arc[e], tab_node[c], tab_node[e]);
     stage_write(0, tab_node[c], tab_node[e]);
+    if (FUSE) {
+#pragma unroll
+      for (int j = 0; j < kJA / 4; ++j) { gf_cur[j] = gf_nxt[j]; gc_cur[j] = gc_nxt[j]; }
+    }
     int c2 = c > 0 ? chunk_begin(c) : 0;
     if (c > 0) stage_load(tab_arc[c2], tab_arc[c], tab_node[c2], tab_node[c]);
     __syncthreads();
@@ -669,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
             for (int j = 0; j < 4; ++j) {
               const int k = min(r0 + j, kCA - 1);
               const int v = arc_dst[b][k];
-              const float g = ng_ring[v & (kRingB - 1)] * __expf(su + arc_w[b][k] - sc_ring[v & (kRingB - 1)]);
+              const float g = ng_ring[v] * __expf(su + arc_w[b][k] - sc_ring[v]);
               if (j < deg) {
                 g_buf[k] = g * delta;
                 acc += g;
@@ -678,7 +753,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
           } else {
             for (int k = r0; k < r0 + deg; ++k) {
               const int v = arc_dst[b][k];
-              const float g = ng_ring[v & (kRingB - 1)] * __expf(su + arc_w[b][k] - sc_ring[v & (kRingB - 1)]);
+              const float g = ng_ring[v] * __expf(su + arc_w[b][k] - sc_ring[v]);
               g_buf[k] = g * delta;
               acc += g;
             }
@@ -691,17 +766,51 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
       // ---- chunk switch (downwards): land the staged chunk and refill first, then
       // flush this chunk's arc gradients (stores stay behind the staged loads)
       const int a1 = tab_arc[e];
+      const int cbase = (l0 + c) * CC, crows = (e - c) * CC;  // chain rows of the finished chunk
       e = c;
       c = c2;
       b ^= 1;
+      if (e > 0) stage_write(b, tab_node[c], tab_node[e]);
+      if (FUSE) {
+        // the finished chunk's arc gradients into the two LDS windows (same lane ->
+        // arc mapping as the staging loads, so the gradInfo is already in registers)
+#pragma unroll
+        for (int j = 0; j < kJA / 4; ++j) {
+          const int kl = 4 * tid + j * 4 * kBlock;
+          const gtnx_f4 gv = *reinterpret_cast<const gtnx_f4*>(&g_buf[kl]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const bool in = kl + q < a1 - a0;
+            const int fi = gf_cur[j][q], ci = gc_cur[j][q] - cbase;
+            if (a.grad_fixed && in && fi >= 0 && !(a.dbg & 2)) atomicAdd(&win_f[fi], gv[q]);
+            if (a.grad_chain && !(a.dbg & 1)) {
+              if (a.dbg & 8) { if (in && ci >= 0) atomicAdd(&win_c[ci], gv[q]); }
+              else lds_add_hot(win_c, ci, gv[q], in && ci >= 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kJA / 4; ++j) { gf_cur[j] = gf_nxt[j]; gc_cur[j] = gc_nxt[j]; }
+      }
       if (e > 0) {
-        stage_write(b, tab_node[c], tab_node[e]);
         c2 = c > 0 ? chunk_begin(c) : 0;
         if (c > 0) stage_load(tab_arc[c2], tab_arc[c], tab_node[c2], tab_node[c]);
       }
       for (int k = a0 + tid; k < a1; k += kBlock) a.arc_grad[k] = g_buf[k - a0];
       lds_barrier();
+      if (FUSE && a.grad_chain && !(a.dbg & 4)) {
+        // (the last level has no out-arcs and no chain row)
+        for (int x = tid; x < crows && cbase + x < a.chain_A; x += kBlock) {
+          a.grad_chain[cbase + x] = win_c[x];
+          win_c[x] = 0.0f;
+        }
+        lds_barrier();
+      }
     }
+  }
+  if (FUSE && a.grad_fixed) {
+    lds_barrier();
+    for (int x = tid; x < a.fixed_A; x += kBlock) a.grad_fixed[x] = win_f[x];
   }
 }
 
@@ -792,11 +901,16 @@ void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
 }
 
 int sd_narrow_ring_backward() { return kRingB; }
+void sd_narrow_fuse_caps(int* cap_fixed, int* cap_chain) {
+  *cap_fixed = kWinF;
+  *cap_chain = kWinC;
+}
 
 void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st) {
   if (n <= 0) return;
   if (narrow && mode == SD_LOG) {
-    hipLaunchKernelGGL(sd_backward_narrow_kernel, dim3(n), dim3(kBlock), 0, st, d_args);
+    if (narrow == 2) hipLaunchKernelGGL(sd_backward_narrow_kernel<true>, dim3(n), dim3(kBlock), 0, st, d_args);
+    else hipLaunchKernelGGL(sd_backward_narrow_kernel<false>, dim3(n), dim3(kBlock), 0, st, d_args);
     return;
   }
   const int g = pick_group(avg_out_degree_x16);

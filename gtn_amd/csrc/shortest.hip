@@ -651,6 +651,13 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
   }
   const int CC = a.chain_C;
   gtnx_i4 gf_cur[kJA / 4], gc_cur[kJA / 4], gf_nxt[kJA / 4], gc_nxt[kJA / 4];
+  // Explicit-input sums are carried in registers: while the lattice is stationary
+  // (levels are shifted copies, compose.hip) slot (j, q) of a chunk refers to the
+  // SAME input arc chunk after chunk, so its sum only goes to LDS when the key changes.
+  int f_key[kJA];
+  float f_acc[kJA];
+#pragma unroll
+  for (int x = 0; x < kJA; ++x) { f_key[x] = -1; f_acc[x] = 0.0f; }
   const GTNX_G int* __restrict__ out_off = s.out_off;
   const GTNX_G int* __restrict__ out_dst = s.out_dstpos;
   const GTNX_G uint8_t* __restrict__ pflags = s.pflags;
@@ -782,7 +789,17 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
           for (int q = 0; q < 4; ++q) {
             const bool in = kl + q < a1 - a0;
             const int fi = gf_cur[j][q], ci = gc_cur[j][q] - cbase;
-            if (a.grad_fixed && in && fi >= 0 && !(a.dbg & 2)) atomicAdd(&win_f[fi], gv[q]);
+            if (a.grad_fixed && !(a.dbg & 2)) {
+              const int key = (in && fi >= 0) ? fi : -1;
+              const int x = j * 4 + q;
+              if (key == f_key[x]) {
+                f_acc[x] += gv[q];
+              } else {
+                if (f_key[x] >= 0) atomicAdd(&win_f[f_key[x]], f_acc[x]);
+                f_key[x] = key;
+                f_acc[x] = gv[q];
+              }
+            }
             if (a.grad_chain && !(a.dbg & 1)) {
               if (a.dbg & 8) { if (in && ci >= 0) atomicAdd(&win_c[ci], gv[q]); }
               else lds_add_hot(win_c, ci, gv[q], in && ci >= 0);
@@ -809,6 +826,9 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
     }
   }
   if (FUSE && a.grad_fixed) {
+#pragma unroll
+    for (int x = 0; x < kJA; ++x)
+      if (f_key[x] >= 0) atomicAdd(&win_f[f_key[x]], f_acc[x]);
     lds_barrier();
     for (int x = tid; x < a.fixed_A; x += kBlock) a.grad_fixed[x] = win_f[x];
   }

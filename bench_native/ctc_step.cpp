@@ -36,10 +36,14 @@ Graph ctcGraph(const std::vector<int>& target) {
 extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const void* emissions, const int* targets,
                                                                          int B, int T, int C, int U, void* loss_dev,
                                                                          void* grad_dev) {
+  static const bool timing = std::getenv("GTN_BENCH_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto tq = now();
+  static auto t_prev_end = tq;
+  decltype(tq) t_tail0 = tq, t_tail1 = tq;
+  int rc = 0;
   try {
-    static const bool timing = std::getenv("GTN_BENCH_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     auto t0 = now();
     std::vector<std::vector<int>> tg(B);
     for (int b = 0; b < B; ++b) tg[b].assign(targets + (size_t)b * U, targets + (size_t)(b + 1) * U);
@@ -58,6 +62,7 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
     if (timing)
       std::fprintf(stderr, "host ms: build %.2f linear %.2f intersect %.2f fwd %.2f bwd %.2f\n", ms(t0, t1), ms(t1, t2),
                    ms(t2, t3), ms(t3, t4), ms(t4, t5));
+    t_tail0 = now();
     auto h = detail::handles(losses);
     detail::check(gtnx_items_device_n(h.data(), B, loss_dev));
     if (grad_dev) {
@@ -66,8 +71,14 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
       for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
       detail::check(gtnx_grads_device_n(he.data(), B, grad_dev, off.data()));
     }
-    return 0;
+    t_tail1 = now();
   } catch (const std::exception& e) {
-    return -1;
+    rc = -1;
   }
+  auto t_end = now();
+  if (timing)
+    std::fprintf(stderr, "host ms: copies %.2f teardown %.2f  between calls %.2f\n", ms(t_tail0, t_tail1),
+                 ms(t_tail1, t_end), ms(t_prev_end, tq));
+  t_prev_end = now();
+  return rc;
 }

@@ -102,7 +102,14 @@ GTNX_API gtnx_status_t gtnx_graph_deep_copy(gtnx_graph_t g, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph::deep_copy(G(g))); });
 }
 GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
-  return guard([&] { delete reinterpret_cast<Graph*>(g); });
+  return guard([&] {
+    Graph* p = reinterpret_cast<Graph*>(g);
+    if (!p) return;
+    if (Runtime::initialized())
+      Runtime::get().defer_delete(p, [](void* q) { delete static_cast<Graph*>(q); });
+    else
+      delete p;
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_node(gtnx_graph_t g, int s, int a, int* id) {
   return guard([&] {

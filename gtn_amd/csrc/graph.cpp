@@ -1,6 +1,10 @@
 // graph.cpp -- host graph model, HBM residency and level scheduling.
 #include "graph.h"
 
+#include <unordered_set>
+
+#include "gtn/parallel.h"  // header-only worker pool (no engine dependency)
+
 #include <algorithm>
 #include <cstring>
 #include <list>
@@ -8,6 +12,11 @@
 #include <queue>
 
 namespace gtnx {
+
+GradState::~GradState() {
+  for (auto& in : inputs)
+    if (in.g) in.g->n_consumers--;
+}
 
 // ======================================================================
 // Structure
@@ -367,6 +376,7 @@ struct Packer {
 void ensure_device_batch(const std::vector<Structure*>& ss) {
   Runtime& rt = Runtime::get();
   std::vector<Structure*> todo;
+  std::unordered_set<Structure*> todo_set;
   for (Structure* s : ss) {
     if (s->kind == KIND_LINEAR) {
       DGraph& v = s->dview;
@@ -382,7 +392,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
       s->dev_valid = true;
       continue;
     }
-    if (!s->dev_valid && std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
+    if (!s->dev_valid && todo_set.insert(s).second) todo.push_back(s);
   }
   if (todo.empty()) return;
   struct Off {
@@ -390,9 +400,15 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
   };
   Packer pk;
   std::vector<Off> offs(todo.size());
+  // per-graph host work (CSR build, packing) fans out over a few host threads when
+  // the batch is large -- a training step uploads one small target graph per utterance
+  auto for_each_todo = [&](auto&& body) {
+    if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 16);
+    else for (size_t i = 0; i < todo.size(); ++i) body(i);
+  };
+  for_each_todo([&](size_t i) { todo[i]->ensure_csr(); });
   for (size_t i = 0; i < todo.size(); ++i) {
     Structure* s = todo[i];
-    s->ensure_csr();
     size_t A = size_t(s->A), N = size_t(s->N);
     Off& o = offs[i];
     o.src = pk.add(4 * A);
@@ -413,7 +429,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
   DevMemP dev = rt.alloc(pk.total);
   char* hb = pin->as<char>();
   char* db = dev->as<char>();
-  for (size_t i = 0; i < todo.size(); ++i) {
+  for_each_todo([&](size_t i) {
     Structure* s = todo[i];
     size_t A = size_t(s->A), N = size_t(s->N);
     const Off& o = offs[i];
@@ -462,16 +478,17 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     v.in_rec = reinterpret_cast<const gtnx_i4*>(db + o.irec);
     s->dev_mem = dev;
     s->dev_valid = true;
-  }
+  });
   rt.h2d(dev->ptr, pin->ptr, pk.total);
 }
 
 void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
   Runtime& rt = Runtime::get();
   std::vector<Weights*> todo;
+  std::unordered_set<Weights*> todo_set;
   for (Weights* w : ws) {
     bool stale = !w->dev_valid || w->host_escaped;
-    if (stale && std::find(todo.begin(), todo.end(), w) == todo.end()) todo.push_back(w);
+    if (stale && todo_set.insert(w).second) todo.push_back(w);
   }
   if (todo.empty()) return;
   Packer pk;

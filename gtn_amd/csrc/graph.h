@@ -101,6 +101,7 @@ struct GradState {
   std::unique_ptr<Graph> grad;
   int n_consumers = 0;           // op outputs that list this graph as an input
   bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
+  ~GradState();                  // gives the consumer counts of `inputs` back
 };
 
 struct Graph {

@@ -1,6 +1,8 @@
 // ops.cpp -- batched graph functions + batch-level autograd (see ops.h)
 #include "ops.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
@@ -80,6 +82,7 @@ float* grad_dev_ptr(Graph& out) {
 // ======================================================================
 void GradSink::flush() {
   if (items.empty()) return;
+  GTNX_HOST_T("gradsink.flush");
   Runtime& rt = Runtime::get();
   std::vector<AxpyArgs> ax;
   std::unordered_set<float*> seen;
@@ -314,6 +317,7 @@ struct SdOp : OpRecord {
   std::vector<Saved> saved;
 
   void backward(std::vector<Member>& ms) override {
+    GTNX_HOST_T("backward.sd_op");
     Runtime& rt = Runtime::get();
     const int n = int(ms.size());
     std::vector<Weights*> ws;
@@ -436,6 +440,7 @@ struct SdOp : OpRecord {
 } // namespace
 
 std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+  GTNX_HOST_T("shortest_distance.total");
   const size_t n = gs.size();
   std::vector<Graph> outs(n, Graph(false));
   if (n == 0) return outs;
@@ -819,10 +824,19 @@ int64_t match_bound(const LabelHist& a, const LabelHist& b) {
 } // namespace
 
 std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect) {
+  GTNX_HOST_T("compose.total");
   const size_t n = std::max(av.size(), bv.size());
   std::vector<Graph> outs;
   if (n == 0) return outs;
   Runtime& rt = Runtime::get();
+  double ht_mark = 0;
+  auto ht_phase = [&](const char* name) {  // GTNX_HOST_TIMING: time since the previous mark
+    if (!HostTimer::enabled()) return;
+    const double now = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    if (ht_mark != 0) { HostTimer t(name); t.t0 = ht_mark; }
+    ht_mark = now;
+  };
+  ht_phase("");
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
   for (size_t i = 0; i < n; ++i) {
@@ -835,6 +849,7 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   }
   ensure_device_batch(ss);
   ensure_weights_device_batch(ws);
+  ht_phase("compose.1_upload_inputs");
   // device-built inputs (results of an earlier compose) get their packed
   // adjacency records now; host-built ones got them at upload
   for (Structure* st : ss) {
@@ -856,6 +871,30 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   for (size_t i = 0; i < n; ++i) {
     Structure& s1 = *bcast(av, n, i).s;
     Structure& s2 = *bcast(bv, n, i).s;
+    if ((s1.kind == KIND_LINEAR) != (s2.kind == KIND_LINEAR)) {
+      // one implicit chain: every label below C matches M chain arcs -- a single
+      // pass over the explicit side's labels, no histogram
+      const bool l1 = s1.kind == KIND_LINEAR;
+      Structure& e = l1 ? s2 : s1;
+      const Structure& ch = l1 ? s1 : s2;
+      e.ensure_host();
+      const std::vector<int>& lab = l1 ? e.il : e.ol;
+      int64_t hit = 0, eps = 0;
+      for (int l : lab) {
+        hit += (l >= 0 && l < ch.C);
+        eps += (l == GTNX_EPSILON);
+      }
+      Cap& c = caps[i];
+      c.N1 = s1.N;
+      c.N2 = s2.N;
+      c.pairs = c.N1 * c.N2;
+      c.Acap = hit * ch.M + eps * ch.N;
+      const int64_t starts = l1 ? int64_t(s2.start.size()) : int64_t(s1.start.size());
+      c.Ncap = std::min<int64_t>(c.pairs, c.Acap + starts);
+      if (c.pairs > (int64_t(1) << 30) || c.Acap > (int64_t(1) << 30))
+        throw_runtime("[gtn::compose] composed graph too large for 32-bit indices");
+      continue;
+    }
     if (!h1.count(&s1)) label_hist(s1, true, h1[&s1]);
     if (!h2.count(&s2)) label_hist(s2, false, h2[&s2]);
     const LabelHist& x = h1[&s1];
@@ -872,6 +911,7 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
       throw_runtime("[gtn::compose] composed graph too large for 32-bit indices");
   }
 
+  ht_phase("compose.2_caps");
   // ---- arenas.  Scratch is laid out by kind (all `state` tables contiguous,
   // all in-degree cursors contiguous) so ONE fill and ONE memset initialise the
   // whole batch; result headers (sizes) are contiguous so ONE copy returns them.
@@ -977,6 +1017,7 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     x.counts = reinterpret_cast<int*>(rp + hdr_cnt) + 2 * i;
     x.out = reinterpret_cast<ComposeOut*>(rp + hdr_out) + i;
   }
+  ht_phase("compose.3_alloc_args");
   // Launch groups share a kernel instantiation: (matcher, g1 linear, g2 linear).
   // First pass: the compact LDS-only variant when the pair tables fit; pairs it
   // hands back (overflow == 2: a node with many candidates, an oversized chunk)
@@ -1040,6 +1081,7 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     if (!redo.empty()) run(redo, false);
   }
 
+  ht_phase("compose.4_launch_wait");
   auto op = std::make_shared<ComposeOp>();
   op->seq = g_seq++;
   op->arena = res;
@@ -1122,6 +1164,7 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     op->saved[i] = {x.gi1, x.gi2, co.A};
     outs.push_back(std::move(out));
   }
+  ht_phase("compose.5_outputs");
   return outs;
 }
 
@@ -1178,6 +1221,7 @@ void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(voi
 // backward (autograd.cpp:17-67)
 // ======================================================================
 void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
+  GTNX_HOST_T("backward.total");
   Runtime& rt = Runtime::get();
   // ---- seed (autograd.cpp:57-67)
   if (grad) {
@@ -1225,10 +1269,21 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
     for (auto& m : members) (void)m.out.grad();  // throws "Gradient not calculated yet." like autograd.cpp:46
     kv.second.first->backward(members);
     if (!retain) {
+      // autograd.cpp:47-50: the tape (inputs, saved forward state) goes away with
+      // backward; the objects themselves are reclaimed at the next sync point
+      auto* dead_ops = new std::vector<std::shared_ptr<OpRecord>>();
+      auto* dead_inputs = new std::vector<std::vector<Graph>>();
+      dead_ops->reserve(members.size());
+      dead_inputs->reserve(members.size());
       for (auto& m : members) {
-        m.out.g->inputs.clear();  // autograd.cpp:47-50
-        m.out.g->op.reset();      // drop the saved forward state with the tape
+        for (auto& in : m.out.g->inputs) in.g->n_consumers--;
+        dead_inputs->push_back(std::move(m.out.g->inputs));
+        m.out.g->inputs.clear();
+        dead_ops->push_back(std::move(m.out.g->op));
+        m.out.g->op.reset();
       }
+      rt.defer_delete(dead_ops, [](void* q) { delete static_cast<std::vector<std::shared_ptr<OpRecord>>*>(q); });
+      rt.defer_delete(dead_inputs, [](void* q) { delete static_cast<std::vector<std::vector<Graph>>*>(q); });
     }
   }
 }

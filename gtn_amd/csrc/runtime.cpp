@@ -72,7 +72,33 @@ void Runtime::set_stream(hipStream_t s) {
   stream_ = s ? s : own_stream_;
 }
 
-void Runtime::sync() { HIP_CHECK(hipStreamSynchronize(stream_)); }
+void Runtime::sync() {
+  drain_deferred();  // the GPU is (usually) still busy: reclaim while we would wait
+  HIP_CHECK(hipStreamSynchronize(stream_));
+}
+
+void Runtime::defer_delete(void* p, void (*del)(void*)) {
+  bool full;
+  {
+    std::lock_guard<std::mutex> lk(defer_mu_);
+    deferred_.push_back({p, del});
+    full = deferred_.size() >= (1u << 15);
+  }
+  if (full) drain_deferred();
+}
+
+void Runtime::drain_deferred() {
+  GTNX_HOST_T("runtime.drain_deferred");
+  for (;;) {
+    std::vector<std::pair<void*, void (*)(void*)>> batch;
+    {
+      std::lock_guard<std::mutex> lk(defer_mu_);
+      batch.swap(deferred_);
+    }
+    if (batch.empty()) return;
+    for (auto& e : batch) e.second(e.first);  // destructors may defer more: loop
+  }
+}
 
 DevMemP Runtime::alloc(size_t bytes) {
   size_t sz = round_size(bytes ? bytes : 1);
@@ -169,6 +195,7 @@ void Runtime::release_pinned(void* p, size_t bytes) {
 }
 
 void Runtime::empty_cache() {
+  drain_deferred();
   (void)hipStreamSynchronize(stream_);
   std::lock_guard<std::mutex> lk(mu_);
   for (auto& kv : free_dev_) {
@@ -181,6 +208,7 @@ void Runtime::empty_cache() {
 }
 
 void Runtime::stats(uint64_t* reserved, uint64_t* in_use) {
+  drain_deferred();
   std::lock_guard<std::mutex> lk(mu_);
   if (reserved) *reserved = reserved_;
   if (in_use) *in_use = in_use_;
@@ -190,8 +218,11 @@ void Runtime::h2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
 }
 void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
+  // reclaim first: a device->host copy into pageable memory blocks inside the copy
+  // call until the stream gets there, so this is the last moment the GPU is busy
+  drain_deferred();
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
-  sync();
+  HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void Runtime::d2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_));
@@ -262,4 +293,42 @@ std::string Runtime::prof_names() {
   return s;
 }
 
+} // namespace gtnx
+
+// ---------------------------------------------------------------- host phase timer
+#include <chrono>
+namespace gtnx {
+namespace {
+struct HostTable {
+  std::mutex mu;
+  std::map<std::string, std::pair<double, long>> t;
+  ~HostTable() {
+    if (!HostTimer::enabled()) return;
+    for (auto& kv : t)
+      std::fprintf(stderr, "[gtnx host] %-28s calls %6ld  total %9.2f ms  avg %8.3f ms\n", kv.first.c_str(),
+                   kv.second.second, kv.second.first, kv.second.first / double(kv.second.second));
+  }
+};
+HostTable& host_table() {
+  static HostTable h;
+  return h;
+}
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+} // namespace
+bool HostTimer::enabled() {
+  static const bool e = std::getenv("GTNX_HOST_TIMING") != nullptr;
+  return e;
+}
+HostTimer::HostTimer(const char* n) : name(n), t0(enabled() ? now_ms() : 0.0) {}
+HostTimer::~HostTimer() {
+  if (!enabled()) return;
+  const double dt = now_ms() - t0;
+  HostTable& h = host_table();
+  std::lock_guard<std::mutex> lk(h.mu);
+  auto& e = h.t[name];
+  e.first += dt;
+  e.second += 1;
+}
 } // namespace gtnx

@@ -62,6 +62,12 @@ class Runtime {
   void empty_cache();
   void stats(uint64_t* reserved, uint64_t* in_use);
 
+  // Deferred reclamation: objects the caller let go of (graph handles, the tape of
+  // a finished backward) are destroyed at the next point where the host would wait
+  // for the GPU anyway (sync / blocking copy), off the caller's critical path.
+  void defer_delete(void* p, void (*del)(void*));
+  void drain_deferred();
+
   // copies (async on the engine stream; h2d source must be pinned or outlive sync())
   void h2d(void* dst, const void* src, size_t bytes);
   void d2h_sync(void* dst, const void* src, size_t bytes);  // returns after the data landed
@@ -107,9 +113,23 @@ class Runtime {
   std::vector<ProfRec> prof_recs_;
   std::vector<hipEvent_t> ev_pool_;
   std::map<std::string, ProfEntry> prof_;
+  std::mutex defer_mu_;
+  std::vector<std::pair<void*, void (*)(void*)>> deferred_;
   friend struct Scope;
 };
 
 #define GTNX_PROF(name, bytes) ::gtnx::Runtime::Scope _prof_scope(&::gtnx::Runtime::get(), name, bytes)
+
+// host wall-clock phases (GTNX_HOST_TIMING=1 prints the table at exit); diagnostics only
+struct HostTimer {
+  const char* name;
+  double t0;
+  explicit HostTimer(const char* n);
+  ~HostTimer();
+  static bool enabled();
+};
+#define GTNX_HT_CAT2(a, b) a##b
+#define GTNX_HT_CAT(a, b) GTNX_HT_CAT2(a, b)
+#define GTNX_HOST_T(name) ::gtnx::HostTimer GTNX_HT_CAT(_host_t_, __LINE__)(name)
 
 } // namespace gtnx

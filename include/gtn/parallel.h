@@ -7,6 +7,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
 #include <exception>
 #include <mutex>
 #include <stdexcept>
@@ -22,30 +25,111 @@ auto pickElem(size_t size, size_t i, const V& v) -> decltype(v[0]) {
   if (v.size() == 1) return v[0];
   throw std::runtime_error("parallelMap getIdxOrBroadcast got invalid size or unbroadcastable vector");
 }
+// Persistent worker pool (the reference keeps one too: thread_pool.h:27-91,
+// parallel_map.cpp:18-46, grown on demand and never shrunk).  A job is a callable
+// every participating thread runs once; the caller takes part as well.
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool p;
+    return p;
+  }
+  /** run `job` on `nthreads` threads (caller included).  Nested or concurrent
+   *  calls run on the calling thread only. */
+  template <class Job>
+  void run(size_t nthreads, Job&& job) {
+    std::unique_lock<std::mutex> call(callMutex_, std::try_to_lock);
+    if (!call.owns_lock() || nthreads <= 1) {
+      job();
+      return;
+    }
+    grow(nthreads - 1);
+    {
+      std::lock_guard<std::mutex> lk(mutex_);
+      job_ = [&job] { job(); };
+      want_ = nthreads - 1;
+      pending_ = nthreads - 1;
+      ++epoch_;
+    }
+    wake_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lk(mutex_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  Pool() = default;
+  ~Pool() {
+    {
+      std::lock_guard<std::mutex> lk(mutex_);
+      stop_ = true;
+    }
+    wake_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  void grow(size_t n) {
+    while (threads_.size() < n) {
+      const size_t idx = threads_.size();
+      uint64_t seen;
+      {
+        std::lock_guard<std::mutex> lk(mutex_);
+        seen = epoch_;
+      }
+      threads_.emplace_back([this, idx, seen]() mutable {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(mutex_);
+            wake_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+            if (stop_) return;
+            seen = epoch_;
+            if (idx >= want_) continue;
+            job = job_;
+          }
+          job();
+          {
+            std::lock_guard<std::mutex> lk(mutex_);
+            --pending_;
+          }
+          done_.notify_one();
+        }
+      });
+    }
+  }
+  std::mutex callMutex_, mutex_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> threads_;
+  std::function<void()> job_;
+  uint64_t epoch_ = 0;
+  size_t want_ = 0, pending_ = 0;
+  bool stop_ = false;
+};
+
 template <class Body>
-void runIndexed(size_t n, Body&& body) {
+void runIndexed(size_t n, Body&& body, size_t maxThreads = 64) {
   // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped:
-  // threads are spawned per call here, and host-side graph building saturates
-  // long before 64 of them
+  // host-side graph building saturates long before 64 of them
   const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
-  const size_t nt = std::min<size_t>(std::min(n, hw), 64);
+  const size_t nt = std::min<size_t>(std::min(n, hw), maxThreads);
   std::atomic<size_t> next{0};
   std::exception_ptr first;
   std::mutex mu;
   auto worker = [&]() {
-    for (size_t i = next++; i < n; i = next++) {
-      try {
-        body(i);
-      } catch (...) {
-        std::lock_guard<std::mutex> lk(mu);
-        if (!first) first = std::current_exception();
+    // a few indices per grab: tasks are small (one target graph each)
+    const size_t grain = std::max<size_t>(1, n / (nt * 4));
+    for (size_t i0 = next.fetch_add(grain); i0 < n; i0 = next.fetch_add(grain)) {
+      for (size_t i = i0; i < std::min(n, i0 + grain); ++i) {
+        try {
+          body(i);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(mu);
+          if (!first) first = std::current_exception();
+        }
       }
     }
   };
-  std::vector<std::thread> pool;
-  for (size_t t = 1; t < nt; ++t) pool.emplace_back(worker);
-  worker();
-  for (auto& t : pool) t.join();
+  Pool::get().run(nt, worker);
   if (first) std::rethrow_exception(first);
 }
 } // namespace detail

@@ -636,6 +636,15 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           st[m] = ld_state(a.state + c.idx[m]);
         }
       }
+      // Arc weights are fetched NOW, ahead of the scan and before any store of this
+      // level: vmcnt retires in order, so a load issued after a store cannot be
+      // waited on without also waiting for that store's HBM round trip.
+      float wpre[KC];
+#pragma unroll
+      for (int m = 0; m < KC; ++m) {
+        wpre[m] = 0.0f;
+        if (m < c.n) wpre[m] = (c.i[m] >= 0 ? a.g1.w[c.i[m]] : 0.0f) + (c.j[m] >= 0 ? a.g2.w[c.j[m]] : 0.0f);
+      }
       if (c.n > KC) atomicOr(&sh_flag[3], 1);
       if (hit) atomicOr(&sh_flag[3], 2);
       wg_barrier(lds_state);
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             const int ai = na + r;
             const int i = c.i[m], j = c.j[m];
             const int il = c.il[m], ol = c.ol[m];
-            const float w = (i >= 0 ? a.g1.w[i] : 0.0f) + (j >= 0 ? a.g2.w[j] : 0.0f);
+            const float w = wpre[m];
             a.src[ai] = node;
             a.il[ai] = il;
             a.ol[ai] = ol;
@@ -952,6 +961,90 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           }
           const bool live_src = tid < hi - lo;
           constexpr int U = 4;
+          constexpr int TF = HC / 2;  // arcs per level the flat path can hold
+          if (Aw <= TF) {
+            // ---- flat path: the level's arc template is transposed through LDS (the
+            // claim hash and the in-row cursors are idle here) from "lane = source
+            // node" to "lane = arc slot", so that every store instruction of a wave
+            // covers 64 CONSECUTIVE elements of its output array (the lane-per-node
+            // layout strides by the node's out-degree and touches ~3x the lines).
+            int* t_sd = hkeys;            // src rank | dst rank << 16
+            int* t_il = hkeys + TF;
+            int* t_ol = hvals;
+            int* t_ca = hvals + TF;       // chain arc at the template's time step
+            int* t_wf = hids;             // fixed-side weight (float bits)
+            int* t_gf = hids + TF;        // fixed-side arc
+            int* t_inl = incur;           // in-row slot -> arc rank
+#pragma unroll
+            for (int m = 0; m < KC; ++m) {
+              if (my_ai[m] >= 0) {
+                const int r = my_ai[m] - na_level;
+                t_sd[r] = tid | ((my_dst[m] - hi) << 16);
+                t_il[r] = my_il[m];
+                t_ol[r] = my_ol[m];
+                t_ca[r] = carc[m];
+                t_wf[r] = __float_as_int(wfix[m]);
+                t_gf[r] = L2 ? my_i[m] : my_j[m];
+                t_inl[my_pos[m] - na_level] = r;
+              }
+            }
+            lds_barrier();
+            constexpr int PE = TF / kBlock;  // flat slots per lane
+            int e_sd[PE], e_il[PE], e_ol[PE], e_ca[PE], e_gf[PE], p_r[PE], p_sd[PE], p_ca[PE];
+            float e_wf[PE], p_wf[PE];
+            bool e_on[PE];
+#pragma unroll
+            for (int x = 0; x < PE; ++x) {
+              const int e = tid + x * kBlock;
+              e_on[x] = e < Aw;
+              const int ee = e_on[x] ? e : 0;
+              e_sd[x] = t_sd[ee]; e_il[x] = t_il[ee]; e_ol[x] = t_ol[ee]; e_ca[x] = t_ca[ee];
+              e_wf[x] = __int_as_float(t_wf[ee]); e_gf[x] = t_gf[ee];
+              p_r[x] = t_inl[ee];
+              p_sd[x] = t_sd[p_r[x]]; p_ca[x] = t_ca[p_r[x]]; p_wf[x] = __int_as_float(t_wf[p_r[x]]);
+            }
+            for (int k0 = 1; k0 <= K; k0 += U) {
+              float we[U][PE], wp[U][PE];
+#pragma unroll
+              for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int x = 0; x < PE; ++x) {
+                  const bool on = e_on[x] && k0 + u <= K;
+                  we[u][x] = on ? cw[e_ca[x] + (k0 + u) * CL] : 0.0f;
+                  wp[u][x] = on ? cw[p_ca[x] + (k0 + u) * CL] : 0.0f;
+                }
+#pragma unroll
+              for (int u = 0; u < U; ++u) {
+                const int k = k0 + u;
+                if (k > K) break;
+                const int dn = k * W, da = k * Aw, dc = k * CL;
+#pragma unroll
+                for (int x = 0; x < PE; ++x) {
+                  if (e_on[x]) {
+                    const int ai = na_level + da + tid + x * kBlock;
+                    a.src[ai] = lo + (e_sd[x] & 0xffff) + dn;
+                    a.dst[ai] = hi + (e_sd[x] >> 16) + dn;
+                    a.il[ai] = e_il[x];
+                    a.ol[ai] = e_ol[x];
+                    a.w[ai] = e_wf[x] + we[u][x];
+                    a.gi1[ai] = L2 ? e_gf[x] : e_ca[x] + dc;
+                    a.gi2[ai] = L2 ? e_ca[x] + dc : e_gf[x];
+                    a.in_list[ai] = na_level + da + p_r[x];
+                    a.in_src[ai] = lo + (p_sd[x] & 0xffff) + dn;
+                    a.in_w[ai] = p_wf[x] + wp[u][x];
+                  }
+                }
+#pragma unroll
+                for (int m = 0; m < KC; ++m)
+                  if (my_own[m] >= 0) a.nflags[my_own[m] + dn] = 0;  // neither start (t > 0) nor accept (t < TM)
+                if (live_src) a.out_off[lo + tid + dn] = my_out + da;
+#pragma unroll
+                for (int x = 0; x < PER; ++x)
+                  if (tid * PER + x < W) a.in_off[hi + tid * PER + x + dn] = my_inoff[x] + da;
+              }
+            }
+            lds_barrier();  // the template arrays go back to their owners
+          } else
           for (int k0 = 1; k0 <= K; k0 += U) {
             float wk[U][KC];
 #pragma unroll

@@ -222,12 +222,14 @@ def main():
         ms = fs["total_ms"] / fs["launches"]
         gbs = fs["algorithmic_bytes"] / fs["launches"] / (ms * 1e-3) / 1e9
         # HBM bytes per launch from the PMC run of this same command (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate passes, profiles/r01_v3_c3_pmc_hbm.json).
+        # FETCH_SIZE / WRITE_SIZE in separate passes; newest profiles/r*_c3_pmc_hbm.json).
         # Calibrated on linear_forward_kernel, whose bytes are known exactly
         # (B*T*C*4): FETCH_SIZE reads half the fetched KiB on gfx950, WRITE_SIZE is exact.
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_v3_c3_pmc_hbm.json")
-        if (B, T, Cn, U) == (512, 1000, 256, 100) and os.path.exists(pmc):
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_pmc_hbm.json")))
+        pmc = pmcs[-1] if pmcs else ""
+        if (B, T, Cn, U) == (512, 1000, 256, 100) and pmc:
             k = json.load(open(pmc)).get("sd_forward_narrow_kernel<true>")
             if k:
                 traffic = (2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024

@@ -32,16 +32,23 @@ gtnx_status_t guard(F&& f) {
   }
 }
 
-inline Graph& G(gtnx_graph_t h) {
+// GL: the handle as it is (a composition may still be symbolic, ops.cpp "lazy chain
+// products"); G: for everything that looks inside the graph -- builds it first
+inline Graph& GL(gtnx_graph_t h) {
   if (!h) throw_invalid("null graph handle");
   return *reinterpret_cast<Graph*>(h);
 }
+inline Graph& G(gtnx_graph_t h) {
+  Graph& g = GL(h);
+  if (g.s->lazy) realize(g);
+  return g;
+}
 inline gtnx_graph_t H(Graph g) { return reinterpret_cast<gtnx_graph_t>(new Graph(std::move(g))); }
 
-std::vector<Graph> vec(const gtnx_graph_t* a, int n) {
+std::vector<Graph> vec(const gtnx_graph_t* a, int n, bool lazy_ok = false) {
   std::vector<Graph> v;
   v.reserve(n > 0 ? n : 0);
-  for (int i = 0; i < n; ++i) v.push_back(G(a[i]));
+  for (int i = 0; i < n; ++i) v.push_back(lazy_ok ? GL(a[i]) : G(a[i]));
   return v;
 }
 void put(std::vector<Graph>& r, gtnx_graph_t* out) {
@@ -96,7 +103,7 @@ GTNX_API gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph(calc_grad != 0)); });
 }
 GTNX_API gtnx_status_t gtnx_graph_copy(gtnx_graph_t g, gtnx_graph_t* out) {
-  return guard([&] { *out = H(G(g)); });
+  return guard([&] { *out = H(GL(g)); });
 }
 GTNX_API gtnx_status_t gtnx_graph_deep_copy(gtnx_graph_t g, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph::deep_copy(G(g))); });
@@ -149,7 +156,7 @@ GTNX_API gtnx_status_t gtnx_graph_num_accept(gtnx_graph_t g, int64_t* out) {
   return guard([&] { *out = G(g).num_accept(); });
 }
 GTNX_API gtnx_status_t gtnx_graph_num_inputs(gtnx_graph_t g, int64_t* out) {
-  return guard([&] { *out = int64_t(G(g).g->inputs.size()); });
+  return guard([&] { *out = int64_t(GL(g).g->inputs.size()); });
 }
 GTNX_API gtnx_status_t gtnx_graph_item(gtnx_graph_t g, float* out) {
   return guard([&] { *out = G(g).item(); });
@@ -361,19 +368,19 @@ GTNX_API gtnx_status_t gtnx_graph_set_weight(gtnx_graph_t g, int a, float w) {
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_calc_grad(gtnx_graph_t g, int* out) {
-  return guard([&] { *out = G(g).calc_grad(); });
+  return guard([&] { *out = GL(g).calc_grad(); });
 }
 GTNX_API gtnx_status_t gtnx_graph_set_calc_grad(gtnx_graph_t g, int c) {
-  return guard([&] { G(g).set_calc_grad(c != 0); });
+  return guard([&] { GL(g).set_calc_grad(c != 0); });
 }
 GTNX_API gtnx_status_t gtnx_graph_is_grad_available(gtnx_graph_t g, int* out) {
-  return guard([&] { *out = G(g).is_grad_available(); });
+  return guard([&] { *out = GL(g).is_grad_available(); });
 }
 GTNX_API gtnx_status_t gtnx_graph_grad(gtnx_graph_t g, gtnx_graph_t* out) {
   return guard([&] { *out = H(G(g).grad()); });
 }
 GTNX_API gtnx_status_t gtnx_graph_zero_grad(gtnx_graph_t g) {
-  return guard([&] { G(g).zero_grad(); });
+  return guard([&] { GL(g).zero_grad(); });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_grad(gtnx_graph_t g, const float* v, int64_t n) {
   return guard([&] { G(g).add_grad_host(v, n); });
@@ -391,7 +398,7 @@ GTNX_API gtnx_status_t gtnx_graph_add_grad_graph(gtnx_graph_t g, gtnx_graph_t o)
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_id(gtnx_graph_t g, uintptr_t* out) {
-  return guard([&] { *out = G(g).id(); });
+  return guard([&] { *out = GL(g).id(); });
 }
 GTNX_API gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n, gtnx_grad_fn fn, void* ctx,
                                             void (*ctx_free)(void*), gtnx_graph_t* out) {
@@ -403,7 +410,7 @@ GTNX_API gtnx_status_t gtnx_graph_create_op(gtnx_graph_t* inputs, int n, gtnx_gr
 
 GTNX_API gtnx_status_t gtnx_graph_get_input(gtnx_graph_t g, int i, gtnx_graph_t* out) {
   return guard([&] {
-    auto& ins = G(g).g->inputs;
+    auto& ins = GL(g).g->inputs;
     if (i < 0 || size_t(i) >= ins.size()) throw_range("input index out of range");
     *out = H(ins[size_t(i)]);
   });
@@ -418,7 +425,7 @@ GTNX_API gtnx_status_t gtnx_graph_set_grad_fn(gtnx_graph_t g, gtnx_grad_fn fn, v
   return guard([&] { set_user_grad_fn(G(g), fn, ctx, ctx_free); });
 }
 GTNX_API gtnx_status_t gtnx_graph_has_grad_fn(gtnx_graph_t g, int* out) {
-  return guard([&] { *out = G(g).g->has_grad_fn ? 1 : 0; });
+  return guard([&] { *out = GL(g).g->has_grad_fn ? 1 : 0; });
 }
 
 // ------------------------------------------------------------------ creations
@@ -436,17 +443,17 @@ GTNX_API gtnx_status_t gtnx_linear_graph_n(int B, int M, int N, int cg, const vo
 }
 
 // ------------------------------------------------------------------ functions
-#define UNARY_FN(name, expr)                                                \
+#define UNARY_FN(name, expr, LAZY_OK)                                       \
   GTNX_API gtnx_status_t name(gtnx_graph_t g, gtnx_graph_t* out) {          \
     return guard([&] {                                                      \
-      std::vector<Graph> v{G(g)};                                           \
+      std::vector<Graph> v{LAZY_OK ? GL(g) : G(g)};                         \
       auto r = expr;                                                        \
       *out = H(std::move(r[0]));                                            \
     });                                                                     \
   }                                                                         \
   GTNX_API gtnx_status_t name##_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out) { \
     return guard([&] {                                                      \
-      auto v = vec(g, n);                                                   \
+      auto v = vec(g, n, LAZY_OK);                                          \
       auto r = expr;                                                        \
       put(r, out);                                                          \
     });                                                                     \
@@ -472,14 +479,14 @@ GTNX_API gtnx_status_t gtnx_linear_graph_n(int B, int M, int N, int cg, const vo
 namespace {
 std::vector<Graph> g_empty;
 }
-UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty))
+UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false)
 BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb))
 BINARY_FN(gtnx_subtract, op_scalar(SK_SUBTRACT, va, vb))
 BINARY_FN(gtnx_compose, op_compose(va, vb, false))
 BINARY_FN(gtnx_intersect, op_compose(va, vb, true))
-UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false))
-UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true))
-UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v))
+UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false), true)
+UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true), true)
+UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v), true)
 
 GTNX_API gtnx_status_t gtnx_items_n(const gtnx_graph_t* g, int n, float* out) {
   return guard([&] {

@@ -72,6 +72,10 @@ struct Structure {
   std::shared_ptr<Schedule> sched;  // valid while the structure is unchanged
   std::mutex grad_lock;             // graph.h:450
 
+  // Non-null: this is a composition that has NOT been built (ops.cpp: lazy chain
+  // products).  Nothing else in the structure is valid until realize() fills it in.
+  std::shared_ptr<struct LazyProduct> lazy;
+
   void materialize();  // LINEAR -> EXPLICIT host arrays
   void ensure_host();  // download a device-built structure
   void ensure_csr();
@@ -136,6 +140,13 @@ struct Graph {
   // floats; when `adopt` the buffer becomes the grad without a copy.
   void add_grad_host(const float* v, int64_t n);
   void add_grad_device(const DevMemP& owner, float* dev, bool adopt);
+};
+
+// compose(chain, fixed) / compose(fixed, chain) kept symbolic (see Structure::lazy)
+struct LazyProduct {
+  Graph chain, fixed;
+  int chain_side;  // 1: chain is the first compose argument, 2: the second
+  bool intersect;
 };
 
 // ---- batched residency helpers (ONE staging copy for a whole batch)

@@ -248,6 +248,53 @@ struct ComposeGradArgs {
 void launch_compose_grad(const ComposeGradArgs* d_args, int n, int maxA, hipStream_t st);
 
 // ---------------------------------------------------------------------------
+// lazy chain products (lazy.hip): shortest distance / path / gradients over
+// chain (T x C emissions) o G without building the product
+// ---------------------------------------------------------------------------
+struct LazyGroup {          // utterances that share one explicit graph G
+  DGraph g;                 // G: CSR + packed records + weights
+  int chain_first;          // compose(chain, G): match on G's ilabel; else on its olabel
+  int T, C, N, nb;          // chain length / labels per step, |G| nodes, utterances
+  int Npad, Cpad;           // LDS row strides (odd: 16 utterance rows hit 16 banks)
+  // G's rows repacked for the time-step kernels: {other node, matched label or -1,
+  // weight bits, arc id} in in-row / out-row order -- one 16-byte load per arc
+  const gtnx_i4* lrec_in;
+  const gtnx_i4* lrec_out;
+  const float* const* em;   // [nb] chain weights, T*C each
+  float* alpha;             // [T+1][nb][N]
+  float* beta;              // [T+1][nb][N] (gradients only)
+  int* bp;                  // [T+1][nb][N] back-pointers (arc of G), tropical only
+  float* score;             // [nb]
+  int* best;                // [nb] best accept node of G (-1: no path), tropical only
+  const float* const* delta;  // [nb] upstream gradient of each score
+  float* const* grad_em;      // [nb] chain gradient buffers (T*C) or null entries
+  float* grad_fixed;          // [A] gradient of G's arcs (zero-filled) or null
+};
+size_t lazy_step_lds_bytes(const LazyGroup& g);
+int lazy_tile_nodes();
+int lazy_tile_batch();
+void launch_lazy_pack(const LazyGroup& g, gtnx_i4* lrec_in, gtnx_i4* lrec_out, hipStream_t st);
+void launch_lazy_init(const LazyGroup& g, int which, hipStream_t st);
+void launch_lazy_step(const LazyGroup& g, int t, int mode, int backward, hipStream_t st);
+void launch_lazy_final(const LazyGroup& g, int mode, hipStream_t st);
+void launch_lazy_path(const LazyGroup& g, int* path_arc, int* path_il, int* path_ol, float* path_w, int* path_len,
+                      hipStream_t st);
+// node_label != null: every node's in-arcs share one matched label (no arc loop)
+void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st);
+void launch_lazy_fixed_grad(const LazyGroup& g, int max_in_deg, hipStream_t st);
+struct LazyPathGrad {
+  const float* delta;   // [len] (stride 1) or one scalar (stride 0)
+  int delta_stride;
+  const int* path_arc;  // [len] arcs of G, first-arc-first
+  const int* il;
+  const int* ol;
+  int len, C, chain_first;
+  float* grad_chain;    // [T*C] or null
+  float* grad_fixed;    // [A] or null
+};
+void launch_lazy_path_grad(const LazyPathGrad& a, hipStream_t st);
+
+// ---------------------------------------------------------------------------
 // small elementwise helpers
 // ---------------------------------------------------------------------------
 void launch_fill_i32(int* p, int v, size_t n, hipStream_t st);

@@ -1,0 +1,490 @@
+// lazy.hip -- shortest distance / path / gradients over a composition that is NEVER
+// materialised: the product of an implicit linear chain (emissions, T x C) with an
+// explicit epsilon-free graph G (N nodes, A arcs).
+//
+// Replaces, for products too large to build (dense ASG
+// transitions, C^2 (T-1) + C = 262 M arcs = 7 GB per utterance), the sequence
+//   compose (compose.cpp:377-522)  ->  shortestDistance / shortestPath
+//   (shortest.cpp:86-272)  ->  their gradFuncs (shortest.cpp:33-82, compose.cpp:496-518).
+// Every state of the product is a pair (t, n); an arc a: s -> d of G with matched
+// label l < C yields (t, s) -> (t+1, d) with weight w[a] + em[t][l] for every t, so
+//   alpha[t+1][d] = (+)_{a: s->d} alpha[t][s] + w[a] + em[t][l(a)]      (forward)
+//   beta [t][s]   = (+)_{a: s->d} w[a] + em[t][l(a)] + beta[t+1][d]     (backward)
+// with alpha[0] = 0 on G's start nodes, beta[T] = 0 on its accept nodes.  The trimmed
+// product the reference would build has the same total score (dead states carry no
+// weight to an accept state), the same best path, and the same gradients.
+//
+// Execution model: one launch per time step over the whole BATCH of utterances that
+// share G.  A workgroup owns a tile of 16 nodes x 16 utterances; lanes 0..15 of a
+// 16-lane DPP row are 16 utterances of ONE node, so G's arc records are fetched once
+// per row (same address across the row) and reused 16 times, while the previous
+// step's scores and the emission rows of the tile's utterances sit in LDS.  This is
+// VALU-bound work (T*C^2 adds/max or exp per utterance), not an HBM stream.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+#include "kernels.h"
+
+namespace gtnx {
+namespace {
+
+constexpr int kBlock = 256;   // element-wise / per-utterance kernels
+constexpr int kTile = 512;    // tile kernels: DT rows of BT lanes
+constexpr int DT = 32;  // nodes per tile
+constexpr int BT = 16;  // utterances per tile (one DPP row)
+constexpr int RC = 32;  // records of a row staged per chunk
+constexpr float NEG_INF = -__builtin_inff();
+
+__device__ __forceinline__ int rec_label(const gtnx_i4& r, int chain_first) { return chain_first ? r.x : r.y; }
+
+__global__ void lazy_pack_kernel(LazyGroup g, gtnx_i4* lrec_in, gtnx_i4* lrec_out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= g.g.A) return;
+#pragma unroll
+  for (int dir = 0; dir < 2; ++dir) {
+    const gtnx_i4 r = dir ? g.g.out_rec[k] : g.g.in_rec[k];
+    const int lab = rec_label(r, g.chain_first);
+    gtnx_i4 o;
+    o.x = r.z;
+    o.y = (lab >= 0 && lab < g.C) ? lab : -1;
+    o.z = __float_as_int(g.g.w[r.w]);
+    o.w = r.w;
+    (dir ? lrec_out : lrec_in)[k] = o;
+  }
+}
+
+__global__ void lazy_init_kernel(LazyGroup g, int which) {
+  // which 0: alpha[0] from start flags; 1: beta[T] from accept flags
+  const int64_t tot = int64_t(g.nb) * g.N;
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= tot) return;
+  const int n = int(i % g.N);
+  const uint8_t f = g.g.nflags[n];
+  if (which == 0)
+    g.alpha[i] = (f & NF_START) ? 0.0f : NEG_INF;
+  else
+    g.beta[int64_t(g.T) * tot + i] = (f & NF_ACCEPT) ? 0.0f : NEG_INF;
+}
+
+// one time step.  FWD: alpha[t] -> alpha[t+1] over in-rows; BWD: beta[t+1] -> beta[t]
+// over out-rows.  MODE SD_LOG: streaming log-sum-exp; SD_TROPICAL (forward only):
+// max with the FIRST maximal in-arc recorded as back-pointer.
+template <int MODE, bool BWD>
+__global__ __launch_bounds__(kTile) void lazy_step_kernel(LazyGroup g, int t) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int N = g.N, C = g.C, Np = g.Npad, Cp = g.Cpad;
+  float* prev = lds;             // [BT][Np]
+  float* emr = lds + BT * Np;    // [BT][Cp]
+  __shared__ __attribute__((aligned(16))) gtnx_i4 rowbuf[DT][RC + 1];  // the tile's rows, RC records at a time
+  const int b0 = blockIdx.y * BT;
+  const int64_t plane = int64_t(g.nb) * N;
+  const float* src_plane = BWD ? g.beta + int64_t(t + 1) * plane : g.alpha + int64_t(t) * plane;
+  {
+    // one wave-row of the block per utterance row: unit-stride copies, no divisions
+    const int rb = tid >> 5, rl = tid & 31;  // 16 rows x 32 lanes
+    const bool on = b0 + rb < g.nb;
+    const float* sp = src_plane + int64_t(b0 + rb) * N;
+    for (int n = rl; n < N; n += 32) prev[rb * Np + n] = on ? sp[n] : NEG_INF;
+    const float* ep = on ? g.em[b0 + rb] + int64_t(t) * C : nullptr;
+    for (int c = rl; c < C; c += 32) emr[rb * Cp + c] = on ? ep[c] : 0.0f;
+  }
+  __syncthreads();
+  const int bl = tid & (BT - 1), dl = tid >> 4;
+  const int node = blockIdx.x * DT + dl;
+  const int b = b0 + bl;
+  const bool live = node < N && b < g.nb;
+  const GTNX_G int* off = BWD ? g.g.out_off : g.g.in_off;
+  const gtnx_i4* __restrict__ rec = BWD ? g.lrec_out : g.lrec_in;
+  const int nd = min(node, N - 1);
+  const int k0 = node < N ? off[nd] : 0, k1 = node < N ? off[nd + 1] : 0;
+  const float* pb = prev + bl * Np;
+  const float* eb = emr + bl * Cp;
+  float m = NEG_INF, s = 0.0f;
+  int arg = -1;
+  // The 16 lanes of a DPP row serve one node: they fetch the node's next RC records
+  // TOGETHER (RC/16 each, coalesced), park them in LDS and then all walk them from
+  // there (same-address LDS reads broadcast).  The fetch of chunk c+1 is issued
+  // before chunk c is reduced, so its latency hides behind RC arcs of VALU work; a
+  // row lives inside one wave, so only the wave's own LDS counter orders this.
+  constexpr int PL = RC / BT;  // records per lane per chunk
+  gtnx_i4 pre[PL];
+  auto fetch = [&](int kk) {
+#pragma unroll
+    for (int x = 0; x < PL; ++x) pre[x] = rec[min(kk + bl * PL + x, max(k1 - 1, 0))];
+  };
+  if (k0 < k1) fetch(k0);
+  for (int k = k0; k < k1; k += RC) {
+#pragma unroll
+    for (int x = 0; x < PL; ++x) rowbuf[dl][bl * PL + x] = pre[x];
+    if (k + RC < k1) fetch(k + RC);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int cnt = min(RC, k1 - k);
+    constexpr int UR = 4;  // arcs whose LDS gathers are in flight together
+    for (int u0 = 0; u0 < cnt; u0 += UR) {
+      gtnx_i4 r[UR];
+      float x[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) r[u] = rowbuf[dl][min(u0 + u, RC - 1)];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const bool ok = u0 + u < cnt && r[u].y >= 0;
+        const int sx = ok ? r[u].x : 0, lx = ok ? r[u].y : 0;
+        x[u] = pb[sx] + __int_as_float(r[u].z) + eb[lx];
+        if (!ok) x[u] = NEG_INF;
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        if (MODE == SD_LOG) {
+          // streaming log-sum-exp: one exp per arc; -inf terms leave (m, s) untouched
+          if (x[u] > m) {
+            s = (m == NEG_INF) ? 1.0f : s * __expf(m - x[u]) + 1.0f;
+            m = x[u];
+          } else if (x[u] != NEG_INF) {
+            s += __expf(x[u] - m);
+          }
+        } else {
+          if (x[u] > m) {
+            m = x[u];
+            arg = r[u].w;
+          }
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // reads done before the next chunk lands
+  }
+  if (!live) return;
+  float out;
+  if (MODE == SD_LOG)
+    out = (m == NEG_INF || m == -NEG_INF) ? m : m + __logf(s);
+  else
+    out = m;
+  if (BWD) {
+    g.beta[int64_t(t) * plane + int64_t(b) * N + node] = out;
+  } else {
+    g.alpha[int64_t(t + 1) * plane + int64_t(b) * N + node] = out;
+    if (MODE == SD_TROPICAL) g.bp[int64_t(t + 1) * plane + int64_t(b) * N + node] = arg;
+  }
+}
+
+// accept reduction (shortest.cpp:148-159): one workgroup per utterance
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void lazy_final_kernel(LazyGroup g) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* last = g.alpha + int64_t(g.T) * g.nb * g.N + int64_t(b) * g.N;
+  __shared__ float sh_v[kBlock];
+  __shared__ int sh_k[kBlock];
+  float mx = NEG_INF;
+  int bestk = INT_MAX;
+  for (int k = tid; k < g.g.n_accept; k += kBlock) {
+    const float v = last[g.g.accept_list[k]];
+    if (v > mx) { mx = v; bestk = k; }
+  }
+  sh_v[tid] = mx;
+  sh_k[tid] = bestk;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      const float v2 = sh_v[tid + o];
+      const int k2 = sh_k[tid + o];
+      if (v2 > sh_v[tid] || (v2 == sh_v[tid] && k2 < sh_k[tid])) { sh_v[tid] = v2; sh_k[tid] = k2; }
+    }
+    __syncthreads();
+  }
+  mx = sh_v[0];
+  bestk = sh_k[0];
+  __syncthreads();
+  if (MODE == SD_TROPICAL) {
+    if (tid == 0) {
+      g.score[b] = mx;
+      g.best[b] = (bestk == INT_MAX || mx == NEG_INF) ? -1 : g.g.accept_list[bestk];
+    }
+    return;
+  }
+  float sum = 0.0f;
+  if (mx != NEG_INF && mx != -NEG_INF)
+    for (int k = tid; k < g.g.n_accept; k += kBlock) sum += expf(last[g.g.accept_list[k]] - mx);
+  sh_v[tid] = sum;
+  __syncthreads();
+  for (int o = kBlock / 2; o > 0; o >>= 1) {
+    if (tid < o) sh_v[tid] += sh_v[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    g.score[b] = (g.g.n_accept == 0 || mx == NEG_INF || mx == -NEG_INF) ? mx : mx + logf(sh_v[0]);
+    g.best[b] = -1;
+  }
+}
+
+// back-pointer chase (shortest.cpp:239-260): one lane per utterance; writes the path
+// first-arc-first as (fixed arc id, composed ilabel, composed olabel, weight)
+__global__ void lazy_path_kernel(LazyGroup g, int* path_arc, int* path_il, int* path_ol, float* path_w,
+                                 int* path_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= g.nb) return;
+  const int64_t plane = int64_t(g.nb) * g.N;
+  int node = g.best[b];
+  if (node < 0) {  // no accepting path: the trimmed product is the empty graph
+    path_len[b] = -1;
+    return;
+  }
+  for (int t = g.T; t >= 1; --t) {
+    const int arc = g.bp[int64_t(t) * plane + int64_t(b) * g.N + node];
+    const int lab = g.chain_first ? g.g.il[arc] : g.g.ol[arc];
+    const int64_t o = int64_t(b) * g.T + (t - 1);
+    path_arc[o] = arc;
+    path_il[o] = g.chain_first ? lab : g.g.il[arc];
+    path_ol[o] = g.chain_first ? g.g.ol[arc] : lab;
+    path_w[o] = g.g.w[arc] + g.em[b][int64_t(t - 1) * g.C + lab];
+    node = g.g.src[arc];
+  }
+  path_len[b] = g.T;
+}
+
+// ---- gradients of the log-semiring score -------------------------------------------
+// posterior of product arc (t, a):  p = exp(alpha[t][s] + w[a] + em[t][l] + beta[t+1][d] - Z)
+
+// chain gradient when every node's in-arcs share one matched label (`node_label`,
+// -1 for nodes without in-arcs): sum_a p = exp(alpha[t+1][d] + beta[t+1][d] - Z), no arc
+// loop.  One workgroup per (t, utterance); labels shared by several nodes (a CTC
+// blank) are summed in an LDS row, then the row is stored once.
+__global__ __launch_bounds__(kBlock) void lazy_chain_grad_nodes_kernel(LazyGroup g, const int* __restrict__ node_label) {
+  extern __shared__ float row[];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  float* out = g.grad_em[b];
+  if (!out) return;
+  for (int c = tid; c < g.C; c += kBlock) row[c] = 0.0f;
+  __syncthreads();
+  const int64_t o = int64_t(t + 1) * g.nb * g.N + int64_t(b) * g.N;
+  // an utterance without any accepting path (score -inf) has an empty product: no gradient
+  const float z0 = g.score[b];
+  const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
+  const float z = zfin ? z0 : 0.0f, dl = zfin ? *g.delta[b] : 0.0f;
+  for (int n = tid; n < g.N; n += kBlock) {
+    const int lab = node_label[n];
+    if (lab < 0) continue;
+    const float x = g.alpha[o + n] + g.beta[o + n] - z;
+    if (x != NEG_INF) atomicAdd(&row[lab], expf(x) * dl);
+  }
+  __syncthreads();
+  for (int c = tid; c < g.C; c += kBlock) out[int64_t(t) * g.C + c] = row[c];
+}
+
+// general chain gradient: per (t, utterance) loop over all arcs of G
+__global__ __launch_bounds__(kBlock) void lazy_chain_grad_arcs_kernel(LazyGroup g) {
+  extern __shared__ float row[];
+  const int t = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  float* out = g.grad_em[b];
+  if (!out) return;
+  for (int c = tid; c < g.C; c += kBlock) row[c] = 0.0f;
+  __syncthreads();
+  const int64_t plane = int64_t(g.nb) * g.N;
+  const float* al = g.alpha + int64_t(t) * plane + int64_t(b) * g.N;
+  const float* be = g.beta + int64_t(t + 1) * plane + int64_t(b) * g.N;
+  const float* em = g.em[b] + int64_t(t) * g.C;
+  // an utterance without any accepting path (score -inf) has an empty product: no gradient
+  const float z0 = g.score[b];
+  const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
+  const float z = zfin ? z0 : 0.0f, dl = zfin ? *g.delta[b] : 0.0f;
+  for (int a = tid; a < g.g.A; a += kBlock) {
+    const int lab = g.chain_first ? g.g.il[a] : g.g.ol[a];
+    if (lab < 0 || lab >= g.C) continue;
+    const float x = al[g.g.src[a]] + g.g.w[a] + em[lab] + be[g.g.dst[a]] - z;
+    if (x != NEG_INF) atomicAdd(&row[lab], expf(x) * dl);
+  }
+  __syncthreads();
+  for (int c = tid; c < g.C; c += kBlock) out[int64_t(t) * g.C + c] = row[c];
+}
+
+// gradient of G's arcs: grad[a] = sum over (t, utterance) of p.  Tile = 16 nodes x 16
+// utterances x a range of time steps; per step the 16 utterances of a node are summed
+// with DPP row shifts and lane 15 of the row adds the sum into an LDS accumulator
+// owned by (node, in-row slot); the accumulators go out with one global atomic each
+// at the end of the tile's time range.
+__device__ __forceinline__ float row16_sum(float x) {
+#define GTNX_ROW_ADD(ctrl) x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false))
+  GTNX_ROW_ADD(0x111);
+  GTNX_ROW_ADD(0x112);
+  GTNX_ROW_ADD(0x114);
+  GTNX_ROW_ADD(0x118);
+#undef GTNX_ROW_ADD
+  return x;  // valid in lane 15 of each 16-lane row
+}
+
+__global__ __launch_bounds__(kTile) void lazy_fixed_grad_kernel(LazyGroup g, int t_per_block, int max_in_deg) {
+  extern __shared__ float lds[];
+  const int tid = threadIdx.x;
+  const int N = g.N, C = g.C, Np = g.Npad, Cp = g.Cpad;
+  float* al = lds;                  // [BT][Np]  alpha[t]
+  float* emr = al + BT * Np;        // [BT][Cp]
+  float* acc = emr + BT * Cp;       // [DT][max_in_deg]
+  __shared__ __attribute__((aligned(16))) gtnx_i4 rowbuf[DT][RC + 1];
+  const int b0 = blockIdx.y * BT;
+  const int t0 = blockIdx.z * t_per_block, t1 = min(g.T, t0 + t_per_block);
+  const int64_t plane = int64_t(g.nb) * N;
+  const int bl = tid & (BT - 1), dl = tid >> 4;
+  const int node = blockIdx.x * DT + dl;
+  const int b = b0 + bl;
+  const bool live = node < N && b < g.nb;
+  for (int i = tid; i < DT * max_in_deg; i += kTile) acc[i] = 0.0f;
+  const int nd = min(node, N - 1);
+  const int k0 = g.g.in_off[nd], deg = node < N ? g.g.in_off[nd + 1] - k0 : 0;
+  // loop bounds must be uniform across the wave for the DPP sums
+  __shared__ int sh_deg;
+  if (tid == 0) sh_deg = 0;
+  __syncthreads();
+  atomicMax(&sh_deg, deg);
+  __syncthreads();
+  const int loop_deg = sh_deg;
+  const float z0 = live ? g.score[b] : 0.0f;
+  const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
+  const float z = zfin ? z0 : 0.0f;
+  const float dlt = (live && zfin) ? *g.delta[b] : 0.0f;
+  for (int t = t0; t < t1; ++t) {
+    __syncthreads();
+    const float* src_plane = g.alpha + int64_t(t) * plane;
+    {
+      const int rb = tid >> 5, rl = tid & 31;
+      const bool on = b0 + rb < g.nb;
+      const float* sp = src_plane + int64_t(b0 + rb) * N;
+      for (int n = rl; n < N; n += 32) al[rb * Np + n] = on ? sp[n] : NEG_INF;
+      const float* ep = on ? g.em[b0 + rb] + int64_t(t) * C : nullptr;
+      for (int c = rl; c < C; c += 32) emr[rb * Cp + c] = on ? ep[c] : 0.0f;
+    }
+    __syncthreads();
+    const float bd = live ? g.beta[int64_t(t + 1) * plane + int64_t(b) * N + node] : NEG_INF;
+    constexpr int PL = RC / BT;
+    gtnx_i4 pre[PL];
+    auto fetch = [&](int jj) {
+#pragma unroll
+      for (int x = 0; x < PL; ++x) pre[x] = g.lrec_in[k0 + min(jj + bl * PL + x, max(deg - 1, 0))];
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < loop_deg; j0 += RC) {
+#pragma unroll
+      for (int x = 0; x < PL; ++x) rowbuf[dl][bl * PL + x] = pre[x];
+      if (j0 + RC < loop_deg) fetch(j0 + RC);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int cnt = min(RC, loop_deg - j0);  // uniform: the DPP sums need every lane
+      for (int u = 0; u < cnt; ++u) {
+        const int j = j0 + u;
+        const gtnx_i4 r = rowbuf[dl][u];
+        float p = 0.0f;
+        if (live && j < deg && r.y >= 0) {
+          const float x = al[bl * Np + r.x] + __int_as_float(r.z) + emr[bl * Cp + r.y] + bd - z;
+          if (x != NEG_INF) p = __expf(x) * dlt;
+        }
+        p = row16_sum(p);
+        if (bl == BT - 1 && j < deg) acc[dl * max_in_deg + j] += p;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  __syncthreads();
+  if (node < N && bl == BT - 1) {
+    for (int j = 0; j < deg; ++j) {
+      const float v = acc[dl * max_in_deg + j];
+      if (v != 0.0f) atomicAdd(g.grad_fixed + g.g.in_rec[k0 + j].w, v);
+    }
+  }
+}
+
+// gradient of the best path (shortest.cpp:262-269 + compose.cpp:496-518): delta of path
+// arc t goes to chain arc (t, label) and to G's arc
+__global__ void lazy_path_grad_kernel(LazyPathGrad a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.len) return;
+  // the reference indexes its saved arcs last-arc-first against deltas first-arc-first
+  // (SURVEY.md section 8 A9): delta[i] lands on the mirrored path position
+  const int pos = a.len - 1 - i;
+  const float d = a.delta[a.delta_stride ? i : 0];
+  const int arc = a.path_arc[pos];
+  const int lab = a.chain_first ? a.il[pos] : a.ol[pos];
+  if (a.grad_chain) atomicAdd(a.grad_chain + int64_t(pos) * a.C + lab, d);
+  if (a.grad_fixed) atomicAdd(a.grad_fixed + arc, d);
+}
+
+} // namespace
+
+size_t lazy_step_lds_bytes(const LazyGroup& g) { return sizeof(float) * size_t(BT) * size_t(g.Npad + g.Cpad); }
+int lazy_tile_nodes() { return DT; }
+int lazy_tile_batch() { return BT; }
+
+void launch_lazy_pack(const LazyGroup& g, gtnx_i4* lrec_in, gtnx_i4* lrec_out, hipStream_t st) {
+  if (g.g.A <= 0) return;
+  hipLaunchKernelGGL(lazy_pack_kernel, dim3((g.g.A + kBlock - 1) / kBlock), dim3(kBlock), 0, st, g, lrec_in, lrec_out);
+}
+
+void launch_lazy_init(const LazyGroup& g, int which, hipStream_t st) {
+  const int64_t tot = int64_t(g.nb) * g.N;
+  if (tot <= 0) return;
+  hipLaunchKernelGGL(lazy_init_kernel, dim3(unsigned((tot + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, g, which);
+}
+
+void launch_lazy_step(const LazyGroup& g, int t, int mode, int backward, hipStream_t st) {
+  const dim3 grid((g.N + DT - 1) / DT, (g.nb + BT - 1) / BT);
+  const size_t lds = lazy_step_lds_bytes(g);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_LOG, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_LOG, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_TROPICAL, false>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_set = true;
+  }
+  if (backward)
+    hipLaunchKernelGGL((lazy_step_kernel<SD_LOG, true>), grid, dim3(kTile), lds, st, g, t);
+  else if (mode == SD_LOG)
+    hipLaunchKernelGGL((lazy_step_kernel<SD_LOG, false>), grid, dim3(kTile), lds, st, g, t);
+  else
+    hipLaunchKernelGGL((lazy_step_kernel<SD_TROPICAL, false>), grid, dim3(kTile), lds, st, g, t);
+}
+
+void launch_lazy_final(const LazyGroup& g, int mode, hipStream_t st) {
+  if (g.nb <= 0) return;
+  if (mode == SD_LOG)
+    hipLaunchKernelGGL(lazy_final_kernel<SD_LOG>, dim3(g.nb), dim3(kBlock), 0, st, g);
+  else
+    hipLaunchKernelGGL(lazy_final_kernel<SD_TROPICAL>, dim3(g.nb), dim3(kBlock), 0, st, g);
+}
+
+void launch_lazy_path(const LazyGroup& g, int* path_arc, int* path_il, int* path_ol, float* path_w, int* path_len,
+                      hipStream_t st) {
+  if (g.nb <= 0) return;
+  hipLaunchKernelGGL(lazy_path_kernel, dim3((g.nb + 63) / 64), dim3(64), 0, st, g, path_arc, path_il, path_ol, path_w,
+                     path_len);
+}
+
+void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st) {
+  if (g.nb <= 0 || g.T <= 0) return;
+  const dim3 grid(g.T, g.nb);
+  const size_t lds = sizeof(float) * size_t(g.C);
+  if (node_label)
+    hipLaunchKernelGGL(lazy_chain_grad_nodes_kernel, grid, dim3(kBlock), lds, st, g, node_label);
+  else
+    hipLaunchKernelGGL(lazy_chain_grad_arcs_kernel, grid, dim3(kBlock), lds, st, g);
+}
+
+void launch_lazy_fixed_grad(const LazyGroup& g, int max_in_deg, hipStream_t st) {
+  if (g.nb <= 0 || g.T <= 0 || max_in_deg <= 0) return;
+  const int t_per_block = 32;
+  const dim3 grid((g.N + DT - 1) / DT, (g.nb + BT - 1) / BT, (g.T + t_per_block - 1) / t_per_block);
+  const size_t lds = lazy_step_lds_bytes(g) + sizeof(float) * size_t(DT) * size_t(max_in_deg);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_fixed_grad_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(lazy_fixed_grad_kernel, grid, dim3(kTile), lds, st, g, t_per_block, max_in_deg);
+}
+
+void launch_lazy_path_grad(const LazyPathGrad& a, hipStream_t st) {
+  if (a.len <= 0) return;
+  hipLaunchKernelGGL(lazy_path_grad_kernel, dim3((a.len + 255) / 256), dim3(256), 0, st, a);
+}
+
+} // namespace gtnx

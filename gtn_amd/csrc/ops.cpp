@@ -2,6 +2,7 @@
 #include "ops.h"
 
 #include <chrono>
+#include <tuple>
 
 #include <algorithm>
 #include <atomic>
@@ -47,6 +48,12 @@ Graph make_output(const std::shared_ptr<OpRecord>& op, int idx, std::vector<Grap
   }
   return out;
 }
+
+// lazy chain products (defined further down)
+std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical);
+std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs);
+std::shared_ptr<OpRecord> make_lazy_compose_op();
+bool lazy_shape_ok(const Structure& chain, const Structure& fixed);
 
 template <class T>
 const T& bcast(const std::vector<T>& v, size_t n, size_t i) {
@@ -444,6 +451,24 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
   const size_t n = gs.size();
   std::vector<Graph> outs(n, Graph(false));
   if (n == 0) return outs;
+  {
+    // symbolic chain products take the time-synchronous kernels; the rest go on below
+    std::vector<Graph> lz, rest;
+    std::vector<size_t> lz_i, rest_i;
+    for (size_t i = 0; i < n; ++i) {
+      if (gs[i].s->lazy) { lz.push_back(gs[i]); lz_i.push_back(i); }
+      else { rest.push_back(gs[i]); rest_i.push_back(i); }
+    }
+    if (!lz.empty()) {
+      std::vector<Graph> lo = lazy_shortest_distance(lz, tropical);
+      for (size_t k = 0; k < lz.size(); ++k) outs[lz_i[k]] = lo[k];
+      if (!rest.empty()) {
+        std::vector<Graph> ro = op_shortest_distance(rest, tropical);
+        for (size_t k = 0; k < rest.size(); ++k) outs[rest_i[k]] = ro[k];
+      }
+      return outs;
+    }
+  }
   Runtime& rt = Runtime::get();
   std::vector<int> lin, exp;
   for (size_t i = 0; i < n; ++i) (gs[i].s->kind == KIND_LINEAR ? lin : exp).push_back(int(i));
@@ -613,6 +638,24 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
   const size_t n = gs.size();
   std::vector<Graph> outs;
   if (n == 0) return outs;
+  {
+    std::vector<Graph> lz, rest;
+    std::vector<size_t> lz_i, rest_i;
+    for (size_t i = 0; i < n; ++i) {
+      if (gs[i].s->lazy) { lz.push_back(gs[i]); lz_i.push_back(i); }
+      else { rest.push_back(gs[i]); rest_i.push_back(i); }
+    }
+    if (!lz.empty()) {
+      outs.assign(n, Graph(false));
+      std::vector<Graph> lo = lazy_viterbi_path(lz);
+      for (size_t k = 0; k < lz.size(); ++k) outs[lz_i[k]] = lo[k];
+      if (!rest.empty()) {
+        std::vector<Graph> ro = op_viterbi_path(rest);
+        for (size_t k = 0; k < rest.size(); ++k) outs[rest_i[k]] = ro[k];
+      }
+      return outs;
+    }
+  }
   Runtime& rt = Runtime::get();
   for (auto& g : gs) g.s->materialize();  // TODO(linear fast path): row arg-max needs no graph
   std::vector<Structure*> ss;
@@ -823,7 +866,12 @@ int64_t match_bound(const LabelHist& a, const LabelHist& b) {
 }
 } // namespace
 
+std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect, bool allow_lazy);
 std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect) {
+  return op_compose_impl(av, bv, intersect, true);
+}
+
+std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect, bool allow_lazy) {
   GTNX_HOST_T("compose.total");
   const size_t n = std::max(av.size(), bv.size());
   std::vector<Graph> outs;
@@ -837,6 +885,8 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
     ht_mark = now;
   };
   ht_phase("");
+  for (auto& g : av) realize(g);
+  for (auto& g : bv) realize(g);
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
   for (size_t i = 0; i < n; ++i) {
@@ -912,6 +962,37 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   }
 
   ht_phase("compose.2_caps");
+  // ---- keep the product symbolic?  Only a chain product with an epsilon-free partner
+  // qualifies; it is taken when building the batch would not fit (or on request).
+  if (allow_lazy) {
+    const char* env = getenv("GTNX_LAZY_COMPOSE");  // "1": whenever eligible, "0": never
+    const bool force = env && env[0] == '1', never = env && env[0] == '0';
+    const char* benv = getenv("GTNX_LAZY_BYTES");
+    const double budget = benv ? atof(benv) : 128e9;
+    bool eligible = !never;
+    double est = 0;
+    for (size_t i = 0; i < n && eligible; ++i) {
+      Graph& a = const_cast<Graph&>(bcast(av, n, i));
+      Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+      const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
+      eligible = (l1 != l2) && (((l1 ? b : a).s->dview.flags & GF_EPS_FREE) != 0) &&
+                 lazy_shape_ok(*(l1 ? a : b).s, *(l1 ? b : a).s);
+      est += 44.0 * double(caps[i].Acap) + 30.0 * double(caps[i].Ncap) + 8.0 * double(caps[i].pairs);
+    }
+    if (eligible && (force || est > budget)) {
+      auto lop = make_lazy_compose_op();
+      for (size_t i = 0; i < n; ++i) {
+        Graph& a = const_cast<Graph&>(bcast(av, n, i));
+        Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+        const bool l1 = a.s->kind == KIND_LINEAR;
+        Graph out = make_output(lop, int(i), {a, b});
+        out.s->host_valid = false;
+        out.s->lazy = std::make_shared<LazyProduct>(LazyProduct{l1 ? a : b, l1 ? b : a, l1 ? 1 : 2, intersect});
+        outs.push_back(std::move(out));
+      }
+      return outs;
+    }
+  }
   // ---- arenas.  Scratch is laid out by kind (all `state` tables contiguous,
   // all in-degree cursors contiguous) so ONE fill and ONE memset initialise the
   // whole batch; result headers (sizes) are contiguous so ONE copy returns them.
@@ -1168,6 +1249,458 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   return outs;
 }
 
+
+// ======================================================================
+// Lazy chain products (kernels: lazy.hip).  compose(chain, G) / compose(G, chain)
+// with an implicit linear chain and an epsilon-free G is kept SYMBOLIC when building
+// it is infeasible (or GTNX_LAZY_COMPOSE=1): forwardScore / viterbiScore /
+// viterbiPath and their gradients then run as time-synchronous dynamic programs
+// over (t, node of G), batched over the utterances that share G.  Any other use of
+// the result (inspection, another op) realises it through the ordinary compose.
+// ======================================================================
+namespace {
+
+struct LazyComposeOp : OpRecord {
+  void backward(std::vector<Member>& ms) override {
+    for (auto& m : ms) {
+      if (!m.out.g->grad_propagated)
+        throw_logic("[gtn::compose] internal: gradient reached an unrealised lazy product");
+      m.out.g->grad_propagated = false;
+    }
+  }
+};
+
+// everything the forward pass of one group leaves behind
+struct LazyGroupState {
+  LazyGroup view{};                 // host copy of the kernel argument
+  DevMemP arena;                    // alpha / bp / score / best / em pointer table
+  DevMemP labels;                   // node_label (null when in-arc labels differ per node)
+  const int* node_label = nullptr;
+  int max_in_deg = 0;
+  Graph fixed;                      // keeps G alive
+  std::vector<Graph> chains;        // per member
+  std::vector<int> member_of;       // output index -> member slot (filled by the caller)
+};
+
+int lazy_lds_limit() { return 150 * 1024; }
+
+std::shared_ptr<OpRecord> make_lazy_compose_op() {
+  auto op = std::make_shared<LazyComposeOp>();
+  op->seq = g_seq++;
+  return op;
+}
+
+bool lazy_shape_ok(const Structure& chain, const Structure& fixed) {
+  const int64_t np = (fixed.N | 1) + 0, cp = (int64_t(chain.C) | 1);
+  return size_t(lazy_tile_batch()) * size_t(np + cp) * 4 <= size_t(lazy_lds_limit()) && fixed.N > 0 && chain.C > 0;
+}
+
+struct LazyKey {
+  Structure* fs;
+  Weights* fw;
+  int T, C, side;
+  bool operator<(const LazyKey& o) const {
+    return std::tie(fs, fw, T, C, side) < std::tie(o.fs, o.fw, o.T, o.C, o.side);
+  }
+};
+
+// forward pass (log or tropical) of every lazy product in `gs`; returns one state per
+// group and, through `slot`, (group, member) of each input
+std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs, int mode,
+                                                          std::vector<std::pair<int, int>>& slot) {
+  Runtime& rt = Runtime::get();
+  std::map<LazyKey, int> index;
+  std::vector<std::shared_ptr<LazyGroupState>> groups;
+  slot.resize(gs.size());
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  for (size_t i = 0; i < gs.size(); ++i) {
+    LazyProduct& lp = *gs[i].s->lazy;
+    LazyKey k{lp.fixed.s.get(), lp.fixed.w.get(), lp.chain.s->M, lp.chain.s->C, lp.chain_side};
+    auto it = index.find(k);
+    if (it == index.end()) {
+      it = index.emplace(k, int(groups.size())).first;
+      auto st = std::make_shared<LazyGroupState>();
+      st->fixed = lp.fixed;
+      groups.push_back(st);
+      ss.push_back(lp.fixed.s.get());
+      ws.push_back(lp.fixed.w.get());
+    }
+    LazyGroupState& st = *groups[it->second];
+    slot[i] = {it->second, int(st.chains.size())};
+    st.chains.push_back(lp.chain);
+    ws.push_back(lp.chain.w.get());
+  }
+  ensure_device_batch(ss);
+  ensure_weights_device_batch(ws);
+  for (auto& gp : groups) {
+    LazyGroupState& st = *gp;
+    Structure& fs = *st.fixed.s;
+    if (!fs.dview.out_rec && fs.A > 0) {  // device-built G: packed records on demand
+      fs.rec_mem = rt.alloc(32 * size_t(fs.A));
+      gtnx_i4* orec = fs.rec_mem->as<gtnx_i4>();
+      gtnx_i4* irec = orec + fs.A;
+      launch_build_records(fs.dview, orec, irec, rt.stream());
+      fs.dview.out_rec = orec;
+      fs.dview.in_rec = irec;
+    }
+    const Structure& cs = *st.chains[0].s;
+    const int nb = int(st.chains.size());
+    const int T = cs.M, C = cs.C, N = int(fs.N);
+    LazyGroup& v = st.view;
+    v.g = device_view(st.fixed);
+    v.T = T;
+    v.C = C;
+    v.N = N;
+    v.nb = nb;
+    v.Npad = N | 1;
+    v.Cpad = C | 1;
+    // host facts about G: shared in-arc label per node, widest in-row
+    fs.ensure_host();
+    fs.ensure_csr();
+    const size_t plane = size_t(nb) * size_t(N);
+    size_t bytes = 0;
+    auto add = [&](size_t b) {
+      size_t o = bytes;
+      bytes = align_up(bytes + b, 256);
+      return o;
+    };
+    const size_t o_alpha = add(4 * plane * size_t(T + 1));
+    const size_t o_bp = mode == SD_LOG ? 0 : add(4 * plane * size_t(T + 1));
+    const size_t o_score = add(4 * size_t(nb));
+    const size_t o_best = add(4 * size_t(nb));
+    const size_t o_em = add(8 * size_t(nb));
+    const size_t o_lin = add(16 * size_t(fs.A));
+    const size_t o_lout = add(16 * size_t(fs.A));
+    st.arena = rt.alloc(bytes);
+    v.lrec_in = st.arena->as<gtnx_i4>(o_lin);
+    v.lrec_out = st.arena->as<gtnx_i4>(o_lout);
+    v.alpha = st.arena->as<float>(o_alpha);
+    v.bp = mode == SD_LOG ? nullptr : st.arena->as<int>(o_bp);
+    v.score = st.arena->as<float>(o_score);
+    v.best = st.arena->as<int>(o_best);
+    std::vector<const float*> em(nb);
+    for (int b = 0; b < nb; ++b) em[b] = st.chains[b].w->dev;
+    PinnedMemP pin = rt.alloc_pinned(8 * size_t(nb));
+    std::memcpy(pin->ptr, em.data(), 8 * size_t(nb));
+    rt.h2d(st.arena->as<char>(o_em), pin->ptr, 8 * size_t(nb));
+    v.em = reinterpret_cast<const float* const*>(st.arena->as<char>(o_em));
+  }
+  // chain_first comes from the products themselves (same for a whole group by key)
+  for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
+  for (auto& gp : groups) {
+    LazyGroupState& st = *gp;
+    GTNX_PROF(mode == SD_LOG ? "lazy_forward_score" : "lazy_viterbi", 0.0);
+    launch_lazy_pack(st.view, const_cast<gtnx_i4*>(st.view.lrec_in), const_cast<gtnx_i4*>(st.view.lrec_out), rt.stream());
+    launch_lazy_init(st.view, 0, rt.stream());
+    for (int t = 0; t < st.view.T; ++t) launch_lazy_step(st.view, t, mode, 0, rt.stream());
+    launch_lazy_final(st.view, mode, rt.stream());
+  }
+  return groups;
+}
+
+// shared in-arc label of every node of G (matched side), or empty if some node's differ
+std::vector<int> lazy_node_labels(Structure& fs, bool chain_first, int C, int* max_in_deg) {
+  std::vector<int> lab(size_t(fs.N), -1);
+  bool moore = true;
+  int md = 0;
+  for (int64_t n = 0; n < fs.N; ++n) {
+    md = std::max(md, fs.in_off[n + 1] - fs.in_off[n]);
+    for (int k = fs.in_off[n]; k < fs.in_off[n + 1]; ++k) {
+      const int a = fs.in_list[k];
+      const int l = chain_first ? fs.il[a] : fs.ol[a];
+      if (l < 0 || l >= C) continue;
+      if (lab[n] == -1) lab[n] = l;
+      else if (lab[n] != l) moore = false;
+    }
+  }
+  *max_in_deg = md;
+  if (!moore) lab.clear();
+  return lab;
+}
+
+struct LazySdOp : OpRecord {
+  int mode;
+  std::vector<std::shared_ptr<LazyGroupState>> groups;
+  std::vector<std::pair<int, int>> slot;  // output index -> (group, member)
+
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    GradSink sink;
+    // members by group
+    std::vector<std::vector<Member*>> by_group(groups.size());
+    for (auto& m : ms) by_group[slot[m.idx].first].push_back(&m);
+    DevMemP zero = rt.alloc_zero(256);
+    for (size_t gi = 0; gi < groups.size(); ++gi) {
+      if (by_group[gi].empty()) continue;
+      LazyGroupState& st = *groups[gi];
+      LazyGroup v = st.view;
+      const int nb = v.nb, T = v.T, C = v.C, N = v.N;
+      const size_t plane = size_t(nb) * size_t(N);
+      Graph& fixed = st.fixed;
+      // per-member pointers: upstream delta, chain gradient buffer
+      std::vector<const float*> delta(nb, zero->as<float>());
+      std::vector<float*> gem(nb, nullptr);
+      size_t gbytes = 0;
+      std::vector<size_t> goff(nb, 0);
+      std::vector<Member*> of_slot(nb, nullptr);
+      for (Member* m : by_group[gi]) of_slot[slot[m->idx].second] = m;
+      for (int b = 0; b < nb; ++b) {
+        if (!of_slot[b]) continue;
+        delta[b] = grad_dev_ptr(of_slot[b]->out);
+        if (st.chains[b].calc_grad()) {
+          goff[b] = gbytes;
+          gbytes = align_up(gbytes + 4 * size_t(T) * size_t(C), 256);
+        }
+      }
+      const bool want_fixed = fixed.calc_grad();
+      const size_t o_fixed = gbytes;
+      if (want_fixed) gbytes = align_up(gbytes + 4 * size_t(fixed.num_arcs()), 256);
+      DevMemP gmem = rt.alloc_zero(gbytes ? gbytes : 1);
+      for (int b = 0; b < nb; ++b)
+        if (of_slot[b] && st.chains[b].calc_grad()) gem[b] = gmem->as<float>(goff[b]);
+      v.grad_fixed = want_fixed ? gmem->as<float>(o_fixed) : nullptr;
+      // pointer tables
+      DevMemP tabs = rt.alloc(16 * size_t(nb));
+      PinnedMemP pin = rt.alloc_pinned(16 * size_t(nb));
+      std::memcpy(pin->as<char>(), delta.data(), 8 * size_t(nb));
+      std::memcpy(pin->as<char>(8 * size_t(nb)), gem.data(), 8 * size_t(nb));
+      rt.h2d(tabs->ptr, pin->ptr, 16 * size_t(nb));
+      v.delta = reinterpret_cast<const float* const*>(tabs->as<char>());
+      v.grad_em = reinterpret_cast<float* const*>(tabs->as<char>(8 * size_t(nb)));
+      if (mode == SD_LOG) {
+        DevMemP beta = rt.alloc(4 * plane * size_t(T + 1));
+        v.beta = beta->as<float>();
+        GTNX_PROF("lazy_forward_score_grad", 0.0);
+        launch_lazy_init(v, 1, rt.stream());
+        for (int t = T - 1; t >= 0; --t) launch_lazy_step(v, t, SD_LOG, 1, rt.stream());
+        if (!st.labels && st.max_in_deg == 0) {
+          fixed.s->ensure_host();
+          fixed.s->ensure_csr();
+          std::vector<int> lab = lazy_node_labels(*fixed.s, v.chain_first != 0, C, &st.max_in_deg);
+          if (!lab.empty()) {
+            st.labels = upload_vec(lab);
+            st.node_label = st.labels->as<int>();
+          }
+        }
+        launch_lazy_chain_grad(v, st.node_label, rt.stream());
+        if (want_fixed) {
+          const size_t lds = lazy_step_lds_bytes(v) + 4 * size_t(lazy_tile_nodes()) * size_t(st.max_in_deg);
+          if (lds > size_t(lazy_lds_limit()))
+            throw_runtime("[gtn::backward] lazy product: graph too wide for the arc-gradient kernel");
+          launch_lazy_fixed_grad(v, st.max_in_deg, rt.stream());
+        }
+        (void)beta;  // released after the launches are queued (stream-ordered pool)
+      } else {
+        // viterbiScore (shortest.cpp:65-74, tropical): one-hot along the best path
+        const size_t pbytes = size_t(nb) * size_t(T) * 16 + 4 * size_t(nb);
+        DevMemP pm = rt.alloc(pbytes ? pbytes : 1);
+        int* parc = pm->as<int>();
+        int* pil = parc + size_t(nb) * T;
+        int* pol = pil + size_t(nb) * T;
+        float* pw = reinterpret_cast<float*>(pol + size_t(nb) * T);
+        int* plen = reinterpret_cast<int*>(pw + size_t(nb) * T);
+        launch_lazy_path(v, parc, pil, pol, pw, plen, rt.stream());
+        std::vector<int> lens(nb);
+        rt.d2h_sync(lens.data(), plen, 4 * size_t(nb));
+        for (int b = 0; b < nb; ++b) {
+          if (!of_slot[b] || lens[b] <= 0) continue;
+          LazyPathGrad a{};
+          a.delta = delta[b];
+          a.delta_stride = 0;
+          a.path_arc = parc + size_t(b) * T;
+          a.il = pil + size_t(b) * T;
+          a.ol = pol + size_t(b) * T;
+          a.len = lens[b];
+          a.C = C;
+          a.chain_first = v.chain_first;
+          a.grad_chain = gem[b];
+          a.grad_fixed = v.grad_fixed;
+          launch_lazy_path_grad(a, rt.stream());
+        }
+      }
+      for (int b = 0; b < nb; ++b) {
+        if (!of_slot[b]) continue;
+        if (gem[b]) sink.add(st.chains[b], gmem, gem[b]);
+        of_slot[b]->out.g->inputs[0].g->grad_propagated = true;
+      }
+      if (want_fixed) sink.add(fixed, gmem, v.grad_fixed);
+    }
+    sink.flush();
+  }
+};
+
+std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+  auto op = std::make_shared<LazySdOp>();
+  op->mode = tropical ? SD_TROPICAL : SD_LOG;
+  op->seq = g_seq++;
+  op->groups = lazy_forward(gs, op->mode, op->slot);
+  std::vector<Graph> outs;
+  for (size_t i = 0; i < gs.size(); ++i) {
+    LazyGroupState& st = *op->groups[op->slot[i].first];
+    Graph out = make_output(op, int(i), {gs[i]});
+    init_scalar_structure(out);
+    set_dev_weights(out, st.arena, st.view.score + op->slot[i].second, 1);
+    outs.push_back(std::move(out));
+  }
+  return outs;
+}
+
+struct LazyPathOp : OpRecord {
+  struct Saved {
+    std::vector<int> arcs, il, ol;  // first-arc-first
+    int C = 0, chain_first = 0;
+  };
+  std::vector<Saved> saved;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    GradSink sink;
+    for (auto& m : ms) {
+      const Saved& sv = saved[m.idx];
+      Graph& comp = m.out.g->inputs[0];
+      comp.g->grad_propagated = true;
+      const int len = int(sv.arcs.size());
+      if (len == 0 || comp.g->inputs.size() != 2) continue;
+      Graph& chain = comp.g->inputs[sv.chain_first ? 0 : 1];
+      Graph& fixed = comp.g->inputs[sv.chain_first ? 1 : 0];
+      std::vector<int> packed;
+      packed.insert(packed.end(), sv.arcs.begin(), sv.arcs.end());
+      packed.insert(packed.end(), sv.il.begin(), sv.il.end());
+      packed.insert(packed.end(), sv.ol.begin(), sv.ol.end());
+      DevMemP dp = upload_vec(packed);
+      size_t bytes = 0;
+      const size_t oc = bytes;
+      if (chain.calc_grad()) bytes = align_up(bytes + 4 * size_t(chain.num_arcs()), 256);
+      const size_t of = bytes;
+      if (fixed.calc_grad()) bytes = align_up(bytes + 4 * size_t(fixed.num_arcs()), 256);
+      DevMemP gm = rt.alloc_zero(bytes ? bytes : 1);
+      LazyPathGrad a{};
+      a.delta = grad_dev_ptr(m.out);
+      a.delta_stride = 1;
+      a.path_arc = dp->as<int>();
+      a.il = a.path_arc + len;
+      a.ol = a.il + len;
+      a.len = len;
+      a.C = sv.C;
+      a.chain_first = sv.chain_first;
+      a.grad_chain = chain.calc_grad() ? gm->as<float>(oc) : nullptr;
+      a.grad_fixed = fixed.calc_grad() ? gm->as<float>(of) : nullptr;
+      launch_lazy_path_grad(a, rt.stream());
+      if (a.grad_chain) sink.add(chain, gm, a.grad_chain);
+      if (a.grad_fixed) sink.add(fixed, gm, a.grad_fixed);
+    }
+    sink.flush();
+  }
+};
+
+std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
+  Runtime& rt = Runtime::get();
+  std::vector<std::pair<int, int>> slot;
+  auto groups = lazy_forward(gs, SD_TROPICAL, slot);
+  auto op = std::make_shared<LazyPathOp>();
+  op->seq = g_seq++;
+  op->saved.resize(gs.size());
+  std::vector<Graph> outs(gs.size(), Graph(false));
+  for (size_t gi = 0; gi < groups.size(); ++gi) {
+    LazyGroupState& st = *groups[gi];
+    const LazyGroup& v = st.view;
+    const size_t nT = size_t(v.nb) * size_t(v.T);
+    const size_t pbytes = nT * 16 + 4 * size_t(v.nb);
+    DevMemP pm = rt.alloc(pbytes ? pbytes : 1);
+    int* parc = pm->as<int>();
+    int* pil = parc + nT;
+    int* pol = pil + nT;
+    float* pw = reinterpret_cast<float*>(pol + nT);
+    int* plen = reinterpret_cast<int*>(pw + nT);
+    launch_lazy_path(v, parc, pil, pol, pw, plen, rt.stream());
+    std::vector<char> host(pbytes);
+    rt.d2h_sync(host.data(), pm->ptr, pbytes);
+    const int* harc = reinterpret_cast<const int*>(host.data());
+    const int* hil = harc + nT;
+    const int* hol = hil + nT;
+    const float* hw = reinterpret_cast<const float*>(hol + nT);
+    const int* hlen = reinterpret_cast<const int*>(hw + nT);
+    for (size_t i = 0; i < gs.size(); ++i) {
+      if (slot[i].first != int(gi)) continue;
+      const int b = slot[i].second;
+      const int len = hlen[b];
+      Graph out = make_output(op, int(i), {gs[i]});
+      // shortest.cpp:248-260; no accepting path -> the empty graph
+      if (len >= 0) {
+        out.add_node(true, len == 0);
+        for (int k = 0; k < len; ++k) {
+          const size_t o = size_t(b) * size_t(v.T) + size_t(k);
+          out.add_node(false, k == len - 1);
+          out.add_arc(k, k + 1, hil[o], hol[o], hw[o]);
+        }
+        LazyPathOp::Saved& sv = op->saved[i];
+        const size_t o0 = size_t(b) * size_t(v.T);
+        sv.arcs.assign(harc + o0, harc + o0 + len);
+        sv.il.assign(hil + o0, hil + o0 + len);
+        sv.ol.assign(hol + o0, hol + o0 + len);
+      }
+      op->saved[i].C = v.C;
+      op->saved[i].chain_first = v.chain_first;
+      outs[i] = std::move(out);
+    }
+  }
+  return outs;
+}
+
+} // namespace
+
+// turn a symbolic product into the ordinary materialised one, in place
+std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect, bool allow_lazy);
+void realize(Graph& g) {
+  if (!g.s || !g.s->lazy) return;
+  LazyProduct lp = *g.s->lazy;
+  g.s->lazy.reset();
+  std::vector<Graph> av{lp.chain_side == 1 ? lp.chain : lp.fixed}, bv{lp.chain_side == 1 ? lp.fixed : lp.chain};
+  std::vector<Graph> r = op_compose_impl(av, bv, lp.intersect, false);
+  Graph& real = r[0];
+  Structure& d = *g.s;
+  Structure& o = *real.s;
+  d.kind = o.kind;
+  d.N = o.N;
+  d.A = o.A;
+  d.M = o.M;
+  d.C = o.C;
+  d.ilabel_sorted = o.ilabel_sorted;
+  d.olabel_sorted = o.olabel_sorted;
+  d.host_valid = o.host_valid;
+  d.src = std::move(o.src);
+  d.dst = std::move(o.dst);
+  d.il = std::move(o.il);
+  d.ol = std::move(o.ol);
+  d.nflags = std::move(o.nflags);
+  d.start = std::move(o.start);
+  d.accept = std::move(o.accept);
+  d.csr_valid = false;
+  d.dev_valid = o.dev_valid;
+  d.dev_mem = o.dev_mem;
+  d.dview = o.dview;
+  d.rec_mem = o.rec_mem;
+  d.sched = o.sched;
+  Weights& dw = *g.w;
+  Weights& ow = *real.w;
+  dw.n = ow.n;
+  dw.host = std::move(ow.host);
+  dw.host_valid = ow.host_valid;
+  dw.host_escaped = false;
+  dw.version++;
+  dw.dev_mem = ow.dev_mem;
+  dw.dev = ow.dev;
+  dw.dev_valid = ow.dev_valid;
+  if (d.sched && d.sched->in_w_of == real.w.get()) {
+    d.sched->in_w_of = g.w.get();
+    d.sched->in_w_version = dw.version;
+  }
+  if (g.g->op) {  // the tape now runs through the real compose record
+    g.g->op = real.g->op;
+    g.g->op_idx = real.g->op_idx;
+  }
+}
+
 // ======================================================================
 // user-defined ops (Graph(GradFunc, inputs), graph.h:76-78)
 // ======================================================================
@@ -1223,6 +1756,7 @@ void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(voi
 void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
   GTNX_HOST_T("backward.total");
   Runtime& rt = Runtime::get();
+  for (auto& r : roots) realize(r);
   // ---- seed (autograd.cpp:57-67)
   if (grad) {
     for (auto& r : roots) {
@@ -1266,7 +1800,9 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
   for (auto& kv : tape) {
     auto& members = kv.second.second;
     std::sort(members.begin(), members.end(), [](const Member& a, const Member& b) { return a.idx < b.idx; });
-    for (auto& m : members) (void)m.out.grad();  // throws "Gradient not calculated yet." like autograd.cpp:46
+    for (auto& m : members)
+      if (!(m.out.s->lazy && m.out.g->grad_propagated))
+        (void)m.out.grad();  // throws "Gradient not calculated yet." like autograd.cpp:46
     kv.second.first->backward(members);
     if (!retain) {
       // autograd.cpp:47-50: the tape (inputs, saved forward state) goes away with

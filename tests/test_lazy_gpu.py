@@ -1,0 +1,137 @@
+"""Lazy (never materialised) chain products -- lazy.hip -- against the materialised
+path (itself pinned to the reference/oracle by test_parity_gpu.py) and the oracle:
+scores within 1e-4 relative, best-path labels exact, gradients at the tolerance
+test_parity_gpu.py documents."""
+import os
+
+import numpy as np
+import pytest
+
+import graphgen as gg
+from oracle_lib import OGraph, ctc_loss
+from test_parity_gpu import asg_transitions
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-4
+
+
+class lazy_mode:
+    def __init__(self, v):
+        self.v = v
+
+    def __enter__(self):
+        self.old = os.environ.get("GTNX_LAZY_COMPOSE")
+        os.environ["GTNX_LAZY_COMPOSE"] = self.v
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("GTNX_LAZY_COMPOSE", None)
+        else:
+            os.environ["GTNX_LAZY_COMPOSE"] = self.old
+
+
+def asg_batch(gtn, B, T, N, seed):
+    rng = np.random.default_rng(seed)
+    em = rng.normal(0, 1, (B, T, N)).astype(np.float32)
+    tw = rng.normal(0, 1, N * N + N).astype(np.float32)
+    trans = asg_transitions(gtn, N, tw[N:])
+    w = trans.weights_to_numpy()
+    w[:N] = tw[:N]
+    trans.set_weights(w)
+    ems = []
+    for b in range(B):
+        e = gtn.linear_graph(T, N)
+        e.set_weights(em[b])
+        ems.append(e)
+    return em, ems, trans
+
+
+@pytest.mark.parametrize("B,T,N", [(1, 7, 4), (5, 30, 12), (19, 40, 35)])
+def test_lazy_asg_forward_viterbi_grads_match_materialised(gtn, B, T, N):
+    res = {}
+    for mode in ("0", "1"):
+        with lazy_mode(mode):
+            em, ems, trans = asg_batch(gtn, B, T, N, 11)
+            comp = gtn.compose(ems, [trans])
+            fs = gtn.forward_score(comp)
+            vs = gtn.viterbi_score(comp)
+            paths = gtn.viterbi_path(comp)
+            gtn.backward(fs)
+            res[mode] = dict(
+                fs=gtn.items(fs), vs=gtn.items(vs), labels=[p.labels_to_list() for p in paths],
+                pw=[p.weights_to_numpy() for p in paths],
+                ge=[e.grad().weights_to_numpy() for e in ems], gt=trans.grad().weights_to_numpy())
+    a, b = res["0"], res["1"]
+    np.testing.assert_allclose(b["fs"], a["fs"], rtol=RTOL)
+    np.testing.assert_allclose(b["vs"], a["vs"], rtol=1e-6)
+    assert b["labels"] == a["labels"]
+    for x, y in zip(b["pw"], a["pw"]):
+        np.testing.assert_allclose(x, y, rtol=1e-6)
+    for x, y in zip(b["ge"], a["ge"]):
+        np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(b["gt"], a["gt"], rtol=1e-3, atol=1e-4)
+
+
+def test_lazy_viterbi_grads_match_materialised(gtn):
+    B, T, N = 4, 12, 6
+    res = {}
+    for mode in ("0", "1"):
+        with lazy_mode(mode):
+            em, ems, trans = asg_batch(gtn, B, T, N, 5)
+            comp = gtn.compose(ems, [trans])
+            vs = gtn.viterbi_score(comp)
+            gtn.backward(vs)
+            g1 = [e.grad().weights_to_numpy() for e in ems]
+            gt1 = trans.grad().weights_to_numpy()
+            em, ems2, trans2 = asg_batch(gtn, B, T, N, 5)
+            paths = gtn.viterbi_path(gtn.compose(ems2, [trans2]))
+            gtn.backward(paths)
+            res[mode] = (g1, gt1, [e.grad().weights_to_numpy() for e in ems2], trans2.grad().weights_to_numpy())
+    for x, y in zip(res["1"][0], res["0"][0]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(res["1"][1], res["0"][1])
+    for x, y in zip(res["1"][2], res["0"][2]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(res["1"][3], res["0"][3])
+
+
+@pytest.mark.parametrize("B,T,C,U", [(3, 60, 10, 7)])
+def test_lazy_ctc_vs_oracle(gtn, B, T, C, U):
+    """per-utterance target graphs (groups of one), chain as the SECOND argument"""
+    import torch
+    em, tg = gg.ctc_inputs(21, B, T, C, U)
+    with lazy_mode("1"):
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+        comp = gtn.intersect(ctcs, ems)
+        loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))
+        gtn.backward(loss)
+        got = gtn.items(loss)
+        # looking inside the product builds it for real
+        oc = OGraph.from_dict(gg.ctc_target_graph(tg[0].tolist())).compose(OGraph.linear(T, C, em[0]), "intersect")
+        assert (comp[0].num_nodes(), comp[0].num_arcs()) == (oc.N, oc.A)
+    for b in range(B):
+        want, wgrad = ctc_loss(em[b], tg[b])
+        assert got[b] == pytest.approx(want, rel=RTOL)
+        z = abs(float(OGraph.linear(T, C, em[b]).shortest_distance()))
+        np.testing.assert_allclose(ems[b].grad().weights_to_numpy().reshape(T, C), wgrad,
+                                   rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)
+        tgt = gg.ctc_target_graph(tg[b].tolist())
+        o = OGraph.from_dict(tgt).compose(OGraph.linear(T, C, em[b]), "intersect")
+        g1, _ = o.compose_grad(o.shortest_distance_grad(), len(tgt["src"]), T * C)
+        np.testing.assert_allclose(ctcs[b].grad().weights_to_numpy(), -np.asarray(g1), rtol=1e-3, atol=1e-4)
+
+
+def test_lazy_no_accepting_path(gtn):
+    """a target longer than the emissions: the trimmed product is empty"""
+    T, C = 3, 5
+    with lazy_mode("1"):
+        e = gtn.linear_graph(T, C)
+        e.set_weights(np.zeros(T * C, np.float32))
+        ctc = gg.to_api(gtn, gg.ctc_target_graph([1, 2, 3, 4, 1, 2]))
+        comp = gtn.intersect(ctc, e)
+        assert gtn.forward_score(comp).item() == -np.inf
+        assert gtn.viterbi_score(comp).item() == -np.inf
+        p = gtn.viterbi_path(comp)
+        assert (p.num_nodes(), p.num_arcs()) == (0, 0)
+        assert comp.num_arcs() == 0

@@ -1,0 +1,88 @@
+"""BASELINE config C4 at full size on one MI355X: ASG with a dense transitions graph,
+B=512, T=1000, C=512 (262 M product arcs per utterance -- never built).
+Times (a) Viterbi decode = viterbiPath(compose(emissions, transitions)) and (b) the
+full-connect term forwardScore(compose(emissions, transitions)) forward + backward
+(gradients of all emissions and of the shared transitions).  Prints one JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def transitions(gtn, N, w):
+    g = gtn.Graph()
+    n = np.arange(N)
+    g.add_nodes(np.array([1] + [0] * N, np.uint8), np.array([0] + [1] * N, np.uint8))
+    src = np.concatenate([np.zeros(N, np.int32), np.tile(n + 1, N).astype(np.int32)])
+    dst = np.concatenate([n + 1, np.repeat(n + 1, N)]).astype(np.int32)
+    lab = np.concatenate([n, np.repeat(n, N)]).astype(np.int32)
+    g.add_arcs(src, dst, lab, lab, w.astype(np.float32))
+    return g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=512)
+    ap.add_argument("--T", type=int, default=1000)
+    ap.add_argument("--C", type=int, default=512)
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    import torch
+    import gtn_amd as gtn
+    B, T, C = args.B, args.T, args.C
+    torch.manual_seed(0)
+    em = (torch.rand(B, T, C, device="cuda") * 10 - 5).contiguous()
+    tw = np.random.default_rng(0).random(C * C + C).astype(np.float32)
+    out = {"workload": f"C4 ASG dense transitions B={B} T={T} C={C}", "product_arcs_per_utterance": C * C * (T - 1) + C}
+
+    def sync():
+        gtn.synchronize()
+        torch.cuda.synchronize()
+
+    # (a) decode
+    times = []
+    for _ in range(args.steps):
+        trans = transitions(gtn, C, tw)
+        ems = gtn.linear_graph_n(B, T, C, em)
+        sync()
+        t0 = time.perf_counter()
+        paths = gtn.viterbi_path(gtn.compose(ems, [trans]))
+        sync()
+        times.append(time.perf_counter() - t0)
+    out["decode_ms_per_batch"] = min(times) * 1e3
+    out["decode_utt_per_s"] = B / min(times)
+    out["decode_path0_head"] = paths[0].labels_to_list()[:8]
+    # (b) full-connect score forward + backward
+    times = []
+    for _ in range(args.steps):
+        trans = transitions(gtn, C, tw)
+        ems = gtn.linear_graph_n(B, T, C, em)
+        sync()
+        t0 = time.perf_counter()
+        fcc = gtn.forward_score(gtn.compose(ems, [trans]))
+        sync()
+        t1 = time.perf_counter()
+        gtn.backward(fcc)
+        sync()
+        t2 = time.perf_counter()
+        times.append((t1 - t0, t2 - t1))
+    f, b = min(x[0] for x in times), min(x[1] for x in times)
+    out["fcc_forward_ms"] = f * 1e3
+    out["fcc_backward_ms"] = b * 1e3
+    out["fcc_fwd_bwd_utt_per_s"] = B / (f + b)
+    out["fcc_score0"] = float(gtn.items(fcc)[0])
+    g = trans.grad().weights_to_numpy()
+    out["transitions_grad_sum"] = float(g.sum())  # = B*T: one arc per step per utterance in expectation
+    out["kernels"] = {n: gtn.prof_get(n) for n in gtn.prof_names() if n.startswith("lazy")}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -135,3 +135,19 @@ def test_lazy_no_accepting_path(gtn):
         p = gtn.viterbi_path(comp)
         assert (p.num_nodes(), p.num_arcs()) == (0, 0)
         assert comp.num_arcs() == 0
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_reference_asg_known_answers_under_lazy_mode(gtn, batched):
+    """test/criterion_test.cpp:182-345 (ASG losses, emission and shared-transition
+    gradients, Viterbi labels) with every eligible composition kept symbolic"""
+    import test_parity_gpu as tp
+    with lazy_mode("1"):
+        tp.test_asg_criterion(gtn, batched)
+        tp.test_asg_viterbi_path(gtn)
+
+
+def test_reference_ctc_known_answers_under_lazy_mode(gtn):
+    import test_parity_gpu as tp
+    with lazy_mode("1"):
+        tp.test_ctc_criterion_known_answers(gtn)

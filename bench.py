@@ -254,7 +254,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE config C3: compose(ctc_target, emissions)+forwardScore CTC loss "
+            "config": {"workload": f"{'BASELINE config C3' if (B, T, Cn, U) == (512, 1000, 256, 100) else 'CTC'}: compose(ctc_target, emissions)+forwardScore CTC loss "
                                    f"fwd+bwd, T={T}, C={Cn}, U={U}, batch={B} per GPU",
                        "global_batch": world * B, "composed_nodes": n_nodes, "composed_arcs": n_arcs,
                        "parallelism": f"dp{world} (utterance sharding, all_gather of losses)",

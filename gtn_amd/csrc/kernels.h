@@ -165,6 +165,7 @@ struct LinArgs {
   GTNX_G float* partial;   // [splits]
   const GTNX_G float* delta;
   GTNX_G float* grad;      // [M][C]
+  int accumulate;          // backward: grad += (the graph already holds a gradient) instead of grad =
 };
 void launch_linear_forward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
 void launch_linear_backward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void linear_backward_kernel(const LinArgs* 
         g = (c == am) ? 1.0f : 0.0f;
       else
         g = expf(row[c] - red);  // exp(score[t] + w - score[t+1])
-      grow[c] = g * delta;
+      grow[c] = a.accumulate ? grow[c] + g * delta : g * delta;
     }
   }
 }

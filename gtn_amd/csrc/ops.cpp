@@ -288,6 +288,7 @@ struct LinearSdOp : OpRecord {
     size_t off = 0;
     int maxM = 0;
     double bytes = 0;
+    std::unordered_set<GradState*> seen_in;
     for (int i = 0; i < n; ++i) {
       Graph& in = ms[i].out.g->inputs[0];
       LinArgs& a = args[i];
@@ -297,6 +298,23 @@ struct LinearSdOp : OpRecord {
       a.out_score = nullptr;
       a.partial = nullptr;
       a.delta = grad_dev_ptr(ms[i].out);
+      a.accumulate = 0;
+      // a gradient that already lives on the device is updated in place (one pass
+      // instead of write + read-modify-write); addGrad semantics, graph.cpp:108-129
+      const bool first_use = seen_in.insert(in.g.get()).second;
+      if (first_use && in.calc_grad() && in.is_grad_available()) {
+        Weights& gw = *in.g->grad->w;
+        if (gw.dev_valid && !gw.host_escaped && gw.n == in.num_arcs()) {
+          a.grad = gw.dev;
+          a.accumulate = 1;
+          gw.host_valid = false;
+          gw.version++;
+          off += 0;
+          maxM = std::max(maxM, a.M);
+          bytes += 12.0 * double(in.num_arcs());
+          continue;
+        }
+      }
       a.grad = grads->as<float>() + off;
       sink.add(in, grads, a.grad);
       off += size_t(in.num_arcs());
@@ -498,6 +516,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       a.partial = partial + size_t(k) * 8;
       a.delta = nullptr;
       a.grad = nullptr;
+      a.accumulate = 0;
       maxM = std::max(maxM, a.M);
       bytes += 4.0 * double(g.num_arcs());
       Graph out = make_output(op, k, {g});

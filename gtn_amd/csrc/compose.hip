@@ -344,6 +344,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   // a constant filter, every later level is the previous one shifted by one time
   // step -- ids + W, arc ids + Aw, chain arc + C -- and is emitted from registers
   // for all remaining stationary t at once instead of one BFS level at a time.
+  const bool skip = FAST && a.skip != 0;  // derivable arrays are left out (see ComposeArgs::skip)
   constexpr bool REP = FAST && (L1 != L2);
   const bool rep_ok = REP && ((L2 ? a.g1.flags : a.g2.flags) & GF_EPS_FREE);
   const int tshift = L2 ? N1 : 1;           // pair-id step per time step
@@ -700,9 +701,11 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             const int i = c.i[m], j = c.j[m];
             const int il = c.il[m], ol = c.ol[m];
             const float w = wpre[m];
-            a.src[ai] = node;
-            a.il[ai] = il;
-            a.ol[ai] = ol;
+            if (!skip) {
+              a.src[ai] = node;
+              a.il[ai] = il;
+              a.ol[ai] = ol;
+            }
             a.w[ai] = w;
             a.gi1[ai] = i;
             a.gi2[ai] = j;
@@ -911,13 +914,14 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           incnt[nidx] = 0;
         }
         from_regs = single_chunk && fast_level;
+        if (skip && !from_regs) sh_flag[1] = 2;  // the re-read path needs src[]: general variant
         wg_barrier(lds_state && from_regs);  // the re-read path needs this level's stores
         if (from_regs) {
 #pragma unroll
           for (int m = 0; m < KC; ++m) {
             if (my_ai[m] >= 0) {
               const int pos = atomicAdd(&incur[my_dst[m] - hi], 1);
-              a.in_list[pos] = my_ai[m];
+              if (!skip) a.in_list[pos] = my_ai[m];
               a.in_src[pos] = lo + tid;
               a.in_w[pos] = my_w[m];
               if (REP) my_pos[m] = pos;
@@ -1022,14 +1026,16 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
                 for (int x = 0; x < PE; ++x) {
                   if (e_on[x]) {
                     const int ai = na_level + da + tid + x * kBlock;
-                    a.src[ai] = lo + (e_sd[x] & 0xffff) + dn;
+                    if (!skip) {
+                      a.src[ai] = lo + (e_sd[x] & 0xffff) + dn;
+                      a.il[ai] = e_il[x];
+                      a.ol[ai] = e_ol[x];
+                      a.in_list[ai] = na_level + da + p_r[x];
+                    }
                     a.dst[ai] = hi + (e_sd[x] >> 16) + dn;
-                    a.il[ai] = e_il[x];
-                    a.ol[ai] = e_ol[x];
                     a.w[ai] = e_wf[x] + we[u][x];
                     a.gi1[ai] = L2 ? e_gf[x] : e_ca[x] + dc;
                     a.gi2[ai] = L2 ? e_ca[x] + dc : e_gf[x];
-                    a.in_list[ai] = na_level + da + p_r[x];
                     a.in_src[ai] = lo + (p_sd[x] & 0xffff) + dn;
                     a.in_w[ai] = p_wf[x] + wp[u][x];
                   }
@@ -1062,14 +1068,16 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
                 if (my_ai[m] >= 0) {
                   const int ai = my_ai[m] + da, pos = my_pos[m] + da;
                   const float w = wfix[m] + wk[u][m];
-                  a.src[ai] = lo + tid + dn;
+                  if (!skip) {
+                    a.src[ai] = lo + tid + dn;
+                    a.il[ai] = my_il[m];
+                    a.ol[ai] = my_ol[m];
+                    a.in_list[pos] = ai;
+                  }
                   a.dst[ai] = my_dst[m] + dn;
-                  a.il[ai] = my_il[m];
-                  a.ol[ai] = my_ol[m];
                   a.w[ai] = w;
                   a.gi1[ai] = L2 ? my_i[m] : my_i[m] + dc;
                   a.gi2[ai] = L2 ? my_j[m] + dc : my_j[m];
-                  a.in_list[pos] = ai;
                   a.in_src[pos] = lo + tid + dn;
                   a.in_w[pos] = w;
                 }
@@ -1117,6 +1125,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     o.max_width = max_width;
     o.max_level_arcs = max_level_arcs;
     o.rep_levels = rep_levels;
+    o.skipped = skip ? 1 : 0;
     o.t_b = int(tk1 - tk0);
     o.t_f = int(wall_clock64() - tk1);
     o.t_rep = int(tk_rep);
@@ -1391,6 +1400,32 @@ void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int
   hipLaunchKernelGGL(tr_chunk_scan_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_args, g_sums, n, chunks);
   hipLaunchKernelGGL(tr_offsets_kernel, dim3(chunks, n), dim3(kBlock), 0, st, d_args, (const int3*)g_sums, chunks);
   hipLaunchKernelGGL(tr_scatter_kernel, dim3(grid_x(maxAcap, 2048), n), dim3(kBlock), 0, st, d_args);
+}
+
+namespace {
+// arrays compose_kernel left out (ComposeArgs::skip), derived from what it did write
+__global__ void compose_fill_src_kernel(ComposeFillArgs a) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= a.N) return;
+  for (int k = a.out_off[n]; k < a.out_off[n + 1]; ++k) a.src[k] = n;
+}
+__global__ void compose_fill_arcs_kernel(ComposeFillArgs a) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= a.A) return;
+  const int i = a.gi1[k], j = a.gi2[k];
+  a.il[k] = i < 0 ? EPS : (a.lab1 ? a.lab1[i] : i % a.C1);  // compose.cpp:443-446
+  a.ol[k] = j < 0 ? EPS : (a.lab2 ? a.lab2[j] : j % a.C2);
+  // in-rows again, this time with the arc id of every slot (tr_scatter_kernel's job)
+  const int pos = atomicAdd(a.in_cursor + a.dst[k], 1);
+  a.in_list[pos] = k;
+  a.in_src[pos] = a.src[k];
+  a.in_w[pos] = a.w[k];
+}
+} // namespace
+
+void launch_compose_fill(const ComposeFillArgs& a, hipStream_t st) {
+  if (a.N > 0) hipLaunchKernelGGL(compose_fill_src_kernel, dim3((a.N + 255) / 256), dim3(256), 0, st, a);
+  if (a.A > 0) hipLaunchKernelGGL(compose_fill_arcs_kernel, dim3((a.A + 255) / 256), dim3(256), 0, st, a);
 }
 
 void launch_build_records(const DGraph& g, void* out_rec, void* in_rec, hipStream_t st) {

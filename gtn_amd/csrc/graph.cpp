@@ -58,8 +58,23 @@ void Structure::materialize() {
   sched.reset();
 }
 
+void Structure::ensure_full() {
+  if (!partial) return;
+  Runtime& rt = Runtime::get();
+  std::shared_ptr<PartialInfo> p = partial;
+  partial.reset();
+  ComposeFillArgs a = p->args;
+  DevMemP cursor = rt.alloc(sizeof(int) * size_t(a.N > 0 ? a.N : 1));
+  if (a.N > 0) rt.d2d(cursor->ptr, dview.in_off, sizeof(int) * size_t(a.N));
+  a.in_cursor = cursor->as<int>();
+  launch_compose_fill(a, rt.stream());
+  // `cursor` goes back to the pool here; the pool is stream-ordered, so a later
+  // allocation cannot touch it before the kernels above have run
+}
+
 void Structure::ensure_host() {
   if (kind == KIND_LINEAR || host_valid) return;
+  ensure_full();
   // device-built (composition result): pull the SoA arrays once
   Runtime& rt = Runtime::get();
   src.resize(A);
@@ -510,6 +525,7 @@ void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
 }
 
 DGraph device_view(Graph& gr) {
+  gr.s->ensure_full();
   DGraph v = gr.s->dview;
   v.w = gr.w ? gr.w->dev : nullptr;
   return v;

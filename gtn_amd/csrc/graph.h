@@ -72,6 +72,12 @@ struct Structure {
   std::shared_ptr<Schedule> sched;  // valid while the structure is unchanged
   std::mutex grad_lock;             // graph.h:450
 
+  // Non-null: a device-built composition whose derivable arrays (src, il, ol, in_list)
+  // have not been written yet (kernels.h: ComposeArgs::skip).  ensure_full() writes them;
+  // every path that hands the arrays to a kernel or to the host goes through it.
+  std::shared_ptr<struct PartialInfo> partial;
+  void ensure_full();
+
   // Non-null: this is a composition that has NOT been built (ops.cpp: lazy chain
   // products).  Nothing else in the structure is valid until realize() fills it in.
   std::shared_ptr<struct LazyProduct> lazy;
@@ -140,6 +146,12 @@ struct Graph {
   // floats; when `adopt` the buffer becomes the grad without a copy.
   void add_grad_host(const float* v, int64_t n);
   void add_grad_device(const DevMemP& owner, float* dev, bool adopt);
+};
+
+struct PartialInfo {
+  ComposeFillArgs args{};                // pointers into the product's own arena
+  std::shared_ptr<Structure> in1, in2;   // keep the inputs' label arrays alive
+  DevMemP keep1, keep2;
 };
 
 // compose(chain, fixed) / compose(fixed, chain) kept symbolic (see Structure::lazy)

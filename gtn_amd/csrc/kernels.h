@@ -183,6 +183,7 @@ struct ComposeOut {
   int max_level_arcs;  // most arcs emitted by one level
   int csr_built;       // in_off / in_list / in_src / in_w were built inside compose_kernel
   int rep_levels;      // BFS levels emitted by stationary-level replication (not expanded one by one)
+  int skipped;         // src / il / ol / in_list were NOT written (ComposeArgs::skip honoured); see compose_fill
   int t_b, t_f, t_rep; // 100 MHz ticks spent in phase B / phase F (total) / replication (diagnostics)
 };
 
@@ -192,6 +193,11 @@ struct ComposeArgs {
   DGraph g1, g2;
   int matcher;
   int lds_state;  // co-reachability / discovered bitmaps live in LDS
+  // FAST variant only: leave out the arrays that are derivable from the others (src from
+  // out_off; il / ol from gradInfo and the inputs' labels; in_list by re-scattering the
+  // in-rows) -- 16 of the 40 bytes a composed arc costs.  launch_compose_fill() writes
+  // them when somebody needs them (inspection, another compose, viterbi, generic kernels).
+  int skip;
   int Ncap, Acap;
   GTNX_G int* state;     // [N1*N2] pair -> INT_MIN unreachable / R / claim / node id
   GTNX_G int* queue;     // [N1*N2] backward-BFS queue of pair ids
@@ -230,6 +236,25 @@ size_t compose_g1_cache_bytes(int N1, int A1);
 int compose_lds_budget();
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
                     int fast, int cache1, hipStream_t st);
+struct ComposeFillArgs {
+  int N, A;
+  const GTNX_G int* out_off;
+  const GTNX_G int* dst;
+  const GTNX_G float* w;
+  const GTNX_G int* gi1;
+  const GTNX_G int* gi2;
+  const GTNX_G int* lab1;  // ilabels of input 1 (null: linear chain with C1 labels per step)
+  const GTNX_G int* lab2;  // olabels of input 2
+  int C1, C2;
+  GTNX_G int* src;
+  GTNX_G int* il;
+  GTNX_G int* ol;
+  GTNX_G int* in_cursor;   // [N] scratch, preset to in_off
+  GTNX_G int* in_list;
+  GTNX_G int* in_src;
+  GTNX_G float* in_w;
+};
+void launch_compose_fill(const ComposeFillArgs& a, hipStream_t st);
 size_t compose_transpose_scratch_bytes(int n, int maxNcap);
 void launch_compose_transpose(const ComposeArgs* d_args, int n, int maxAcap, int maxNcap, void* scratch,
                               hipStream_t st);

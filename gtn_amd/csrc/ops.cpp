@@ -262,7 +262,8 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
 namespace {
 
 // effective schedule view for this call: in_w only while it still matches the weights
-DSched sched_view(Graph& g) {
+DSched sched_view(Graph& g, bool need_full = true) {
+  if (need_full) g.s->ensure_full();  // in_arc (= in_list) may not have been written yet
   Schedule& sc = *g.s->sched;
   DSched v = sc.view;
   v.in_w = (sc.in_w && sc.in_w_of == g.w.get() && sc.in_w_version == g.w->version) ? sc.in_w : nullptr;
@@ -374,6 +375,8 @@ struct SdOp : OpRecord {
       }
       narrow = narrow && tot_levels >= 32 * int64_t(n);
     }
+    if (!narrow)
+      for (int i = 0; i < n; ++i) ms[i].out.g->inputs[0].s->ensure_full();
     // Fused compose-gradient scatter: when every lattice of the batch is a layered
     // product with one linear chain, produced by a compose whose ONLY consumer is
     // this forwardScore and which holds no gradient yet, the kernel sums the arc
@@ -574,7 +577,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       Graph& g = gs[exp[k]];
       Schedule& sc = *g.s->sched;
       SdArgs& a = args[k];
-      a.s = sched_view(g);
+      a.s = sched_view(g, /*need_full=*/!narrow);  // the narrow kernel reads in_src / in_w / row offsets only
       a.w = g.w->dev;
       a.scores = arena->as<float>(off_s[k]);
       a.argmax = tropical ? arena->as<int>(off_a[k]) : nullptr;
@@ -599,6 +602,8 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     GTNX_PROF(tropical ? "viterbi_score" : "forward_score", alg);
     bool all_inw = true;
     for (auto& a : args) all_inw = all_inw && a.s.in_w != nullptr;
+    if (!all_inw)
+      for (int k = 0; k < m; ++k) gs[exp[k]].s->ensure_full();  // weights by arc id need in_arc
     launch_sd_forward(d->as<SdArgs>(), m, op->mode, narrow ? (all_inw ? 2 : 1) : 0,
                       int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
   }
@@ -923,6 +928,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   // adjacency records now; host-built ones got them at upload
   for (Structure* st : ss) {
     if (st->kind != KIND_EXPLICIT || st->dview.out_rec || st->A == 0) continue;
+    st->ensure_full();
     st->rec_mem = rt.alloc(32 * size_t(st->A));
     gtnx_i4* orec = st->rec_mem->as<gtnx_i4>();
     gtnx_i4* irec = orec + st->A;
@@ -1091,6 +1097,15 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     x.matcher = (s1 && s2) ? MATCH_DOUBLY : (s1 ? MATCH_SINGLY_G1 : (s2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
     if (getenv("GTNX_COMPOSE_DEBUG_B")) x.matcher |= 0x100;
     x.lds_state = lds_state ? 1 : 0;
+    {
+      // chain product, epsilon-free partner no wider than a workgroup: every level is a
+      // single fast chunk, so the FAST variant may leave the derivable arrays out
+      static const bool full_env = getenv("GTNX_FULL_COMPOSE") != nullptr;
+      const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
+      const Structure& ex = l1 ? *b.s : *a.s;
+      x.skip = (!full_env && lds_state && l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) && ex.N <= 256)
+                   ? 1 : 0;
+    }
     x.Ncap = int(c.Ncap);
     x.Acap = int(c.Acap);
     char* rp = res->as<char>();
@@ -1134,7 +1149,10 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     const size_t m = order.size();
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
     std::vector<ComposeArgs> sorted_args(m);
-    for (size_t i = 0; i < m; ++i) sorted_args[i] = args[order[i]];
+    for (size_t i = 0; i < m; ++i) {
+      sorted_args[i] = args[order[i]];
+      if (!fast) sorted_args[i].skip = 0;
+    }
     DevMemP dargs = upload_vec(sorted_args);
     DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(m), int(maxN)));
     {
@@ -1220,6 +1238,32 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     v.in_off = x.in_off;
     v.in_list = x.in_list;
     set_dev_weights(out, res, x.w, co.A);
+    if (co.skipped) {
+      auto pi = std::make_shared<PartialInfo>();
+      ComposeFillArgs& f = pi->args;
+      f.N = co.N;
+      f.A = co.A;
+      f.out_off = x.out_off;
+      f.dst = x.dst;
+      f.w = x.w;
+      f.gi1 = x.gi1;
+      f.gi2 = x.gi2;
+      f.lab1 = a.s->kind == KIND_LINEAR ? nullptr : x.g1.il;
+      f.lab2 = b.s->kind == KIND_LINEAR ? nullptr : x.g2.ol;
+      f.C1 = a.s->kind == KIND_LINEAR ? a.s->C : 1;
+      f.C2 = b.s->kind == KIND_LINEAR ? b.s->C : 1;
+      f.src = x.src;
+      f.il = x.il;
+      f.ol = x.ol;
+      f.in_list = x.in_list;
+      f.in_src = x.in_src;
+      f.in_w = x.in_w;
+      pi->in1 = a.s;
+      pi->in2 = b.s;
+      pi->keep1 = a.s->dev_mem;
+      pi->keep2 = b.s->dev_mem;
+      s.partial = pi;
+    }
     if (co.layered) {
       auto sc = std::make_shared<Schedule>();
       sc->mem = res;
@@ -1356,6 +1400,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     LazyGroupState& st = *gp;
     Structure& fs = *st.fixed.s;
     if (!fs.dview.out_rec && fs.A > 0) {  // device-built G: packed records on demand
+      fs.ensure_full();
       fs.rec_mem = rt.alloc(32 * size_t(fs.A));
       gtnx_i4* orec = fs.rec_mem->as<gtnx_i4>();
       gtnx_i4* irec = orec + fs.A;
@@ -1700,6 +1745,7 @@ void realize(Graph& g) {
   d.dview = o.dview;
   d.rec_mem = o.rec_mem;
   d.sched = o.sched;
+  d.partial = o.partial;
   Weights& dw = *g.w;
   Weights& ow = *real.w;
   dw.n = ow.n;

@@ -471,7 +471,7 @@ def test_torch_ctc_loss_matches_torch_and_oracle(gtn):
     # gtn returns d loss / d log_probs, so compare with the oracle instead
     for b in range(B):
         want, wgrad = ctc_loss(lp2.detach().numpy()[b], tg[b].numpy())
-        assert float(loss[b]) == pytest.approx(want, rel=1e-4)
+        assert float(loss[b].detach()) == pytest.approx(want, rel=1e-4)
         np.testing.assert_allclose(lp.grad[b].cpu().numpy(), wgrad, rtol=1e-4, atol=1e-5)
 
 

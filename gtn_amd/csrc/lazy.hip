@@ -33,7 +33,7 @@ constexpr int kBlock = 256;   // element-wise / per-utterance kernels
 constexpr int kTile = 512;    // tile kernels: DT rows of BT lanes
 constexpr int DT = 32;  // nodes per tile
 constexpr int BT = 16;  // utterances per tile (one DPP row)
-constexpr int RC = 32;  // records of a row staged per chunk
+constexpr int RC = 16;  // records of a row staged per chunk (LDS: two 512-thread workgroups per CU at C4)
 constexpr float NEG_INF = -__builtin_inff();
 
 __device__ __forceinline__ int rec_label(const gtnx_i4& r, int chain_first) { return chain_first ? r.x : r.y; }

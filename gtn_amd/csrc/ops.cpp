@@ -412,6 +412,7 @@ struct SdOp : OpRecord {
     }
     std::vector<SdArgs> args(n);
     GradSink sink;
+    std::unordered_set<GradState*> fused_chain_seen;
     int64_t tot_out = 0, tot_p = 0;
     double alg = 0;
     for (int i = 0; i < n; ++i) {
@@ -447,7 +448,20 @@ struct SdOp : OpRecord {
         a.grad_chain = chain.calc_grad() ? fg->as<float>(off_c[i]) : nullptr;
         a.chunk_levels = std::max(1, std::min(a.chunk_levels, cap_c / std::max(sc.chain_C, 1)));
         if (a.grad_fixed) sink.add(fixed, fg, a.grad_fixed);
-        if (a.grad_chain) sink.add(chain, fg, a.grad_chain);
+        // a chain that already holds a device gradient (e.g. from forwardScore(emissions),
+        // run earlier in the sweep) is accumulated into in place: one pass, no axpy
+        bool in_place = false;
+        if (a.grad_chain && chain.is_grad_available() && fused_chain_seen.insert(chain.g.get()).second) {
+          Weights& gw = *chain.g->grad->w;
+          if (gw.dev_valid && !gw.host_escaped && gw.n == chain.num_arcs()) {
+            a.grad_chain = gw.dev;
+            a.chain_accumulate = 1;
+            gw.host_valid = false;
+            gw.version++;
+            in_place = true;
+          }
+        }
+        if (a.grad_chain && !in_place) sink.add(chain, fg, a.grad_chain);
         in.g->grad_propagated = true;
         alg += 8.0 * double(in.num_arcs()) + 4.0 * double(fixed.num_arcs() + chain.num_arcs());
       }

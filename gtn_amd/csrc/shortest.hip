@@ -818,7 +818,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
       if (FUSE && a.grad_chain && !(a.dbg & 4)) {
         // (the last level has no out-arcs and no chain row)
         for (int x = tid; x < crows && cbase + x < a.chain_A; x += kBlock) {
-          a.grad_chain[cbase + x] = win_c[x];
+          a.grad_chain[cbase + x] = a.chain_accumulate ? a.grad_chain[cbase + x] + win_c[x] : win_c[x];
           win_c[x] = 0.0f;
         }
         lds_barrier();

@@ -168,8 +168,10 @@ struct LinArgs {
   GTNX_G float* grad;      // [M][C]
   int accumulate;          // backward: grad += (the graph already holds a gradient) instead of grad =
 };
-void launch_linear_forward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
-void launch_linear_backward(const LinArgs* d_args, int n, int tropical, int maxM, hipStream_t st);
+// vec_rows != 0 (log semiring only): every member has C % 4 == 0, C <= 1024 and 16-byte
+// aligned weight / gradient rows -- rows are reduced out of registers (linear_rows_kernel)
+void launch_linear_forward(const LinArgs* d_args, int n, int tropical, int vec_rows, hipStream_t st);
+void launch_linear_backward(const LinArgs* d_args, int n, int tropical, int vec_rows, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // composition (gtn/functions/compose.cpp:377-522)

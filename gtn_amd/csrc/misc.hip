@@ -67,6 +67,114 @@ __device__ __forceinline__ float row_reduce(const float* __restrict__ row, int C
   return mx + log1pf(sum - 1.0f);
 }
 
+// ---- log-semiring rows held in registers (C % 4 == 0, C <= 1024) ------------------
+// One wave reduces TWO rows per iteration: each lane owns up to four float4 pieces of
+// a row (one 16-byte load each, all in flight together), the max and the exp-sum go
+// across the wave with DPP row shifts / broadcasts (VALU speed; the __shfl_xor form
+// is six dependent LDS permutes per reduction), and the row is read from HBM once --
+// the backward kernel produces the gradient from the same registers.
+#define GTNX_DPP_F(x, op, old, ctrl, rmask) \
+  x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), ctrl, rmask, 0xf, false)))
+__device__ __forceinline__ float dpp_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_max_dpp(float x) {
+  GTNX_DPP_F(x, fmaxf, x, 0x111, 0xf);
+  GTNX_DPP_F(x, fmaxf, x, 0x112, 0xf);
+  GTNX_DPP_F(x, fmaxf, x, 0x114, 0xf);
+  GTNX_DPP_F(x, fmaxf, x, 0x118, 0xf);
+  GTNX_DPP_F(x, fmaxf, x, 0x142, 0xa);
+  GTNX_DPP_F(x, fmaxf, x, 0x143, 0xc);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float x) {
+  GTNX_DPP_F(x, dpp_add, 0.0f, 0x111, 0xf);
+  GTNX_DPP_F(x, dpp_add, 0.0f, 0x112, 0xf);
+  GTNX_DPP_F(x, dpp_add, 0.0f, 0x114, 0xf);
+  GTNX_DPP_F(x, dpp_add, 0.0f, 0x118, 0xf);
+  GTNX_DPP_F(x, dpp_add, 0.0f, 0x142, 0xa);
+  GTNX_DPP_F(x, dpp_add, 0.0f, 0x143, 0xc);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
+constexpr int kRowPieces = 4;  // float4 pieces per lane: C <= 4 * 256
+constexpr int kRowsPerIter = 2;
+
+template <bool BWD>
+__global__ __launch_bounds__(kBlock) void linear_rows_kernel(const LinArgs* __restrict__ args) {
+  const LinArgs a = args[blockIdx.x / kSplits];
+  const int split = blockIdx.x % kSplits;
+  const int rows_per = (a.M + kSplits - 1) / kSplits;
+  const int r0 = split * rows_per, r1 = min(a.M, r0 + rows_per);
+  const int wave = threadIdx.x / 64, lane = threadIdx.x % 64;
+  const int C = a.C;
+  const float delta = BWD ? *a.delta : 0.0f;
+  float acc = 0.0f;
+  for (int rb = r0 + wave * kRowsPerIter; rb < r1; rb += (kBlock / 64) * kRowsPerIter) {
+    gtnx_f4 v[kRowsPerIter][kRowPieces];
+#pragma unroll
+    for (int q = 0; q < kRowsPerIter; ++q) {
+      const int r = min(rb + q, r1 - 1);
+      const GTNX_G float* row = a.w + (size_t)r * C;
+#pragma unroll
+      for (int k = 0; k < kRowPieces; ++k) {
+        const int c = lane * 4 + k * 256;
+        v[q][k] = gtnx_f4{NEG_INF, NEG_INF, NEG_INF, NEG_INF};
+        if (k * 256 < C && c < C) v[q][k] = *reinterpret_cast<const GTNX_G gtnx_f4*>(row + c);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kRowsPerIter; ++q) {
+      float mx = NEG_INF;
+#pragma unroll
+      for (int k = 0; k < kRowPieces; ++k)
+        if (k * 256 < C)  // wave-uniform: pieces past the row end cost nothing
+          mx = fmaxf(fmaxf(fmaxf(v[q][k].x, v[q][k].y), fmaxf(v[q][k].z, v[q][k].w)), mx);
+      mx = wave_max_dpp(mx);
+      float red = mx;
+      if (mx != POS_INF && mx != NEG_INF) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kRowPieces; ++k)
+          if (k * 256 < C)
+            sum += expf(v[q][k].x - mx) + expf(v[q][k].y - mx) + expf(v[q][k].z - mx) + expf(v[q][k].w - mx);
+        sum = wave_sum_dpp(sum);
+        red = mx + log1pf(sum - 1.0f);
+      }
+      const bool real = rb + q < r1;
+      if (!BWD) {
+        if (real) acc += red;
+      } else if (real) {
+        GTNX_G float* grow = a.grad + (size_t)(rb + q) * C;
+#pragma unroll
+        for (int k = 0; k < kRowPieces; ++k) {
+          const int c = lane * 4 + k * 256;
+          if (c < C) {
+            gtnx_f4 g;
+            g.x = expf(v[q][k].x - red) * delta;  // exp(score[t] + w - score[t+1])
+            g.y = expf(v[q][k].y - red) * delta;
+            g.z = expf(v[q][k].z - red) * delta;
+            g.w = expf(v[q][k].w - red) * delta;
+            GTNX_G gtnx_f4* gp = reinterpret_cast<GTNX_G gtnx_f4*>(grow + c);
+            if (a.accumulate) {
+              const gtnx_f4 o = *gp;
+              g.x += o.x; g.y += o.y; g.z += o.z; g.w += o.w;
+            }
+            *gp = g;
+          }
+        }
+      }
+    }
+  }
+  if (BWD) return;
+  __shared__ float sh[kBlock / 64];
+  if (lane == 0) sh[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int i = 0; i < kBlock / 64; ++i) t += sh[i];
+    a.partial[split] = t;
+  }
+}
+
 template <bool TROPICAL>
 __global__ __launch_bounds__(kBlock) void linear_forward_kernel(const LinArgs* __restrict__ args) {
   const LinArgs a = args[blockIdx.x / kSplits];
@@ -192,18 +300,22 @@ int grid_for(size_t n, int block = 256, int cap = 4096) {
 
 } // namespace
 
-void launch_linear_forward(const LinArgs* d, int n, int tropical, int /*maxM*/, hipStream_t st) {
+void launch_linear_forward(const LinArgs* d, int n, int tropical, int vec_rows, hipStream_t st) {
   if (n <= 0) return;
-  if (tropical)
+  if (!tropical && vec_rows)
+    hipLaunchKernelGGL(linear_rows_kernel<false>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
+  else if (tropical)
     hipLaunchKernelGGL(linear_forward_kernel<true>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
   else
     hipLaunchKernelGGL(linear_forward_kernel<false>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
   hipLaunchKernelGGL(linear_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d, n);
 }
 
-void launch_linear_backward(const LinArgs* d, int n, int tropical, int /*maxM*/, hipStream_t st) {
+void launch_linear_backward(const LinArgs* d, int n, int tropical, int vec_rows, hipStream_t st) {
   if (n <= 0) return;
-  if (tropical)
+  if (!tropical && vec_rows)
+    hipLaunchKernelGGL(linear_rows_kernel<true>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
+  else if (tropical)
     hipLaunchKernelGGL(linear_backward_kernel<true>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
   else
     hipLaunchKernelGGL(linear_backward_kernel<false>, dim3(n * kSplits), dim3(kBlock), 0, st, d);

@@ -325,7 +325,12 @@ struct LinearSdOp : OpRecord {
     DevMemP d = upload_vec(args);
     {
       GTNX_PROF("linear_forward_grad", bytes);
-      launch_linear_backward(d->as<LinArgs>(), n, tropical ? 1 : 0, maxM, rt.stream());
+      bool vec_rows = true;
+      for (auto& a : args)
+        vec_rows = vec_rows && a.C % 4 == 0 && a.C <= 1024 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 &&
+                   (reinterpret_cast<uintptr_t>(a.grad) & 15) == 0;
+      (void)maxM;
+      launch_linear_backward(d->as<LinArgs>(), n, tropical ? 1 : 0, vec_rows ? 1 : 0, rt.stream());
     }
     sink.flush();
   }
@@ -543,7 +548,10 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     }
     DevMemP d = upload_vec(args);
     GTNX_PROF("linear_forward", bytes);
-    launch_linear_forward(d->as<LinArgs>(), m, tropical ? 1 : 0, maxM, rt.stream());
+    bool vec_rows = true;
+    for (auto& a : args) vec_rows = vec_rows && a.C % 4 == 0 && a.C <= 1024 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+    (void)maxM;
+    launch_linear_forward(d->as<LinArgs>(), m, tropical ? 1 : 0, vec_rows ? 1 : 0, rt.stream());
   }
 
   // ---- general DAGs: level-scheduled persistent kernel

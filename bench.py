@@ -260,6 +260,18 @@ def main():
                        "parallelism": f"dp{world} (utterance sharding, all_gather of losses)",
                        "host": "python (gtn_amd/api.py)" if native is None else "C++ (include/gtn/, bench_native/ctc_step.cpp)"},
             "roofline": roof,
+            # the other two big kernels against the same 8 TB/s, algorithmic bytes as SURVEY.md
+            # section 8(d) defines them (utterance 0's lattice size x batch): compose writes
+            # 36A + 8N; forwardScore's backward with the fused compose-gradient scatter reads /
+            # writes 12A + 12N (shortest distance) + 12A + 4TC (compose gradient)
+            "roofline_other": {
+                name: {"achieved": bytes_ / (prof[name]["total_ms"] / prof[name]["launches"] * 1e-3) / 1e9,
+                       "frac": bytes_ / (prof[name]["total_ms"] / prof[name]["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "unit": "GB/s", "algorithmic_bytes_per_launch": bytes_,
+                       "ms_per_launch": prof[name]["total_ms"] / prof[name]["launches"]}
+                for name, bytes_ in (("intersect", B * (36.0 * n_arcs + 8.0 * n_nodes)),
+                                     ("forward_score_grad", B * (24.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)))
+                if name in prof and prof[name]["launches"]},
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
             "loss_mean": float(np.mean(losses)),
         }

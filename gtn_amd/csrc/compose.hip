@@ -517,10 +517,6 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       a.state[x] = ((reach_bits[x >> 5] >> (x & 31)) & 1u) ? ST_REACH : ST_UNREACH;
     __syncthreads();
   }
-  if (a.matcher & 0x100) {  // debug: stop after phase B (timing experiments only)
-    if (tid == 0) { ComposeOut o{}; o.layered = 1; o.csr_built = 1; *a.out = o; a.counts[0] = a.counts[1] = 0; }
-    return;
-  }
   // ------------------------------------------------------------------ phase F
   const long long tk1 = wall_clock64();
   cache_g1(false);

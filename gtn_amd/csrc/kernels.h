@@ -119,7 +119,6 @@ struct SdArgs {
   GTNX_G float* grad_chain;   // [T*C]     zero-filled by the host; may be null
   int chain_C, fixed_A, chain_A;
   int chain_accumulate;  // grad_chain already holds a gradient: rows are added to, not stored
-  int dbg;  // timing experiments only (GTNX_FUSE_DBG): 1 skip chain sums, 2 skip fixed sums, 4 skip row flush, 8 plain atomics
 };
 
 enum : int { SD_LOG = 0, SD_TROPICAL = 1, SD_PATH = 2 };

@@ -448,7 +448,6 @@ struct SdOp : OpRecord {
         a.chain_C = sc.chain_C;
         a.fixed_A = int(sc.fixed_A);
         a.chain_A = int(chain.num_arcs());
-        if (const char* e = getenv("GTNX_FUSE_DBG")) a.dbg = atoi(e);
         a.grad_fixed = fixed.calc_grad() ? fg->as<float>(off_f[i]) : nullptr;
         a.grad_chain = chain.calc_grad() ? fg->as<float>(off_c[i]) : nullptr;
         a.chunk_levels = std::max(1, std::min(a.chunk_levels, cap_c / std::max(sc.chain_C, 1)));
@@ -1117,12 +1116,11 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     const bool s1 = intersect ? (a.s->ilabel_sorted || a.s->olabel_sorted) : a.s->olabel_sorted;
     const bool s2 = intersect ? (b.s->ilabel_sorted || b.s->olabel_sorted) : b.s->ilabel_sorted;
     x.matcher = (s1 && s2) ? MATCH_DOUBLY : (s1 ? MATCH_SINGLY_G1 : (s2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
-    if (getenv("GTNX_COMPOSE_DEBUG_B")) x.matcher |= 0x100;
     x.lds_state = lds_state ? 1 : 0;
     {
       // chain product, epsilon-free partner no wider than a workgroup: every level is a
       // single fast chunk, so the FAST variant may leave the derivable arrays out
-      static const bool full_env = getenv("GTNX_FULL_COMPOSE") != nullptr;
+      const bool full_env = getenv("GTNX_FULL_COMPOSE") != nullptr;
       const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
       const Structure& ex = l1 ? *b.s : *a.s;
       x.skip = (!full_env && lds_state && l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) && ex.N <= 256)

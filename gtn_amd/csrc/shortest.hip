@@ -789,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
           for (int q = 0; q < 4; ++q) {
             const bool in = kl + q < a1 - a0;
             const int fi = gf_cur[j][q], ci = gc_cur[j][q] - cbase;
-            if (a.grad_fixed && !(a.dbg & 2)) {
+            if (a.grad_fixed) {
               const int key = (in && fi >= 0) ? fi : -1;
               const int x = j * 4 + q;
               if (key == f_key[x]) {
@@ -800,10 +800,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
                 f_acc[x] = gv[q];
               }
             }
-            if (a.grad_chain && !(a.dbg & 1)) {
-              if (a.dbg & 8) { if (in && ci >= 0) atomicAdd(&win_c[ci], gv[q]); }
-              else lds_add_hot(win_c, ci, gv[q], in && ci >= 0);
-            }
+            if (a.grad_chain) lds_add_hot(win_c, ci, gv[q], in && ci >= 0);
           }
         }
 #pragma unroll
@@ -815,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
       }
       for (int k = a0 + tid; k < a1; k += kBlock) a.arc_grad[k] = g_buf[k - a0];
       lds_barrier();
-      if (FUSE && a.grad_chain && !(a.dbg & 4)) {
+      if (FUSE && a.grad_chain) {
         // (the last level has no out-arcs and no chain row)
         for (int x = tid; x < crows && cbase + x < a.chain_A; x += kBlock) {
           a.grad_chain[cbase + x] = a.chain_accumulate ? a.grad_chain[cbase + x] + win_c[x] : win_c[x];

@@ -538,3 +538,16 @@ def test_full_size_c3_invariants(gtn):
     g0 = ctcs[0].grad().weights_to_numpy()
     assert g0.shape[0] == ctcs[0].num_arcs() and (np.abs(g0) <= T + 1e-2).all()
     assert abs(float(-g0.sum()) - T) < 0.5          # one lattice arc per time step in expectation
+
+
+@pytest.mark.parametrize("var", ["GTNX_FULL_COMPOSE", "GTNX_NO_FUSED_SCATTER"])
+def test_alternative_code_paths_give_the_same_results(gtn, var):
+    """README 'Runtime switches': the eager (all arrays written) compose and the unfused
+    compose-gradient kernel against the same oracle checks as the default paths"""
+    import os
+    os.environ[var] = "1"
+    try:
+        test_batched_ctc_vs_oracle(gtn, 4, 300, 64, 30)
+        test_compose_linear_first_structure_vs_oracle(gtn, 120, 20, 8)
+    finally:
+        os.environ.pop(var, None)

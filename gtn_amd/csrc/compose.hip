@@ -313,11 +313,26 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   extern __shared__ __attribute__((aligned(16))) unsigned dyn_bits[];
   const int nwords = (N1 * N2 + 31) >> 5;
   const bool lds_state = FAST ? true : (a.lds_state != 0);
-  unsigned* reach_bits = dyn_bits;
-  unsigned* disc_bits = dyn_bits + nwords;
+  // Two layouts of the co-reachability / discovered bitmaps in LDS:
+  //  classic : 2 x (N1*N2) bits, indexed by pair id;
+  //  chain   : (a.chain_bits > 0; chain products with an epsilon-free partner only) a
+  //            WINDOW of the last `Wmax` time slices of No bits each (slice s = time
+  //            TM - s), one slice for the stationary set every earlier time shares, and
+  //            two per-level "discovered" slices -- independent of the chain length, so
+  //            T*U products far beyond the classic budget stay on the fast path.
+  constexpr bool CHP = FAST && (L1 != L2);
+  const bool CH = CHP && a.chain_bits > 0;
+  const int No = L2 ? N1 : N2;               // nodes of the explicit partner
+  const int NoW = (No + 31) >> 5;
+  const int Wmax = a.chain_bits;
+  const int bm_words = CH ? NoW * (Wmax + 3) : 2 * nwords;
+  unsigned* reach_bits = dyn_bits;           // classic [nwords] | chain window [Wmax][NoW]
+  unsigned* disc_bits = dyn_bits + nwords;   // classic
+  unsigned* stat_bits = dyn_bits + NoW * (CH ? Wmax : 0);  // chain: stationary set (zero until known)
+  unsigned* disc2 = stat_bits + NoW;         // chain: [2][NoW], by level parity
   // ---- optional LDS cache of g1: offsets, records (16 B aligned), node flags
   const int A1 = a.g1.A;
-  int* c_off = reinterpret_cast<int*>(dyn_bits + ((2 * nwords + 3) & ~3));
+  int* c_off = reinterpret_cast<int*>(dyn_bits + ((bm_words + 3) & ~3));
   gtnx_i4* c_rec = reinterpret_cast<gtnx_i4*>(c_off + ((N1 + 1 + 3) & ~3));
   uint8_t* c_fl = reinterpret_cast<uint8_t*>(c_rec + A1);
   LGraph lg;
@@ -351,6 +366,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
   const int TM = L2 ? a.g2.M : a.g1.M;      // chain length
   const int CL = L2 ? a.g2.C : a.g1.C;      // chain arcs per time step
   int tB = -1;                              // B[t] is the stationary set for every t <= tB
+  // chain layout helpers; the caller knows the time of the pair it asks about
+  auto other_of = [&](int idx, int t) { return L2 ? idx - N1 * t : (idx - t) / N1; };
+  auto ch_word = [&](int t, int n) -> unsigned* {
+    const int sl = TM - t;
+    return ((tB >= 0 && t <= tB) || sl >= Wmax || sl < 0) ? &stat_bits[n >> 5] : &reach_bits[sl * NoW + (n >> 5)];
+  };
   if (tid == 0) {
     sh_tail = 0;
     sh_rep[0] = sh_rep[1] = 0;
@@ -387,33 +408,53 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
     const int seeds = na1 * na2;
     if (lds_state) {
-      for (int x = tid; x < 2 * nwords; x += kBlock) dyn_bits[x] = 0u;
+      for (int x = tid; x < bm_words; x += kBlock) dyn_bits[x] = 0u;
       __syncthreads();
     }
     cache_g1(true);
     for (int t = tid; t < seeds; t += kBlock) {
       const int f = g_accept_at<L1>(a.g1, t / na2), s = g_accept_at<L2>(a.g2, t % na2);
       const int idx = f + N1 * s;
-      if (lds_state) atomicOr(&reach_bits[idx >> 5], 1u << (idx & 31));
+      if (CH) {
+        const int n = other_of(idx, TM);
+        atomicOr(&reach_bits[n >> 5], 1u << (n & 31));  // slice 0 = time TM
+      } else if (lds_state) atomicOr(&reach_bits[idx >> 5], 1u << (idx & 31));
       else st_state(a.state + idx, ST_REACH);
       if (t < BQ) bq(0)[t] = idx; else a.queue[t] = idx;
     }
     if (tid == 0) sh_tail = seeds;
     __syncthreads();
     int lo = 0, hi = seeds, cur = 0;
+    int tau = TM;  // time of the frontier being expanded (rep_ok: one time per level)
     auto mark = [&](int idx, int nxt) {
-      const bool fresh = lds_state ? !(atomicOr(&reach_bits[idx >> 5], 1u << (idx & 31)) & (1u << (idx & 31)))
-                                   : atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH;
+      bool fresh;
+      int chn = 0, chs = 0;
+      if (CH) {
+        chs = TM - (tau - 1);  // slice of the pairs being marked
+        if (chs >= Wmax) {     // not stationary within the window: the general variant takes over
+          sh_flag[1] = 2;
+          return;
+        }
+        chn = other_of(idx, tau - 1);
+        const unsigned bit = 1u << (chn & 31);
+        fresh = !(atomicOr(&reach_bits[chs * NoW + (chn >> 5)], bit) & bit);
+      } else {
+        fresh = lds_state ? !(atomicOr(&reach_bits[idx >> 5], 1u << (idx & 31)) & (1u << (idx & 31)))
+                          : atomicCAS(a.state + idx, ST_UNREACH, ST_REACH) == ST_UNREACH;
+      }
       if (fresh) {
         const int pos = atomicAdd(&sh_tail, 1);
         if (pos - hi < BQ) bq(nxt)[pos - hi] = idx; else a.queue[pos] = idx;
         if (REP && rep_ok) {  // same partner node one time step later must be in the set
-          const int q = idx + tshift;
-          if (!((reach_bits[q >> 5] >> (q & 31)) & 1u)) sh_rep[0] = 1;
+          if (CH) {
+            if (!((reach_bits[(chs - 1) * NoW + (chn >> 5)] >> (chn & 31)) & 1u)) sh_rep[0] = 1;
+          } else {
+            const int q = idx + tshift;
+            if (!((reach_bits[q >> 5] >> (q & 31)) & 1u)) sh_rep[0] = 1;
+          }
         }
       }
     };
-    int tau = TM;  // time of the frontier being expanded (rep_ok: one time per level)
 #ifdef GTNX_TIMING
     long long t_enum = 0, t_mark = 0, t_bar = 0, t_q = 0, t0, t1; int nlev = 0;
 #endif
@@ -441,7 +482,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
 #pragma unroll
           for (int m = 0; m < KC; ++m) {
             if (m >= c.n) st[m] = 0;
-            else if (lds_state) st[m] = ((reach_bits[c.idx[m] >> 5] >> (c.idx[m] & 31)) & 1u) ? 0 : ST_UNREACH;
+            else if (CH) {
+              const int n = other_of(c.idx[m], tau - 1);
+              st[m] = ((*ch_word(tau - 1, n) >> (n & 31)) & 1u) ? 0 : ST_UNREACH;
+            } else if (lds_state) st[m] = ((reach_bits[c.idx[m] >> 5] >> (c.idx[m] & 31)) & 1u) ? 0 : ST_UNREACH;
             else st[m] = ld_state(a.state + c.idx[m]);
           }
 #pragma unroll
@@ -473,7 +517,14 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       if (REP && rep_ok && tid == 0) sh_rep[0] = 0;
       wg_barrier(lds_state && (hi - lo) <= BQ);
       if (REP && rep_ok) {
-        if (same && hi - lo == prev_w && prev_w > 0 && tau >= 2) {
+        if (CH && same && hi - lo == prev_w && prev_w > 0 && tau >= 1) {
+          // B[tau-1] == B[tau]: that set serves every earlier time; no fill in this layout
+          tB = tau;
+          for (int x = tid; x < NoW; x += kBlock) stat_bits[x] = reach_bits[(TM - tau) * NoW + x];
+          lds_barrier();
+          break;
+        }
+        if (!CH && same && hi - lo == prev_w && prev_w > 0 && tau >= 2) {
           // B[tau-1] == B[tau]: fill every earlier time with the same partner set
           tB = tau;
           const int total_bits = N1 * N2;
@@ -511,7 +562,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
     if (tid == 0) { ComposeOut o{}; o.overflow = 2; *a.out = o; a.counts[0] = a.counts[1] = 0; }
     return;
   }
-  if (lds_state) {
+  if (lds_state && !CH) {
     // publish the co-reachability table for the general (HBM) code paths of phase F
     for (int x = tid; x < N1 * N2; x += kBlock)
       a.state[x] = ((reach_bits[x >> 5] >> (x & 31)) & 1u) ? ST_REACH : ST_UNREACH;
@@ -537,7 +588,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         s1 = g_start_at<L1>(a.g1, t / ns2);
         s2 = g_start_at<L2>(a.g2, t % ns2);
         idx = s1 + N1 * s2;
-        ok = ld_state(a.state + idx) == ST_REACH;
+        if (CH) {
+          const int n = other_of(idx, 0);
+          ok = (*ch_word(0, n) >> (n & 31)) & 1u;
+        } else {
+          ok = ld_state(a.state + idx) == ST_REACH;
+        }
       }
       int tot, tota;
       const int off = block_excl_scan(ok, sh_scan, tot);
@@ -552,7 +608,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           if (acc0) a.accept_list[na_tot + offa] = id;
           a.in_off[id] = 0;  // level 0 has no in-arcs in a layered product
           if (id < FC) front[0][id] = idx;
-          if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
+          if (lds_state && !CH) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
           st_state(a.state + idx, id);
         } else {
           sh_flag[1] = 1;
@@ -573,6 +629,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       a.level_off[L] = lo;
       if (REP) sh_rep[1] = 0;
     }
+    if (CH)  // level L flags pairs of time L+1 in slice (L+1)&1; the other one is recycled for level L+1
+      for (int x = tid; x < NoW; x += kBlock) disc2[(L & 1) * NoW + x] = 0u;
     const int na_level = na;
     max_width = max(max_width, hi - lo);
     const bool front_in_lds = (hi - lo) <= FC;
@@ -624,6 +682,12 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
       for (int m = 0; m < KC; ++m) {
         if (m >= c.n) {
           st[m] = ST_UNREACH;
+        } else if (CH) {
+          const int n = other_of(c.idx[m], L + 1);
+          const unsigned bit = 1u << (n & 31);
+          st[m] = !(*ch_word(L + 1, n) & bit) ? ST_UNREACH
+                                               : ((disc2[((L + 1) & 1) * NoW + (n >> 5)] & bit) ? 0 : ST_REACH);
+          hit = hit || st[m] == 0;
         } else if (lds_state) {
           const unsigned bit = 1u << (c.idx[m] & 31);
           const int wd = c.idx[m] >> 5;
@@ -754,7 +818,10 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
               a.pair_of[id] = idx;
               a.nflags[id] = uint8_t(fl);
               if (id - hi < FC) front[fcur ^ 1][id - hi] = idx;
-              if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
+              if (CH) {
+                const int n = other_of(idx, L + 1);
+                atomicOr(&disc2[((L + 1) & 1) * NoW + (n >> 5)], 1u << (n & 31));
+              } else if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
               st_state(a.state + idx, id);
             } else {
               hids[slot[m]] = 0;
@@ -1094,6 +1161,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           hi += K * W;
           L += K;
           rep_levels += K;
+          if (CH)  // the level parity jumped: both per-level slices start clean
+            for (int x = tid; x < 2 * NoW; x += kBlock) disc2[x] = 0u;
           tk_rep += wall_clock64() - tr0;
         }
       }
@@ -1330,6 +1399,7 @@ int grid_x(int n, int cap) {
 } // namespace
 
 int compose_max_bitmap_bytes() { return kMaxBitmapBytes; }
+size_t compose_chain_bitmap_bytes(int No, int slices) { return 4 * size_t((No + 31) / 32) * size_t(slices + 3); }
 
 namespace {
 template <int MATCH, bool L1, bool L2, bool FAST, bool C1>

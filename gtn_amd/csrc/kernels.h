@@ -200,6 +200,9 @@ struct ComposeArgs {
   // in-rows) -- 16 of the 40 bytes a composed arc costs.  launch_compose_fill() writes
   // them when somebody needs them (inspection, another compose, viterbi, generic kernels).
   int skip;
+  // FAST variant, chain product with an epsilon-free partner: > 0 selects the time-windowed
+  // bitmap layout with this many time slices (compose.hip); 0 = classic pair-indexed bitmaps
+  int chain_bits;
   int Ncap, Acap;
   GTNX_G int* state;     // [N1*N2] pair -> INT_MIN unreachable / R / claim / node id
   GTNX_G int* queue;     // [N1*N2] backward-BFS queue of pair ids
@@ -229,6 +232,8 @@ struct ComposeArgs {
 // dyn_lds_bytes: 2 bitmaps of N1*N2 bits for the largest pair table of the batch
 // when every graph has lds_state set, else 0
 int compose_max_bitmap_bytes();
+// bytes of the chain layout for a partner with `No` nodes and `slices` time slices
+size_t compose_chain_bitmap_bytes(int No, int slices);
 // all n problems share (matcher, g1 is linear, g2 is linear)
 // fast != 0: the compact LDS-only variant (needs dyn_lds_bytes > 0); pairs it cannot
 // handle come back with ComposeOut::overflow == 2 and must be re-run with fast = 0

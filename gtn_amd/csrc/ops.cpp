@@ -1089,10 +1089,40 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   DevMemP res = rt.alloc(rb ? rb : 1);
   // small pair tables keep their bitmaps in LDS (whole batch must qualify, the
   // dynamic LDS request is per launch); the HBM table is then written by the kernel
-  size_t max_pairs = 0;
-  for (size_t i = 0; i < n; ++i) max_pairs = std::max(max_pairs, size_t(caps[i].pairs));
-  const int bitmap_bytes = int(2 * 4 * ((max_pairs + 31) / 32));
-  const bool lds_state = bitmap_bytes <= compose_max_bitmap_bytes();
+  // Two layouts (compose.hip): the classic pair-indexed bitmaps (2 * N1*N2 bits), and for
+  // chain products with an epsilon-free partner a window of time slices whose size does
+  // not depend on the chain length.  `fast_ok`: every pair fits one of them (FAST variant);
+  // `classic_ok[i]`: the general variant may keep pair i's classic bitmaps in LDS.
+  std::vector<int> chain_slices(n, 0);
+  std::vector<char> classic_ok(n, 0);
+  size_t fast_bm = 0, classic_bm = 0;
+  bool fast_ok = true;
+  {
+    const bool no_chain = getenv("GTNX_CLASSIC_BITMAPS") != nullptr;
+    const size_t budget = size_t(compose_max_bitmap_bytes());
+    for (size_t i = 0; i < n; ++i) {
+      const Structure& s1 = *bcast(av, n, i).s;
+      const Structure& s2 = *bcast(bv, n, i).s;
+      const size_t classic = 2 * 4 * ((size_t(caps[i].pairs) + 31) / 32);
+      classic_ok[i] = classic <= budget;
+      if (classic_ok[i]) classic_bm = std::max(classic_bm, classic);
+      size_t mine = classic;
+      const bool l1 = s1.kind == KIND_LINEAR, l2 = s2.kind == KIND_LINEAR;
+      if (!no_chain && l1 != l2 && ((l1 ? s2 : s1).dview.flags & GF_EPS_FREE)) {
+        const int No = int((l1 ? s2 : s1).N), TMc = (l1 ? s1 : s2).M;
+        const int64_t room = int64_t(budget / (4 * size_t((No + 31) / 32))) - 3;
+        const int slices = int(std::min<int64_t>(TMc + 1, room));
+        if (slices >= std::min(TMc + 1, 64)) {
+          chain_slices[i] = slices;
+          mine = compose_chain_bitmap_bytes(No, slices);
+        }
+      }
+      fast_ok = fast_ok && mine <= budget;
+      fast_bm = std::max(fast_bm, mine);
+    }
+  }
+  const int bitmap_bytes = int(fast_bm);
+  const bool lds_state = fast_ok;  // the FAST variant can run
   // ... and, when it still fits, g1's adjacency records as well
   size_t g1_cache = 0;
   for (size_t i = 0; i < n; ++i) {
@@ -1101,7 +1131,12 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   }
   const bool cache1 = lds_state && g1_cache > 0 && bitmap_bytes + int(g1_cache) <= compose_lds_budget();
   const int dyn_fast = bitmap_bytes + (cache1 ? int(g1_cache) : 0);
-  if (!lds_state) launch_fill_i32(st_mem->as<int>(), INT32_MIN, st_b / 4, rt.stream());
+  bool state_filled = false;
+  auto fill_state = [&] {  // the general variant's HBM pair table starts as "unreached"
+    if (!state_filled) launch_fill_i32(st_mem->as<int>(), INT32_MIN, st_b / 4, rt.stream());
+    state_filled = true;
+  };
+  if (!lds_state) fill_state();
   HIP_CHECK(hipMemsetAsync(cu_mem->ptr, 0, cu_b ? cu_b : 1, rt.stream()));
   std::vector<ComposeArgs> args(n);
   for (size_t i = 0; i < n; ++i) {
@@ -1116,7 +1151,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     const bool s1 = intersect ? (a.s->ilabel_sorted || a.s->olabel_sorted) : a.s->olabel_sorted;
     const bool s2 = intersect ? (b.s->ilabel_sorted || b.s->olabel_sorted) : b.s->ilabel_sorted;
     x.matcher = (s1 && s2) ? MATCH_DOUBLY : (s1 ? MATCH_SINGLY_G1 : (s2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
-    x.lds_state = lds_state ? 1 : 0;
+    x.lds_state = classic_ok[i] ? 1 : 0;  // read by the general variant only (FAST implies LDS)
+    x.chain_bits = chain_slices[i];
     {
       // chain product, epsilon-free partner no wider than a workgroup: every level is a
       // single fast chunk, so the FAST variant may leave the derivable arrays out
@@ -1171,7 +1207,10 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     std::vector<ComposeArgs> sorted_args(m);
     for (size_t i = 0; i < m; ++i) {
       sorted_args[i] = args[order[i]];
-      if (!fast) sorted_args[i].skip = 0;
+      if (!fast) {
+        sorted_args[i].skip = 0;
+        if (!sorted_args[i].lds_state) fill_state();
+      }
     }
     DevMemP dargs = upload_vec(sorted_args);
     DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(m), int(maxN)));
@@ -1182,8 +1221,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         while (g1 < m && key_of(order[g1]) == key_of(order[g0])) ++g1;
         const int key = key_of(order[g0]);
         launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
-                       lds_state ? (fast ? dyn_fast : bitmap_bytes) : 0, fast ? 1 : 0, (fast && cache1) ? 1 : 0,
-                       rt.stream());
+                       fast ? dyn_fast : int(classic_bm), fast ? 1 : 0, (fast && cache1) ? 1 : 0, rt.stream());
         g0 = g1;
       }
     }

@@ -227,6 +227,7 @@ __device__ __forceinline__ void wg_barrier(bool lds_only) {
   if (lds_only) lds_barrier(); else __syncthreads();
 }
 
+template <int BLK = kBlock>
 __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int& total, bool lds_only = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int x = v;
@@ -240,7 +241,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int
   wg_barrier(lds_only);
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < kBlock / 64; ++w) {
+  for (int w = 0; w < BLK / 64; ++w) {
     const int s = sh[w];
     if (w < wave) base += s;
     tot += s;
@@ -294,8 +295,19 @@ struct SelView<false> {
 };
 
 // C1: g1 (explicit, small) has its adjacency of the current phase cached in LDS
-template <int MATCH, bool L1, bool L2, bool FAST, bool C1>
-__global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __restrict__ args) {
+// BLK: workgroup size.  256 by default; the FAST variant also exists at 512 lanes with
+// doubled LDS working set, so that partners of up to 512 nodes keep every BFS level in
+// ONE chunk (which the fused in-row build, the skipped arrays and the stationary-level
+// replication all require).
+template <int MATCH, bool L1, bool L2, bool FAST, bool C1, int BLK>
+__global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restrict__ args) {
+  constexpr int kBlock = BLK;
+  constexpr int HC = 4 * BLK;
+  constexpr int HC_LOG2 = BLK == 256 ? 10 : 11;
+  constexpr int FC = BLK;
+  constexpr int WC = 2 * BLK;
+  constexpr int BQ = HC;
+  static_assert(BLK == 256 || BLK == 512, "claim-hash width is tied to the block size");
   const ComposeArgs a = args[blockIdx.x];
   const int tid = threadIdx.x;
   const int N1 = a.g1.N, N2 = a.g2.N;
@@ -596,9 +608,9 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         }
       }
       int tot, tota;
-      const int off = block_excl_scan(ok, sh_scan, tot);
+      const int off = block_excl_scan<BLK>(ok, sh_scan, tot);
       const int acc0 = ok && g_accept<L1>(g1v, s1) && g_accept<L2>(a.g2, s2);
-      const int offa = block_excl_scan(acc0, sh_scan, tota);
+      const int offa = block_excl_scan<BLK>(acc0, sh_scan, tota);
       if (ok) {
         const int id = nn + off;
         if (id < a.Ncap) {
@@ -731,7 +743,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           enum_eps<false, L2>(a.g2, o2, true, [&](const Rec& r) { cnt += ld_state(a.state + n1 + N1 * r.node) != ST_UNREACH; });
       }
       int total;
-      const int off = block_excl_scan(cnt, sh_scan, total, lds_state);
+      const int off = block_excl_scan<BLK>(cnt, sh_scan, total, lds_state);
       const bool fast = !(chunk_flags & 1) && total <= (HC * 3) / 4;
       if (FAST && !fast) {
         if (tid == 0) sh_flag[1] = 2;
@@ -793,7 +805,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           nown += own[m];
         }
         int t2;
-        int rank = block_excl_scan(nown, sh_scan, t2, lds_state);
+        int rank = block_excl_scan<BLK>(nown, sh_scan, t2, lds_state);
         newn = t2;
         int own_id[KC], own_fl[KC], n_s = 0, n_a = 0;
 #pragma unroll
@@ -832,8 +844,8 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
         wg_barrier(lds_state);
         if (sh_lst) {  // workgroup-uniform: some lane numbered a start / accept node
           int ts, ta;
-          int os = block_excl_scan(n_s, sh_scan, ts, lds_state);
-          int oa = block_excl_scan(n_a, sh_scan, ta, lds_state);
+          int os = block_excl_scan<BLK>(n_s, sh_scan, ts, lds_state);
+          int oa = block_excl_scan<BLK>(n_a, sh_scan, ta, lds_state);
 #pragma unroll
           for (int m = 0; m < KC; ++m) {
             if (own_fl[m] & NF_START) a.start_list[ns_tot + os++] = own_id[m];
@@ -903,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
             own = ld_state(a.state + idx) == claim_of(r);
           }
           int t2;
-          const int rank = block_excl_scan(own, sh_scan, t2);
+          const int rank = block_excl_scan<BLK>(own, sh_scan, t2);
           int id = -1;
           if (own) {
             id = nn + newn + rank;
@@ -966,7 +978,7 @@ __global__ __launch_bounds__(kBlock) void compose_kernel(const ComposeArgs* __re
           sum += loc[x];
         }
         int tot;
-        int run = block_excl_scan(sum, sh_scan, tot, lds_state);
+        int run = block_excl_scan<BLK>(sum, sh_scan, tot, lds_state);
 #pragma unroll
         for (int x = 0; x < PER; ++x) {
           const int nidx = tid * PER + x;
@@ -1402,15 +1414,22 @@ int compose_max_bitmap_bytes() { return kMaxBitmapBytes; }
 size_t compose_chain_bitmap_bytes(int No, int slices) { return 4 * size_t((No + 31) / 32) * size_t(slices + 3); }
 
 namespace {
-template <int MATCH, bool L1, bool L2, bool FAST, bool C1>
-void launch_compose_t(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
+template <int MATCH, bool L1, bool L2, bool FAST, bool C1, int BLK>
+void launch_compose_b(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
   static int max_set = 0;
   if (dyn > max_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2, FAST, C1>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2, FAST, C1, BLK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
     max_set = dyn;
   }
-  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST, C1>), dim3(n), dim3(kBlock), dyn, st, d_args);
+  hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST, C1, BLK>), dim3(n), dim3(BLK), dyn, st, d_args);
+}
+int g_compose_wide = 0;  // set by launch_compose for the duration of one dispatch
+template <int MATCH, bool L1, bool L2, bool FAST, bool C1>
+void launch_compose_t(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
+  // the 512-lane form only for chain products (one side linear) on the FAST variant
+  if (FAST && (L1 != L2) && g_compose_wide) launch_compose_b<MATCH, L1, L2, FAST, C1, (FAST && (L1 != L2)) ? 512 : 256>(d_args, n, dyn, st);
+  else launch_compose_b<MATCH, L1, L2, FAST, C1, 256>(d_args, n, dyn, st);
 }
 template <int MATCH, bool FAST>
 void launch_compose_f(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, int cache1, hipStream_t st) {
@@ -1438,11 +1457,13 @@ void launch_compose_m(const ComposeArgs* d, int n, int lin1, int lin2, int dyn, 
 size_t compose_g1_cache_bytes(int N1, int A1) {
   return 16 + 4 * size_t((N1 + 1 + 3) & ~3) + 16 * size_t(A1) + size_t((N1 + 15) & ~15);
 }
-int compose_lds_budget() { return 80 * 1024 - 19 * 1024; }  // dynamic bytes that keep 2 workgroups per CU
+// dynamic bytes that keep 2 workgroups per CU next to the static working set
+int compose_lds_budget(int wide) { return 80 * 1024 - (wide ? 38 : 19) * 1024; }
 
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
-                    int fast, int cache1, hipStream_t st) {
+                    int fast, int cache1, int wide, hipStream_t st) {
   if (n <= 0) return;
+  g_compose_wide = wide;
   switch (matcher) {
     case MATCH_UNSORTED: launch_compose_m<MATCH_UNSORTED>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, cache1, st); break;
     case MATCH_SINGLY_G1: launch_compose_m<MATCH_SINGLY_G1>(d_args, n, lin1, lin2, dyn_lds_bytes, fast, cache1, st); break;

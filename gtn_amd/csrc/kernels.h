@@ -240,9 +240,10 @@ size_t compose_chain_bitmap_bytes(int No, int slices);
 // cache1 != 0 (fast only): g1's adjacency is cached in LDS; dyn_lds_bytes then
 // covers the bitmaps plus compose_g1_cache_bytes() of the largest g1
 size_t compose_g1_cache_bytes(int N1, int A1);
-int compose_lds_budget();
+int compose_lds_budget(int wide);
+// wide != 0 (fast chain products only): 512-lane workgroups, partners of up to 512 nodes
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
-                    int fast, int cache1, hipStream_t st);
+                    int fast, int cache1, int wide, hipStream_t st);
 struct ComposeFillArgs {
   int N, A;
   const GTNX_G int* out_off;

@@ -1097,9 +1097,24 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   std::vector<char> classic_ok(n, 0);
   size_t fast_bm = 0, classic_bm = 0;
   bool fast_ok = true;
+  // 512-lane workgroups when some chain product's partner has 257..512 nodes (and none more)
+  bool wide = false;
+  {
+    bool any_wide = false, all_fit = true;
+    for (size_t i = 0; i < n; ++i) {
+      const Structure& s1 = *bcast(av, n, i).s;
+      const Structure& s2 = *bcast(bv, n, i).s;
+      const bool l1 = s1.kind == KIND_LINEAR, l2 = s2.kind == KIND_LINEAR;
+      if (l1 == l2) continue;
+      const int64_t No = (l1 ? s2 : s1).N;
+      any_wide = any_wide || No > 256;
+      all_fit = all_fit && No <= 512;
+    }
+    wide = any_wide && all_fit && !getenv("GTNX_NARROW_COMPOSE");
+  }
   {
     const bool no_chain = getenv("GTNX_CLASSIC_BITMAPS") != nullptr;
-    const size_t budget = size_t(compose_max_bitmap_bytes());
+    const size_t budget = std::min<size_t>(size_t(compose_max_bitmap_bytes()), size_t(compose_lds_budget(wide ? 1 : 0)));
     for (size_t i = 0; i < n; ++i) {
       const Structure& s1 = *bcast(av, n, i).s;
       const Structure& s2 = *bcast(bv, n, i).s;
@@ -1111,7 +1126,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       if (!no_chain && l1 != l2 && ((l1 ? s2 : s1).dview.flags & GF_EPS_FREE)) {
         const int No = int((l1 ? s2 : s1).N), TMc = (l1 ? s1 : s2).M;
         const int64_t room = int64_t(budget / (4 * size_t((No + 31) / 32))) - 3;
-        const int slices = int(std::min<int64_t>(TMc + 1, room));
+        // stationarity of the co-reachable set arrives within ~No steps, if at all
+        const int slices = int(std::min<int64_t>(std::min<int64_t>(TMc + 1, No + 64), room));
         if (slices >= std::min(TMc + 1, 64)) {
           chain_slices[i] = slices;
           mine = compose_chain_bitmap_bytes(No, slices);
@@ -1129,7 +1145,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     const Structure& s1 = *bcast(av, n, i).s;
     if (s1.kind == KIND_EXPLICIT) g1_cache = std::max(g1_cache, compose_g1_cache_bytes(int(s1.N), int(s1.A)));
   }
-  const bool cache1 = lds_state && g1_cache > 0 && bitmap_bytes + int(g1_cache) <= compose_lds_budget();
+  const bool cache1 = lds_state && g1_cache > 0 && bitmap_bytes + int(g1_cache) <= compose_lds_budget(wide ? 1 : 0);
   const int dyn_fast = bitmap_bytes + (cache1 ? int(g1_cache) : 0);
   bool state_filled = false;
   auto fill_state = [&] {  // the general variant's HBM pair table starts as "unreached"
@@ -1159,7 +1175,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const bool full_env = getenv("GTNX_FULL_COMPOSE") != nullptr;
       const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
       const Structure& ex = l1 ? *b.s : *a.s;
-      x.skip = (!full_env && lds_state && l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) && ex.N <= 256)
+      x.skip = (!full_env && lds_state && l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) &&
+                ex.N <= (wide ? 512 : 256))
                    ? 1 : 0;
     }
     x.Ncap = int(c.Ncap);
@@ -1221,7 +1238,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         while (g1 < m && key_of(order[g1]) == key_of(order[g0])) ++g1;
         const int key = key_of(order[g0]);
         launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
-                       fast ? dyn_fast : int(classic_bm), fast ? 1 : 0, (fast && cache1) ? 1 : 0, rt.stream());
+                       fast ? dyn_fast : int(classic_bm), fast ? 1 : 0, (fast && cache1) ? 1 : 0,
+                       (fast && wide) ? 1 : 0, rt.stream());
         g0 = g1;
       }
     }

@@ -136,7 +136,10 @@ int sd_narrow_ring_backward();
 // with reach <= sd_narrow_ring_backward())
 // narrow == 2: as 1, plus the fused gradient scatter into the compose inputs (every
 // graph must satisfy fixed_A <= cap_fixed and chunk_levels * chain_C <= cap_chain)
-void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st);
+// fuse_lds_bytes (narrow == 2): dynamic LDS of the chain window, max over the batch of
+// chunk_levels * chain_C * 4
+void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st,
+                        int fuse_lds_bytes = 0);
 void sd_narrow_fuse_caps(int* cap_fixed, int* cap_chain);
 
 // viterbiPath pointer chase (shortest.cpp:239-245): writes path arc ids first-arc-first

@@ -476,8 +476,11 @@ struct SdOp : OpRecord {
     DevMemP d = upload_vec(args);
     {
       GTNX_PROF(mode == SD_LOG ? "forward_score_grad" : "viterbi_score_grad", alg);
+      int fuse_lds = 0;
+      if (fuse)
+        for (auto& a : args) fuse_lds = std::max(fuse_lds, 4 * std::max(a.chunk_levels, 1) * a.chain_C);
       launch_sd_backward(d->as<SdArgs>(), n, mode, narrow ? (fuse ? 2 : 1) : 0,
-                         int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream());
+                         int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream(), fuse_lds);
     }
     sink.flush();
   }

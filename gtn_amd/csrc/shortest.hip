@@ -627,7 +627,7 @@ __device__ __forceinline__ void lds_add_hot(float* win, int key, float val, bool
 
 constexpr int kRingB = 2048;
 constexpr int kWinF = 1024;  // explicit-input arcs (floats) -- fused scatter
-constexpr int kWinC = 1024;  // chain arcs of one chunk: chunk_levels * C
+constexpr int kWinC = 4096;  // most chain arcs of one chunk (chunk_levels * C); the window is dynamic LDS
 
 template <bool FUSE>
 __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs* __restrict__ args) {
@@ -644,10 +644,10 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
   __shared__ int tab_arc[kTab + 2];
   __shared__ __attribute__((aligned(16))) float g_buf[kCA];  // arc gradients of the chunk, flushed at the switch
   __shared__ float win_f[FUSE ? kWinF : 1];
-  __shared__ float win_c[FUSE ? kWinC : 1];
+  extern __shared__ float win_c[];  // FUSE: chunk_levels * chain_C floats (sized by the host)
   if (FUSE) {
     for (int x = tid; x < kWinF; x += kBlock) win_f[x] = 0.0f;
-    for (int x = tid; x < kWinC; x += kBlock) win_c[x] = 0.0f;
+    for (int x = tid; x < max(a.chunk_levels, 1) * a.chain_C; x += kBlock) win_c[x] = 0.0f;
   }
   const int CC = a.chain_C;
   gtnx_i4 gf_cur[kJA / 4], gc_cur[kJA / 4], gf_nxt[kJA / 4], gc_nxt[kJA / 4];
@@ -923,10 +923,11 @@ void sd_narrow_fuse_caps(int* cap_fixed, int* cap_chain) {
   *cap_chain = kWinC;
 }
 
-void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st) {
+void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int avg_out_degree_x16, hipStream_t st,
+                        int fuse_lds_bytes) {
   if (n <= 0) return;
   if (narrow && mode == SD_LOG) {
-    if (narrow == 2) hipLaunchKernelGGL(sd_backward_narrow_kernel<true>, dim3(n), dim3(kBlock), 0, st, d_args);
+    if (narrow == 2) hipLaunchKernelGGL(sd_backward_narrow_kernel<true>, dim3(n), dim3(kBlock), size_t(fuse_lds_bytes), st, d_args);
     else hipLaunchKernelGGL(sd_backward_narrow_kernel<false>, dim3(n), dim3(kBlock), 0, st, d_args);
     return;
   }

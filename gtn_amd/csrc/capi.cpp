@@ -41,6 +41,7 @@ inline Graph& GL(gtnx_graph_t h) {
 inline Graph& G(gtnx_graph_t h) {
   Graph& g = GL(h);
   if (g.s->lazy) realize(g);
+  if (g.s->deferred) g.s->resolve_sizes();  // sizes a compose left on the device
   return g;
 }
 inline gtnx_graph_t H(Graph g) { return reinterpret_cast<gtnx_graph_t>(new Graph(std::move(g))); }
@@ -82,7 +83,10 @@ GTNX_API gtnx_status_t gtnx_set_stream(void* s) {
 }
 GTNX_API gtnx_status_t gtnx_synchronize(void) {
   return guard([&] {
-    if (Runtime::initialized()) Runtime::get().sync();
+    if (Runtime::initialized()) {
+      Runtime::get().sync();
+      deferred_resolve_all();
+    }
   });
 }
 GTNX_API gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
@@ -537,13 +541,17 @@ GTNX_API gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out)
 
 // ------------------------------------------------------------------ profiling
 GTNX_API gtnx_status_t gtnx_prof_enable(int on) {
-  return guard([&] { Runtime::get().prof_enable(on != 0); });
+  return guard([&] {
+    if (!on) deferred_resolve_all();  // algorithmic bytes owed by unresolved compositions
+    Runtime::get().prof_enable(on != 0);
+  });
 }
 GTNX_API gtnx_status_t gtnx_prof_reset(void) {
   return guard([&] { Runtime::get().prof_reset(); });
 }
 GTNX_API gtnx_status_t gtnx_prof_get(const char* name, double* ms, int64_t* n, double* bytes) {
   return guard([&] {
+    deferred_resolve_all();
     ProfEntry e = Runtime::get().prof_get(name);
     if (ms) *ms = e.total_ms;
     if (n) *n = e.launches;

@@ -58,7 +58,97 @@ void Structure::materialize() {
   sched.reset();
 }
 
+// ---------------------------------------------------------------- deferred sizes
+void apply_compose_sizes(Structure& s, Weights* w, const ComposeOut& co, int n_start, int n_accept) {
+  s.N = co.N;
+  s.A = co.A;
+  DGraph& v = s.dview;
+  v.N = co.N;
+  v.A = co.A;
+  v.n_start = n_start;
+  v.n_accept = n_accept;
+  if (w) w->n = co.A;
+  if (s.partial) {
+    s.partial->args.N = co.N;
+    s.partial->args.A = co.A;
+  }
+  if (s.sched) {
+    Schedule& sc = *s.sched;
+    sc.n_in = co.A;
+    sc.n_out = co.A;
+    sc.max_level_width = co.max_width;
+    sc.max_level_arcs = co.max_level_arcs;
+    sc.max_reach = 2 * co.max_width;  // in-arcs come from the previous level only
+    sc.view.P = co.N;
+    sc.view.L = co.L;
+    sc.view.n_accept = n_accept;
+  }
+}
+
+namespace {
+std::mutex g_def_mu;
+std::vector<std::shared_ptr<DeferredSizes>> g_deferred;
+}
+void deferred_register(const std::shared_ptr<DeferredSizes>& d) {
+  std::lock_guard<std::mutex> lk(g_def_mu);
+  g_deferred.push_back(d);
+}
+void deferred_limit(size_t keep) {
+  for (;;) {
+    std::shared_ptr<DeferredSizes> d;
+    {
+      std::lock_guard<std::mutex> lk(g_def_mu);
+      // drop what is resolved already
+      while (!g_deferred.empty() && g_deferred.front()->done) g_deferred.erase(g_deferred.begin());
+      if (g_deferred.size() <= keep) return;
+      d = g_deferred.front();
+      g_deferred.erase(g_deferred.begin());
+    }
+    d->resolve();
+  }
+}
+void deferred_resolve_all() { deferred_limit(0); }
+
+DeferredSizes::~DeferredSizes() {
+  if (ev) (void)hipEventDestroy(ev);
+}
+
+void DeferredSizes::resolve() {
+  if (done) return;
+  done = true;
+  HIP_CHECK(hipEventSynchronize(ev));
+  const ComposeOut* outs = reinterpret_cast<const ComposeOut*>(host->as<char>(hdr_out));
+  const int* cnts = reinterpret_cast<const int*>(host->as<char>(hdr_cnt));
+  for (size_t i = 0; i < members.size(); ++i) {
+    const ComposeOut& co = outs[i];
+    if (co.overflow || !co.layered || !co.csr_built)
+      throw_runtime("[gtn::compose] internal: a deferred-size composition left the proven fast path (overflow " +
+                    std::to_string(co.overflow) + ", layered " + std::to_string(co.layered) + ", csr " +
+                    std::to_string(co.csr_built) + ", N " + std::to_string(co.N) + ", A " + std::to_string(co.A) + ")");
+    std::shared_ptr<Structure> s = members[i].s.lock();
+    if (!s) continue;
+    std::shared_ptr<Weights> w = members[i].w.lock();
+    apply_compose_sizes(*s, w.get(), co, cnts[2 * i], cnts[2 * i + 1]);
+    s->deferred.reset();
+  }
+  for (auto& gw : grads)
+    if (auto w = gw.w.lock()) w->n = outs[gw.member].A;
+  if (!prof.empty() && Runtime::initialized()) {
+    Runtime& rt = Runtime::get();
+    for (auto& p : prof)
+      rt.prof_add_bytes(p.name, p.per_arc * double(outs[p.member].A) + p.per_node * double(outs[p.member].N));
+  }
+  prof.clear();
+}
+
+void Structure::resolve_sizes() {
+  if (!deferred) return;
+  std::shared_ptr<DeferredSizes> d = deferred;  // resolve() clears the member
+  d->resolve();
+}
+
 void Structure::ensure_full() {
+  resolve_sizes();
   if (!partial) return;
   Runtime& rt = Runtime::get();
   std::shared_ptr<PartialInfo> p = partial;
@@ -341,6 +431,9 @@ void Graph::add_grad_host(const float* v, int64_t n) {
 void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
   if (!calc_grad()) return;
   Runtime& rt = Runtime::get();
+  // sizes still on the device: only the "first gradient, adopt the buffer" case can go
+  // on without them (the gradient graph's arc count is filled in when they arrive)
+  if (s->deferred && !(adopt && !is_grad_available())) s->resolve_sizes();
   int64_t n = s->A;
   std::lock_guard<std::mutex> lk(s->grad_lock);
   if (!is_grad_available()) {
@@ -348,6 +441,7 @@ void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
     Weights& gw = *g->grad->w;
     gw.n = n;
     gw.host_valid = false;
+    if (s->deferred) s->deferred->grads.push_back({g->grad->w, s->deferred_idx});
     if (adopt) {
       gw.dev_mem = owner;
       gw.dev = dev;

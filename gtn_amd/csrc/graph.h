@@ -12,6 +12,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "kernels.h"
@@ -47,6 +48,9 @@ struct Schedule {
   int64_t fixed_A = 0;               // arcs of the other input
   const int* gi_fixed = nullptr;     // gradInfo column of the explicit input
   const int* gi_chain = nullptr;     // gradInfo column of the chain
+  // the producing compose's result block on the device (sizes for the narrow kernels)
+  const struct ComposeOut* dyn_out = nullptr;
+  const int* dyn_counts = nullptr;
 };
 
 struct Structure {
@@ -71,6 +75,16 @@ struct Structure {
 
   std::shared_ptr<Schedule> sched;  // valid while the structure is unchanged
   std::mutex grad_lock;             // graph.h:450
+
+  // Non-null: a composition whose sizes (N, A, levels, start / accept counts) are still
+  // on the device -- the compose that produced it did not wait for them (DeferredSizes).
+  // N and A read -1 meanwhile; capN / capA bound them.  resolve_sizes() waits and fills in.
+  std::shared_ptr<struct DeferredSizes> deferred;
+  int deferred_idx = 0;
+  int64_t capN = 0, capA = 0;
+  void resolve_sizes();
+  int64_t bound_nodes() const { return deferred ? capN : N; }
+  int64_t bound_arcs() const { return deferred ? capA : A; }
 
   // Non-null: a device-built composition whose derivable arrays (src, il, ol, in_list)
   // have not been written yet (kernels.h: ComposeArgs::skip).  ensure_full() writes them;
@@ -147,6 +161,44 @@ struct Graph {
   void add_grad_host(const float* v, int64_t n);
   void add_grad_device(const DevMemP& owner, float* dev, bool adopt);
 };
+
+// Sizes of one compose batch left on the device.  For a chain product whose partner is
+// epsilon-free, no wider than a workgroup, with at most KC out-arcs per node, every
+// capacity and every fast-path condition of compose_kernel is provable on the host, so
+// nothing the host does next depends on the actual sizes: the CTC / ASG loss path
+// (forwardScore, its backward) sizes its buffers by the bounds and the kernels read N, L
+// and the accept count from the ComposeOut block on the device.  The header is copied
+// to pinned memory behind the kernel; whoever needs real numbers first (inspection,
+// another op) waits on the event -- see resolve().
+struct DeferredSizes {
+  hipEvent_t ev = nullptr;
+  PinnedMemP host;
+  size_t hdr_out = 0, hdr_cnt = 0;
+  bool done = false;
+  struct Member {
+    std::weak_ptr<Structure> s;
+    std::weak_ptr<Weights> w;
+  };
+  std::vector<Member> members;
+  struct GradW {
+    std::weak_ptr<Weights> w;
+    int member;
+  };
+  std::vector<GradW> grads;        // gradient graphs adopted meanwhile: their n is A
+  struct ProfFix {
+    std::string name;
+    double per_arc, per_node;
+    int member;
+  };
+  std::vector<ProfFix> prof;       // algorithmic bytes owed to the profiler
+  void resolve();
+  ~DeferredSizes();
+};
+// compose batches still unresolved, oldest first; the run-ahead of the host is capped
+void deferred_register(const std::shared_ptr<DeferredSizes>& d);
+void deferred_resolve_all();
+void deferred_limit(size_t keep);
+void apply_compose_sizes(Structure& s, Weights* w, const ComposeOut& co, int n_start, int n_accept);
 
 struct PartialInfo {
   ComposeFillArgs args{};                // pointers into the product's own arena

@@ -110,6 +110,10 @@ struct SdArgs {
   GTNX_G float* node_grad;    // [P]
   GTNX_G float* arc_grad;     // [A] arc-id order
   int chunk_levels;           // narrow kernels: levels per LDS chunk (host: caps / widest level)
+  // narrow kernels: when set, P / L / accept count are read from the producing compose's
+  // result block on the device (the host may not know them yet -- graph.h DeferredSizes)
+  const GTNX_G struct ComposeOut* dyn_out;
+  const GTNX_G int* dyn_counts;
   // fused compose-gradient scatter (narrow backward only; see sd_narrow_fuse_caps):
   // arc k of the lattice came from arc gi_fixed[k] of the explicit compose input and
   // arc gi_chain[k] of the linear chain, whose arcs of level l lie in [l*C, (l+1)*C)

@@ -101,6 +101,7 @@ void GradSink::flush() {
       g.add_grad_device(it.owner, it.ptr, /*adopt=*/true);
       continue;
     }
+    g.s->resolve_sizes();  // accumulating into an existing gradient needs the arc count
     Weights& gw = *g.g->grad->w;
     if (!gw.dev_valid || gw.host_escaped) {
       std::vector<Weights*> v{&gw};
@@ -360,9 +361,10 @@ struct SdOp : OpRecord {
     bool need_zero = false;
     for (int i = 0; i < n; ++i) {
       Graph& in = ms[i].out.g->inputs[0];
+      if (in.s->deferred && mode != SD_LOG) in.s->resolve_sizes();
       const Saved& sv = saved[ms[i].idx];
       off_a[i] = bytes;
-      bytes = align_up(bytes + 4 * size_t(in.num_arcs()), 256);
+      bytes = align_up(bytes + 4 * size_t(in.s->bound_arcs()), 256);
       off_n[i] = bytes;
       bytes = align_up(bytes + 4 * size_t(sv.sched->view.P), 256);
       need_zero |= !sv.sched->all_written;
@@ -381,7 +383,7 @@ struct SdOp : OpRecord {
       narrow = narrow && tot_levels >= 32 * int64_t(n);
     }
     if (!narrow)
-      for (int i = 0; i < n; ++i) ms[i].out.g->inputs[0].s->ensure_full();
+      for (int i = 0; i < n; ++i) ms[i].out.g->inputs[0].s->ensure_full();  // (waits for deferred sizes too)
     // Fused compose-gradient scatter: when every lattice of the batch is a layered
     // product with one linear chain, produced by a compose whose ONLY consumer is
     // this forwardScore and which holds no gradient yet, the kernel sums the arc
@@ -467,11 +469,20 @@ struct SdOp : OpRecord {
         }
         if (a.grad_chain && !in_place) sink.add(chain, fg, a.grad_chain);
         in.g->grad_propagated = true;
-        alg += 8.0 * double(in.num_arcs()) + 4.0 * double(fixed.num_arcs() + chain.num_arcs());
+        alg += 4.0 * double(fixed.num_arcs() + chain.num_arcs());
       }
       tot_out += sv.sched->n_out;
       tot_p += sv.sched->view.P;
-      alg += 12.0 * double(in.num_arcs()) + 12.0 * double(sv.sched->view.P);
+      const char* pname = mode == SD_LOG ? "forward_score_grad" : "viterbi_score_grad";
+      if (in.s->deferred) {
+        if (rt.prof_on()) in.s->deferred->prof.push_back({pname, fuse ? 20.0 : 12.0, 12.0, in.s->deferred_idx});
+      } else {
+        alg += (fuse ? 20.0 : 12.0) * double(in.num_arcs()) + 12.0 * double(sv.sched->view.P);
+      }
+      if (narrow) {
+        a.dyn_out = sv.sched->dyn_out;
+        a.dyn_counts = sv.sched->dyn_counts;
+      }
     }
     DevMemP d = upload_vec(args);
     {
@@ -559,6 +570,10 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
   // ---- general DAGs: level-scheduled persistent kernel
   if (!exp.empty()) {
     const int m = int(exp.size());
+    // lattices whose sizes are still on the device stay that way only for the
+    // log-semiring narrow kernel (bounds suffice on the host); everything else waits
+    for (int i : exp)
+      if (gs[i].s->deferred && (tropical || !gs[i].s->sched)) gs[i].s->resolve_sizes();
     std::vector<Structure*> ss;
     for (int i : exp) ss.push_back(gs[i].s.get());
     ensure_schedule_batch(ss, false);
@@ -597,10 +612,13 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       tot_levels += sc.view.L;
     }
     narrow = narrow && tot_levels >= 32 * int64_t(m);
+    if (!narrow)
+      for (int k = 0; k < m; ++k) gs[exp[k]].s->resolve_sizes();  // generic kernels take sizes from the host
     for (int k = 0; k < m; ++k) {
       Graph& g = gs[exp[k]];
       Schedule& sc = *g.s->sched;
       SdArgs& a = args[k];
+      std::memset(&a, 0, sizeof(a));
       a.s = sched_view(g, /*need_full=*/!narrow);  // the narrow kernel reads in_src / in_w / row offsets only
       a.w = g.w->dev;
       a.scores = arena->as<float>(off_s[k]);
@@ -612,11 +630,20 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       a.arc_grad = nullptr;
       a.chunk_levels = std::max(1, std::min(sd_narrow_tmp_cap() / std::max(sc.max_level_arcs, 1),
                                             sd_narrow_node_cap() / std::max(sc.max_level_width, 1)));
+      if (narrow) {
+        a.dyn_out = sc.dyn_out;
+        a.dyn_counts = sc.dyn_counts;
+      }
       op->saved[k] = {g.s->sched, a.scores, a.argmax, a.result};
       tot_in += sc.n_in;
       tot_p += sc.view.P;
       maxw = std::max(maxw, sc.max_level_width);
-      alg += 8.0 * double(g.num_arcs()) + 8.0 * double(g.num_nodes());
+      if (g.s->deferred) {
+        if (rt.prof_on())
+          g.s->deferred->prof.push_back({tropical ? "viterbi_score" : "forward_score", 8.0, 8.0, g.s->deferred_idx});
+      } else {
+        alg += 8.0 * double(g.num_arcs()) + 8.0 * double(g.num_nodes());
+      }
       Graph out = make_output(op, k, {g});
       init_scalar_structure(out);
       set_dev_weights(out, arena, a.out_score, 1);
@@ -813,6 +840,7 @@ struct ComposeOp : OpRecord {
     int A;
   };
   std::vector<Saved> saved;
+  std::shared_ptr<DeferredSizes> deferred;  // sizes of the batch still on the device
   void backward(std::vector<Member>& all) override {
     Runtime& rt = Runtime::get();
     // members whose consumer already scattered their gradient (SdOp::backward, fused)
@@ -822,6 +850,10 @@ struct ComposeOp : OpRecord {
       else ms.push_back(m);
     }
     if (ms.empty()) return;
+    if (deferred) {  // the separate gradient kernel needs the arc counts
+      deferred->resolve();
+      for (auto& m : ms) saved[m.idx].A = int(m.out.s->A);
+    }
     const int n = int(ms.size());
     size_t bytes = 0;
     std::vector<size_t> o1(n), o2(n);
@@ -935,6 +967,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   ht_phase("");
   for (auto& g : av) realize(g);
   for (auto& g : bv) realize(g);
+  for (auto& g : av) g.s->resolve_sizes();
+  for (auto& g : bv) g.s->resolve_sizes();
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
   for (size_t i = 0; i < n; ++i) {
@@ -1097,7 +1131,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   // not depend on the chain length.  `fast_ok`: every pair fits one of them (FAST variant);
   // `classic_ok[i]`: the general variant may keep pair i's classic bitmaps in LDS.
   std::vector<int> chain_slices(n, 0);
-  std::vector<char> classic_ok(n, 0);
+  std::vector<char> classic_ok(n, 0), full_window(n, 0);
   size_t fast_bm = 0, classic_bm = 0;
   bool fast_ok = true;
   // 512-lane workgroups when some chain product's partner has 257..512 nodes (and none more)
@@ -1129,8 +1163,11 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       if (!no_chain && l1 != l2 && ((l1 ? s2 : s1).dview.flags & GF_EPS_FREE)) {
         const int No = int((l1 ? s2 : s1).N), TMc = (l1 ? s1 : s2).M;
         const int64_t room = int64_t(budget / (4 * size_t((No + 31) / 32))) - 3;
-        // stationarity of the co-reachable set arrives within ~No steps, if at all
-        const int slices = int(std::min<int64_t>(std::min<int64_t>(TMc + 1, No + 64), room));
+        // a window over ALL times when it fits (then the fast variant cannot run out of
+        // slices); else ~No slices: stationarity arrives within that many steps, if at all
+        int slices = int(std::min<int64_t>(TMc + 1, room));
+        if (slices < TMc + 1) slices = int(std::min<int64_t>(No + 64, room));
+        full_window[i] = slices >= TMc + 1;
         if (slices >= std::min(TMc + 1, 64)) {
           chain_slices[i] = slices;
           mine = compose_chain_bitmap_bytes(No, slices);
@@ -1208,6 +1245,25 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     x.counts = reinterpret_cast<int*>(rp + hdr_cnt) + 2 * i;
     x.out = reinterpret_cast<ComposeOut*>(rp + hdr_out) + i;
   }
+  // ---- may the sizes stay on the device (graph.h: DeferredSizes)?  Every pair must be a
+  // chain product the FAST variant provably finishes: single-chunk levels (partner no
+  // wider than the workgroup), at most KC candidates per node (out-degree), a level's
+  // arcs within the claim hash, a bitmap window over all times, arrays left out.
+  bool defer = lds_state && n > 0 && !getenv("GTNX_SYNC_COMPOSE");
+  for (size_t i = 0; i < n && defer; ++i) {
+    Graph& a = const_cast<Graph&>(bcast(av, n, i));
+    Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+    const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
+    defer = l1 != l2 && args[i].skip && full_window[i] && chain_slices[i] > 0;
+    if (!defer) break;
+    Structure& ex = l1 ? *b.s : *a.s;
+    ex.ensure_host();
+    ex.ensure_csr();
+    int max_deg = 0;  // phase B walks in-lists, phase F out-lists: both within KC candidates
+    for (int64_t nn = 0; nn < ex.N; ++nn)
+      max_deg = std::max(max_deg, std::max(ex.out_off[nn + 1] - ex.out_off[nn], ex.in_off[nn + 1] - ex.in_off[nn]));
+    defer = max_deg <= 4 && ex.A <= (wide ? 1536 : 768) && ex.N >= 1 && (l1 ? a : b).s->M >= 1;
+  }
   ht_phase("compose.3_alloc_args");
   // Launch groups share a kernel instantiation: (matcher, g1 linear, g2 linear).
   // First pass: the compact LDS-only variant when the pair tables fit; pairs it
@@ -1221,6 +1277,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   const int* res_counts = reinterpret_cast<const int*>(hdr.data() + hdr_cnt);
   double alg = 0;
   for (size_t i = 0; i < n; ++i) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
+  std::shared_ptr<DeferredSizes> deferred;
   auto run = [&](std::vector<size_t> order, bool fast) {
     const size_t m = order.size();
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
@@ -1246,6 +1303,18 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         g0 = g1;
       }
     }
+    if (defer && fast) {
+      // no wait: the header follows the kernel into pinned memory, an event marks it
+      rt.drain_deferred();
+      deferred = std::make_shared<DeferredSizes>();
+      deferred->host = rt.alloc_pinned(hdr.size());
+      deferred->hdr_out = hdr_out;
+      deferred->hdr_cnt = hdr_cnt;
+      HIP_CHECK(hipMemcpyAsync(deferred->host->ptr, res->ptr, hdr.size(), hipMemcpyDeviceToHost, rt.stream()));
+      HIP_CHECK(hipEventCreateWithFlags(&deferred->ev, hipEventDisableTiming));
+      HIP_CHECK(hipEventRecord(deferred->ev, rt.stream()));
+      return;
+    }
     // sizes back to the host: the contiguous header block, one copy, one sync
     rt.d2h_sync(hdr.data(), res->ptr, hdr.size());
     // products whose in-arc CSR / start & accept lists were not produced inside the
@@ -1267,11 +1336,12 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   {
     std::vector<size_t> all(n);
     for (size_t i = 0; i < n; ++i) all[i] = i;
+    if (defer) deferred_limit(1);  // the host runs at most two batches ahead of the GPU
     run(all, lds_state);
     std::vector<size_t> redo;
-    for (size_t i = 0; i < n; ++i)
+    for (size_t i = 0; i < n && !deferred; ++i)
       if (res_out[i].overflow == 2) redo.push_back(i);
-    if (getenv("GTNX_COMPOSE_STATS"))
+    if (getenv("GTNX_COMPOSE_STATS") && !deferred)
       fprintf(stderr, "[gtnx] compose: n=%zu redo=%zu graph0: N=%d A=%d levels=%d replicated=%d  us: B=%.0f F=%.0f (rep %.0f)\n", n, redo.size(),
               res_out[0].N, res_out[0].A, res_out[0].L, res_out[0].rep_levels, res_out[0].t_b * 0.01,
               res_out[0].t_f * 0.01, res_out[0].t_rep * 0.01);
@@ -1284,7 +1354,13 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   op->arena = res;
   op->saved.resize(n);
   for (size_t i = 0; i < n; ++i) {
-    const ComposeOut& co = res_out[i];
+    ComposeOut co = deferred ? ComposeOut{} : res_out[i];
+    if (deferred) {  // what the proven fast path guarantees; the numbers come later
+      co.layered = 1;
+      co.csr_built = 1;
+      co.skipped = 1;
+      co.N = co.A = -1;
+    }
     if (co.overflow) throw_runtime("[gtn::compose] internal capacity bound exceeded");
     const ComposeArgs& x = args[i];
     Graph& a = const_cast<Graph&>(bcast(av, n, i));
@@ -1302,8 +1378,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     v.kind = KIND_EXPLICIT;
     v.N = co.N;
     v.A = co.A;
-    v.n_start = res_counts[2 * i];
-    v.n_accept = res_counts[2 * i + 1];
+    v.n_start = deferred ? -1 : res_counts[2 * i];
+    v.n_accept = deferred ? -1 : res_counts[2 * i + 1];
     v.flags = 0;
     v.src = x.src;
     v.dst = x.dst;
@@ -1372,8 +1448,22 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       sc->in_w = x.in_w;
       sc->in_w_of = out.w.get();
       sc->in_w_version = out.w->version;
+      sc->dyn_out = x.out;
+      sc->dyn_counts = x.counts;
       // exactly one implicit chain and an epsilon-free partner: level == chain time
       const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
+      if (deferred) {
+        // bounds in place of the numbers (the kernels read the real ones on the device)
+        const Structure& ex = l1 ? *b.s : *a.s;
+        const Structure& ch = l1 ? *a.s : *b.s;
+        sc->n_in = sc->n_out = caps[i].Acap;
+        sc->max_level_width = int(ex.N);
+        sc->max_level_arcs = int(caps[i].Acap / std::max(ch.M, 1));
+        sc->max_reach = 2 * int(ex.N);
+        d.P = int(caps[i].Ncap);
+        d.L = ch.M + 1;
+        d.n_accept = 0;
+      }
       if (l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) && out.calc_grad()) {
         sc->producer_seq = op->seq;
         sc->chain_side = l1 ? 1 : 2;
@@ -1385,7 +1475,18 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       s.sched = sc;
     }
     op->saved[i] = {x.gi1, x.gi2, co.A};
+    if (deferred) {
+      s.deferred = deferred;
+      s.deferred_idx = int(i);
+      s.capN = caps[i].Ncap;
+      s.capA = caps[i].Acap;
+      deferred->members.push_back({out.s, out.w});
+    }
     outs.push_back(std::move(out));
+  }
+  if (deferred) {
+    op->deferred = deferred;
+    deferred_register(deferred);
   }
   ht_phase("compose.5_outputs");
   return outs;
@@ -1801,6 +1902,7 @@ void realize(Graph& g) {
   std::vector<Graph> av{lp.chain_side == 1 ? lp.chain : lp.fixed}, bv{lp.chain_side == 1 ? lp.fixed : lp.chain};
   std::vector<Graph> r = op_compose_impl(av, bv, lp.intersect, false);
   Graph& real = r[0];
+  real.s->resolve_sizes();  // the pieces move into `g` below: they must be final
   Structure& d = *g.s;
   Structure& o = *real.s;
   d.kind = o.kind;

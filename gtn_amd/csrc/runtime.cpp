@@ -258,6 +258,8 @@ Runtime::Scope::~Scope() {
   if (idx >= 0) (void)hipEventRecord(rt->prof_recs_[idx].b, rt->stream_);
 }
 
+void Runtime::prof_add_bytes(const std::string& name, double bytes) { prof_[name].bytes += bytes; }
+
 void Runtime::collect_prof() {
   if (prof_recs_.empty()) return;
   (void)hipStreamSynchronize(stream_);

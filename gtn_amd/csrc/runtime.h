@@ -75,6 +75,7 @@ class Runtime {
 
   // ---- profiler: hipEvent pairs around kernel families on the launch stream
   void prof_enable(bool on);
+  void prof_add_bytes(const std::string& name, double bytes);  // late algorithmic-byte credit
   void prof_reset();
   bool prof_on() const { return prof_on_; }
   struct Scope {

@@ -231,7 +231,12 @@ constexpr int kJA = kCA / kBlock, kJN = kCN / kBlock;
 template <bool HAS_INW>
 __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs* __restrict__ args) {
   const SdArgs a = args[blockIdx.x];
-  const DSched s = a.s;
+  DSched s = a.s;
+  if (a.dyn_out) {  // sizes straight from the compose that built the lattice
+    s.P = a.dyn_out->N;
+    s.L = a.dyn_out->L;
+    s.n_accept = a.dyn_counts[1];
+  }
   const int tid = threadIdx.x;
   __shared__ float ring[kRing];
   // arc_sp holds BYTE offsets into `ring` ((position & (kRing-1)) * 4, applied once at
@@ -632,7 +637,12 @@ constexpr int kWinC = 4096;  // most chain arcs of one chunk (chunk_levels * C);
 template <bool FUSE>
 __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs* __restrict__ args) {
   const SdArgs a = args[blockIdx.x];
-  const DSched s = a.s;
+  DSched s = a.s;
+  if (a.dyn_out) {
+    s.P = a.dyn_out->N;
+    s.L = a.dyn_out->L;
+    s.n_accept = a.dyn_counts[1];
+  }
   const int tid = threadIdx.x;
   __shared__ float sc_ring[kRingB];
   __shared__ float ng_ring[kRingB];

@@ -540,10 +540,11 @@ def test_full_size_c3_invariants(gtn):
     assert abs(float(-g0.sum()) - T) < 0.5          # one lattice arc per time step in expectation
 
 
-@pytest.mark.parametrize("var", ["GTNX_FULL_COMPOSE", "GTNX_NO_FUSED_SCATTER"])
+@pytest.mark.parametrize("var", ["GTNX_FULL_COMPOSE", "GTNX_NO_FUSED_SCATTER", "GTNX_SYNC_COMPOSE", "GTNX_CLASSIC_BITMAPS"])
 def test_alternative_code_paths_give_the_same_results(gtn, var):
-    """README 'Runtime switches': the eager (all arrays written) compose and the unfused
-    compose-gradient kernel against the same oracle checks as the default paths"""
+    """README 'Runtime switches': the eager (all arrays written) compose, the unfused
+    compose-gradient kernel, the synchronous size read-back and the pair-indexed bitmaps
+    against the same oracle checks as the default paths"""
     import os
     os.environ[var] = "1"
     try:

@@ -184,7 +184,7 @@ def main():
             ctcs = build_ctc_graphs(gtn, tg)
             ems = gtn.linear_graph_n(B, T, Cn, em_dev)
             comp = gtn.intersect(ctcs, ems)
-            loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))
+            loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))  # Python: left to right
             gtn.backward(loss)
             gtn.items_to_device(loss, loss_dev)
             if world > 1:

@@ -54,7 +54,10 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
     auto t2 = now();
     auto comp = batched::intersect(ctcs, ems);
     auto t3 = now();
-    auto losses = batched::subtract(batched::forwardScore(ems), batched::forwardScore(comp));
+    // (named in this order: C++ leaves the evaluation order of call arguments open)
+    auto norm = batched::forwardScore(ems);
+    auto score = batched::forwardScore(comp);
+    auto losses = batched::subtract(norm, score);
     auto t4 = now();
     // bwd of benchmarks/ctc.cpp:160
     batched::backward(losses);

@@ -372,6 +372,10 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
   // step -- ids + W, arc ids + Aw, chain arc + C -- and is emitted from registers
   // for all remaining stationary t at once instead of one BFS level at a time.
   const bool skip = FAST && a.skip != 0;  // derivable arrays are left out (see ComposeArgs::skip)
+  // pair -> node id table in HBM: only ever read back for pairs discovered in an earlier
+  // chunk of the same level or across levels (non-layered arcs); with single-chunk levels
+  // (skip) in the time-windowed layout neither can happen, so the writes are dropped too
+  const bool no_state = skip && (FAST && (L1 != L2)) && a.chain_bits > 0;
   constexpr bool REP = FAST && (L1 != L2);
   const bool rep_ok = REP && ((L2 ? a.g1.flags : a.g2.flags) & GF_EPS_FREE);
   const int tshift = L2 ? N1 : 1;           // pair-id step per time step
@@ -621,7 +625,7 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
           a.in_off[id] = 0;  // level 0 has no in-arcs in a layered product
           if (id < FC) front[0][id] = idx;
           if (lds_state && !CH) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
-          st_state(a.state + idx, id);
+          if (!no_state) st_state(a.state + idx, id);
         } else {
           sh_flag[1] = 1;
         }
@@ -834,7 +838,7 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
                 const int n = other_of(idx, L + 1);
                 atomicOr(&disc2[((L + 1) & 1) * NoW + (n >> 5)], 1u << (n & 31));
               } else if (lds_state) atomicOr(&disc_bits[idx >> 5], 1u << (idx & 31));
-              st_state(a.state + idx, id);
+              if (!no_state) st_state(a.state + idx, id);
             } else {
               hids[slot[m]] = 0;
               sh_flag[1] = 1;

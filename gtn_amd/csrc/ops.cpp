@@ -1193,7 +1193,11 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     state_filled = true;
   };
   if (!lds_state) fill_state();
-  HIP_CHECK(hipMemsetAsync(cu_mem->ptr, 0, cu_b ? cu_b : 1, rt.stream()));
+  bool cursors_zeroed = false;
+  auto zero_cursors = [&] {  // in-degree cursors of the transpose passes
+    if (!cursors_zeroed) HIP_CHECK(hipMemsetAsync(cu_mem->ptr, 0, cu_b ? cu_b : 1, rt.stream()));
+    cursors_zeroed = true;
+  };
   std::vector<ComposeArgs> args(n);
   for (size_t i = 0; i < n; ++i) {
     const Cap& c = caps[i];
@@ -1326,6 +1330,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       need_tr = need_tr || (!co.csr_built && co.overflow == 0);
     }
     if (need_tr) {
+      zero_cursors();
       {
         GTNX_PROF("compose_transpose", 0.0);
         launch_compose_transpose(dargs->as<ComposeArgs>(), int(m), int(maxA), int(maxN), tscratch->ptr, rt.stream());

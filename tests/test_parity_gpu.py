@@ -552,3 +552,67 @@ def test_alternative_code_paths_give_the_same_results(gtn, var):
         test_compose_linear_first_structure_vs_oracle(gtn, 120, 20, 8)
     finally:
         os.environ.pop(var, None)
+
+
+def _ctc_flow(gtn, B, T, C, U, seed, ops):
+    """one CTC batch pushed through a list of follow-up uses of the lattice; returns plain data"""
+    import torch
+    em, tg = gg.ctc_inputs(seed, B, T, C, U)
+    ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+    ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    comp = gtn.intersect(ctcs, ems)
+    out = {}
+    fs = gtn.forward_score(comp)
+    loss = gtn.subtract(gtn.forward_score(ems), fs)
+    if "retain2" in ops:
+        gtn.backward(loss, retain_graph=True)
+        gtn.backward(loss, retain_graph=True)
+    else:
+        gtn.backward(loss)
+    out["loss"] = gtn.items(loss)
+    out["gem"] = [e.grad().weights_to_numpy() for e in ems]
+    out["gctc"] = [c.grad().weights_to_numpy() for c in ctcs]
+    # the lattice's own gradient is the caller's to read (shortest.cpp:81, graph.cpp:91-129)
+    out["gcomp_sum"] = [float(c.grad().weights_to_numpy().sum()) for c in comp]
+    out["gcomp_n"] = [c.grad().num_arcs() for c in comp]
+    out["sizes"] = [(c.num_nodes(), c.num_arcs(), c.num_start(), c.num_accept()) for c in comp]
+    out["vit"] = [p.labels_to_list() for p in gtn.viterbi_path(comp)]
+    out["vs"] = gtn.items(gtn.viterbi_score(comp))
+    out["arcs0"] = gg.from_api(comp[0])
+    # the lattice as an INPUT of another composition (records built from the derived arrays)
+    again = gtn.intersect([comp[0]], [comp[0]])[0]
+    out["self_intersect"] = (again.num_nodes(), again.num_arcs())
+    out["copy_equal"] = gtn.equal(comp[1], comp[1].deep_copy())
+    return out
+
+
+@pytest.mark.parametrize("ops", [(), ("retain2",)])
+def test_deferred_and_partial_lattices_behave_like_eager_ones(gtn, ops):
+    """the default path (sizes left on the device, derivable arrays left out, fused
+    scatter) against the fully eager one on every later use of the lattice: gradients
+    (also over a retained tape, twice), the lattice's own gradient, sizes, Viterbi,
+    download, and the lattice as an input of another composition"""
+    import os
+    eager_env = ["GTNX_SYNC_COMPOSE", "GTNX_FULL_COMPOSE", "GTNX_NO_FUSED_SCATTER"]
+    fast = _ctc_flow(gtn, 3, 90, 14, 9, 77, ops)
+    for v in eager_env:
+        os.environ[v] = "1"
+    try:
+        slow = _ctc_flow(gtn, 3, 90, 14, 9, 77, ops)
+    finally:
+        for v in eager_env:
+            os.environ.pop(v, None)
+    np.testing.assert_allclose(fast["loss"], slow["loss"], rtol=1e-5)
+    for a, b in zip(fast["gem"], slow["gem"]):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-5)
+    for a, b in zip(fast["gctc"], slow["gctc"]):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(fast["gcomp_sum"], slow["gcomp_sum"], rtol=1e-4)
+    assert fast["gcomp_n"] == slow["gcomp_n"] == [s[1] for s in slow["sizes"]]
+    assert fast["sizes"] == slow["sizes"]
+    assert fast["vit"] == slow["vit"]
+    np.testing.assert_allclose(fast["vs"], slow["vs"], rtol=1e-6)
+    for k in ("start", "accept", "src", "dst", "il", "ol"):
+        assert fast["arcs0"][k] == slow["arcs0"][k], k
+    assert fast["self_intersect"] == slow["self_intersect"]
+    assert fast["copy_equal"] and slow["copy_equal"]

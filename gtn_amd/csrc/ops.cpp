@@ -17,7 +17,6 @@ namespace gtnx {
 namespace {
 std::atomic<uint64_t> g_seq{1};
 
-const float NEG_INF_F = -__builtin_huge_valf();
 
 // ---- the constant structure of a scalar result (functions.cpp:26-28, shortest.cpp:183-186)
 void init_scalar_structure(Graph& g) {

@@ -323,9 +323,6 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     for (int j = 0; j < kJN; ++j) node_fl[b][tid + j * kBlock] = uint8_t(st_fl[j]);
   };
 
-#ifdef GTNX_TIMING
-  long long tm_upd = 0, tm_pre = 0, tm_bar = 0, tm_sw = 0, tm_w = 0, tm_l = 0, tm_last = wall_clock64();
-#endif
   for (int l0 = 0; l0 < s.L; l0 += kTab) {
     const int nl = min(kTab, s.L - l0);
     __syncthreads();
@@ -409,19 +406,9 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
         ring[p & (kRing - 1)] = out;
       };
       preload(c);
-#ifdef GTNX_TIMING
-      long long t0 = wall_clock64(), t1;
-      tm_sw += t0 - tm_last;
-#endif
       for (int i = c; i < e; ++i) {
         const int nhi = q_nhi;
-#ifdef GTNX_TIMING
-        t0 = wall_clock64();
-#endif
         if (q_p < nhi) node_update(q_p, q_r0, q_deg, q_fl, q_sp, q_w);
-#ifdef GTNX_TIMING
-        t1 = wall_clock64(); tm_upd += t1 - t0; t0 = t1;
-#endif
         for (int p = q_p + kBlock; p < nhi; p += kBlock) {  // levels wider than the workgroup
           const int r0 = node_off[b][p - n0] - a0, deg = node_off[b][p - n0 + 1] - a0 - r0;
           int sp4[4];
@@ -434,14 +421,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
           node_update(p, r0, deg, node_fl[b][p - n0], sp4, w4);
         }
         if (i + 1 < e) preload(i + 1);
-#ifdef GTNX_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        t1 = wall_clock64(); tm_pre += t1 - t0; t0 = t1;
-#endif
         lds_barrier();
-#ifdef GTNX_TIMING
-        t1 = wall_clock64(); tm_bar += t1 - t0; tm_last = t1;
-#endif
       }
       // ---- chunk switch: land the staged chunk, refill the registers, THEN flush
       // the finished scores -- the vmcnt(0) in front of stage_write() must only
@@ -452,19 +432,9 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
       e = e2;
       b ^= 1;
       if (c < nl) {
-#ifdef GTNX_TIMING
-        long long u0 = wall_clock64(), u1;
-#endif
         stage_write(b);
-#ifdef GTNX_TIMING
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        u1 = wall_clock64(); tm_w += u1 - u0; u0 = u1;
-#endif
         e2 = e < nl ? chunk_end(e, nl) : e;
         if (e < nl) stage_load(tab_arc[e], tab_arc[e2], tab_node[e]);
-#ifdef GTNX_TIMING
-        u1 = wall_clock64(); tm_l += u1 - u0;
-#endif
       }
       (void)pc; (void)pe;
       for (int p = n0 + tid; p < n1; p += kBlock) scores[p] = ring[p & (kRing - 1)];
@@ -472,10 +442,6 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     }
   }
   __syncthreads();  // scores[] stores visible before the accept reduction reads them
-#ifdef GTNX_TIMING
-  if (blockIdx.x == 0 && tid == 0)
-    printf("fwd narrow: L %d update %lld preload %lld barrier %lld switch %lld (stage_write %lld, chunk_end+stage_load %lld) (10ns ticks)\n", s.L, tm_upd, tm_pre, tm_bar, tm_sw, tm_w, tm_l);
-#endif
 
   // ---- accept reduction (identical to the generic kernel)
   __shared__ float sh_v[kBlock];
@@ -669,9 +635,6 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
 #pragma unroll
   for (int x = 0; x < kJA; ++x) { f_key[x] = -1; f_acc[x] = 0.0f; }
   const GTNX_G int* __restrict__ out_off = s.out_off;
-  const GTNX_G int* __restrict__ out_dst = s.out_dstpos;
-  const GTNX_G uint8_t* __restrict__ pflags = s.pflags;
-  const GTNX_G float* __restrict__ scores = a.scores;
   const int last_node = s.P > 0 ? s.P - 1 : 0;
   const SdResult res = *a.result;
   const float delta = *a.delta;

@@ -616,3 +616,62 @@ def test_deferred_and_partial_lattices_behave_like_eager_ones(gtn, ops):
         assert fast["arcs0"][k] == slow["arcs0"][k], k
     assert fast["self_intersect"] == slow["self_intersect"]
     assert fast["copy_equal"] and slow["copy_equal"]
+
+
+@pytest.mark.parametrize("T,C,target", [
+    (1, 4, [2]),             # one frame, one label
+    (2, 4, [1, 1]),          # needs 3 frames (blank between repeats): no path
+    (3, 4, [1, 1]),          # exactly enough
+    (5, 3, []),              # empty target: blanks only
+    (4, 3, [2, 7]),          # a label outside the alphabet never matches
+    (40, 6, [5, 4, 3, 2, 1] * 3),
+    (300, 5, [1, 2] * 130),  # 521-state target: wider than any fast variant
+])
+def test_ctc_edge_shapes_vs_oracle(gtn, T, C, target):
+    """corner shapes through the default (deferred / windowed / fused) paths"""
+    rng = np.random.default_rng(len(target) * 1000 + T)
+    em = rng.normal(0, 1, (T, C)).astype(np.float32)
+    tgt = gg.ctc_target_graph(target)
+    e = gtn.linear_graph(T, C)
+    e.set_weights(em)
+    ctc = gg.to_api(gtn, tgt)
+    comp = gtn.intersect(ctc, e)
+    fs = gtn.forward_score(comp)
+    oc = OGraph.from_dict(tgt).compose(OGraph.linear(T, C, em), "intersect")
+    want = oc.shortest_distance()
+    got = fs.item()
+    if np.isinf(want):
+        assert got == want
+    else:
+        assert got == pytest.approx(want, rel=RTOL, abs=1e-5)
+        gtn.backward(fs)
+        g1, g2 = oc.compose_grad(oc.shortest_distance_grad(), len(tgt["src"]), T * C)
+        np.testing.assert_allclose(e.grad().weights_to_numpy(), g2, rtol=1e-3, atol=1e-5)
+        if len(tgt["src"]):
+            np.testing.assert_allclose(ctc.grad().weights_to_numpy(), g1, rtol=1e-3, atol=1e-4)
+    assert (comp.num_nodes(), comp.num_arcs()) == (oc.N, oc.A)
+    d, o = gg.from_api(comp), oc.to_dict()
+    for k in ("start", "accept", "src", "dst", "il", "ol"):
+        assert d[k] == o[k], k
+
+
+def test_shared_target_graph_broadcasts(gtn):
+    """one target graph against a batch of emissions (parallel_map.h:77-89 broadcast):
+    its gradient accumulates over the batch"""
+    import torch
+    B, T, C = 5, 50, 8
+    em, tg = gg.ctc_inputs(3, B, T, C, 6)
+    tgt = gg.ctc_target_graph(tg[0].tolist())
+    ctc = gg.to_api(gtn, tgt)
+    ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+    fs = gtn.forward_score(gtn.intersect([ctc], ems))
+    gtn.backward(fs)
+    got = gtn.items(fs)
+    acc = np.zeros(len(tgt["src"]), np.float64)
+    for b in range(B):
+        oc = OGraph.from_dict(tgt).compose(OGraph.linear(T, C, em[b]), "intersect")
+        assert got[b] == pytest.approx(oc.shortest_distance(), rel=RTOL)
+        g1, g2 = oc.compose_grad(oc.shortest_distance_grad(), len(tgt["src"]), T * C)
+        acc += np.asarray(g1, np.float64)
+        np.testing.assert_allclose(ems[b].grad().weights_to_numpy(), g2, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(ctc.grad().weights_to_numpy(), acc, rtol=1e-3, atol=1e-4)

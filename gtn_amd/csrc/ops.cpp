@@ -1024,6 +1024,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     int64_t N1, N2, Ncap, Acap, pairs;
   };
   std::vector<Cap> caps(n);
+  std::map<std::tuple<Structure*, int, bool>, std::pair<int64_t, int64_t>> direct_counts;
   for (size_t i = 0; i < n; ++i) {
     Structure& s1 = *bcast(av, n, i).s;
     Structure& s2 = *bcast(bv, n, i).s;
@@ -1033,13 +1034,20 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const bool l1 = s1.kind == KIND_LINEAR;
       Structure& e = l1 ? s2 : s1;
       const Structure& ch = l1 ? s1 : s2;
-      e.ensure_host();
-      const std::vector<int>& lab = l1 ? e.il : e.ol;
-      int64_t hit = 0, eps = 0;
-      for (int l : lab) {
-        hit += (l >= 0 && l < ch.C);
-        eps += (l == GTNX_EPSILON);
+      // (a partner shared by the whole batch -- ASG transitions -- is counted once)
+      const auto key = std::make_tuple(&e, ch.C, l1);
+      auto hit_it = direct_counts.find(key);
+      if (hit_it == direct_counts.end()) {
+        e.ensure_host();
+        const std::vector<int>& lab = l1 ? e.il : e.ol;
+        int64_t h = 0, ep = 0;
+        for (int l : lab) {
+          h += (l >= 0 && l < ch.C);
+          ep += (l == GTNX_EPSILON);
+        }
+        hit_it = direct_counts.emplace(key, std::make_pair(h, ep)).first;
       }
+      const int64_t hit = hit_it->second.first, eps = hit_it->second.second;
       Cap& c = caps[i];
       c.N1 = s1.N;
       c.N2 = s2.N;

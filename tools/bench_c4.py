@@ -83,6 +83,37 @@ def main():
     out["fcc_score0"] = float(gtn.items(fcc)[0])
     g = trans.grad().weights_to_numpy()
     out["transitions_grad_sum"] = float(g.sum())  # = B*T: one arc per step per utterance in expectation
+    # (c) the whole ASG criterion of examples/asg.cpp:59-68 -- full-connect minus force-align
+    # score, U=100 targets; the force-align lattices (compose(emissions, compose(fal, transitions)))
+    # are small and go through the materialising compose, the full-connect term stays symbolic
+    U = 100
+    rng = np.random.default_rng(1)
+    tgts = rng.integers(0, C, size=(B, U))
+    times = []
+    for _ in range(max(1, args.steps - 1)):
+        trans.zero_grad()
+        ems = gtn.linear_graph_n(B, T, C, em)
+        fals = []
+        for b in range(B):
+            f = gtn.Graph()
+            f.add_nodes(np.array([1] + [0] * U, np.uint8), np.array([0] * U + [1], np.uint8))
+            lab = tgts[b].astype(np.int32)
+            idx = np.arange(1, U + 1, dtype=np.int32)
+            f.add_arcs(np.concatenate([idx - 1, idx]), np.concatenate([idx, idx]), np.concatenate([lab, lab]))
+            fals.append(f)
+        sync()
+        t0 = time.perf_counter()
+        fcc = gtn.forward_score(gtn.compose(ems, [trans]))
+        fal = gtn.forward_score(gtn.compose(ems, gtn.compose(fals, [trans])))
+        loss = gtn.subtract(fcc, fal)
+        gtn.backward(loss)
+        sync()
+        times.append(time.perf_counter() - t0)
+    out["asg_loss_fwd_bwd_ms"] = min(times) * 1e3
+    out["asg_loss_utt_per_s"] = B / min(times)
+    lv = gtn.items(loss)
+    out["asg_loss_mean"] = float(lv.mean())
+    out["asg_loss_min"] = float(lv.min())  # a loss is a -log probability ratio: never negative
     out["kernels"] = {n: gtn.prof_get(n) for n in gtn.prof_names() if n.startswith("lazy")}
     print(json.dumps(out))
 

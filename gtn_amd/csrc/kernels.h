@@ -310,6 +310,15 @@ struct LazyGroup {          // utterances that share one explicit graph G
   const float* const* delta;  // [nb] upstream gradient of each score
   float* const* grad_em;      // [nb] chain gradient buffers (T*C) or null entries
   float* grad_fixed;          // [A] gradient of G's arcs (zero-filled) or null
+  // dense regime (log semiring; every node's in-arcs share one matched label and G is
+  // nearly complete): the recursion is a product with E = exp(w - cmax) in the
+  // probability domain -- see lazy.hip "dense regime"
+  const float* E;             // [N][N] row = source, col = destination (0: no arc)
+  const float* cmax;          // [N] largest in-arc weight per destination (-inf: none)
+  const int* nlab;            // [N] matched label of the node's in-arcs (-1: none)
+  float* amax;                // [T+1][nb] row max of alpha[t]   (written by the forward steps)
+  float* bmax;                // [T][nb]   row max of em + beta[t+1] + cmax (backward steps)
+  float* R;                   // [N][N] sum over (t, utterance) of the arc posteriors / exp(w)
 };
 size_t lazy_step_lds_bytes(const LazyGroup& g);
 int lazy_tile_nodes();
@@ -334,6 +343,12 @@ struct LazyPathGrad {
   float* grad_fixed;    // [A] or null
 };
 void launch_lazy_path_grad(const LazyPathGrad& a, hipStream_t st);
+// dense regime
+void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set
+// backward: vin / vout = the two halves of a [2][nb][N] scratch (vin null on the first step)
+void launch_lazy_dense_step(const LazyGroup& g, int t, int backward, hipStream_t st, const float* vin = nullptr,
+                            float* vout = nullptr);
+void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st);                   // R zero-filled
 
 // ---------------------------------------------------------------------------
 // small elementwise helpers

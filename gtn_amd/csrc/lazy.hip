@@ -405,6 +405,210 @@ __global__ void lazy_path_grad_kernel(LazyPathGrad a) {
   if (a.grad_fixed) atomicAdd(a.grad_fixed + arc, d);
 }
 
+
+// =====================================================================================
+// dense regime (log semiring).  When every node's in-arcs carry one label (so the
+// emission term factors out of the sum) and G is nearly complete, a time step is
+//   alpha[t+1][b][d] = em[t][b][lab d] + cmax[d] + m_b + log( sum_s A[b][s] * E[s][d] ),
+//   A[b][s] = exp(alpha[t][b][s] - m_b),  m_b = max_s alpha[t][b][s],  E = exp(w - cmax[d]),
+// i.e. ONE multiply-add per arc instead of a streaming log-sum-exp (~20 instructions):
+// a [nb x N] * [N x N] product per step in fp32 FMAs, LDS-tiled (32 x 32 outputs per
+// workgroup, 2 x 2 per lane).  Row maxima keep A in [0, 1]; S >= E[s*][d] > 0 whenever d
+// is reachable from the row's best state, and a complete G makes every d reachable, which
+// is why the regime asks for a nearly complete G.  Same for beta with E transposed, and
+// the gradient of G's arcs is exp(w[a]) * R[src][dst] with R = sum over (t, b) of an
+// outer product, again FMAs.  The tropical semiring does not factor; it keeps the
+// record-walking kernel above.
+// =====================================================================================
+constexpr int TT = 32;      // tile edge (outputs) and K chunk
+constexpr int kDense = 256;
+
+__global__ void lazy_dense_cmax_kernel(LazyGroup g, float* cmax) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= g.N) return;
+  float m = NEG_INF;
+  for (int k = g.g.in_off[d]; k < g.g.in_off[d + 1]; ++k) {
+    const gtnx_i4 r = g.lrec_in[k];
+    if (r.y >= 0) m = fmaxf(m, __int_as_float(r.z));
+  }
+  cmax[d] = m;
+}
+__global__ void lazy_dense_fill_kernel(LazyGroup g, float* E, const float* cmax) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= g.g.A) return;
+  const gtnx_i4 r = g.lrec_in[k];  // {src, label, weight, arc}; destination from the arc
+  if (r.y < 0) return;
+  const int d = g.g.dst[r.w];
+  atomicAdd(&E[int64_t(r.x) * g.N + d], expf(__int_as_float(r.z) - cmax[d]));
+}
+
+// one time step; BWD: contraction over destinations with E transposed
+// BWD: `vin` (when non-null) holds the contraction input of this step, beta[t+1] + em[t] +
+// cmax per destination, written by the previous launch's epilogue into `vout`
+template <bool BWD>
+__global__ __launch_bounds__(kDense) void lazy_dense_step_kernel(LazyGroup g, int t, const float* vin, float* vout) {
+  __shared__ float As[TT][TT + 2];   // [k][b]
+  __shared__ float Es[TT][TT + 2];   // [k][out]
+  __shared__ float mrow[TT];
+  const int tid = threadIdx.x;
+  const int N = g.N, C = g.C;
+  const int b0 = blockIdx.y * TT, o0 = blockIdx.x * TT;  // utterance tile, output-node tile
+  const int64_t plane = int64_t(g.nb) * N;
+  const float* prev = BWD ? g.beta + int64_t(t + 1) * plane : g.alpha + int64_t(t) * plane;
+  // value entering the contraction for (utterance b, inner node k)
+  auto inner = [&](int b, int k) -> float {
+    if (b >= g.nb || k >= N) return NEG_INF;
+    if (BWD && vin) return vin[int64_t(b) * N + k];
+    const float v = prev[int64_t(b) * N + k];
+    if (!BWD) return v;
+    const int lab = g.nlab[k];
+    if (lab < 0) return NEG_INF;
+    return v + g.em[b][int64_t(t) * C + lab] + g.cmax[k];
+  };
+  // ---- row maxima of the tile's 32 utterances (8 lanes per row)
+  {
+    const int rb = tid >> 3, rl = tid & 7;
+    float m = NEG_INF;
+    for (int k = rl; k < N; k += 8) m = fmaxf(m, inner(b0 + rb, k));
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 8));
+    if (rl == 0) {
+      mrow[rb] = m;
+      if (blockIdx.x == 0 && b0 + rb < g.nb) (BWD ? g.bmax : g.amax)[int64_t(t) * g.nb + b0 + rb] = m;
+    }
+  }
+  __syncthreads();
+  const int tx = tid & 15, ty = tid >> 4;  // outputs (2*ty .. +1 utterances) x (2*tx .. +1 nodes)
+  float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  for (int k0 = 0; k0 < N; k0 += TT) {
+    // stage: As[k][b] = exp(inner - m_b);  Es[k][o] = E[k][o] (FWD) | E[o][k] (BWD)
+    for (int i = tid; i < TT * TT; i += kDense) {
+      const int bb = i / TT, kk = i % TT;   // consecutive lanes walk k: unit stride in `prev`
+      const float m = mrow[bb];
+      const float v = inner(b0 + bb, k0 + kk);
+      As[kk][bb] = (v == NEG_INF || m == NEG_INF) ? 0.0f : __expf(v - m);
+      const int r = i / TT, c = i % TT;
+      float e = 0.0f;
+      if (!BWD) {  // row k0 + r, columns o0 + c
+        if (k0 + r < N && o0 + c < N) e = g.E[int64_t(k0 + r) * N + o0 + c];
+        Es[r][c] = e;
+      } else {     // row o0 + r (output = source), columns k0 + c (inner = destination)
+        if (o0 + r < N && k0 + c < N) e = g.E[int64_t(o0 + r) * N + k0 + c];
+        Es[c][r] = e;
+      }
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < TT; ++k) {
+      const float a0 = As[k][2 * ty], a1 = As[k][2 * ty + 1];
+      const float e0 = Es[k][2 * tx], e1 = Es[k][2 * tx + 1];
+      acc[0][0] += a0 * e0;
+      acc[0][1] += a0 * e1;
+      acc[1][0] += a1 * e0;
+      acc[1][1] += a1 * e1;
+    }
+    __syncthreads();
+  }
+  float* out_plane = BWD ? g.beta + int64_t(t) * plane : g.alpha + int64_t(t + 1) * plane;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int b = b0 + 2 * ty + i;
+    if (b >= g.nb) continue;
+    const float m = mrow[2 * ty + i];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int o = o0 + 2 * tx + j;
+      if (o >= N) continue;
+      float v = NEG_INF;
+      if (acc[i][j] > 0.0f && m != NEG_INF) {
+        v = __logf(acc[i][j]) + m;
+        if (!BWD) {
+          const int lab = g.nlab[o];
+          v = lab < 0 ? NEG_INF : v + g.cmax[o] + g.em[b][int64_t(t) * C + lab];
+        }
+      }
+      out_plane[int64_t(b) * N + o] = v;
+      if (BWD && vout && t >= 1) {  // what step t-1 contracts over
+        const int lab = g.nlab[o];
+        vout[int64_t(b) * N + o] =
+            (lab < 0 || v == NEG_INF) ? NEG_INF : v + g.em[b][int64_t(t - 1) * C + lab] + g.cmax[o];
+      }
+    }
+  }
+}
+
+// R[s][d] += sum over a slice of (t, b) pairs of A'[s] * Q'[d], with the pair's two
+// factors balanced around c = amax + bmax - Z so that neither side over- or underflows:
+//   A' = exp(alpha[t][b][s] - amax + c/2),  Q' = exp(em + beta[t+1][b][d] - bmax + c/2) * delta
+__global__ __launch_bounds__(kDense) void lazy_dense_fixed_grad_kernel(LazyGroup g, int pairs_per_block) {
+  __shared__ float As[TT][TT + 2];   // [k][s]
+  __shared__ float Qs[TT][TT + 2];   // [k][d]
+  const int tid = threadIdx.x;
+  const int N = g.N, C = g.C;
+  const int s0 = blockIdx.x * TT, d0 = blockIdx.y * TT;
+  const int64_t plane = int64_t(g.nb) * N;
+  const int64_t npairs = int64_t(g.T) * g.nb;
+  const int64_t p0 = int64_t(blockIdx.z) * pairs_per_block, p1 = min(npairs, p0 + pairs_per_block);
+  const int tx = tid & 15, ty = tid >> 4;
+  float acc[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  for (int64_t q0 = p0; q0 < p1; q0 += TT) {
+    for (int i = tid; i < TT * TT; i += kDense) {
+      const int kk = i / TT, c = i % TT;  // pair kk of the chunk, column c of the tile
+      const int64_t p = q0 + kk;
+      float av = 0.0f, qv = 0.0f;
+      if (p < p1) {
+        const int t = int(p / g.nb), b = int(p % g.nb);
+        const float z = g.score[b];
+        const float am = g.amax[int64_t(t) * g.nb + b], bm = g.bmax[int64_t(t) * g.nb + b];
+        if (z != NEG_INF && z != -NEG_INF && am != NEG_INF && bm != NEG_INF) {
+          const float half = 0.5f * (am + bm - z);
+          if (s0 + c < N) {
+            const float al = g.alpha[int64_t(t) * plane + int64_t(b) * N + s0 + c];
+            if (al != NEG_INF) av = __expf(al - am + half);
+          }
+          if (d0 + c < N) {
+            const int lab = g.nlab[d0 + c];
+            const float be = g.beta[int64_t(t + 1) * plane + int64_t(b) * N + d0 + c];
+            if (lab >= 0 && be != NEG_INF)
+              qv = __expf(g.em[b][int64_t(t) * C + lab] + be - bm + half) * (*g.delta[b]);
+          }
+        }
+      }
+      As[kk][c] = av;
+      Qs[kk][c] = qv;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < TT; ++k) {
+      const float a0 = As[k][2 * ty], a1 = As[k][2 * ty + 1];
+      const float e0 = Qs[k][2 * tx], e1 = Qs[k][2 * tx + 1];
+      acc[0][0] += a0 * e0;
+      acc[0][1] += a0 * e1;
+      acc[1][0] += a1 * e0;
+      acc[1][1] += a1 * e1;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int s = s0 + 2 * ty + i, d = d0 + 2 * tx + j;
+      if (s < N && d < N && acc[i][j] != 0.0f) atomicAdd(&g.R[int64_t(s) * N + d], acc[i][j]);
+    }
+}
+// grad[a] += exp(w[a]) * R[src][dst]  (the balancing shifts of A' and Q' cancel exactly:
+// A' * Q' = exp(alpha + em + beta - Z) * delta)
+__global__ void lazy_dense_arc_grad_kernel(LazyGroup g) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= g.g.A) return;
+  const gtnx_i4 r = g.lrec_in[k];
+  if (r.y < 0) return;
+  const int d = g.g.dst[r.w];
+  const float v = g.R[int64_t(r.x) * g.N + d];
+  if (v != 0.0f) atomicAdd(g.grad_fixed + r.w, v * __expf(__int_as_float(r.z)));
+}
+
 } // namespace
 
 size_t lazy_step_lds_bytes(const LazyGroup& g) { return sizeof(float) * size_t(BT) * size_t(g.Npad + g.Cpad); }
@@ -487,4 +691,30 @@ void launch_lazy_path_grad(const LazyPathGrad& a, hipStream_t st) {
   hipLaunchKernelGGL(lazy_path_grad_kernel, dim3((a.len + 255) / 256), dim3(256), 0, st, a);
 }
 
+} // namespace gtnx
+
+namespace gtnx {
+void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st) {
+  if (g.N <= 0) return;
+  (void)hipMemsetAsync(E, 0, sizeof(float) * size_t(g.N) * size_t(g.N), st);
+  hipLaunchKernelGGL(lazy_dense_cmax_kernel, dim3((g.N + 255) / 256), dim3(256), 0, st, g, cmax);
+  if (g.g.A > 0)
+    hipLaunchKernelGGL(lazy_dense_fill_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g, E, (const float*)cmax);
+}
+void launch_lazy_dense_step(const LazyGroup& g, int t, int backward, hipStream_t st, const float* vin, float* vout) {
+  const dim3 grid((g.N + TT - 1) / TT, (g.nb + TT - 1) / TT);
+  if (backward)
+    hipLaunchKernelGGL(lazy_dense_step_kernel<true>, grid, dim3(kDense), 0, st, g, t, vin, vout);
+  else
+    hipLaunchKernelGGL(lazy_dense_step_kernel<false>, grid, dim3(kDense), 0, st, g, t, (const float*)nullptr,
+                       (float*)nullptr);
+}
+void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st) {
+  if (g.N <= 0 || g.T <= 0 || g.nb <= 0 || !g.grad_fixed) return;
+  const int64_t npairs = int64_t(g.T) * g.nb;
+  const int pairs_per_block = 16384;
+  const dim3 grid((g.N + TT - 1) / TT, (g.N + TT - 1) / TT, unsigned((npairs + pairs_per_block - 1) / pairs_per_block));
+  hipLaunchKernelGGL(lazy_dense_fixed_grad_kernel, grid, dim3(kDense), 0, st, g, pairs_per_block);
+  if (g.g.A > 0) hipLaunchKernelGGL(lazy_dense_arc_grad_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g);
+}
 } // namespace gtnx

@@ -1556,6 +1556,8 @@ struct LazyGroupState {
   DevMemP labels;                   // node_label (null when in-arc labels differ per node)
   const int* node_label = nullptr;
   int max_in_deg = 0;
+  bool dense = false;               // probability-domain products (lazy.hip "dense regime")
+  DevMemP dense_mem;
   Graph fixed;                      // keeps G alive
   std::vector<Graph> chains;        // per member
   std::vector<int> member_of;       // output index -> member slot (filled by the caller)
@@ -1585,6 +1587,7 @@ struct LazyKey {
 
 // forward pass (log or tropical) of every lazy product in `gs`; returns one state per
 // group and, through `slot`, (group, member) of each input
+std::vector<int> lazy_node_labels(Structure& fs, bool chain_first, int C, int* max_in_deg);
 std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs, int mode,
                                                           std::vector<std::pair<int, int>>& slot) {
   Runtime& rt = Runtime::get();
@@ -1666,6 +1669,38 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     rt.h2d(st.arena->as<char>(o_em), pin->ptr, 8 * size_t(nb));
     v.em = reinterpret_cast<const float* const*>(st.arena->as<char>(o_em));
   }
+  // dense regime? (log semiring, one label per node's in-arcs, G nearly complete)
+  for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
+  for (auto& gp : groups) {
+    LazyGroupState& st = *gp;
+    LazyGroup& v = st.view;
+    Structure& fs = *st.fixed.s;
+    if (mode != SD_LOG || getenv("GTNX_NO_DENSE") || v.N > 1024 || v.N < 8) continue;
+    std::vector<int> lab = lazy_node_labels(fs, v.chain_first != 0, v.C, &st.max_in_deg);
+    if (lab.empty()) continue;
+    int64_t valid = 0;
+    const std::vector<int>& ml = v.chain_first ? fs.il : fs.ol;
+    for (int l : ml) valid += (l >= 0 && l < v.C);
+    if (2 * valid < int64_t(v.N) * v.N) continue;
+    st.labels = upload_vec(lab);
+    st.node_label = st.labels->as<int>();
+    const size_t nn = size_t(v.N) * size_t(v.N);
+    size_t bytes = 0;
+    auto add = [&](size_t b) {
+      size_t o2 = bytes;
+      bytes = align_up(bytes + b, 256);
+      return o2;
+    };
+    const size_t o_E = add(4 * nn), o_c = add(4 * size_t(v.N)), o_am = add(4 * size_t(v.T + 1) * size_t(v.nb)),
+                 o_bm = add(4 * size_t(v.T + 1) * size_t(v.nb));
+    st.dense_mem = rt.alloc(bytes);
+    v.E = st.dense_mem->as<float>(o_E);
+    v.cmax = st.dense_mem->as<float>(o_c);
+    v.nlab = st.node_label;
+    v.amax = st.dense_mem->as<float>(o_am);
+    v.bmax = st.dense_mem->as<float>(o_bm);
+    st.dense = true;
+  }
   // chain_first comes from the products themselves (same for a whole group by key)
   for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
   for (auto& gp : groups) {
@@ -1673,7 +1708,12 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     GTNX_PROF(mode == SD_LOG ? "lazy_forward_score" : "lazy_viterbi", 0.0);
     launch_lazy_pack(st.view, const_cast<gtnx_i4*>(st.view.lrec_in), const_cast<gtnx_i4*>(st.view.lrec_out), rt.stream());
     launch_lazy_init(st.view, 0, rt.stream());
-    for (int t = 0; t < st.view.T; ++t) launch_lazy_step(st.view, t, mode, 0, rt.stream());
+    if (st.dense) {
+      launch_lazy_dense_prep(st.view, const_cast<float*>(st.view.E), const_cast<float*>(st.view.cmax), rt.stream());
+      for (int t = 0; t < st.view.T; ++t) launch_lazy_dense_step(st.view, t, 0, rt.stream());
+    } else {
+      for (int t = 0; t < st.view.T; ++t) launch_lazy_step(st.view, t, mode, 0, rt.stream());
+    }
     launch_lazy_final(st.view, mode, rt.stream());
   }
   return groups;
@@ -1753,7 +1793,14 @@ struct LazySdOp : OpRecord {
         v.beta = beta->as<float>();
         GTNX_PROF("lazy_forward_score_grad", 0.0);
         launch_lazy_init(v, 1, rt.stream());
-        for (int t = T - 1; t >= 0; --t) launch_lazy_step(v, t, SD_LOG, 1, rt.stream());
+        if (st.dense) {
+          DevMemP vs = rt.alloc(8 * plane);  // two planes: input of this step / of the next
+          float* vb[2] = {vs->as<float>(), vs->as<float>() + plane};
+          for (int t = T - 1; t >= 0; --t)
+            launch_lazy_dense_step(v, t, 1, rt.stream(), t == T - 1 ? nullptr : vb[(t + 1) & 1], vb[t & 1]);
+        } else {
+          for (int t = T - 1; t >= 0; --t) launch_lazy_step(v, t, SD_LOG, 1, rt.stream());
+        }
         if (!st.labels && st.max_in_deg == 0) {
           fixed.s->ensure_host();
           fixed.s->ensure_csr();
@@ -1764,7 +1811,11 @@ struct LazySdOp : OpRecord {
           }
         }
         launch_lazy_chain_grad(v, st.node_label, rt.stream());
-        if (want_fixed) {
+        if (want_fixed && st.dense) {
+          DevMemP rmem = rt.alloc_zero(4 * size_t(N) * size_t(N));
+          v.R = rmem->as<float>();
+          launch_lazy_dense_fixed_grad(v, rt.stream());
+        } else if (want_fixed) {
           const size_t lds = lazy_step_lds_bytes(v) + 4 * size_t(lazy_tile_nodes()) * size_t(st.max_in_deg);
           if (lds > size_t(lazy_lds_limit()))
             throw_runtime("[gtn::backward] lazy product: graph too wide for the arc-gradient kernel");

@@ -439,7 +439,14 @@ __global__ void lazy_dense_fill_kernel(LazyGroup g, float* E, const float* cmax)
   const gtnx_i4 r = g.lrec_in[k];  // {src, label, weight, arc}; destination from the arc
   if (r.y < 0) return;
   const int d = g.g.dst[r.w];
-  atomicAdd(&E[int64_t(r.x) * g.N + d], expf(__int_as_float(r.z) - cmax[d]));
+  const float w = __int_as_float(r.z), c = cmax[d];
+  // w - c is NaN when both are the same infinity: -inf/-inf is a column without any live
+  // arc (stays 0), +inf/+inf is the arc that makes the column's score +inf (weight 1)
+  float e;
+  if (c == NEG_INF) return;
+  else if (c == -NEG_INF) e = (w == -NEG_INF) ? 1.0f : 0.0f;
+  else e = expf(w - c);
+  if (e != 0.0f) atomicAdd(&E[int64_t(r.x) * g.N + d], e);
 }
 
 // one time step; BWD: contraction over destinations with E transposed

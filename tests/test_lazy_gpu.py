@@ -190,3 +190,46 @@ def test_full_size_c4_invariants(gtn):
     tol = 8 * 1.2e-7 * float(np.abs(f).max())
     assert float((rows - 1).abs().max()) < max(5e-3, tol)
     assert float(trans.grad().weights_to_numpy().sum()) == pytest.approx(B * T, rel=max(1e-3, tol))
+
+
+def test_dense_regime_with_impossible_emissions_and_transitions(gtn):
+    """log(0) = -inf emission frames / transition weights through the probability-domain
+    (dense) kernels, the record-walking lazy kernels and the materialised path"""
+    B, T, N = 6, 25, 16
+    res = {}
+    for name, env in (("mat", {"GTNX_LAZY_COMPOSE": "0"}), ("walk", {"GTNX_LAZY_COMPOSE": "1", "GTNX_NO_DENSE": "1"}),
+                      ("dense", {"GTNX_LAZY_COMPOSE": "1"})):
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            em, ems, trans = asg_batch(gtn, B, T, N, 4)
+            em = em.copy()
+            em[0, 3, :5] = -np.inf
+            em[2, :, 7] = -np.inf
+            for b in (0, 2):
+                ems[b].set_weights(em[b])
+            w = trans.weights_to_numpy()
+            w[N + 5 * N + 2] = -np.inf      # p(5 | 2) = 0
+            w[3] = -np.inf                   # p(3 | <s>) = 0
+            trans.set_weights(w)
+            comp = gtn.compose(ems, [trans])
+            fs = gtn.forward_score(comp)
+            gtn.backward(fs)
+            res[name] = (gtn.items(fs), [e.grad().weights_to_numpy() for e in ems], trans.grad().weights_to_numpy())
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    # scores agree with the materialised (reference-order) path.  Its GRADIENTS are NaN
+    # wherever a -inf weight meets a -inf score (the reference's exp(-inf - -inf),
+    # autograd_test.cpp:339-386); the symbolic paths return the finite limit instead, so
+    # they are compared with each other and, where the reference is finite, with it
+    for other in ("walk", "dense"):
+        np.testing.assert_allclose(res[other][0], res["mat"][0], rtol=1e-5)
+        for x, y in zip(res[other][1], res["mat"][1]):
+            assert np.isfinite(x).all()
+            ok = np.isfinite(y)
+            np.testing.assert_allclose(x[ok], y[ok], rtol=1e-3, atol=1e-5)
+    for x, y in zip(res["dense"][1], res["walk"][1]):
+        np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-5)
+    assert np.isfinite(res["dense"][2]).all()
+    np.testing.assert_allclose(res["dense"][2], res["walk"][2], rtol=1e-3, atol=1e-4)

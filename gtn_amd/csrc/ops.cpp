@@ -1416,7 +1416,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     v.A = co.A;
     v.n_start = deferred ? -1 : res_counts[2 * i];
     v.n_accept = deferred ? -1 : res_counts[2 * i + 1];
-    v.flags = 0;
+    // a product's labels come from its inputs' arcs (epsilon only where an input had one)
+    v.flags = (x.g1.flags & x.g2.flags & GF_EPS_FREE);
     v.src = x.src;
     v.dst = x.dst;
     v.il = x.il;

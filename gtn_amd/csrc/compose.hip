@@ -1404,7 +1404,7 @@ void launch_compose_b(const ComposeArgs* d_args, int n, int dyn, hipStream_t st)
   }
   hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST, C1, BLK>), dim3(n), dim3(BLK), dyn, st, d_args);
 }
-int g_compose_wide = 0;  // set by launch_compose for the duration of one dispatch
+thread_local int g_compose_wide = 0;  // set by launch_compose for the duration of one dispatch (ops may run on several host threads)
 template <int MATCH, bool L1, bool L2, bool FAST, bool C1>
 void launch_compose_t(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
   // the 512-lane form only for chain products (one side linear) on the FAST variant

@@ -601,8 +601,9 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     int64_t tot_in = 0, tot_p = 0;
     int maxw = 0;
     double alg = 0;
-    // deep & narrow lattices take the LDS-ring kernel (whole batch must qualify)
-    bool narrow = !tropical;
+    // deep & narrow lattices take the LDS-ring kernel (whole batch must qualify; the
+    // tropical form additionally needs the row-ordered weights compose emits)
+    bool narrow = true;
     int64_t tot_levels = 0;
     for (int k = 0; k < m; ++k) {
       Schedule& sc = *gs[exp[k]].s->sched;
@@ -618,7 +619,8 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       Schedule& sc = *g.s->sched;
       SdArgs& a = args[k];
       std::memset(&a, 0, sizeof(a));
-      a.s = sched_view(g, /*need_full=*/!narrow);  // the narrow kernel reads in_src / in_w / row offsets only
+      // the log narrow kernel reads in_src / in_w / row offsets only; everything else also arc ids
+      a.s = sched_view(g, /*need_full=*/!narrow || tropical);
       a.w = g.w->dev;
       a.scores = arena->as<float>(off_s[k]);
       a.argmax = tropical ? arena->as<int>(off_a[k]) : nullptr;

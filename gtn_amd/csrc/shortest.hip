@@ -228,7 +228,11 @@ constexpr int kCN = 1024;    // nodes per chunk (and per level)
 constexpr int kTab = 256;    // levels per offset-table refill
 constexpr int kJA = kCA / kBlock, kJN = kCN / kBlock;
 
-template <bool HAS_INW>
+// TROP: the tropical semiring (viterbiScore) on the same machinery -- max instead of
+// log-sum-exp, the arg-max in-arc written per node (ties to the smallest arc id, the
+// reference's in-list order for src-sorted products); needs HAS_INW and the arc ids of
+// the in-row slots, staged alongside.
+template <bool HAS_INW, bool TROP = false>
 __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs* __restrict__ args) {
   const SdArgs a = args[blockIdx.x];
   DSched s = a.s;
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
   // staging); both arc arrays are padded so a lane may read its 4 row slots unclamped
   __shared__ __attribute__((aligned(16))) int arc_sp[2][kCA + 4];
   __shared__ __attribute__((aligned(16))) float arc_w[2][kCA + 4];
+  __shared__ __attribute__((aligned(16))) int arc_id[TROP ? 2 : 1][TROP ? kCA + 4 : 4];
   __shared__ __attribute__((aligned(16))) int node_off[2][kCN + kBlock];
   __shared__ __attribute__((aligned(16))) uint8_t node_fl[2][kCN];
   __shared__ int tab_node[kTab + 2];
@@ -271,6 +276,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
   // LDS with ds_write_b128; host-built schedules use clamped scalar loads.
   gtnx_i4 v_sp[kJA / 4];
   gtnx_f4 v_w[kJA / 4];
+  gtnx_i4 v_id[TROP ? kJA / 4 : 1];
   gtnx_i4 v_off;
   int v_off_last = 0;
   unsigned v_fl = 0;
@@ -281,6 +287,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
         const int k = a0 + 4 * tid + j * 4 * kBlock;
         v_sp[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.in_srcpos + k);
         v_w[j] = *reinterpret_cast<const GTNX_G gtnx_f4*>(s.in_w + k);
+        if (TROP) v_id[j] = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.in_arc + k);
       }
       const int nb = min(n0 + 4 * tid, last_node + 1);
       v_off = *reinterpret_cast<const GTNX_G gtnx_i4*>(s.row_off + nb);
@@ -306,6 +313,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
       for (int j = 0; j < kJA / 4; ++j) {
         *reinterpret_cast<gtnx_i4*>(&arc_sp[b][4 * tid + j * 4 * kBlock]) = (v_sp[j] & (kRing - 1)) << 2;
         *reinterpret_cast<gtnx_f4*>(&arc_w[b][4 * tid + j * 4 * kBlock]) = v_w[j];
+        if (TROP) *reinterpret_cast<gtnx_i4*>(&arc_id[b][4 * tid + j * 4 * kBlock]) = v_id[j];
       }
       *reinterpret_cast<gtnx_i4*>(&node_off[b][4 * tid]) = v_off;
       if (tid == 0) node_off[b][kCN] = v_off_last;
@@ -347,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
       // level i's barrier, so a level's critical path is: ring gather -> max /
       // exp / log -> ring write -> barrier.
       int q_p = 0, q_r0 = 0, q_deg = 0, q_fl = 0, q_nhi = 0;
-      int q_sp[4];
+      int q_sp[4], q_id[4];
       float q_w[4];
       const int n_end = tab_node[e];  // chunk end (uniform)
       int next_lo = n0;               // level i's first node == level i-1's end: no table read on the chain
@@ -365,9 +373,40 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
         for (int j = 0; j < 4; ++j) {
           q_sp[j] = spb[j];
           q_w[j] = wb[j];
+          q_id[j] = TROP ? arc_id[TROP ? b : 0][q_r0 + j] : 0;
         }
       };
-      auto node_update = [&](int p, int r0, int deg, int fl, const int* sp4, const float* w4) {
+      auto node_update = [&](int p, int r0, int deg, int fl, const int* sp4, const float* w4, const int* id4) {
+        if (TROP) {
+          // max over the in-arcs, first by score then by smallest arc id; the start
+          // node's virtual 0.0 comes last (shortest.cpp:118-135)
+          float mx = NEG_INF;
+          int best = -1;
+          auto take = [&](float x, int id) {
+            if (x > mx || (x == mx && x > NEG_INF && id < best)) {
+              mx = x;
+              best = id;
+            }
+          };
+          if (deg <= 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < deg) take(ring_at(sp4[j]) + w4[j], id4[j]);
+          } else {
+            for (int k = r0; k < r0 + deg; ++k) take(ring_at(arc_sp[b][k]) + arc_w[b][k], arc_id[TROP ? b : 0][k]);
+          }
+          if (!(mx > NEG_INF)) best = -1;
+          const bool is_start = (fl & NF_START) != 0;
+          if (is_start && 0.0f > mx) {
+            mx = 0.0f;
+            best = -1;
+          }
+          float out = (deg + (is_start ? 1 : 0) == 0) ? NEG_INF : mx;
+          if (fl & NF_ORPHAN) out = 0.0f;
+          ring[p & (kRing - 1)] = out;
+          a.argmax[p] = best;
+          return;
+        }
         // the slot being overwritten belongs to position p - kRing, which no
         // later level reads (reach <= kRing); same-level lanes read other slots
         if (fl == 0 && deg <= 4) {
@@ -408,17 +447,18 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
       preload(c);
       for (int i = c; i < e; ++i) {
         const int nhi = q_nhi;
-        if (q_p < nhi) node_update(q_p, q_r0, q_deg, q_fl, q_sp, q_w);
+        if (q_p < nhi) node_update(q_p, q_r0, q_deg, q_fl, q_sp, q_w, q_id);
         for (int p = q_p + kBlock; p < nhi; p += kBlock) {  // levels wider than the workgroup
           const int r0 = node_off[b][p - n0] - a0, deg = node_off[b][p - n0 + 1] - a0 - r0;
-          int sp4[4];
+          int sp4[4], id4[4];
           float w4[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             sp4[j] = arc_sp[b][r0 + j];
             w4[j] = arc_w[b][r0 + j];
+            id4[j] = TROP ? arc_id[TROP ? b : 0][r0 + j] : 0;
           }
-          node_update(p, r0, deg, node_fl[b][p - n0], sp4, w4);
+          node_update(p, r0, deg, node_fl[b][p - n0], sp4, w4, id4);
         }
         if (i + 1 < e) preload(i + 1);
         lds_barrier();
@@ -467,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
   bestk = sh_k[0];
   __syncthreads();
   float sum = 0.0f;
-  if (s.n_accept > 0 && mx != POS_INF && mx != NEG_INF)
+  if (!TROP && s.n_accept > 0 && mx != POS_INF && mx != NEG_INF)
     for (int k = tid; k < s.n_accept; k += kBlock) sum += expf(scores[s.acc_pos[k]] - mx);
   sh_v[tid] = sum;
   __syncthreads();
@@ -476,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
     __syncthreads();
   }
   if (tid == 0) {
-    const float out = finish_lse(mx, sh_v[0], s.n_accept);
+    const float out = TROP ? (s.n_accept == 0 ? NEG_INF : mx) : finish_lse(mx, sh_v[0], s.n_accept);
     SdResult r;
     r.score = out;
     r.max_final = mx;
@@ -879,6 +919,10 @@ void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
       hipLaunchKernelGGL(sd_forward_narrow_kernel<true>, dim3(n), dim3(kBlock), 0, st, d_args);
     else
       hipLaunchKernelGGL(sd_forward_narrow_kernel<false>, dim3(n), dim3(kBlock), 0, st, d_args);
+    return;
+  }
+  if (narrow == 2 && mode == SD_TROPICAL) {  // row-ordered weights + arc ids of the in-row slots
+    hipLaunchKernelGGL((sd_forward_narrow_kernel<true, true>), dim3(n), dim3(kBlock), 0, st, d_args);
     return;
   }
   const int g = pick_group(avg_in_degree_x16);

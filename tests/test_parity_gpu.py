@@ -675,3 +675,28 @@ def test_shared_target_graph_broadcasts(gtn):
         acc += np.asarray(g1, np.float64)
         np.testing.assert_allclose(ems[b].grad().weights_to_numpy(), g2, rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(ctc.grad().weights_to_numpy(), acc, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,C,U", [(3, 200, 12, 15), (2, 700, 40, 60)])
+def test_viterbi_score_on_ctc_lattices_vs_oracle(gtn, B, T, C, U):
+    """viterbiScore over deep narrow lattices (the tropical form of the LDS-ring kernel):
+    score, arg-max one-hot gradients and the best path's labels against the oracle"""
+    import torch
+    em, tg = gg.ctc_inputs(41, B, T, C, U)
+    ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+    ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    comp = gtn.intersect(ctcs, ems)
+    vs = gtn.viterbi_score(comp)
+    gtn.backward(vs)
+    got = gtn.items(vs)
+    paths = gtn.viterbi_path(comp)
+    for b in range(B):
+        tgt = gg.ctc_target_graph(tg[b].tolist())
+        oc = OGraph.from_dict(tgt).compose(OGraph.linear(T, C, em[b]), "intersect")
+        assert got[b] == pytest.approx(oc.shortest_distance(True), rel=1e-6)
+        g1, g2 = oc.compose_grad(oc.shortest_distance_grad(True), len(tgt["src"]), T * C)
+        np.testing.assert_array_equal(ems[b].grad().weights_to_numpy(), np.asarray(g2, np.float32))
+        np.testing.assert_array_equal(ctcs[b].grad().weights_to_numpy(), np.asarray(g1, np.float32))
+        arcs, _ = oc.shortest_path()
+        od = oc.to_dict()
+        assert paths[b].labels_to_list() == [od["il"][a] for a in arcs]

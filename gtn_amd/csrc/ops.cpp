@@ -762,6 +762,7 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     }
   }
   Runtime& rt = Runtime::get();
+  for (auto& g : gs) g.s->resolve_sizes();  // path extraction sizes its buffers from the real counts
   for (auto& g : gs) g.s->materialize();  // TODO(linear fast path): row arg-max needs no graph
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
@@ -806,7 +807,11 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     a.delta = nullptr;
     a.node_grad = nullptr;
     a.arc_grad = nullptr;
-    a.chunk_levels = 1;
+    {
+      const Schedule& sc = *g.s->sched;
+      a.chunk_levels = std::max(1, std::min(sd_narrow_tmp_cap() / std::max(sc.max_level_arcs, 1),
+                                            sd_narrow_node_cap() / std::max(sc.max_level_width, 1)));
+    }
     PathArgs& p = pargs[k];
     p.s = a.s;
     p.g = device_view(g);
@@ -826,7 +831,17 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
   DevMemP dp = upload_vec(pargs);
   {
     GTNX_PROF("viterbi_path", 0.0);
-    launch_sd_forward(d->as<SdArgs>(), m, SD_PATH, 0, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
+    // deep narrow lattices with row-ordered weights (compose products): LDS-ring kernel
+    bool narrow = true;
+    int64_t tot_levels = 0;
+    for (int k = 0; k < m; ++k) {
+      const Schedule& sc = *gs[k].s->sched;
+      narrow = narrow && args[k].s.in_w != nullptr && sc.max_level_arcs <= sd_narrow_tmp_cap() &&
+               sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring();
+      tot_levels += sc.view.L;
+    }
+    narrow = narrow && tot_levels >= 32 * int64_t(m);
+    launch_sd_forward(d->as<SdArgs>(), m, SD_PATH, narrow ? 2 : 0, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
     launch_path_chase(dp->as<PathArgs>(), m, rt.stream());
   }
   // the path is at most L arcs: bring it to the host and build the chain graph there

@@ -232,7 +232,10 @@ constexpr int kJA = kCA / kBlock, kJN = kCN / kBlock;
 // log-sum-exp, the arg-max in-arc written per node (ties to the smallest arc id, the
 // reference's in-list order for src-sorted products); needs HAS_INW and the arc ids of
 // the in-row slots, staged alongside.
-template <bool HAS_INW, bool TROP = false>
+// PATH (with TROP): viterbiPath's relaxation instead -- the start node's virtual 0.0 is
+// considered FIRST (strict '>', shortest.cpp:200-223), the back-pointer is the in-row
+// SLOT (what path_chase_kernel follows), unreachable nodes keep -inf.
+template <bool HAS_INW, bool TROP = false, bool PATH = false>
 __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs* __restrict__ args) {
   const SdArgs a = args[blockIdx.x];
   DSched s = a.s;
@@ -381,28 +384,36 @@ __global__ __launch_bounds__(kBlock) void sd_forward_narrow_kernel(const SdArgs*
           // max over the in-arcs, first by score then by smallest arc id; the start
           // node's virtual 0.0 comes last (shortest.cpp:118-135)
           float mx = NEG_INF;
-          int best = -1;
-          auto take = [&](float x, int id) {
-            if (x > mx || (x == mx && x > NEG_INF && id < best)) {
+          int best = -1, best_rank = INT_MAX;
+          // `slot`: global in-row slot of the candidate (PATH's back-pointer)
+          auto take = [&](float x, int id, int slot) {
+            if (x > mx || (x == mx && x > NEG_INF && id < best_rank)) {
               mx = x;
-              best = id;
+              best_rank = id;
+              best = PATH ? slot : id;
             }
           };
+          const int slot0 = a0 + r0;  // global slot of the row's first in-arc
           if (deg <= 4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-              if (j < deg) take(ring_at(sp4[j]) + w4[j], id4[j]);
+              if (j < deg) take(ring_at(sp4[j]) + w4[j], id4[j], slot0 + j);
           } else {
-            for (int k = r0; k < r0 + deg; ++k) take(ring_at(arc_sp[b][k]) + arc_w[b][k], arc_id[TROP ? b : 0][k]);
+            for (int k = r0; k < r0 + deg; ++k)
+              take(ring_at(arc_sp[b][k]) + arc_w[b][k], arc_id[TROP ? b : 0][k], a0 + k);
           }
           if (!(mx > NEG_INF)) best = -1;
           const bool is_start = (fl & NF_START) != 0;
-          if (is_start && 0.0f > mx) {
-            mx = 0.0f;
-            best = -1;
+          if (is_start) {
+            if (PATH) {
+              if (!(mx > 0.0f)) { mx = 0.0f; best = -1; }
+            } else if (0.0f > mx) {
+              mx = 0.0f;
+              best = -1;
+            }
           }
           float out = (deg + (is_start ? 1 : 0) == 0) ? NEG_INF : mx;
-          if (fl & NF_ORPHAN) out = 0.0f;
+          if (!PATH && (fl & NF_ORPHAN)) out = 0.0f;
           ring[p & (kRing - 1)] = out;
           a.argmax[p] = best;
           return;
@@ -923,6 +934,10 @@ void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
   }
   if (narrow == 2 && mode == SD_TROPICAL) {  // row-ordered weights + arc ids of the in-row slots
     hipLaunchKernelGGL((sd_forward_narrow_kernel<true, true>), dim3(n), dim3(kBlock), 0, st, d_args);
+    return;
+  }
+  if (narrow == 2 && mode == SD_PATH) {
+    hipLaunchKernelGGL((sd_forward_narrow_kernel<true, true, true>), dim3(n), dim3(kBlock), 0, st, d_args);
     return;
   }
   const int g = pick_group(avg_in_degree_x16);

@@ -319,6 +319,11 @@ struct LazyGroup {          // utterances that share one explicit graph G
   float* amax;                // [T+1][nb] row max of alpha[t]   (written by the forward steps)
   float* bmax;                // [T][nb]   row max of em + beta[t+1] + cmax (backward steps)
   float* R;                   // [N][N] sum over (t, utterance) of the arc posteriors / exp(w)
+  // gradients: per (t, utterance) normaliser log sum_n exp(alpha[t+1][n] + beta[t+1][n]).  It
+  // equals the total score exactly in exact arithmetic; in float32 the two sweeps drift apart
+  // by a few ulps of |score| over T steps, and normalising each time step by its own sum keeps
+  // every step's posterior mass at 1 (the standard alpha-beta remedy).  Null: use `score`.
+  const float* zt;
 };
 size_t lazy_step_lds_bytes(const LazyGroup& g);
 int lazy_tile_nodes();
@@ -330,6 +335,7 @@ void launch_lazy_final(const LazyGroup& g, int mode, hipStream_t st);
 void launch_lazy_path(const LazyGroup& g, int* path_arc, int* path_il, int* path_ol, float* path_w, int* path_len,
                       hipStream_t st);
 // node_label != null: every node's in-arcs share one matched label (no arc loop)
+void launch_lazy_local_z(const LazyGroup& g, float* zt, hipStream_t st);  // [T][nb]
 void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st);
 void launch_lazy_fixed_grad(const LazyGroup& g, int max_in_deg, hipStream_t st);
 struct LazyPathGrad {

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void lazy_chain_grad_nodes_kernel(LazyGroup
   __syncthreads();
   const int64_t o = int64_t(t + 1) * g.nb * g.N + int64_t(b) * g.N;
   // an utterance without any accepting path (score -inf) has an empty product: no gradient
-  const float z0 = g.score[b];
+  const float z0 = g.zt ? g.zt[int64_t(t) * g.nb + b] : g.score[b];
   const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
   const float z = zfin ? z0 : 0.0f, dl = zfin ? *g.delta[b] : 0.0f;
   for (int n = tid; n < g.N; n += kBlock) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void lazy_chain_grad_arcs_kernel(LazyGroup 
   const float* be = g.beta + int64_t(t + 1) * plane + int64_t(b) * g.N;
   const float* em = g.em[b] + int64_t(t) * g.C;
   // an utterance without any accepting path (score -inf) has an empty product: no gradient
-  const float z0 = g.score[b];
+  const float z0 = g.zt ? g.zt[int64_t(t) * g.nb + b] : g.score[b];
   const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
   const float z = zfin ? z0 : 0.0f, dl = zfin ? *g.delta[b] : 0.0f;
   for (int a = tid; a < g.g.A; a += kBlock) {
@@ -337,11 +337,12 @@ __global__ __launch_bounds__(kTile) void lazy_fixed_grad_kernel(LazyGroup g, int
   atomicMax(&sh_deg, deg);
   __syncthreads();
   const int loop_deg = sh_deg;
-  const float z0 = live ? g.score[b] : 0.0f;
-  const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
-  const float z = zfin ? z0 : 0.0f;
-  const float dlt = (live && zfin) ? *g.delta[b] : 0.0f;
+  const float dl0 = live ? *g.delta[b] : 0.0f;
   for (int t = t0; t < t1; ++t) {
+    const float z0 = live ? (g.zt ? g.zt[int64_t(t) * g.nb + b] : g.score[b]) : 0.0f;
+    const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
+    const float z = zfin ? z0 : 0.0f;
+    const float dlt = (live && zfin) ? dl0 : 0.0f;
     __syncthreads();
     const float* src_plane = g.alpha + int64_t(t) * plane;
     {
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kDense) void lazy_dense_fixed_grad_kernel(LazyGroup
       float av = 0.0f, qv = 0.0f;
       if (p < p1) {
         const int t = int(p / g.nb), b = int(p % g.nb);
-        const float z = g.score[b];
+        const float z = g.zt ? g.zt[int64_t(t) * g.nb + b] : g.score[b];
         const float am = g.amax[int64_t(t) * g.nb + b], bm = g.bmax[int64_t(t) * g.nb + b];
         if (z != NEG_INF && z != -NEG_INF && am != NEG_INF && bm != NEG_INF) {
           const float half = 0.5f * (am + bm - z);
@@ -614,6 +615,28 @@ __global__ void lazy_dense_arc_grad_kernel(LazyGroup g) {
   const int d = g.g.dst[r.w];
   const float v = g.R[int64_t(r.x) * g.N + d];
   if (v != 0.0f) atomicAdd(g.grad_fixed + r.w, v * __expf(__int_as_float(r.z)));
+}
+
+// zt[t][b] = log sum_n exp(alpha[t+1][b][n] + beta[t+1][b][n]); one wave per (t, b)
+__global__ void lazy_local_z_kernel(LazyGroup g, float* zt) {
+  const int64_t row = int64_t(blockIdx.x) * (blockDim.x / 64) + threadIdx.x / 64;
+  const int lane = threadIdx.x & 63;
+  if (row >= int64_t(g.T) * g.nb) return;
+  const int t = int(row / g.nb), b = int(row % g.nb);
+  const int64_t o = int64_t(t + 1) * g.nb * g.N + int64_t(b) * g.N;
+  float m = NEG_INF;
+  for (int n = lane; n < g.N; n += 64) m = fmaxf(m, g.alpha[o + n] + g.beta[o + n]);
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+  float sum = 0.0f;
+  if (m != NEG_INF && m != -NEG_INF)
+    for (int n = lane; n < g.N; n += 64) {
+      const float x = g.alpha[o + n] + g.beta[o + n];
+      if (x != NEG_INF) sum += expf(x - m);
+    }
+#pragma unroll
+  for (int k = 32; k > 0; k >>= 1) sum += __shfl_xor(sum, k, 64);
+  if (lane == 0) zt[row] = (m == NEG_INF || m == -NEG_INF) ? m : m + logf(sum);
 }
 
 } // namespace
@@ -667,6 +690,12 @@ void launch_lazy_path(const LazyGroup& g, int* path_arc, int* path_il, int* path
   if (g.nb <= 0) return;
   hipLaunchKernelGGL(lazy_path_kernel, dim3((g.nb + 63) / 64), dim3(64), 0, st, g, path_arc, path_il, path_ol, path_w,
                      path_len);
+}
+
+void launch_lazy_local_z(const LazyGroup& g, float* zt, hipStream_t st) {
+  const int64_t rows = int64_t(g.T) * g.nb;
+  if (rows <= 0) return;
+  hipLaunchKernelGGL(lazy_local_z_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, st, g, zt);
 }
 
 void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st) {

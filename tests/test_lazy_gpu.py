@@ -184,12 +184,10 @@ def test_full_size_c4_invariants(gtn):
     gtn.grads_to_device(ems, out, [b * T * C for b in range(B)])
     gtn.synchronize()
     rows = out.sum(dim=2)
-    # float32 scores of magnitude |z| ~ 9.5e3 resolve 1e-3, so posteriors (exp of score
-    # differences) carry the ~8*eps*|z| relative noise test_parity_gpu.py documents for the
-    # reference itself: 0.9 % here
-    tol = 8 * 1.2e-7 * float(np.abs(f).max())
-    assert float((rows - 1).abs().max()) < max(5e-3, tol)
-    assert float(trans.grad().weights_to_numpy().sum()) == pytest.approx(B * T, rel=max(1e-3, tol))
+    # every time step is normalised by its own alpha-beta sum, so the float32 drift between
+    # the two sweeps (scores of magnitude ~9.5e3 resolve 1e-3) does not reach the posteriors
+    assert float((rows - 1).abs().max()) < 1e-3
+    assert float(trans.grad().weights_to_numpy().sum()) == pytest.approx(B * T, rel=1e-3)
 
 
 def test_dense_regime_with_impossible_emissions_and_transitions(gtn):

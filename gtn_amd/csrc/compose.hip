@@ -227,15 +227,25 @@ __device__ __forceinline__ void wg_barrier(bool lds_only) {
   if (lds_only) lds_barrier(); else __syncthreads();
 }
 
+// wave64 inclusive prefix sum by DPP: row_shr 1/2/4/8 scan each 16-lane row (lanes without a
+// source add 0), row_bcast:15 carries row 0 -> 1 and 2 -> 3, row_bcast:31 carries lanes
+// 0..31 -> rows 2, 3.  Six VALU ops instead of six dependent LDS permutes (__shfl_up).
+__device__ __forceinline__ int wave_incl_scan_dpp(int x) {
+#define GTNX_SCAN_STEP(ctrl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)
+  GTNX_SCAN_STEP(0x111, 0xf);
+  GTNX_SCAN_STEP(0x112, 0xf);
+  GTNX_SCAN_STEP(0x114, 0xf);
+  GTNX_SCAN_STEP(0x118, 0xf);
+  GTNX_SCAN_STEP(0x142, 0xa);
+  GTNX_SCAN_STEP(0x143, 0xc);
+#undef GTNX_SCAN_STEP
+  return x;
+}
+
 template <int BLK = kBlock>
 __device__ __forceinline__ int block_excl_scan(int v, int* sh /*>= 8 ints*/, int& total, bool lds_only = false) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int x = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
-  }
+  const int x = wave_incl_scan_dpp(v);
   wg_barrier(lds_only);  // protect sh from a previous use
   if (lane == 63) sh[wave] = x;
   wg_barrier(lds_only);

@@ -652,10 +652,16 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
       Adj o1{}, o2{};
       Cand c;
       c.n = 0;
-      // clear the claim hash (ordered before its use by the scan's barriers)
-      for (int x = tid; x < HC; x += kBlock) {
-        hkeys[x] = -1;
-        hvals[x] = INT_MAX;
+      // clear the claim table (ordered before its use by the scan's barriers).  In the
+      // time-windowed layout every candidate of this level lives at time L+1, so the partner
+      // node (< No <= HC) indexes the table directly: no keys, no probing
+      if (CH) {
+        for (int x = tid; x < No; x += kBlock) hvals[x] = INT_MAX;
+      } else {
+        for (int x = tid; x < HC; x += kBlock) {
+          hkeys[x] = -1;
+          hvals[x] = INT_MAX;
+        }
       }
       if (live) {
         const int pr = front_in_lds ? front[fcur][node - lo] : a.pair_of[node];
@@ -775,11 +781,16 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
             my_w[m] = w;
             if (REP) { my_i[m] = i; my_j[m] = j; my_il[m] = il; my_ol[m] = ol; }
             if (st[m] < 0) {  // co-reachable, not discovered yet: claim by smallest arc rank
-              unsigned h = (unsigned(c.idx[m]) * 2654435761u) >> (32 - HC_LOG2);
-              while (true) {
-                const int old = atomicCAS(&hkeys[h], -1, c.idx[m]);
-                if (old == -1 || old == c.idx[m]) break;
-                h = (h + 1) & (HC - 1);
+              unsigned h;
+              if (CH) {
+                h = unsigned(other_of(c.idx[m], L + 1));
+              } else {
+                h = (unsigned(c.idx[m]) * 2654435761u) >> (32 - HC_LOG2);
+                while (true) {
+                  const int old = atomicCAS(&hkeys[h], -1, c.idx[m]);
+                  if (old == -1 || old == c.idx[m]) break;
+                  h = (h + 1) & (HC - 1);
+                }
               }
               atomicMin(&hvals[h], r);
               slot[m] = int(h);

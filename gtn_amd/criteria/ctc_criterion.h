@@ -1,0 +1,81 @@
+// ctc_criterion.h -- the CTC criterion of benchmarks/ctc.cpp:40-58,150-165 (same as
+// examples/ctc.cpp:21-41 and bindings/python/examples/pytorch_loss.py) written against the
+// drop-in C++ API of include/gtn, batched: host threads build the target graphs, the graph
+// functions run as batch-of-graphs launches on the GPU, losses and emission gradients stay
+// on the device.  Header-only; used by bench_native/ctc_step.cpp and by
+// gtn_amd/criteria/criteria_capi.cpp (the PyTorch loss).
+#pragma once
+
+#include <chrono>
+#include <cstdint>
+#include <vector>
+
+#include "gtn/gtn.h"
+
+namespace gtn {
+namespace criteria {
+
+/** target acceptor: 2U+1 states, blank at even states, skip arcs between different labels */
+inline Graph ctcTargetGraph(const std::vector<int>& target, int blank = 0, bool calcGrad = true) {
+  const size_t L = 2 * target.size() + 1;
+  Graph ctc(calcGrad);
+  for (size_t l = 0; l < L; l++) {
+    const size_t idx = (l - 1) / 2;
+    ctc.addNode(l == 0, l == L - 1 || l + 2 == L);
+    const int label = l % 2 ? target[idx] : blank;
+    ctc.addArc(l, l, label);
+    if (l > 0) ctc.addArc(l - 1, l, label);
+    if (l % 2 && l > 1 && label != target[idx - 1]) ctc.addArc(l - 2, l, label);
+  }
+  ctc.arcSort();
+  return ctc;
+}
+
+struct CtcStepTimes {
+  double build = 0, linear = 0, intersect = 0, forward = 0, backward = 0;
+};
+
+/** forward + backward of  loss_b = forwardScore(emissions_b) - forwardScore(target_b ∩ emissions_b)
+ *  for a batch.  `emissions`: device [B][T][C]; `lossDev`: device [B]; `gradDev`: device
+ *  [B][T][C] (d loss / d emissions) or null.  Targets may have different lengths. */
+inline void ctcLossBatch(
+    const void* emissions,
+    const std::vector<std::vector<int>>& targets,
+    int T,
+    int C,
+    int blank,
+    void* lossDev,
+    void* gradDev,
+    bool targetGrad = true,  // benchmarks/ctc.cpp builds its targets with calcGrad = true
+    CtcStepTimes* times = nullptr) {
+  const int B = (int)targets.size();
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto t0 = now();
+  auto ctcs =
+      parallelMap([blank, targetGrad](const std::vector<int>& t) { return ctcTargetGraph(t, blank, targetGrad); }, targets);
+  auto t1 = now();
+  auto ems = linearGraphs(B, T, C, emissions, gradDev != nullptr);
+  auto t2 = now();
+  auto comp = batched::intersect(ctcs, ems);
+  auto t3 = now();
+  // (named in this order: C++ leaves the evaluation order of call arguments open)
+  auto norm = batched::forwardScore(ems);
+  auto score = batched::forwardScore(comp);
+  auto losses = batched::subtract(norm, score);
+  auto t4 = now();
+  if (gradDev) batched::backward(losses);
+  auto t5 = now();
+  if (times) *times = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5)};
+  auto h = detail::handles(losses);
+  detail::check(gtnx_items_device_n(h.data(), B, lossDev));
+  if (gradDev) {
+    auto he = detail::handles(ems);
+    std::vector<int64_t> off(B);
+    for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
+    detail::check(gtnx_grads_device_n(he.data(), B, gradDev, off.data()));
+  }
+}
+
+} // namespace criteria
+} // namespace gtn

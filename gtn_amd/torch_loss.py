@@ -5,9 +5,33 @@ bindings/python/examples/pytorch_loss.py:19-102: the emissions tensor never leav
 the GPU (no inputs.cpu(), no per-sample weights_to_numpy), the batch runs through
 the batched graph functions, and the emission gradients come back as one tensor.
 """
+import ctypes as C
+import os
+
+import numpy as np
 import torch
 
 import gtn_amd as gtn
+
+_NATIVE = None
+
+
+def _native():
+    """libgtn_criteria.so (gtn_amd/criteria/): the whole batch step in one native call --
+    target graphs on host threads, batched graph functions, loss and gradient on the device"""
+    global _NATIVE
+    if _NATIVE is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgtn_criteria.so")
+        if os.path.exists(path) and not os.environ.get("GTN_AMD_PYTHON_CRITERIA"):
+            lib = C.CDLL(path)
+            lib.gtn_ctc_loss_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p]
+            lib.gtn_ctc_loss_n.restype = C.c_int
+            lib.gtn_criteria_last_error.restype = C.c_char_p
+            _NATIVE = lib
+        else:
+            _NATIVE = False
+    return _NATIVE
 
 
 def ctc_target_graph(target, blank=0):
@@ -37,6 +61,24 @@ class _CTCLoss(torch.autograd.Function):
         gtn.set_stream(stream.cuda_stream if stream.cuda_stream else None)
         if not stream.cuda_stream:
             torch.cuda.current_stream(x.device).synchronize()  # engine runs on its own stream
+        lib = _native()
+        if lib:
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(t, np.int32).reshape(-1) for t in targets])
+                                        if len(targets) else np.zeros(0, np.int32), dtype=np.int32)
+            lens = np.ascontiguousarray([len(t) for t in targets], dtype=np.int32)
+            out = torch.empty(B, dtype=torch.float32, device=x.device)
+            grad = torch.empty(B, T, C, dtype=torch.float32, device=x.device) if log_probs.requires_grad else None
+            rc = lib.gtn_ctc_loss_n(x.data_ptr(), flat.ctypes.data, lens.ctypes.data, B, T, C, int(blank),
+                                    out.data_ptr(), grad.data_ptr() if grad is not None else None)
+            if rc != 0:
+                raise RuntimeError(lib.gtn_criteria_last_error().decode())
+            if not stream.cuda_stream:
+                gtn.synchronize()
+            ctx.graphs = None
+            ctx.grad = grad
+            ctx.shape = (B, T, C)
+            ctx.reduction = reduction
+            return out.mean() if reduction == "mean" else (out.sum() if reduction == "sum" else out)
         ems = gtn.linear_graph_n(B, T, C, x, calc_grad=log_probs.requires_grad)
         tgs = [ctc_target_graph(list(t), blank) for t in targets]
         losses = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(gtn.intersect(tgs, ems)))
@@ -55,12 +97,15 @@ class _CTCLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        losses, ems = ctx.graphs
         B, T, C = ctx.shape
-        gtn.backward(losses)
-        grad = torch.empty(B, T, C, dtype=torch.float32, device=grad_out.device)
-        gtn.grads_to_device(ems, grad, [b * T * C for b in range(B)])
-        gtn.synchronize()
+        if ctx.graphs is None:
+            grad = ctx.grad  # computed with the forward pass by the native criterion
+        else:
+            losses, ems = ctx.graphs
+            gtn.backward(losses)
+            grad = torch.empty(B, T, C, dtype=torch.float32, device=grad_out.device)
+            gtn.grads_to_device(ems, grad, [b * T * C for b in range(B)])
+            gtn.synchronize()
         if ctx.reduction == "mean":
             scale = (grad_out / B).reshape(1, 1, 1)
         elif ctx.reduction == "sum":

@@ -450,11 +450,17 @@ def test_asg_shape_vs_oracle(gtn):
     np.testing.assert_allclose(trans.grad().weights_to_numpy(), g2, rtol=1e-4, atol=1e-5)
 
 
-def test_torch_ctc_loss_matches_torch_and_oracle(gtn):
+@pytest.mark.parametrize("impl", ["native", "python"])
+def test_torch_ctc_loss_matches_torch_and_oracle(gtn, impl):
     """gtn_amd.torch_loss.ctc_loss (the pytorch_loss.py entry point, device resident)
     against torch.nn.functional.ctc_loss on log-softmax inputs and against the oracle"""
     import torch
+    import gtn_amd.torch_loss as tl
     from gtn_amd.torch_loss import ctc_loss as gtn_ctc
+    # native: libgtn_criteria.so (one call per batch); python: the same ops through gtn_amd.api
+    tl._NATIVE = None if impl == "native" else False
+    if impl == "native":
+        assert tl._native(), "gtn_amd/lib/libgtn_criteria.so missing (build())"
     B, T, C, U = 3, 40, 9, 5
     g = torch.Generator().manual_seed(4)
     x = torch.randn(B, T, C, generator=g)
@@ -700,3 +706,23 @@ def test_viterbi_score_on_ctc_lattices_vs_oracle(gtn, B, T, C, U):
         arcs, _ = oc.shortest_path()
         od = oc.to_dict()
         assert paths[b].labels_to_list() == [od["il"][a] for a in arcs]
+
+
+def test_torch_ctc_loss_ragged_targets_native(gtn):
+    """targets of different lengths through the native criterion"""
+    import torch
+    import gtn_amd.torch_loss as tl
+    tl._NATIVE = None
+    if not tl._native():
+        pytest.skip("libgtn_criteria.so not built")
+    T, C = 30, 7
+    targets = [[1, 2, 3], [4], [2, 2, 5, 6, 1], []]
+    B = len(targets)
+    x = torch.randn(B, T, C, generator=torch.Generator().manual_seed(9))
+    lp = x.cuda().requires_grad_(True)
+    loss = tl.ctc_loss(lp, targets, blank=0, reduction="none")
+    loss.sum().backward()
+    for b in range(B):
+        want, wgrad = ctc_loss(x[b].numpy(), np.asarray(targets[b], np.int32))
+        assert float(loss[b].detach()) == pytest.approx(want, rel=1e-4, abs=1e-5)
+        np.testing.assert_allclose(lp.grad[b].cpu().numpy(), wgrad, rtol=1e-4, atol=1e-5)

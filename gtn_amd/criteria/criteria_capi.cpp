@@ -4,6 +4,10 @@
 #include <cstring>
 #include <string>
 
+#include <map>
+#include <mutex>
+
+#include "asg_criterion.h"
 #include "ctc_criterion.h"
 
 namespace {
@@ -26,6 +30,44 @@ extern "C" __attribute__((visibility("default"))) int gtn_ctc_loss_n(const void*
       o += size_t(lengths[b]);
     }
     gtn::criteria::ctcLossBatch(emissions, tg, T, C, blank, loss, grad, /*targetGrad=*/false);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
+// ASG over a shared transitions graph.  emissions: DEVICE float [B][T][N]; targets / lengths:
+// host int32 (concatenated / [B]); trans_w: DEVICE float [N + N*N] in the arc order of
+// gtn::criteria::asgTransitions BEFORE its arcSort (arc i: <s> -> i; arc N + i*N + j: j -> i);
+// loss: DEVICE float [B]; grad_em: DEVICE [B][T][N] or null; grad_trans: DEVICE [N + N*N] or null.
+extern "C" __attribute__((visibility("default"))) int gtn_asg_loss_n(const void* emissions, const int* targets,
+                                                                     const int* lengths, int B, int T, int N,
+                                                                     const void* trans_w, void* loss, void* grad_em,
+                                                                     void* grad_trans) {
+  try {
+    // the transitions STRUCTURE is kept across calls (a trainer only changes the weights)
+    static std::mutex mu;
+    static auto* cache = new std::map<int, gtn::Graph>();  // never destroyed: outlives the engine's teardown
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache->find(N);
+    if (it == cache->end()) it = cache->emplace(N, gtn::criteria::asgTransitions(N)).first;
+    gtn::Graph& trans = it->second;
+    trans.setCalcGrad(grad_trans != nullptr);
+    trans.zeroGrad();
+    trans.setWeightsDevice(trans_w);  // arc ids are creation order: arcSort permutes lists, not ids
+    std::vector<std::vector<int>> tg(B);
+    size_t o = 0;
+    for (int b = 0; b < B; ++b) {
+      tg[b].assign(targets + o, targets + o + lengths[b]);
+      o += size_t(lengths[b]);
+    }
+    gtn::criteria::asgLossBatch(emissions, tg, T, N, trans, loss, grad_em);
+    if (grad_trans) {
+      gtnx_graph_t h = trans.handle();
+      int64_t off = 0;
+      gtn::detail::check(gtnx_grads_device_n(&h, 1, grad_trans, &off));
+    }
     return 0;
   } catch (const std::exception& e) {
     g_err = e.what();

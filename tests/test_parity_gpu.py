@@ -726,3 +726,75 @@ def test_torch_ctc_loss_ragged_targets_native(gtn):
         want, wgrad = ctc_loss(x[b].numpy(), np.asarray(targets[b], np.int32))
         assert float(loss[b].detach()) == pytest.approx(want, rel=1e-4, abs=1e-5)
         np.testing.assert_allclose(lp.grad[b].cpu().numpy(), wgrad, rtol=1e-4, atol=1e-5)
+
+
+def test_torch_asg_loss_reference_known_answers(gtn):
+    """gtn_amd.torch_loss.asg_loss (native gtn_asg_loss_n) on test/criterion_test.cpp:182-306:
+    losses, emission gradients and the batch-summed transition gradient"""
+    import torch
+    import gtn_amd.torch_loss as tl
+    tl._NATIVE = None
+    assert tl._native(), "gtn_amd/lib/libgtn_criteria.so missing (build())"
+    T, N = 5, 6
+    targets = [[2, 1, 5, 1, 3], [4, 3, 5], [3, 2, 2, 1]]
+    expected_loss = [7.7417464256287, 6.4200420379639, 8.2780694961548]
+    em = torch.tensor(np.asarray(ASG_EMISSIONS, np.float32).reshape(3, T, N)).cuda().requires_grad_(True)
+    tr = torch.zeros(N, N, device="cuda", requires_grad=True)
+    st = torch.zeros(N, device="cuda", requires_grad=True)
+    for _ in range(2):  # second pass: cached transitions structure, gradients must not carry over
+        em.grad = tr.grad = st.grad = None
+        loss = tl.asg_loss(em, tr, targets, start=st, reduction="none")
+        loss.sum().backward()
+        np.testing.assert_allclose(loss.detach().cpu().numpy(), expected_loss, atol=1e-3)
+        np.testing.assert_allclose(em.grad.cpu().numpy().reshape(3, -1), np.asarray(ASG_EM_GRADS), atol=1e-4)
+        np.testing.assert_allclose(tr.grad.cpu().numpy().reshape(-1), ASG_TRANS_GRAD, atol=1e-4)
+    # every alignment starts with exactly one start arc: fcc posterior mass 1, fal mass 1 on target[0]
+    sg = st.grad.cpu().numpy()
+    assert abs(sg.sum()) < 1e-4
+
+
+def test_torch_asg_loss_vs_graph_api_random_weights(gtn):
+    """random transition / start scores: native criterion == the same graph ops through gtn_amd.api"""
+    import torch
+    import gtn_amd.torch_loss as tl
+    tl._NATIVE = None
+    assert tl._native()
+    B, T, N = 4, 12, 5
+    g = torch.Generator().manual_seed(21)
+    em = torch.randn(B, T, N, generator=g)
+    tw = torch.randn(N, N, generator=g)
+    sw = torch.randn(N, generator=g)
+    targets = [[1, 2, 2, 3], [0], [4, 4, 4], [3, 1, 0, 2, 4]]
+    e_t = em.cuda().requires_grad_(True)
+    t_t = tw.cuda().requires_grad_(True)
+    s_t = sw.cuda().requires_grad_(True)
+    loss = tl.asg_loss(e_t, t_t, targets, start=s_t, reduction="mean")
+    loss.backward()
+    # graph API, per utterance
+    trans = asg_transitions(gtn, N, tw.numpy().reshape(-1))
+    wts = trans.weights_to_numpy().copy()
+    wts[:N] = sw.numpy()
+    trans.set_weights(wts)
+    vals = []
+    ems = []
+    for b in range(B):
+        fal = gtn.Graph(False)
+        fal.add_node(True, False)
+        for l in range(1, len(targets[b]) + 1):
+            fal.add_node(False, l == len(targets[b]))
+            fal.add_arc(l - 1, l, targets[b][l - 1])
+            fal.add_arc(l, l, targets[b][l - 1])
+        e = gtn.linear_graph(T, N)
+        e.set_weights(em[b].numpy().reshape(-1))
+        l_ = gtn.subtract(gtn.forward_score(gtn.compose(e, trans)),
+                          gtn.forward_score(gtn.compose(gtn.compose(fal, trans), e)))
+        gtn.backward(l_)
+        vals.append(l_.item())
+        ems.append(e)
+    assert float(loss.detach()) == pytest.approx(np.mean(vals), rel=1e-4)
+    for b in range(B):
+        np.testing.assert_allclose(e_t.grad[b].cpu().numpy().reshape(-1), ems[b].grad().weights_to_numpy() / B,
+                                   rtol=1e-3, atol=1e-5)
+    tg = trans.grad().weights_to_numpy() / B
+    np.testing.assert_allclose(s_t.grad.cpu().numpy(), tg[:N], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(t_t.grad.cpu().numpy().reshape(-1), tg[N:], rtol=1e-3, atol=1e-5)

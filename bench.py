@@ -222,29 +222,79 @@ def main():
     e0 = gtn.linear_graph_n(1, T, Cn, em_dev)
     comp = gtn.intersect(build_ctc_graphs(gtn, tg[:1]), e0)
     ems = e0
-    fs = prof.get("forward_score", {"total_ms": 0.0, "launches": 0, "algorithmic_bytes": 0.0})
-    roof = None
-    if fs["launches"]:
-        ms = fs["total_ms"] / fs["launches"]
-        gbs = fs["algorithmic_bytes"] / fs["launches"] / (ms * 1e-3) / 1e9
-        # HBM bytes per launch from the PMC run of this same command (rocprofv3 --pmc
-        # FETCH_SIZE / WRITE_SIZE in separate passes; newest profiles/r*_c3_pmc_hbm.json).
-        # Calibrated on linear_forward_kernel, whose bytes are known exactly
-        # (B*T*C*4): FETCH_SIZE reads half the fetched KiB on gfx950, WRITE_SIZE is exact.
-        traffic = None
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_pmc_hbm.json")))
-        pmc = pmcs[-1] if pmcs else ""
-        if (B, T, Cn, U) == (512, 1000, 256, 100) and pmc:
-            k = json.load(open(pmc)).get("sd_forward_narrow_kernel<true>")
-            if k:
-                traffic = (2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024
-        roof = {"bound": "hbm", "kernel": "sd_forward_narrow_kernel<true> (forwardScore over the composed lattices)",
-                "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                "traffic": traffic, "ms_per_launch": ms,
-                "algorithmic_bytes_per_launch": fs["algorithmic_bytes"] / fs["launches"]}
+    n_nodes, n_arcs = comp[0].num_nodes(), comp[0].num_arcs()
+
+    # ---- roofline of every profiled kernel family of the timed loop, against HBM peak.
+    # Algorithmic bytes per launch (DESIGN.md section 3 / SURVEY.md section 8d):
+    #   lazy_pair_forward_score       4TC + 4(T+1)N per utterance  (emissions in, alpha out)
+    #   lazy_pair_forward_score_grad  8TC + 4(T+1)N + 4A           (emissions in, gradient out, alpha in)
+    #   linear_forward / _grad        4TC  /  12TC                 (rows in; rows in + gradient read-modify-write)
+    #   intersect                     36A + 8N of the built lattice;  forward_score 24A + 12N (reported by
+    #   the engine);  forward_score_grad 24A + 12N + 4TC
+    # measured = the engine's hipEvent pairs around each family on the launch stream.
+    KERNEL_OF = {
+        "lazy_pair_forward_score": "lazy_pair_forward_kernel<256>",
+        "lazy_pair_forward_score_grad": "lazy_pair_backward_kernel<256, 16>",
+        "linear_forward": "linear_rows_kernel<false>",
+        "linear_forward_grad": "linear_rows_kernel<true>",
+        "forward_score": "sd_forward_narrow_kernel<true>",
+        "forward_score_grad": "sd_backward_narrow_kernel<true>",
+        "intersect": "compose_kernel<3, false, true, true, true, 256>",
+    }
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_pmc_hbm.json")))
+    pmc = json.load(open(pmcs[-1])) if pmcs and (B, T, Cn, U) == (512, 1000, 256, 100) else {}
+
+    def rooflines(pr):
+        fixed = {"linear_forward": B * 4.0 * T * Cn, "linear_forward_grad": B * 12.0 * T * Cn,
+                 "intersect": B * (36.0 * n_arcs + 8.0 * n_nodes),
+                 "forward_score_grad": B * (24.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}
+        out = {}
+        for name, e in pr.items():
+            if not e["launches"] or name not in KERNEL_OF:
+                continue
+            per = fixed.get(name, e["algorithmic_bytes"] / e["launches"])
+            ms = e["total_ms"] / e["launches"]
+            if per <= 0 or ms <= 0:
+                continue
+            k = pmc.get(KERNEL_OF[name])
+            # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE, separate passes; newest profiles/r*_c3_pmc_hbm.json).  Calibrated on
+            # linear_rows_kernel<false>, whose bytes are known exactly: FETCH_SIZE reads half the
+            # fetched KiB on gfx950, WRITE_SIZE is exact (profiles/README.md)
+            traffic = (2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024 if k else None
+            gbs = per / (ms * 1e-3) / 1e9
+            out[name] = {"bound": "hbm", "kernel": KERNEL_OF[name], "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "ms_per_launch": ms,
+                         "algorithmic_bytes_per_launch": per}
+        return out
+
+    roofs = rooflines(prof)
+    dominant = max(roofs, key=lambda k: roofs[k]["ms_per_launch"]) if roofs else None
+    roof = roofs.get(dominant)
+
+    # ---- the same step with every lattice BUILT (the path graphs that are not CTC-shaped take,
+    # and what GTNX_LAZY_COMPOSE=0 selects): untimed for `value`, profiled for its kernels
+    built = None
+    if native is not None and "lazy_pair_forward_score" in prof and not os.environ.get("GTNX_LAZY_COMPOSE"):
+        os.environ["GTNX_LAZY_COMPOSE"] = "0"
+        try:
+            for _ in range(3):
+                step()
+            fence()
+            gtn.prof_reset()
+            gtn.prof_enable(True)
+            t1 = time.perf_counter()
+            for _ in range(5):
+                step()
+            fence()
+            dt_built = (time.perf_counter() - t1) / 5
+            gtn.prof_enable(False)
+            pb = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+            built = {"ms_per_step": dt_built * 1e3, "losses_per_s": B / dt_built, "roofline": rooflines(pb)}
+        finally:
+            os.environ.pop("GTNX_LAZY_COMPOSE", None)
     if rank == 0:
-        n_nodes, n_arcs = comp[0].num_nodes(), comp[0].num_arcs()
         losses = loss_dev.cpu().numpy()
         out = {
             "metric": "CTC forward+backward losses/sec (T=1000, C=256)" if (T, Cn) == (1000, 256)
@@ -266,18 +316,10 @@ def main():
                        "parallelism": f"dp{world} (utterance sharding, all_gather of losses)",
                        "host": "python (gtn_amd/api.py)" if native is None else "C++ (include/gtn/, bench_native/ctc_step.cpp)"},
             "roofline": roof,
-            # the other two big kernels against the same 8 TB/s, algorithmic bytes as SURVEY.md
-            # section 8(d) defines them (utterance 0's lattice size x batch): compose writes
-            # 36A + 8N; forwardScore's backward with the fused compose-gradient scatter reads /
-            # writes 12A + 12N (shortest distance) + 12A + 4TC (compose gradient)
-            "roofline_other": {
-                name: {"achieved": bytes_ / (prof[name]["total_ms"] / prof[name]["launches"] * 1e-3) / 1e9,
-                       "frac": bytes_ / (prof[name]["total_ms"] / prof[name]["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                       "unit": "GB/s", "algorithmic_bytes_per_launch": bytes_,
-                       "ms_per_launch": prof[name]["total_ms"] / prof[name]["launches"]}
-                for name, bytes_ in (("intersect", B * (36.0 * n_arcs + 8.0 * n_nodes)),
-                                     ("forward_score_grad", B * (24.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)))
-                if name in prof and prof[name]["launches"]},
+            # every other kernel family of the timed loop against the same 8 TB/s
+            "roofline_other": {k: v for k, v in roofs.items() if k != dominant},
+            # the step with the lattices built (compose -> forwardScore kernel -> fused backward)
+            "built_lattice_path": built,
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
             "loss_mean": float(np.mean(losses)),
         }

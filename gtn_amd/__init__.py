@@ -38,6 +38,7 @@ device_count = _api.device_count
 synchronize = _api.synchronize
 set_device = _api.set_device
 set_stream = _api.set_stream
+compose_mode = _api.compose_mode
 memory_stats = _api.memory_stats
 empty_cache = _api.empty_cache
 prof_enable = _api.prof_enable

@@ -24,6 +24,7 @@ OK, INVALID_ARGUMENT, LOGIC_ERROR, RUNTIME_ERROR, OUT_OF_RANGE, DEVICE_ERROR = r
 _SIGS = {
     "gtnx_set_device": [C.c_int],
     "gtnx_set_stream": [C.c_void_p],
+    "gtnx_compose_mode": [C.c_int, C.POINTER(C.c_int)],
     "gtnx_synchronize": [],
     "gtnx_memory_stats": [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gtnx_empty_cache": [],

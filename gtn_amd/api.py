@@ -454,6 +454,13 @@ def make_api(lib):
         """stream: hipStream_t address (torch.cuda.Stream.cuda_stream) or None"""
         check(lib.gtnx_set_stream(int(stream) if stream else None))
 
+    def compose_mode(mode):
+        """0: build compositions (default); 1: keep chain compositions symbolic whenever eligible;
+        2: when the per-utterance sweep kernels apply.  Returns the previous mode (gtn_amd.h)."""
+        prev = C.c_int()
+        check(lib.gtnx_compose_mode(int(mode), C.byref(prev)))
+        return prev.value
+
     def memory_stats():
         r, u = C.c_uint64(), C.c_uint64()
         check(lib.gtnx_memory_stats(C.byref(r), C.byref(u)))
@@ -480,6 +487,7 @@ def make_api(lib):
     ns.synchronize = synchronize
     ns.set_device = set_device
     ns.set_stream = set_stream
+    ns.compose_mode = compose_mode
     ns.memory_stats = memory_stats
     ns.empty_cache = lambda: check(lib.gtnx_empty_cache())
     ns.prof_enable = prof_enable

@@ -58,6 +58,7 @@ inline void asgLossBatch(
   auto fals = parallelMap(asgForceAlign, targets);
   auto ems = linearGraphs(B, T, N, emissions, gradDev != nullptr);
   std::vector<Graph> trans{transitions};
+  SymbolicCompose symbolic;  // force-align lattices: per-utterance sweeps where they apply
   auto fcc = batched::forwardScore(batched::compose(ems, trans));
   auto fal = batched::forwardScore(batched::compose(ems, batched::compose(fals, trans)));
   auto losses = batched::subtract(fcc, fal);

@@ -57,6 +57,8 @@ inline void ctcLossBatch(
   auto t1 = now();
   auto ems = linearGraphs(B, T, C, emissions, gradDev != nullptr);
   auto t2 = now();
+  // only forwardScore of the lattices is taken: they need not be built (lazy_pair.hip sweeps them)
+  SymbolicCompose symbolic;
   auto comp = batched::intersect(ctcs, ems);
   auto t3 = now();
   // (named in this order: C++ leaves the evaluation order of call arguments open)

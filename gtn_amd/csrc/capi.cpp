@@ -78,6 +78,13 @@ GTNX_API gtnx_status_t gtnx_set_device(int d) {
     }
   });
 }
+GTNX_API gtnx_status_t gtnx_compose_mode(int mode, int* previous) {
+  return guard([&] {
+    if (mode < 0 || mode > 2) throw_invalid("[gtnx_compose_mode] mode must be 0, 1 or 2");
+    const int old = compose_mode_hint(mode);
+    if (previous) *previous = old;
+  });
+}
 GTNX_API gtnx_status_t gtnx_set_stream(void* s) {
   return guard([&] { Runtime::get().set_stream(static_cast<hipStream_t>(s)); });
 }

@@ -27,7 +27,19 @@ void Structure::touch() {
   rec_mem.reset();
   sched.reset();
   csr_valid = false;
+  max_deg = -1;
   ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65
+}
+
+int Structure::max_degree() {
+  if (max_deg >= 0) return max_deg;
+  if (kind == KIND_LINEAR) return max_deg = (M > 0 ? C : 0);
+  ensure_host();
+  ensure_csr();
+  int d = 0;
+  for (int64_t n = 0; n < N; ++n)
+    d = std::max(d, std::max(out_off[n + 1] - out_off[n], in_off[n + 1] - in_off[n]));
+  return max_deg = d;
 }
 
 void Structure::materialize() {
@@ -245,6 +257,11 @@ Graph::Graph(bool calc_grad)
   g->calc_grad = calc_grad;
 }
 
+Graph::Graph(bool calc_grad, std::shared_ptr<Structure> shared)
+    : s(std::move(shared)), w(std::make_shared<Weights>()), g(std::make_shared<GradState>()) {
+  g->calc_grad = calc_grad;
+}
+
 Graph Graph::make_result(bool calc_grad) { return Graph(calc_grad); }
 
 int Graph::add_node(bool start, bool accept) {
@@ -407,8 +424,7 @@ void Graph::set_calc_grad(bool c) {
 }
 
 static void make_grad_graph(Graph& self) {
-  self.g->grad = std::make_unique<Graph>(false);
-  self.g->grad->s = self.s;  // shares the structure (graph.cpp:102-103)
+  self.g->grad = std::unique_ptr<Graph>(new Graph(false, self.s));  // shares the structure (graph.cpp:102-103)
 }
 
 void Graph::add_grad_host(const float* v, int64_t n) {

@@ -96,6 +96,9 @@ struct Structure {
   // products).  Nothing else in the structure is valid until realize() fills it in.
   std::shared_ptr<struct LazyProduct> lazy;
 
+  int max_deg = -1;     // widest in- or out-row (cached; touch() forgets it)
+  int max_degree();
+
   void materialize();  // LINEAR -> EXPLICIT host arrays
   void ensure_host();  // download a device-built structure
   void ensure_csr();
@@ -134,6 +137,7 @@ struct Graph {
   std::shared_ptr<GradState> g;
 
   explicit Graph(bool calc_grad = true);
+  Graph(bool calc_grad, std::shared_ptr<Structure> shared);  // fresh weights / grad state over an existing structure
   static Graph make_result(bool calc_grad);  // fresh pieces, for op outputs
 
   // graph.cpp:33-67

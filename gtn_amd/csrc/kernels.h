@@ -349,6 +349,24 @@ struct LazyPathGrad {
   float* grad_fixed;    // [A] or null
 };
 void launch_lazy_path_grad(const LazyPathGrad& a, hipStream_t st);
+// one workgroup per (chain, small G) pair: lazy_pair.hip
+struct LazyPair {
+  DGraph g;                    // G with packed records and weights
+  const GTNX_G float* em;      // [T][C] chain weights
+  GTNX_G float* alpha;         // [T+1][N]
+  GTNX_G float* score;         // [1]
+  const GTNX_G float* delta;   // [1] upstream gradient of the score   (backward)
+  GTNX_G float* grad_em;       // [T][C] written completely, or null   (backward)
+  GTNX_G float* grad_fixed;    // [A] zero-filled by the host, or null (backward)
+  int T, C, chain_first, pad;
+};
+int lazy_pair_max_nodes();
+int lazy_pair_max_degree();
+int lazy_pair_block(int max_nodes);   // lanes per workgroup for a batch whose largest G has max_nodes
+int lazy_pair_max_labels(int block);
+// all pairs of one launch share C; cus: compute units of the device (workgroups are spread evenly)
+void launch_lazy_pair_forward(const LazyPair* d_pairs, int n, int block, int C, int cus, hipStream_t st);
+void launch_lazy_pair_backward(const LazyPair* d_pairs, int n, int block, int C, int cus, hipStream_t st);
 // dense regime
 void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set
 // backward: vin / vout = the two halves of a [2][nb][N] scratch (vin null on the first step)

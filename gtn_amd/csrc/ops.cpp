@@ -33,6 +33,20 @@ void init_scalar_structure(Graph& g) {
   s.host_valid = true;
 }
 
+// The same graph as an OP RESULT.  A scalar result is the linear graph with one step and
+// one label (node 0 -> node 1, label 0), so it uses the implicit KIND_LINEAR form: no host
+// arrays at all -- a training step makes three scalars per utterance, and their seven
+// one-element vectors each were a sixth of the step's allocations.
+void init_scalar_result(Graph& g) {
+  Structure& s = *g.s;
+  s.kind = KIND_LINEAR;
+  s.M = 1;
+  s.C = 1;
+  s.N = 2;
+  s.A = 1;
+  s.host_valid = true;  // implicit
+}
+
 // result graph on the tape: calcGrad = any(inputs) (graph.cpp:16-27)
 Graph make_output(const std::shared_ptr<OpRecord>& op, int idx, std::vector<Graph> inputs) {
   bool cg = false;
@@ -53,6 +67,7 @@ std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical)
 std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs);
 std::shared_ptr<OpRecord> make_lazy_compose_op();
 bool lazy_shape_ok(const Structure& chain, const Structure& fixed);
+bool lazy_pair_shape_ok(const Structure& chain, Structure& fixed);
 
 template <class T>
 const T& bcast(const std::vector<T>& v, size_t n, size_t i) {
@@ -246,7 +261,7 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
     }
     args[i].out = res->as<float>() + i;
     Graph out = make_output(op, int(i), std::move(ins));
-    init_scalar_structure(out);
+    init_scalar_result(out);
     set_dev_weights(out, res, res->as<float>() + i, 1);
     outs.push_back(std::move(out));
   }
@@ -554,7 +569,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       maxM = std::max(maxM, a.M);
       bytes += 4.0 * double(g.num_arcs());
       Graph out = make_output(op, k, {g});
-      init_scalar_structure(out);
+      init_scalar_result(out);
       set_dev_weights(out, res, scal + k, 1);
       outs[lin[k]] = std::move(out);
     }
@@ -646,7 +661,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
         alg += 8.0 * double(g.num_arcs()) + 8.0 * double(g.num_nodes());
       }
       Graph out = make_output(op, k, {g});
-      init_scalar_structure(out);
+      init_scalar_result(out);
       set_dev_weights(out, arena, a.out_score, 1);
       outs[exp[k]] = std::move(out);
     }
@@ -991,6 +1006,15 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   return op_compose_impl(av, bv, intersect, true);
 }
 
+namespace {
+thread_local int t_compose_mode = 0;
+}
+int compose_mode_hint(int mode) {
+  const int old = t_compose_mode;
+  t_compose_mode = mode;
+  return old;
+}
+
 std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect, bool allow_lazy) {
   GTNX_HOST_T("compose.total");
   const size_t n = std::max(av.size(), bv.size());
@@ -1096,11 +1120,17 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   // ---- keep the product symbolic?  Only a chain product with an epsilon-free partner
   // qualifies; it is taken when building the batch would not fit (or on request).
   if (allow_lazy) {
-    const char* env = getenv("GTNX_LAZY_COMPOSE");  // "1": whenever eligible, "0": never
-    const bool force = env && env[0] == '1', never = env && env[0] == '0';
+    // mode 0: only when the batch would not fit; 1: whenever eligible; 2: when the per-pair
+    // kernels of lazy_pair.hip apply.  The caller's hint (gtnx_compose_mode), overridden by
+    // GTNX_LAZY_COMPOSE ("0" additionally forbids symbolic products altogether)
+    const char* env = getenv("GTNX_LAZY_COMPOSE");
+    const int mode = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : t_compose_mode;
+    const bool force = mode == 1, never = env && env[0] == '0';
     const char* benv = getenv("GTNX_LAZY_BYTES");
     const double budget = benv ? atof(benv) : 128e9;
     bool eligible = !never;
+    // "2": also whenever every product has the per-pair kernels of lazy_pair.hip (small G)
+    bool pairs = mode == 2;
     double est = 0;
     for (size_t i = 0; i < n && eligible; ++i) {
       Graph& a = const_cast<Graph&>(bcast(av, n, i));
@@ -1108,9 +1138,14 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
       eligible = (l1 != l2) && (((l1 ? b : a).s->dview.flags & GF_EPS_FREE) != 0) &&
                  lazy_shape_ok(*(l1 ? a : b).s, *(l1 ? b : a).s);
+      pairs = pairs && eligible && lazy_pair_shape_ok(*(l1 ? a : b).s, *(l1 ? b : a).s);
       est += 44.0 * double(caps[i].Acap) + 30.0 * double(caps[i].Ncap) + 8.0 * double(caps[i].pairs);
     }
-    if (eligible && (force || est > budget)) {
+    if (eligible && (force || pairs || est > budget)) {
+      // nothing downstream of a symbolic product waits for the GPU, so this is the step's
+      // reclamation point (objects the caller let go of since the last one; cheap while
+      // their memory is still warm for the allocator -- see Runtime::defer_delete)
+      rt.drain_deferred();
       auto lop = make_lazy_compose_op();
       for (size_t i = 0; i < n; ++i) {
         Graph& a = const_cast<Graph&>(bcast(av, n, i));
@@ -1883,7 +1918,7 @@ struct LazySdOp : OpRecord {
   }
 };
 
-std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+std::vector<Graph> lazy_group_shortest_distance(std::vector<Graph>& gs, bool tropical) {
   auto op = std::make_shared<LazySdOp>();
   op->mode = tropical ? SD_TROPICAL : SD_LOG;
   op->seq = g_seq++;
@@ -1892,11 +1927,175 @@ std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical)
   for (size_t i = 0; i < gs.size(); ++i) {
     LazyGroupState& st = *op->groups[op->slot[i].first];
     Graph out = make_output(op, int(i), {gs[i]});
-    init_scalar_structure(out);
+    init_scalar_result(out);
     set_dev_weights(out, st.arena, st.view.score + op->slot[i].second, 1);
     outs.push_back(std::move(out));
   }
   return outs;
+}
+
+// ---- one workgroup per (chain, small G) pair: lazy_pair.hip.  The CTC shape -- every
+// utterance brings its own target graph -- where the batched time-step kernels above
+// (one G shared by the batch) would run one launch per utterance and time step.
+bool lazy_pair_shape_ok(const Structure& cs, Structure& fs) {
+  if (fs.kind != KIND_EXPLICIT || fs.N < 1 || fs.N > lazy_pair_max_nodes() || cs.C < 1) return false;
+  if (cs.C > lazy_pair_max_labels(lazy_pair_block(int(fs.N)))) return false;
+  return fs.max_degree() <= lazy_pair_max_degree();
+}
+bool lazy_pair_ok(const LazyProduct& lp) { return lazy_pair_shape_ok(*lp.chain.s, *lp.fixed.s); }
+
+struct LazyPairSdOp : OpRecord {
+  std::vector<LazyPair> pairs;  // by output index; device pointers
+  std::vector<Graph> chains, fixed;
+  DevMemP arena;                // alpha planes + scores
+
+  // launches `tab` (any order) grouped by label count, widest G of a group picks the block
+  static void launch(std::vector<LazyPair>& tab, bool backward) {
+    Runtime& rt = Runtime::get();
+    if (tab.empty()) return;
+    std::stable_sort(tab.begin(), tab.end(), [](const LazyPair& x, const LazyPair& y) { return x.C < y.C; });
+    DevMemP d = upload_vec(tab);
+    const LazyPair* dp = d->as<LazyPair>();
+    for (size_t i0 = 0; i0 < tab.size();) {
+      size_t i1 = i0;
+      int maxn = 0;
+      while (i1 < tab.size() && tab[i1].C == tab[i0].C) maxn = std::max(maxn, tab[i1++].g.N);
+      const int blk = lazy_pair_block(maxn);
+      if (backward)
+        launch_lazy_pair_backward(dp + i0, int(i1 - i0), blk, tab[i0].C, rt.cu_count(), rt.stream());
+      else
+        launch_lazy_pair_forward(dp + i0, int(i1 - i0), blk, tab[i0].C, rt.cu_count(), rt.stream());
+      i0 = i1;
+    }
+  }
+
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    GradSink sink;
+    size_t eb = 0, fb = 0;
+    std::vector<size_t> eo(ms.size(), 0), fo(ms.size(), 0);
+    for (size_t k = 0; k < ms.size(); ++k) {
+      const int i = ms[k].idx;
+      if (chains[i].calc_grad()) {
+        eo[k] = eb;
+        eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+      }
+      if (fixed[i].calc_grad()) {
+        fo[k] = fb;
+        fb = align_up(fb + 4 * size_t(pairs[i].g.A), 256);
+      }
+    }
+    DevMemP gem = rt.alloc(eb ? eb : 1);       // every row is written by the kernel
+    DevMemP gfx = rt.alloc_zero(fb ? fb : 1);  // arcs that never match stay 0
+    std::vector<LazyPair> tab;
+    tab.reserve(ms.size());
+    for (size_t k = 0; k < ms.size(); ++k) {
+      const int i = ms[k].idx;
+      LazyPair p = pairs[i];
+      p.delta = grad_dev_ptr(ms[k].out);
+      p.grad_em = chains[i].calc_grad() ? gem->as<float>(eo[k]) : nullptr;
+      p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
+      tab.push_back(p);
+      if (p.grad_em) sink.add(chains[i], gem, p.grad_em);
+      if (p.grad_fixed) sink.add(fixed[i], gfx, p.grad_fixed);
+      ms[k].out.g->inputs[0].g->grad_propagated = true;
+    }
+    {
+      // algorithmic bytes: emissions in, emission gradient out, alpha back in, G's arc gradients out
+      double bytes = 0;
+      for (const LazyPair& p : tab)
+        bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.g.N + (p.grad_fixed ? 4.0 * p.g.A : 0.0);
+      GTNX_PROF("lazy_pair_forward_score_grad", bytes);
+      launch(tab, true);
+    }
+    sink.flush();
+  }
+};
+
+std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
+  Runtime& rt = Runtime::get();
+  auto op = std::make_shared<LazyPairSdOp>();
+  op->seq = g_seq++;
+  const size_t n = gs.size();
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  for (size_t i = 0; i < n; ++i) {
+    LazyProduct& lp = *gs[i].s->lazy;
+    op->chains.push_back(lp.chain);
+    op->fixed.push_back(lp.fixed);
+    ss.push_back(lp.fixed.s.get());
+    ws.push_back(lp.fixed.w.get());
+    ws.push_back(lp.chain.w.get());
+  }
+  ensure_device_batch(ss);
+  ensure_weights_device_batch(ws);
+  for (Structure* st : ss) {  // device-built G: packed records on demand
+    if (st->dview.out_rec || st->A == 0) continue;
+    st->ensure_full();
+    st->rec_mem = rt.alloc(32 * size_t(st->A));
+    gtnx_i4* orec = st->rec_mem->as<gtnx_i4>();
+    gtnx_i4* irec = orec + st->A;
+    launch_build_records(st->dview, orec, irec, rt.stream());
+    st->dview.out_rec = orec;
+    st->dview.in_rec = irec;
+  }
+  size_t bytes = align_up(4 * n, 256);
+  std::vector<size_t> ao(n);
+  for (size_t i = 0; i < n; ++i) {
+    ao[i] = bytes;
+    bytes = align_up(bytes + 4 * size_t(op->chains[i].s->M + 1) * size_t(op->fixed[i].s->N), 256);
+  }
+  op->arena = rt.alloc(bytes);
+  op->pairs.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    LazyPair& p = op->pairs[i];
+    p = LazyPair{};
+    p.g = device_view(op->fixed[i]);
+    p.em = op->chains[i].w->dev;
+    p.alpha = op->arena->as<float>(ao[i]);
+    p.score = op->arena->as<float>(4 * i);
+    p.T = op->chains[i].s->M;
+    p.C = op->chains[i].s->C;
+    p.chain_first = gs[i].s->lazy->chain_side == 1;
+  }
+  {
+    double bytes = 0;  // algorithmic: emissions in, alpha out (kept for the backward sweep)
+    for (const LazyPair& p : op->pairs) bytes += 4.0 * p.T * p.C + 4.0 * double(p.T + 1) * p.g.N;
+    GTNX_PROF("lazy_pair_forward_score", bytes);
+    std::vector<LazyPair> tab = op->pairs;
+    LazyPairSdOp::launch(tab, false);
+  }
+  std::vector<Graph> outs;
+  outs.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    Graph out = make_output(op, int(i), {gs[i]});
+    init_scalar_result(out);
+    set_dev_weights(out, op->arena, op->pairs[i].score, 1);
+    outs.push_back(std::move(out));
+  }
+  return outs;
+}
+
+std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+  if (!tropical && !getenv("GTNX_NO_LAZY_PAIRS")) {
+    std::vector<Graph> pr, gr;
+    std::vector<size_t> pi, gi;
+    for (size_t i = 0; i < gs.size(); ++i) {
+      if (lazy_pair_ok(*gs[i].s->lazy)) { pr.push_back(gs[i]); pi.push_back(i); }
+      else { gr.push_back(gs[i]); gi.push_back(i); }
+    }
+    if (!pr.empty()) {
+      std::vector<Graph> outs(gs.size(), Graph(false));
+      std::vector<Graph> po = lazy_pair_forward_score(pr);
+      for (size_t k = 0; k < pi.size(); ++k) outs[pi[k]] = std::move(po[k]);
+      if (!gr.empty()) {
+        std::vector<Graph> go = lazy_group_shortest_distance(gr, tropical);
+        for (size_t k = 0; k < gi.size(); ++k) outs[gi[k]] = std::move(go[k]);
+      }
+      return outs;
+    }
+  }
+  return lazy_group_shortest_distance(gs, tropical);
 }
 
 struct LazyPathOp : OpRecord {

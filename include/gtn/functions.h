@@ -60,6 +60,21 @@ inline Graph forwardScore(const Graph& g) { return detail::unary(&gtnx_forward_s
 inline Graph viterbiScore(const Graph& g) { return detail::unary(&gtnx_viterbi_score, g); }
 inline Graph viterbiPath(const Graph& g) { return detail::unary(&gtnx_viterbi_path, g); }
 
+/** Engine extension (not in the reference): while alive, compose / intersect of an emissions
+ *  chain with a small epsilon-free graph may stay symbolic on this thread (gtnx_compose_mode in
+ *  gtn_amd.h) -- for criteria that only take forwardScore / viterbiScore / viterbiPath of the
+ *  composition and never read the composition's own grad(). */
+class SymbolicCompose {
+ public:
+  explicit SymbolicCompose(int mode = 2) { detail::check(gtnx_compose_mode(mode, &prev_)); }
+  ~SymbolicCompose() { gtnx_compose_mode(prev_, nullptr); }
+  SymbolicCompose(const SymbolicCompose&) = delete;
+  SymbolicCompose& operator=(const SymbolicCompose&) = delete;
+
+ private:
+  int prev_ = 0;
+};
+
 // Batched forms live in gtn::batched so that the plain names stay un-overloaded
 // (reference callers pass them as function pointers, e.g. parallelMap(negate, v)).
 namespace batched {

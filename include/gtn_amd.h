@@ -57,6 +57,15 @@ int gtnx_device_count(void);                /* 0 when no GPU is visible */
 gtnx_status_t gtnx_set_device(int device);  /* hipSetDevice for this process */
 gtnx_status_t gtnx_set_stream(void* hip_stream); /* NULL = the engine's own stream */
 gtnx_status_t gtnx_synchronize(void);
+/* How compose / intersect of an implicit emissions chain with an epsilon-free graph treat their
+ * result, for the calling thread.  0 (default): build it, unless the batch would not fit in memory.
+ * 1: keep it symbolic whenever eligible.  2: keep it symbolic when the per-utterance sweep kernels
+ * apply (partner of <= 512 nodes and <= 4 arcs per node: CTC targets).  A symbolic result supports
+ * forwardScore / viterbiScore / viterbiPath and backward through them; any other use builds it.  What
+ * a symbolic result does not have is its OWN gradient graph (Graph::grad() of the composition), so
+ * this is a hint for criteria that never read it.  `previous` (may be NULL) receives the old mode.
+ * The environment variable GTNX_LAZY_COMPOSE (0 / 1 / 2) overrides the hint. */
+gtnx_status_t gtnx_compose_mode(int mode, int* previous);
 /* bytes currently held by the engine's device arena pool / bytes in use */
 gtnx_status_t gtnx_memory_stats(uint64_t* reserved, uint64_t* in_use);
 gtnx_status_t gtnx_empty_cache(void);

@@ -231,3 +231,148 @@ def test_dense_regime_with_impossible_emissions_and_transitions(gtn):
         np.testing.assert_allclose(x, y, rtol=1e-3, atol=1e-5)
     assert np.isfinite(res["dense"][2]).all()
     np.testing.assert_allclose(res["dense"][2], res["walk"][2], rtol=1e-3, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------
+# per-utterance sweep kernels (lazy_pair.hip): compose_mode(2), the path the criteria take
+# ---------------------------------------------------------------------------
+class pair_mode:
+    """gtn.compose_mode(2) for the block; `used()` tells whether the pair kernels ran"""
+
+    def __init__(self, gtn):
+        self.gtn = gtn
+
+    def __enter__(self):
+        self.prev = self.gtn.compose_mode(2)
+        self.gtn.prof_reset()
+        self.gtn.prof_enable(True)
+        return self
+
+    def __exit__(self, *a):
+        self.gtn.prof_enable(False)
+        self.names = self.gtn.prof_names()
+        self.gtn.compose_mode(self.prev)
+
+    def used(self):
+        return "lazy_pair_forward_score" in self.names
+
+
+def _ctc_pair_check(gtn, ems_np, targets, chain_first=False):
+    """CTC losses and both gradients through the pair kernels against the oracle"""
+    B = len(targets)
+    with pair_mode(gtn) as pm:
+        ems, ctcs = [], []
+        for b in range(B):
+            T, C = ems_np[b].shape
+            e = gtn.linear_graph(T, C)
+            e.set_weights(ems_np[b])
+            ems.append(e)
+            ctcs.append(gg.to_api(gtn, gg.ctc_target_graph(list(targets[b]))))
+        comp = gtn.compose(ems, ctcs) if chain_first else gtn.intersect(ctcs, ems)
+        loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))
+        gtn.backward(loss)
+        got = gtn.items(loss)
+    assert pm.used(), "the per-utterance sweep kernels did not run"
+    for b in range(B):
+        T, C = ems_np[b].shape
+        want, wgrad = ctc_loss(ems_np[b], np.asarray(targets[b], np.int32))
+        if np.isinf(want):
+            assert np.isinf(got[b])
+            continue
+        assert got[b] == pytest.approx(want, rel=RTOL)
+        z = abs(float(OGraph.linear(T, C, ems_np[b]).shortest_distance()))
+        np.testing.assert_allclose(ems[b].grad().weights_to_numpy().reshape(T, C), wgrad,
+                                   rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)
+        tgt = gg.ctc_target_graph(list(targets[b]))
+        o = OGraph.from_dict(tgt).compose(OGraph.linear(T, C, ems_np[b]), "intersect")
+        g1, _ = o.compose_grad(o.shortest_distance_grad(), len(tgt["src"]), T * C)
+        np.testing.assert_allclose(ctcs[b].grad().weights_to_numpy(), -np.asarray(g1), rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,T,C,U,chain_first", [
+    (4, 50, 9, 5, False),     # odd label count: scalar staging tail
+    (3, 300, 64, 30, False),
+    (3, 300, 64, 30, True),   # compose(emissions, target): matches the target's ilabels
+    (2, 90, 300, 10, False),  # 4 time steps per chunk
+    (2, 40, 1100, 6, False),  # 1 time step per chunk
+    (2, 400, 20, 150, False), # 301-node targets: 512-lane workgroups
+    (1, 1, 4, 1, False),      # a single frame
+])
+def test_pair_kernels_ctc_vs_oracle(gtn, B, T, C, U, chain_first):
+    rng = np.random.default_rng(B * 1000 + T + C)
+    ems = [rng.normal(0, 1, (T, C)).astype(np.float32) for _ in range(B)]
+    tg = [rng.integers(1, C, U).tolist() for _ in range(B)]
+    _ctc_pair_check(gtn, ems, tg, chain_first)
+
+
+def test_pair_kernels_mixed_shapes_in_one_batch(gtn):
+    """utterances of different length, alphabet and target size in ONE call (launch groups by label
+    count), an empty target and a target that cannot be aligned"""
+    rng = np.random.default_rng(5)
+    shapes = [(30, 7), (55, 7), (12, 19), (30, 7), (3, 6), (20, 5)]
+    ems = [rng.normal(0, 1, s).astype(np.float32) for s in shapes]
+    tg = [[1, 2, 3], [4, 4, 4, 1], [18, 2], [], [1, 2, 3, 4, 5], [2, 4]]
+    _ctc_pair_check(gtn, ems, tg)
+
+
+def test_pair_kernels_shared_target_and_general_partner(gtn):
+    """one target graph shared by the whole batch (its gradient accumulates) and a partner whose
+    in-arcs carry DIFFERENT labels per node (per-arc gradient terms), against the built lattice"""
+    B, T, C = 5, 25, 6
+    rng = np.random.default_rng(8)
+    em = rng.normal(0, 1, (B, T, C)).astype(np.float32)
+
+    def run(mode):
+        prev = gtn.compose_mode(mode)
+        try:
+            g = gtn.Graph()
+            for i in range(7):
+                g.add_node(i == 0, i >= 5)
+            wts = rng_w.normal(0, 1, 16).astype(np.float32)
+            arcs = [(0, 1, 1), (0, 2, 2), (1, 1, 1), (1, 2, 3), (2, 3, 4), (3, 3, 5), (1, 3, 2), (3, 4, 0), (2, 4, 1),
+                    (4, 5, 2), (4, 4, 3), (4, 6, 4), (5, 6, 5), (5, 5, 0), (6, 6, 1), (3, 5, 9)]  # label 9 never matches
+            for k, (s_, d_, l_) in enumerate(arcs):
+                g.add_arc(s_, d_, l_, l_, float(wts[k]))
+            ems = []
+            for b in range(B):
+                e = gtn.linear_graph(T, C)
+                e.set_weights(em[b])
+                ems.append(e)
+            fs = gtn.forward_score(gtn.intersect([g], ems))
+            gtn.backward(fs)
+            return gtn.items(fs), [e.grad().weights_to_numpy() for e in ems], g.grad().weights_to_numpy()
+        finally:
+            gtn.compose_mode(prev)
+
+    rng_w = np.random.default_rng(3)
+    built = run(0)
+    rng_w = np.random.default_rng(3)
+    with pair_mode(gtn) as pm:
+        swept = run(2)
+    assert pm.used()
+    np.testing.assert_allclose(swept[0], built[0], rtol=RTOL)
+    for a, b in zip(swept[1], built[1]):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(swept[2], built[2], rtol=1e-3, atol=1e-5)
+
+
+def test_pair_mode_other_uses_of_the_composition(gtn):
+    """a symbolic composition is still a graph: sizes, Viterbi path and score agree with the built one"""
+    import torch
+    B, T, C, U = 3, 40, 8, 6
+    em, tg = gg.ctc_inputs(31, B, T, C, U)
+    res = {}
+    for mode in (0, 2):
+        prev = gtn.compose_mode(mode)
+        try:
+            ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+            ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+            comp = gtn.intersect(ctcs, ems)
+            res[mode] = (gtn.items(gtn.viterbi_score(comp)), [p.labels_to_list() for p in gtn.viterbi_path(comp)],
+                         gtn.items(gtn.forward_score(comp)), [(c.num_nodes(), c.num_arcs()) for c in comp])
+        finally:
+            gtn.compose_mode(prev)
+    np.testing.assert_allclose(res[2][0], res[0][0], rtol=1e-6)
+    assert res[2][1] == res[0][1]
+    np.testing.assert_allclose(res[2][2], res[0][2], rtol=RTOL)
+    assert res[2][3] == res[0][3]

@@ -1,0 +1,94 @@
+// host_step.cpp -- runs the native CTC benchmark step (bench_native/libgtn_bench.so) against the
+// null HIP device of nullhip.cpp and prints host milliseconds per step.  Diagnostic only.
+//   make -C tools/nullhip && tools/nullhip/run.sh [steps] [B] [T] [C] [U]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <dlfcn.h>
+#include <execinfo.h>
+#include <signal.h>
+#include <time.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+#include <algorithm>
+#include <vector>
+
+// GTN_HOST_SAMPLE=<file>: sample the MAIN thread's call stack every 100 us of its CPU time
+// and dump raw return addresses (+ /proc/self/maps) for tools/nullhip/report.py
+namespace {
+constexpr int kDepth = 24;
+constexpr int kMaxSamples = 400000;
+void* g_samples[kMaxSamples][kDepth];
+int g_depth[kMaxSamples];
+volatile int g_ns = 0;
+void on_prof(int, siginfo_t*, void*) {
+  const int i = g_ns;
+  if (i >= kMaxSamples) return;
+  g_depth[i] = backtrace(g_samples[i], kDepth);
+  g_ns = i + 1;
+}
+void start_sampler() {
+  void* warm[4];
+  backtrace(warm, 4);  // loads libgcc outside the handler
+  struct sigaction sa {};
+  sa.sa_sigaction = on_prof;
+  sa.sa_flags = SA_SIGINFO | SA_RESTART;
+  sigaction(SIGPROF, &sa, nullptr);
+  struct sigevent sev {};
+  sev.sigev_notify = SIGEV_THREAD_ID;
+  sev.sigev_signo = SIGPROF;
+  sev._sigev_un._tid = int(syscall(SYS_gettid));
+  timer_t tm;
+  timer_create(CLOCK_THREAD_CPUTIME_ID, &sev, &tm);
+  struct itimerspec its {};
+  its.it_interval.tv_nsec = its.it_value.tv_nsec = 100000;
+  timer_settime(tm, 0, &its, nullptr);
+}
+void dump_samples(const char* path) {
+  FILE* f = std::fopen(path, "w");
+  FILE* m = std::fopen("/proc/self/maps", "r");
+  char line[512];
+  while (std::fgets(line, sizeof line, m)) std::fprintf(f, "M %s", line);
+  std::fclose(m);
+  for (int i = 0; i < g_ns; ++i) {
+    std::fprintf(f, "S");
+    for (int d = 0; d < g_depth[i]; ++d) std::fprintf(f, " %p", g_samples[i][d]);
+    std::fprintf(f, "\n");
+  }
+  std::fclose(f);
+}
+} // namespace
+
+using step_fn = int (*)(const void*, const int*, int, int, int, int, void*, void*);
+
+int main(int argc, char** argv) {
+  const int steps = argc > 1 ? atoi(argv[1]) : 20;
+  const int B = argc > 2 ? atoi(argv[2]) : 512, T = argc > 3 ? atoi(argv[3]) : 1000;
+  const int C = argc > 4 ? atoi(argv[4]) : 256, U = argc > 5 ? atoi(argv[5]) : 100;
+  void* h = dlopen(argc > 6 ? argv[6] : "bench_native/libgtn_bench.so", RTLD_NOW);
+  if (!h) { std::fprintf(stderr, "%s\n", dlerror()); return 1; }
+  auto step = reinterpret_cast<step_fn>(dlsym(h, "gtn_bench_ctc_step"));
+  void* eng = dlopen("gtn_amd/lib/libgtn_amd.so", RTLD_NOW);
+  auto sync = reinterpret_cast<int (*)()>(dlsym(eng, "gtnx_synchronize"));  // reclaims what the step let go of
+  std::vector<float> em(size_t(B) * T * C, 0.0f), grad(size_t(B) * T * C), loss(B);
+  std::vector<int> tg(size_t(B) * U);
+  for (size_t i = 0; i < tg.size(); ++i) tg[i] = 1 + int((i * 2654435761u >> 7) % unsigned(C - 1));
+  double best = 1e30, sum = 0, rsum = 0;
+  std::vector<double> all;
+  const char* sample = std::getenv("GTN_HOST_SAMPLE");
+  for (int s = 0; s < steps; ++s) {
+    if (s == 3 && sample) start_sampler();
+    auto t0 = std::chrono::steady_clock::now();
+    if (step(em.data(), tg.data(), B, T, C, U, loss.data(), grad.data()) != 0) { std::fprintf(stderr, "step failed\n"); return 2; }
+    auto t1 = std::chrono::steady_clock::now();
+    sync();
+    auto t2 = std::chrono::steady_clock::now();
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (s >= 3) { all.push_back(ms); best = ms < best ? ms : best; sum += ms; rsum += std::chrono::duration<double, std::milli>(t2 - t1).count(); }
+  }
+  if (sample) dump_samples(sample);
+  std::sort(all.begin(), all.end());
+  std::printf("host ms/step: best %.2f median %.2f mean %.2f + reclaim %.2f (B=%d T=%d C=%d U=%d)\n", best,
+              all[all.size() / 2], sum / (steps - 3), rsum / (steps - 3), B, T, C, U);
+  return 0;
+}

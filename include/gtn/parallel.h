@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstdint>
 #include <functional>
 #include <exception>
@@ -110,7 +111,16 @@ template <class Body>
 void runIndexed(size_t n, Body&& body, size_t maxThreads = 64) {
   // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped:
   // host-side graph building saturates long before 64 of them
-  const size_t hw = std::max<size_t>(1, std::thread::hardware_concurrency());
+  // One process per GPU: the ranks of a node share its cores (torchrun exports LOCAL_WORLD_SIZE),
+  // and a step is host-bound, so each rank takes its share instead of oversubscribing.
+  static const size_t hw = [] {
+    size_t h = std::max<size_t>(1, std::thread::hardware_concurrency());
+    if (const char* lws = std::getenv("LOCAL_WORLD_SIZE")) {
+      const long r = std::atol(lws);
+      if (r > 1) h = std::max<size_t>(1, h / size_t(r));
+    }
+    return h;
+  }();
   const size_t nt = std::min<size_t>(std::min(n, hw), maxThreads);
   std::atomic<size_t> next{0};
   std::exception_ptr first;

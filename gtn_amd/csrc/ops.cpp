@@ -1244,7 +1244,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       size_t mine = classic;
       const bool l1 = s1.kind == KIND_LINEAR, l2 = s2.kind == KIND_LINEAR;
       // (partners of up to 1024 nodes: the kernel indexes its claim table by partner node)
-      if (!no_chain && l1 != l2 && ((l1 ? s2 : s1).dview.flags & GF_EPS_FREE) && (l1 ? s2 : s1).N <= 1024) {
+      if (!no_chain && l1 != l2 && ((l1 ? s2 : s1).dview.flags & GF_EPS_FREE) && (l1 ? s2 : s1).N >= 1 &&
+          (l1 ? s2 : s1).N <= 1024) {
         const int No = int((l1 ? s2 : s1).N), TMc = (l1 ? s1 : s2).M;
         const int64_t room = int64_t(budget / (4 * size_t((No + 31) / 32))) - 3;
         // a window over ALL times when it fits (then the fast variant cannot run out of

@@ -68,7 +68,8 @@ int main(int argc, char** argv) {
   void* h = dlopen(argc > 6 ? argv[6] : "bench_native/libgtn_bench.so", RTLD_NOW);
   if (!h) { std::fprintf(stderr, "%s\n", dlerror()); return 1; }
   auto step = reinterpret_cast<step_fn>(dlsym(h, "gtn_bench_ctc_step"));
-  void* eng = dlopen("gtn_amd/lib/libgtn_amd.so", RTLD_NOW);
+  void* eng = dlopen("libgtn_amd.so", RTLD_NOW | RTLD_NOLOAD);  // the copy the bench library pulled in
+  if (!eng) eng = dlopen("gtn_amd/lib/libgtn_amd.so", RTLD_NOW);
   auto sync = reinterpret_cast<int (*)()>(dlsym(eng, "gtnx_synchronize"));  // reclaims what the step let go of
   std::vector<float> em(size_t(B) * T * C, 0.0f), grad(size_t(B) * T * C), loss(B);
   std::vector<int> tg(size_t(B) * U);

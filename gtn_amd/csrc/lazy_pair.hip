@@ -270,11 +270,11 @@ __global__ __launch_bounds__(BLK) void lazy_pair_backward_kernel(const LazyPair*
   int key = 0;
   for (int c = n; c < C; c += BLK) {
     const int h = hist[c];
-    if (h >= 8) key = max(key, (h << 12) | c);  // C <= 4096
+    if (h >= 8) key = max(key, (h << 13) | c);  // C <= SR * 512 = 8192; h <= 4 * 512
   }
   const int hk = block_max_int<BLK>(key, reinterpret_cast<int*>(red));
   __syncthreads();  // red is reused below
-  const int hot = hk ? (hk & 4095) : -1;
+  const int hot = hk ? (hk & 8191) : -1;
   for (int c = n; c < C; c += BLK) grow[c] = 0.0f;
 
   float stage[SR];

@@ -1628,7 +1628,9 @@ std::shared_ptr<OpRecord> make_lazy_compose_op() {
 
 bool lazy_shape_ok(const Structure& chain, const Structure& fixed) {
   const int64_t np = (fixed.N | 1) + 0, cp = (int64_t(chain.C) | 1);
-  return size_t(lazy_tile_batch()) * size_t(np + cp) * 4 <= size_t(lazy_lds_limit()) && fixed.N > 0 && chain.C > 0;
+  // (a chain without a step has no accept node, creations.cpp:20-33: left to the ordinary compose)
+  return size_t(lazy_tile_batch()) * size_t(np + cp) * 4 <= size_t(lazy_lds_limit()) && fixed.N > 0 && chain.C > 0 &&
+         chain.M >= 1;
 }
 
 struct LazyKey {
@@ -1939,7 +1941,7 @@ std::vector<Graph> lazy_group_shortest_distance(std::vector<Graph>& gs, bool tro
 // utterance brings its own target graph -- where the batched time-step kernels above
 // (one G shared by the batch) would run one launch per utterance and time step.
 bool lazy_pair_shape_ok(const Structure& cs, Structure& fs) {
-  if (fs.kind != KIND_EXPLICIT || fs.N < 1 || fs.N > lazy_pair_max_nodes() || cs.C < 1) return false;
+  if (fs.kind != KIND_EXPLICIT || fs.N < 1 || fs.N > lazy_pair_max_nodes() || cs.C < 1 || cs.M < 1) return false;
   if (cs.C > lazy_pair_max_labels(lazy_pair_block(int(fs.N)))) return false;
   return fs.max_degree() <= lazy_pair_max_degree();
 }

@@ -212,3 +212,60 @@ def test_golden_ctc(golden):
         loss, grad = ctc_loss(em, c["target"])
         assert loss == pytest.approx(c["loss"], rel=1e-5), c["name"]
         np.testing.assert_allclose(grad.reshape(-1), c["grad"], rtol=1e-4, atol=1e-6)
+
+
+# ---- reference test/criterion_test.cpp:182-345: the ASG criterion --------------------------------
+def _asg_transitions(N, weights=None):
+    """examples/asg.cpp:36-47 / criterion_test.cpp:262-272: arc i: <s> -> i; arc N + i*N + j: j -> i"""
+    arcs = [(0, i + 1, i, i, 0.0) for i in range(N)]
+    for i in range(N):
+        for j in range(N):
+            arcs.append((j + 1, i + 1, i, i, 0.0 if weights is None else float(weights[i * N + j])))
+    return G([0], list(range(1, N + 1)), arcs)
+
+
+def _force_align(target):
+    arcs = []
+    for l in range(1, len(target) + 1):
+        arcs.append((l - 1, l, target[l - 1], target[l - 1], 0.0))
+        arcs.append((l, l, target[l - 1], target[l - 1], 0.0))
+    return G([0], [len(target)], arcs)
+
+
+def test_asg_criterion_known_answers():
+    """losses, emission gradients and the transition gradient summed over the three utterances
+    (wav2letter's vectors, criterion_test.cpp:186-305) through compose / shortest distance /
+    their gradients of the oracle"""
+    from test_parity_gpu import ASG_EMISSIONS, ASG_EM_GRADS, ASG_TRANS_GRAD
+    T, N = 5, 6
+    targets = [[2, 1, 5, 1, 3], [4, 3, 5], [3, 2, 2, 1]]
+    expected_loss = [7.7417464256287, 6.4200420379639, 8.2780694961548]
+    trans = _asg_transitions(N)
+    gtrans = np.zeros(trans.A, np.float64)
+    for b in range(3):
+        e = OGraph.linear(T, N, np.asarray(ASG_EMISSIONS[b], np.float32))
+        fal = _force_align(targets[b])
+        fcc = e.compose(trans)                      # compose(emissions, transitions)
+        ft = fal.compose(trans)
+        falc = ft.compose(e)                        # compose(compose(fal, transitions), emissions)
+        loss = fcc.shortest_distance() - falc.shortest_distance()
+        assert loss == pytest.approx(expected_loss[b], abs=1e-3)
+        # d loss: +1 through the full-connect term, -1 through the force-align term
+        ge1, gt1 = fcc.compose_grad(fcc.shortest_distance_grad(delta=1.0), e.A, trans.A)
+        gft, ge2 = falc.compose_grad(falc.shortest_distance_grad(delta=-1.0), ft.A, e.A)
+        _, gt2 = ft.compose_grad(gft, fal.A, trans.A)
+        np.testing.assert_allclose(ge1 + ge2, ASG_EM_GRADS[b], atol=1e-4)
+        gtrans += gt1.astype(np.float64) + gt2
+    np.testing.assert_allclose(gtrans[N:], ASG_TRANS_GRAD, atol=1e-4)
+
+
+def test_asg_viterbi_path_known_answer():
+    """criterion_test.cpp:308-345"""
+    T, N = 4, 3
+    em = np.array([0, 0, 7, 5, 4, 3, 5, 8, 5, 5, 4, 3], np.float32)
+    tw = [0, 2, 0, 0, 0, 2, 2, 0, 0]
+    comp = OGraph.linear(T, N, em).compose(_asg_transitions(N, tw))
+    arcs, has = comp.shortest_path()
+    assert has
+    d = comp.to_dict()
+    assert [d["ol"][a] for a in arcs] == [2, 1, 1, 0]

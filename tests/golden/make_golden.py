@@ -97,9 +97,41 @@ def ctc_case(name, seed, T, C, U):
             "viterbi_labels": vit.labels_to_list()}
 
 
+def asg_case(name, seed, T, N, target):
+    """examples/asg.cpp:30-68 with random emissions / transition / start scores: loss, emission gradient,
+    transition gradient (arc order of the transitions graph: N start arcs, then arc N + i*N + j = j -> i)
+    and the Viterbi decode of compose(emissions, transitions)"""
+    rng = np.random.default_rng(seed)
+    em = rng.normal(0, 1, (T, N)).astype(np.float32)
+    tw = rng.normal(0, 1, N + N * N).astype(np.float32)
+    trans = ref.Graph()
+    trans.add_node(True)
+    for i in range(N):
+        trans.add_node(False, True)
+        trans.add_arc(0, i + 1, i, i, float(tw[i]))
+    for i in range(N):
+        for j in range(N):
+            trans.add_arc(j + 1, i + 1, i, i, float(tw[N + i * N + j]))
+    fal = ref.Graph()
+    fal.add_node(True, len(target) == 0)
+    for l in range(1, len(target) + 1):
+        fal.add_node(False, l == len(target))
+        fal.add_arc(l - 1, l, target[l - 1])
+        fal.add_arc(l, l, target[l - 1])
+    e = ref.linear_graph(T, N)
+    e.set_weights(em)
+    loss = ref.subtract(ref.forward_score(ref.compose(e, trans)),
+                        ref.forward_score(ref.compose(ref.compose(fal, trans), e)))
+    ref.backward(loss)
+    vit = ref.viterbi_path(ref.compose(e, trans))
+    return {"name": name, "seed": seed, "T": T, "N": N, "target": list(target), "emissions": fl(em),
+            "transitions": fl(tw), "loss": loss.item(), "grad_emissions": fl(e.grad().weights_to_numpy()),
+            "grad_transitions": fl(trans.grad().weights_to_numpy()), "viterbi_labels": vit.labels_to_list()}
+
+
 def main():
     rng = np.random.default_rng(20240925)
-    out = {"shortest": [], "compose": [], "ctc": []}
+    out = {"shortest": [], "compose": [], "ctc": [], "asg": []}
 
     # ---- shortest distance / path
     empty = {"start": [], "accept": [], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": None}
@@ -161,6 +193,11 @@ def main():
     # ---- CTC
     for i, (T, C, U) in enumerate([(5, 4, 2), (12, 5, 4), (20, 6, 5), (50, 10, 8), (100, 28, 20)]):
         out["ctc"].append(ctc_case(f"ctc_T{T}_C{C}_U{U}", 1234 + i, T, C, U))
+
+    # ---- ASG (own seeds: the sections above keep their random stream)
+    for i, (T, N, target) in enumerate([(4, 3, [1]), (6, 4, [2, 2, 0]), (12, 6, [5, 1, 1, 3]), (25, 9, [0, 8, 3, 3, 4, 1, 7]),
+                                        (40, 28, [3, 20, 20, 7, 7, 7, 1, 27, 0, 12])]):
+        out["asg"].append(asg_case(f"asg_T{T}_N{N}_U{len(target)}", 777 + i, T, N, target))
 
     path = os.path.join(HERE, "golden.json")
     with open(path, "w") as f:

@@ -269,3 +269,30 @@ def test_asg_viterbi_path_known_answer():
     assert has
     d = comp.to_dict()
     assert [d["ol"][a] for a in arcs] == [2, 1, 1, 0]
+
+
+def test_golden_asg(golden):
+    """tests/golden/golden.json "asg": the unmodified reference on random ASG instances
+    (losses, both gradients, Viterbi decode)"""
+    for c in golden["asg"]:
+        T, N = c["T"], c["N"]
+        tw = np.asarray(c["transitions"], np.float32)
+        trans = _asg_transitions(N, tw[N:])
+        d = trans.to_dict()
+        d["w"][:N] = [float(x) for x in tw[:N]]
+        d["sort"] = None
+        trans = OGraph.from_dict(d)
+        e = OGraph.linear(T, N, np.asarray(c["emissions"], np.float32))
+        fal = _force_align(c["target"]) if c["target"] else G([0], [0], [])
+        fcc = e.compose(trans)
+        ft = fal.compose(trans)
+        falc = ft.compose(e)
+        assert fcc.shortest_distance() - falc.shortest_distance() == pytest.approx(c["loss"], rel=1e-5), c["name"]
+        ge1, gt1 = fcc.compose_grad(fcc.shortest_distance_grad(delta=1.0), e.A, trans.A)
+        gft, ge2 = falc.compose_grad(falc.shortest_distance_grad(delta=-1.0), ft.A, e.A)
+        _, gt2 = ft.compose_grad(gft, fal.A, trans.A)
+        np.testing.assert_allclose(ge1 + ge2, c["grad_emissions"], rtol=1e-4, atol=1e-5, err_msg=c["name"])
+        np.testing.assert_allclose(gt1 + gt2, c["grad_transitions"], rtol=1e-4, atol=1e-5, err_msg=c["name"])
+        arcs, has = fcc.shortest_path()
+        dd = fcc.to_dict()
+        assert has and [dd["ol"][a] for a in arcs] == c["viterbi_labels"], c["name"]

@@ -800,3 +800,35 @@ def test_torch_asg_loss_vs_graph_api_random_weights(gtn):
     tg = trans.grad().weights_to_numpy() / B
     np.testing.assert_allclose(s_t.grad.cpu().numpy(), tg[:N], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(t_t.grad.cpu().numpy().reshape(-1), tg[N:], rtol=1e-3, atol=1e-5)
+
+
+def test_golden_asg(gtn, golden):
+    """tests/golden/golden.json "asg": the unmodified reference on random ASG instances -- loss, emission and
+    transition gradients (BASELINE.md gate: element-wise within 1e-4 absolute on O(1) posteriors) and the
+    Viterbi decode of compose(emissions, transitions).  (Added at the end of round 1, after the GPU budget
+    of the round was spent: same ops and tolerances as test_asg_criterion / test_golden_ctc above.)"""
+    for c in golden["asg"]:
+        T, N, target = c["T"], c["N"], c["target"]
+        tw = np.asarray(c["transitions"], np.float32)
+        trans = asg_transitions(gtn, N, tw[N:])
+        w = trans.weights_to_numpy().copy()
+        w[:N] = tw[:N]
+        trans.set_weights(w)
+        fal = gtn.Graph()
+        fal.add_node(True, len(target) == 0)
+        for l in range(1, len(target) + 1):
+            fal.add_node(False, l == len(target))
+            fal.add_arc(l - 1, l, target[l - 1])
+            fal.add_arc(l, l, target[l - 1])
+        e = gtn.linear_graph(T, N)
+        e.set_weights(np.asarray(c["emissions"], np.float32))
+        loss = gtn.subtract(gtn.forward_score(gtn.compose(e, trans)),
+                            gtn.forward_score(gtn.compose(gtn.compose(fal, trans), e)))
+        assert loss.item() == pytest.approx(c["loss"], rel=RTOL), c["name"]
+        gtn.backward(loss)
+        np.testing.assert_allclose(e.grad().weights_to_numpy(), c["grad_emissions"], rtol=1e-3, atol=1e-4,
+                                   err_msg=c["name"])
+        np.testing.assert_allclose(trans.grad().weights_to_numpy(), c["grad_transitions"], rtol=1e-3, atol=2e-4,
+                                   err_msg=c["name"])
+        vit = gtn.viterbi_path(gtn.compose(e, trans))
+        assert vit.labels_to_list() == c["viterbi_labels"], c["name"]

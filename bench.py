@@ -267,6 +267,15 @@ def main():
             out[name] = {"bound": "hbm", "kernel": KERNEL_OF[name], "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "ms_per_launch": ms,
                          "algorithmic_bytes_per_launch": per}
+            # The sweep kernels compute forwardScore (and its gradient) of the SAME lattices without building
+            # them.  SURVEY.md section 8(d) prices those on the lattice -- forwardScore 8A+8N, its backward plus
+            # the compose gradient 24A+12N+4TC -- and asks to "quote both": `frac` above is the HBM utilisation
+            # on the bytes the sweep really needs; this is the rate at which it gets through the lattice work.
+            equiv = {"lazy_pair_forward_score": B * (8.0 * n_arcs + 8.0 * n_nodes),
+                     "lazy_pair_forward_score_grad": B * (24.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}.get(name)
+            if equiv:
+                out[name]["lattice_equivalent"] = {"bytes_per_launch": equiv, "achieved": equiv / (ms * 1e-3) / 1e9,
+                                                   "frac": equiv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
         return out
 
     roofs = rooflines(prof)

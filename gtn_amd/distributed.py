@@ -4,8 +4,9 @@ A batch of independent utterance graphs shards embarrassingly: rank r owns a
 contiguous block of utterances, runs the whole loss locally, and the only
 exchange is an all_gather of the per-utterance scalar losses (RCCL over xGMI on
 GPUs; gloo in the CPU tests).  No gradient collective is needed for CTC: the
-emission gradients stay on the rank that owns the utterances.  (The ASG variant's
-shared transition-graph gradient would add one all_reduce of C*C + C floats.)
+emission gradients stay on the rank that owns the utterances.  The ASG variant has one
+real exchange: the transitions graph is shared by every utterance, so its gradient is
+a sum over the WHOLE batch -- `all_reduce_shared_grad` (C*C + C floats).
 """
 import torch
 import torch.distributed as dist
@@ -36,6 +37,16 @@ def gather_losses(local_losses, n_items=None):
         lo, hi = shard_range(n_items, r, world)
         out.append(parts[r][: hi - lo])
     return torch.cat(out)
+
+
+def all_reduce_shared_grad(grad):
+    """Sum over ranks of the gradient of a graph every utterance shares (ASG transitions:
+    criterion_test.cpp:289-305 accumulates it over the batch; `asg_loss` / `gtn_asg_loss_n` return
+    the rank's partial sum as a tensor).  In place; returns `grad`.  1.05 MB at C = 512: ring
+    all-reduce over xGMI is ~12 us of wire time, so it is issued once per step, not bucketed."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    return grad
 
 
 def max_over_ranks(seconds, device=None):

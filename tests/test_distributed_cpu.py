@@ -54,3 +54,36 @@ def test_sharded_losses_match_single_process(B):
     want = np.array([ctc_loss(em[b], tg[b])[0] for b in range(B)], np.float32)
     np.testing.assert_array_equal(ret["losses"], want)
     assert ret["t"] == 1.5        # slowest rank
+
+
+def _asg_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gtn_amd.distributed import all_reduce_shared_grad, shard_range
+    from test_oracle import asg_utterance_grads
+    from test_parity_gpu import ASG_EMISSIONS
+    targets = [[2, 1, 5, 1, 3], [4, 3, 5], [3, 2, 2, 1]]
+    lo, hi = shard_range(3, rank, world)
+    part = np.zeros(6 + 36, np.float64)
+    for b in range(lo, hi):
+        part += asg_utterance_grads(5, 6, ASG_EMISSIONS[b], targets[b])[2]
+    g = all_reduce_shared_grad(torch.from_numpy(part))
+    if rank == 0:
+        ret["grad"] = g.numpy().copy()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_asg_shared_transition_grad_all_reduce():
+    """the one real exchange of the ASG variant.  Two ranks own 2 + 1 utterances of the
+    reference's ASG test; the all-reduced transition gradient is the batch sum it pins
+    (criterion_test.cpp:289-305)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_parity_gpu import ASG_TRANS_GRAD
+    ret = mp.Manager().dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_asg_worker, args=(2, port, ret), nprocs=2, join=True)
+    np.testing.assert_allclose(ret["grad"][6:], ASG_TRANS_GRAD, atol=1e-4)

@@ -232,6 +232,21 @@ def _force_align(target):
     return G([0], [len(target)], arcs)
 
 
+def asg_utterance_grads(T, N, emissions, target, trans_w=None):
+    """-> (loss, d loss / d emissions, d loss / d transitions) of one utterance through the oracle"""
+    trans = _asg_transitions(N) if trans_w is None else trans_w
+    e = OGraph.linear(T, N, np.asarray(emissions, np.float32))
+    fal = _force_align(target)
+    fcc = e.compose(trans)
+    ft = fal.compose(trans)
+    falc = ft.compose(e)
+    loss = fcc.shortest_distance() - falc.shortest_distance()
+    ge1, gt1 = fcc.compose_grad(fcc.shortest_distance_grad(delta=1.0), e.A, trans.A)
+    gft, ge2 = falc.compose_grad(falc.shortest_distance_grad(delta=-1.0), ft.A, e.A)
+    _, gt2 = ft.compose_grad(gft, fal.A, trans.A)
+    return loss, ge1 + ge2, gt1.astype(np.float64) + gt2
+
+
 def test_asg_criterion_known_answers():
     """losses, emission gradients and the transition gradient summed over the three utterances
     (wav2letter's vectors, criterion_test.cpp:186-305) through compose / shortest distance /

@@ -87,6 +87,20 @@ void set_dev_weights(Graph& g, const DevMemP& owner, float* ptr, int64_t n) {
   w.version++;
 }
 
+// packed adjacency records of a device-built structure (results of an earlier compose),
+// made on first use as an op input; host-built structures get theirs at upload
+void ensure_records(Structure& st) {
+  if (st.kind != KIND_EXPLICIT || st.dview.out_rec || st.A == 0) return;
+  Runtime& rt = Runtime::get();
+  st.ensure_full();
+  st.rec_mem = rt.alloc(32 * size_t(st.A));
+  gtnx_i4* orec = st.rec_mem->as<gtnx_i4>();
+  gtnx_i4* irec = orec + st.A;
+  launch_build_records(st.dview, orec, irec, rt.stream());
+  st.dview.out_rec = orec;
+  st.dview.in_rec = irec;
+}
+
 float* grad_dev_ptr(Graph& out) {
   // the incoming delta of an output graph, resident on the device
   Graph& gr = out.grad();
@@ -1048,16 +1062,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   ht_phase("compose.1_upload_inputs");
   // device-built inputs (results of an earlier compose) get their packed
   // adjacency records now; host-built ones got them at upload
-  for (Structure* st : ss) {
-    if (st->kind != KIND_EXPLICIT || st->dview.out_rec || st->A == 0) continue;
-    st->ensure_full();
-    st->rec_mem = rt.alloc(32 * size_t(st->A));
-    gtnx_i4* orec = st->rec_mem->as<gtnx_i4>();
-    gtnx_i4* irec = orec + st->A;
-    launch_build_records(st->dview, orec, irec, rt.stream());
-    st->dview.out_rec = orec;
-    st->dview.in_rec = irec;
-  }
+  for (Structure* st : ss) ensure_records(*st);
 
   // ---- capacities from label histograms (exact upper bound on matches)
   std::unordered_map<Structure*, LabelHist> h1, h2;
@@ -1675,15 +1680,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
   for (auto& gp : groups) {
     LazyGroupState& st = *gp;
     Structure& fs = *st.fixed.s;
-    if (!fs.dview.out_rec && fs.A > 0) {  // device-built G: packed records on demand
-      fs.ensure_full();
-      fs.rec_mem = rt.alloc(32 * size_t(fs.A));
-      gtnx_i4* orec = fs.rec_mem->as<gtnx_i4>();
-      gtnx_i4* irec = orec + fs.A;
-      launch_build_records(fs.dview, orec, irec, rt.stream());
-      fs.dview.out_rec = orec;
-      fs.dview.in_rec = irec;
-    }
+    ensure_records(fs);
     const Structure& cs = *st.chains[0].s;
     const int nb = int(st.chains.size());
     const int T = cs.M, C = cs.C, N = int(fs.N);
@@ -2032,16 +2029,7 @@ std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
   }
   ensure_device_batch(ss);
   ensure_weights_device_batch(ws);
-  for (Structure* st : ss) {  // device-built G: packed records on demand
-    if (st->dview.out_rec || st->A == 0) continue;
-    st->ensure_full();
-    st->rec_mem = rt.alloc(32 * size_t(st->A));
-    gtnx_i4* orec = st->rec_mem->as<gtnx_i4>();
-    gtnx_i4* irec = orec + st->A;
-    launch_build_records(st->dview, orec, irec, rt.stream());
-    st->dview.out_rec = orec;
-    st->dview.in_rec = irec;
-  }
+  for (Structure* st : ss) ensure_records(*st);
   size_t bytes = align_up(4 * n, 256);
   std::vector<size_t> ao(n);
   for (size_t i = 0; i < n; ++i) {

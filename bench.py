@@ -218,6 +218,15 @@ def main():
     dt = max_over_ranks(dt, dev)
 
     prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+    losses_timed = loss_dev.cpu().numpy().copy()  # of the timed loop's last step
+    grad_timed = None
+    if native is not None:
+        try:
+            with torch.cuda.stream(stream):
+                grad_timed = grad_dev.clone()
+            stream.synchronize()
+        except Exception:
+            grad_timed = None
     # composed-lattice size of utterance 0 (one extra untimed intersect)
     e0 = gtn.linear_graph_n(1, T, Cn, em_dev)
     comp = gtn.intersect(build_ctc_graphs(gtn, tg[:1]), e0)
@@ -300,11 +309,22 @@ def main():
             dt_built = (time.perf_counter() - t1) / 5
             gtn.prof_enable(False)
             pb = {n: gtn.prof_get(n) for n in gtn.prof_names()}
-            built = {"ms_per_step": dt_built * 1e3, "losses_per_s": B / dt_built, "roofline": rooflines(pb)}
+            lb = loss_dev.cpu().numpy()
+            try:
+                with torch.cuda.stream(stream):
+                    gdiff = float((grad_dev - grad_timed).abs().max().item())
+            except Exception:  # a diagnostic must not cost the bench line
+                gdiff = None
+            built = {"ms_per_step": dt_built * 1e3, "losses_per_s": B / dt_built, "roofline": rooflines(pb),
+                     "loss_mean": float(np.mean(lb)),
+                     # the two paths on the same batch: largest relative difference of a per-utterance loss
+                     "max_rel_diff_vs_timed_path": float(np.max(np.abs(lb - losses_timed) / np.maximum(np.abs(lb), 1e-30))),
+                     # ... and largest absolute difference of an emission-gradient element (posteriors in [-1, 1])
+                     "max_abs_grad_diff_vs_timed_path": gdiff}
         finally:
             os.environ.pop("GTNX_LAZY_COMPOSE", None)
     if rank == 0:
-        losses = loss_dev.cpu().numpy()
+        losses = losses_timed
         out = {
             "metric": "CTC forward+backward losses/sec (T=1000, C=256)" if (T, Cn) == (1000, 256)
             else f"CTC forward+backward losses/sec (T={T}, C={Cn})",

@@ -28,6 +28,7 @@ _SIGS = {
     "gtnx_synchronize": [],
     "gtnx_memory_stats": [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
     "gtnx_empty_cache": [],
+    "gtnx_reclaim": [],
     "gtnx_graph_create": [C.c_int, c_graph_p],
     "gtnx_graph_copy": [c_graph, c_graph_p],
     "gtnx_graph_deep_copy": [c_graph, c_graph_p],

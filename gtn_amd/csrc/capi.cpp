@@ -103,6 +103,11 @@ GTNX_API gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
     if (Runtime::initialized()) Runtime::get().stats(r, u);
   });
 }
+GTNX_API gtnx_status_t gtnx_reclaim(void) {
+  return guard([&] {
+    if (Runtime::initialized()) Runtime::get().drain_deferred();
+  });
+}
 GTNX_API gtnx_status_t gtnx_empty_cache(void) {
   return guard([&] {
     if (Runtime::initialized()) Runtime::get().empty_cache();

@@ -69,6 +69,11 @@ gtnx_status_t gtnx_compose_mode(int mode, int* previous);
 /* bytes currently held by the engine's device arena pool / bytes in use */
 gtnx_status_t gtnx_memory_stats(uint64_t* reserved, uint64_t* in_use);
 gtnx_status_t gtnx_empty_cache(void);
+/* Destroys what the caller has let go of since the last reclamation point (released handles, finished tapes);
+ * never waits for the GPU, cheap when nothing is pending.  The engine reclaims by itself wherever the host
+ * would wait for the device; a host loop with idle time of its own (the caller of parallelMap while the
+ * workers build graphs -- include/gtn/parallel.h does this) can offer it here. */
+gtnx_status_t gtnx_reclaim(void);
 
 /* ------------------------------------------------------------------ Graph
  * class Graph, gtn/graph.h:75-415 */

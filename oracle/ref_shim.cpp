@@ -90,6 +90,7 @@ gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
   return GTNX_OK;
 }
 gtnx_status_t gtnx_empty_cache(void) { return GTNX_OK; }
+gtnx_status_t gtnx_reclaim(void) { return GTNX_OK; }
 
 gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph(calc_grad != 0)); });

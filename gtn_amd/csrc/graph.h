@@ -9,6 +9,7 @@
 //   GradState : autograd tape node (producing op, inputs, grad graph)
 #pragma once
 
+#include <atomic>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -126,7 +127,7 @@ struct GradState {
   bool has_grad_fn = false;      // mirrors `gradFunc != nullptr`
   std::vector<Graph> inputs;
   std::unique_ptr<Graph> grad;
-  int n_consumers = 0;           // op outputs that list this graph as an input
+  std::atomic<int> n_consumers{0};  // op outputs that list this graph as an input (two threads may reclaim at once)
   bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
   ~GradState();                  // gives the consumer counts of `inputs` back
 };

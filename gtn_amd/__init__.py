@@ -33,6 +33,21 @@ items = _api.items
 items_to_device = _api.items_to_device
 grads_to_device = _api.grads_to_device
 parallel_for = _api.parallel_for
+clone = _api.clone
+project_input = _api.project_input
+project_output = _api.project_output
+closure = _api.closure
+concat = _api.concat
+union = _api.union
+remove = _api.remove
+sample = _api.sample
+rand_equivalent = _api.rand_equivalent
+load = _api.load
+save = _api.save
+loadtxt = _api.loadtxt
+savetxt = _api.savetxt
+write_dot = _api.write_dot
+draw = _api.draw
 backend = _api.backend
 device_count = _api.device_count
 synchronize = _api.synchronize

@@ -93,7 +93,15 @@ def make_api(lib):
             check(lib.gtnx_graph_add_node(self._h, int(bool(start)), int(bool(accept)), C.byref(i)))
             return i.value
 
-        def add_arc(self, src_node, dst_node, ilabel, olabel=None, weight=0.0):
+        def add_arc(self, src_node, dst_node, ilabel=None, olabel=None, weight=0.0, label=None):
+            """add_arc(src_node, dst_node, label) / add_arc(src_node, dst_node, ilabel, olabel, weight=0.0)
+            (the binding's two overloads, _graph.cpp:30-43)"""
+            if label is not None:
+                if ilabel is not None or olabel is not None:
+                    raise TypeError("add_arc: give either label or ilabel / olabel")
+                ilabel = label
+            if ilabel is None:
+                raise TypeError("add_arc: missing label")
             if olabel is None:
                 olabel = ilabel
             i = C.c_int()
@@ -309,12 +317,192 @@ def make_api(lib):
             return Graph._from_handle(h.value)
 
         def __repr__(self):
+            host = _host(required=False)
+            if host is not None:  # operator<< of utils.h (what the binding prints)
+                need = C.c_size_t()
+                hcheck(host.gtnh_repr(self._h, None, 0, C.byref(need)))
+                buf = C.create_string_buffer(need.value)
+                hcheck(host.gtnh_repr(self._h, buf, need.value, None))
+                return buf.value.decode()
             s, d, i, o, w = self.arcs()
             lines = [" ".join(map(str, self.start())), " ".join(map(str, self.accept()))]
             lines += [f"{a} {b} {c} {e} {f:g}" for a, b, c, e, f in zip(s, d, i, o, w)]
             return "\n".join(lines)
 
     ns.Graph = Graph
+
+    # ---------------------------------------------------------------- host-side builders / formats
+    # gtn_amd/hostops: C entry points over include/gtn's header-only clone / project / concat / closure /
+    # union / remove / sample / randEquivalent / load / save / draw.  One copy sits next to (and is linked
+    # against) each C-ABI library; RTLD_DEEPBIND keeps its gtnx_* calls on that library even when the
+    # product and the reference shim are loaded side by side.
+    _hostlib = []
+
+    def _host(required=True):
+        if not _hostlib:
+            import os
+            path = os.path.join(os.path.dirname(os.path.abspath(getattr(lib, "_path", ""))), "libgtn_hostops.so")
+            h = None
+            if os.path.exists(path):
+                h = C.CDLL(path, mode=getattr(os, "RTLD_DEEPBIND", 0) | getattr(os, "RTLD_NOW", 2))
+                vp, vpp, ip = C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)
+                for name, args in {
+                    "gtnh_clone": [vp, C.c_int, vpp], "gtnh_concat": [vpp, C.c_int, vpp], "gtnh_closure": [vp, vpp],
+                    "gtnh_union": [vpp, C.c_int, vpp], "gtnh_remove": [vp, C.c_int, C.c_int, vpp],
+                    "gtnh_sample": [vp, C.c_size_t, vpp],
+                    "gtnh_rand_equivalent": [vp, vp, C.c_size_t, C.c_double, C.c_size_t, ip],
+                    "gtnh_load": [C.c_char_p, vpp], "gtnh_save": [C.c_char_p, vp],
+                    "gtnh_loadtxt": [C.c_char_p, vpp], "gtnh_savetxt": [C.c_char_p, vp],
+                    "gtnh_write_dot": [vp, C.c_char_p, ip, C.POINTER(C.c_char_p), C.c_int, ip, C.POINTER(C.c_char_p),
+                                       C.c_int],
+                    "gtnh_repr": [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)],
+                }.items():
+                    fn = getattr(h, name)
+                    fn.argtypes = args
+                    fn.restype = C.c_int
+                h.gtnh_last_error.restype = C.c_char_p
+            _hostlib.append(h)
+        if _hostlib[0] is None and required:
+            raise ImportError("gtn_amd: libgtn_hostops.so not found next to the C-ABI library "
+                              "(python -c 'import __graft_entry__ as g; g.build()')")
+        return _hostlib[0]
+
+    def hcheck(status):
+        if status != 0:
+            msg = _host().gtnh_last_error().decode("utf-8", "replace")
+            raise _EXC.get(status, GtnError)(msg)
+
+    def _host_unary(name, *extra):
+        def one(g, *args):
+            h = C.c_void_p()
+            hcheck(getattr(_host(), name)(g._h, *args, C.byref(h)))
+            return Graph._from_handle(h.value)
+        return one
+
+    def _host_nary(name):
+        def one(graphs):
+            graphs = list(graphs)
+            arr = (C.c_void_p * max(len(graphs), 1))(*[g._h for g in graphs])
+            h = C.c_void_p()
+            hcheck(getattr(_host(), name)(arr, len(graphs), C.byref(h)))
+            return Graph._from_handle(h.value)
+        return one
+
+    _clone1 = _host_unary("gtnh_clone")
+    _closure1 = _host_unary("gtnh_closure")
+    _remove1 = _host_unary("gtnh_remove")
+    _concat1 = _host_nary("gtnh_concat")
+    _union1 = _host_nary("gtnh_union")
+
+    def clone(g, projection=0):
+        """clone(g) (_functions.cpp:78-83); lists map element-wise"""
+        if _is_seq(g):
+            return [_clone1(x, int(projection)) for x in g]
+        return _clone1(g, int(projection))
+
+    def project_input(g):
+        return [_clone1(x, 1) for x in g] if _is_seq(g) else _clone1(g, 1)
+
+    def project_output(g):
+        return [_clone1(x, 2) for x in g] if _is_seq(g) else _clone1(g, 2)
+
+    def closure(g):
+        return [_closure1(x) for x in g] if _is_seq(g) else _closure1(g)
+
+    def _bcast(seq, n):
+        seq = list(seq)
+        if len(seq) == n:
+            return seq
+        if len(seq) == 1:
+            return seq * n
+        raise RuntimeError("parallelMap getIdxOrBroadcast got invalid size or unbroadcastable vector")
+
+    def concat(a, b=None):
+        """concat(g1, g2) / concat(graphs1, graphs2) / concat(graphs) / concat(list of lists)
+        (_functions.cpp:36-68)"""
+        if b is not None:
+            if _is_seq(a) or _is_seq(b):
+                la = list(a) if _is_seq(a) else [a]
+                lb = list(b) if _is_seq(b) else [b]
+                n = max(len(la), len(lb))
+                return [_concat1([x, y]) for x, y in zip(_bcast(la, n), _bcast(lb, n))]
+            return _concat1([a, b])
+        if len(a) and _is_seq(a[0]):
+            return [_concat1(x) for x in a]
+        return _concat1(a)
+
+    def union(graphs):
+        """union(graphs) / union(list of lists) (_functions.cpp:221-233)"""
+        if len(graphs) and _is_seq(graphs[0]):
+            return [_union1(x) for x in graphs]
+        return _union1(graphs)
+
+    def remove(g, ilabel=None, olabel=None, label=None, labels=None):
+        """remove(g, label=epsilon) / remove(g, ilabel, olabel) / remove(graphs, labels=[epsilon])
+        (_functions.cpp:179-203)"""
+        if _is_seq(g):
+            lab = labels if labels is not None else (ilabel if ilabel is not None else [ns.epsilon])
+            lab = list(lab) if _is_seq(lab) else [lab]
+            n = max(len(g), len(lab))
+            return [_remove1(x, int(l), int(l)) for x, l in zip(_bcast(g, n), _bcast(lab, n))]
+        if label is not None:
+            ilabel = olabel = label
+        if ilabel is None:
+            ilabel = ns.epsilon
+        if olabel is None:
+            olabel = ilabel
+        return _remove1(g, int(ilabel), int(olabel))
+
+    def sample(g, max_length=1000):
+        h = C.c_void_p()
+        hcheck(_host().gtnh_sample(g._h, int(max_length), C.byref(h)))
+        return Graph._from_handle(h.value)
+
+    def rand_equivalent(g1, g2, num_samples=1000, tol=1e-4, max_length=1000):
+        v = C.c_int()
+        hcheck(_host().gtnh_rand_equivalent(g1._h, g2._h, int(num_samples), float(tol), int(max_length), C.byref(v)))
+        return bool(v.value)
+
+    def load(file_name):
+        h = C.c_void_p()
+        hcheck(_host().gtnh_load(str(file_name).encode(), C.byref(h)))
+        return Graph._from_handle(h.value)
+
+    def save(file_name, graph):
+        hcheck(_host().gtnh_save(str(file_name).encode(), graph._h))
+
+    def loadtxt(file_name):
+        h = C.c_void_p()
+        hcheck(_host().gtnh_loadtxt(str(file_name).encode(), C.byref(h)))
+        return Graph._from_handle(h.value)
+
+    def savetxt(file_name, graph):
+        hcheck(_host().gtnh_savetxt(str(file_name).encode(), graph._h))
+
+    def write_dot(g, file_name, isymbols={}, osymbols={}):
+        def table(m):
+            keys = (C.c_int * max(len(m), 1))(*[int(k) for k in m])
+            names = (C.c_char_p * max(len(m), 1))(*[str(v).encode() for v in m.values()])
+            return keys, names, len(m)
+        ik, inames, ni = table(isymbols)
+        ok, onames, no = table(osymbols)
+        hcheck(_host().gtnh_write_dot(g._h, str(file_name).encode(), ik, inames, ni, ok, onames, no))
+
+    def draw(graph, file_name, isymbols={}, osymbols={}):
+        """bindings/python/gtn/__init__.py:22-26: dot -> picture through graphviz"""
+        import os
+        import subprocess
+        import tempfile
+        ext = os.path.splitext(file_name)[1]
+        with tempfile.NamedTemporaryFile() as tmpf:
+            write_dot(graph, tmpf.name, isymbols, osymbols)
+            subprocess.check_call(["dot", "-T" + ext[1:], tmpf.name, "-o", file_name])
+
+    for _n, _f in (("clone", clone), ("project_input", project_input), ("project_output", project_output),
+                   ("closure", closure), ("concat", concat), ("union", union), ("remove", remove),
+                   ("sample", sample), ("rand_equivalent", rand_equivalent), ("load", load), ("save", save),
+                   ("loadtxt", loadtxt), ("savetxt", savetxt), ("write_dot", write_dot), ("draw", draw)):
+        setattr(ns, _n, _f)
 
     # ---------------------------------------------------------------- functions
     def _unary(single, batched):
@@ -363,6 +551,19 @@ def make_api(lib):
         elif grad_or_retain is not None:
             retain_graph = grad_or_retain
         if _is_seq(g):
+            # backward(graphs, retain_graphs=[0]) / backward(graphs, grads, retain_graphs=[0]): parallelMap
+            # with size-1 lists broadcast (_autograd.cpp:27-60)
+            grads = None
+            if _is_seq(grad_or_retain) and grad_or_retain and isinstance(grad_or_retain[0], Graph):
+                grads = list(grad_or_retain)
+            elif _is_seq(grad_or_retain):
+                retain_graph = grad_or_retain
+            if grads is not None:
+                rl = list(retain_graph) if _is_seq(retain_graph) else [retain_graph]
+                n = max(len(g), len(grads), len(rl))
+                for x, gr, r in zip(_bcast(g, n), _bcast(grads, n), _bcast(rl, n)):
+                    check(lib.gtnx_backward_with_grad(x._h, gr._h, int(bool(r))))
+                return
             if _is_seq(retain_graph):
                 retain_graph = retain_graph[0] if retain_graph else False
             if len(g):

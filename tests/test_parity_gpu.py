@@ -832,3 +832,42 @@ def test_golden_asg(gtn, golden):
                                    err_msg=c["name"])
         vit = gtn.viterbi_path(gtn.compose(e, trans))
         assert vit.labels_to_list() == c["viterbi_labels"], c["name"]
+
+
+def test_python_host_side_builders_and_formats(gtn, tmp_path):
+    """the rest of the binding's surface on the engine (gtn_amd/hostops: header-only builders of include/gtn
+    behind C entry points -- the same code test_dropin_gpu.py exercises from C++): closure / concat / union /
+    remove / clone / project, text and binary formats, repr, keyword forms of add_arc; forwardScore through a
+    concatenation with gradients landing in the parts (functions.cpp:112-163)"""
+    g1 = gtn.Graph()
+    g1.add_node(True)
+    g1.add_node(False, True)
+    g1.add_arc(src_node=0, dst_node=1, label=1)
+    g1.add_arc(0, 1, ilabel=2, olabel=3, weight=0.5)
+    g2 = gtn.Graph()
+    g2.add_node(True)
+    g2.add_node(False, True)
+    g2.add_arc(0, 1, 4, 4, 1.5)
+    cat = gtn.concat(g1, g2)
+    assert (cat.num_nodes(), cat.num_arcs()) == (4, 4)          # + one epsilon link
+    assert gtn.equal(gtn.concat([g1, g2]), cat)
+    fs = gtn.forward_score(cat)
+    assert fs.item() == pytest.approx(np.log(np.exp(0.0) + np.exp(0.5)) + 1.5, rel=1e-5)
+    gtn.backward(fs)
+    np.testing.assert_allclose(g2.grad().weights_to_numpy(), [1.0], atol=1e-6)
+    np.testing.assert_allclose(g1.grad().weights_to_numpy().sum(), 1.0, atol=1e-6)
+    u = gtn.union([g1, g2])
+    assert (u.num_start(), u.num_accept(), u.num_arcs()) == (2, 2, 3)
+    c = gtn.closure(g2)
+    assert c.num_arcs() == g2.num_arcs() + 2
+    assert gtn.project_output(g1).labels_to_list(True) == [1, 3]
+    assert gtn.project_input(g1).labels_to_list(False) == [1, 2]
+    assert gtn.equal(gtn.clone(g1), g1)
+    r = gtn.remove(gtn.concat(g1, g2))                          # the epsilon link is gone (and, as in the
+    assert (r.num_nodes(), r.num_arcs()) == (3, 3)              # reference, so are the weights: functions.cpp:253-318)
+    assert r.labels_to_list() == [1, 2, 4] and r.labels_to_list(False) == [1, 3, 4]
+    for save, load in ((gtn.savetxt, gtn.loadtxt), (gtn.save, gtn.load)):
+        p = str(tmp_path / "g.bin")
+        save(p, g1)
+        assert gtn.equal(load(p), g1)
+    assert "0 1 2 3 0.5" in repr(g1)

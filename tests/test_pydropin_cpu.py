@@ -1,0 +1,33 @@
+"""The Python side of the drop-in, on the CPU-only host: the reference's OWN Python binding tests
+(bindings/python/test/test_*.py, 47 tests: graph construction, weights, formats, functions incl. the
+rational ops, autograd, criteria, parallel forms) run UNMODIFIED with `import gtn` resolving to this
+repo's `gtn_amd` package, bound to oracle/_ref/libgtn_ref.so -- the unmodified reference behind the C ABI
+of include/gtn_amd.h.  What this pins is the Python mirror (gtn_amd/api.py + gtn_amd/hostops): same names,
+overloads, keyword arguments, broadcasting and exception types as the pybind11 binding.  Needs
+/root/reference (test sources are read where they lie) -- skipped elsewhere."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_TESTS = "/root/reference/bindings/python/test"
+
+
+def test_reference_python_binding_tests_run_on_the_mirror(tmp_path):
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
+    host = os.path.join(ROOT, "oracle", "_ref", "libgtn_hostops.so")
+    if not (os.path.isdir(REF_TESTS) and os.path.exists(ref_lib) and os.path.exists(host)):
+        pytest.skip("needs /root/reference and oracle/_ref (python -c 'import __graft_entry__ as g; g.build()')")
+    pkg = tmp_path / "gtn"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text(
+        "import gtn_amd as _g\n"
+        "globals().update({k: getattr(_g, k) for k in dir(_g) if not k.startswith('__')})\n")
+    env = dict(os.environ, GTN_AMD_LIB=ref_lib, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    r = subprocess.run([sys.executable, "-m", "unittest", "discover", "-s", REF_TESTS], capture_output=True, text=True,
+                       timeout=600, env=env, cwd=str(tmp_path))
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "Ran 47 tests" in tail and "\nOK" in tail, tail

@@ -4,9 +4,13 @@
 // function live on the MI355X behind the ABI.
 #pragma once
 
+// (the standard headers the reference's graph.h:10-16 pulls in: callers rely on them transitively)
+#include <cassert>
+#include <climits>
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>

@@ -3,6 +3,7 @@
 #pragma once
 
 #include <fstream>
+#include <iostream>  // as utils.h:10-12 of the reference: examples print graphs with std::cout
 #include <istream>
 #include <unordered_map>
 #include <ostream>

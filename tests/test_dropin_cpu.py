@@ -41,3 +41,24 @@ def test_headers_and_abi_over_the_unmodified_reference(name, tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "All tests passed" in r.stdout
+
+
+EXAMPLES = ["asg", "count_ngrams", "ctc", "edit_distance", "learned_decompositions", "priors", "tutorial"]
+
+
+@pytest.mark.parametrize("name", EXAMPLES)
+def test_reference_examples_build_and_run_over_the_reference(name, tmp_path):
+    """examples/*.cpp (and benchmarks/*.cpp, compile-only) build unmodified against include/gtn -- they lean on
+    headers the reference pulls in transitively (<iostream>, <cassert>) -- and the examples run to completion,
+    their own asserts included, on the reference backend behind the C ABI."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(BIN, "ex_" + name)
+    ref = os.path.join(root, "oracle", "_ref", "libgtn_ref.so")
+    if not os.path.exists(exe) or not os.path.exists(ref):
+        pytest.skip("needs tests/dropin/_bin and oracle/_ref (built from /root/reference by __graft_entry__.build())")
+    for b in ("ctc", "functions", "graph", "parallel"):
+        assert os.path.exists(os.path.join(BIN, "bm_" + b)), "benchmarks/%s.cpp did not build" % b
+    os.symlink(ref, tmp_path / "libgtn_amd.so")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path) + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]

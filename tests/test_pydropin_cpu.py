@@ -31,3 +31,26 @@ def test_reference_python_binding_tests_run_on_the_mirror(tmp_path):
     tail = (r.stdout + r.stderr)[-3000:]
     assert r.returncode == 0, tail
     assert "Ran 47 tests" in tail and "\nOK" in tail, tail
+
+
+@pytest.mark.parametrize("script,expect", [("linear_crf.py", "Test: Accuracy"), ("pytorch_loss.py", "Grad has shape")])
+def test_reference_python_examples_run_on_the_mirror(script, expect, tmp_path):
+    """bindings/python/examples: a linear-chain CRF trained for 10 000 steps with gtn ops + autograd, and the
+    PyTorch CTC loss module (pytorch_loss.py:19-102) -- unmodified, `import gtn` = gtn_amd over the reference
+    backend.  (simple_graph.py and word_decompositions.py only need graphviz's `dot` on top, absent here.)"""
+    ref_lib = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
+    src = os.path.join("/root/reference/bindings/python/examples", script)
+    if not (os.path.exists(src) and os.path.exists(ref_lib)):
+        pytest.skip("needs /root/reference and oracle/_ref")
+    pkg = tmp_path / "gtn"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text(
+        "import gtn_amd as _g\n"
+        "globals().update({k: getattr(_g, k) for k in dir(_g) if not k.startswith('__')})\n")
+    env = dict(os.environ, GTN_AMD_LIB=ref_lib, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    r = subprocess.run([sys.executable, src], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert expect in r.stdout, r.stdout[-2000:]
+    if script == "linear_crf.py":
+        acc = float(r.stdout.strip().splitlines()[-1].split()[-1])
+        assert acc > 0.9, r.stdout[-500:]

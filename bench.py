@@ -218,6 +218,15 @@ def main():
     dt = max_over_ranks(dt, dev)
 
     prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+    host_ms = None
+    if native is not None:
+        try:  # host phases of the timed loop's last step (bench_native/ctc_step.cpp)
+            buf = (C.c_double * 5)()
+            native.gtn_bench_last_host_ms(buf)
+            host_ms = dict(zip(("target_graphs", "emission_graphs", "intersect", "forward_scores", "backward"),
+                               [round(float(x), 3) for x in buf]))
+        except Exception:
+            host_ms = None
     losses_timed = loss_dev.cpu().numpy().copy()  # of the timed loop's last step
     grad_timed = None
     if native is not None:
@@ -349,6 +358,9 @@ def main():
             "roofline_other": {k: v for k, v in roofs.items() if k != dominant},
             # the step with the lattices built (compose -> forwardScore kernel -> fused backward)
             "built_lattice_path": built,
+            # where a step's wall time goes on the host thread (ms, last timed step) next to the GPU work below:
+            # with the sweep kernels the step is host-bound
+            "host_ms_last_step": host_ms,
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
             "loss_mean": float(np.mean(losses)),
         }

@@ -14,6 +14,13 @@
 
 using namespace gtn;
 
+// host milliseconds of the last step's phases on the calling thread: target graphs (parallelMap), emissions
+// graphs, intersect, the two forwardScores + subtract, backward -- what bounds a step once the GPU work is short
+static double g_last[5] = {0, 0, 0, 0, 0};
+extern "C" __attribute__((visibility("default"))) void gtn_bench_last_host_ms(double* out5) {
+  for (int i = 0; i < 5; ++i) out5[i] = g_last[i];
+}
+
 // emissions: DEVICE [B][T][C]; targets: host [B][U]; loss_dev: DEVICE [B];
 // grad_dev: DEVICE [B][T][C] or null.  Returns 0 or a gtnx status.
 extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const void* emissions, const int* targets,
@@ -33,6 +40,11 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
     criteria::CtcStepTimes tm;
     t_tail0 = now();
     criteria::ctcLossBatch(emissions, tg, T, C, /*blank=*/0, loss_dev, grad_dev, /*targetGrad=*/true, &tm);
+    g_last[0] = tm.build;
+    g_last[1] = tm.linear;
+    g_last[2] = tm.intersect;
+    g_last[3] = tm.forward;
+    g_last[4] = tm.backward;
     if (timing)
       std::fprintf(stderr, "host ms: build %.2f linear %.2f intersect %.2f fwd %.2f bwd %.2f\n", tm.build, tm.linear,
                    tm.intersect, tm.forward, tm.backward);

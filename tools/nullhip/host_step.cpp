@@ -9,6 +9,7 @@
 #include <signal.h>
 #include <time.h>
 #include <unistd.h>
+#include <sys/resource.h>
 #include <sys/syscall.h>
 #include <algorithm>
 #include <vector>
@@ -75,11 +76,17 @@ int main(int argc, char** argv) {
   std::vector<int> tg(size_t(B) * U);
   for (size_t i = 0; i < tg.size(); ++i) tg[i] = 1 + int((i * 2654435761u >> 7) % unsigned(C - 1));
   double best = 1e30, sum = 0, rsum = 0;
+  long flt0 = 0;
   std::vector<double> all;
   const char* sample = std::getenv("GTN_HOST_SAMPLE");
   const bool no_sync = std::getenv("HOST_STEP_NO_SYNC") != nullptr;
   for (int s = 0; s < steps; ++s) {
     if (s == 3 && sample) start_sampler();
+    if (s == 3) {
+      struct rusage ru;
+      getrusage(RUSAGE_SELF, &ru);
+      flt0 = ru.ru_minflt;
+    }
     auto t0 = std::chrono::steady_clock::now();
     if (step(em.data(), tg.data(), B, T, C, U, loss.data(), grad.data()) != 0) { std::fprintf(stderr, "step failed\n"); return 2; }
     auto t1 = std::chrono::steady_clock::now();
@@ -89,6 +96,11 @@ int main(int argc, char** argv) {
     if (s >= 3) { all.push_back(ms); best = ms < best ? ms : best; sum += ms; rsum += std::chrono::duration<double, std::milli>(t2 - t1).count(); }
   }
   if (sample) dump_samples(sample);
+  {
+    struct rusage ru;
+    getrusage(RUSAGE_SELF, &ru);
+    std::printf("minor page faults per step: %.0f\n", double(ru.ru_minflt - flt0) / (steps - 3));
+  }
   std::sort(all.begin(), all.end());
   std::printf("host ms/step: best %.2f median %.2f mean %.2f + reclaim %.2f (B=%d T=%d C=%d U=%d)\n", best,
               all[all.size() / 2], sum / (steps - 3), rsum / (steps - 3), B, T, C, U);

@@ -28,7 +28,93 @@ void Structure::touch() {
   sched.reset();
   csr_valid = false;
   max_deg = -1;
+  band[0].reset();
+  band[1].reset();
   ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65
+}
+
+bool Weights::is_all_zero() {
+  if (!host_valid || host_escaped) return false;
+  if (zero_version != version) {
+    all_zero = true;
+    for (int64_t i = 0; i < n && all_zero; ++i) all_zero = host[size_t(i)] == 0.0f;
+    zero_version = version;
+  }
+  return all_zero;
+}
+
+// Band records of a host-built structure (kernels.h: BandNode).  O(A); cached until touch().
+std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel) {
+  std::shared_ptr<BandInfo>& slot = s.band[use_ilabel ? 0 : 1];
+  if (slot) return slot;
+  auto b = std::make_shared<BandInfo>();
+  slot = b;
+  if (s.kind != KIND_EXPLICIT || !s.host_valid || s.lazy || s.N < 1 || s.N > band_max_nodes()) return b;
+  const size_t N = size_t(s.N), A = size_t(s.A);
+  b->nodes.assign(N, BandNode{-1, {-1, -1, -1}});
+  const std::vector<int>& lab = use_ilabel ? s.il : s.ol;
+  for (size_t a = 0; a < A; ++a) {
+    const int k = s.dst[a] - s.src[a], l = lab[a];
+    if (k < 0 || k > 2 || l < 0) return b;
+    BandNode& nd = b->nodes[size_t(s.dst[a])];
+    if (nd.aid[k] >= 0 || (nd.lab >= 0 && nd.lab != l)) return b;
+    nd.lab = l;
+    nd.aid[k] = int(a);
+    b->max_label = std::max(b->max_label, l);
+  }
+  b->ok = true;
+  b->unit_shape = true;
+  for (size_t m = 0; m < N && b->unit_shape; ++m)
+    b->unit_shape = b->nodes[m].aid[0] >= 0 && (m == 0 || b->nodes[m].aid[1] >= 0);
+  // the label most nodes share: its posteriors are summed across the wave, not by LDS atomics
+  std::vector<int> ls;
+  ls.reserve(N);
+  for (const BandNode& nd : b->nodes)
+    if (nd.lab >= 0) ls.push_back(nd.lab);
+  std::sort(ls.begin(), ls.end());
+  size_t best = 0;
+  for (size_t i = 0; i < ls.size();) {
+    size_t j = i;
+    while (j < ls.size() && ls[j] == ls[i]) ++j;
+    if (j - i > best) {
+      best = j - i;
+      b->hot = ls[i];
+    }
+    i = j;
+  }
+  if (best < 8) b->hot = -1;
+  return b;
+}
+
+// one staging copy + one H2D for the band records (and node flags) of a batch
+void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vector<Structure*>& ss) {
+  Runtime& rt = Runtime::get();
+  std::vector<size_t> todo;
+  std::unordered_set<BandInfo*> seen;
+  for (size_t i = 0; i < bs.size(); ++i)
+    if (!bs[i]->dev && seen.insert(bs[i]).second) todo.push_back(i);
+  if (todo.empty()) return;
+  size_t total = 0;
+  std::vector<size_t> on(todo.size()), of(todo.size());
+  for (size_t q = 0; q < todo.size(); ++q) {
+    const size_t N = bs[todo[q]]->nodes.size();
+    on[q] = total;
+    of[q] = total + sizeof(BandNode) * N;
+    total = align_up(of[q] + N, 64);
+  }
+  PinnedMemP pin = rt.alloc_pinned(total);
+  DevMemP dev = rt.alloc(total);
+  auto body = [&](size_t q) {
+    BandInfo* b = bs[todo[q]];
+    const size_t N = b->nodes.size();
+    std::memcpy(pin->as<char>(on[q]), b->nodes.data(), sizeof(BandNode) * N);
+    std::memcpy(pin->as<char>(of[q]), ss[todo[q]]->nflags.data(), N);
+    b->dev_mem = dev;
+    b->dev = dev->as<BandNode>(on[q]);
+    b->dev_flags = dev->as<uint8_t>(of[q]);
+  };
+  for (size_t q = 0; q < todo.size(); ++q) body(q);
+  rt.h2d(dev->ptr, pin->ptr, total);
 }
 
 int Structure::max_degree() {

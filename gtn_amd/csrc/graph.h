@@ -97,6 +97,10 @@ struct Structure {
   // products).  Nothing else in the structure is valid until realize() fills it in.
   std::shared_ptr<struct LazyProduct> lazy;
 
+  // Cached band records (kernels.h: BandNode) per matched-label side (0: ilabel, 1: olabel);
+  // made by band_info() on first use as the fixed side of a symbolic chain product
+  std::shared_ptr<struct BandInfo> band[2];
+
   int max_deg = -1;     // widest in- or out-row (cached; touch() forgets it)
   int max_degree();
 
@@ -114,11 +118,29 @@ struct Weights {
   bool host_valid = true;
   bool host_escaped = false;  // a mutable host pointer was handed out (Graph::weights())
   uint64_t version = 0;       // bumped on every mutation
+  uint64_t zero_version = ~uint64_t(0);  // version all_zero was taken at
+  bool all_zero = false;
+  bool is_all_zero();         // host-valid weights only; cached per version
   DevMemP dev_mem;
   float* dev = nullptr;
   bool dev_valid = false;
   void ensure_host();
 };
+
+// Is G banded (arcs n -> n, n+1, n+2, one per step, one matched label per node)?  Then the
+// sweeps of band.hip apply and this is all of G the device ever sees (16 bytes per node).
+struct BandInfo {
+  bool ok = false;
+  bool unit_shape = false;  // self-loop at every node and an arc from the previous node at every node but 0
+  int hot = -1;             // label carried by >= 8 nodes (CTC: blank)
+  int max_label = -1;
+  std::vector<BandNode> nodes;
+  DevMemP dev_mem;          // one arena per uploaded batch
+  const BandNode* dev = nullptr;
+  const uint8_t* dev_flags = nullptr;
+};
+std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel);   // host part, cached
+void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vector<Structure*>& ss);
 
 struct GradState {
   bool calc_grad = true;

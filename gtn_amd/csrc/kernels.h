@@ -367,6 +367,38 @@ int lazy_pair_max_labels(int block);
 // all pairs of one launch share C; cus: compute units of the device (workgroups are spread evenly)
 void launch_lazy_pair_forward(const LazyPair* d_pairs, int n, int block, int C, int cus, hipStream_t st);
 void launch_lazy_pair_backward(const LazyPair* d_pairs, int n, int block, int C, int cus, hipStream_t st);
+// one workgroup per (chain, BANDED G) pair: band.hip.  G's arcs go from n to n, n+1 or n+2,
+// at most one per (n, step), and all in-arcs of a node carry one matched label.
+struct BandNode {
+  int lab;     // matched label of the node's in-arcs (-1: no in-arc)
+  int aid[3];  // arc id of the in-arc from n, n-1, n-2 (-1: none)
+};
+struct BandPair {
+  const GTNX_G BandNode* nodes;    // [N]
+  const GTNX_G uint8_t* nflags;    // [N] NF_START | NF_ACCEPT
+  const GTNX_G float* w;           // G's weights, arc-id order; null: all zero
+  const GTNX_G float* em;          // [T][C] chain weights
+  GTNX_G float* alpha;             // [T+1][NS] log2 units, shifted rows
+  GTNX_G double* aoff;             // [T+2] shift of every alpha row; [T+1]: the score in log2 units
+  GTNX_G float* score;             // [1]
+  GTNX_G float* norm;              // [1] forwardScore of the chain itself, or null
+  GTNX_G float* rowlse;            // [T] log2-sum-exp2 of every emission row, or null
+  const GTNX_G float* delta;       // [1] upstream gradient of the score         (backward)
+  const GTNX_G float* delta_norm;  // [1] upstream gradient of norm, or null     (backward)
+  GTNX_G float* grad_em;           // [T][C] written completely, or null         (backward)
+  GTNX_G float* grad_fixed;        // [A] zero-filled by the host, or null       (backward)
+  int N, T, C, NS;
+  int hot;                         // label shared by >= 8 nodes of G (CTC: blank), or -1
+  int pad;
+};
+int band_max_nodes();
+int band_max_labels();
+int band_npl(int max_nodes);               // nodes per sweeper lane: 1, 2, 4 or 8
+int band_row_stride(int N, int npl);       // NS
+// all pairs of one launch share C and npl; unit: self-loop + previous-node arc at every node, all weights 0
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, bool unit, hipStream_t st);
+void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg,
+                          hipStream_t st);
 // dense regime
 void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set
 // backward: vin / vout = the two halves of a [2][nb][N] scratch (vin null on the first step)

@@ -2067,17 +2067,190 @@ std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
   return outs;
 }
 
+// ---- one workgroup per (chain, BANDED G) pair: band.hip.  CTC targets and force-alignment
+// acceptors: a single wave carries the whole recursion, the other waves stage.
+bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out = nullptr) {
+  const Structure& cs = *lp.chain.s;
+  if (cs.kind != KIND_LINEAR || cs.C < 1 || cs.C > band_max_labels() || cs.M < 0) return false;
+  std::shared_ptr<BandInfo> b = band_info(*lp.fixed.s, lp.chain_side == 1);
+  if (!b->ok || b->max_label >= cs.C) return false;
+  if (out) *out = b;
+  return true;
+}
+
+struct BandSdOp : OpRecord {
+  std::vector<BandPair> pairs;  // by output index; device pointers
+  std::vector<Graph> chains, fixed;
+  std::vector<std::shared_ptr<BandInfo>> infos;
+  std::vector<uint8_t> unit;    // unit-shaped G with all-zero weights
+  DevMemP arena;                // alpha planes, row shifts, scores
+
+  struct Key {
+    int C, npl, unit, gradg;
+    bool operator<(const Key& o) const {
+      return std::tie(C, npl, unit, gradg) < std::tie(o.C, o.npl, o.unit, o.gradg);
+    }
+    bool operator==(const Key& o) const { return !(*this < o) && !(o < *this); }
+  };
+  // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient)
+  static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward) {
+    Runtime& rt = Runtime::get();
+    if (tab.empty()) return;
+    std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    std::vector<BandPair> flat;
+    flat.reserve(tab.size());
+    for (auto& e : tab) flat.push_back(e.second);
+    DevMemP d = upload_vec(flat);
+    const BandPair* dp = d->as<BandPair>();
+    for (size_t i0 = 0; i0 < tab.size();) {
+      size_t i1 = i0;
+      int max_ns = 0;
+      while (i1 < tab.size() && tab[i1].first == tab[i0].first) max_ns = std::max(max_ns, tab[i1++].second.NS);
+      const Key& k = tab[i0].first;
+      if (backward)
+        launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, rt.stream());
+      else
+        launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, k.unit != 0, rt.stream());
+      i0 = i1;
+    }
+  }
+
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    GradSink sink;
+    size_t eb = 0, fb = 0;
+    std::vector<size_t> eo(ms.size(), 0), fo(ms.size(), 0);
+    for (size_t k = 0; k < ms.size(); ++k) {
+      const int i = ms[k].idx;
+      if (chains[i].calc_grad()) {
+        eo[k] = eb;
+        eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+      }
+      if (fixed[i].calc_grad()) {
+        fo[k] = fb;
+        fb = align_up(fb + 4 * size_t(fixed[i].s->A), 256);
+      }
+    }
+    DevMemP gem = rt.alloc(eb ? eb : 1);       // every row is written by the kernel
+    DevMemP gfx = rt.alloc_zero(fb ? fb : 1);  // arcs that never match stay 0
+    std::vector<std::pair<Key, BandPair>> tab;
+    tab.reserve(ms.size());
+    double bytes = 0;
+    for (size_t k = 0; k < ms.size(); ++k) {
+      const int i = ms[k].idx;
+      BandPair p = pairs[i];
+      p.delta = grad_dev_ptr(ms[k].out);
+      p.delta_norm = nullptr;
+      p.grad_em = chains[i].calc_grad() ? gem->as<float>(eo[k]) : nullptr;
+      p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
+      tab.push_back({Key{p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0}, p});
+      if (p.grad_em) sink.add(chains[i], gem, p.grad_em);
+      if (p.grad_fixed) sink.add(fixed[i], gfx, p.grad_fixed);
+      ms[k].out.g->inputs[0].g->grad_propagated = true;
+      // algorithmic bytes: emissions in, emission gradient out, alpha back in, G's arc gradients out
+      bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
+               (p.grad_fixed ? 4.0 * double(fixed[i].s->A) : 0.0);
+    }
+    {
+      GTNX_PROF("band_forward_score_grad", bytes);
+      launch(tab, true);
+    }
+    sink.flush();
+  }
+};
+
+std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
+  Runtime& rt = Runtime::get();
+  auto op = std::make_shared<BandSdOp>();
+  op->seq = g_seq++;
+  const size_t n = gs.size();
+  std::vector<BandInfo*> bis;
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  op->unit.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    LazyProduct& lp = *gs[i].s->lazy;
+    std::shared_ptr<BandInfo> b;
+    band_ok(lp, &b);
+    op->chains.push_back(lp.chain);
+    op->fixed.push_back(lp.fixed);
+    op->infos.push_back(b);
+    bis.push_back(b.get());
+    ss.push_back(lp.fixed.s.get());
+    const bool zero = lp.fixed.w->is_all_zero();
+    op->unit[i] = zero && b->unit_shape;
+    if (!zero) ws.push_back(lp.fixed.w.get());
+    ws.push_back(lp.chain.w.get());
+  }
+  ensure_band_device_batch(bis, ss);
+  ensure_weights_device_batch(ws);
+  size_t bytes = align_up(4 * n, 256);
+  std::vector<size_t> ao(n), oo(n);
+  for (size_t i = 0; i < n; ++i) {
+    const int T = op->chains[i].s->M, N = int(op->fixed[i].s->N);
+    const int ns = band_row_stride(N, band_npl(N));
+    oo[i] = bytes;
+    bytes = align_up(bytes + 8 * size_t(T + 2), 256);
+    ao[i] = bytes;
+    bytes = align_up(bytes + 4 * size_t(T + 1) * size_t(ns), 256);
+  }
+  op->arena = rt.alloc(bytes);
+  op->pairs.resize(n);
+  std::vector<std::pair<BandSdOp::Key, BandPair>> tab;
+  tab.reserve(n);
+  double abytes = 0;
+  for (size_t i = 0; i < n; ++i) {
+    BandPair& p = op->pairs[i];
+    p = BandPair{};
+    const BandInfo& b = *op->infos[i];
+    p.nodes = b.dev;
+    p.nflags = b.dev_flags;
+    p.w = op->fixed[i].w->is_all_zero() ? nullptr : op->fixed[i].w->dev;
+    p.em = op->chains[i].w->dev;
+    p.N = int(op->fixed[i].s->N);
+    p.T = op->chains[i].s->M;
+    p.C = op->chains[i].s->C;
+    p.NS = band_row_stride(p.N, band_npl(p.N));
+    p.alpha = op->arena->as<float>(ao[i]);
+    p.aoff = op->arena->as<double>(oo[i]);
+    p.score = op->arena->as<float>(4 * i);
+    p.hot = b.hot;
+    tab.push_back({BandSdOp::Key{p.C, band_npl(p.N), int(op->unit[i]), 0}, p});
+    abytes += 4.0 * p.T * p.C + 4.0 * double(p.T + 1) * p.NS;  // emissions in, alpha out (kept for the backward sweep)
+  }
+  {
+    GTNX_PROF("band_forward_score", abytes);
+    BandSdOp::launch(tab, false);
+  }
+  std::vector<Graph> outs;
+  outs.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    Graph out = make_output(op, int(i), {gs[i]});
+    init_scalar_result(out);
+    set_dev_weights(out, op->arena, op->pairs[i].score, 1);
+    outs.push_back(std::move(out));
+  }
+  return outs;
+}
+
 std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical) {
   if (!tropical && !getenv("GTNX_NO_LAZY_PAIRS")) {
-    std::vector<Graph> pr, gr;
-    std::vector<size_t> pi, gi;
+    std::vector<Graph> br, pr, gr;
+    std::vector<size_t> bi, pi, gi;
+    const bool band = getenv("GTNX_NO_BAND") == nullptr;  // read per call: tests flip it at run time
     for (size_t i = 0; i < gs.size(); ++i) {
-      if (lazy_pair_ok(*gs[i].s->lazy)) { pr.push_back(gs[i]); pi.push_back(i); }
+      if (band && band_ok(*gs[i].s->lazy)) { br.push_back(gs[i]); bi.push_back(i); }
+      else if (lazy_pair_ok(*gs[i].s->lazy)) { pr.push_back(gs[i]); pi.push_back(i); }
       else { gr.push_back(gs[i]); gi.push_back(i); }
     }
-    if (!pr.empty()) {
+    if (br.size() == gs.size()) return band_forward_score(br);
+    if (!pr.empty() || !br.empty()) {
       std::vector<Graph> outs(gs.size(), Graph(false));
-      std::vector<Graph> po = lazy_pair_forward_score(pr);
+      if (!br.empty()) {
+        std::vector<Graph> bo = band_forward_score(br);
+        for (size_t k = 0; k < bi.size(); ++k) outs[bi[k]] = std::move(bo[k]);
+      }
+      std::vector<Graph> po = pr.empty() ? std::vector<Graph>() : lazy_pair_forward_score(pr);
       for (size_t k = 0; k < pi.size(); ++k) outs[pi[k]] = std::move(po[k]);
       if (!gr.empty()) {
         std::vector<Graph> go = lazy_group_shortest_distance(gr, tropical);

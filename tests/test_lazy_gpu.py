@@ -237,30 +237,44 @@ def test_dense_regime_with_impossible_emissions_and_transitions(gtn):
 # per-utterance sweep kernels (lazy_pair.hip): compose_mode(2), the path the criteria take
 # ---------------------------------------------------------------------------
 class pair_mode:
-    """gtn.compose_mode(2) for the block; `used()` tells whether the pair kernels ran"""
+    """gtn.compose_mode(2) for the block; `used()` tells whether the per-utterance sweep kernels ran.
+    band=False keeps banded partners (CTC targets) away from band.hip, i.e. on lazy_pair.hip."""
 
-    def __init__(self, gtn):
+    def __init__(self, gtn, band=True):
         self.gtn = gtn
+        self.band = band
 
     def __enter__(self):
+        import os
+        self.env = os.environ.pop("GTNX_NO_BAND", None)
+        if not self.band:
+            os.environ["GTNX_NO_BAND"] = "1"
         self.prev = self.gtn.compose_mode(2)
         self.gtn.prof_reset()
         self.gtn.prof_enable(True)
         return self
 
     def __exit__(self, *a):
+        import os
         self.gtn.prof_enable(False)
         self.names = self.gtn.prof_names()
         self.gtn.compose_mode(self.prev)
+        os.environ.pop("GTNX_NO_BAND", None)
+        if self.env is not None:
+            os.environ["GTNX_NO_BAND"] = self.env
 
     def used(self):
-        return "lazy_pair_forward_score" in self.names
+        return "lazy_pair_forward_score" in self.names or "band_forward_score" in self.names
+
+    def used_band(self):
+        return "band_forward_score" in self.names
 
 
-def _ctc_pair_check(gtn, ems_np, targets, chain_first=False):
-    """CTC losses and both gradients through the pair kernels against the oracle"""
+def _ctc_pair_check(gtn, ems_np, targets, chain_first=False, band=True):
+    """CTC losses and both gradients through the sweep kernels (band.hip, or lazy_pair.hip with
+    band=False) against the oracle"""
     B = len(targets)
-    with pair_mode(gtn) as pm:
+    with pair_mode(gtn, band) as pm:
         ems, ctcs = [], []
         for b in range(B):
             T, C = ems_np[b].shape
@@ -273,6 +287,7 @@ def _ctc_pair_check(gtn, ems_np, targets, chain_first=False):
         gtn.backward(loss)
         got = gtn.items(loss)
     assert pm.used(), "the per-utterance sweep kernels did not run"
+    assert pm.used_band() == band
     for b in range(B):
         T, C = ems_np[b].shape
         want, wgrad = ctc_loss(ems_np[b], np.asarray(targets[b], np.int32))
@@ -289,6 +304,7 @@ def _ctc_pair_check(gtn, ems_np, targets, chain_first=False):
         np.testing.assert_allclose(ctcs[b].grad().weights_to_numpy(), -np.asarray(g1), rtol=1e-3, atol=1e-4)
 
 
+@pytest.mark.parametrize("band", [True, False])
 @pytest.mark.parametrize("B,T,C,U,chain_first", [
     (4, 50, 9, 5, False),     # odd label count: scalar staging tail
     (3, 300, 64, 30, False),
@@ -298,21 +314,22 @@ def _ctc_pair_check(gtn, ems_np, targets, chain_first=False):
     (2, 400, 20, 150, False), # 301-node targets: 512-lane workgroups
     (1, 1, 4, 1, False),      # a single frame
 ])
-def test_pair_kernels_ctc_vs_oracle(gtn, B, T, C, U, chain_first):
+def test_pair_kernels_ctc_vs_oracle(gtn, B, T, C, U, chain_first, band):
     rng = np.random.default_rng(B * 1000 + T + C)
     ems = [rng.normal(0, 1, (T, C)).astype(np.float32) for _ in range(B)]
     tg = [rng.integers(1, C, U).tolist() for _ in range(B)]
-    _ctc_pair_check(gtn, ems, tg, chain_first)
+    _ctc_pair_check(gtn, ems, tg, chain_first, band)
 
 
-def test_pair_kernels_mixed_shapes_in_one_batch(gtn):
+@pytest.mark.parametrize("band", [True, False])
+def test_pair_kernels_mixed_shapes_in_one_batch(gtn, band):
     """utterances of different length, alphabet and target size in ONE call (launch groups by label
     count), an empty target and a target that cannot be aligned"""
     rng = np.random.default_rng(5)
     shapes = [(30, 7), (55, 7), (12, 19), (30, 7), (3, 6), (20, 5)]
     ems = [rng.normal(0, 1, s).astype(np.float32) for s in shapes]
     tg = [[1, 2, 3], [4, 4, 4, 1], [18, 2], [], [1, 2, 3, 4, 5], [2, 4]]
-    _ctc_pair_check(gtn, ems, tg)
+    _ctc_pair_check(gtn, ems, tg, band=band)
 
 
 def test_pair_kernels_shared_target_and_general_partner(gtn):

@@ -9,20 +9,21 @@
 // creations.cpp:20-33) and the backward launch adds its softmax gradient, so every
 // emission is read once per sweep and every gradient row is written exactly once.
 //
-// One workgroup per utterance, 4 waves with different jobs:
-//   wave 0  (the sweeper) owns ALL nodes of G, NPL consecutive nodes per lane.  The T
-//           dependent steps never leave the wave: no barrier, no LDS round trip for the
-//           recursion -- neighbours inside a lane are registers, the two values that
-//           cross a lane boundary move with one DPP wave shift each.  Scores are in log2
-//           units (bare v_exp_f32 / v_log_f32), "minus infinity" is -1e30 so no step needs
-//           an inf / NaN guard, and every RN steps the row is shifted by its maximum (the
-//           shifts are summed in fp64) so the magnitudes stay O(10) and float32 keeps
-//           ~1e-6 relative accuracy on every posterior for any T.
-//   waves 1-3 (the stagers) do everything that is not the recursion: HBM -> registers ->
-//           LDS for the emission chunk after next (16-byte loads a whole chunk ahead),
-//           the per-row log-sum-exp of the normaliser, and in the backward kernel the
-//           alpha rows, the softmax term of the gradient rows and their single coalesced
-//           store.  They meet the sweeper at ONE LDS-only barrier per chunk of rows.
+// One workgroup of 4 waves per utterance; wave w owns nodes [64w NPL, 64(w+1) NPL), NPL = 1
+// or 2 nodes per lane.  The recursion over time is a SKEWED PIPELINE: a node needs values of
+// lower-numbered nodes only (higher-numbered in the backward sweep), so wave w runs one time
+// step behind wave w-1 and finds the two boundary values it needs in LDS, written a whole
+// step earlier.  Inside a wave neighbours move by DPP wave shifts.  One LDS-only barrier per
+// tick keeps the waves in step; nothing on the critical path waits for LDS or HBM latency:
+//   * emission rows live in an LDS ring, landed a chunk ahead from 16-byte loads issued two
+//     chunks ahead (every wave stages its share; there are no helper waves);
+//   * scores are in log2 units (bare v_exp_f32 / v_log_f32), "minus infinity" is -1e30 so no
+//     step needs an inf / NaN guard, and every RN rows the row is shifted by the maximum of
+//     the row RN rows back (the shifts are summed in fp64): magnitudes stay O(10) and float32
+//     keeps ~1e-5 relative accuracy on every posterior for any T;
+//   * the backward sweep adds node posteriors into an LDS ring of gradient rows (pre-filled
+//     with the normaliser's softmax term) which is drained with coalesced stores once the
+//     last wave is through with a chunk; G's arc gradients are register accumulators.
 // HBM traffic per utterance: forward 4TC + 4(T+1)NS, backward 8TC + 4(T+1)NS (+ G).
 #include <hip/hip_runtime.h>
 
@@ -33,51 +34,64 @@
 namespace gtnx {
 namespace {
 
-constexpr float NEGF = -1.0e30f;        // log-domain zero
-constexpr float DEADF = -1.0e29f;       // anything below is "no path"
+constexpr float NEGF = -1.0e30f;   // log-domain zero
+constexpr float DEADF = -1.0e29f;  // anything below is "no path"
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr double LN2 = 0.693147180559945309417;
-constexpr int BW = 256;    // lanes per workgroup
-constexpr int NSTG = 192;  // stager lanes (waves 1..3)
-constexpr int SL4 = 6;     // 16-byte slots per stager lane and chunk (4096 floats / 4 / 192)
-constexpr int SL1 = 22;    // 4-byte slots (chunk base not 16-byte aligned)
-constexpr int RN = 4;      // steps between renormalisations of the running row
+constexpr int BW = 256;  // lanes per workgroup (4 waves)
+constexpr int RN = 4;    // rows between shifts of the running row; also the lag of the shift
+constexpr int LAGW = 3;  // ticks between the leading and the last wave
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 
-// lane i <- lane i-1 (lane 0 keeps `fill`) / lane i <- lane i+1 (lane 63 keeps `fill`)
+// lane i <- lane i-1 (lane 0 takes `fill`) / lane i <- lane i+1 (lane 63 takes `fill`)
 __device__ __forceinline__ float wave_shr1(float x, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float wave_shl1(float x, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x130, 0xf, 0xf, false));
 }
-#define GTNX_BAND_DPP(op, x, ctrl, rmask, idv) \
-  x = op(x, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(idv), __float_as_int(x), ctrl, rmask, 0xf, false)))
-__device__ __forceinline__ float fadd(float a, float b) { return a + b; }
-// wave64 reductions by DPP row shifts / broadcasts (all 64 lanes active); result uniform
-__device__ __forceinline__ float wave_max(float x) {
-  GTNX_BAND_DPP(fmaxf, x, 0x111, 0xf, x);
-  GTNX_BAND_DPP(fmaxf, x, 0x112, 0xf, x);
-  GTNX_BAND_DPP(fmaxf, x, 0x114, 0xf, x);
-  GTNX_BAND_DPP(fmaxf, x, 0x118, 0xf, x);
-  GTNX_BAND_DPP(fmaxf, x, 0x142, 0xa, x);
-  GTNX_BAND_DPP(fmaxf, x, 0x143, 0xc, x);
+// wave64 reductions: six DPP ops (a lane without a source keeps its value), total in lane 63
+#define GTNX_DPP6(op)                                                         \
+  "s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"     \
+  "s_nop 1\n\t" op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  \
+  "s_nop 1\n\t" op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  \
+  "s_nop 1"
+__device__ __forceinline__ float wave_max(float x) {  // uniform result
+  asm volatile(GTNX_DPP6("v_max_f32_dpp") : "+v"(x));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 __device__ __forceinline__ float wave_sum63(float x) {  // lane 63 holds the total
-  GTNX_BAND_DPP(fadd, x, 0x111, 0xf, 0.0f);
-  GTNX_BAND_DPP(fadd, x, 0x112, 0xf, 0.0f);
-  GTNX_BAND_DPP(fadd, x, 0x114, 0xf, 0.0f);
-  GTNX_BAND_DPP(fadd, x, 0x118, 0xf, 0.0f);
-  GTNX_BAND_DPP(fadd, x, 0x142, 0xa, 0.0f);
-  GTNX_BAND_DPP(fadd, x, 0x143, 0xc, 0.0f);
+  asm volatile(GTNX_DPP6("v_add_f32_dpp") : "+v"(x));
   return x;
 }
 __device__ __forceinline__ float wave_sum(float x) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(x)), 63));
+}
+// all-reduce inside every aligned group of 16 lanes (one DPP row) by rotations
+#define GTNX_ROR4(op)                                                        \
+  "s_nop 1\n\t" op " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"    \
+  "s_nop 1\n\t" op " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"    \
+  "s_nop 1\n\t" op " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"    \
+  "s_nop 1\n\t" op " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"    \
+  "s_nop 1"
+__device__ __forceinline__ float row16_max(float x) {
+  asm volatile(GTNX_ROR4("v_max_f32_dpp") : "+v"(x));
+  return x;
+}
+__device__ __forceinline__ float row16_sum(float x) {
+  asm volatile(GTNX_ROR4("v_add_f32_dpp") : "+v"(x));
+  return x;
+}
+// LDS float add without return value (the compiler's atomic optimiser would wrap a plain
+// atomicAdd of a uniform address in a lane loop)
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  asm volatile("ds_add_f32 %0, %1" ::"v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))), "v"(v) : "memory");
 }
 
 // log2(2^x0 + 2^x1 + 2^x2): the largest term is exactly 1, so two v_exp_f32 and one v_log_f32
@@ -88,28 +102,28 @@ __device__ __forceinline__ float lse3(float x0, float x1, float x2) {
   return mx + lg2(1.0f + ex2(md - mx) + ex2(mn - mx));
 }
 
-// what a sweeper lane knows about its NPL nodes
+// what a lane knows about its NPL nodes
 template <int NPL>
 struct NodeRegs {
-  int lab[NPL];     // matched label (0 when the node has no in-arc; its weights are NEGF then)
-  float wi[3][NPL]; // in-arc from n-k, log2 units (NEGF: no such arc)
-  float wo[3][NPL]; // out-arc to n+k
-  int ai[3][NPL];   // arc ids of the in-arcs (-1: none)
-  int ao[3][NPL];   // arc ids of the out-arcs
+  int lab[NPL];      // matched label (0 when the node has no in-arc; its weights are NEGF then)
+  float wi[3][NPL];  // in-arc from n-k, log2 units (NEGF: no such arc)
+  float wo[3][NPL];  // out-arc to n+k
+  int ao[3][NPL];    // arc ids of the out-arcs (-1: none)
+  bool has_in[NPL];
   bool start[NPL], accept[NPL];
 };
 template <int NPL, bool WANT_OUT>
-__device__ __forceinline__ void load_nodes(const BandPair& P, int lane, NodeRegs<NPL>& g) {
+__device__ __forceinline__ void load_nodes(const BandPair& P, int m0, NodeRegs<NPL>& g) {
   const GTNX_G gtnx_i4* nodes = reinterpret_cast<const GTNX_G gtnx_i4*>(P.nodes);
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
-    const int m = lane * NPL + j;
+    const int m = m0 + j;
     g.lab[j] = 0;
-    g.start[j] = g.accept[j] = false;
+    g.start[j] = g.accept[j] = g.has_in[j] = false;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       g.wi[k][j] = g.wo[k][j] = NEGF;
-      g.ai[k][j] = g.ao[k][j] = -1;
+      g.ao[k][j] = -1;
     }
     if (m < P.N) {
       const gtnx_i4 q = nodes[m];  // {label, arc from m, arc from m-1, arc from m-2}
@@ -121,7 +135,7 @@ __device__ __forceinline__ void load_nodes(const BandPair& P, int lane, NodeRegs
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         if (a[k] >= 0) {
-          g.ai[k][j] = a[k];
+          g.has_in[j] = true;
           g.wi[k][j] = P.w ? fmaxf(P.w[a[k]] * LOG2E, NEGF) : 0.0f;
         }
     }
@@ -141,184 +155,312 @@ __device__ __forceinline__ void load_nodes(const BandPair& P, int lane, NodeRegs
   }
 }
 
-template <int NPL>
-__device__ __forceinline__ void store_row(GTNX_G float* p, const float (&a)[NPL]) {
-  if constexpr (NPL == 1) {
-    p[0] = a[0];
-  } else if constexpr (NPL == 2) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    *reinterpret_cast<GTNX_G f2*>(p) = f2{a[0], a[1]};
-  } else {
-#pragma unroll
-    for (int j = 0; j < NPL; j += 4) *reinterpret_cast<GTNX_G gtnx_f4*>(p + j) = gtnx_f4{a[j], a[j + 1], a[j + 2], a[j + 3]};
-  }
-}
-template <int NPL>
-__device__ __forceinline__ void load_row_lds(const float* p, float (&a)[NPL]) {
-  if constexpr (NPL == 1) {
-    a[0] = p[0];
-  } else if constexpr (NPL == 2) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    const f2 v = *reinterpret_cast<const f2*>(p);
-    a[0] = v.x;
-    a[1] = v.y;
-  } else {
-#pragma unroll
-    for (int j = 0; j < NPL; j += 4) {
-      const gtnx_f4 v = *reinterpret_cast<const gtnx_f4*>(p + j);
-      a[j] = v.x;
-      a[j + 1] = v.y;
-      a[j + 2] = v.z;
-      a[j + 3] = v.w;
-    }
-  }
-}
-
-// ---- stager side: a contiguous range of `cnt` floats, HBM -> registers -> LDS --------------
-struct Stage {
-  float v[4 * SL4];  // 24 >= SL1
-};
-__device__ __forceinline__ void stage_issue(Stage& s, const GTNX_G float* src, int cnt, bool vec, int sl) {
-  if (vec) {
-#pragma unroll
-    for (int i = 0; i < SL4; ++i) {
-      const int e = 4 * (i * NSTG + sl);
-      gtnx_f4 q = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (e < cnt) q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
-      s.v[4 * i] = q.x;
-      s.v[4 * i + 1] = q.y;
-      s.v[4 * i + 2] = q.z;
-      s.v[4 * i + 3] = q.w;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < SL1; ++i) {
-      const int e = i * NSTG + sl;
-      s.v[i] = e < cnt ? src[e] : 0.0f;
-    }
-  }
-}
 // emissions land in log2 units with -inf clamped to the finite log-zero
 __device__ __forceinline__ float em2(float x) { return fmaxf(x * LOG2E, NEGF); }
-template <bool SCALE>
-__device__ __forceinline__ void stage_land(const Stage& s, float* dst, int cnt, bool vec, int sl) {
-  if (vec) {
-#pragma unroll
-    for (int i = 0; i < SL4; ++i) {
-      const int e = 4 * (i * NSTG + sl);
-      if (e < cnt) {
-        gtnx_f4 q = {s.v[4 * i], s.v[4 * i + 1], s.v[4 * i + 2], s.v[4 * i + 3]};
-        if (SCALE) q = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-        *reinterpret_cast<gtnx_f4*>(dst + e) = q;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < SL1; ++i) {
-      const int e = i * NSTG + sl;
-      if (e < cnt) dst[e] = SCALE ? em2(s.v[i]) : s.v[i];
-    }
-  }
+
+// rows of a chunk are contiguous in HBM: element e (0 .. rows * W) -> row e / W; W <= 4096, e <= 4096
+__device__ __forceinline__ int row_of(int e, int W, float invW) {
+  int r = int(float(e) * invW);
+  if (r * W > e) --r;
+  if ((r + 1) * W <= e) ++r;
+  return r;
 }
 
-// row-wise log2-sum-exp2 of `rows` staged emission rows, one wave per row; wave `w` of `nw`
-__device__ __forceinline__ void row_lse(const float* e0, int rows, int C, int t0, int w, int nw, int lane,
-                                        GTNX_G float* rowlse, double& acc) {
-  for (int r = w; r < rows; r += nw) {
-    const float* e = e0 + r * C;
-    float mx = NEGF;
-    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, e[c]);
-    mx = wave_max(mx);
-    float s = 0.0f;
-    for (int c = lane; c < C; c += 64) s += ex2(e[c] - mx);
-    s = wave_sum(s);
-    const float l = mx + lg2(s);
-    acc += double(l);
-    if (rowlse && lane == 0) rowlse[t0 + r] = l;
+// A chunk of `rows` contiguous HBM rows of W floats each, staged through NS floats per lane:
+// issue() starts the loads, land() writes them to an LDS ring whose row `slot_of(r)` holds chunk row r.
+template <int NS>
+struct Stage {
+  float v[NS];
+  __device__ __forceinline__ void issue(const GTNX_G float* src, int cnt, bool vec, int tid) {
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < NS / 4; ++i) {
+        const int e = 4 * (i * BW + tid);
+        gtnx_f4 q = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (e < cnt) q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
+        v[4 * i] = q.x;
+        v[4 * i + 1] = q.y;
+        v[4 * i + 2] = q.z;
+        v[4 * i + 3] = q.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int e = i * BW + tid;
+        v[i] = e < cnt ? src[e] : 0.0f;
+      }
+    }
   }
+  // f(i, e, r, c, q): slot index, element, chunk row, column, values (4 in vec mode, else q.x)
+  template <class F>
+  __device__ __forceinline__ void each(int cnt, int W, bool vec, int tid, F&& f) const {
+    const float invW = 1.0f / float(W);
+    if (vec) {
+#pragma unroll
+      for (int i = 0; i < NS / 4; ++i) {
+        const int e = 4 * (i * BW + tid);
+        if (e < cnt) {
+          const int r = row_of(e, W, invW);
+          f(i, e, r, e - r * W, gtnx_f4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]});
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        const int e = i * BW + tid;
+        if (e < cnt) {
+          const int r = row_of(e, W, invW);
+          f(i, e, r, e - r * W, gtnx_f4{v[i], 0.0f, 0.0f, 0.0f});
+        }
+      }
+    }
+  }
+};
+
+// shift applied to row `row` (a multiple of RN, >= RN): the maximum of row - RN over all waves
+__device__ __forceinline__ float shift_of(const float* mxr, int row) {
+  const float* p = mxr + (((row - RN) / RN) & 7) * 4;
+  const float s = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
+  return s > DEADF ? s : 0.0f;
+}
+
+// LDS layout shared by host (size) and device (carving); all counts in floats
+struct BandLds {
+  int CS;               // ring row stride of emission / gradient rows
+  int NER, NAR, NGR;    // ring depths: emission rows, alpha rows, gradient rows
+  int o_ering, o_aring, o_obuf, o_gring, o_scratch, o_misc, total;
+};
+__host__ __device__ inline BandLds band_lds(int C, int R, int NSmax, bool backward) {
+  BandLds L;
+  L.CS = C + 4;
+  L.NER = 2 * R + LAGW + 1;
+  L.NAR = backward ? L.NER : 0;
+  L.NGR = backward ? (R >= 4 ? 3 * R : 4 * R) : 0;
+  int o = 0;
+  L.o_ering = o;
+  o += L.NER * L.CS;
+  o = (o + 3) & ~3;
+  L.o_aring = o;
+  o += L.NAR * NSmax;
+  o = (o + 3) & ~3;
+  L.o_obuf = o;  // doubles
+  o += 2 * L.NAR;
+  o = (o + 3) & ~3;
+  L.o_gring = o;
+  o += L.NGR * L.CS;
+  L.o_scratch = o;
+  o += backward ? BW : 0;
+  o = (o + 3) & ~3;
+  L.o_misc = o;  // red[16] doubles, bnd[4][4][2], mxr[8][4], fin[8], lse pairs [2][16][8][2]
+  o += 32 + 32 + 32 + 8 + 512;
+  L.total = o;
+  return L;
 }
 
 // ==========================================================================================
 // forward: alpha[t+1][m] = em[t][lab m] + log sum_k exp(alpha[t][m-k] + w_k(m))
 // ==========================================================================================
 template <int NPL, bool UNIT>
-__global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __restrict__ pairs, int R) {
+__global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __restrict__ pairs, int R, int NSmax) {
   const BandPair P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
-  const int RC = R * C;
-  float* ebuf = lds;  // [2][RC]
-  __shared__ double red[4];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const BandLds L = band_lds(C, R, NSmax, false);
+  float* ering = lds + L.o_ering;
+  double* red = reinterpret_cast<double*>(lds + L.o_misc);  // [16]
+  float* bnd = lds + L.o_misc + 32;    // [4 waves][4 slots][2]
+  float* mxr = bnd + 32;               // [8 slots][4 waves]
+  float* fin = mxr + 32;               // [4 waves][2]
+  float* lsep = fin + 8;               // [2 chunk parities][16 rows][8 groups][2]
+  const int CS = L.CS, NER = L.NER;
+  const int Rm = R - 1, lgR = 31 - __builtin_clz(R);
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l = tid & 63;
+  const int m0 = tid * NPL;
   const int nchunks = (T + R - 1) / R;
+  const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0));
+  const bool want_lse = P.norm != nullptr || P.rowlse != nullptr;
 
-  if (wave == 0) {
-    // ------------------------------------------------------------------ sweeper
-    NodeRegs<NPL> g;
-    load_nodes<NPL, false>(P, lane, g);
-    const bool writer = lane * NPL < NS;
-    float a[NPL];
+  NodeRegs<NPL> g;
+  load_nodes<NPL, false>(P, m0, g);
+  const bool writer = m0 < NS;
+  float a[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) a[j] = g.start[j] ? 0.0f : NEGF;
-    double off = 0.0;
-    GTNX_G float* arow = P.alpha + lane * NPL;
-    if (writer) store_row<NPL>(arow, a);
-    if (lane == 0) P.aoff[0] = 0.0;
-    for (int k = 0; k < nchunks; ++k) {
-      lds_barrier();  // chunk k is in ebuf[k & 1]
-      const float* e0 = ebuf + (k & 1) * RC;
-      const int t0 = k * R, rows = min(R, T - t0);
-      float e[NPL];
+  for (int j = 0; j < NPL; ++j) a[j] = g.start[j] ? 0.0f : NEGF;
+  double off = 0.0;
+  GTNX_G float* arow = P.alpha + m0;
+  if (writer) {
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) e[j] = e0[g.lab[j]];
-      for (int r = 0; r < rows; ++r) {
-        const int t = t0 + r;
-        float en[NPL];  // next row's emissions, in flight during this step
-        const float* e1 = e0 + min(r + 1, rows - 1) * C;
+    for (int j = 0; j < NPL; ++j) arow[j] = a[j];
+  }
+  if (tid == 0) P.aoff[1] = 0.0;
+
+  // ---- staging of the emission ring
+  Stage<16> st;
+  auto rows_of = [&](int c) { return c < nchunks ? min(R, T - c * R) : 0; };
+  auto issue = [&](int c) { st.issue(P.em + int64_t(c) * R * C, rows_of(c) * C, vec, tid); };
+  auto land = [&](int c) {
+    const int base = (c * R) % NER;
+    st.each(rows_of(c) * C, C, vec, tid, [&](int, int, int r, int col, gtnx_f4 q) {
+      int s = base + r;
+      if (s >= NER) s -= NER;
+      float* d = ering + s * CS + col;
+      if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
+      else d[0] = em2(q.x);
+    });
+  };
+  // ---- row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / R lanes per row, pairs
+  // (max, sum) per 16-lane group in phase A, merged per row by one lane in phase B
+  const int LPR = BW / R, G16 = LPR / 16;
+  const int EPL = (C + LPR - 1) / LPR;  // <= 16
+  double normacc = 0.0;
+  auto lse_a = [&](int c) {
+    const int rows = rows_of(c), rr = tid / LPR, sub = tid - rr * LPR;
+    if (rows <= 0) return;
+    int s = (c * R) % NER + min(rr, rows - 1);
+    if (s >= NER) s -= NER;
+    const float* e = ering + s * CS + sub * EPL;
+    float x[16];
+    float m = NEGF;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) en[j] = e1[g.lab[j]];
-        const float p1 = wave_shr1(a[NPL - 1], NEGF);
-        const float p2 = NPL >= 2 ? wave_shr1(a[NPL >= 2 ? NPL - 2 : 0], NEGF) : wave_shr1(p1, NEGF);
-        float nw[NPL];
+    for (int i = 0; i < 16; ++i) {
+      x[i] = (i < EPL && sub * EPL + i < C) ? e[i] : NEGF;
+      m = fmaxf(m, x[i]);
+    }
+    m = row16_max(m);
+    float sum = 0.0f;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-          const float s1 = j >= 1 ? a[j >= 1 ? j - 1 : 0] : p1;
-          const float s2 = j >= 2 ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
-          float x0, x1, x2;
-          if (UNIT) {  // self-loop and previous-node arc everywhere, weight 0
-            x0 = a[j];
-            x1 = s1;
-            x2 = s2 + g.wi[2][j];
-          } else {
-            x0 = a[j] + g.wi[0][j];
-            x1 = s1 + g.wi[1][j];
-            x2 = s2 + g.wi[2][j];
-          }
-          nw[j] = lse3(x0, x1, x2) + e[j];
-        }
-        if ((t + 1) % RN == 0) {  // uniform
-          float mx = nw[0];
+    for (int i = 0; i < 16; ++i) sum += (i < EPL) ? ex2(x[i] - m) : 0.0f;
+    sum = row16_sum(sum);
+    if ((tid & 15) == 0 && rr < rows) {
+      float* p = lsep + (c & 1) * 256 + (rr * 8 + (sub >> 4)) * 2;
+      p[0] = m;
+      p[1] = sum;
+    }
+  };
+  auto lse_b = [&](int c) {
+    const int rows = rows_of(c);
+    if (tid < rows) {
+      const float* p = lsep + (c & 1) * 256 + tid * 16;
+      float M = p[0];
+      for (int k = 1; k < G16; ++k) M = fmaxf(M, p[2 * k]);
+      float S = 0.0f;
+      for (int k = 0; k < G16; ++k) S += p[2 * k + 1] * ex2(p[2 * k] - M);
+      const float l2 = M + lg2(S);
+      if (P.rowlse) P.rowlse[c * R + tid] = l2;
+      normacc += double(l2);
+    }
+  };
+
+  // ---- prologue
+  issue(0);
+  land(0);
+  issue(1);
+  if (NPL == 1) {
+    if (l >= 62) bnd[(w * 4 + 0) * 2 + (63 - l)] = a[0];
+  } else if (l == 63) {
+    bnd[(w * 4 + 0) * 2 + 0] = a[NPL - 1];
+    bnd[(w * 4 + 0) * 2 + 1] = a[0];
+  }
+  {
+    float mx = a[0];
 #pragma unroll
-          for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, nw[j]);
-          mx = wave_max(mx);
-          if (mx > DEADF) {
+    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, a[j]);
+    mx = wave_max(mx);
+    if (l == 0) mxr[0 * 4 + w] = mx;
+  }
+  lds_barrier();
+
+  float e[NPL], b1 = NEGF, b2 = NEGF;
+  int ps = 0;  // ring slot of the next row to prefetch (rows come in order from 0)
+  auto prefetch = [&](int t) {  // inputs of the tick that consumes emission row t
+    if (t >= 0 && t < T) {
+      const float* er = ering + ps * CS;
+      ps = ps + 1 == NER ? 0 : ps + 1;
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) nw[j] = fmaxf(nw[j] - mx, NEGF);
-            off += double(mx);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-          a[j] = nw[j];
-          e[j] = en[j];
-        }
-        arow += NS;
-        if (writer) store_row<NPL>(arow, a);
-        if (lane == 0) P.aoff[t + 1] = off;
+      for (int j = 0; j < NPL; ++j) e[j] = er[g.lab[j]];
+      if (w > 0) {
+        const float* bp = bnd + ((w - 1) * 4 + (t & 3)) * 2;
+        b1 = bp[0];
+        b2 = bp[1];
       }
     }
-    // score = log sum over accept nodes of alpha[T]  (shortest.cpp:153-167)
+  };
+  prefetch(0 - w);
+
+  const int nticks = T + LAGW;
+  int pa = -1, pb = -1;  // chunk whose lse phase A / B runs this tick
+  for (int tau = 0; tau < nticks; ++tau) {
+    if ((tau & Rm) == 0) {  // chunk boundary of the leading wave: chunk tau / R + 1 lands, + 2 is requested
+      const int c = tau >> lgR;
+      land(c + 1);
+      issue(c + 2);
+    }
+    if (want_lse) {
+      if (pb >= 0) lse_b(pb);
+      pb = pa;
+      pa = -1;
+      if (tau == 0) pa = 0;
+      else if (((tau - 1) & Rm) == 0) pa = ((tau - 1) >> lgR) + 1;
+      if (pa >= nchunks) pa = -1;
+      if (pa >= 0) lse_a(pa);
+    }
+    const int t = tau - w;
+    if (t >= 0 && t < T) {
+      const float p1 = wave_shr1(a[NPL - 1], b1);
+      const float p2 = NPL == 2 ? wave_shr1(a[0], b2) : wave_shr1(p1, b2);
+      float nw[NPL];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const float s1 = j == 0 ? p1 : a[0];
+        const float s2 = j == 0 ? p2 : p1;
+        float x0, x1, x2;
+        if (UNIT) {  // self-loop and previous-node arc everywhere, weight 0
+          x0 = a[j];
+          x1 = s1;
+          x2 = s2 + g.wi[2][j];
+        } else {
+          x0 = a[j] + g.wi[0][j];
+          x1 = s1 + g.wi[1][j];
+          x2 = s2 + g.wi[2][j];
+        }
+        nw[j] = lse3(x0, x1, x2) + e[j];
+      }
+      const int row = t + 1;
+      if (row % RN == 0) {  // uniform
+        const float sft = shift_of(mxr, row);
+        float mx = NEGF;
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+          nw[j] -= sft;
+          mx = fmaxf(mx, nw[j]);
+        }
+        off += double(sft);
+        mx = wave_max(mx);
+        if (l == 0) mxr[((row / RN) & 7) * 4 + w] = mx;
+        if (tid == 0) P.aoff[1 + row / RN] = off;
+      }
+      arow += NS;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) a[j] = nw[j];
+      if (writer) {
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) arow[j] = a[j];
+      }
+      if (NPL == 1) {
+        if (l >= 62) bnd[(w * 4 + (row & 3)) * 2 + (63 - l)] = a[0];
+      } else if (l == 63) {
+        bnd[(w * 4 + (row & 3)) * 2 + 0] = a[NPL - 1];
+        bnd[(w * 4 + (row & 3)) * 2 + 1] = a[0];
+      }
+    }
+    prefetch(t + 1);
+    lds_barrier();
+  }
+  if (want_lse && pb >= 0) lse_b(pb);
+  // score = log sum over accept nodes of alpha[T]  (shortest.cpp:153-167)
+  {
     float f = NEGF;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) f = fmaxf(f, g.accept[j] ? a[j] : NEGF);
@@ -327,36 +469,26 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
 #pragma unroll
     for (int j = 0; j < NPL; ++j) s += g.accept[j] ? ex2(a[j] - mx) : 0.0f;
     s = wave_sum(s);
-    const bool dead = !(mx > DEADF);
-    const double z2 = dead ? double(NEGF) : off + double(mx) + double(lg2(s));
-    if (lane == 0) {
-      P.aoff[T + 1] = z2;
-      P.score[0] = dead ? -__builtin_inff() : float(z2 * LN2);
+    if (l == 0) {
+      fin[2 * w] = mx;
+      fin[2 * w + 1] = s;
     }
-    lds_barrier();  // the stagers' partial sums of the normaliser
-    if (P.norm && lane == 0) {
-      const double n2 = red[1] + red[2] + red[3];
+    if (tid < 16) red[tid] = normacc;
+  }
+  lds_barrier();
+  if (tid == 0) {
+    const float M = fmaxf(fmaxf(fin[0], fin[2]), fmaxf(fin[4], fin[6]));
+    const bool dead = !(M > DEADF);
+    float S = 0.0f;
+    for (int k = 0; k < 4; ++k) S += fin[2 * k + 1] * ex2(fin[2 * k] - M);
+    const double z2 = dead ? double(NEGF) : off + double(M) + double(lg2(S));
+    P.aoff[0] = z2;
+    P.score[0] = dead ? -__builtin_inff() : float(z2 * LN2);
+    if (P.norm) {
+      double n2 = 0.0;
+      for (int k = 0; k < 16; ++k) n2 += red[k];
       P.norm[0] = n2 < double(DEADF) ? -__builtin_inff() : float(n2 * LN2);
     }
-  } else {
-    // ------------------------------------------------------------------ stagers
-    const int sl = threadIdx.x - 64;
-    const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0));
-    const bool want_lse = P.norm != nullptr || P.rowlse != nullptr;
-    Stage st;
-    double acc = 0.0;
-    auto cnt_of = [&](int k) { return k < nchunks ? min(R, T - k * R) * C : 0; };
-    stage_issue(st, P.em, cnt_of(0), vec, sl);
-    stage_land<true>(st, ebuf, cnt_of(0), vec, sl);
-    stage_issue(st, P.em + int64_t(RC), cnt_of(1), vec, sl);
-    for (int k = 0; k < nchunks; ++k) {
-      lds_barrier();  // chunk k readable; the sweeper is done with chunk k-1, i.e. with ebuf[(k+1) & 1]
-      stage_land<true>(st, ebuf + ((k + 1) & 1) * RC, cnt_of(k + 1), vec, sl);
-      stage_issue(st, P.em + int64_t(k + 2) * RC, cnt_of(k + 2), vec, sl);
-      if (want_lse) row_lse(ebuf + (k & 1) * RC, min(R, T - k * R), C, k * R, wave - 1, 3, lane, P.rowlse, acc);
-    }
-    if (lane == 0) red[wave] = acc;
-    lds_barrier();
   }
 }
 
@@ -364,276 +496,295 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
 // backward: beta[t][n] = log sum_k exp(w_k + em[t][lab(n+k)] + beta[t+1][n+k]);
 //   d score / d em[t][l]   = sum over nodes m with label l of exp(alpha[t+1][m] + beta[t+1][m] - score)
 //   d score / d w(n->n+k)  = sum_t exp(alpha[t][n] + w + em[t][lab(n+k)] + beta[t+1][n+k] - score)
+// Virtual row v = T-1-t ascends with the ticks; wave 3 leads.
 // ==========================================================================================
 template <int NPL, bool UNIT, bool GRADG>
-__global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __restrict__ pairs, int R) {
+__global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __restrict__ pairs, int R, int NSmax) {
   const BandPair P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, NS = P.NS;
-  const int Cp = C + 64;  // gradient rows carry 64 scratch columns (one per lane) for redirected adds
   extern __shared__ float lds[];
-  const int RC = R * C, RG = R * Cp, RA = R * NS;
-  float* abuf = lds;                 // [2][RA]  alpha rows t0 .. t0+rows-1 (16-byte rows)
-  double* obuf = reinterpret_cast<double*>(abuf + 2 * RA);  // [2][R] their offsets
-  float* ebuf = abuf + 2 * RA + 4 * R;  // [2][RC]  emissions, log2 units
-  float* grow = ebuf + 2 * RC;       // [2][RG]  gradient rows of the chunk
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const BandLds L = band_lds(C, R, NSmax, true);
+  float* ering = lds + L.o_ering;
+  float* aring = lds + L.o_aring;
+  double* obuf = reinterpret_cast<double*>(lds + L.o_obuf);
+  float* gring = lds + L.o_gring;
+  float* scratch = lds + L.o_scratch;
+  float* bnd = lds + L.o_misc + 32;  // [4 waves][4 slots][2]
+  float* mxr = bnd + 32;             // [8 slots][4 waves]
+  const int CS = L.CS, NER = L.NER, NGR = L.NGR;
+  const int Rm = R - 1, lgR = 31 - __builtin_clz(R);
+  const int tid = threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lag = 3 - w;
+  const int l = tid & 63;
+  const int m0 = tid * NPL;
   const int nchunks = (T + R - 1) / R;
-  const double z2 = P.aoff[T + 1];
+  const double z2 = P.aoff[0];
   const bool dead = !(z2 > double(DEADF));
   const float ds = P.delta[0];
   const bool want_em = P.grad_em != nullptr;
+  const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0 &&
+                                                      (!want_em || (reinterpret_cast<uintptr_t>(P.grad_em) & 15) == 0)));
+  const float dn = P.delta_norm ? P.delta_norm[0] : 0.0f;
+  const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
 
-  if (wave == 0) {
-    // ------------------------------------------------------------------ sweeper
-    NodeRegs<NPL> g;
-    load_nodes<NPL, true>(P, lane, g);
-    int gcol[NPL];
-    bool hotn[NPL];
+  NodeRegs<NPL> g;
+  load_nodes<NPL, true>(P, m0, g);
+  bool hotn[NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int m = lane * NPL + j;
-      const bool has_in = m < P.N && (g.ai[0][j] >= 0 || g.ai[1][j] >= 0 || g.ai[2][j] >= 0);
-      hotn[j] = has_in && g.lab[j] == P.hot;
-      gcol[j] = (has_in && !hotn[j]) ? g.lab[j] : C + lane;
-    }
-    float b[NPL], ahi[NPL];
-    float acc[3][NPL];
+  for (int j = 0; j < NPL; ++j) hotn[j] = g.has_in[j] && g.lab[j] == P.hot;
+  float b[NPL], ahi[NPL], acc[3][NPL];
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      b[j] = g.accept[j] ? 0.0f : NEGF;
-      acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
-    }
-    {
-      const GTNX_G float* pa = P.alpha + int64_t(T) * NS + lane * NPL;
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) ahi[j] = lane * NPL < NS ? pa[j] : NEGF;
-    }
-    double Ahi = P.aoff[T];
-    double bz = -z2;  // (sum of beta's shifts) - score
-    for (int i = 0; i < nchunks; ++i) {
-      lds_barrier();  // chunk i (counted from the end) is staged
-      const int k = nchunks - 1 - i, t0 = k * R, rows = min(R, T - t0);
-      const float* eb = ebuf + (i & 1) * RC;
-      const float* ab = abuf + (i & 1) * RA + lane * NPL;
-      float* gb = grow + (i & 1) * RG;
-      const double* ob = obuf + (i & 1) * R;
-      if (dead) continue;  // no accepting path: only the normaliser's term reaches the gradient rows
-      for (int r = rows - 1; r >= 0; --r) {
-        const int t = t0 + r;
-        float e[NPL], alo[NPL];
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) e[j] = eb[r * C + g.lab[j]];
-        load_row_lds<NPL>(ab + r * NS, alo);
-        const double Alo = ob[r];
-        // node posteriors at time t+1 -> gradient row t
-        if (want_em) {
-          const float dh = float(Ahi + bz);
-          float hv = 0.0f;
-#pragma unroll
-          for (int j = 0; j < NPL; ++j) {
-            const float occ = ex2(ahi[j] + b[j] + dh) * ds;
-            if (hotn[j]) hv += occ;
-            atomicAdd(gb + r * Cp + gcol[j], hotn[j] ? 0.0f : occ);
-          }
-          if (P.hot >= 0) {
-            hv = wave_sum63(hv);
-            if (lane == 63) atomicAdd(gb + r * Cp + P.hot, hv);
-          }
+  for (int j = 0; j < NPL; ++j) {
+    b[j] = g.accept[j] ? 0.0f : NEGF;
+    ahi[j] = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
+    acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+  }
+  double Ahi = P.aoff[1 + T / RN];
+  double bz = -z2;  // (sum of beta's shifts) - score
+
+  // ---- staging: chunk c covers virtual rows [cR, cR + rows), i.e. t from T-1-cR down; HBM rows t_lo ..
+  Stage<8> se;   // emissions
+  Stage<16> sa;  // alpha rows
+  float lse_v[8];
+  double off_v = 0.0;
+  auto rows_of = [&](int c) { return c < nchunks ? min(R, T - c * R) : 0; };
+  auto tlo_of = [&](int c) { return T - c * R - rows_of(c); };
+  auto issue = [&](int c) {
+    const int rows = rows_of(c), tlo = tlo_of(c);
+    se.issue(P.em + int64_t(tlo) * C, rows * C, vec, tid);
+    sa.issue(P.alpha + int64_t(tlo) * NS, rows * NS, true, tid);
+    if (tid < rows) off_v = P.aoff[1 + (tlo + tid) / RN];
+    if (soft && want_em)
+      se.each(rows * C, C, vec, tid, [&](int i, int, int r, int, gtnx_f4) { lse_v[i] = P.rowlse[tlo + r]; });
+  };
+  // chunk row r (HBM order, ascending t) is virtual row vhi - r
+  auto land = [&](int c) {
+    const int rows = rows_of(c);
+    if (rows <= 0) return;
+    const int vhi = c * R + rows - 1;
+    const int eb = vhi % NER, gb = vhi % NGR;
+    se.each(rows * C, C, vec, tid, [&](int i, int, int r, int col, gtnx_f4 q) {
+      int s = eb - r;
+      if (s < 0) s += NER;
+      float* d = ering + s * CS + col;
+      const gtnx_f4 q2 = {em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
+      if (vec) *reinterpret_cast<gtnx_f4*>(d) = q2;
+      else d[0] = q2.x;
+      if (want_em) {  // the gradient row starts as the normaliser's term dn * softmax(em[t]) (or zero)
+        int sg = gb - r;
+        if (sg < 0) sg += NGR;
+        float* dg = gring + sg * CS + col;
+        gtnx_f4 p = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (soft) {
+          const float lv = lse_v[i];
+          p = gtnx_f4{dn * ex2(q2.x - lv), dn * ex2(q2.y - lv), dn * ex2(q2.z - lv), dn * ex2(q2.w - lv)};
         }
-        float q[NPL];
+        if (vec) *reinterpret_cast<gtnx_f4*>(dg) = p;
+        else dg[0] = p.x;
+      }
+    });
+    sa.each(rows * NS, NS, true, tid, [&](int, int, int r, int col, gtnx_f4 q) {
+      int s = eb - r;
+      if (s < 0) s += NER;
+      *reinterpret_cast<gtnx_f4*>(aring + s * NSmax + col) = q;
+    });
+    if (tid < rows) {
+      int s = eb - tid;
+      if (s < 0) s += NER;
+      obuf[s] = off_v;
+    }
+  };
+  // finished gradient rows of chunk c: LDS -> HBM
+  auto drain = [&](int c) {
+    const int rows = rows_of(c);
+    if (!want_em || rows <= 0) return;
+    const int vhi = c * R + rows - 1, gb = vhi % NGR, cnt = rows * C;
+    GTNX_G float* dst = P.grad_em + int64_t(tlo_of(c)) * C;
+    const float invC = 1.0f / float(C);
+    if (vec) {
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) q[j] = e[j] + b[j];
-        const float n1 = wave_shl1(q[0], NEGF);
-        const float n2 = NPL >= 2 ? wave_shl1(q[NPL >= 2 ? 1 : 0], NEGF) : wave_shl1(n1, NEGF);
-        const float dl = GRADG ? float(Alo + bz) : 0.0f;
-        float nb[NPL];
+      for (int i = 0; i < 2; ++i) {
+        const int e = 4 * (i * BW + tid);
+        if (e < cnt) {
+          const int r = row_of(e, C, invC);
+          int sg = gb - r;
+          if (sg < 0) sg += NGR;
+          *reinterpret_cast<GTNX_G gtnx_f4*>(dst + e) = *reinterpret_cast<const gtnx_f4*>(gring + sg * CS + (e - r * C));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = i * BW + tid;
+        if (e < cnt) {
+          const int r = row_of(e, C, invC);
+          int sg = gb - r;
+          if (sg < 0) sg += NGR;
+          dst[e] = gring[sg * CS + (e - r * C)];
+        }
+      }
+    }
+  };
+
+  // ---- prologue
+  issue(0);
+  land(0);
+  issue(1);
+  if (NPL == 1) {
+    // q of row v is published per tick; nothing to publish for the initial beta
+  }
+  {
+    float mx = b[0];
+#pragma unroll
+    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, b[j]);
+    mx = wave_max(mx);
+    if (l == 0) mxr[0 * 4 + w] = mx;
+  }
+  lds_barrier();
+
+  float e[NPL], alo[NPL];
+  double Alo = 0.0;
+  int ps = 0, gs = 0;  // ring slots (emission / alpha, gradient) of the next row: rows come in order from 0
+  auto prefetch = [&](int v) {  // inputs of the tick that consumes virtual row v
+    if (v >= 0 && v < T) {
+      const int s = ps;
+      ps = ps + 1 == NER ? 0 : ps + 1;
+      const float* er = ering + s * CS;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        e[j] = er[g.lab[j]];
+        alo[j] = aring[s * NSmax + min(m0 + j, NSmax - 1)];
+      }
+      Alo = obuf[s];
+    }
+  };
+  prefetch(0 - lag);
+
+  const int nticks = T + LAGW;
+  int cd = 0;  // next chunk to drain
+  for (int tau = 0; tau < nticks; ++tau) {
+    if (cd < nchunks && tau == (cd + 1) * R + LAGW) {  // the last wave left chunk cd a tick ago
+      drain(cd);
+      ++cd;
+    }
+    if ((tau & Rm) == 0) {
+      const int c = tau >> lgR;
+      land(c + 1);
+      issue(c + 2);
+    }
+    const int v = tau - lag;
+    if (v >= 0 && v < T && !dead) {
+      float n1b = NEGF, n2b = NEGF;
+      if (w < 3) {  // q of the next wave's first nodes for this row, published a tick ago
+        const float* bp = bnd + ((w + 1) * 4 + (v & 3)) * 2;
+        n1b = bp[0];
+        n2b = bp[1];
+      }
+      float q[NPL];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) q[j] = e[j] + b[j];
+      if (NPL == 1) {
+        if (l < 2) bnd[(w * 4 + (v & 3)) * 2 + l] = q[0];
+      } else if (l == 0) {
+        bnd[(w * 4 + (v & 3)) * 2 + 0] = q[0];
+        bnd[(w * 4 + (v & 3)) * 2 + 1] = q[NPL - 1];
+      }
+      // node posteriors at time t+1 -> gradient row t
+      if (want_em) {
+        const float dh = float(Ahi + bz);
+        float* grow = gring + gs * CS;
+        float hv = 0.0f;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-          const float s1 = j + 1 < NPL ? q[j + 1 < NPL ? j + 1 : 0] : n1;
-          const float s2 = j + 2 < NPL ? q[j + 2 < NPL ? j + 2 : 0] : (j + 2 == NPL ? n1 : n2);
-          float y0, y1, y2;
-          if (UNIT) {
-            y0 = q[j];
-            y1 = s1;
-            y2 = s2 + g.wo[2][j];
-          } else {
-            y0 = q[j] + g.wo[0][j];
-            y1 = s1 + g.wo[1][j];
-            y2 = s2 + g.wo[2][j];
-          }
-          if (GRADG) {
-            // the exponentials of the log-sum-exp are the arc posteriors up to one factor per node
-            const float mx = fmaxf(fmaxf(y0, y1), y2);
-            const float e0 = ex2(y0 - mx), e1 = ex2(y1 - mx), e2 = ex2(y2 - mx);
-            nb[j] = mx + lg2(e0 + e1 + e2);
-            const float f = ex2(alo[j] + mx + dl);
-            acc[0][j] += e0 * f;
-            acc[1][j] += e1 * f;
-            acc[2][j] += e2 * f;
-          } else {
-            nb[j] = lse3(y0, y1, y2);
-          }
+          const float occ = ex2(ahi[j] + b[j] + dh) * ds;
+          const bool direct = g.has_in[j] && !hotn[j];
+          if (hotn[j]) hv += occ;
+          lds_add(direct ? grow + g.lab[j] : scratch + tid, occ);
         }
-        if (t % RN == 0) {
-          float mx = nb[0];
-#pragma unroll
-          for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, nb[j]);
-          mx = wave_max(mx);
-          if (mx > DEADF) {
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) nb[j] = fmaxf(nb[j] - mx, NEGF);
-            bz += double(mx);
-          }
+        if (P.hot >= 0) {
+          hv = wave_sum63(hv);
+          lds_add(l == 63 ? grow + P.hot : scratch + tid, hv);
         }
+      }
+      const float n1 = wave_shl1(q[0], n1b);
+      const float n2 = NPL == 2 ? wave_shl1(q[NPL - 1], n2b) : wave_shl1(n1, n2b);
+      const float dl = GRADG ? float(Alo + bz) : 0.0f;
+      float nb[NPL];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const float s1 = j + 1 < NPL ? q[NPL - 1] : n1;
+        const float s2 = j + 1 < NPL ? n1 : (NPL == 2 ? n2 : n2);
+        float y0, y1, y2;
+        if (UNIT) {
+          y0 = q[j];
+          y1 = s1;
+          y2 = s2 + g.wo[2][j];
+        } else {
+          y0 = q[j] + g.wo[0][j];
+          y1 = s1 + g.wo[1][j];
+          y2 = s2 + g.wo[2][j];
+        }
+        if (GRADG) {
+          // the exponentials of the log-sum-exp are the arc posteriors up to one factor per node
+          const float mx = fmaxf(fmaxf(y0, y1), y2);
+          const float e0 = ex2(y0 - mx), e1 = ex2(y1 - mx), e2 = ex2(y2 - mx);
+          nb[j] = mx + lg2(e0 + e1 + e2);
+          const float f = ex2(alo[j] + mx + dl);
+          acc[0][j] += e0 * f;
+          acc[1][j] += e1 * f;
+          acc[2][j] += e2 * f;
+        } else {
+          nb[j] = lse3(y0, y1, y2);
+        }
+      }
+      const int row = v + 1;
+      if (row % RN == 0) {
+        const float sft = shift_of(mxr, row);
+        float mx = NEGF;
 #pragma unroll
         for (int j = 0; j < NPL; ++j) {
-          b[j] = nb[j];
-          ahi[j] = alo[j];
+          nb[j] -= sft;
+          mx = fmaxf(mx, nb[j]);
         }
-        Ahi = Alo;
+        bz += double(sft);
+        mx = wave_max(mx);
+        if (l == 0) mxr[((row / RN) & 7) * 4 + w] = mx;
       }
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        b[j] = nb[j];
+        ahi[j] = alo[j];
+      }
+      Ahi = Alo;
+      gs = gs + 1 == NGR ? 0 : gs + 1;
     }
+    prefetch(v + 1);
     lds_barrier();
-    if (GRADG && P.grad_fixed && !dead) {
+  }
+  for (; cd < nchunks; ++cd) drain(cd);
+  if (GRADG && P.grad_fixed && !dead) {
 #pragma unroll
-      for (int j = 0; j < NPL; ++j)
+    for (int j = 0; j < NPL; ++j)
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (g.ao[k][j] >= 0) P.grad_fixed[g.ao[k][j]] = acc[k][j] * ds;
-    }
-  } else {
-    // ------------------------------------------------------------------ stagers
-    const int sl = threadIdx.x - 64;
-    const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0 &&
-                                                        (!want_em || (reinterpret_cast<uintptr_t>(P.grad_em) & 15) == 0)));
-    const float dn = P.delta_norm ? P.delta_norm[0] : 0.0f;
-    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
-    Stage se, sa;
-    float lse_v[SL1];  // row log-sum-exp of the element(s) of each slot (softmax term)
-    double off_v = 0.0;
-    auto rows_of = [&](int i) { return i < nchunks ? min(R, T - (nchunks - 1 - i) * R) : 0; };
-    auto t0_of = [&](int i) { return (nchunks - 1 - i) * R; };
-    // element e of a chunk -> (row, column)
-    auto row_of = [&](int e) {
-      int r = int(float(e) * (1.0f / float(C)));
-      if (r * C > e) --r;
-      if ((r + 1) * C <= e) ++r;
-      return r;
-    };
-    auto issue = [&](int i) {
-      const int rows = rows_of(i), t0 = t0_of(i);
-      stage_issue(se, P.em + int64_t(t0) * C, rows * C, vec, sl);
-      stage_issue(sa, P.alpha + int64_t(t0) * NS, rows * NS, true, sl);
-      if (sl < rows) off_v = P.aoff[t0 + sl];
-      if (soft && want_em) {
-        const int ns = vec ? SL4 : SL1;
-#pragma unroll
-        for (int s = 0; s < SL1; ++s) {
-          if (s < ns) {
-            const int e = vec ? 4 * (s * NSTG + sl) : s * NSTG + sl;
-            lse_v[s] = e < rows * C ? P.rowlse[t0 + row_of(e)] : 0.0f;
-          }
-        }
-      }
-    };
-    // gradient rows of chunk i start as the normaliser's term dn * softmax(em[t]) (or zero)
-    auto prefill = [&](int i) {
-      if (!want_em) return;
-      const int rows = rows_of(i), cnt = rows * C;
-      float* gb = grow + (i & 1) * RG;
-      if (vec) {
-#pragma unroll
-        for (int s = 0; s < SL4; ++s) {
-          const int e = 4 * (s * NSTG + sl);
-          if (e < cnt) {
-            const int r = row_of(e), c = e - r * C;
-            gtnx_f4 q = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (soft) {
-              const float l = lse_v[s];
-              q = gtnx_f4{dn * ex2(em2(se.v[4 * s]) - l), dn * ex2(em2(se.v[4 * s + 1]) - l),
-                          dn * ex2(em2(se.v[4 * s + 2]) - l), dn * ex2(em2(se.v[4 * s + 3]) - l)};
-            }
-            *reinterpret_cast<gtnx_f4*>(gb + r * Cp + c) = q;
-          }
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < SL1; ++s) {
-          const int e = s * NSTG + sl;
-          if (e < cnt) {
-            const int r = row_of(e), c = e - r * C;
-            gb[r * Cp + c] = soft ? dn * ex2(em2(se.v[s]) - lse_v[s]) : 0.0f;
-          }
-        }
-      }
-    };
-    // finished gradient rows of chunk i: LDS -> HBM, same element -> lane map as prefill
-    auto drain = [&](int i) {
-      if (!want_em) return;
-      const int rows = rows_of(i), cnt = rows * C;
-      const float* gb = grow + (i & 1) * RG;
-      GTNX_G float* dst = P.grad_em + int64_t(t0_of(i)) * C;
-      if (vec) {
-#pragma unroll
-        for (int s = 0; s < SL4; ++s) {
-          const int e = 4 * (s * NSTG + sl);
-          if (e < cnt) {
-            const int r = row_of(e), c = e - r * C;
-            *reinterpret_cast<GTNX_G gtnx_f4*>(dst + e) = *reinterpret_cast<const gtnx_f4*>(gb + r * Cp + c);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < SL1; ++s) {
-          const int e = s * NSTG + sl;
-          if (e < cnt) {
-            const int r = row_of(e), c = e - r * C;
-            dst[e] = gb[r * Cp + c];
-          }
-        }
-      }
-    };
-    auto land = [&](int i) {
-      const int rows = rows_of(i);
-      stage_land<true>(se, ebuf + (i & 1) * RC, rows * C, vec, sl);
-      stage_land<false>(sa, abuf + (i & 1) * RA, rows * NS, true, sl);
-      if (sl < rows) obuf[(i & 1) * R + sl] = off_v;
-      prefill(i);
-    };
-    issue(0);
-    land(0);
-    issue(1);
-    for (int i = 0; i < nchunks; ++i) {
-      lds_barrier();  // chunk i is the sweeper's; it is done with chunk i-1
-      if (i >= 1) drain(i - 1);
-      land(i + 1);  // into the buffers drain(i-1) just emptied, by the same lanes
-      issue(i + 2);
-    }
-    lds_barrier();
-    if (nchunks >= 1) drain(nchunks - 1);
+      for (int k = 0; k < 3; ++k)
+        if (g.ao[k][j] >= 0) P.grad_fixed[g.ao[k][j]] = acc[k][j] * ds;
   }
 }
 
-size_t band_lds_bytes(int C, int R, int NS, bool backward) {
-  size_t fl = 2 * size_t(R) * C;
-  if (backward) fl += 2 * size_t(R) * (C + 64) + 2 * size_t(R) * NS + 4 * size_t(R);
-  return 4 * fl + 64;
-}
-
 template <int NPL>
-void launch_fwd_npl(const BandPair* d, int n, int R, size_t lds, bool unit, hipStream_t st) {
-  if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true>), dim3(n), dim3(BW), lds, st, d, R);
-  else hipLaunchKernelGGL((band_forward_kernel<NPL, false>), dim3(n), dim3(BW), lds, st, d, R);
+void launch_fwd_npl(const BandPair* d, int n, int R, int ns, size_t lds, bool unit, hipStream_t st) {
+  if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true>), dim3(n), dim3(BW), lds, st, d, R, ns);
+  else hipLaunchKernelGGL((band_forward_kernel<NPL, false>), dim3(n), dim3(BW), lds, st, d, R, ns);
 }
 template <int NPL>
-void launch_bwd_npl(const BandPair* d, int n, int R, size_t lds, bool unit, bool gradg, hipStream_t st) {
+void launch_bwd_npl(const BandPair* d, int n, int R, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
   if (unit) {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true>), dim3(n), dim3(BW), lds, st, d, R);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false>), dim3(n), dim3(BW), lds, st, d, R);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true>), dim3(n), dim3(BW), lds, st, d, R, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false>), dim3(n), dim3(BW), lds, st, d, R, ns);
   } else {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true>), dim3(n), dim3(BW), lds, st, d, R);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false>), dim3(n), dim3(BW), lds, st, d, R);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true>), dim3(n), dim3(BW), lds, st, d, R, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false>), dim3(n), dim3(BW), lds, st, d, R, ns);
   }
 }
 
@@ -649,52 +800,44 @@ void band_attrs() {
   big_lds(band_backward_kernel<NPL, true, true>);     \
   big_lds(band_backward_kernel<NPL, true, false>);    \
   big_lds(band_backward_kernel<NPL, false, true>);    \
-  big_lds(band_backward_kernel<NPL, false, false>);
+  big_lds(band_backward_kernel<NPL, false, false>);   \
+  big_lds(band_forward_kernel<NPL, true>);            \
+  big_lds(band_forward_kernel<NPL, false>);
   GTNX_BAND_ATTR(1)
   GTNX_BAND_ATTR(2)
-  GTNX_BAND_ATTR(4)
-  GTNX_BAND_ATTR(8)
 #undef GTNX_BAND_ATTR
 }
 
 } // namespace
 
 int band_max_nodes() { return 512; }
-int band_max_labels() { return 4096; }
-int band_npl(int max_nodes) { return max_nodes <= 64 ? 1 : (max_nodes <= 128 ? 2 : (max_nodes <= 256 ? 4 : 8)); }
-int band_row_stride(int N, int npl) {
-  const int q = npl < 4 ? 4 : npl;
-  return (N + q - 1) / q * q;
-}
+int band_max_labels() { return 1024; }
+int band_npl(int max_nodes) { return max_nodes <= 256 ? 1 : 2; }
+int band_row_stride(int N, int) { return (N + 3) / 4 * 4; }
 int band_rows_per_chunk(int C, bool backward) {
-  const int cap = backward ? 2048 : 4096, top = backward ? 8 : 16;
-  return std::max(1, std::min(top, cap / std::max(C, 1)));
+  const int cap = backward ? 2048 : 4096;
+  for (int r = backward ? 8 : 16; r > 2; r /= 2)
+    if (r * C <= cap) return r;
+  return 2;
 }
 
-void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, bool unit, hipStream_t st) {
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, hipStream_t st) {
   if (n <= 0) return;
+  band_attrs();
   const int R = band_rows_per_chunk(C, false);
-  const size_t lds = band_lds_bytes(C, R, 0, false);
-  switch (npl) {
-    case 1: launch_fwd_npl<1>(d_pairs, n, R, lds, unit, st); break;
-    case 2: launch_fwd_npl<2>(d_pairs, n, R, lds, unit, st); break;
-    case 4: launch_fwd_npl<4>(d_pairs, n, R, lds, unit, st); break;
-    default: launch_fwd_npl<8>(d_pairs, n, R, lds, unit, st); break;
-  }
+  const size_t lds = 4 * size_t(band_lds(C, R, max_NS, false).total) + 64;
+  if (npl == 1) launch_fwd_npl<1>(d_pairs, n, R, max_NS, lds, unit, st);
+  else launch_fwd_npl<2>(d_pairs, n, R, max_NS, lds, unit, st);
 }
 
-// every pair of the launch shares C and the row stride NS
-void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int NS, bool unit, bool gradg, hipStream_t st) {
+// every pair of the launch shares C; max_NS: largest alpha row stride of the launch
+void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, hipStream_t st) {
   if (n <= 0) return;
   band_attrs();
   const int R = band_rows_per_chunk(C, true);
-  const size_t lds = band_lds_bytes(C, R, NS, true);
-  switch (npl) {
-    case 1: launch_bwd_npl<1>(d_pairs, n, R, lds, unit, gradg, st); break;
-    case 2: launch_bwd_npl<2>(d_pairs, n, R, lds, unit, gradg, st); break;
-    case 4: launch_bwd_npl<4>(d_pairs, n, R, lds, unit, gradg, st); break;
-    default: launch_bwd_npl<8>(d_pairs, n, R, lds, unit, gradg, st); break;
-  }
+  const size_t lds = 4 * size_t(band_lds(C, R, max_NS, true).total) + 64;
+  if (npl == 1) launch_bwd_npl<1>(d_pairs, n, R, max_NS, lds, unit, gradg, st);
+  else launch_bwd_npl<2>(d_pairs, n, R, max_NS, lds, unit, gradg, st);
 }
 
 } // namespace gtnx

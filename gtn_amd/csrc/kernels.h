@@ -379,7 +379,7 @@ struct BandPair {
   const GTNX_G float* w;           // G's weights, arc-id order; null: all zero
   const GTNX_G float* em;          // [T][C] chain weights
   GTNX_G float* alpha;             // [T+1][NS] log2 units, shifted rows
-  GTNX_G double* aoff;             // [T+2] shift of every alpha row; [T+1]: the score in log2 units
+  GTNX_G double* aoff;             // [0]: the score in log2 units; [1 + r / 4]: shift of alpha row r
   GTNX_G float* score;             // [1]
   GTNX_G float* norm;              // [1] forwardScore of the chain itself, or null
   GTNX_G float* rowlse;            // [T] log2-sum-exp2 of every emission row, or null
@@ -393,10 +393,10 @@ struct BandPair {
 };
 int band_max_nodes();
 int band_max_labels();
-int band_npl(int max_nodes);               // nodes per sweeper lane: 1, 2, 4 or 8
+int band_npl(int max_nodes);               // nodes per lane: 1 or 2
 int band_row_stride(int N, int npl);       // NS
 // all pairs of one launch share C and npl; unit: self-loop + previous-node arc at every node, all weights 0
-void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, bool unit, hipStream_t st);
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, hipStream_t st);
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg,
                           hipStream_t st);
 // dense regime

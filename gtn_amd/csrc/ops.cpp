@@ -2071,7 +2071,7 @@ std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
 // acceptors: a single wave carries the whole recursion, the other waves stage.
 bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out = nullptr) {
   const Structure& cs = *lp.chain.s;
-  if (cs.kind != KIND_LINEAR || cs.C < 1 || cs.C > band_max_labels() || cs.M < 0) return false;
+  if (cs.kind != KIND_LINEAR || cs.C < 1 || cs.C > band_max_labels() || cs.M < 0 || cs.M > (1 << 20)) return false;
   std::shared_ptr<BandInfo> b = band_info(*lp.fixed.s, lp.chain_side == 1);
   if (!b->ok || b->max_label >= cs.C) return false;
   if (out) *out = b;
@@ -2110,7 +2110,7 @@ struct BandSdOp : OpRecord {
       if (backward)
         launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, rt.stream());
       else
-        launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, k.unit != 0, rt.stream());
+        launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, rt.stream());
       i0 = i1;
     }
   }

@@ -287,7 +287,8 @@ def _ctc_pair_check(gtn, ems_np, targets, chain_first=False, band=True):
         gtn.backward(loss)
         got = gtn.items(loss)
     assert pm.used(), "the per-utterance sweep kernels did not run"
-    assert pm.used_band() == band
+    # band.hip takes alphabets up to 1024 labels; wider ones stay on lazy_pair.hip
+    assert pm.used_band() == (band and min(e.shape[1] for e in ems_np) <= 1024)
     for b in range(B):
         T, C = ems_np[b].shape
         want, wgrad = ctc_loss(ems_np[b], np.asarray(targets[b], np.int32))

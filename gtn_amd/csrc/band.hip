@@ -10,26 +10,33 @@
 // emission is read once per sweep and every gradient row is written exactly once.
 //
 // One workgroup of 4 waves per utterance; wave w owns nodes [64w NPL, 64(w+1) NPL), NPL = 1
-// or 2 nodes per lane.  The recursion over time is a SKEWED PIPELINE: a node needs values of
-// lower-numbered nodes only (higher-numbered in the backward sweep), so wave w runs one time
-// step behind wave w-1 and finds the two boundary values it needs in LDS, written a whole
-// step earlier.  Inside a wave neighbours move by DPP wave shifts.  One LDS-only barrier per
-// tick keeps the waves in step; nothing on the critical path waits for LDS or HBM latency:
-//   * emission rows live in an LDS ring, landed a chunk ahead from 16-byte loads issued two
-//     chunks ahead (every wave stages its share; there are no helper waves);
+// or 2 nodes per lane.  The recursion over time is a BLOCK-SKEWED PIPELINE: a node needs
+// values of lower-numbered nodes only (higher-numbered in the backward sweep), so wave w runs
+// one block of K time steps behind wave w-1 and finds the boundary values of a whole block in
+// LDS, written a tick earlier.  Inside a tick a wave runs its K steps with no synchronisation
+// at all (neighbours move by DPP wave shifts; the block's emission gathers, boundary values
+// and alpha rows are fetched from LDS up front); one LDS-only barrier per tick keeps the
+// waves in step.  Nothing on the critical path waits for LDS or HBM latency:
+//   * emission rows live in an LDS ring of 5 blocks, landed a tick ahead from 16-byte loads
+//     issued 8 rows ahead (every wave stages its share; there are no helper waves);
 //   * scores are in log2 units (bare v_exp_f32 / v_log_f32), "minus infinity" is -1e30 so no
-//     step needs an inf / NaN guard, and every RN rows the row is shifted by the maximum of
-//     the row RN rows back (the shifts are summed in fp64): magnitudes stay O(10) and float32
-//     keeps ~1e-5 relative accuracy on every posterior for any T;
+//     step needs an inf / NaN guard, and every RN rows each wave shifts ITS nodes by their
+//     maximum (per-wave shifts summed in fp64; boundary values are re-based when they cross
+//     waves): magnitudes stay O(10) and float32 keeps ~1e-6 relative accuracy on every
+//     posterior for any T;
 //   * the backward sweep adds node posteriors into an LDS ring of gradient rows (pre-filled
 //     with the normaliser's softmax term) which is drained with coalesced stores once the
-//     last wave is through with a chunk; G's arc gradients are register accumulators.
+//     last wave is through with a block; G's arc gradients are register accumulators.
 // HBM traffic per utterance: forward 4TC + 4(T+1)NS, backward 8TC + 4(T+1)NS (+ G).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 
 #include "kernels.h"
+
+#ifdef GTNX_BAND_TIMING
+__device__ long long g_band_timing[64];
+#endif
 
 namespace gtnx {
 namespace {
@@ -39,8 +46,36 @@ constexpr float DEADF = -1.0e29f;  // anything below is "no path"
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr double LN2 = 0.693147180559945309417;
 constexpr int BW = 256;  // lanes per workgroup (4 waves)
-constexpr int RN = 4;    // rows between shifts of the running row; also the lag of the shift
-constexpr int LAGW = 3;  // ticks between the leading and the last wave
+constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
+constexpr int NBG = 6;   // blocks in the gradient ring: one pre-filled, four in use, one draining
+
+#ifdef GTNX_BAND_TIMING
+// diagnostic build (tools/ubench/band_bench.hip): cycles per phase of a tick, wave 0 of workgroup 0
+#define GTNX_TM(slot)                 \
+  do {                                \
+    const long long now_ = clock64(); \
+    tm_acc[slot] += now_ - tm_last;   \
+    tm_last = now_;                   \
+  } while (0)
+#define GTNX_TM_INIT(base)                       \
+  const int tm_base = base;                      \
+  long long tm_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  long long tm_n = 0;                            \
+  long long tm_last = clock64()
+#define GTNX_TM_TICK() tm_n += 1
+#define GTNX_TM_DUMP()                                                      \
+  do {                                                                      \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                       \
+      for (int i_ = 0; i_ < 7; ++i_) g_band_timing[tm_base + (threadIdx.x >> 6) * 7 + i_] += tm_acc[i_]; \
+      if (threadIdx.x == 0) g_band_timing[tm_base + 31] += tm_n;            \
+    }                                                                       \
+  } while (0)
+#else
+#define GTNX_TM(slot) do { } while (0)
+#define GTNX_TM_INIT(base) do { } while (0)
+#define GTNX_TM_TICK() do { } while (0)
+#define GTNX_TM_DUMP() do { } while (0)
+#endif
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -88,12 +123,6 @@ __device__ __forceinline__ float row16_sum(float x) {
   asm volatile(GTNX_ROR4("v_add_f32_dpp") : "+v"(x));
   return x;
 }
-// LDS float add without return value (the compiler's atomic optimiser would wrap a plain
-// atomicAdd of a uniform address in a lane loop)
-__device__ __forceinline__ void lds_add(float* p, float v) {
-  asm volatile("ds_add_f32 %0, %1" ::"v"(static_cast<unsigned>(reinterpret_cast<uintptr_t>(p))), "v"(v) : "memory");
-}
-
 // log2(2^x0 + 2^x1 + 2^x2): the largest term is exactly 1, so two v_exp_f32 and one v_log_f32
 __device__ __forceinline__ float lse3(float x0, float x1, float x2) {
   const float mx = fmaxf(fmaxf(x0, x1), x2);
@@ -217,42 +246,30 @@ struct Stage {
   }
 };
 
-// shift applied to row `row` (a multiple of RN, >= RN): the maximum of row - RN over all waves
-__device__ __forceinline__ float shift_of(const float* mxr, int row) {
-  const float* p = mxr + (((row - RN) / RN) & 7) * 4;
-  const float s = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[2], p[3]));
-  return s > DEADF ? s : 0.0f;
-}
-
 // LDS layout shared by host (size) and device (carving); all counts in floats
 struct BandLds {
-  int CS;               // ring row stride of emission / gradient rows
-  int NER, NAR, NGR;    // ring depths: emission rows, alpha rows, gradient rows
-  int o_ering, o_aring, o_obuf, o_gring, o_scratch, o_misc, total;
+  int CS;  // ring row stride of emission / gradient rows
+  int o_ering, o_aring, o_gring, o_scratch, o_misc, total;
 };
-__host__ __device__ inline BandLds band_lds(int C, int R, int NSmax, bool backward) {
+__host__ __device__ inline BandLds band_lds(int C, int K, int NSmax, bool backward) {
   BandLds L;
   L.CS = C + 4;
-  L.NER = 2 * R + LAGW + 1;
-  L.NAR = backward ? L.NER : 0;
-  L.NGR = backward ? (R >= 4 ? 3 * R : 4 * R) : 0;
   int o = 0;
-  L.o_ering = o;
-  o += L.NER * L.CS;
+  L.o_ering = o;  // the backward sweep keeps a block's emissions until its gradient rows are out
+  o += (backward ? NBG : NBE) * K * L.CS;
   o = (o + 3) & ~3;
   L.o_aring = o;
-  o += L.NAR * NSmax;
+  o += backward ? NBE * K * NSmax : 0;
   o = (o + 3) & ~3;
-  L.o_obuf = o;  // doubles
-  o += 2 * L.NAR;
+  L.o_gring = o;  // node posteriors
+  o += backward ? NBG * K * NSmax : 0;
+  L.o_scratch = o;  // label runs: start[C], end[C], sorted nodes[<= 512]
+  o += backward ? 2 * C + 512 : 0;
   o = (o + 3) & ~3;
-  L.o_gring = o;
-  o += L.NGR * L.CS;
-  L.o_scratch = o;
-  o += backward ? BW : 0;
-  o = (o + 3) & ~3;
-  L.o_misc = o;  // red[16] doubles, bnd[4][4][2], mxr[8][4], fin[8], lse pairs [2][16][8][2]
-  o += 32 + 32 + 32 + 8 + 512;
+  // offr[4][16] doubles, red[16] doubles, find[4] doubles | bndr[4][4K][2], then forward: fin[8],
+  // lsep[2][16][8][2]; backward: lser[NBG][K]
+  L.o_misc = o;
+  o += 128 + 32 + 8 + 32 * K + 8 + 512;
   L.total = o;
   return L;
 }
@@ -260,25 +277,28 @@ __host__ __device__ inline BandLds band_lds(int C, int R, int NSmax, bool backwa
 // ==========================================================================================
 // forward: alpha[t+1][m] = em[t][lab m] + log sum_k exp(alpha[t][m-k] + w_k(m))
 // ==========================================================================================
-template <int NPL, bool UNIT>
-__global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __restrict__ pairs, int R, int NSmax) {
+template <int NPL, bool UNIT, int K>
+__global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
+  constexpr int RNk = K >= 4 ? 4 : K;  // rows between shifts of a wave's running row
+  constexpr int NP = K / RNk;          // shift periods per block
+  constexpr int D = 8 / K;             // ticks a staged chunk is in flight (8 rows ahead)
   const BandPair P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
-  const BandLds L = band_lds(C, R, NSmax, false);
+  const BandLds L = band_lds(C, K, NSmax, false);
   float* ering = lds + L.o_ering;
-  double* red = reinterpret_cast<double*>(lds + L.o_misc);  // [16]
-  float* bnd = lds + L.o_misc + 32;    // [4 waves][4 slots][2]
-  float* mxr = bnd + 32;               // [8 slots][4 waves]
-  float* fin = mxr + 32;               // [4 waves][2]
-  float* lsep = fin + 8;               // [2 chunk parities][16 rows][8 groups][2]
-  const int CS = L.CS, NER = L.NER;
-  const int Rm = R - 1, lgR = 31 - __builtin_clz(R);
+  double* offr = reinterpret_cast<double*>(lds + L.o_misc);  // [4 waves][16 periods]
+  double* red = offr + 64;                                   // [16]
+  double* find = red + 16;                                   // [4]
+  float* bndr = lds + L.o_misc + 168;                        // [4 waves][4K rows][2]
+  float* fin = bndr + 32 * K;                                // [4 waves][2]
+  float* lsep = fin + 8;                                     // [2 chunk parities][16 rows][8 groups][2]
+  const int CS = L.CS;
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l = tid & 63;
   const int m0 = tid * NPL;
-  const int nchunks = (T + R - 1) / R;
+  const int nblocks = (T + K - 1) / K;
   const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0));
   const bool want_lse = P.norm != nullptr || P.rowlse != nullptr;
 
@@ -288,39 +308,44 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
   float a[NPL];
 #pragma unroll
   for (int j = 0; j < NPL; ++j) a[j] = g.start[j] ? 0.0f : NEGF;
-  double off = 0.0;
+  double off = 0.0;  // this wave's shift: true alpha = a + off
   GTNX_G float* arow = P.alpha + m0;
   if (writer) {
 #pragma unroll
     for (int j = 0; j < NPL; ++j) arow[j] = a[j];
   }
-  if (tid == 0) P.aoff[1] = 0.0;
+  if (l == 0) {
+    P.aoff[1 + w] = 0.0;
+    offr[w * 16] = 0.0;
+  }
+  if (NPL == 1) {
+    if (l >= 62) bndr[(w * 4 * K) * 2 + (63 - l)] = a[0];
+  } else if (l == 63) {
+    bndr[(w * 4 * K) * 2 + 0] = a[NPL - 1];
+    bndr[(w * 4 * K) * 2 + 1] = a[0];
+  }
 
-  // ---- staging of the emission ring
-  Stage<16> st;
-  auto rows_of = [&](int c) { return c < nchunks ? min(R, T - c * R) : 0; };
-  auto issue = [&](int c) { st.issue(P.em + int64_t(c) * R * C, rows_of(c) * C, vec, tid); };
-  auto land = [&](int c) {
-    const int base = (c * R) % NER;
-    st.each(rows_of(c) * C, C, vec, tid, [&](int, int, int r, int col, gtnx_f4 q) {
-      int s = base + r;
-      if (s >= NER) s -= NER;
-      float* d = ering + s * CS + col;
+  // ---- staging of the emission ring: chunk c = rows [cK, cK + K) = block c
+  Stage<8> st[D];
+  auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+  auto issue = [&](Stage<8>& s, int c) { s.issue(P.em + int64_t(c) * K * C, rows_of(c) * C, vec, tid); };
+  auto land = [&](const Stage<8>& s, int c) {
+    float* base = ering + (c % NBE) * K * CS;
+    s.each(rows_of(c) * C, C, vec, tid, [&](int, int, int r, int col, gtnx_f4 q) {
+      float* d = base + r * CS + col;
       if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
       else d[0] = em2(q.x);
     });
   };
-  // ---- row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / R lanes per row, pairs
-  // (max, sum) per 16-lane group in phase A, merged per row by one lane in phase B
-  const int LPR = BW / R, G16 = LPR / 16;
-  const int EPL = (C + LPR - 1) / LPR;  // <= 16
+  // ---- row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / K lanes per row, pairs
+  // (max, sum) per 16-lane group in phase A, merged per row by one lane in phase B (a tick later)
+  constexpr int LPR = BW / K, G16 = LPR / 16;
+  const int EPL = (C + LPR - 1) / LPR;  // <= 16: K * C <= 2048 ... 4096
   double normacc = 0.0;
   auto lse_a = [&](int c) {
     const int rows = rows_of(c), rr = tid / LPR, sub = tid - rr * LPR;
     if (rows <= 0) return;
-    int s = (c * R) % NER + min(rr, rows - 1);
-    if (s >= NER) s -= NER;
-    const float* e = ering + s * CS + sub * EPL;
+    const float* e = ering + ((c % NBE) * K + min(rr, rows - 1)) * CS + sub * EPL;
     float x[16];
     float m = NEGF;
 #pragma unroll
@@ -344,121 +369,148 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
     if (tid < rows) {
       const float* p = lsep + (c & 1) * 256 + tid * 16;
       float M = p[0];
+#pragma unroll
       for (int k = 1; k < G16; ++k) M = fmaxf(M, p[2 * k]);
       float S = 0.0f;
+#pragma unroll
       for (int k = 0; k < G16; ++k) S += p[2 * k + 1] * ex2(p[2 * k] - M);
       const float l2 = M + lg2(S);
-      if (P.rowlse) P.rowlse[c * R + tid] = l2;
+      if (P.rowlse) P.rowlse[c * K + tid] = l2;
       normacc += double(l2);
     }
   };
 
-  // ---- prologue
-  issue(0);
-  land(0);
-  issue(1);
-  if (NPL == 1) {
-    if (l >= 62) bnd[(w * 4 + 0) * 2 + (63 - l)] = a[0];
-  } else if (l == 63) {
-    bnd[(w * 4 + 0) * 2 + 0] = a[NPL - 1];
-    bnd[(w * 4 + 0) * 2 + 1] = a[0];
-  }
-  {
-    float mx = a[0];
+  // ---- prologue: chunk 0 landed, chunks 1 .. D requested
+  issue(st[0], 0);
+  land(st[0], 0);
 #pragma unroll
-    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, a[j]);
-    mx = wave_max(mx);
-    if (l == 0) mxr[0 * 4 + w] = mx;
-  }
+  for (int c = 1; c <= D; ++c) issue(st[c % D], c);
   lds_barrier();
 
-  float e[NPL], b1 = NEGF, b2 = NEGF;
-  int ps = 0;  // ring slot of the next row to prefetch (rows come in order from 0)
-  auto prefetch = [&](int t) {  // inputs of the tick that consumes emission row t
-    if (t >= 0 && t < T) {
-      const float* er = ering + ps * CS;
-      ps = ps + 1 == NER ? 0 : ps + 1;
+  const int nticks = nblocks + 3;
+  GTNX_TM_INIT(0);
+  float hist[K][NPL];  // this wave's rows of the last block, stored a tick late
+  int pend = 0;
+  auto flush = [&]() {
+    if (writer) {
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) e[j] = er[g.lab[j]];
-      if (w > 0) {
-        const float* bp = bnd + ((w - 1) * 4 + (t & 3)) * 2;
-        b1 = bp[0];
-        b2 = bp[1];
-      }
+      for (int i = 0; i < K; ++i)
+        if (i < pend) {
+          arow += NS;
+#pragma unroll
+          for (int j = 0; j < NPL; ++j) arow[j] = hist[i][j];
+        }
     }
+    pend = 0;
   };
-  prefetch(0 - w);
-
-  const int nticks = T + LAGW;
-  int pa = -1, pb = -1;  // chunk whose lse phase A / B runs this tick
-  for (int tau = 0; tau < nticks; ++tau) {
-    if ((tau & Rm) == 0) {  // chunk boundary of the leading wave: chunk tau / R + 1 lands, + 2 is requested
-      const int c = tau >> lgR;
-      land(c + 1);
-      issue(c + 2);
-    }
-    if (want_lse) {
-      if (pb >= 0) lse_b(pb);
-      pb = pa;
-      pa = -1;
-      if (tau == 0) pa = 0;
-      else if (((tau - 1) & Rm) == 0) pa = ((tau - 1) >> lgR) + 1;
-      if (pa >= nchunks) pa = -1;
-      if (pa >= 0) lse_a(pa);
-    }
-    const int t = tau - w;
-    if (t >= 0 && t < T) {
-      const float p1 = wave_shr1(a[NPL - 1], b1);
-      const float p2 = NPL == 2 ? wave_shr1(a[0], b2) : wave_shr1(p1, b2);
-      float nw[NPL];
+  for (int tau0 = 0; tau0 < nticks; tau0 += D) {
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const float s1 = j == 0 ? p1 : a[0];
-        const float s2 = j == 0 ? p2 : p1;
-        float x0, x1, x2;
-        if (UNIT) {  // self-loop and previous-node arc everywhere, weight 0
-          x0 = a[j];
-          x1 = s1;
-          x2 = s2 + g.wi[2][j];
-        } else {
-          x0 = a[j] + g.wi[0][j];
-          x1 = s1 + g.wi[1][j];
-          x2 = s2 + g.wi[2][j];
+    for (int d = 0; d < D; ++d) {
+      const int tau = tau0 + d;
+      if (tau >= nticks) break;
+      // chunk tau + 1 lands (its ring block was last read a tick ago), chunk tau + 1 + D is requested
+      GTNX_TM(0);
+      land(st[(d + 1) % D], tau + 1);
+      GTNX_TM(1);
+      issue(st[(d + 1) % D], tau + 1 + D);
+      GTNX_TM(2);
+      flush();
+      GTNX_TM(3);
+      if (want_lse) {
+        if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
+        if (tau < nblocks) lse_a(tau);
+      }
+      GTNX_TM(4);
+      const int beta = tau - w;
+      if (beta >= 0 && beta < nblocks) {
+        const int t0 = beta * K, rows = min(K, T - t0);
+        const float* eb = ering + (beta % NBE) * K * CS;
+        float ev[K][NPL], bv1[K], bv2[K];
+        double offp[NP + 1];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+          for (int j = 0; j < NPL; ++j) ev[i][j] = eb[i * CS + g.lab[j]];
+          bv1[i] = bv2[i] = NEGF;
+          if (w > 0) {  // alpha[t0 + i] of the two nodes below this wave, in the previous wave's frame
+            const float* bp = bndr + ((w - 1) * 4 * K + (beta & 3) * K + i) * 2;
+            bv1[i] = bp[0];
+            bv2[i] = bp[1];
+          }
         }
-        nw[j] = lse3(x0, x1, x2) + e[j];
-      }
-      const int row = t + 1;
-      if (row % RN == 0) {  // uniform
-        const float sft = shift_of(mxr, row);
-        float mx = NEGF;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-          nw[j] -= sft;
-          mx = fmaxf(mx, nw[j]);
+        for (int q = 0; q <= NP; ++q) offp[q] = w > 0 ? offr[(w - 1) * 16 + ((beta * NP + q) & 15)] : 0.0;
+        float dconv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          if (i < rows) {
+            if (i % RNk == 0 && w > 0) dconv = float(offp[i / RNk] - off);
+            const float b1 = bv1[i] + dconv, b2 = bv2[i] + dconv;
+            const float p1 = wave_shr1(a[NPL - 1], b1);
+            const float p2 = NPL == 2 ? wave_shr1(a[0], b2) : wave_shr1(p1, b2);
+            float nw[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+              const float s1 = j == 0 ? p1 : a[0];
+              const float s2 = j == 0 ? p2 : p1;
+              float x0, x1, x2;
+              if (UNIT) {  // self-loop and previous-node arc everywhere, weight 0
+                x0 = a[j];
+                x1 = s1;
+                x2 = s2 + g.wi[2][j];
+              } else {
+                x0 = a[j] + g.wi[0][j];
+                x1 = s1 + g.wi[1][j];
+                x2 = s2 + g.wi[2][j];
+              }
+              nw[j] = lse3(x0, x1, x2) + ev[i][j];
+            }
+            if ((i + 1) % RNk == 0) {  // shift this wave's row t0 + i + 1 by its maximum
+              float mx = nw[0];
+#pragma unroll
+              for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, nw[j]);
+              mx = wave_max(mx);
+              if (mx > DEADF) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) nw[j] -= mx;
+                off += double(mx);
+              } else if (w > 0) {
+                off = offp[(i + 1) / RNk];  // nothing alive here yet: follow the wave below
+              }
+              if (l == 0) {
+                const int p = (t0 + i + 1) / RNk;
+                offr[w * 16 + (p & 15)] = off;
+                P.aoff[1 + p * 4 + w] = off;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) hist[i][j] = a[j] = nw[j];
+          }
         }
-        off += double(sft);
-        mx = wave_max(mx);
-        if (l == 0) mxr[((row / RN) & 7) * 4 + w] = mx;
-        if (tid == 0) P.aoff[1 + row / RN] = off;
-      }
-      arow += NS;
+        pend = rows;  // stored at the start of the next tick: a wait for staged loads never covers fresh stores
+        // boundary values of rows t0 + 1 .. t0 + rows for the wave above
+        if (NPL == 1 ? l >= 62 : l == 63) {
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) a[j] = nw[j];
-      if (writer) {
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) arow[j] = a[j];
+          for (int i = 0; i < K; ++i)
+            if (i < rows) {
+              float* bp = bndr + (w * 4 * K + (((beta & 3) * K + i + 1) & (4 * K - 1))) * 2;
+              if (NPL == 1) {
+                bp[63 - l] = hist[i][0];
+              } else {
+                bp[0] = hist[i][NPL - 1];
+                bp[1] = hist[i][0];
+              }
+            }
+        }
       }
-      if (NPL == 1) {
-        if (l >= 62) bnd[(w * 4 + (row & 3)) * 2 + (63 - l)] = a[0];
-      } else if (l == 63) {
-        bnd[(w * 4 + (row & 3)) * 2 + 0] = a[NPL - 1];
-        bnd[(w * 4 + (row & 3)) * 2 + 1] = a[0];
-      }
+      GTNX_TM(5);
+      lds_barrier();
+      GTNX_TM(6);
+      GTNX_TM_TICK();
     }
-    prefetch(t + 1);
-    lds_barrier();
   }
-  if (want_lse && pb >= 0) lse_b(pb);
+  flush();
+  GTNX_TM_DUMP();
   // score = log sum over accept nodes of alpha[T]  (shortest.cpp:153-167)
   {
     float f = NEGF;
@@ -472,16 +524,20 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
     if (l == 0) {
       fin[2 * w] = mx;
       fin[2 * w + 1] = s;
+      find[w] = off;
     }
     if (tid < 16) red[tid] = normacc;
   }
   lds_barrier();
   if (tid == 0) {
-    const float M = fmaxf(fmaxf(fin[0], fin[2]), fmaxf(fin[4], fin[6]));
-    const bool dead = !(M > DEADF);
+    double M = double(NEGF);
+    for (int k = 0; k < 4; ++k)
+      if (fin[2 * k] > DEADF) M = fmax(M, find[k] + double(fin[2 * k]));
+    const bool dead = !(M > double(DEADF));
     float S = 0.0f;
-    for (int k = 0; k < 4; ++k) S += fin[2 * k + 1] * ex2(fin[2 * k] - M);
-    const double z2 = dead ? double(NEGF) : off + double(M) + double(lg2(S));
+    for (int k = 0; k < 4; ++k)
+      if (fin[2 * k] > DEADF) S += fin[2 * k + 1] * ex2(float(find[k] + double(fin[2 * k]) - M));
+    const double z2 = dead ? double(NEGF) : M + double(lg2(S));
     P.aoff[0] = z2;
     P.score[0] = dead ? -__builtin_inff() : float(z2 * LN2);
     if (P.norm) {
@@ -496,43 +552,47 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
 // backward: beta[t][n] = log sum_k exp(w_k + em[t][lab(n+k)] + beta[t+1][n+k]);
 //   d score / d em[t][l]   = sum over nodes m with label l of exp(alpha[t+1][m] + beta[t+1][m] - score)
 //   d score / d w(n->n+k)  = sum_t exp(alpha[t][n] + w + em[t][lab(n+k)] + beta[t+1][n+k] - score)
-// Virtual row v = T-1-t ascends with the ticks; wave 3 leads.
+// Virtual row v = T-1-t ascends with the ticks; wave 3 leads.  LDS float atomics retire about
+// one lane per 3 clocks per CU (tools/ubench/lat.hip), so nothing is scattered: every node
+// writes its posterior to an LDS ring with a plain store, and when the last wave has left a
+// block, thread c GATHERS the nodes that carry label c (lists sorted by label come with the
+// pair) and stores the finished gradient element -- coalesced, once.
 // ==========================================================================================
-template <int NPL, bool UNIT, bool GRADG>
-__global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __restrict__ pairs, int R, int NSmax) {
+template <int NPL, bool UNIT, bool GRADG, int K>
+__global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
+  constexpr int RNk = K >= 4 ? 4 : K;
+  constexpr int NP = K / RNk;
+  constexpr int D = 8 / K;
   const BandPair P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
-  const BandLds L = band_lds(C, R, NSmax, true);
-  float* ering = lds + L.o_ering;
-  float* aring = lds + L.o_aring;
-  double* obuf = reinterpret_cast<double*>(lds + L.o_obuf);
-  float* gring = lds + L.o_gring;
-  float* scratch = lds + L.o_scratch;
-  float* bnd = lds + L.o_misc + 32;  // [4 waves][4 slots][2]
-  float* mxr = bnd + 32;             // [8 slots][4 waves]
-  const int CS = L.CS, NER = L.NER, NGR = L.NGR;
-  const int Rm = R - 1, lgR = 31 - __builtin_clz(R);
+  const BandLds L = band_lds(C, K, NSmax, true);
+  float* ering = lds + L.o_ering;    // [NBG blocks][K][CS]    emissions (kept until the block's gradient is out)
+  float* aring = lds + L.o_aring;    // [NBE blocks][K][NSmax] alpha rows
+  float* oring = lds + L.o_gring;    // [NBG blocks][K][NSmax] node posteriors
+  int* cls = reinterpret_cast<int*>(lds + L.o_scratch);      // [C] start, [C] end of a label's run in snode
+  int* snode = cls + 2 * C;                                  // [n_lab] nodes sorted by (label, node)
+  double* offr = reinterpret_cast<double*>(lds + L.o_misc);  // [4 waves][16 periods]
+  float* bndr = lds + L.o_misc + 168;                        // [4 waves][4K rows][2]
+  float* lser = bndr + 32 * K;                               // [NBG blocks][K] row log-sum-exp (softmax term)
+  const int CS = L.CS;
   const int tid = threadIdx.x;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lag = 3 - w;
   const int l = tid & 63;
   const int m0 = tid * NPL;
-  const int nchunks = (T + R - 1) / R;
-  const double z2 = P.aoff[0];
+  const int nblocks = (T + K - 1) / K;
+  const GTNX_G double* ao = P.aoff;
+  const double z2 = ao[0];
   const bool dead = !(z2 > double(DEADF));
   const float ds = P.delta[0];
   const bool want_em = P.grad_em != nullptr;
-  const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0 &&
-                                                      (!want_em || (reinterpret_cast<uintptr_t>(P.grad_em) & 15) == 0)));
+  const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0));
   const float dn = P.delta_norm ? P.delta_norm[0] : 0.0f;
   const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
 
   NodeRegs<NPL> g;
   load_nodes<NPL, true>(P, m0, g);
-  bool hotn[NPL];
-#pragma unroll
-  for (int j = 0; j < NPL; ++j) hotn[j] = g.has_in[j] && g.lab[j] == P.hot;
   float b[NPL], ahi[NPL], acc[3][NPL];
 #pragma unroll
   for (int j = 0; j < NPL; ++j) {
@@ -540,229 +600,232 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
     ahi[j] = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
     acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
   }
-  double Ahi = P.aoff[1 + T / RN];
-  double bz = -z2;  // (sum of beta's shifts) - score
+  // frames: true alpha[r] = stored + ao[1 + (r >> lgrn) * 4 + w] (periods of the FORWARD launch); true beta = b + bsum
+  auto aoff_of = [&](int r) { return ao[1 + (min(max(r, 0), T) >> P.lgrn) * 4 + w]; };
+  double Ahi = aoff_of(T);
+  double bsum = 0.0;
+  double Acur[K], Anext[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) Acur[i] = aoff_of(T - 1 - i);  // block 0: t = T-1-i
+  if (l == 0) offr[w * 16] = 0.0;
+  // label -> run of nodes
+  for (int c = tid; c < 2 * C; c += BW) cls[c] = 0;
+  __syncthreads();
+  for (int i = tid; i < P.n_lab; i += BW) {
+    const int lab = P.slab[i];
+    snode[i] = P.snode[i];
+    if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
+    if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
+  }
 
-  // ---- staging: chunk c covers virtual rows [cR, cR + rows), i.e. t from T-1-cR down; HBM rows t_lo ..
-  Stage<8> se;   // emissions
-  Stage<16> sa;  // alpha rows
-  float lse_v[8];
-  double off_v = 0.0;
-  auto rows_of = [&](int c) { return c < nchunks ? min(R, T - c * R) : 0; };
-  auto tlo_of = [&](int c) { return T - c * R - rows_of(c); };
-  auto issue = [&](int c) {
+  // ---- staging: chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; HBM rows tlo ..
+  Stage<8> se[D], sa[D];
+  float lse_s[D];
+  auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+  auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
+  auto issue = [&](int d, int c) {
     const int rows = rows_of(c), tlo = tlo_of(c);
-    se.issue(P.em + int64_t(tlo) * C, rows * C, vec, tid);
-    sa.issue(P.alpha + int64_t(tlo) * NS, rows * NS, true, tid);
-    if (tid < rows) off_v = P.aoff[1 + (tlo + tid) / RN];
-    if (soft && want_em)
-      se.each(rows * C, C, vec, tid, [&](int i, int, int r, int, gtnx_f4) { lse_v[i] = P.rowlse[tlo + r]; });
+    se[d].issue(P.em + int64_t(tlo) * C, rows * C, vec, tid);
+    sa[d].issue(P.alpha + int64_t(tlo) * NS, rows * NS, true, tid);
+    lse_s[d] = (soft && tid < rows) ? P.rowlse[tlo + tid] : 0.0f;
   };
-  // chunk row r (HBM order, ascending t) is virtual row vhi - r
-  auto land = [&](int c) {
+  // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block
+  auto land = [&](int d, int c) {
     const int rows = rows_of(c);
     if (rows <= 0) return;
-    const int vhi = c * R + rows - 1;
-    const int eb = vhi % NER, gb = vhi % NGR;
-    se.each(rows * C, C, vec, tid, [&](int i, int, int r, int col, gtnx_f4 q) {
-      int s = eb - r;
-      if (s < 0) s += NER;
-      float* d = ering + s * CS + col;
+    float* eb = ering + (c % NBG) * K * CS;
+    float* ab = aring + (c % NBE) * K * NSmax;
+    se[d].each(rows * C, C, vec, tid, [&](int, int, int r, int col, gtnx_f4 q) {
+      float* dd = eb + (rows - 1 - r) * CS + col;
       const gtnx_f4 q2 = {em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-      if (vec) *reinterpret_cast<gtnx_f4*>(d) = q2;
-      else d[0] = q2.x;
-      if (want_em) {  // the gradient row starts as the normaliser's term dn * softmax(em[t]) (or zero)
-        int sg = gb - r;
-        if (sg < 0) sg += NGR;
-        float* dg = gring + sg * CS + col;
-        gtnx_f4 p = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (soft) {
-          const float lv = lse_v[i];
-          p = gtnx_f4{dn * ex2(q2.x - lv), dn * ex2(q2.y - lv), dn * ex2(q2.z - lv), dn * ex2(q2.w - lv)};
-        }
-        if (vec) *reinterpret_cast<gtnx_f4*>(dg) = p;
-        else dg[0] = p.x;
-      }
+      if (vec) *reinterpret_cast<gtnx_f4*>(dd) = q2;
+      else dd[0] = q2.x;
     });
-    sa.each(rows * NS, NS, true, tid, [&](int, int, int r, int col, gtnx_f4 q) {
-      int s = eb - r;
-      if (s < 0) s += NER;
-      *reinterpret_cast<gtnx_f4*>(aring + s * NSmax + col) = q;
+    sa[d].each(rows * NS, NS, true, tid, [&](int, int, int r, int col, gtnx_f4 q) {
+      *reinterpret_cast<gtnx_f4*>(ab + (rows - 1 - r) * NSmax + col) = q;
     });
-    if (tid < rows) {
-      int s = eb - tid;
-      if (s < 0) s += NER;
-      obuf[s] = off_v;
-    }
+    if (tid < rows) lser[(c % NBG) * K + rows - 1 - tid] = lse_s[d];
   };
-  // finished gradient rows of chunk c: LDS -> HBM
+  // gradient rows of block c (every wave is through with it): gather by label, add the
+  // normaliser's softmax term, store
   auto drain = [&](int c) {
     const int rows = rows_of(c);
     if (!want_em || rows <= 0) return;
-    const int vhi = c * R + rows - 1, gb = vhi % NGR, cnt = rows * C;
-    GTNX_G float* dst = P.grad_em + int64_t(tlo_of(c)) * C;
-    const float invC = 1.0f / float(C);
-    if (vec) {
+    const float* ob = oring + (c % NBG) * K * NSmax;
+    const float* eb = ering + (c % NBG) * K * CS;
+    const float* lb = lser + (c % NBG) * K;
+    GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
+    for (int cc = tid; cc < C; cc += BW) {
+      float sum[K];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int e = 4 * (i * BW + tid);
-        if (e < cnt) {
-          const int r = row_of(e, C, invC);
-          int sg = gb - r;
-          if (sg < 0) sg += NGR;
-          *reinterpret_cast<GTNX_G gtnx_f4*>(dst + e) = *reinterpret_cast<const gtnx_f4*>(gring + sg * CS + (e - r * C));
+      for (int r = 0; r < K; ++r) sum[r] = 0.0f;
+      if (cc != P.hot) {
+        for (int i = cls[cc], e = dead ? 0 : cls[C + cc]; i < e; ++i) {
+          const float* o = ob + snode[i];
+#pragma unroll
+          for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
         }
+#pragma unroll
+        for (int r = 0; r < K; ++r)
+          if (r < rows) {
+            const float sm = soft ? dn * ex2(eb[r * CS + cc] - lb[r]) : 0.0f;
+            dst[-int64_t(r) * C + cc] = sum[r] + sm;
+          }
       }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int e = i * BW + tid;
-        if (e < cnt) {
-          const int r = row_of(e, C, invC);
-          int sg = gb - r;
-          if (sg < 0) sg += NGR;
-          dst[e] = gring[sg * CS + (e - r * C)];
-        }
+    }
+    if (P.hot >= 0 && w < rows) {  // the label most nodes carry (CTC: blank): one wave per row
+      const int r = w;
+      float part = 0.0f;
+      for (int i = cls[P.hot] + l, e = dead ? 0 : cls[C + P.hot]; i < e; i += 64) part += ob[r * NSmax + snode[i]];
+      part = wave_sum63(part);
+      if (l == 63) {
+        const float sm = soft ? dn * ex2(eb[r * CS + P.hot] - lb[r]) : 0.0f;
+        dst[-int64_t(r) * C + P.hot] = part + sm;
       }
     }
   };
 
-  // ---- prologue
-  issue(0);
-  land(0);
-  issue(1);
-  if (NPL == 1) {
-    // q of row v is published per tick; nothing to publish for the initial beta
-  }
-  {
-    float mx = b[0];
+  // ---- prologue: chunk 0 landed, chunks 1 .. D requested
+  issue(0, 0);
+  land(0, 0);
 #pragma unroll
-    for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, b[j]);
-    mx = wave_max(mx);
-    if (l == 0) mxr[0 * 4 + w] = mx;
-  }
+  for (int c = 1; c <= D; ++c) issue(c % D, c);
   lds_barrier();
 
-  float e[NPL], alo[NPL];
-  double Alo = 0.0;
-  int ps = 0, gs = 0;  // ring slots (emission / alpha, gradient) of the next row: rows come in order from 0
-  auto prefetch = [&](int v) {  // inputs of the tick that consumes virtual row v
-    if (v >= 0 && v < T) {
-      const int s = ps;
-      ps = ps + 1 == NER ? 0 : ps + 1;
-      const float* er = ering + s * CS;
+  const int nticks = nblocks + 4;  // block c is drained at tick c + 4
+  GTNX_TM_INIT(32);
+  for (int tau0 = 0; tau0 < nticks; tau0 += D) {
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        e[j] = er[g.lab[j]];
-        alo[j] = aring[s * NSmax + min(m0 + j, NSmax - 1)];
+    for (int d = 0; d < D; ++d) {
+      const int tau = tau0 + d;
+      if (tau >= nticks) break;
+      GTNX_TM(0);
+      land((d + 1) % D, tau + 1);
+      GTNX_TM(1);
+      issue((d + 1) % D, tau + 1 + D);
+      GTNX_TM(2);
+      if (tau >= 4) drain(tau - 4);  // the last wave left it a tick ago; its stores have a tick to retire
+      GTNX_TM(3);
+      const int beta = tau - lag;
+      // alpha frames of the next block's rows: in flight for a whole tick
+#pragma unroll
+      for (int i = 0; i < K; ++i) Anext[i] = aoff_of(T - 1 - (beta + 1) * K - i);
+      if (beta >= 0 && beta < nblocks && !dead) {
+        const int v0 = beta * K, rows = min(K, T - v0);
+        const float* eb = ering + (beta % NBG) * K * CS;
+        const float* ab = aring + (beta % NBE) * K * NSmax;
+        float* ob = oring + (beta % NBG) * K * NSmax + m0;
+        float ev[K][NPL], alov[K][NPL], bq1[K], bq2[K];
+        double offp[NP + 1];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+#pragma unroll
+          for (int j = 0; j < NPL; ++j) {
+            ev[i][j] = eb[i * CS + g.lab[j]];
+            alov[i][j] = ab[i * NSmax + min(m0 + j, NSmax - 1)];
+          }
+          bq1[i] = bq2[i] = NEGF;
+          if (w < 3) {  // q[v0 + i] of the two nodes above this wave, in the next wave's frame
+            const float* bp = bndr + ((w + 1) * 4 * K + (beta & 3) * K + i) * 2;
+            bq1[i] = bp[0];
+            bq2[i] = bp[1];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q <= NP; ++q) offp[q] = w < 3 ? offr[(w + 1) * 16 + ((beta * NP + q) & 15)] : 0.0;
+        float qh[K][NPL];
+        float dconv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          if (i < rows) {
+            if (i % RNk == 0 && w < 3) dconv = float(offp[i / RNk] - bsum);
+            const double bz = bsum - z2;
+            float q[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) qh[i][j] = q[j] = ev[i][j] + b[j];
+            // node posteriors at time t+1 (they belong to gradient row t)
+            if (want_em && m0 < NSmax) {
+              const float dh = float(Ahi + bz);
+#pragma unroll
+              for (int j = 0; j < NPL; ++j) ob[i * NSmax + j] = ex2(ahi[j] + b[j] + dh) * ds;
+            }
+            const float n1 = wave_shl1(q[0], bq1[i] + dconv);
+            const float n2 = NPL == 2 ? wave_shl1(q[NPL - 1], bq2[i] + dconv) : wave_shl1(n1, bq2[i] + dconv);
+            const float dl = GRADG ? float(Acur[i] + bz) : 0.0f;
+            float nb[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+              const float s1 = j + 1 < NPL ? q[NPL - 1] : n1;
+              const float s2 = j + 1 < NPL ? n1 : n2;
+              float y0, y1, y2;
+              if (UNIT) {
+                y0 = q[j];
+                y1 = s1;
+                y2 = s2 + g.wo[2][j];
+              } else {
+                y0 = q[j] + g.wo[0][j];
+                y1 = s1 + g.wo[1][j];
+                y2 = s2 + g.wo[2][j];
+              }
+              if (GRADG) {
+                // the exponentials of the log-sum-exp are the arc posteriors up to one factor per node
+                const float mx = fmaxf(fmaxf(y0, y1), y2);
+                const float e0 = ex2(y0 - mx), e1 = ex2(y1 - mx), e2 = ex2(y2 - mx);
+                nb[j] = mx + lg2(e0 + e1 + e2);
+                const float f = ex2(alov[i][j] + mx + dl);
+                acc[0][j] += e0 * f;
+                acc[1][j] += e1 * f;
+                acc[2][j] += e2 * f;
+              } else {
+                nb[j] = lse3(y0, y1, y2);
+              }
+            }
+            if ((i + 1) % RNk == 0) {  // shift this wave's beta row v0 + i + 1 by its maximum
+              float mx = nb[0];
+#pragma unroll
+              for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, nb[j]);
+              mx = wave_max(mx);
+              if (mx > DEADF) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) nb[j] -= mx;
+                bsum += double(mx);
+              } else if (w < 3) {
+                bsum = offp[(i + 1) / RNk];
+              }
+              if (l == 0) offr[w * 16 + (((v0 + i + 1) / RNk) & 15)] = bsum;
+            }
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+              b[j] = nb[j];
+              ahi[j] = alov[i][j];
+            }
+            Ahi = Acur[i];
+          }
+        }
+        // q of this wave's first two nodes for the wave below
+        if (NPL == 1 ? l < 2 : l == 0) {
+#pragma unroll
+          for (int i = 0; i < K; ++i)
+            if (i < rows) {
+              float* bp = bndr + (w * 4 * K + (beta & 3) * K + i) * 2;
+              if (NPL == 1) {
+                bp[l] = qh[i][0];
+              } else {
+                bp[0] = qh[i][0];
+                bp[1] = qh[i][NPL - 1];
+              }
+            }
+        }
       }
-      Alo = obuf[s];
+#pragma unroll
+      for (int i = 0; i < K; ++i) Acur[i] = Anext[i];
+      GTNX_TM(5);
+      lds_barrier();
+      GTNX_TM(6);
+      GTNX_TM_TICK();
     }
-  };
-  prefetch(0 - lag);
-
-  const int nticks = T + LAGW;
-  int cd = 0;  // next chunk to drain
-  for (int tau = 0; tau < nticks; ++tau) {
-    if (cd < nchunks && tau == (cd + 1) * R + LAGW) {  // the last wave left chunk cd a tick ago
-      drain(cd);
-      ++cd;
-    }
-    if ((tau & Rm) == 0) {
-      const int c = tau >> lgR;
-      land(c + 1);
-      issue(c + 2);
-    }
-    const int v = tau - lag;
-    if (v >= 0 && v < T && !dead) {
-      float n1b = NEGF, n2b = NEGF;
-      if (w < 3) {  // q of the next wave's first nodes for this row, published a tick ago
-        const float* bp = bnd + ((w + 1) * 4 + (v & 3)) * 2;
-        n1b = bp[0];
-        n2b = bp[1];
-      }
-      float q[NPL];
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) q[j] = e[j] + b[j];
-      if (NPL == 1) {
-        if (l < 2) bnd[(w * 4 + (v & 3)) * 2 + l] = q[0];
-      } else if (l == 0) {
-        bnd[(w * 4 + (v & 3)) * 2 + 0] = q[0];
-        bnd[(w * 4 + (v & 3)) * 2 + 1] = q[NPL - 1];
-      }
-      // node posteriors at time t+1 -> gradient row t
-      if (want_em) {
-        const float dh = float(Ahi + bz);
-        float* grow = gring + gs * CS;
-        float hv = 0.0f;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-          const float occ = ex2(ahi[j] + b[j] + dh) * ds;
-          const bool direct = g.has_in[j] && !hotn[j];
-          if (hotn[j]) hv += occ;
-          lds_add(direct ? grow + g.lab[j] : scratch + tid, occ);
-        }
-        if (P.hot >= 0) {
-          hv = wave_sum63(hv);
-          lds_add(l == 63 ? grow + P.hot : scratch + tid, hv);
-        }
-      }
-      const float n1 = wave_shl1(q[0], n1b);
-      const float n2 = NPL == 2 ? wave_shl1(q[NPL - 1], n2b) : wave_shl1(n1, n2b);
-      const float dl = GRADG ? float(Alo + bz) : 0.0f;
-      float nb[NPL];
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const float s1 = j + 1 < NPL ? q[NPL - 1] : n1;
-        const float s2 = j + 1 < NPL ? n1 : (NPL == 2 ? n2 : n2);
-        float y0, y1, y2;
-        if (UNIT) {
-          y0 = q[j];
-          y1 = s1;
-          y2 = s2 + g.wo[2][j];
-        } else {
-          y0 = q[j] + g.wo[0][j];
-          y1 = s1 + g.wo[1][j];
-          y2 = s2 + g.wo[2][j];
-        }
-        if (GRADG) {
-          // the exponentials of the log-sum-exp are the arc posteriors up to one factor per node
-          const float mx = fmaxf(fmaxf(y0, y1), y2);
-          const float e0 = ex2(y0 - mx), e1 = ex2(y1 - mx), e2 = ex2(y2 - mx);
-          nb[j] = mx + lg2(e0 + e1 + e2);
-          const float f = ex2(alo[j] + mx + dl);
-          acc[0][j] += e0 * f;
-          acc[1][j] += e1 * f;
-          acc[2][j] += e2 * f;
-        } else {
-          nb[j] = lse3(y0, y1, y2);
-        }
-      }
-      const int row = v + 1;
-      if (row % RN == 0) {
-        const float sft = shift_of(mxr, row);
-        float mx = NEGF;
-#pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-          nb[j] -= sft;
-          mx = fmaxf(mx, nb[j]);
-        }
-        bz += double(sft);
-        mx = wave_max(mx);
-        if (l == 0) mxr[((row / RN) & 7) * 4 + w] = mx;
-      }
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        b[j] = nb[j];
-        ahi[j] = alo[j];
-      }
-      Ahi = Alo;
-      gs = gs + 1 == NGR ? 0 : gs + 1;
-    }
-    prefetch(v + 1);
-    lds_barrier();
   }
-  for (; cd < nchunks; ++cd) drain(cd);
+  GTNX_TM_DUMP();
   if (GRADG && P.grad_fixed && !dead) {
 #pragma unroll
     for (int j = 0; j < NPL; ++j)
@@ -772,72 +835,80 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
   }
 }
 
-template <int NPL>
-void launch_fwd_npl(const BandPair* d, int n, int R, int ns, size_t lds, bool unit, hipStream_t st) {
-  if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true>), dim3(n), dim3(BW), lds, st, d, R, ns);
-  else hipLaunchKernelGGL((band_forward_kernel<NPL, false>), dim3(n), dim3(BW), lds, st, d, R, ns);
-}
-template <int NPL>
-void launch_bwd_npl(const BandPair* d, int n, int R, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
-  if (unit) {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true>), dim3(n), dim3(BW), lds, st, d, R, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false>), dim3(n), dim3(BW), lds, st, d, R, ns);
-  } else {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true>), dim3(n), dim3(BW), lds, st, d, R, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false>), dim3(n), dim3(BW), lds, st, d, R, ns);
-  }
-}
-
 template <class K>
 void big_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
 }
-void band_attrs() {
-  static bool done = false;
-  if (done) return;
-  done = true;
-#define GTNX_BAND_ATTR(NPL)                           \
-  big_lds(band_backward_kernel<NPL, true, true>);     \
-  big_lds(band_backward_kernel<NPL, true, false>);    \
-  big_lds(band_backward_kernel<NPL, false, true>);    \
-  big_lds(band_backward_kernel<NPL, false, false>);   \
-  big_lds(band_forward_kernel<NPL, true>);            \
-  big_lds(band_forward_kernel<NPL, false>);
-  GTNX_BAND_ATTR(1)
-  GTNX_BAND_ATTR(2)
-#undef GTNX_BAND_ATTR
+
+template <int NPL, int K>
+void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, hipStream_t st) {
+  static bool attr = (big_lds(band_forward_kernel<NPL, true, K>), big_lds(band_forward_kernel<NPL, false, K>), true);
+  (void)attr;
+  if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true, K>), dim3(n), dim3(BW), lds, st, d, ns);
+  else hipLaunchKernelGGL((band_forward_kernel<NPL, false, K>), dim3(n), dim3(BW), lds, st, d, ns);
 }
+template <int NPL, int K>
+void launch_bwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+  static bool attr = (big_lds(band_backward_kernel<NPL, true, true, K>), big_lds(band_backward_kernel<NPL, true, false, K>),
+                      big_lds(band_backward_kernel<NPL, false, true, K>), big_lds(band_backward_kernel<NPL, false, false, K>), true);
+  (void)attr;
+  if (unit) {
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K>), dim3(n), dim3(BW), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K>), dim3(n), dim3(BW), lds, st, d, ns);
+  } else {
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K>), dim3(n), dim3(BW), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K>), dim3(n), dim3(BW), lds, st, d, ns);
+  }
+}
+
+constexpr size_t LDS_TWO = 78 * 1024;   // two workgroups per CU
+constexpr size_t LDS_ONE = 156 * 1024;  // one
 
 } // namespace
 
+int band_block_rows(int C, int max_NS, bool backward);
 int band_max_nodes() { return 512; }
 int band_max_labels() { return 1024; }
 int band_npl(int max_nodes) { return max_nodes <= 256 ? 1 : 2; }
 int band_row_stride(int N, int) { return (N + 3) / 4 * 4; }
-int band_rows_per_chunk(int C, bool backward) {
-  const int cap = backward ? 2048 : 4096;
-  for (int r = backward ? 8 : 16; r > 2; r /= 2)
-    if (r * C <= cap) return r;
-  return 2;
+int band_forward_lgrn(int C) { return band_block_rows(C, 0, false) >= 4 ? 2 : 1; }
+// rows per tick: the largest block that keeps two workgroups on a CU, else the smallest (one per CU)
+int band_block_rows(int C, int max_NS, bool backward) {
+  for (int k = backward ? 4 : 8; k >= 2; k /= 2) {
+    if (k * C > 2048 || k * max_NS > 2048) continue;
+    if (4 * size_t(band_lds(C, k, max_NS, backward).total) + 64 <= LDS_TWO) return k;
+  }
+  if (4 * size_t(band_lds(C, 2, max_NS, backward).total) + 64 <= LDS_ONE) return 2;
+  return 0;
 }
 
 void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, hipStream_t st) {
   if (n <= 0) return;
-  band_attrs();
-  const int R = band_rows_per_chunk(C, false);
-  const size_t lds = 4 * size_t(band_lds(C, R, max_NS, false).total) + 64;
-  if (npl == 1) launch_fwd_npl<1>(d_pairs, n, R, max_NS, lds, unit, st);
-  else launch_fwd_npl<2>(d_pairs, n, R, max_NS, lds, unit, st);
+  const int K = band_block_rows(C, 0, false);  // the forward sweep stages no alpha rows
+  const size_t lds = 4 * size_t(band_lds(C, K, max_NS, false).total) + 64;
+  if (npl == 1) {
+    if (K == 8) launch_fwd<1, 8>(d_pairs, n, max_NS, lds, unit, st);
+    else if (K == 4) launch_fwd<1, 4>(d_pairs, n, max_NS, lds, unit, st);
+    else launch_fwd<1, 2>(d_pairs, n, max_NS, lds, unit, st);
+  } else {
+    if (K == 8) launch_fwd<2, 8>(d_pairs, n, max_NS, lds, unit, st);
+    else if (K == 4) launch_fwd<2, 4>(d_pairs, n, max_NS, lds, unit, st);
+    else launch_fwd<2, 2>(d_pairs, n, max_NS, lds, unit, st);
+  }
 }
 
 // every pair of the launch shares C; max_NS: largest alpha row stride of the launch
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, hipStream_t st) {
   if (n <= 0) return;
-  band_attrs();
-  const int R = band_rows_per_chunk(C, true);
-  const size_t lds = 4 * size_t(band_lds(C, R, max_NS, true).total) + 64;
-  if (npl == 1) launch_bwd_npl<1>(d_pairs, n, R, max_NS, lds, unit, gradg, st);
-  else launch_bwd_npl<2>(d_pairs, n, R, max_NS, lds, unit, gradg, st);
+  const int K = band_block_rows(C, max_NS, true);
+  const size_t lds = 4 * size_t(band_lds(C, K, max_NS, true).total) + 64;
+  if (npl == 1) {
+    if (K == 4) launch_bwd<1, 4>(d_pairs, n, max_NS, lds, unit, gradg, st);
+    else launch_bwd<1, 2>(d_pairs, n, max_NS, lds, unit, gradg, st);
+  } else {
+    if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, st);
+    else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, st);
+  }
 }
 
 } // namespace gtnx

@@ -66,21 +66,28 @@ std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel) {
   b->unit_shape = true;
   for (size_t m = 0; m < N && b->unit_shape; ++m)
     b->unit_shape = b->nodes[m].aid[0] >= 0 && (m == 0 || b->nodes[m].aid[1] >= 0);
-  // the label most nodes share: its posteriors are summed across the wave, not by LDS atomics
-  std::vector<int> ls;
-  ls.reserve(N);
-  for (const BandNode& nd : b->nodes)
-    if (nd.lab >= 0) ls.push_back(nd.lab);
-  std::sort(ls.begin(), ls.end());
+  // nodes by label (the backward sweep gathers posteriors by label); the label most nodes
+  // share gets a wave of its own
+  std::vector<std::pair<int, int>> ln;
+  ln.reserve(N);
+  for (size_t m = 0; m < N; ++m)
+    if (b->nodes[m].lab >= 0) ln.push_back({b->nodes[m].lab, int(m)});
+  std::sort(ln.begin(), ln.end());
+  b->snode.resize(ln.size());
+  b->slab.resize(ln.size());
   size_t best = 0;
-  for (size_t i = 0; i < ls.size();) {
+  for (size_t i = 0; i < ln.size();) {
     size_t j = i;
-    while (j < ls.size() && ls[j] == ls[i]) ++j;
+    while (j < ln.size() && ln[j].first == ln[i].first) ++j;
     if (j - i > best) {
       best = j - i;
-      b->hot = ls[i];
+      b->hot = ln[i].first;
     }
     i = j;
+  }
+  for (size_t i = 0; i < ln.size(); ++i) {
+    b->slab[i] = ln[i].first;
+    b->snode[i] = ln[i].second;
   }
   if (best < 8) b->hot = -1;
   return b;
@@ -100,7 +107,8 @@ void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vecto
     const size_t N = bs[todo[q]]->nodes.size();
     on[q] = total;
     of[q] = total + sizeof(BandNode) * N;
-    total = align_up(of[q] + N, 64);
+    total = align_up(of[q] + N, 64) + 8 * bs[todo[q]]->snode.size();
+    total = align_up(total, 64);
   }
   PinnedMemP pin = rt.alloc_pinned(total);
   DevMemP dev = rt.alloc(total);
@@ -112,6 +120,11 @@ void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vecto
     b->dev_mem = dev;
     b->dev = dev->as<BandNode>(on[q]);
     b->dev_flags = dev->as<uint8_t>(of[q]);
+    const size_t os = align_up(of[q] + N, 64), nl = b->snode.size();
+    std::memcpy(pin->as<char>(os), b->snode.data(), 4 * nl);
+    std::memcpy(pin->as<char>(os + 4 * nl), b->slab.data(), 4 * nl);
+    b->dev_snode = dev->as<int>(os);
+    b->dev_slab = dev->as<int>(os + 4 * nl);
   };
   for (size_t q = 0; q < todo.size(); ++q) body(q);
   rt.h2d(dev->ptr, pin->ptr, total);

@@ -135,9 +135,12 @@ struct BandInfo {
   int hot = -1;             // label carried by >= 8 nodes (CTC: blank)
   int max_label = -1;
   std::vector<BandNode> nodes;
+  std::vector<int> snode, slab;  // nodes with an in-arc sorted by (label, node), and their labels
   DevMemP dev_mem;          // one arena per uploaded batch
   const BandNode* dev = nullptr;
   const uint8_t* dev_flags = nullptr;
+  const int* dev_snode = nullptr;
+  const int* dev_slab = nullptr;
 };
 std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel);   // host part, cached
 void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vector<Structure*>& ss);

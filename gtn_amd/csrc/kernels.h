@@ -376,10 +376,12 @@ struct BandNode {
 struct BandPair {
   const GTNX_G BandNode* nodes;    // [N]
   const GTNX_G uint8_t* nflags;    // [N] NF_START | NF_ACCEPT
+  const GTNX_G int* snode;         // [n_lab] nodes with an in-arc, sorted by (label, node)
+  const GTNX_G int* slab;          // [n_lab] their labels
   const GTNX_G float* w;           // G's weights, arc-id order; null: all zero
   const GTNX_G float* em;          // [T][C] chain weights
   GTNX_G float* alpha;             // [T+1][NS] log2 units, shifted rows
-  GTNX_G double* aoff;             // [0]: the score in log2 units; [1 + r / 4]: shift of alpha row r
+  GTNX_G double* aoff;             // [0]: the score in log2 units; [1 + (r >> lgrn) * 4 + w]: shift of alpha row r, wave w
   GTNX_G float* score;             // [1]
   GTNX_G float* norm;              // [1] forwardScore of the chain itself, or null
   GTNX_G float* rowlse;            // [T] log2-sum-exp2 of every emission row, or null
@@ -389,12 +391,14 @@ struct BandPair {
   GTNX_G float* grad_fixed;        // [A] zero-filled by the host, or null       (backward)
   int N, T, C, NS;
   int hot;                         // label shared by >= 8 nodes of G (CTC: blank), or -1
-  int pad;
+  int lgrn;                        // log2 of the rows per shift period of the forward launch
+  int n_lab, pad;
 };
 int band_max_nodes();
 int band_max_labels();
 int band_npl(int max_nodes);               // nodes per lane: 1 or 2
 int band_row_stride(int N, int npl);       // NS
+int band_forward_lgrn(int C);
 // all pairs of one launch share C and npl; unit: self-loop + previous-node arc at every node, all weights 0
 void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, hipStream_t st);
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg,

@@ -2190,7 +2190,7 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     const int T = op->chains[i].s->M, N = int(op->fixed[i].s->N);
     const int ns = band_row_stride(N, band_npl(N));
     oo[i] = bytes;
-    bytes = align_up(bytes + 8 * size_t(T + 2), 256);
+    bytes = align_up(bytes + 8 * (2 * size_t(T) + 8), 256);  // score + one shift per wave and period (>= 2 rows)
     ao[i] = bytes;
     bytes = align_up(bytes + 4 * size_t(T + 1) * size_t(ns), 256);
   }
@@ -2205,6 +2205,9 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     const BandInfo& b = *op->infos[i];
     p.nodes = b.dev;
     p.nflags = b.dev_flags;
+    p.snode = b.dev_snode;
+    p.slab = b.dev_slab;
+    p.n_lab = int(b.snode.size());
     p.w = op->fixed[i].w->is_all_zero() ? nullptr : op->fixed[i].w->dev;
     p.em = op->chains[i].w->dev;
     p.N = int(op->fixed[i].s->N);
@@ -2215,6 +2218,7 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     p.aoff = op->arena->as<double>(oo[i]);
     p.score = op->arena->as<float>(4 * i);
     p.hot = b.hot;
+    p.lgrn = band_forward_lgrn(p.C);
     tab.push_back({BandSdOp::Key{p.C, band_npl(p.N), int(op->unit[i]), 0}, p});
     abytes += 4.0 * p.T * p.C + 4.0 * double(p.T + 1) * p.NS;  // emissions in, alpha out (kept for the backward sweep)
   }

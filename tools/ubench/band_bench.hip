@@ -1,0 +1,146 @@
+// Kernel-only bench of band.hip (diagnostic tool): CTC-shaped pairs, no host engine.
+//   hipcc --offload-arch=gfx950 -O3 -w -I gtn_amd/csrc -I include [-DGTNX_BAND_TIMING] tools/ubench/band_bench.hip -o tools/ubench/band_bench
+//   tools/ubench/band_bench [B T C U]
+#include "../../gtn_amd/csrc/band.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+using namespace gtnx;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+int main(int argc, char** argv) {
+  int B = argc > 1 ? atoi(argv[1]) : 512, T = argc > 2 ? atoi(argv[2]) : 1000, C = argc > 3 ? atoi(argv[3]) : 256,
+      U = argc > 4 ? atoi(argv[4]) : 100;
+  const int N = 2 * U + 1, npl = band_npl(N), NS = band_row_stride(N, npl);
+  std::mt19937 rng(1234);
+  std::uniform_real_distribution<float> ud(-5.f, 5.f);
+  std::vector<float> em(size_t(B) * T * C);
+  for (auto& v : em) v = ud(rng);
+  float* d_em;
+  CK(hipMalloc(&d_em, em.size() * 4));
+  CK(hipMemcpy(d_em, em.data(), em.size() * 4, hipMemcpyHostToDevice));
+  float* d_grad;
+  CK(hipMalloc(&d_grad, em.size() * 4));
+  std::vector<BandPair> pairs(B);
+  size_t per_nodes = sizeof(BandNode) * N, per_flags = (N + 63) / 64 * 64, per_s = 4 * size_t(N);
+  size_t per_g = per_nodes + per_flags + 2 * per_s;
+  char* d_g;
+  CK(hipMalloc(&d_g, per_g * B));
+  std::vector<char> h_g(per_g * B);
+  const size_t per_alpha = size_t(T + 1) * NS * 4, per_off = 8 * (2 * size_t(T) + 8);
+  char *d_alpha, *d_off;
+  CK(hipMalloc(&d_alpha, per_alpha * B));
+  CK(hipMalloc(&d_off, per_off * B));
+  float *d_score, *d_delta, *d_gfix, *d_norm, *d_rowlse;
+  CK(hipMalloc(&d_score, 4 * B));
+  CK(hipMalloc(&d_norm, 4 * B));
+  CK(hipMalloc(&d_rowlse, 4 * size_t(B) * T));
+  CK(hipMalloc(&d_delta, 4 * B));
+  CK(hipMalloc(&d_gfix, 4 * size_t(B) * 3 * N));
+  CK(hipMemset(d_gfix, 0, 4 * size_t(B) * 3 * N));
+  std::vector<float> ones(B, -1.0f);
+  CK(hipMemcpy(d_delta, ones.data(), 4 * B, hipMemcpyHostToDevice));
+  int A = 0;
+  for (int b = 0; b < B; ++b) {
+    std::vector<int> tg(U);
+    for (auto& v : tg) v = 1 + rng() % (C - 1);
+    BandNode* nd = reinterpret_cast<BandNode*>(h_g.data() + per_g * b);
+    uint8_t* fl = reinterpret_cast<uint8_t*>(h_g.data() + per_g * b + per_nodes);
+    int* sn = reinterpret_cast<int*>(h_g.data() + per_g * b + per_nodes + per_flags);
+    int* sl = sn + N;
+    int a = 0;
+    std::vector<std::pair<int, int>> ln;
+    for (int m = 0; m < N; ++m) {
+      const int lab = m % 2 ? tg[(m - 1) / 2] : 0;
+      nd[m].lab = lab;
+      nd[m].aid[0] = a++;
+      nd[m].aid[1] = m > 0 ? a++ : -1;
+      nd[m].aid[2] = (m % 2 && m > 1 && lab != tg[(m - 1) / 2 - 1]) ? a++ : -1;
+      fl[m] = (m == 0 ? NF_START : 0) | (m >= N - 2 ? NF_ACCEPT : 0);
+      ln.push_back({lab, m});
+    }
+    A = a;
+    std::sort(ln.begin(), ln.end());
+    for (int i = 0; i < N; ++i) {
+      sl[i] = ln[i].first;
+      sn[i] = ln[i].second;
+    }
+    BandPair& p = pairs[b];
+    p = BandPair{};
+    p.nodes = reinterpret_cast<BandNode*>(d_g + per_g * b);
+    p.nflags = reinterpret_cast<uint8_t*>(d_g + per_g * b + per_nodes);
+    p.snode = reinterpret_cast<int*>(d_g + per_g * b + per_nodes + per_flags);
+    p.slab = p.snode + N;
+    p.n_lab = N;
+    p.w = nullptr;
+    p.em = d_em + size_t(b) * T * C;
+    p.alpha = reinterpret_cast<float*>(d_alpha + per_alpha * b);
+    p.aoff = reinterpret_cast<double*>(d_off + per_off * b);
+    p.score = d_score + b;
+    p.norm = getenv("FUSE") ? d_norm + b : nullptr;
+    p.rowlse = getenv("FUSE") ? d_rowlse + size_t(b) * T : nullptr;
+    p.delta = d_delta + b;
+    p.delta_norm = getenv("FUSE") ? d_delta + b : nullptr;
+    p.grad_em = d_grad + size_t(b) * T * C;
+    p.grad_fixed = getenv("NOGRADG") ? nullptr : d_gfix + size_t(b) * 3 * N;
+    p.N = N;
+    p.T = T;
+    p.C = C;
+    p.NS = NS;
+    p.hot = 0;
+    p.lgrn = band_forward_lgrn(C);
+  }
+  CK(hipMemcpy(d_g, h_g.data(), h_g.size(), hipMemcpyHostToDevice));
+  BandPair* d_pairs;
+  CK(hipMalloc(&d_pairs, sizeof(BandPair) * B));
+  CK(hipMemcpy(d_pairs, pairs.data(), sizeof(BandPair) * B, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1, e2;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  CK(hipEventCreate(&e2));
+  const bool gradg = getenv("NOGRADG") == nullptr;
+  float fsum = 0, bsum = 0;
+  const int reps = 20;
+  for (int it = 0; it < reps + 3; ++it) {
+    CK(hipEventRecord(e0, 0));
+    launch_band_forward(d_pairs, B, npl, C, NS, true, 0);
+    CK(hipEventRecord(e1, 0));
+    launch_band_backward(d_pairs, B, npl, C, NS, true, gradg, 0);
+    CK(hipEventRecord(e2, 0));
+    CK(hipEventSynchronize(e2));
+    float f, bw;
+    CK(hipEventElapsedTime(&f, e0, e1));
+    CK(hipEventElapsedTime(&bw, e1, e2));
+    if (it >= 3) {
+      fsum += f;
+      bsum += bw;
+    }
+  }
+  const double fb = double(B) * (4.0 * T * C + 4.0 * (T + 1) * NS), bb = double(B) * (8.0 * T * C + 4.0 * (T + 1) * NS);
+  printf("B %d T %d C %d U %d (N %d NS %d npl %d Kf %d Kb %d): forward %.3f ms (%.2f TB/s)  backward %.3f ms (%.2f TB/s)\n", B, T,
+         C, U, N, NS, npl, band_block_rows(C, 0, false), band_block_rows(C, NS, true), fsum / reps,
+         fb / (fsum / reps) * 1e-9, bsum / reps, bb / (bsum / reps) * 1e-9);
+  std::vector<float> sc(B);
+  CK(hipMemcpy(sc.data(), d_score, 4 * B, hipMemcpyDeviceToHost));
+  printf("score[0..3] %.4f %.4f %.4f %.4f\n", sc[0], sc[1], sc[2], sc[3]);
+#ifdef GTNX_BAND_TIMING
+  long long h[64];
+  CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(::g_band_timing), sizeof(h)));
+  for (int k = 0; k < 2; ++k) {
+    printf("%s timing, workgroup 0, cycles per tick (loop | land | issue | store/drain | lse | compute | barrier), ticks %lld\n",
+           k ? "backward" : "forward", h[k * 32 + 31]);
+    for (int wv = 0; wv < 4; ++wv) {
+      printf("  wave %d:", wv);
+      for (int i = 0; i < 7; ++i) printf(" %6.0f", double(h[k * 32 + wv * 7 + i]) / double(h[k * 32 + 31] ? h[k * 32 + 31] : 1));
+      printf("\n");
+    }
+  }
+#endif
+  return 0;
+}
+#endif

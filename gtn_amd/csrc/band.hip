@@ -35,7 +35,7 @@
 #include "kernels.h"
 
 #ifdef GTNX_BAND_TIMING
-__device__ long long g_band_timing[64];
+__device__ long long g_band_timing[128];
 #endif
 
 namespace gtnx {
@@ -45,7 +45,8 @@ constexpr float NEGF = -1.0e30f;   // log-domain zero
 constexpr float DEADF = -1.0e29f;  // anything below is "no path"
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr double LN2 = 0.693147180559945309417;
-constexpr int BW = 256;  // lanes per workgroup (4 waves)
+constexpr int BW = 256;  // lanes of one role: 4 sweeper waves + 4 helper waves per workgroup
+constexpr int WG = 512;
 constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
 constexpr int NBG = 6;   // blocks in the gradient ring: one pre-filled, four in use, one draining
 
@@ -67,7 +68,7 @@ constexpr int NBG = 6;   // blocks in the gradient ring: one pre-filled, four in
   do {                                                                      \
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                       \
       for (int i_ = 0; i_ < 7; ++i_) g_band_timing[tm_base + (threadIdx.x >> 6) * 7 + i_] += tm_acc[i_]; \
-      if (threadIdx.x == 0) g_band_timing[tm_base + 31] += tm_n;            \
+      if (threadIdx.x == 0) g_band_timing[tm_base + 63] += tm_n;            \
     }                                                                       \
   } while (0)
 #else
@@ -200,13 +201,18 @@ __device__ __forceinline__ int row_of(int e, int W, float invW) {
 template <int NS>
 struct Stage {
   float v[NS];
-  __device__ __forceinline__ void issue(const GTNX_G float* src, int cnt, bool vec, int tid) {
-    if (vec) {
+  // loads are unconditional (lanes past the end re-read the last element): a conditional load
+  // would have to be merged with its default, i.e. waited for, right where it is issued.  VEC
+  // is a compile-time choice: with both forms in one kernel the second would wait for the first
+  // (they write the same registers)
+  template <bool VEC>
+  __device__ __forceinline__ void issue(const GTNX_G float* src, int cnt, int tid) {
+    if (cnt <= 0) return;  // uniform
+    if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < NS / 4; ++i) {
-        const int e = 4 * (i * BW + tid);
-        gtnx_f4 q = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (e < cnt) q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
+        const int e = min(4 * (i * BW + tid), cnt - 4);
+        const gtnx_f4 q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
         v[4 * i] = q.x;
         v[4 * i + 1] = q.y;
         v[4 * i + 2] = q.z;
@@ -214,17 +220,14 @@ struct Stage {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        const int e = i * BW + tid;
-        v[i] = e < cnt ? src[e] : 0.0f;
-      }
+      for (int i = 0; i < NS; ++i) v[i] = src[min(i * BW + tid, cnt - 1)];
     }
   }
   // f(i, e, r, c, q): slot index, element, chunk row, column, values (4 in vec mode, else q.x)
-  template <class F>
-  __device__ __forceinline__ void each(int cnt, int W, bool vec, int tid, F&& f) const {
+  template <bool VEC, class F>
+  __device__ __forceinline__ void each(int cnt, int W, int tid, F&& f) const {
     const float invW = 1.0f / float(W);
-    if (vec) {
+    if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < NS / 4; ++i) {
         const int e = 4 * (i * BW + tid);
@@ -248,8 +251,8 @@ struct Stage {
 
 // LDS layout shared by host (size) and device (carving); all counts in floats
 struct BandLds {
-  int CS;  // ring row stride of emission / gradient rows
-  int o_ering, o_aring, o_gring, o_scratch, o_misc, total;
+  int CS;  // ring row stride of emission rows
+  int o_ering, o_aring, o_oring, o_snode, o_misc, total;
 };
 __host__ __device__ inline BandLds band_lds(int C, int K, int NSmax, bool backward) {
   BandLds L;
@@ -258,27 +261,51 @@ __host__ __device__ inline BandLds band_lds(int C, int K, int NSmax, bool backwa
   L.o_ering = o;  // the backward sweep keeps a block's emissions until its gradient rows are out
   o += (backward ? NBG : NBE) * K * L.CS;
   o = (o + 3) & ~3;
-  L.o_aring = o;
+  L.o_aring = o;  // alpha rows
   o += backward ? NBE * K * NSmax : 0;
   o = (o + 3) & ~3;
-  L.o_gring = o;  // node posteriors
-  o += backward ? NBG * K * NSmax : 0;
-  L.o_scratch = o;  // label runs: start[C], end[C], sorted nodes[<= 512]
-  o += backward ? 2 * C + 512 : 0;
+  L.o_oring = o;  // node posteriors (>= 2C ints: the prologue sorts labels here)
+  o += backward ? max(NBG * K * NSmax, 2 * C) : 0;
   o = (o + 3) & ~3;
-  // offr[4][16] doubles, red[16] doubles, find[4] doubles | bndr[4][4K][2], then forward: fin[8],
-  // lsep[2][16][8][2]; backward: lser[NBG][K]
+  L.o_snode = o;  // nodes sorted by (label, node)
+  o += backward ? 512 : 0;
+  // doubles: offr[5][16], red[16], find[4], aofr[NBE][K][4] | floats: bndr[5][4K][2], fin[8], lsep[2][16][8][2] / lser[NBG][K]
+  // (region 0 of offr / bndr is constant: what the first wave of the pipeline reads as its neighbour)
   L.o_misc = o;
-  o += 128 + 32 + 8 + 32 * K + 8 + 512;
+  o += 160 + 32 + 8 + 2 * NBE * K * 4 + 40 * K + 8 + 512;
   L.total = o;
   return L;
+}
+struct BandMisc {
+  double *offr, *red, *find, *aofr;
+  float *bndr, *fin, *lsep;
+};
+template <int K>
+__device__ __forceinline__ BandMisc band_misc(float* lds, const BandLds& L) {
+  BandMisc m;
+  m.offr = reinterpret_cast<double*>(lds + L.o_misc);
+  m.red = m.offr + 80;
+  m.find = m.red + 16;
+  m.aofr = m.find + 4;
+  m.bndr = lds + L.o_misc + 200 + 2 * NBE * K * 4;
+  m.fin = m.bndr + 40 * K;
+  m.lsep = m.fin + 8;
+  return m;
+}
+
+// shift of a wave's running row by its maximum; the reduction is independent of the next
+// steps' chain, so the scheduler may interleave it with them
+__device__ __forceinline__ float wave_max_of(const float* v, int n) {
+  float mx = v[0];
+  for (int j = 1; j < n; ++j) mx = fmaxf(mx, v[j]);
+  return wave_max(mx);
 }
 
 // ==========================================================================================
 // forward: alpha[t+1][m] = em[t][lab m] + log sum_k exp(alpha[t][m-k] + w_k(m))
 // ==========================================================================================
-template <int NPL, bool UNIT, int K>
-__global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
+template <int NPL, bool UNIT, int K, bool VEC>
+__global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
   constexpr int RNk = K >= 4 ? 4 : K;  // rows between shifts of a wave's running row
   constexpr int NP = K / RNk;          // shift periods per block
   constexpr int D = 8 / K;             // ticks a staged chunk is in flight (8 rows ahead)
@@ -287,140 +314,51 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
   extern __shared__ float lds[];
   const BandLds L = band_lds(C, K, NSmax, false);
   float* ering = lds + L.o_ering;
-  double* offr = reinterpret_cast<double*>(lds + L.o_misc);  // [4 waves][16 periods]
-  double* red = offr + 64;                                   // [16]
-  double* find = red + 16;                                   // [4]
-  float* bndr = lds + L.o_misc + 168;                        // [4 waves][4K rows][2]
-  float* fin = bndr + 32 * K;                                // [4 waves][2]
-  float* lsep = fin + 8;                                     // [2 chunk parities][16 rows][8 groups][2]
+  const BandMisc M = band_misc<K>(lds, L);
   const int CS = L.CS;
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l = tid & 63;
-  const int m0 = tid * NPL;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool sweeper = wv < 4;
+  const int l = threadIdx.x & 63;
   const int nblocks = (T + K - 1) / K;
-  const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0));
-  const bool want_lse = P.norm != nullptr || P.rowlse != nullptr;
-
-  NodeRegs<NPL> g;
-  load_nodes<NPL, false>(P, m0, g);
-  const bool writer = m0 < NS;
-  float a[NPL];
-#pragma unroll
-  for (int j = 0; j < NPL; ++j) a[j] = g.start[j] ? 0.0f : NEGF;
-  double off = 0.0;  // this wave's shift: true alpha = a + off
-  GTNX_G float* arow = P.alpha + m0;
-  if (writer) {
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) arow[j] = a[j];
-  }
-  if (l == 0) {
-    P.aoff[1 + w] = 0.0;
-    offr[w * 16] = 0.0;
-  }
-  if (NPL == 1) {
-    if (l >= 62) bndr[(w * 4 * K) * 2 + (63 - l)] = a[0];
-  } else if (l == 63) {
-    bndr[(w * 4 * K) * 2 + 0] = a[NPL - 1];
-    bndr[(w * 4 * K) * 2 + 1] = a[0];
-  }
-
-  // ---- staging of the emission ring: chunk c = rows [cK, cK + K) = block c
-  Stage<8> st[D];
-  auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-  auto issue = [&](Stage<8>& s, int c) { s.issue(P.em + int64_t(c) * K * C, rows_of(c) * C, vec, tid); };
-  auto land = [&](const Stage<8>& s, int c) {
-    float* base = ering + (c % NBE) * K * CS;
-    s.each(rows_of(c) * C, C, vec, tid, [&](int, int, int r, int col, gtnx_f4 q) {
-      float* d = base + r * CS + col;
-      if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-      else d[0] = em2(q.x);
-    });
-  };
-  // ---- row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / K lanes per row, pairs
-  // (max, sum) per 16-lane group in phase A, merged per row by one lane in phase B (a tick later)
-  constexpr int LPR = BW / K, G16 = LPR / 16;
-  const int EPL = (C + LPR - 1) / LPR;  // <= 16: K * C <= 2048 ... 4096
-  double normacc = 0.0;
-  auto lse_a = [&](int c) {
-    const int rows = rows_of(c), rr = tid / LPR, sub = tid - rr * LPR;
-    if (rows <= 0) return;
-    const float* e = ering + ((c % NBE) * K + min(rr, rows - 1)) * CS + sub * EPL;
-    float x[16];
-    float m = NEGF;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      x[i] = (i < EPL && sub * EPL + i < C) ? e[i] : NEGF;
-      m = fmaxf(m, x[i]);
-    }
-    m = row16_max(m);
-    float sum = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sum += (i < EPL) ? ex2(x[i] - m) : 0.0f;
-    sum = row16_sum(sum);
-    if ((tid & 15) == 0 && rr < rows) {
-      float* p = lsep + (c & 1) * 256 + (rr * 8 + (sub >> 4)) * 2;
-      p[0] = m;
-      p[1] = sum;
-    }
-  };
-  auto lse_b = [&](int c) {
-    const int rows = rows_of(c);
-    if (tid < rows) {
-      const float* p = lsep + (c & 1) * 256 + tid * 16;
-      float M = p[0];
-#pragma unroll
-      for (int k = 1; k < G16; ++k) M = fmaxf(M, p[2 * k]);
-      float S = 0.0f;
-#pragma unroll
-      for (int k = 0; k < G16; ++k) S += p[2 * k + 1] * ex2(p[2 * k] - M);
-      const float l2 = M + lg2(S);
-      if (P.rowlse) P.rowlse[c * K + tid] = l2;
-      normacc += double(l2);
-    }
-  };
-
-  // ---- prologue: chunk 0 landed, chunks 1 .. D requested
-  issue(st[0], 0);
-  land(st[0], 0);
-#pragma unroll
-  for (int c = 1; c <= D; ++c) issue(st[c % D], c);
-  lds_barrier();
-
   const int nticks = nblocks + 3;
   GTNX_TM_INIT(0);
-  float hist[K][NPL];  // this wave's rows of the last block, stored a tick late
-  int pend = 0;
-  auto flush = [&]() {
+
+  if (sweeper) {
+    // ------------------------------------------------------------------ the recursion: no global loads
+    const int w = wv;
+    const int m0 = threadIdx.x * NPL;
+    NodeRegs<NPL> g;
+    load_nodes<NPL, false>(P, m0, g);
+    const bool writer = m0 < NS;
+    float a[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) a[j] = g.start[j] ? 0.0f : NEGF;
+    double off = 0.0;  // this wave's shift: true alpha = a + off
+    GTNX_G float* arow = P.alpha + m0;
     if (writer) {
 #pragma unroll
-      for (int i = 0; i < K; ++i)
-        if (i < pend) {
-          arow += NS;
-#pragma unroll
-          for (int j = 0; j < NPL; ++j) arow[j] = hist[i][j];
-        }
+      for (int j = 0; j < NPL; ++j) arow[j] = a[j];
     }
-    pend = 0;
-  };
-  for (int tau0 = 0; tau0 < nticks; tau0 += D) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int tau = tau0 + d;
-      if (tau >= nticks) break;
-      // chunk tau + 1 lands (its ring block was last read a tick ago), chunk tau + 1 + D is requested
+    // pipeline position s = w: this wave publishes into region s + 1 and reads region s (0: constants)
+    float* bnd_own = M.bndr + (w + 1) * 4 * K * 2;
+    const float* bnd_prev = M.bndr + w * 4 * K * 2;
+    double* off_own = M.offr + (w + 1) * 16;
+    const double* off_prev = M.offr + w * 16;
+    if (threadIdx.x < 8 * K) M.bndr[threadIdx.x] = NEGF;
+    if (threadIdx.x < 16) M.offr[threadIdx.x] = 0.0;
+    if (l == 0) {
+      P.aoff[1 + w] = 0.0;
+      off_own[0] = 0.0;
+    }
+    if (NPL == 1) {
+      if (l >= 62) bnd_own[63 - l] = a[0];
+    } else if (l == 63) {
+      bnd_own[0] = a[NPL - 1];
+      bnd_own[1] = a[0];
+    }
+    lds_barrier();
+    for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      land(st[(d + 1) % D], tau + 1);
-      GTNX_TM(1);
-      issue(st[(d + 1) % D], tau + 1 + D);
-      GTNX_TM(2);
-      flush();
-      GTNX_TM(3);
-      if (want_lse) {
-        if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
-        if (tau < nblocks) lse_a(tau);
-      }
-      GTNX_TM(4);
       const int beta = tau - w;
       if (beta >= 0 && beta < nblocks) {
         const int t0 = beta * K, rows = min(K, T - t0);
@@ -431,20 +369,19 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
         for (int i = 0; i < K; ++i) {
 #pragma unroll
           for (int j = 0; j < NPL; ++j) ev[i][j] = eb[i * CS + g.lab[j]];
-          bv1[i] = bv2[i] = NEGF;
-          if (w > 0) {  // alpha[t0 + i] of the two nodes below this wave, in the previous wave's frame
-            const float* bp = bndr + ((w - 1) * 4 * K + (beta & 3) * K + i) * 2;
-            bv1[i] = bp[0];
-            bv2[i] = bp[1];
-          }
+          // alpha[t0 + i] of the two nodes below this wave, in the previous wave's frame
+          const float* bp = bnd_prev + ((beta & 3) * K + i) * 2;
+          bv1[i] = bp[0];
+          bv2[i] = bp[1];
         }
 #pragma unroll
-        for (int q = 0; q <= NP; ++q) offp[q] = w > 0 ? offr[(w - 1) * 16 + ((beta * NP + q) & 15)] : 0.0;
+        for (int q = 0; q <= NP; ++q) offp[q] = off_prev[(beta * NP + q) & 15];
+        float hist[K][NPL];
         float dconv = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
           if (i < rows) {
-            if (i % RNk == 0 && w > 0) dconv = float(offp[i / RNk] - off);
+            if (i % RNk == 0) dconv = float(offp[i / RNk] - off);
             const float b1 = bv1[i] + dconv, b2 = bv2[i] + dconv;
             const float p1 = wave_shr1(a[NPL - 1], b1);
             const float p2 = NPL == 2 ? wave_shr1(a[0], b2) : wave_shr1(p1, b2);
@@ -466,10 +403,7 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
               nw[j] = lse3(x0, x1, x2) + ev[i][j];
             }
             if ((i + 1) % RNk == 0) {  // shift this wave's row t0 + i + 1 by its maximum
-              float mx = nw[0];
-#pragma unroll
-              for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, nw[j]);
-              mx = wave_max(mx);
+              const float mx = wave_max_of(nw, NPL);
               if (mx > DEADF) {
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) nw[j] -= mx;
@@ -479,7 +413,7 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
               }
               if (l == 0) {
                 const int p = (t0 + i + 1) / RNk;
-                offr[w * 16 + (p & 15)] = off;
+                off_own[p & 15] = off;
                 P.aoff[1 + p * 4 + w] = off;
               }
             }
@@ -487,13 +421,21 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
             for (int j = 0; j < NPL; ++j) hist[i][j] = a[j] = nw[j];
           }
         }
-        pend = rows;  // stored at the start of the next tick: a wait for staged loads never covers fresh stores
+        if (writer) {  // this wave never loads from HBM, so it never waits for these
+#pragma unroll
+          for (int i = 0; i < K; ++i)
+            if (i < rows) {
+              arow += NS;
+#pragma unroll
+              for (int j = 0; j < NPL; ++j) arow[j] = hist[i][j];
+            }
+        }
         // boundary values of rows t0 + 1 .. t0 + rows for the wave above
         if (NPL == 1 ? l >= 62 : l == 63) {
 #pragma unroll
           for (int i = 0; i < K; ++i)
             if (i < rows) {
-              float* bp = bndr + (w * 4 * K + (((beta & 3) * K + i + 1) & (4 * K - 1))) * 2;
+              float* bp = bnd_own + ((((beta & 3) * K + i + 1) & (4 * K - 1))) * 2;
               if (NPL == 1) {
                 bp[63 - l] = hist[i][0];
               } else {
@@ -508,11 +450,7 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
       GTNX_TM(6);
       GTNX_TM_TICK();
     }
-  }
-  flush();
-  GTNX_TM_DUMP();
-  // score = log sum over accept nodes of alpha[T]  (shortest.cpp:153-167)
-  {
+    // score = log sum over accept nodes of alpha[T]  (shortest.cpp:153-167)
     float f = NEGF;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) f = fmaxf(f, g.accept[j] ? a[j] : NEGF);
@@ -522,27 +460,114 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
     for (int j = 0; j < NPL; ++j) s += g.accept[j] ? ex2(a[j] - mx) : 0.0f;
     s = wave_sum(s);
     if (l == 0) {
-      fin[2 * w] = mx;
-      fin[2 * w + 1] = s;
-      find[w] = off;
+      M.fin[2 * w] = mx;
+      M.fin[2 * w + 1] = s;
+      M.find[w] = off;
     }
-    if (tid < 16) red[tid] = normacc;
+  } else {
+    // ------------------------------------------------------------------ helpers: everything else
+    const int hid = threadIdx.x - BW;
+    constexpr bool vec = VEC;  // host: C % 4 == 0 and 16-byte aligned emissions
+    const bool want_lse = P.norm != nullptr || P.rowlse != nullptr;
+    // staging of the emission ring: chunk c = rows [cK, cK + K) = block c
+    Stage<8> st[D];
+    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+    auto issue = [&](Stage<8>& s, int c) { s.template issue<VEC>(P.em + int64_t(c) * K * C, rows_of(c) * C, hid); };
+    auto land = [&](const Stage<8>& s, int c) {
+      float* base = ering + (c % NBE) * K * CS;
+      s.template each<VEC>(rows_of(c) * C, C, hid, [&](int, int, int r, int col, gtnx_f4 q) {
+        float* d = base + r * CS + col;
+        if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
+        else d[0] = em2(q.x);
+      });
+    };
+    // row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / K lanes per row, pairs
+    // (max, sum) per 16-lane group in phase A, merged per row by one lane in phase B (a tick later)
+    constexpr int LPR = BW / K, G16 = LPR / 16;
+    const int EPL = (C + LPR - 1) / LPR;  // <= 16
+    double normacc = 0.0;
+    auto lse_a = [&](int c) {
+      const int rows = rows_of(c), rr = hid / LPR, sub = hid - rr * LPR;
+      if (rows <= 0) return;
+      const float* e = ering + ((c % NBE) * K + min(rr, rows - 1)) * CS + sub * EPL;
+      float x[16];
+      float m = NEGF;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        x[i] = (i < EPL && sub * EPL + i < C) ? e[i] : NEGF;
+        m = fmaxf(m, x[i]);
+      }
+      m = row16_max(m);
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += (i < EPL) ? ex2(x[i] - m) : 0.0f;
+      sum = row16_sum(sum);
+      if ((hid & 15) == 0 && rr < rows) {
+        float* p = M.lsep + (c & 1) * 256 + (rr * 8 + (sub >> 4)) * 2;
+        p[0] = m;
+        p[1] = sum;
+      }
+    };
+    auto lse_b = [&](int c) {
+      const int rows = rows_of(c);
+      if (hid < rows) {
+        const float* p = M.lsep + (c & 1) * 256 + hid * 16;
+        float Mx = p[0];
+#pragma unroll
+        for (int k = 1; k < G16; ++k) Mx = fmaxf(Mx, p[2 * k]);
+        float S = 0.0f;
+#pragma unroll
+        for (int k = 0; k < G16; ++k) S += p[2 * k + 1] * ex2(p[2 * k] - Mx);
+        const float l2 = Mx + lg2(S);
+        if (P.rowlse) P.rowlse[c * K + hid] = l2;
+        normacc += double(l2);
+      }
+    };
+    // prologue: chunk 0 landed, chunks 1 .. D requested
+    issue(st[0], 0);
+    land(st[0], 0);
+#pragma unroll
+    for (int c = 1; c <= D; ++c) issue(st[c % D], c);
+    lds_barrier();
+    for (int tau0 = 0; tau0 < nticks; tau0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int tau = tau0 + d;
+        if (tau >= nticks) break;
+        GTNX_TM(0);
+        // chunk tau + 1 lands (its ring block was last read a tick ago), chunk tau + 1 + D is requested
+        land(st[(d + 1) % D], tau + 1);
+        GTNX_TM(1);
+        issue(st[(d + 1) % D], tau + 1 + D);
+        GTNX_TM(2);
+        if (want_lse) {
+          if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
+          if (tau < nblocks) lse_a(tau);
+        }
+        GTNX_TM(4);
+        lds_barrier();
+        GTNX_TM(6);
+        GTNX_TM_TICK();
+      }
+    }
+    if (hid < 16) M.red[hid] = normacc;
   }
+  GTNX_TM_DUMP();
   lds_barrier();
-  if (tid == 0) {
-    double M = double(NEGF);
+  if (threadIdx.x == 0) {
+    double Mx = double(NEGF);
     for (int k = 0; k < 4; ++k)
-      if (fin[2 * k] > DEADF) M = fmax(M, find[k] + double(fin[2 * k]));
-    const bool dead = !(M > double(DEADF));
+      if (M.fin[2 * k] > DEADF) Mx = fmax(Mx, M.find[k] + double(M.fin[2 * k]));
+    const bool dead = !(Mx > double(DEADF));
     float S = 0.0f;
     for (int k = 0; k < 4; ++k)
-      if (fin[2 * k] > DEADF) S += fin[2 * k + 1] * ex2(float(find[k] + double(fin[2 * k]) - M));
-    const double z2 = dead ? double(NEGF) : M + double(lg2(S));
+      if (M.fin[2 * k] > DEADF) S += M.fin[2 * k + 1] * ex2(float(M.find[k] + double(M.fin[2 * k]) - Mx));
+    const double z2 = dead ? double(NEGF) : Mx + double(lg2(S));
     P.aoff[0] = z2;
     P.score[0] = dead ? -__builtin_inff() : float(z2 * LN2);
     if (P.norm) {
       double n2 = 0.0;
-      for (int k = 0; k < 16; ++k) n2 += red[k];
+      for (int k = 0; k < 16; ++k) n2 += M.red[k];
       P.norm[0] = n2 < double(DEADF) ? -__builtin_inff() : float(n2 * LN2);
     }
   }
@@ -555,11 +580,11 @@ __global__ __launch_bounds__(BW) void band_forward_kernel(const BandPair* __rest
 // Virtual row v = T-1-t ascends with the ticks; wave 3 leads.  LDS float atomics retire about
 // one lane per 3 clocks per CU (tools/ubench/lat.hip), so nothing is scattered: every node
 // writes its posterior to an LDS ring with a plain store, and when the last wave has left a
-// block, thread c GATHERS the nodes that carry label c (lists sorted by label come with the
-// pair) and stores the finished gradient element -- coalesced, once.
+// block, helper lane c GATHERS the nodes that carry label c (lists sorted by label come with
+// the pair) and stores the finished gradient element -- coalesced, once.
 // ==========================================================================================
-template <int NPL, bool UNIT, bool GRADG, int K>
-__global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
+template <int NPL, bool UNIT, bool GRADG, int K, bool VEC>
+__global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
   constexpr int RNk = K >= 4 ? 4 : K;
   constexpr int NP = K / RNk;
   constexpr int D = 8 / K;
@@ -567,156 +592,143 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
   const BandLds L = band_lds(C, K, NSmax, true);
-  float* ering = lds + L.o_ering;    // [NBG blocks][K][CS]    emissions (kept until the block's gradient is out)
-  float* aring = lds + L.o_aring;    // [NBE blocks][K][NSmax] alpha rows
-  float* oring = lds + L.o_gring;    // [NBG blocks][K][NSmax] node posteriors
-  int* cls = reinterpret_cast<int*>(lds + L.o_scratch);      // [C] start, [C] end of a label's run in snode
-  int* snode = cls + 2 * C;                                  // [n_lab] nodes sorted by (label, node)
-  double* offr = reinterpret_cast<double*>(lds + L.o_misc);  // [4 waves][16 periods]
-  float* bndr = lds + L.o_misc + 168;                        // [4 waves][4K rows][2]
-  float* lser = bndr + 32 * K;                               // [NBG blocks][K] row log-sum-exp (softmax term)
+  float* ering = lds + L.o_ering;  // [NBG blocks][K][CS]    emissions (kept until the block's gradient is out)
+  float* aring = lds + L.o_aring;  // [NBE blocks][K][NSmax] alpha rows
+  float* oring = lds + L.o_oring;  // [NBG blocks][K][NSmax] node posteriors
+  int* snode = reinterpret_cast<int*>(lds + L.o_snode);  // [n_lab] nodes sorted by (label, node)
+  const BandMisc M = band_misc<K>(lds, L);
+  float* lser = M.lsep;            // [NBG blocks][K] row log-sum-exp (softmax term)
   const int CS = L.CS;
-  const int tid = threadIdx.x;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lag = 3 - w;
-  const int l = tid & 63;
-  const int m0 = tid * NPL;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool sweeper = wv < 4;
+  const int l = threadIdx.x & 63;
   const int nblocks = (T + K - 1) / K;
+  const int nticks = nblocks + 4;  // block c is drained at tick c + 4
   const GTNX_G double* ao = P.aoff;
   const double z2 = ao[0];
   const bool dead = !(z2 > double(DEADF));
   const float ds = P.delta[0];
   const bool want_em = P.grad_em != nullptr;
-  const bool vec = __builtin_amdgcn_readfirstlane(int(C % 4 == 0 && (reinterpret_cast<uintptr_t>(P.em) & 15) == 0));
-  const float dn = P.delta_norm ? P.delta_norm[0] : 0.0f;
-  const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
+  GTNX_TM_INIT(64);
 
-  NodeRegs<NPL> g;
-  load_nodes<NPL, true>(P, m0, g);
-  float b[NPL], ahi[NPL], acc[3][NPL];
+  if (sweeper) {
+    // ------------------------------------------------------------------ the recursion: no global loads in the loop
+    const int w = wv;
+    const int lag = 3 - w;
+    const int m0 = threadIdx.x * NPL;
+    NodeRegs<NPL> g;
+    load_nodes<NPL, true>(P, m0, g);
+    float b[NPL], ahi[NPL], acc[3][NPL];
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) {
-    b[j] = g.accept[j] ? 0.0f : NEGF;
-    ahi[j] = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
-    acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
-  }
-  // frames: true alpha[r] = stored + ao[1 + (r >> lgrn) * 4 + w] (periods of the FORWARD launch); true beta = b + bsum
-  auto aoff_of = [&](int r) { return ao[1 + (min(max(r, 0), T) >> P.lgrn) * 4 + w]; };
-  double Ahi = aoff_of(T);
-  double bsum = 0.0;
-  double Acur[K], Anext[K];
+    for (int j = 0; j < NPL; ++j) {
+      b[j] = g.accept[j] ? 0.0f : NEGF;
+      ahi[j] = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
+      acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+    }
+    // frames: true alpha[r] = stored + ao[1 + (r >> lgrn) * 4 + w] (periods of the FORWARD launch); true beta = b + bsum
+    double Ahi = ao[1 + (T >> P.lgrn) * 4 + w];
+    double bsum = 0.0;
+    // pipeline position s = 3 - w: this wave publishes into region s + 1 and reads region s (0: constants)
+    float* bnd_own = M.bndr + (4 - w) * 4 * K * 2;
+    const float* bnd_prev = M.bndr + (3 - w) * 4 * K * 2;
+    double* off_own = M.offr + (4 - w) * 16;
+    const double* off_prev = M.offr + (3 - w) * 16;
+    if (threadIdx.x < 8 * K) M.bndr[threadIdx.x] = NEGF;
+    if (threadIdx.x < 16) M.offr[threadIdx.x] = 0.0;
+    if (l == 0) off_own[0] = 0.0;
+    lds_barrier();  // (the helpers sort labels in the posterior ring ...
+    lds_barrier();  //  ... done)
+    const int tid = threadIdx.x;
+    const float dn = P.delta_norm ? P.delta_norm[0] : 0.0f;
+    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
+    const int* cls = reinterpret_cast<const int*>(oring);
+    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+    // this lane's labels (tid, tid + 256, ...): run of nodes, the first two inline
+    constexpr int NCS = 8 / K;  // C <= 2048 / K labels, 256 per round
+    int cs_s[NCS], cs_e[NCS], cs_n0[NCS], cs_n1[NCS];
+    float cs_m0[NCS], cs_m1[NCS];
 #pragma unroll
-  for (int i = 0; i < K; ++i) Acur[i] = aoff_of(T - 1 - i);  // block 0: t = T-1-i
-  if (l == 0) offr[w * 16] = 0.0;
-  // label -> run of nodes
-  for (int c = tid; c < 2 * C; c += BW) cls[c] = 0;
-  __syncthreads();
-  for (int i = tid; i < P.n_lab; i += BW) {
-    const int lab = P.slab[i];
-    snode[i] = P.snode[i];
-    if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
-    if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
-  }
-
-  // ---- staging: chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; HBM rows tlo ..
-  Stage<8> se[D], sa[D];
-  float lse_s[D];
-  auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-  auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
-  auto issue = [&](int d, int c) {
-    const int rows = rows_of(c), tlo = tlo_of(c);
-    se[d].issue(P.em + int64_t(tlo) * C, rows * C, vec, tid);
-    sa[d].issue(P.alpha + int64_t(tlo) * NS, rows * NS, true, tid);
-    lse_s[d] = (soft && tid < rows) ? P.rowlse[tlo + tid] : 0.0f;
-  };
-  // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block
-  auto land = [&](int d, int c) {
-    const int rows = rows_of(c);
-    if (rows <= 0) return;
-    float* eb = ering + (c % NBG) * K * CS;
-    float* ab = aring + (c % NBE) * K * NSmax;
-    se[d].each(rows * C, C, vec, tid, [&](int, int, int r, int col, gtnx_f4 q) {
-      float* dd = eb + (rows - 1 - r) * CS + col;
-      const gtnx_f4 q2 = {em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-      if (vec) *reinterpret_cast<gtnx_f4*>(dd) = q2;
-      else dd[0] = q2.x;
-    });
-    sa[d].each(rows * NS, NS, true, tid, [&](int, int, int r, int col, gtnx_f4 q) {
-      *reinterpret_cast<gtnx_f4*>(ab + (rows - 1 - r) * NSmax + col) = q;
-    });
-    if (tid < rows) lser[(c % NBG) * K + rows - 1 - tid] = lse_s[d];
-  };
-  // gradient rows of block c (every wave is through with it): gather by label, add the
-  // normaliser's softmax term, store
-  auto drain = [&](int c) {
-    const int rows = rows_of(c);
-    if (!want_em || rows <= 0) return;
-    const float* ob = oring + (c % NBG) * K * NSmax;
-    const float* eb = ering + (c % NBG) * K * CS;
-    const float* lb = lser + (c % NBG) * K;
-    GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
-    for (int cc = tid; cc < C; cc += BW) {
-      float sum[K];
+    for (int s = 0; s < NCS; ++s) {
+      const int cc = tid + s * BW;
+      cs_s[s] = cs_e[s] = 0;
+      if (cc < C && cc != P.hot) {
+        cs_s[s] = cls[cc];
+        cs_e[s] = cls[C + cc];
+      }
+      const int cnt = cs_e[s] - cs_s[s];
+      cs_n0[s] = cnt > 0 ? snode[cs_s[s]] : 0;
+      cs_n1[s] = cnt > 1 ? snode[cs_s[s] + 1] : 0;
+      cs_m0[s] = cnt > 0 ? 1.0f : 0.0f;
+      cs_m1[s] = cnt > 1 ? 1.0f : 0.0f;
+    }
+    const int hot_s = P.hot >= 0 ? cls[P.hot] : 0, hot_e = P.hot >= 0 ? cls[C + P.hot] : 0;
+    int hn[4];  // this lane's share of the hot label's nodes (at most 256 + ... of them inline)
+    float hm[4];
 #pragma unroll
-      for (int r = 0; r < K; ++r) sum[r] = 0.0f;
-      if (cc != P.hot) {
-        for (int i = cls[cc], e = dead ? 0 : cls[C + cc]; i < e; ++i) {
-          const float* o = ob + snode[i];
+    for (int k = 0; k < 4; ++k) {
+      const int i = hot_s + l + 64 * k;
+      hn[k] = i < hot_e ? snode[i] : 0;
+      hm[k] = i < hot_e ? 1.0f : 0.0f;
+    }
+    // gradient rows of block c (every sweeper is through with it): gather by label, add the
+    // normaliser's softmax term, store
+    auto drain = [&](int c) {
+      const int rows = rows_of(c);
+      if (!want_em || rows <= 0) return;
+      const float* ob = oring + (c % NBG) * K * NSmax;
+      const float* eb = ering + (c % NBG) * K * CS;
+      const float* lb = lser + (c % NBG) * K;
+      GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
 #pragma unroll
-          for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
-        }
+      for (int s = 0; s < NCS; ++s) {
+        const int cc = tid + s * BW;
+        if (cc < C && cc != P.hot) {
+          float sum[K];
 #pragma unroll
-        for (int r = 0; r < K; ++r)
-          if (r < rows) {
-            const float sm = soft ? dn * ex2(eb[r * CS + cc] - lb[r]) : 0.0f;
-            dst[-int64_t(r) * C + cc] = sum[r] + sm;
+          for (int r = 0; r < K; ++r)
+            sum[r] = dead ? 0.0f : ob[r * NSmax + cs_n0[s]] * cs_m0[s] + ob[r * NSmax + cs_n1[s]] * cs_m1[s];
+          for (int i = cs_s[s] + 2; i < cs_e[s] && !dead; ++i) {
+            const float* o = ob + snode[i];
+#pragma unroll
+            for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
           }
-      }
-    }
-    if (P.hot >= 0 && w < rows) {  // the label most nodes carry (CTC: blank): one wave per row
-      const int r = w;
-      float part = 0.0f;
-      for (int i = cls[P.hot] + l, e = dead ? 0 : cls[C + P.hot]; i < e; i += 64) part += ob[r * NSmax + snode[i]];
-      part = wave_sum63(part);
-      if (l == 63) {
-        const float sm = soft ? dn * ex2(eb[r * CS + P.hot] - lb[r]) : 0.0f;
-        dst[-int64_t(r) * C + P.hot] = part + sm;
-      }
-    }
-  };
-
-  // ---- prologue: chunk 0 landed, chunks 1 .. D requested
-  issue(0, 0);
-  land(0, 0);
 #pragma unroll
-  for (int c = 1; c <= D; ++c) issue(c % D, c);
-  lds_barrier();
-
-  const int nticks = nblocks + 4;  // block c is drained at tick c + 4
-  GTNX_TM_INIT(32);
-  for (int tau0 = 0; tau0 < nticks; tau0 += D) {
+          for (int r = 0; r < K; ++r)
+            if (r < rows) {
+              const float sm = soft ? dn * ex2(eb[r * CS + cc] - lb[r]) : 0.0f;
+              dst[-int64_t(r) * C + cc] = sum[r] + sm;
+            }
+        }
+      }
+      if (P.hot >= 0 && w < rows) {  // the label most nodes carry (CTC: blank): one wave per row
+        const int r = w;
+        float part = 0.0f;
+        if (!dead) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      const int tau = tau0 + d;
-      if (tau >= nticks) break;
+          for (int k = 0; k < 4; ++k) part += ob[r * NSmax + hn[k]] * hm[k];
+          for (int i = hot_s + l + 256; i < hot_e; i += 64) part += ob[r * NSmax + snode[i]];
+        }
+        part = wave_sum63(part);
+        if (l == 63) {
+          const float sm = soft ? dn * ex2(eb[r * CS + P.hot] - lb[r]) : 0.0f;
+          dst[-int64_t(r) * C + P.hot] = part + sm;
+        }
+      }
+    };
+    lds_barrier();  // the label table is in registers: the posterior ring may be written
+    for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      land((d + 1) % D, tau + 1);
-      GTNX_TM(1);
-      issue((d + 1) % D, tau + 1 + D);
-      GTNX_TM(2);
-      if (tau >= 4) drain(tau - 4);  // the last wave left it a tick ago; its stores have a tick to retire
+      if (tau >= 4) drain(tau - 4);  // the last wave left block tau - 4 a tick ago
       GTNX_TM(3);
       const int beta = tau - lag;
-      // alpha frames of the next block's rows: in flight for a whole tick
-#pragma unroll
-      for (int i = 0; i < K; ++i) Anext[i] = aoff_of(T - 1 - (beta + 1) * K - i);
       if (beta >= 0 && beta < nblocks && !dead) {
         const int v0 = beta * K, rows = min(K, T - v0);
         const float* eb = ering + (beta % NBG) * K * CS;
         const float* ab = aring + (beta % NBE) * K * NSmax;
+        const double* Ab = M.aofr + ((beta % NBE) * K) * 4 + w;
         float* ob = oring + (beta % NBG) * K * NSmax + m0;
         float ev[K][NPL], alov[K][NPL], bq1[K], bq2[K];
-        double offp[NP + 1];
+        double Acur[K], offp[NP + 1];
 #pragma unroll
         for (int i = 0; i < K; ++i) {
 #pragma unroll
@@ -724,21 +736,20 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
             ev[i][j] = eb[i * CS + g.lab[j]];
             alov[i][j] = ab[i * NSmax + min(m0 + j, NSmax - 1)];
           }
-          bq1[i] = bq2[i] = NEGF;
-          if (w < 3) {  // q[v0 + i] of the two nodes above this wave, in the next wave's frame
-            const float* bp = bndr + ((w + 1) * 4 * K + (beta & 3) * K + i) * 2;
-            bq1[i] = bp[0];
-            bq2[i] = bp[1];
-          }
+          Acur[i] = Ab[i * 4];
+          // q[v0 + i] of the two nodes above this wave, in the next wave's frame
+          const float* bp = bnd_prev + ((beta & 3) * K + i) * 2;
+          bq1[i] = bp[0];
+          bq2[i] = bp[1];
         }
 #pragma unroll
-        for (int q = 0; q <= NP; ++q) offp[q] = w < 3 ? offr[(w + 1) * 16 + ((beta * NP + q) & 15)] : 0.0;
+        for (int q = 0; q <= NP; ++q) offp[q] = off_prev[(beta * NP + q) & 15];
         float qh[K][NPL];
         float dconv = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
           if (i < rows) {
-            if (i % RNk == 0 && w < 3) dconv = float(offp[i / RNk] - bsum);
+            if (i % RNk == 0) dconv = float(offp[i / RNk] - bsum);
             const double bz = bsum - z2;
             float q[NPL];
 #pragma unroll
@@ -781,10 +792,7 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
               }
             }
             if ((i + 1) % RNk == 0) {  // shift this wave's beta row v0 + i + 1 by its maximum
-              float mx = nb[0];
-#pragma unroll
-              for (int j = 1; j < NPL; ++j) mx = fmaxf(mx, nb[j]);
-              mx = wave_max(mx);
+              const float mx = wave_max_of(nb, NPL);
               if (mx > DEADF) {
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) nb[j] -= mx;
@@ -792,7 +800,7 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
               } else if (w < 3) {
                 bsum = offp[(i + 1) / RNk];
               }
-              if (l == 0) offr[w * 16 + (((v0 + i + 1) / RNk) & 15)] = bsum;
+              if (l == 0) off_own[((v0 + i + 1) / RNk) & 15] = bsum;
             }
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
 #pragma unroll
           for (int i = 0; i < K; ++i)
             if (i < rows) {
-              float* bp = bndr + (w * 4 * K + (beta & 3) * K + i) * 2;
+              float* bp = bnd_own + ((beta & 3) * K + i) * 2;
               if (NPL == 1) {
                 bp[l] = qh[i][0];
               } else {
@@ -817,21 +825,91 @@ __global__ __launch_bounds__(BW) void band_backward_kernel(const BandPair* __res
             }
         }
       }
-#pragma unroll
-      for (int i = 0; i < K; ++i) Acur[i] = Anext[i];
       GTNX_TM(5);
       lds_barrier();
       GTNX_TM(6);
       GTNX_TM_TICK();
     }
-  }
-  GTNX_TM_DUMP();
-  if (GRADG && P.grad_fixed && !dead) {
+    GTNX_TM_DUMP();
+    if (GRADG && P.grad_fixed && !dead) {
 #pragma unroll
-    for (int j = 0; j < NPL; ++j)
+      for (int j = 0; j < NPL; ++j)
 #pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (g.ao[k][j] >= 0) P.grad_fixed[g.ao[k][j]] = acc[k][j] * ds;
+        for (int k = 0; k < 3; ++k)
+          if (g.ao[k][j] >= 0) P.grad_fixed[g.ao[k][j]] = acc[k][j] * ds;
+    }
+  } else {
+    // ------------------------------------------------------------------ helpers: staging, gradient rows
+    const int hid = threadIdx.x - BW;
+    constexpr bool vec = VEC;
+    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
+    // label -> run of nodes in snode (table built in the posterior ring, which is idle until the first tick)
+    int* cls = reinterpret_cast<int*>(oring);
+    for (int c = hid; c < 2 * C; c += BW) cls[c] = 0;
+    lds_barrier();
+    for (int i = hid; i < P.n_lab; i += BW) {
+      const int lab = P.slab[i];
+      snode[i] = P.snode[i];
+      if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
+      if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
+    }
+    // ---- staging: chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; HBM rows tlo ..
+    Stage<8> se[D], sa[D];
+    float lse_s[D] = {};
+    double af_s[D] = {};
+    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+    auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
+    auto issue = [&](int d, int c) {
+      const int rows = rows_of(c), tlo = tlo_of(c);
+      se[d].template issue<VEC>(P.em + int64_t(tlo) * C, rows * C, hid);
+      sa[d].template issue<true>(P.alpha + int64_t(tlo) * NS, rows * NS, hid);
+      if (rows > 0) {  // uniform; unconditional clamped loads (see Stage::issue)
+        if (soft) lse_s[d] = P.rowlse[tlo + min(hid, rows - 1)];
+        // alpha frame of ring row i = hid / 4 (t = T-1-cK-i) for sweeper wave hid % 4
+        af_s[d] = ao[1 + ((T - 1 - c * K - min(hid >> 2, rows - 1)) >> P.lgrn) * 4 + (hid & 3)];
+      }
+    };
+    // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block
+    auto land = [&](int d, int c) {
+      const int rows = rows_of(c);
+      if (rows <= 0) return;
+      float* eb = ering + (c % NBG) * K * CS;
+      float* ab = aring + (c % NBE) * K * NSmax;
+      se[d].template each<VEC>(rows * C, C, hid, [&](int, int, int r, int col, gtnx_f4 q) {
+        float* dd = eb + (rows - 1 - r) * CS + col;
+        const gtnx_f4 q2 = {em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
+        if (vec) *reinterpret_cast<gtnx_f4*>(dd) = q2;
+        else dd[0] = q2.x;
+      });
+      sa[d].template each<true>(rows * NS, NS, hid, [&](int, int, int r, int col, gtnx_f4 q) {
+        *reinterpret_cast<gtnx_f4*>(ab + (rows - 1 - r) * NSmax + col) = q;
+      });
+      if (hid < rows) lser[(c % NBG) * K + rows - 1 - hid] = lse_s[d];
+      if (hid < 4 * rows) M.aofr[((c % NBE) * K) * 4 + hid] = af_s[d];
+    };
+    // prologue: chunk 0 landed, chunks 1 .. D requested
+    issue(0, 0);
+    land(0, 0);
+#pragma unroll
+    for (int c = 1; c <= D; ++c) issue(c % D, c);
+    lds_barrier();
+    lds_barrier();  // (the sweepers read their label runs; then the posterior ring is theirs)
+    for (int tau0 = 0; tau0 < nticks; tau0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int tau = tau0 + d;
+        if (tau >= nticks) break;
+        GTNX_TM(0);
+        land((d + 1) % D, tau + 1);
+        GTNX_TM(1);
+        issue((d + 1) % D, tau + 1 + D);
+        GTNX_TM(2);
+        lds_barrier();
+        GTNX_TM(6);
+        GTNX_TM_TICK();
+      }
+    }
+    GTNX_TM_DUMP();
   }
 }
 
@@ -840,25 +918,36 @@ void big_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
 }
 
-template <int NPL, int K>
-void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, hipStream_t st) {
-  static bool attr = (big_lds(band_forward_kernel<NPL, true, K>), big_lds(band_forward_kernel<NPL, false, K>), true);
+template <int NPL, int K, bool VEC>
+void launch_fwd2(const BandPair* d, int n, int ns, size_t lds, bool unit, hipStream_t st) {
+  static bool attr = (big_lds(band_forward_kernel<NPL, true, K, VEC>), big_lds(band_forward_kernel<NPL, false, K, VEC>), true);
   (void)attr;
-  if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true, K>), dim3(n), dim3(BW), lds, st, d, ns);
-  else hipLaunchKernelGGL((band_forward_kernel<NPL, false, K>), dim3(n), dim3(BW), lds, st, d, ns);
+  if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
+  else hipLaunchKernelGGL((band_forward_kernel<NPL, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
 }
 template <int NPL, int K>
-void launch_bwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
-  static bool attr = (big_lds(band_backward_kernel<NPL, true, true, K>), big_lds(band_backward_kernel<NPL, true, false, K>),
-                      big_lds(band_backward_kernel<NPL, false, true, K>), big_lds(band_backward_kernel<NPL, false, false, K>), true);
+void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool vec, hipStream_t st) {
+  if (vec) launch_fwd2<NPL, K, true>(d, n, ns, lds, unit, st);
+  else launch_fwd2<NPL, K, false>(d, n, ns, lds, unit, st);
+}
+template <int NPL, int K, bool VEC>
+void launch_bwd2(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+  static bool attr =
+      (big_lds(band_backward_kernel<NPL, true, true, K, VEC>), big_lds(band_backward_kernel<NPL, true, false, K, VEC>),
+       big_lds(band_backward_kernel<NPL, false, true, K, VEC>), big_lds(band_backward_kernel<NPL, false, false, K, VEC>), true);
   (void)attr;
   if (unit) {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K>), dim3(n), dim3(BW), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K>), dim3(n), dim3(BW), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
   } else {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K>), dim3(n), dim3(BW), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K>), dim3(n), dim3(BW), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
   }
+}
+template <int NPL, int K>
+void launch_bwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, hipStream_t st) {
+  if (vec) launch_bwd2<NPL, K, true>(d, n, ns, lds, unit, gradg, st);
+  else launch_bwd2<NPL, K, false>(d, n, ns, lds, unit, gradg, st);
 }
 
 constexpr size_t LDS_TWO = 78 * 1024;   // two workgroups per CU
@@ -882,32 +971,33 @@ int band_block_rows(int C, int max_NS, bool backward) {
   return 0;
 }
 
-void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, hipStream_t st) {
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st) {
   if (n <= 0) return;
   const int K = band_block_rows(C, 0, false);  // the forward sweep stages no alpha rows
   const size_t lds = 4 * size_t(band_lds(C, K, max_NS, false).total) + 64;
   if (npl == 1) {
-    if (K == 8) launch_fwd<1, 8>(d_pairs, n, max_NS, lds, unit, st);
-    else if (K == 4) launch_fwd<1, 4>(d_pairs, n, max_NS, lds, unit, st);
-    else launch_fwd<1, 2>(d_pairs, n, max_NS, lds, unit, st);
+    if (K == 8) launch_fwd<1, 8>(d_pairs, n, max_NS, lds, unit, vec, st);
+    else if (K == 4) launch_fwd<1, 4>(d_pairs, n, max_NS, lds, unit, vec, st);
+    else launch_fwd<1, 2>(d_pairs, n, max_NS, lds, unit, vec, st);
   } else {
-    if (K == 8) launch_fwd<2, 8>(d_pairs, n, max_NS, lds, unit, st);
-    else if (K == 4) launch_fwd<2, 4>(d_pairs, n, max_NS, lds, unit, st);
-    else launch_fwd<2, 2>(d_pairs, n, max_NS, lds, unit, st);
+    if (K == 8) launch_fwd<2, 8>(d_pairs, n, max_NS, lds, unit, vec, st);
+    else if (K == 4) launch_fwd<2, 4>(d_pairs, n, max_NS, lds, unit, vec, st);
+    else launch_fwd<2, 2>(d_pairs, n, max_NS, lds, unit, vec, st);
   }
 }
 
 // every pair of the launch shares C; max_NS: largest alpha row stride of the launch
-void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, hipStream_t st) {
+void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
+                          hipStream_t st) {
   if (n <= 0) return;
   const int K = band_block_rows(C, max_NS, true);
   const size_t lds = 4 * size_t(band_lds(C, K, max_NS, true).total) + 64;
   if (npl == 1) {
-    if (K == 4) launch_bwd<1, 4>(d_pairs, n, max_NS, lds, unit, gradg, st);
-    else launch_bwd<1, 2>(d_pairs, n, max_NS, lds, unit, gradg, st);
+    if (K == 4) launch_bwd<1, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
+    else launch_bwd<1, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
   } else {
-    if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, st);
-    else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, st);
+    if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
+    else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
   }
 }
 

@@ -399,9 +399,10 @@ int band_max_labels();
 int band_npl(int max_nodes);               // nodes per lane: 1 or 2
 int band_row_stride(int N, int npl);       // NS
 int band_forward_lgrn(int C);
-// all pairs of one launch share C and npl; unit: self-loop + previous-node arc at every node, all weights 0
-void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, hipStream_t st);
-void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg,
+// all pairs of one launch share C and npl; unit: self-loop + previous-node arc at every node, all weights 0;
+// vec: C % 4 == 0 and every pair's emissions are 16-byte aligned (16-byte staging loads)
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st);
+void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
                           hipStream_t st);
 // dense regime
 void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set

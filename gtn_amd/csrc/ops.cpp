@@ -2086,13 +2086,14 @@ struct BandSdOp : OpRecord {
   DevMemP arena;                // alpha planes, row shifts, scores
 
   struct Key {
-    int C, npl, unit, gradg;
+    int C, npl, unit, gradg, vec;
     bool operator<(const Key& o) const {
-      return std::tie(C, npl, unit, gradg) < std::tie(o.C, o.npl, o.unit, o.gradg);
+      return std::tie(C, npl, unit, gradg, vec) < std::tie(o.C, o.npl, o.unit, o.gradg, o.vec);
     }
     bool operator==(const Key& o) const { return !(*this < o) && !(o < *this); }
   };
-  // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient)
+  static int band_vec(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
+  // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
   static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward) {
     Runtime& rt = Runtime::get();
     if (tab.empty()) return;
@@ -2108,9 +2109,9 @@ struct BandSdOp : OpRecord {
       while (i1 < tab.size() && tab[i1].first == tab[i0].first) max_ns = std::max(max_ns, tab[i1++].second.NS);
       const Key& k = tab[i0].first;
       if (backward)
-        launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, rt.stream());
+        launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, k.vec != 0, rt.stream());
       else
-        launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, rt.stream());
+        launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.vec != 0, rt.stream());
       i0 = i1;
     }
   }
@@ -2143,7 +2144,7 @@ struct BandSdOp : OpRecord {
       p.delta_norm = nullptr;
       p.grad_em = chains[i].calc_grad() ? gem->as<float>(eo[k]) : nullptr;
       p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
-      tab.push_back({Key{p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0}, p});
+      tab.push_back({Key{p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0, band_vec(p)}, p});
       if (p.grad_em) sink.add(chains[i], gem, p.grad_em);
       if (p.grad_fixed) sink.add(fixed[i], gfx, p.grad_fixed);
       ms[k].out.g->inputs[0].g->grad_propagated = true;
@@ -2219,7 +2220,7 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     p.score = op->arena->as<float>(4 * i);
     p.hot = b.hot;
     p.lgrn = band_forward_lgrn(p.C);
-    tab.push_back({BandSdOp::Key{p.C, band_npl(p.N), int(op->unit[i]), 0}, p});
+    tab.push_back({BandSdOp::Key{p.C, band_npl(p.N), int(op->unit[i]), 0, BandSdOp::band_vec(p)}, p});
     abytes += 4.0 * p.T * p.C + 4.0 * double(p.T + 1) * p.NS;  // emissions in, alpha out (kept for the backward sweep)
   }
   {

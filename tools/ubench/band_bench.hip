@@ -108,9 +108,9 @@ int main(int argc, char** argv) {
   const int reps = 20;
   for (int it = 0; it < reps + 3; ++it) {
     CK(hipEventRecord(e0, 0));
-    launch_band_forward(d_pairs, B, npl, C, NS, true, 0);
+    launch_band_forward(d_pairs, B, npl, C, NS, true, C % 4 == 0, 0);
     CK(hipEventRecord(e1, 0));
-    launch_band_backward(d_pairs, B, npl, C, NS, true, gradg, 0);
+    launch_band_backward(d_pairs, B, npl, C, NS, true, gradg, C % 4 == 0, 0);
     CK(hipEventRecord(e2, 0));
     CK(hipEventSynchronize(e2));
     float f, bw;
@@ -129,14 +129,14 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(sc.data(), d_score, 4 * B, hipMemcpyDeviceToHost));
   printf("score[0..3] %.4f %.4f %.4f %.4f\n", sc[0], sc[1], sc[2], sc[3]);
 #ifdef GTNX_BAND_TIMING
-  long long h[64];
+  long long h[128];
   CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(::g_band_timing), sizeof(h)));
   for (int k = 0; k < 2; ++k) {
     printf("%s timing, workgroup 0, cycles per tick (loop | land | issue | store/drain | lse | compute | barrier), ticks %lld\n",
-           k ? "backward" : "forward", h[k * 32 + 31]);
-    for (int wv = 0; wv < 4; ++wv) {
+           k ? "backward" : "forward", h[k * 64 + 63]);
+    for (int wv = 0; wv < 8; ++wv) {
       printf("  wave %d:", wv);
-      for (int i = 0; i < 7; ++i) printf(" %6.0f", double(h[k * 32 + wv * 7 + i]) / double(h[k * 32 + 31] ? h[k * 32 + 31] : 1));
+      for (int i = 0; i < 7; ++i) printf(" %6.0f", double(h[k * 64 + wv * 7 + i]) / double(h[k * 64 + 63] ? h[k * 64 + 63] : 1));
       printf("\n");
     }
   }

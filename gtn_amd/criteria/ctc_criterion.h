@@ -17,16 +17,26 @@ namespace criteria {
 
 /** target acceptor: 2U+1 states, blank at even states, skip arcs between different labels */
 inline Graph ctcTargetGraph(const std::vector<int>& target, int blank = 0, bool calcGrad = true) {
-  const size_t L = 2 * target.size() + 1;
-  Graph ctc(calcGrad);
-  for (size_t l = 0; l < L; l++) {
-    const size_t idx = (l - 1) / 2;
-    ctc.addNode(l == 0, l == L - 1 || l + 2 == L);
+  // the graph of benchmarks/ctc.cpp:40-58, handed to the engine in two bulk calls (same node and
+  // arc order as the reference's addNode / addArc loop)
+  const int L = 2 * (int)target.size() + 1;
+  std::vector<uint8_t> st(L, 0), ac(L, 0);
+  std::vector<int> src, dst, lab;
+  src.reserve(3 * L);
+  dst.reserve(3 * L);
+  lab.reserve(3 * L);
+  for (int l = 0; l < L; l++) {
+    const int idx = (l - 1) / 2;
+    st[l] = l == 0;
+    ac[l] = l == L - 1 || l + 2 == L;
     const int label = l % 2 ? target[idx] : blank;
-    ctc.addArc(l, l, label);
-    if (l > 0) ctc.addArc(l - 1, l, label);
-    if (l % 2 && l > 1 && label != target[idx - 1]) ctc.addArc(l - 2, l, label);
+    src.push_back(l), dst.push_back(l), lab.push_back(label);
+    if (l > 0) src.push_back(l - 1), dst.push_back(l), lab.push_back(label);
+    if (l % 2 && l > 1 && label != target[idx - 1]) src.push_back(l - 2), dst.push_back(l), lab.push_back(label);
   }
+  Graph ctc(calcGrad);
+  detail::check(gtnx_graph_add_nodes(ctc.handle(), L, st.data(), ac.data()));
+  detail::check(gtnx_graph_add_arcs(ctc.handle(), (int)src.size(), src.data(), dst.data(), lab.data(), lab.data(), nullptr));
   ctc.arcSort();
   return ctc;
 }

@@ -148,15 +148,13 @@ GTNX_API gtnx_status_t gtnx_graph_add_arc(gtnx_graph_t g, int src, int dst, int 
 }
 GTNX_API gtnx_status_t gtnx_graph_add_nodes(gtnx_graph_t g, int n, const uint8_t* s, const uint8_t* a) {
   return guard([&] {
-    Graph& gr = G(g);
-    for (int i = 0; i < n; ++i) gr.add_node(s && s[i], a && a[i]);
+    G(g).add_nodes(n, s, a);
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_arcs(gtnx_graph_t g, int n, const int* src, const int* dst, const int* il,
                                            const int* ol, const float* w) {
   return guard([&] {
-    Graph& gr = G(g);
-    for (int i = 0; i < n; ++i) gr.add_arc(src[i], dst[i], il[i], ol[i], w ? w[i] : 0.0f);
+    G(g).add_arcs(n, src, dst, il, ol, w);
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_num_nodes(gtnx_graph_t g, int64_t* out) {

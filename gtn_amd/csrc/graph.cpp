@@ -27,6 +27,7 @@ void Structure::touch() {
   rec_mem.reset();
   sched.reset();
   csr_valid = false;
+  sort_pending = 0;
   max_deg = -1;
   band[0].reset();
   band[1].reset();
@@ -68,26 +69,26 @@ std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel) {
     b->unit_shape = b->nodes[m].aid[0] >= 0 && (m == 0 || b->nodes[m].aid[1] >= 0);
   // nodes by label (the backward sweep gathers posteriors by label); the label most nodes
   // share gets a wave of its own
-  std::vector<std::pair<int, int>> ln;
+  std::vector<uint64_t> ln;  // (label, node) keys
   ln.reserve(N);
   for (size_t m = 0; m < N; ++m)
-    if (b->nodes[m].lab >= 0) ln.push_back({b->nodes[m].lab, int(m)});
+    if (b->nodes[m].lab >= 0) ln.push_back((uint64_t(uint32_t(b->nodes[m].lab)) << 32) | uint64_t(m));
   std::sort(ln.begin(), ln.end());
   b->snode.resize(ln.size());
   b->slab.resize(ln.size());
   size_t best = 0;
   for (size_t i = 0; i < ln.size();) {
     size_t j = i;
-    while (j < ln.size() && ln[j].first == ln[i].first) ++j;
+    while (j < ln.size() && (ln[j] >> 32) == (ln[i] >> 32)) ++j;
     if (j - i > best) {
       best = j - i;
-      b->hot = ln[i].first;
+      b->hot = int(ln[i] >> 32);
     }
     i = j;
   }
   for (size_t i = 0; i < ln.size(); ++i) {
-    b->slab[i] = ln[i].first;
-    b->snode[i] = ln[i].second;
+    b->slab[i] = int(ln[i] >> 32);
+    b->snode[i] = int(ln[i] & 0xffffffffu);
   }
   if (best < 8) b->hot = -1;
   return b;
@@ -325,6 +326,15 @@ void Structure::ensure_csr() {
     in_list[ci[dst[a]]++] = int(a);
   }
   csr_valid = true;
+  if (sort_pending) {  // graph.cpp:162-177, asked for before anything needed the lists
+    const std::vector<int>& key = sort_pending == 2 ? ol : il;
+    auto cmp = [&key](int a, int b) { return key[a] < key[b]; };
+    for (int64_t n = 0; n < N; ++n) {
+      std::sort(in_list.begin() + in_off[n], in_list.begin() + in_off[n + 1], cmp);
+      std::sort(out_list.begin() + out_off[n], out_list.begin() + out_off[n + 1], cmp);
+    }
+    sort_pending = 0;
+  }
 }
 
 int Structure::num_in(int n) {
@@ -395,6 +405,44 @@ int Graph::add_arc(int src, int dst, int il, int ol, float wt) {
   return idx;
 }
 
+void Graph::add_nodes(int n, const uint8_t* start, const uint8_t* accept) {
+  if (n <= 0) return;
+  s->materialize();
+  s->ensure_host();
+  s->nflags.reserve(s->nflags.size() + size_t(n));
+  for (int i = 0; i < n; ++i) {
+    const bool st = start && start[i], ac = accept && accept[i];
+    const int idx = int(s->N) + i;
+    s->nflags.push_back(uint8_t((st ? NF_START : 0) | (ac ? NF_ACCEPT : 0)));
+    if (st) s->start.push_back(idx);
+    if (ac) s->accept.push_back(idx);
+  }
+  s->N += n;
+  s->touch();
+}
+
+void Graph::add_arcs(int n, const int* src, const int* dst, const int* il, const int* ol, const float* wt) {
+  if (n <= 0) return;
+  s->materialize();
+  s->ensure_host();
+  for (int i = 0; i < n; ++i) {
+    if (src[i] < 0 || src[i] >= s->N || dst[i] < 0 || dst[i] >= s->N) throw_range("[Graph::addArc] node index out of range");
+    if (il[i] < GTNX_EPSILON || ol[i] < GTNX_EPSILON) throw_invalid("[Graph::addArc] labels must be >= epsilon");  // graph.cpp:57
+  }
+  w->ensure_host();
+  s->src.insert(s->src.end(), src, src + n);
+  s->dst.insert(s->dst.end(), dst, dst + n);
+  s->il.insert(s->il.end(), il, il + n);
+  s->ol.insert(s->ol.end(), ol, ol + n);
+  if (wt) w->host.insert(w->host.end(), wt, wt + n);
+  else w->host.resize(w->host.size() + size_t(n), 0.0f);
+  w->n = int64_t(w->host.size());
+  w->dev_valid = false;
+  w->version++;
+  s->A += n;
+  s->touch();
+}
+
 int64_t Graph::num_start() {
   if (s->kind == KIND_LINEAR) return 1;
   s->ensure_host();
@@ -416,6 +464,25 @@ float Graph::item() {
 void Graph::arc_sort(bool olabel) {
   // graph.cpp:162-177
   if ((olabel && s->olabel_sorted) || (!olabel && s->ilabel_sorted)) return;
+  if (s->kind == KIND_EXPLICIT && s->host_valid && !s->csr_valid) {
+    // nobody has looked at the per-node lists yet: sort them when they are first built.  A
+    // criterion that only takes forwardScore of a symbolic composition never needs them.
+    s->sort_pending = olabel ? 2 : 1;
+    s->dev_valid = false;
+    s->dev_mem.reset();
+    s->sched.reset();
+    s->olabel_sorted = olabel;
+    s->ilabel_sorted = !olabel;
+    // A small graph that has just been sorted is about to be composed.  Host code builds such
+    // graphs on many threads (parallelMap): take the band records now, on this thread, instead of
+    // on the one thread that later calls the batched compose.
+    if (s->N <= band_max_nodes()) {
+      band_info(*s, true);
+      if (s->il == s->ol) s->band[1] = s->band[0];  // an acceptor matches the same labels either way round
+      (void)w->is_all_zero();
+    }
+    return;
+  }
   s->ensure_csr();
   const std::vector<int>& key = olabel ? s->ol : s->il;
   auto cmp = [&key](int a, int b) { return key[a] < key[b]; };

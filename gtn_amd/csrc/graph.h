@@ -66,6 +66,7 @@ struct Structure {
   std::vector<uint8_t> nflags;
   std::vector<int> start, accept;
   bool csr_valid = false;
+  int sort_pending = 0;  // arcSort asked for before the lists existed: 1 by ilabel, 2 by olabel (applied by ensure_csr)
   std::vector<int> in_off, in_list, out_off, out_list;
 
   // ---- device mirror
@@ -145,17 +146,7 @@ struct BandInfo {
 std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel);   // host part, cached
 void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vector<Structure*>& ss);
 
-struct GradState {
-  bool calc_grad = true;
-  std::shared_ptr<OpRecord> op;  // producing op; nullptr for leaves
-  int op_idx = 0;
-  bool has_grad_fn = false;      // mirrors `gradFunc != nullptr`
-  std::vector<Graph> inputs;
-  std::unique_ptr<Graph> grad;
-  std::atomic<int> n_consumers{0};  // op outputs that list this graph as an input (two threads may reclaim at once)
-  bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
-  ~GradState();                  // gives the consumer counts of `inputs` back
-};
+struct GradState;
 
 struct Graph {
   std::shared_ptr<Structure> s;
@@ -169,6 +160,9 @@ struct Graph {
   // graph.cpp:33-67
   int add_node(bool start, bool accept);
   int add_arc(int src, int dst, int il, int ol, float w);
+  // bulk forms (one reservation, one invalidation): flags NF_START | NF_ACCEPT per node; w may be null (zeros)
+  void add_nodes(int n, const uint8_t* start, const uint8_t* accept);
+  void add_arcs(int n, const int* src, const int* dst, const int* il, const int* ol, const float* w);
   int64_t num_nodes() const { return s->N; }
   int64_t num_arcs() const { return s->A; }
   int64_t num_start();
@@ -179,11 +173,11 @@ struct Graph {
   const float* weights_host(bool mut);
   void set_weights_host(const float* p);
   void set_weights_device(const void* p);
-  bool calc_grad() const { return g->calc_grad; }
-  bool is_grad_available() const { return g->grad != nullptr; }
+  inline bool calc_grad() const;
+  inline bool is_grad_available() const;
   Graph& grad();
   void set_calc_grad(bool c);
-  void zero_grad() { g->grad.reset(); }
+  inline void zero_grad();
   uintptr_t id() const { return reinterpret_cast<uintptr_t>(g.get()); }
 
   // addGrad (graph.cpp:91-129).  `owner`/`dev` is a device vector of numArcs
@@ -191,6 +185,21 @@ struct Graph {
   void add_grad_host(const float* v, int64_t n);
   void add_grad_device(const DevMemP& owner, float* dev, bool adopt);
 };
+
+struct GradState {
+  bool calc_grad = true;
+  std::shared_ptr<OpRecord> op;  // producing op; nullptr for leaves
+  int op_idx = 0;
+  bool has_grad_fn = false;      // mirrors `gradFunc != nullptr`
+  std::vector<Graph> inputs;
+  std::unique_ptr<Graph> grad;
+  std::atomic<int> n_consumers{0};  // op outputs that list this graph as an input (two threads may reclaim at once)
+  bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
+  ~GradState();                  // gives the consumer counts of `inputs` back
+};
+inline bool Graph::calc_grad() const { return g->calc_grad; }
+inline bool Graph::is_grad_available() const { return g->grad != nullptr; }
+inline void Graph::zero_grad() { g->grad.reset(); }
 
 // Sizes of one compose batch left on the device.  For a chain product whose partner is
 // epsilon-free, no wider than a workgroup, with at most KC out-arcs per node, every

@@ -1,6 +1,8 @@
 // ops.cpp -- batched graph functions + batch-level autograd (see ops.h)
 #include "ops.h"
 
+#include "gtn/parallel.h"  // header-only worker pool (no engine dependency)
+
 #include <chrono>
 #include <tuple>
 
@@ -68,6 +70,8 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs);
 std::shared_ptr<OpRecord> make_lazy_compose_op();
 bool lazy_shape_ok(const Structure& chain, const Structure& fixed);
 bool lazy_pair_shape_ok(const Structure& chain, Structure& fixed);
+bool band_shape_ok(const Structure& chain, Structure& fixed, bool chain_first);
+void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first);
 
 template <class T>
 const T& bcast(const std::vector<T>& v, size_t n, size_t i) {
@@ -1043,6 +1047,54 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     ht_mark = now;
   };
   ht_phase("");
+  if (allow_lazy) {
+    // The criteria's hint (mode 2) with banded partners -- CTC targets: the product stays symbolic and
+    // band.hip sweeps it, so nothing of the inputs is uploaded, counted or sorted here.
+    const char* env = getenv("GTNX_LAZY_COMPOSE");
+    const int mode = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : t_compose_mode;
+    if (mode == 2 && !getenv("GTNX_NO_BAND")) {
+      bool ok = true;
+      std::vector<Graph*> fx(n);
+      std::vector<uint8_t> cf(n);
+      for (size_t i = 0; i < n && ok; ++i) {
+        Graph& a = const_cast<Graph&>(bcast(av, n, i));
+        Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+        const bool l1 = a.s->kind == KIND_LINEAR && !a.s->lazy, l2 = b.s->kind == KIND_LINEAR && !b.s->lazy;
+        ok = l1 != l2;
+        if (!ok) break;
+        fx[i] = l1 ? &b : &a;
+        cf[i] = l1;
+        ok = !fx[i]->s->lazy && !fx[i]->s->deferred && fx[i]->s->kind == KIND_EXPLICIT && fx[i]->s->host_valid;
+      }
+      if (ok) {
+        ht_phase("compose.0a_checks");
+        band_prepare(fx, cf);
+        ht_phase("compose.0b_band_prepare");
+        for (size_t i = 0; i < n && ok; ++i) {
+          Graph& a = const_cast<Graph&>(bcast(av, n, i));
+          Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+          ok = band_shape_ok(*(cf[i] ? a : b).s, *fx[i]->s, cf[i] != 0);
+        }
+      }
+      if (ok) {
+        ht_phase("compose.0c_shape_ok");
+        rt.drain_deferred();  // the step's reclamation point (see below)
+        ht_phase("compose.0d_drain");
+        auto lop = make_lazy_compose_op();
+        outs.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+          Graph& a = const_cast<Graph&>(bcast(av, n, i));
+          Graph& b = const_cast<Graph&>(bcast(bv, n, i));
+          Graph out = make_output(lop, int(i), {a, b});
+          out.s->host_valid = false;
+          out.s->lazy = std::make_shared<LazyProduct>(LazyProduct{cf[i] ? a : b, cf[i] ? b : a, cf[i] ? 1 : 2, intersect});
+          outs.push_back(std::move(out));
+        }
+        ht_phase("compose.0_symbolic_band");
+        return outs;
+      }
+    }
+  }
   for (auto& g : av) realize(g);
   for (auto& g : bv) realize(g);
   for (auto& g : av) g.s->resolve_sizes();
@@ -2069,13 +2121,32 @@ std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
 
 // ---- one workgroup per (chain, BANDED G) pair: band.hip.  CTC targets and force-alignment
 // acceptors: a single wave carries the whole recursion, the other waves stage.
-bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out = nullptr) {
-  const Structure& cs = *lp.chain.s;
+bool band_shape_ok(const Structure& cs, Structure& fs, bool chain_first) {
   if (cs.kind != KIND_LINEAR || cs.C < 1 || cs.C > band_max_labels() || cs.M < 0 || cs.M > (1 << 20)) return false;
-  std::shared_ptr<BandInfo> b = band_info(*lp.fixed.s, lp.chain_side == 1);
-  if (!b->ok || b->max_label >= cs.C) return false;
-  if (out) *out = b;
+  std::shared_ptr<BandInfo> b = band_info(fs, chain_first);
+  return b->ok && b->max_label < cs.C;
+}
+bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out = nullptr) {
+  if (!band_shape_ok(*lp.chain.s, *lp.fixed.s, lp.chain_side == 1)) return false;
+  if (out) *out = band_info(*lp.fixed.s, lp.chain_side == 1);
   return true;
+}
+// band records and the all-zero test of a batch of partners, on the worker pool (a training step
+// brings one fresh target graph per utterance); both are cached on the graph afterwards
+void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first) {
+  std::vector<size_t> todo;
+  std::unordered_set<Structure*> seen;
+  for (size_t i = 0; i < fixed.size(); ++i) {
+    Structure* st = fixed[i]->s.get();
+    if (!st->band[chain_first[i] ? 0 : 1] && seen.insert(st).second) todo.push_back(i);
+  }
+  auto body = [&](size_t q) {
+    Graph& g = *fixed[todo[q]];
+    band_info(*g.s, chain_first[todo[q]] != 0);
+    (void)g.w->is_all_zero();
+  };
+  if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 32);
+  else for (size_t q = 0; q < todo.size(); ++q) body(q);
 }
 
 struct BandSdOp : OpRecord {
@@ -2169,6 +2240,18 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
   op->unit.resize(n);
+  {
+    std::vector<Graph*> fx(n);
+    std::vector<uint8_t> cf(n);
+    for (size_t i = 0; i < n; ++i) {
+      fx[i] = &gs[i].s->lazy->fixed;
+      cf[i] = gs[i].s->lazy->chain_side == 1;
+    }
+    band_prepare(fx, cf);
+  }
+  op->chains.reserve(n);
+  op->fixed.reserve(n);
+  op->infos.reserve(n);
   for (size_t i = 0; i < n; ++i) {
     LazyProduct& lp = *gs[i].s->lazy;
     std::shared_ptr<BandInfo> b;

@@ -48,7 +48,7 @@ constexpr double LN2 = 0.693147180559945309417;
 constexpr int BW = 256;  // lanes of one role: 4 sweeper waves + 4 helper waves per workgroup
 constexpr int WG = 512;
 constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
-constexpr int NBG = 6;   // blocks in the gradient ring: one pre-filled, four in use, one draining
+constexpr int NBG = 7;   // blocks the backward sweep keeps: one landing, four in use, one being summed, one draining
 
 #ifdef GTNX_BAND_TIMING
 // diagnostic build (tools/ubench/band_bench.hip): cycles per phase of a tick, wave 0 of workgroup 0
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
   const bool sweeper = wv < 4;
   const int l = threadIdx.x & 63;
   const int nblocks = (T + K - 1) / K;
-  const int nticks = nblocks + 4;  // block c is drained at tick c + 4
+  const int nticks = nblocks + 5;  // block c: row sums at tick c + 4, gradient rows out at tick c + 5
   const GTNX_G double* ao = P.aoff;
   const double z2 = ao[0];
   const bool dead = !(z2 > double(DEADF));
@@ -672,12 +672,41 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
     }
     // gradient rows of block c (every sweeper is through with it): gather by label, add the
     // normaliser's softmax term, store
+    float* rnorm = lser + NBG * K;  // [NBG blocks][K] what makes a row's posteriors sum to one
+    // Posteriors of a time step sum to one; in float32 the two sweeps and the score drift apart by
+    // ~1e-4 over a thousand steps (all nodes of a row alike).  When every wave has left block c, wave r
+    // sums row r and the row is rescaled to its exact total -- and, having the hot label's share in hand
+    // as well, stores that gradient element.
+    auto rowsum = [&](int c) {
+      const int rows = rows_of(c);
+      if (!want_em || w >= rows) return;
+      const int r = w;
+      const float* ob = oring + ((c % NBG) * K + r) * NSmax;
+      float all = 0.0f, hotp = 0.0f;
+      if (!dead) {
+        for (int m = l; m < P.N; m += 64) all += ob[m];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hotp += ob[hn[k]] * hm[k];
+        for (int i = hot_s + l + 256; i < hot_e; i += 64) hotp += ob[snode[i]];
+      }
+      all = wave_sum(all);
+      const float f = (all != 0.0f && !dead) ? ds / all : 1.0f;
+      if (P.hot >= 0) {
+        hotp = wave_sum63(hotp);
+        if (l == 63) {
+          const float sm = soft ? dn * ex2(ering[((c % NBG) * K + r) * CS + P.hot] - lser[(c % NBG) * K + r]) : 0.0f;
+          P.grad_em[int64_t(T - 1 - c * K - r) * C + P.hot] = hotp * f + sm;
+        }
+      }
+      if (l == 0) rnorm[(c % NBG) * K + r] = f;
+    };
     auto drain = [&](int c) {
       const int rows = rows_of(c);
       if (!want_em || rows <= 0) return;
       const float* ob = oring + (c % NBG) * K * NSmax;
       const float* eb = ering + (c % NBG) * K * CS;
       const float* lb = lser + (c % NBG) * K;
+      const float* fb = rnorm + (c % NBG) * K;
       GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
 #pragma unroll
       for (int s = 0; s < NCS; ++s) {
@@ -696,29 +725,16 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
           for (int r = 0; r < K; ++r)
             if (r < rows) {
               const float sm = soft ? dn * ex2(eb[r * CS + cc] - lb[r]) : 0.0f;
-              dst[-int64_t(r) * C + cc] = sum[r] + sm;
+              dst[-int64_t(r) * C + cc] = sum[r] * fb[r] + sm;
             }
-        }
-      }
-      if (P.hot >= 0 && w < rows) {  // the label most nodes carry (CTC: blank): one wave per row
-        const int r = w;
-        float part = 0.0f;
-        if (!dead) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) part += ob[r * NSmax + hn[k]] * hm[k];
-          for (int i = hot_s + l + 256; i < hot_e; i += 64) part += ob[r * NSmax + snode[i]];
-        }
-        part = wave_sum63(part);
-        if (l == 63) {
-          const float sm = soft ? dn * ex2(eb[r * CS + P.hot] - lb[r]) : 0.0f;
-          dst[-int64_t(r) * C + P.hot] = part + sm;
         }
       }
     };
     lds_barrier();  // the label table is in registers: the posterior ring may be written
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      if (tau >= 4) drain(tau - 4);  // the last wave left block tau - 4 a tick ago
+      if (tau >= 5) drain(tau - 5);
+      if (tau >= 4) rowsum(tau - 4);  // the last wave left block tau - 4 a tick ago
       GTNX_TM(3);
       const int beta = tau - lag;
       if (beta >= 0 && beta < nblocks && !dead) {

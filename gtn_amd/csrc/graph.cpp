@@ -636,7 +636,7 @@ void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
     return;
   }
   Weights& gw = *g->grad->w;
-  if (!gw.dev_valid) {
+  if (!gw.dev_valid || (gw.host_escaped && gw.host_valid)) {
     std::vector<Weights*> v{&gw};
     ensure_weights_device_batch(v);
   }
@@ -647,6 +647,8 @@ void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
   rt.h2d(d->ptr, pin->ptr, sizeof(AxpyArgs));
   launch_axpy_batch(d->as<AxpyArgs>(), 1, n, 0, rt.stream());
   gw.host_valid = false;
+  gw.host_escaped = false;  // the device copy is the live one now
+  gw.version++;
 }
 
 // ======================================================================
@@ -778,7 +780,9 @@ void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
   std::vector<Weights*> todo;
   std::unordered_set<Weights*> todo_set;
   for (Weights* w : ws) {
-    bool stale = !w->dev_valid || w->host_escaped;
+    // (a mutable host pointer that escaped matters only while the host copy is the live one: after a
+    //  device-side write the device copy is authoritative and host_valid is false)
+    bool stale = !w->dev_valid || (w->host_escaped && w->host_valid);
     if (stale && todo_set.insert(w).second) todo.push_back(w);
   }
   if (todo.empty()) return;

@@ -17,7 +17,12 @@
 namespace gtnx {
 
 namespace {
-std::atomic<uint64_t> g_seq{1};
+// Records are ordered by creation; sequence numbers are 2^20 apart so that a record made later
+// to stand in for an older one (realize()) can be filed right behind it.
+constexpr uint64_t kSeqStride = uint64_t(1) << 20;
+std::atomic<uint64_t> g_seq_ctr{1};
+std::atomic<uint64_t> g_seq_sub{0};
+inline uint64_t next_seq() { return g_seq_ctr.fetch_add(1) * kSeqStride; }
 
 
 // ---- the constant structure of a scalar result (functions.cpp:26-28, shortest.cpp:183-186)
@@ -140,6 +145,7 @@ void GradSink::flush() {
       ensure_weights_device_batch(v);
     }
     gw.host_valid = false;
+    gw.host_escaped = false;  // the device copy is the live one now
     gw.version++;
     if (!seen.insert(gw.dev).second) dup = true;
     ax.push_back({gw.dev, it.ptr, g.num_arcs(), 1.0f});
@@ -264,7 +270,7 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
   ensure_weights_device_batch(ws);
   auto op = std::make_shared<ScalarOp>();
   op->kind = k;
-  op->seq = g_seq++;
+  op->seq = next_seq();
   DevMemP res = rt.alloc(sizeof(float) * n);
   std::vector<ScalarArgs> args(n);
   for (size_t i = 0; i < n; ++i) {
@@ -338,7 +344,7 @@ struct LinearSdOp : OpRecord {
       const bool first_use = seen_in.insert(in.g.get()).second;
       if (first_use && in.calc_grad() && in.is_grad_available()) {
         Weights& gw = *in.g->grad->w;
-        if (gw.dev_valid && !gw.host_escaped && gw.n == in.num_arcs()) {
+        if (gw.dev_valid && !(gw.host_escaped && gw.host_valid) && gw.n == in.num_arcs()) {
           a.grad = gw.dev;
           a.accumulate = 1;
           gw.host_valid = false;
@@ -491,7 +497,7 @@ struct SdOp : OpRecord {
         bool in_place = false;
         if (a.grad_chain && chain.is_grad_available() && fused_chain_seen.insert(chain.g.get()).second) {
           Weights& gw = *chain.g->grad->w;
-          if (gw.dev_valid && !gw.host_escaped && gw.n == chain.num_arcs()) {
+          if (gw.dev_valid && !(gw.host_escaped && gw.host_valid) && gw.n == chain.num_arcs()) {
             a.grad_chain = gw.dev;
             a.chain_accumulate = 1;
             gw.host_valid = false;
@@ -566,7 +572,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     const int m = int(lin.size());
     auto op = std::make_shared<LinearSdOp>();
     op->tropical = tropical;
-    op->seq = g_seq++;
+    op->seq = next_seq();
     DevMemP res = rt.alloc(sizeof(float) * size_t(m) * 9);
     float* scal = res->as<float>();
     float* partial = scal + m;
@@ -613,7 +619,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       if (gs[i].s->sched->error) throw_invalid(kCycleMsg);  // shortest.cpp:149-152
     auto op = std::make_shared<SdOp>();
     op->mode = tropical ? SD_TROPICAL : SD_LOG;
-    op->seq = g_seq++;
+    op->seq = next_seq();
     size_t bytes = 0;
     std::vector<size_t> off_s(m), off_a(m), off_r(m);
     for (int k = 0; k < m; ++k) {
@@ -881,7 +887,7 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
   std::vector<char> host(bytes);
   rt.d2h_sync(host.data(), arena->ptr, bytes);
   auto op = std::make_shared<PathOp>();
-  op->seq = g_seq++;
+  op->seq = next_seq();
   op->arcs_rev.resize(m);
   for (int k = 0; k < m; ++k) {
     const char* pb = host.data() + off_p[k];
@@ -1497,7 +1503,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
 
   ht_phase("compose.4_launch_wait");
   auto op = std::make_shared<ComposeOp>();
-  op->seq = g_seq++;
+  op->seq = next_seq();
   op->arena = res;
   op->saved.resize(n);
   for (size_t i = 0; i < n; ++i) {
@@ -1679,7 +1685,7 @@ int lazy_lds_limit() { return 150 * 1024; }
 
 std::shared_ptr<OpRecord> make_lazy_compose_op() {
   auto op = std::make_shared<LazyComposeOp>();
-  op->seq = g_seq++;
+  op->seq = next_seq();
   return op;
 }
 
@@ -1973,7 +1979,7 @@ struct LazySdOp : OpRecord {
 std::vector<Graph> lazy_group_shortest_distance(std::vector<Graph>& gs, bool tropical) {
   auto op = std::make_shared<LazySdOp>();
   op->mode = tropical ? SD_TROPICAL : SD_LOG;
-  op->seq = g_seq++;
+  op->seq = next_seq();
   op->groups = lazy_forward(gs, op->mode, op->slot);
   std::vector<Graph> outs;
   for (size_t i = 0; i < gs.size(); ++i) {
@@ -2067,7 +2073,7 @@ struct LazyPairSdOp : OpRecord {
 std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
   Runtime& rt = Runtime::get();
   auto op = std::make_shared<LazyPairSdOp>();
-  op->seq = g_seq++;
+  op->seq = next_seq();
   const size_t n = gs.size();
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
@@ -2234,7 +2240,7 @@ struct BandSdOp : OpRecord {
 std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
   Runtime& rt = Runtime::get();
   auto op = std::make_shared<BandSdOp>();
-  op->seq = g_seq++;
+  op->seq = next_seq();
   const size_t n = gs.size();
   std::vector<BandInfo*> bis;
   std::vector<Structure*> ss;
@@ -2274,7 +2280,7 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     const int T = op->chains[i].s->M, N = int(op->fixed[i].s->N);
     const int ns = band_row_stride(N, band_npl(N));
     oo[i] = bytes;
-    bytes = align_up(bytes + 8 * (2 * size_t(T) + 8), 256);  // score + one shift per wave and period (>= 2 rows)
+    bytes = align_up(bytes + 8 * (4 * size_t(T) + 16), 256);  // score + one shift per wave and period (>= 1 row)
     ao[i] = bytes;
     bytes = align_up(bytes + 4 * size_t(T + 1) * size_t(ns), 256);
   }
@@ -2402,7 +2408,7 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
   std::vector<std::pair<int, int>> slot;
   auto groups = lazy_forward(gs, SD_TROPICAL, slot);
   auto op = std::make_shared<LazyPathOp>();
-  op->seq = g_seq++;
+  op->seq = next_seq();
   op->saved.resize(gs.size());
   std::vector<Graph> outs(gs.size(), Graph(false));
   for (size_t gi = 0; gi < groups.size(); ++gi) {
@@ -2496,9 +2502,15 @@ void realize(Graph& g) {
     d.sched->in_w_of = g.w.get();
     d.sched->in_w_version = dw.version;
   }
-  if (g.g->op) {  // the tape now runs through the real compose record
+  if (g.g->op) {
+    // The tape now runs through the real compose record -- filed where the symbolic one was:
+    // consumers already recorded against this product (forwardScore of it, say) must still run
+    // first in the reverse sweep.
+    const uint64_t old = g.g->op->seq;
     g.g->op = real.g->op;
     g.g->op_idx = real.g->op_idx;
+    g.g->op->seq = old + 1 + g_seq_sub.fetch_add(1) % (kSeqStride - 2);
+    if (d.sched && d.sched->producer_seq) d.sched->producer_seq = g.g->op->seq;
   }
 }
 
@@ -2529,7 +2541,7 @@ Graph make_user_op(std::vector<Graph>& inputs, gtnx_grad_fn fn, void* ctx, void 
   op->fn = fn;
   op->ctx = ctx;
   op->ctx_free = ctx_free;
-  op->seq = g_seq++;
+  op->seq = next_seq();
   Graph out = make_output(op, 0, inputs);
   if (!fn) out.g->has_grad_fn = false;
   return out;
@@ -2545,7 +2557,7 @@ void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(voi
   op->fn = fn;
   op->ctx = ctx;
   op->ctx_free = ctx_free;
-  op->seq = g_seq++;
+  op->seq = next_seq();
   g.g->op = op;
   g.g->op_idx = 0;
   g.g->has_grad_fn = fn != nullptr;
@@ -2601,10 +2613,16 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
   for (auto& kv : tape) {
     auto& members = kv.second.second;
     std::sort(members.begin(), members.end(), [](const Member& a, const Member& b) { return a.idx < b.idx; });
+    // a consumer of a symbolic product pushes its gradient straight into the product's inputs
+    // (grad_propagated); if that was the only consumer there is nothing left for this record to do
+    // for that member -- also when the product has been built in the meantime
+    members.erase(std::remove_if(members.begin(), members.end(),
+                                 [](const Member& m) { return m.out.g->grad_propagated && !m.out.is_grad_available() && !m.out.s->lazy; }),
+                  members.end());
     for (auto& m : members)
       if (!(m.out.s->lazy && m.out.g->grad_propagated))
         (void)m.out.grad();  // throws "Gradient not calculated yet." like autograd.cpp:46
-    kv.second.first->backward(members);
+    if (!members.empty()) kv.second.first->backward(members);
     if (!retain) {
       // autograd.cpp:47-50: the tape (inputs, saved forward state) goes away with
       // backward; the objects themselves are reclaimed at the next sync point

@@ -1,0 +1,60 @@
+"""CTC loss and gradients in float64 (TEST INFRASTRUCTURE ONLY) -- the yardstick for float32 error.
+
+What it computes is what benchmarks/ctc.cpp:150-160 computes: forwardScore(emissions) -
+forwardScore(intersect(ctcGraph(target), emissions)) and d loss / d emissions, i.e.
+shortest.cpp:86-170 / :33-62 over the product compose.cpp:377-522 builds -- here as the alpha-beta
+recursion over (time, node of the target graph) in float64 with numpy, so that the float32 results
+of the reference, of the C oracle and of the HIP kernels can each be measured against (practically)
+exact arithmetic.  The untrimmed recursion visits the dead states the reference trims; they carry
+zero posterior mass, so every score and gradient is the same.
+"""
+import numpy as np
+
+
+def _lse(a, axis=None):
+    m = np.max(a, axis=axis, keepdims=True)
+    m = np.where(np.isfinite(m), m, 0.0)
+    with np.errstate(divide="ignore"):
+        return (np.log(np.sum(np.exp(a - m), axis=axis, keepdims=True)) + m).squeeze(axis)
+
+
+def ctc_loss_fp64(emissions, target, blank=0):
+    """-> (loss, grad[T, C], target_arc_grad or None): float64"""
+    em = np.asarray(emissions, dtype=np.float64)
+    T, C = em.shape
+    tg = np.asarray(target, dtype=np.int64)
+    U = tg.size
+    S = 2 * U + 1
+    lab = np.full(S, blank, dtype=np.int64)
+    lab[1::2] = tg
+    skip = np.zeros(S, dtype=bool)  # arc from s-2 (label nodes whose previous label differs)
+    for s in range(3, S, 2):
+        skip[s] = lab[s] != lab[s - 2]
+    NEG = -np.inf
+    alpha = np.full((T + 1, S), NEG)
+    alpha[0, 0] = 0.0
+    e = em[:, lab]  # [T, S]
+    for t in range(T):
+        a = alpha[t]
+        x1 = np.concatenate([[NEG], a[:-1]])
+        x2 = np.where(skip, np.concatenate([[NEG, NEG], a[:-2]]), NEG)
+        alpha[t + 1] = _lse(np.stack([a, x1, x2]), axis=0) + e[t]
+    acc = [S - 1] if S == 1 else [S - 1, S - 2]
+    z = _lse(alpha[T, acc])
+    norm_rows = _lse(em, axis=1)
+    loss = float(np.sum(norm_rows) - z)
+    grad = np.exp(em - norm_rows[:, None])  # d forwardScore(emissions)
+    if not np.isfinite(z):
+        return loss, grad, None
+    beta = np.full((T + 1, S), NEG)
+    beta[T, acc] = 0.0
+    skip_out = np.concatenate([skip[2:], [False, False]])  # arc s -> s+2
+    for t in range(T - 1, -1, -1):
+        q = e[t] + beta[t + 1]
+        y1 = np.concatenate([q[1:], [NEG]])
+        y2 = np.where(skip_out, np.concatenate([q[2:], [NEG, NEG]]), NEG)
+        beta[t] = _lse(np.stack([q, y1, y2]), axis=0)
+    occ = np.exp(alpha[1:] + beta[1:] - z)  # node posteriors after consuming frame t
+    for s in range(S):
+        grad[:, lab[s]] -= occ[:, s]
+    return loss, grad, None

@@ -32,7 +32,7 @@ int main(int argc, char** argv) {
   char* d_g;
   CK(hipMalloc(&d_g, per_g * B));
   std::vector<char> h_g(per_g * B);
-  const size_t per_alpha = size_t(T + 1) * NS * 4, per_off = 8 * (2 * size_t(T) + 8);
+  const size_t per_alpha = size_t(T + 1) * NS * 4, per_off = 8 * (4 * size_t(T) + 16);
   char *d_alpha, *d_off;
   CK(hipMalloc(&d_alpha, per_alpha * B));
   CK(hipMalloc(&d_off, per_off * B));

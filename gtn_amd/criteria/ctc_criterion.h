@@ -71,9 +71,10 @@ inline void ctcLossBatch(
   SymbolicCompose symbolic;
   auto comp = batched::intersect(ctcs, ems);
   auto t3 = now();
-  // (named in this order: C++ leaves the evaluation order of call arguments open)
-  auto norm = batched::forwardScore(ems);
+  // (C++ leaves the evaluation order of benchmarks/ctc.cpp:157's call arguments open; this order lets the
+  //  sweep over target o emissions, which reads every emission anyway, leave forwardScore(emissions) behind)
   auto score = batched::forwardScore(comp);
+  auto norm = batched::forwardScore(ems);
   auto losses = batched::subtract(norm, score);
   auto t4 = now();
   if (gradDev) batched::backward(losses);

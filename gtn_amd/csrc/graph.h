@@ -113,6 +113,15 @@ struct Structure {
   int num_out(int n);
 };
 
+// forwardScore of a linear chain over these weights, left behind by a sweep that read every
+// emission anyway (band.hip): the scalar and the per-row log2-sum-exp2 (softmax term of the gradient)
+struct NormCache {
+  uint64_t version = 0;  // of the weights it was computed from
+  DevMemP mem;
+  float* norm = nullptr;
+  float* rowlse = nullptr;
+};
+
 struct Weights {
   int64_t n = 0;
   std::vector<float> host;
@@ -122,6 +131,10 @@ struct Weights {
   uint64_t zero_version = ~uint64_t(0);  // version all_zero was taken at
   bool all_zero = false;
   bool is_all_zero();         // host-valid weights only; cached per version
+  std::shared_ptr<NormCache> norm_cache;
+  const NormCache* valid_norm_cache() const {
+    return norm_cache && norm_cache->version == version && dev_valid ? norm_cache.get() : nullptr;
+  }
   DevMemP dev_mem;
   float* dev = nullptr;
   bool dev_valid = false;

@@ -309,15 +309,60 @@ DSched sched_view(Graph& g, bool need_full = true) {
   return v;
 }
 
+// ---- gradient launches of one backward() over the same emission chains, gathered before they go:
+// forwardScore(emissions) contributes dn * softmax(row), forwardScore(target o emissions) the node
+// posteriors; registered here by their records and launched together (flush_chain_plan) the
+// band backward kernel writes every gradient row once, softmax term included.
+struct ChainGradPlan {
+  struct Lin {
+    Member m;             // output of forwardScore(chain)
+    Graph chain;          // (the tape forgets the inputs as soon as the record's backward returns)
+    const float* delta;   // d / d norm
+    const float* rowlse;  // per-row log2-sum-exp2 of the chain (NormCache)
+    DevMemP keep;
+    bool fused = false;
+  };
+  struct Band {
+    int C, npl, unit, gradg, vec;
+    BandPair p;
+    Weights* chain_w;
+  };
+  std::unordered_map<Weights*, Lin> lin;  // by chain weights
+  std::vector<Band> band;
+  std::vector<DevMemP> keep;
+  GradSink sink;
+  double bytes = 0;
+  bool empty() const { return lin.empty() && band.empty(); }
+};
+thread_local ChainGradPlan* t_chain_plan = nullptr;
+void flush_chain_plan();
+
 struct LinearSdOp : OpRecord {
   bool tropical;
-  void backward(std::vector<Member>& ms) override {
+  bool joins_chain_plan() const override { return !tropical; }
+  void backward(std::vector<Member>& all) override {
+    // members whose chain has its row log-sum-exps at hand wait for the sweep over the same chain
+    std::vector<Member> ms;
+    std::vector<Graph> ins;
+    for (auto& m : all) {
+      Graph& in = m.out.g->inputs[0];
+      const NormCache* nc = (!tropical && t_chain_plan && in.calc_grad()) ? in.w->valid_norm_cache() : nullptr;
+      if (nc && nc->rowlse && !t_chain_plan->lin.count(in.w.get())) {
+        ChainGradPlan::Lin l{m, in, grad_dev_ptr(m.out), nc->rowlse, nc->mem, false};
+        t_chain_plan->lin.emplace(in.w.get(), std::move(l));
+      } else {
+        ms.push_back(m);
+        ins.push_back(in);
+      }
+    }
+    if (!ms.empty()) run_now(ms, ins);
+  }
+  void run_now(std::vector<Member>& ms, std::vector<Graph>& ins) {
     Runtime& rt = Runtime::get();
     const int n = int(ms.size());
     std::vector<Weights*> ws;
     size_t total = 0;
-    for (auto& m : ms) {
-      Graph& in = m.out.g->inputs[0];
+    for (auto& in : ins) {
       ws.push_back(in.w.get());
       total += size_t(in.num_arcs());
     }
@@ -330,7 +375,7 @@ struct LinearSdOp : OpRecord {
     double bytes = 0;
     std::unordered_set<GradState*> seen_in;
     for (int i = 0; i < n; ++i) {
-      Graph& in = ms[i].out.g->inputs[0];
+      Graph& in = ins[i];
       LinArgs& a = args[i];
       a.w = in.w->dev;
       a.M = in.s->M;
@@ -579,8 +624,20 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     std::vector<LinArgs> args(m);
     int maxM = 0;
     double bytes = 0;
+    std::vector<LinArgs> todo;
+    todo.reserve(m);
     for (int k = 0; k < m; ++k) {
       Graph& g = gs[lin[k]];
+      Graph out = make_output(op, k, {g});
+      init_scalar_result(out);
+      // a sweep over target o emissions has read every emission of this chain already and left
+      // forwardScore(emissions) behind (band.hip): nothing to launch
+      const NormCache* nc = tropical ? nullptr : g.w->valid_norm_cache();
+      if (nc && nc->norm) {
+        set_dev_weights(out, nc->mem, nc->norm, 1);
+        outs[lin[k]] = std::move(out);
+        continue;
+      }
       LinArgs& a = args[k];
       a.w = g.w->dev;
       a.M = g.s->M;
@@ -592,17 +649,18 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
       a.accumulate = 0;
       maxM = std::max(maxM, a.M);
       bytes += 4.0 * double(g.num_arcs());
-      Graph out = make_output(op, k, {g});
-      init_scalar_result(out);
+      todo.push_back(a);
       set_dev_weights(out, res, scal + k, 1);
       outs[lin[k]] = std::move(out);
     }
-    DevMemP d = upload_vec(args);
-    GTNX_PROF("linear_forward", bytes);
-    bool vec_rows = true;
-    for (auto& a : args) vec_rows = vec_rows && a.C % 4 == 0 && a.C <= 1024 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
-    (void)maxM;
-    launch_linear_forward(d->as<LinArgs>(), m, tropical ? 1 : 0, vec_rows ? 1 : 0, rt.stream());
+    if (!todo.empty()) {
+      DevMemP d = upload_vec(todo);
+      GTNX_PROF("linear_forward", bytes);
+      bool vec_rows = true;
+      for (auto& a : todo) vec_rows = vec_rows && a.C % 4 == 0 && a.C <= 1024 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
+      (void)maxM;
+      launch_linear_forward(d->as<LinArgs>(), int(todo.size()), tropical ? 1 : 0, vec_rows ? 1 : 0, rt.stream());
+    }
   }
 
   // ---- general DAGs: level-scheduled persistent kernel
@@ -2195,7 +2253,6 @@ struct BandSdOp : OpRecord {
 
   void backward(std::vector<Member>& ms) override {
     Runtime& rt = Runtime::get();
-    GradSink sink;
     size_t eb = 0, fb = 0;
     std::vector<size_t> eo(ms.size(), 0), fo(ms.size(), 0);
     for (size_t k = 0; k < ms.size(); ++k) {
@@ -2211,9 +2268,16 @@ struct BandSdOp : OpRecord {
     }
     DevMemP gem = rt.alloc(eb ? eb : 1);       // every row is written by the kernel
     DevMemP gfx = rt.alloc_zero(fb ? fb : 1);  // arcs that never match stay 0
-    std::vector<std::pair<Key, BandPair>> tab;
-    tab.reserve(ms.size());
-    double bytes = 0;
+    ChainGradPlan local;
+    ChainGradPlan& plan = t_chain_plan ? *t_chain_plan : local;
+    plan.keep.push_back(gem);
+    plan.keep.push_back(gfx);
+    plan.keep.push_back(arena);
+    for (size_t k = 0; k < ms.size(); ++k) {  // what the deferred launch reads must outlive this record
+      plan.keep.push_back(infos[ms[k].idx]->dev_mem);
+      plan.keep.push_back(chains[ms[k].idx].w->dev_mem);
+      plan.keep.push_back(fixed[ms[k].idx].w->dev_mem);
+    }
     for (size_t k = 0; k < ms.size(); ++k) {
       const int i = ms[k].idx;
       BandPair p = pairs[i];
@@ -2221,21 +2285,66 @@ struct BandSdOp : OpRecord {
       p.delta_norm = nullptr;
       p.grad_em = chains[i].calc_grad() ? gem->as<float>(eo[k]) : nullptr;
       p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
-      tab.push_back({Key{p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0, band_vec(p)}, p});
-      if (p.grad_em) sink.add(chains[i], gem, p.grad_em);
-      if (p.grad_fixed) sink.add(fixed[i], gfx, p.grad_fixed);
+      plan.band.push_back({p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0, band_vec(p), p, chains[i].w.get()});
+      if (p.grad_em) plan.sink.add(chains[i], gem, p.grad_em);
+      if (p.grad_fixed) plan.sink.add(fixed[i], gfx, p.grad_fixed);
       ms[k].out.g->inputs[0].g->grad_propagated = true;
       // algorithmic bytes: emissions in, emission gradient out, alpha back in, G's arc gradients out
-      bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
-               (p.grad_fixed ? 4.0 * double(fixed[i].s->A) : 0.0);
+      plan.bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
+                    (p.grad_fixed ? 4.0 * double(fixed[i].s->A) : 0.0);
     }
-    {
-      GTNX_PROF("band_forward_score_grad", bytes);
-      launch(tab, true);
+    if (!t_chain_plan) {  // not inside backward(): launch at once
+      t_chain_plan = &local;
+      flush_chain_plan();
+      t_chain_plan = nullptr;
     }
-    sink.flush();
   }
+  bool joins_chain_plan() const override { return true; }
 };
+
+// launches what the records of one backward() registered: band sweeps (with the softmax term of the
+// normaliser where forwardScore(emissions) of the same chain is on the tape too), then the normalisers
+// that found no sweep to ride with
+void flush_chain_plan() {
+  ChainGradPlan* plan = t_chain_plan;
+  if (!plan || plan->empty()) return;
+  Runtime& rt = Runtime::get();
+  std::vector<std::pair<BandSdOp::Key, BandPair>> tab;
+  tab.reserve(plan->band.size());
+  for (auto& b : plan->band) {
+    auto it = b.p.grad_em ? plan->lin.find(b.chain_w) : plan->lin.end();
+    if (it != plan->lin.end() && !it->second.fused) {
+      b.p.delta_norm = it->second.delta;
+      b.p.rowlse = const_cast<float*>(it->second.rowlse);
+      it->second.fused = true;
+    } else {
+      b.p.delta_norm = nullptr;
+    }
+    tab.push_back({BandSdOp::Key{b.C, b.npl, b.unit, b.gradg, b.vec}, b.p});
+  }
+  if (!tab.empty()) {
+    GTNX_PROF("band_forward_score_grad", plan->bytes);
+    BandSdOp::launch(tab, true);
+  }
+  plan->sink.flush();
+  // normalisers without a sweep: their own kernel
+  std::vector<Member> rest;
+  std::vector<Graph> rest_in;
+  for (auto& kv : plan->lin)
+    if (!kv.second.fused) {
+      rest.push_back(kv.second.m);
+      rest_in.push_back(kv.second.chain);
+    }
+  if (!rest.empty()) {
+    LinearSdOp lin;
+    lin.tropical = false;
+    lin.run_now(rest, rest_in);
+  }
+  plan->band.clear();
+  plan->lin.clear();
+  plan->keep.clear();
+  plan->bytes = 0;
+}
 
 std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
   Runtime& rt = Runtime::get();
@@ -2274,11 +2383,15 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
   }
   ensure_band_device_batch(bis, ss);
   ensure_weights_device_batch(ws);
-  size_t bytes = align_up(4 * n, 256);
-  std::vector<size_t> ao(n), oo(n);
+  // scores [n], then per pair: the chain's own forwardScore (a by-product: every emission is read
+  // anyway) + its per-row log-sum-exps, shifts, alpha plane
+  size_t bytes = align_up(8 * n, 256);
+  std::vector<size_t> ao(n), oo(n), lo(n);
   for (size_t i = 0; i < n; ++i) {
     const int T = op->chains[i].s->M, N = int(op->fixed[i].s->N);
     const int ns = band_row_stride(N, band_npl(N));
+    lo[i] = bytes;
+    bytes = align_up(bytes + 4 * size_t(T > 0 ? T : 1), 256);
     oo[i] = bytes;
     bytes = align_up(bytes + 8 * (4 * size_t(T) + 16), 256);  // score + one shift per wave and period (>= 1 row)
     ao[i] = bytes;
@@ -2307,6 +2420,10 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     p.alpha = op->arena->as<float>(ao[i]);
     p.aoff = op->arena->as<double>(oo[i]);
     p.score = op->arena->as<float>(4 * i);
+    if (!op->chains[i].w->valid_norm_cache()) {
+      p.norm = op->arena->as<float>(4 * (n + i));
+      p.rowlse = op->arena->as<float>(lo[i]);
+    }
     p.hot = b.hot;
     p.lgrn = band_forward_lgrn(p.C);
     tab.push_back({BandSdOp::Key{p.C, band_npl(p.N), int(op->unit[i]), 0, BandSdOp::band_vec(p)}, p});
@@ -2315,6 +2432,16 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
   {
     GTNX_PROF("band_forward_score", abytes);
     BandSdOp::launch(tab, false);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const BandPair& p = op->pairs[i];
+    if (!p.norm) continue;
+    auto nc = std::make_shared<NormCache>();
+    nc->version = op->chains[i].w->version;
+    nc->mem = op->arena;
+    nc->norm = p.norm;
+    nc->rowlse = p.rowlse;
+    op->chains[i].w->norm_cache = std::move(nc);
   }
   std::vector<Graph> outs;
   outs.reserve(n);
@@ -2610,8 +2737,15 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
     }
   }
   // ---- reverse sweep: creation order is a topological order
+  ChainGradPlan plan;
+  struct PlanScope {
+    ChainGradPlan* prev;
+    explicit PlanScope(ChainGradPlan* p) : prev(t_chain_plan) { t_chain_plan = p; }
+    ~PlanScope() { t_chain_plan = prev; }
+  } plan_scope(&plan);
   for (auto& kv : tape) {
     auto& members = kv.second.second;
+    if (!kv.second.first->joins_chain_plan()) flush_chain_plan();  // anything else may look at the chains' gradients
     std::sort(members.begin(), members.end(), [](const Member& a, const Member& b) { return a.idx < b.idx; });
     // a consumer of a symbolic product pushes its gradient straight into the product's inputs
     // (grad_propagated); if that was the only consumer there is nothing left for this record to do
@@ -2641,6 +2775,7 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
       rt.defer_delete(dead_inputs, [](void* q) { delete static_cast<std::vector<std::vector<Graph>>*>(q); });
     }
   }
+  flush_chain_plan();
 }
 
 // ======================================================================

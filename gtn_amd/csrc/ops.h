@@ -28,6 +28,10 @@ struct Member {
 struct OpRecord {
   uint64_t seq = 0;
   virtual void backward(std::vector<Member>& members) = 0;
+  // true: this record's backward may only REGISTER its launch with the running backward's chain-gradient
+  // plan (ops.cpp: ChainGradPlan), so that the normaliser's softmax term and the sweep's posteriors
+  // of the same emissions leave in one kernel
+  virtual bool joins_chain_plan() const { return false; }
   virtual ~OpRecord() {}
 };
 

@@ -90,23 +90,27 @@ def cpu_baseline(B, T, Cn, U, seed):
         lib = C.CDLL(path)
         lib.ref_ctc_batch.restype = C.c_double
         lib.ref_ctc_batch.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]
-        nb = int(min(B, max(cores * 2, 8)))
+        # batch >= 4 x cores so every thread has work, 3 timed iterations
+        # (ref_ctc_batch returns the mean seconds per iteration); bounded to about 30 s of CPU work
+        nb = int(max(cores * 4, 8))
+        scale = (T * Cn * U) / (1000.0 * 256 * 100)
+        if scale > 1.5:
+            nb = int(max(cores, 8))
         em, tg = gg.ctc_inputs(seed, nb, T, Cn, U)
         losses = np.zeros(nb, np.float32)
         thr = C.c_int()
         t0 = time.time()
-        sec = lib.ref_ctc_batch(em.ctypes.data, tg.ctypes.data, nb, T, Cn, U, 0, 1, losses.ctypes.data, None,
-                                C.byref(thr))
-        iters = 1
-        # aim at ~10-20 s of CPU work in total
-        extra = int(min(20, max(0, 12.0 / max(sec, 1e-3) - 1)))
-        if extra > 0:
-            sec = lib.ref_ctc_batch(em.ctypes.data, tg.ctypes.data, nb, T, Cn, U, 0, extra, losses.ctypes.data,
-                                    None, C.byref(thr))
-            iters = extra
+        secs = []
+        while len(secs) < 3 and (not secs or time.time() - t0 + secs[-1] < 45.0):
+            secs.append(lib.ref_ctc_batch(em.ctypes.data, tg.ctypes.data, nb, T, Cn, U, 0, 1, losses.ctypes.data, None,
+                                          C.byref(thr)))
+        iters = len(secs)
+        sec = float(np.mean(secs))
         return {"value": nb / sec, "unit": "losses/s", "cores": int(thr.value), "kind": "reference",
-                "sample": f"{iters} iteration(s) of parallelMap(fwd)+parallelMap(bwd) over {nb} utterances "
-                          f"(T={T}, C={Cn}, U={U}), {time.time() - t0:.1f}s wall; host has {cores} logical cores"}
+                "sample": f"mean of {iters} timed iteration(s) of parallelMap(fwd)+parallelMap(bwd) "
+                          f"over {nb} utterances (T={T}, C={Cn}, U={U}); per-iteration losses/s min "
+                          f"{nb / max(secs):.1f} max {nb / min(secs):.1f}; {time.time() - t0:.1f}s wall; host has "
+                          f"{cores} logical cores"}
     from oracle_lib import ctc_loss
     em, tg = gg.ctc_inputs(seed, 4, T, Cn, U)
     t0 = time.time()
@@ -120,16 +124,23 @@ def cpu_baseline(B, T, Cn, U, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=512, help="utterances per GPU (C3: 512)")
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--U", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--built-lattice", action="store_true",
+                    help="also run the step with every lattice built (compose -> forwardScore kernel -> fused "
+                         "backward) and report its kernels as built_lattice_path")
+    ap.add_argument("--config", choices=["c3", "c5"], default=None,
+                    help="BASELINE.json configs: c3 = T 1000, C 256, U 100 (default); c5 = T 2000, C 1024, U 200")
     ap.add_argument("--python-host", action="store_true",
                     help="drive the step through the Python interface instead of the C++ one")
     args = ap.parse_args()
+    if args.config == "c5":
+        args.T, args.C, args.U = 2000, 1024, 200
 
     import torch
     import torch.distributed as dist
@@ -244,15 +255,19 @@ def main():
 
     # ---- roofline of every profiled kernel family of the timed loop, against HBM peak.
     # Algorithmic bytes per launch (DESIGN.md section 3 / SURVEY.md section 8d):
-    #   lazy_pair_forward_score       4TC + 4(T+1)N per utterance  (emissions in, alpha out)
-    #   lazy_pair_forward_score_grad  8TC + 4(T+1)N + 4A           (emissions in, gradient out, alpha in)
+    #   band_forward_score            4TC + 4(T+1)NS per utterance (emissions in, alpha out; NS = N rounded up to 4)
+    #   band_forward_score_grad       8TC + 4(T+1)NS + 4A          (emissions in, gradient out, alpha in, G's gradient)
     #   linear_forward / _grad        4TC  /  12TC                 (rows in; rows in + gradient read-modify-write)
-    #   intersect                     36A + 8N of the built lattice;  forward_score 24A + 12N (reported by
-    #   the engine);  forward_score_grad 24A + 12N + 4TC
+    #   intersect                     20A + 8N: what the chain-product variant of compose_kernel writes (src, il,
+    #                                 ol, in_list are derivable and left out: DESIGN.md section 2)
+    #   forward_score                 8A + 8N (reported by the engine)
+    #   forward_score_grad            20A + 12N + 4TC (in-rows, arc gradients, node rows, emission gradient)
     # measured = the engine's hipEvent pairs around each family on the launch stream.
-    KERNEL_OF = {
-        "lazy_pair_forward_score": "lazy_pair_forward_kernel<256>",
-        "lazy_pair_forward_score_grad": "lazy_pair_backward_kernel<256, 16>",
+    KERNEL_OF = {  # family -> kernel (template arguments depend on the shape: matched by prefix in the PMC table)
+        "band_forward_score": "band_forward_kernel",
+        "band_forward_score_grad": "band_backward_kernel",
+        "lazy_pair_forward_score": "lazy_pair_forward_kernel",
+        "lazy_pair_forward_score_grad": "lazy_pair_backward_kernel",
         "linear_forward": "linear_rows_kernel<false>",
         "linear_forward_grad": "linear_rows_kernel<true>",
         "forward_score": "sd_forward_narrow_kernel<true>",
@@ -265,8 +280,8 @@ def main():
 
     def rooflines(pr):
         fixed = {"linear_forward": B * 4.0 * T * Cn, "linear_forward_grad": B * 12.0 * T * Cn,
-                 "intersect": B * (36.0 * n_arcs + 8.0 * n_nodes),
-                 "forward_score_grad": B * (24.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}
+                 "intersect": B * (20.0 * n_arcs + 8.0 * n_nodes),
+                 "forward_score_grad": B * (20.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}
         out = {}
         for name, e in pr.items():
             if not e["launches"] or name not in KERNEL_OF:
@@ -275,7 +290,7 @@ def main():
             ms = e["total_ms"] / e["launches"]
             if per <= 0 or ms <= 0:
                 continue
-            k = pmc.get(KERNEL_OF[name])
+            k = next((v for kk, v in pmc.items() if kk.startswith(KERNEL_OF[name])), None)
             # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
             # WRITE_SIZE, separate passes; newest profiles/r*_c3_pmc_hbm.json).  Calibrated on
             # linear_rows_kernel<false>, whose bytes are known exactly: FETCH_SIZE reads half the
@@ -285,15 +300,6 @@ def main():
             out[name] = {"bound": "hbm", "kernel": KERNEL_OF[name], "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "ms_per_launch": ms,
                          "algorithmic_bytes_per_launch": per}
-            # The sweep kernels compute forwardScore (and its gradient) of the SAME lattices without building
-            # them.  SURVEY.md section 8(d) prices those on the lattice -- forwardScore 8A+8N, its backward plus
-            # the compose gradient 24A+12N+4TC -- and asks to "quote both": `frac` above is the HBM utilisation
-            # on the bytes the sweep really needs; this is the rate at which it gets through the lattice work.
-            equiv = {"lazy_pair_forward_score": B * (8.0 * n_arcs + 8.0 * n_nodes),
-                     "lazy_pair_forward_score_grad": B * (24.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}.get(name)
-            if equiv:
-                out[name]["lattice_equivalent"] = {"bytes_per_launch": equiv, "achieved": equiv / (ms * 1e-3) / 1e9,
-                                                   "frac": equiv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s"}
         return out
 
     roofs = rooflines(prof)
@@ -303,7 +309,7 @@ def main():
     # ---- the same step with every lattice BUILT (the path graphs that are not CTC-shaped take,
     # and what GTNX_LAZY_COMPOSE=0 selects): untimed for `value`, profiled for its kernels
     built = None
-    if native is not None and "lazy_pair_forward_score" in prof and not os.environ.get("GTNX_LAZY_COMPOSE"):
+    if native is not None and args.built_lattice and not os.environ.get("GTNX_LAZY_COMPOSE"):
         os.environ["GTNX_LAZY_COMPOSE"] = "0"
         try:
             for _ in range(3):

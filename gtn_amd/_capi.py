@@ -81,6 +81,7 @@ _SIGS = {
     "gtnx_scalar_graph": [C.c_float, C.c_int, c_graph_p],
     "gtnx_linear_graph": [C.c_int, C.c_int, C.c_int, c_graph_p],
     "gtnx_linear_graph_n": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_graph_p],
+    "gtnx_linear_graph_borrow_n": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_graph_p],
     "gtnx_negate": [c_graph, c_graph_p],
     "gtnx_add": [c_graph, c_graph, c_graph_p],
     "gtnx_subtract": [c_graph, c_graph, c_graph_p],
@@ -100,6 +101,7 @@ _SIGS = {
     "gtnx_items_n": [c_graph_p, C.c_int, C.c_void_p],
     "gtnx_items_device_n": [c_graph_p, C.c_int, C.c_void_p],
     "gtnx_grads_device_n": [c_graph_p, C.c_int, C.c_void_p, C.c_void_p],
+    "gtnx_grads_bind_device_n": [c_graph_p, C.c_int, C.c_void_p, C.c_void_p],
     "gtnx_backward": [c_graph, C.c_int],
     "gtnx_backward_with_grad": [c_graph, c_graph, C.c_int],
     "gtnx_backward_n": [c_graph_p, C.c_int, C.c_int],

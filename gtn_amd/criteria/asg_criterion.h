@@ -56,7 +56,13 @@ inline void asgLossBatch(
     void* gradDev) {
   const int B = (int)targets.size();
   auto fals = parallelMap(asgForceAlign, targets);
-  auto ems = linearGraphs(B, T, N, emissions, gradDev != nullptr);
+  auto ems = linearGraphs(B, T, N, emissions, gradDev != nullptr, /*borrow=*/true);
+  std::vector<int64_t> off(B);
+  for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * N;
+  if (gradDev) {
+    auto he = detail::handles(ems);
+    detail::check(gtnx_grads_bind_device_n(he.data(), B, gradDev, off.data()));
+  }
   std::vector<Graph> trans{transitions};
   SymbolicCompose symbolic;  // force-align lattices: per-utterance sweeps where they apply
   auto fcc = batched::forwardScore(batched::compose(ems, trans));
@@ -67,8 +73,6 @@ inline void asgLossBatch(
   detail::check(gtnx_items_device_n(h.data(), B, lossDev));
   if (gradDev) {
     auto he = detail::handles(ems);
-    std::vector<int64_t> off(B);
-    for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * N;
     detail::check(gtnx_grads_device_n(he.data(), B, gradDev, off.data()));
   }
 }

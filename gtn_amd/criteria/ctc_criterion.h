@@ -65,7 +65,15 @@ inline void ctcLossBatch(
   auto ctcs =
       parallelMap([blank, targetGrad](const std::vector<int>& t) { return ctcTargetGraph(t, blank, targetGrad); }, targets);
   auto t1 = now();
-  auto ems = linearGraphs(B, T, C, emissions, gradDev != nullptr);
+  // the emissions are read in place (the caller's tensor outlives the step) and their gradient is
+  // written straight into the caller's tensor: no copy of either [B][T][C] block
+  auto ems = linearGraphs(B, T, C, emissions, gradDev != nullptr, /*borrow=*/true);
+  std::vector<int64_t> off(B);
+  for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
+  if (gradDev) {
+    auto he = detail::handles(ems);
+    detail::check(gtnx_grads_bind_device_n(he.data(), B, gradDev, off.data()));
+  }
   auto t2 = now();
   // only forwardScore of the lattices is taken: they need not be built (lazy_pair.hip sweeps them)
   SymbolicCompose symbolic;
@@ -84,9 +92,7 @@ inline void ctcLossBatch(
   detail::check(gtnx_items_device_n(h.data(), B, lossDev));
   if (gradDev) {
     auto he = detail::handles(ems);
-    std::vector<int64_t> off(B);
-    for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
-    detail::check(gtnx_grads_device_n(he.data(), B, gradDev, off.data()));
+    detail::check(gtnx_grads_device_n(he.data(), B, gradDev, off.data()));  // (no-op for rows already in place)
   }
 }
 

@@ -82,6 +82,21 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
 
+// A value that came from a global load and is first used inside the main loop would make the
+// compiler put its `s_waitcnt vmcnt` THERE -- where it also waits for every global store issued
+// since (stores count in vmcnt on gfx9): one store round trip per gradient row.  settle() is a
+// use in front of the loop; uniform() does the same and moves a wave-uniform value to an SGPR.
+__device__ __forceinline__ void settle(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void settle(int& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ float uniform(float x) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x)));
+}
+__device__ __forceinline__ double uniform(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = __builtin_amdgcn_readfirstlane(unsigned(b)), hi = __builtin_amdgcn_readfirstlane(unsigned(b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // lane i <- lane i-1 (lane 0 takes `fill`) / lane i <- lane i+1 (lane 63 takes `fill`)
 __device__ __forceinline__ float wave_shr1(float x, float fill) {
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), 0x138, 0xf, 0xf, false));
@@ -108,6 +123,19 @@ __device__ __forceinline__ float wave_sum63(float x) {  // lane 63 holds the tot
 }
 __device__ __forceinline__ float wave_sum(float x) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wave_sum63(x)), 63));
+}
+// two wave64 sums at once (the two chains fill each other's DPP wait states); totals in lane 63
+#define GTNX_DPP2(ctl)                                                  \
+  "v_add_f32_dpp %0, %0, %0 " ctl "\n\tv_add_f32_dpp %1, %1, %1 " ctl "\n\ts_nop 0\n\t"
+__device__ __forceinline__ void wave_sum63x2(float& a, float& b) {
+  asm volatile("s_nop 1\n\t"
+               GTNX_DPP2("row_shr:1 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_shr:2 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_shr:4 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_shr:8 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+               GTNX_DPP2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+               : "+v"(a), "+v"(b));
 }
 // all-reduce inside every aligned group of 16 lanes (one DPP row) by rotations
 #define GTNX_ROR4(op)                                                        \
@@ -196,22 +224,23 @@ __device__ __forceinline__ int row_of(int e, int W, float invW) {
   return r;
 }
 
-// A chunk of `rows` contiguous HBM rows of W floats each, staged through NS floats per lane:
-// issue() starts the loads, land() writes them to an LDS ring whose row `slot_of(r)` holds chunk row r.
-template <int NS>
+// A chunk of `rows` contiguous HBM rows of W floats each, staged through NS floats per lane of
+// a group of LN lanes: issue() starts the loads, each() hands them back with their coordinates.
+template <int NS, int LN = BW>
 struct Stage {
   float v[NS];
-  // loads are unconditional (lanes past the end re-read the last element): a conditional load
-  // would have to be merged with its default, i.e. waited for, right where it is issued.  VEC
-  // is a compile-time choice: with both forms in one kernel the second would wait for the first
-  // (they write the same registers)
+  // loads are unconditional per lane (lanes past the end re-read the last element): a load under
+  // a lane mask would have to be merged with its default, i.e. waited for, right where it is
+  // issued.  Whole rounds past the end are skipped (uniform).  VEC is a compile-time choice: with
+  // both forms in one kernel the second would wait for the first (they write the same registers)
   template <bool VEC>
   __device__ __forceinline__ void issue(const GTNX_G float* src, int cnt, int tid) {
     if (cnt <= 0) return;  // uniform
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < NS / 4; ++i) {
-        const int e = min(4 * (i * BW + tid), cnt - 4);
+        if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
+        const int e = min(4 * (i * LN + tid), cnt - 4);
         const gtnx_f4 q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
         v[4 * i] = q.x;
         v[4 * i + 1] = q.y;
@@ -220,8 +249,39 @@ struct Stage {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) v[i] = src[min(i * BW + tid, cnt - 1)];
+      for (int i = 0; i < NS; ++i) {
+        if (i > 0 && i * LN >= cnt) break;  // uniform
+        v[i] = src[min(i * LN + tid, cnt - 1)];
+      }
     }
+  }
+  // VEC mode: where slot i of a FULL chunk of K rows lands in a ring block whose rows are `stride`
+  // floats apart and in reverse order (chunk row r -> block row K-1-r), computed once: a chunk of
+  // fewer rows sits (K - rows) block rows lower
+  int off[NS / 4];
+  __device__ __forceinline__ void init_offsets(int W, int stride, int K, int tid) {
+    const float invW = 1.0f / float(W);
+#pragma unroll
+    for (int i = 0; i < NS / 4; ++i) {
+      const int e = 4 * (i * LN + tid);
+      const int r = row_of(min(e, 4096), W, invW);
+      off[i] = (K - 1 - r) * stride + (e - r * W);
+    }
+  }
+  // f(i, ring offset, values) for the slots of a chunk of `rows` rows of W floats
+  template <class F>
+  __device__ __forceinline__ void each_vec(int cnt, int shift, int tid, F&& f) const {
+#pragma unroll
+    for (int i = 0; i < NS / 4; ++i) {
+      if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
+      if (4 * (i * LN + tid) < cnt) f(i, off[i] - shift, gtnx_f4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]});
+    }
+  }
+  // a use of every staging register: all of this wave's loads are waited for HERE, and the
+  // compiler knows that none is pending when the next issue() reuses the registers
+  __device__ __forceinline__ void settle_all() {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) asm volatile("" : "+v"(v[i]));
   }
   // f(i, e, r, c, q): slot index, element, chunk row, column, values (4 in vec mode, else q.x)
   template <bool VEC, class F>
@@ -230,7 +290,8 @@ struct Stage {
     if constexpr (VEC) {
 #pragma unroll
       for (int i = 0; i < NS / 4; ++i) {
-        const int e = 4 * (i * BW + tid);
+        if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
+        const int e = 4 * (i * LN + tid);
         if (e < cnt) {
           const int r = row_of(e, W, invW);
           f(i, e, r, e - r * W, gtnx_f4{v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]});
@@ -239,7 +300,8 @@ struct Stage {
     } else {
 #pragma unroll
       for (int i = 0; i < NS; ++i) {
-        const int e = i * BW + tid;
+        if (i > 0 && i * LN >= cnt) break;  // uniform
+        const int e = i * LN + tid;
         if (e < cnt) {
           const int r = row_of(e, W, invW);
           f(i, e, r, e - r * W, gtnx_f4{v[i], 0.0f, 0.0f, 0.0f});
@@ -583,11 +645,13 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
 // block, helper lane c GATHERS the nodes that carry label c (lists sorted by label come with
 // the pair) and stores the finished gradient element -- coalesced, once.
 // ==========================================================================================
-template <int NPL, bool UNIT, bool GRADG, int K, bool VEC>
-__global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
+// BIG: a block of K rows holds more than 1024 emissions (K = 2, C > 512): 32 staging registers per
+// helper lane and stream instead of 16 -- such shapes run one workgroup per CU (LDS), so the
+// register budget is 256 there and 128 otherwise
+template <int NPL, bool UNIT, bool GRADG, int K, bool VEC, bool BIG>
+__global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
   constexpr int RNk = K >= 4 ? 4 : K;
   constexpr int NP = K / RNk;
-  constexpr int D = 8 / K;
   const BandPair P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
@@ -605,9 +669,9 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
   const int nblocks = (T + K - 1) / K;
   const int nticks = nblocks + 5;  // block c: row sums at tick c + 4, gradient rows out at tick c + 5
   const GTNX_G double* ao = P.aoff;
-  const double z2 = ao[0];
+  const double z2 = uniform(ao[0]);
   const bool dead = !(z2 > double(DEADF));
-  const float ds = P.delta[0];
+  const float ds = uniform(P.delta[0]);
   const bool want_em = P.grad_em != nullptr;
   GTNX_TM_INIT(64);
 
@@ -618,16 +682,25 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
     const int m0 = threadIdx.x * NPL;
     NodeRegs<NPL> g;
     load_nodes<NPL, true>(P, m0, g);
-    float b[NPL], ahi[NPL], acc[3][NPL];
+    float b[NPL], post[NPL], acc[3][NPL];
+    // frames: true alpha[r] = stored + ao[1 + (r >> lgrn) * 4 + w] (periods of the FORWARD launch); true beta = b + bsum
+    const double Ahi = uniform(ao[1 + (T >> P.lgrn) * 4 + w]);
+    double bsum = 0.0;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       b[j] = g.accept[j] ? 0.0f : NEGF;
-      ahi[j] = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
+      float ahi = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
+      settle(ahi);
+      // posterior of node n at time T (gradient row T-1); every later one comes out of the recursion
+      post[j] = dead ? 0.0f : ex2(ahi + b[j] + float(Ahi - z2));  // (the row scale carries d score)
       acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
+      settle(g.lab[j]);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        settle(g.wo[k][j]);
+        settle(g.ao[k][j]);
+      }
     }
-    // frames: true alpha[r] = stored + ao[1 + (r >> lgrn) * 4 + w] (periods of the FORWARD launch); true beta = b + bsum
-    double Ahi = ao[1 + (T >> P.lgrn) * 4 + w];
-    double bsum = 0.0;
     // pipeline position s = 3 - w: this wave publishes into region s + 1 and reads region s (0: constants)
     float* bnd_own = M.bndr + (4 - w) * 4 * K * 2;
     const float* bnd_prev = M.bndr + (3 - w) * 4 * K * 2;
@@ -638,37 +711,27 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
     if (l == 0) off_own[0] = 0.0;
     lds_barrier();  // (the helpers sort labels in the posterior ring ...
     lds_barrier();  //  ... done)
-    const int tid = threadIdx.x;
-    const float dn = P.delta_norm ? P.delta_norm[0] : 0.0f;
+    const float dn = P.delta_norm ? uniform(P.delta_norm[0]) : 0.0f;
     const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
-    const int* cls = reinterpret_cast<const int*>(oring);
     auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-    // this lane's labels (tid, tid + 256, ...): run of nodes, the first two inline
-    constexpr int NCS = 8 / K;  // C <= 2048 / K labels, 256 per round
-    int cs_s[NCS], cs_e[NCS], cs_n0[NCS], cs_n1[NCS];
-    float cs_m0[NCS], cs_m1[NCS];
+    // row sums: lane l of the summing wave owns nodes 4l .. 4l+3 (+ 256 for the second read); the ring
+    // holds 0 for nodes past N, so only whole reads past the row are masked
+    float rs_in[NPL];
+    gtnx_f4 rs_hot[NPL];
 #pragma unroll
-    for (int s = 0; s < NCS; ++s) {
-      const int cc = tid + s * BW;
-      cs_s[s] = cs_e[s] = 0;
-      if (cc < C && cc != P.hot) {
-        cs_s[s] = cls[cc];
-        cs_e[s] = cls[C + cc];
+    for (int q = 0; q < NPL; ++q) {
+      const int mb = 256 * q + 4 * l;
+      rs_in[q] = mb < NSmax ? 1.0f : 0.0f;
+      float hm[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = mb + k;
+        int lab = -1;
+        if (m < P.N) lab = P.nodes[m].lab;
+        settle(lab);
+        hm[k] = (P.hot >= 0 && lab == P.hot) ? 1.0f : 0.0f;
       }
-      const int cnt = cs_e[s] - cs_s[s];
-      cs_n0[s] = cnt > 0 ? snode[cs_s[s]] : 0;
-      cs_n1[s] = cnt > 1 ? snode[cs_s[s] + 1] : 0;
-      cs_m0[s] = cnt > 0 ? 1.0f : 0.0f;
-      cs_m1[s] = cnt > 1 ? 1.0f : 0.0f;
-    }
-    const int hot_s = P.hot >= 0 ? cls[P.hot] : 0, hot_e = P.hot >= 0 ? cls[C + P.hot] : 0;
-    int hn[4];  // this lane's share of the hot label's nodes (at most 256 + ... of them inline)
-    float hm[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int i = hot_s + l + 64 * k;
-      hn[k] = i < hot_e ? snode[i] : 0;
-      hm[k] = i < hot_e ? 1.0f : 0.0f;
+      rs_hot[q] = gtnx_f4{hm[0], hm[1], hm[2], hm[3]};
     }
     // gradient rows of block c (every sweeper is through with it): gather by label, add the
     // normaliser's softmax term, store
@@ -682,58 +745,33 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
       if (!want_em || w >= rows) return;
       const int r = w;
       const float* ob = oring + ((c % NBG) * K + r) * NSmax;
-      float all = 0.0f, hotp = 0.0f;
-      if (!dead) {
-        for (int m = l; m < P.N; m += 64) all += ob[m];
+      // lane l sums nodes 4l .. 4l+3 (and 256 + 4l .. for two nodes per lane): one 16-byte read each;
+      // the hot label's share comes out of the same registers through a per-node mask
+      gtnx_f4 v[NPL];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) hotp += ob[hn[k]] * hm[k];
-        for (int i = hot_s + l + 256; i < hot_e; i += 64) hotp += ob[snode[i]];
+      for (int q = 0; q < NPL; ++q) v[q] = *reinterpret_cast<const gtnx_f4*>(ob + min(256 * q + 4 * l, NSmax - 4));
+      const float em_hot = ering[((c % NBG) * K + r) * CS + max(P.hot, 0)];
+      const float ls_hot = lser[(c % NBG) * K + r];
+      float all = 0.0f, hotp = 0.0f;
+#pragma unroll
+      for (int q = 0; q < NPL; ++q) {
+        all += (v[q].x * rs_in[q] + v[q].y * rs_in[q]) + (v[q].z * rs_in[q] + v[q].w * rs_in[q]);
+        hotp += (v[q].x * rs_hot[q].x + v[q].y * rs_hot[q].y) + (v[q].z * rs_hot[q].z + v[q].w * rs_hot[q].w);
       }
-      all = wave_sum(all);
-      const float f = (all != 0.0f && !dead) ? ds / all : 1.0f;
-      if (P.hot >= 0) {
-        hotp = wave_sum63(hotp);
-        if (l == 63) {
-          const float sm = soft ? dn * ex2(ering[((c % NBG) * K + r) * CS + P.hot] - lser[(c % NBG) * K + r]) : 0.0f;
-          P.grad_em[int64_t(T - 1 - c * K - r) * C + P.hot] = hotp * f + sm;
-        }
+      if (dead) all = hotp = 0.0f;  // nothing wrote the ring
+      wave_sum63x2(all, hotp);
+      all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all), 63));
+      const float f = (all != 0.0f && !dead) ? ds * __builtin_amdgcn_rcpf(all) : 1.0f;
+      if (l == 63 && P.hot >= 0) {
+        float sm = dn * ex2(em_hot - ls_hot);
+        sm = soft ? sm : 0.0f;
+        P.grad_em[int64_t(T - 1 - c * K - r) * C + P.hot] = (dead ? 0.0f : hotp * f) + sm;
       }
       if (l == 0) rnorm[(c % NBG) * K + r] = f;
-    };
-    auto drain = [&](int c) {
-      const int rows = rows_of(c);
-      if (!want_em || rows <= 0) return;
-      const float* ob = oring + (c % NBG) * K * NSmax;
-      const float* eb = ering + (c % NBG) * K * CS;
-      const float* lb = lser + (c % NBG) * K;
-      const float* fb = rnorm + (c % NBG) * K;
-      GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
-#pragma unroll
-      for (int s = 0; s < NCS; ++s) {
-        const int cc = tid + s * BW;
-        if (cc < C && cc != P.hot) {
-          float sum[K];
-#pragma unroll
-          for (int r = 0; r < K; ++r)
-            sum[r] = dead ? 0.0f : ob[r * NSmax + cs_n0[s]] * cs_m0[s] + ob[r * NSmax + cs_n1[s]] * cs_m1[s];
-          for (int i = cs_s[s] + 2; i < cs_e[s] && !dead; ++i) {
-            const float* o = ob + snode[i];
-#pragma unroll
-            for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
-          }
-#pragma unroll
-          for (int r = 0; r < K; ++r)
-            if (r < rows) {
-              const float sm = soft ? dn * ex2(eb[r * CS + cc] - lb[r]) : 0.0f;
-              dst[-int64_t(r) * C + cc] = sum[r] * fb[r] + sm;
-            }
-        }
-      }
     };
     lds_barrier();  // the label table is in registers: the posterior ring may be written
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      if (tau >= 5) drain(tau - 5);
       if (tau >= 4) rowsum(tau - 4);  // the last wave left block tau - 4 a tick ago
       GTNX_TM(3);
       const int beta = tau - lag;
@@ -750,7 +788,7 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
 #pragma unroll
           for (int j = 0; j < NPL; ++j) {
             ev[i][j] = eb[i * CS + g.lab[j]];
-            alov[i][j] = ab[i * NSmax + min(m0 + j, NSmax - 1)];
+            alov[i][j] = ab[i * NSmax + min(m0 + j, NS - 1)];  // (landed data only: lanes past N stay finite)
           }
           Acur[i] = Ab[i * 4];
           // q[v0 + i] of the two nodes above this wave, in the next wave's frame
@@ -766,19 +804,17 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
         for (int i = 0; i < K; ++i) {
           if (i < rows) {
             if (i % RNk == 0) dconv = float(offp[i / RNk] - bsum);
-            const double bz = bsum - z2;
             float q[NPL];
 #pragma unroll
             for (int j = 0; j < NPL; ++j) qh[i][j] = q[j] = ev[i][j] + b[j];
-            // node posteriors at time t+1 (they belong to gradient row t)
+            // node posteriors at time t+1 (they belong to gradient row t): carried over from the step before
             if (want_em && m0 < NSmax) {
-              const float dh = float(Ahi + bz);
 #pragma unroll
-              for (int j = 0; j < NPL; ++j) ob[i * NSmax + j] = ex2(ahi[j] + b[j] + dh) * ds;
+              for (int j = 0; j < NPL; ++j) ob[i * NSmax + j] = post[j];
             }
             const float n1 = wave_shl1(q[0], bq1[i] + dconv);
             const float n2 = NPL == 2 ? wave_shl1(q[NPL - 1], bq2[i] + dconv) : wave_shl1(n1, bq2[i] + dconv);
-            const float dl = GRADG ? float(Acur[i] + bz) : 0.0f;
+            const float dl = float(Acur[i] + (bsum - z2));
             float nb[NPL];
 #pragma unroll
             for (int j = 0; j < NPL; ++j) {
@@ -794,18 +830,23 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
                 y1 = s1 + g.wo[1][j];
                 y2 = s2 + g.wo[2][j];
               }
+              // exp(alpha[t][n] + y_k - score) is the posterior of arc k leaving (t, n); their sum is the
+              // posterior of node n at time t -- the NEXT row's gradient term, for one multiply
+              const float mx = fmaxf(fmaxf(y0, y1), y2);
+              const float f = ex2(alov[i][j] + mx + dl);
+              float S;
               if (GRADG) {
-                // the exponentials of the log-sum-exp are the arc posteriors up to one factor per node
-                const float mx = fmaxf(fmaxf(y0, y1), y2);
                 const float e0 = ex2(y0 - mx), e1 = ex2(y1 - mx), e2 = ex2(y2 - mx);
-                nb[j] = mx + lg2(e0 + e1 + e2);
-                const float f = ex2(alov[i][j] + mx + dl);
+                S = e0 + e1 + e2;
                 acc[0][j] += e0 * f;
                 acc[1][j] += e1 * f;
                 acc[2][j] += e2 * f;
-              } else {
-                nb[j] = lse3(y0, y1, y2);
+              } else {  // the largest term is exactly 1
+                const float md = __builtin_amdgcn_fmed3f(y0, y1, y2), mn = fminf(fminf(y0, y1), y2);
+                S = 1.0f + ex2(md - mx) + ex2(mn - mx);
               }
+              nb[j] = mx + lg2(S);
+              post[j] = f * S;
             }
             if ((i + 1) % RNk == 0) {  // shift this wave's beta row v0 + i + 1 by its maximum
               const float mx = wave_max_of(nb, NPL);
@@ -819,11 +860,7 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
               if (l == 0) off_own[((v0 + i + 1) / RNk) & 15] = bsum;
             }
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-              b[j] = nb[j];
-              ahi[j] = alov[i][j];
-            }
-            Ahi = Acur[i];
+            for (int j = 0; j < NPL; ++j) b[j] = nb[j];
           }
         }
         // q of this wave's first two nodes for the wave below
@@ -857,7 +894,6 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
   } else {
     // ------------------------------------------------------------------ helpers: staging, gradient rows
     const int hid = threadIdx.x - BW;
-    constexpr bool vec = VEC;
     const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
     // label -> run of nodes in snode (table built in the posterior ring, which is idle until the first tick)
     int* cls = reinterpret_cast<int*>(oring);
@@ -870,60 +906,146 @@ __global__ __launch_bounds__(WG) void band_backward_kernel(const BandPair* __res
       if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
     }
     // ---- staging: chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; HBM rows tlo ..
-    Stage<8> se[D], sa[D];
-    float lse_s[D] = {};
-    double af_s[D] = {};
+    // Helper wave h owns the chunks c = h (mod 4): it lands chunk c during tick c - 1 and then
+    // requests chunk c + 4, so a load has four ticks to arrive and a wave only ever waits for its
+    // OWN loads (vmcnt is per wave) -- with one wave staging every chunk the compiler's counter
+    // made each request wait for the chunk requested a tick earlier.
+    const int h = wv - 4;
+    Stage<BIG ? 32 : 16, 64> se, sa;  // K C and K NS floats over 64 lanes (<= 1024, BIG: <= 2048)
+    if constexpr (VEC) se.init_offsets(C, CS, K, l);
+    sa.init_offsets(NS, NSmax, K, l);
+    float lse_s = 0.0f;
+    double af_s = 0.0;
     auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
     auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
-    auto issue = [&](int d, int c) {
+    auto issue = [&](int c) {
       const int rows = rows_of(c), tlo = tlo_of(c);
-      se[d].template issue<VEC>(P.em + int64_t(tlo) * C, rows * C, hid);
-      sa[d].template issue<true>(P.alpha + int64_t(tlo) * NS, rows * NS, hid);
+      se.template issue<VEC>(P.em + int64_t(tlo) * C, rows * C, l);
+      sa.template issue<true>(P.alpha + int64_t(tlo) * NS, rows * NS, l);
       if (rows > 0) {  // uniform; unconditional clamped loads (see Stage::issue)
-        if (soft) lse_s[d] = P.rowlse[tlo + min(hid, rows - 1)];
-        // alpha frame of ring row i = hid / 4 (t = T-1-cK-i) for sweeper wave hid % 4
-        af_s[d] = ao[1 + ((T - 1 - c * K - min(hid >> 2, rows - 1)) >> P.lgrn) * 4 + (hid & 3)];
+        if (soft) lse_s = P.rowlse[tlo + min(l, rows - 1)];
+        // alpha frame of ring row i = l / 4 (t = T-1-cK-i) for sweeper wave l % 4
+        af_s = ao[1 + ((T - 1 - c * K - min(l >> 2, rows - 1)) >> P.lgrn) * 4 + (l & 3)];
       }
     };
     // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block
-    auto land = [&](int d, int c) {
+    auto land = [&](int c) {
       const int rows = rows_of(c);
+      se.settle_all();
+      sa.settle_all();
+      asm volatile("" : "+v"(lse_s), "+v"(af_s));
+      GTNX_TM(4);
       if (rows <= 0) return;
       float* eb = ering + (c % NBG) * K * CS;
       float* ab = aring + (c % NBE) * K * NSmax;
-      se[d].template each<VEC>(rows * C, C, hid, [&](int, int, int r, int col, gtnx_f4 q) {
-        float* dd = eb + (rows - 1 - r) * CS + col;
-        const gtnx_f4 q2 = {em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-        if (vec) *reinterpret_cast<gtnx_f4*>(dd) = q2;
-        else dd[0] = q2.x;
-      });
-      sa[d].template each<true>(rows * NS, NS, hid, [&](int, int, int r, int col, gtnx_f4 q) {
-        *reinterpret_cast<gtnx_f4*>(ab + (rows - 1 - r) * NSmax + col) = q;
-      });
-      if (hid < rows) lser[(c % NBG) * K + rows - 1 - hid] = lse_s[d];
-      if (hid < 4 * rows) M.aofr[((c % NBE) * K) * 4 + hid] = af_s[d];
-    };
-    // prologue: chunk 0 landed, chunks 1 .. D requested
-    issue(0, 0);
-    land(0, 0);
-#pragma unroll
-    for (int c = 1; c <= D; ++c) issue(c % D, c);
-    lds_barrier();
-    lds_barrier();  // (the sweepers read their label runs; then the posterior ring is theirs)
-    for (int tau0 = 0; tau0 < nticks; tau0 += D) {
-#pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int tau = tau0 + d;
-        if (tau >= nticks) break;
-        GTNX_TM(0);
-        land((d + 1) % D, tau + 1);
-        GTNX_TM(1);
-        issue((d + 1) % D, tau + 1 + D);
-        GTNX_TM(2);
-        lds_barrier();
-        GTNX_TM(6);
-        GTNX_TM_TICK();
+      if constexpr (VEC) {
+        se.each_vec(rows * C, (K - rows) * CS, l, [&](int, int o, gtnx_f4 q) {
+          *reinterpret_cast<gtnx_f4*>(eb + o) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
+        });
+      } else {
+        se.template each<false>(rows * C, C, l, [&](int, int, int r, int col, gtnx_f4 q) {
+          eb[(rows - 1 - r) * CS + col] = em2(q.x);
+        });
       }
+      sa.each_vec(rows * NS, (K - rows) * NSmax, l, [&](int, int o, gtnx_f4 q) { *reinterpret_cast<gtnx_f4*>(ab + o) = q; });
+      if (l < rows) lser[(c % NBG) * K + rows - 1 - l] = lse_s;
+      if (l < 4 * rows) M.aofr[((c % NBE) * K) * 4 + l] = af_s;
+    };
+    // prologue: chunk 0 landed, chunks 1 .. 4 requested
+    issue(h);
+    if (h == 0) {
+      land(0);
+      issue(4);
+    }
+    lds_barrier();
+    // gradient rows of block c (every sweeper is through with it, its rows are summed): helper lane
+    // cc GATHERS the posteriors of the nodes that carry label cc, adds the normaliser's softmax
+    // term and stores the finished element -- coalesced, once
+    const float dn = P.delta_norm ? uniform(P.delta_norm[0]) : 0.0f;
+    const float* rnorm = lser + NBG * K;
+    // this lane's labels (tid, tid + 256, ...): run of nodes, the first two inline
+    constexpr int NCS = 8 / K;  // C <= 2048 / K labels, 256 per round
+    int cs_s[NCS], cs_e[NCS], cs_n0[NCS], cs_n1[NCS];
+    float cs_m0[NCS], cs_m1[NCS];
+#pragma unroll
+    for (int s = 0; s < NCS; ++s) {
+      const int cc = hid + s * BW;
+      cs_s[s] = cs_e[s] = 0;
+      if (cc < C && cc != P.hot) {
+        cs_s[s] = cls[cc];
+        cs_e[s] = cls[C + cc];
+      }
+      const int cnt = cs_e[s] - cs_s[s];
+      cs_n0[s] = cnt > 0 ? snode[cs_s[s]] : 0;
+      cs_n1[s] = cnt > 1 ? snode[cs_s[s] + 1] : 0;
+      cs_m0[s] = cnt > 0 ? 1.0f : 0.0f;
+      cs_m1[s] = cnt > 1 ? 1.0f : 0.0f;
+    }
+    auto drain = [&](int c) {
+      const int rows = rows_of(c);
+      if (!want_em || rows <= 0) return;
+      const float* ob = oring + (c % NBG) * K * NSmax;
+      const float* eb = ering + (c % NBG) * K * CS;
+      const float* lb = lser + (c % NBG) * K;
+      const float* fb = rnorm + (c % NBG) * K;
+      GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
+#pragma unroll
+      for (int s = 0; s < NCS; ++s) {
+        if (s > 0 && s * BW >= C) break;  // uniform
+        const int cc = hid + s * BW;
+        const bool mine = cc < C && cc != P.hot;
+        // every LDS read of the K rows first (addresses are known up front), then the arithmetic
+        float p0[K], p1[K], e[K], ls[K], f[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          p0[r] = ob[r * NSmax + cs_n0[s]];
+          p1[r] = ob[r * NSmax + cs_n1[s]];
+          e[r] = eb[r * CS + min(cc, C - 1)];
+        }
+        if constexpr (K == 4) {  // the rows' scalars: two 16-byte broadcast reads
+          const gtnx_f4 l4 = *reinterpret_cast<const gtnx_f4*>(lb), f4 = *reinterpret_cast<const gtnx_f4*>(fb);
+          ls[0] = l4.x, ls[1] = l4.y, ls[2] = l4.z, ls[3] = l4.w;
+          f[0] = f4.x, f[1] = f4.y, f[2] = f4.z, f[3] = f4.w;
+        } else {
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            ls[r] = lb[r];
+            f[r] = fb[r];
+          }
+        }
+        float sum[K];
+#pragma unroll
+        for (int r = 0; r < K; ++r) sum[r] = p0[r] * cs_m0[s] + p1[r] * cs_m1[s];
+        for (int i = cs_s[s] + 2; i < cs_e[s]; ++i) {  // (a label on more than two nodes)
+          const float* o = ob + snode[i];
+#pragma unroll
+          for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) {
+          float sm = dn * ex2(e[r] - ls[r]);
+          sm = soft ? sm : 0.0f;
+          const float val = (dead ? 0.0f : sum[r] * f[r]) + sm;
+          if (mine && r < rows) dst[-int64_t(r) * C + cc] = val;
+        }
+      }
+    };
+    lds_barrier();  // (label runs are in registers; the posterior ring is the sweepers')
+    for (int tau = 0; tau < nticks; ++tau) {
+      GTNX_TM(0);
+      // (landing first: its s_waitcnt vmcnt(0) also covers this wave's gradient stores -- stores count
+      //  in vmcnt -- and the ones of the drain below would be a tick old instead of just issued)
+      if (((tau + 1) & 3) == h) {  // uniform
+        land(tau + 1);
+        GTNX_TM(1);
+        issue(tau + 5);
+        GTNX_TM(2);
+      }
+      if (tau >= 5) drain(tau - 5);
+      GTNX_TM(3);
+      lds_barrier();
+      GTNX_TM(6);
+      GTNX_TM_TICK();
     }
     GTNX_TM_DUMP();
   }
@@ -946,24 +1068,32 @@ void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool ve
   if (vec) launch_fwd2<NPL, K, true>(d, n, ns, lds, unit, st);
   else launch_fwd2<NPL, K, false>(d, n, ns, lds, unit, st);
 }
-template <int NPL, int K, bool VEC>
-void launch_bwd2(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+template <int NPL, int K, bool VEC, bool BIG>
+void launch_bwd3(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
   static bool attr =
-      (big_lds(band_backward_kernel<NPL, true, true, K, VEC>), big_lds(band_backward_kernel<NPL, true, false, K, VEC>),
-       big_lds(band_backward_kernel<NPL, false, true, K, VEC>), big_lds(band_backward_kernel<NPL, false, false, K, VEC>), true);
+      (big_lds(band_backward_kernel<NPL, true, true, K, VEC, BIG>), big_lds(band_backward_kernel<NPL, true, false, K, VEC, BIG>),
+       big_lds(band_backward_kernel<NPL, false, true, K, VEC, BIG>), big_lds(band_backward_kernel<NPL, false, false, K, VEC, BIG>),
+       true);
   (void)attr;
   if (unit) {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
   } else {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
   }
 }
 template <int NPL, int K>
-void launch_bwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, hipStream_t st) {
-  if (vec) launch_bwd2<NPL, K, true>(d, n, ns, lds, unit, gradg, st);
-  else launch_bwd2<NPL, K, false>(d, n, ns, lds, unit, gradg, st);
+void launch_bwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, bool big, hipStream_t st) {
+  if constexpr (K == 2) {
+    if (big) {
+      if (vec) launch_bwd3<NPL, K, true, true>(d, n, ns, lds, unit, gradg, st);
+      else launch_bwd3<NPL, K, false, true>(d, n, ns, lds, unit, gradg, st);
+      return;
+    }
+  }
+  if (vec) launch_bwd3<NPL, K, true, false>(d, n, ns, lds, unit, gradg, st);
+  else launch_bwd3<NPL, K, false, false>(d, n, ns, lds, unit, gradg, st);
 }
 
 constexpr size_t LDS_TWO = 78 * 1024;   // two workgroups per CU
@@ -981,6 +1111,7 @@ int band_forward_lgrn(int C) { return band_block_rows(C, 0, false) >= 4 ? 2 : 1;
 int band_block_rows(int C, int max_NS, bool backward) {
   for (int k = backward ? 4 : 8; k >= 2; k /= 2) {
     if (k * C > 2048 || k * max_NS > 2048) continue;
+    if (backward && k > 2 && (k * C > 1024 || k * max_NS > 1024)) continue;  // 16 staging registers per stream
     if (4 * size_t(band_lds(C, k, max_NS, backward).total) + 64 <= LDS_TWO) return k;
   }
   if (4 * size_t(band_lds(C, 2, max_NS, backward).total) + 64 <= LDS_ONE) return 2;
@@ -1008,12 +1139,13 @@ void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int ma
   if (n <= 0) return;
   const int K = band_block_rows(C, max_NS, true);
   const size_t lds = 4 * size_t(band_lds(C, K, max_NS, true).total) + 64;
+  const bool big = K * C > 1024 || K * max_NS > 1024;
   if (npl == 1) {
-    if (K == 4) launch_bwd<1, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
-    else launch_bwd<1, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
+    if (K == 4) launch_bwd<1, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
+    else launch_bwd<1, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
   } else {
-    if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
-    else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, st);
+    if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
+    else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
   }
 }
 

@@ -455,6 +455,13 @@ GTNX_API gtnx_status_t gtnx_linear_graph_n(int B, int M, int N, int cg, const vo
     put(r, out);
   });
 }
+GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, const void* dev, gtnx_graph_t* out) {
+  return guard([&] {
+    if (!dev && B > 0 && M > 0 && N > 0) throw_invalid("[gtnx_linear_graph_borrow_n] null device tensor");
+    auto r = make_linear_graphs_device(B, M, N, cg != 0, dev, /*borrow=*/true);
+    put(r, out);
+  });
+}
 
 // ------------------------------------------------------------------ functions
 #define UNARY_FN(name, expr, LAZY_OK)                                       \
@@ -518,6 +525,12 @@ GTNX_API gtnx_status_t gtnx_grads_device_n(const gtnx_graph_t* g, int n, void* o
   return guard([&] {
     auto v = vec(g, n);
     grads_device(v, out, offsets);
+  });
+}
+GTNX_API gtnx_status_t gtnx_grads_bind_device_n(const gtnx_graph_t* g, int n, void* out, const int64_t* offsets) {
+  return guard([&] {
+    auto v = vec(g, n);
+    grads_bind_device(v, out, offsets);
   });
 }
 

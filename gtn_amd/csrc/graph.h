@@ -208,6 +208,10 @@ struct GradState {
   std::unique_ptr<Graph> grad;
   std::atomic<int> n_consumers{0};  // op outputs that list this graph as an input (two threads may reclaim at once)
   bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
+  // gtnx_grads_bind_device_n: caller-owned device memory the FIRST gradient of this graph is to be
+  // written to (the emission-gradient tensor of a criterion); kernels that can store there directly do
+  DevMemP grad_dest_mem;
+  float* grad_dest = nullptr;
   ~GradState();                  // gives the consumer counts of `inputs` back
 };
 inline bool Graph::calc_grad() const { return g->calc_grad; }

@@ -188,13 +188,21 @@ Graph make_linear_graph(int M, int N, bool calc_grad) {
   return g;
 }
 
-std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev) {
+std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev, bool borrow) {
   Runtime& rt = Runtime::get();
   std::vector<Graph> out;
   out.reserve(B);
   const int64_t A = int64_t(M) * N;
-  DevMemP arena = rt.alloc(sizeof(float) * size_t(A) * size_t(B > 0 ? B : 1));
-  if (dev && A && B) rt.d2d(arena->ptr, dev, sizeof(float) * size_t(A) * size_t(B));
+  DevMemP arena;
+  if (borrow && dev) {  // the weights ARE the caller's tensor (it promises to keep it alive and unchanged)
+    arena = std::make_shared<DevMem>();
+    arena->ptr = const_cast<void*>(dev);
+    arena->bytes = sizeof(float) * size_t(A) * size_t(B);
+    arena->borrowed = true;
+  } else {
+    arena = rt.alloc(sizeof(float) * size_t(A) * size_t(B > 0 ? B : 1));
+    if (dev && A && B) rt.d2d(arena->ptr, dev, sizeof(float) * size_t(A) * size_t(B));
+  }
   for (int b = 0; b < B; ++b) {
     Graph g(calc_grad);
     Structure& s = *g.s;
@@ -2090,11 +2098,20 @@ struct LazyPairSdOp : OpRecord {
     GradSink sink;
     size_t eb = 0, fb = 0;
     std::vector<size_t> eo(ms.size(), 0), fo(ms.size(), 0);
+    std::vector<float*> dest(ms.size(), nullptr);
+    std::vector<DevMemP> dest_mem(ms.size());
     for (size_t k = 0; k < ms.size(); ++k) {
       const int i = ms[k].idx;
       if (chains[i].calc_grad()) {
-        eo[k] = eb;
-        eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+        GradState& cg = *chains[i].g;
+        if (cg.grad_dest && !chains[i].is_grad_available()) {  // first gradient: straight into the caller's tensor
+          dest[k] = cg.grad_dest;
+          dest_mem[k] = cg.grad_dest_mem;
+          cg.grad_dest = nullptr;  // (a second sweep over the same chain accumulates onto it)
+        } else {
+          eo[k] = eb;
+          eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+        }
       }
       if (fixed[i].calc_grad()) {
         fo[k] = fb;
@@ -2109,10 +2126,10 @@ struct LazyPairSdOp : OpRecord {
       const int i = ms[k].idx;
       LazyPair p = pairs[i];
       p.delta = grad_dev_ptr(ms[k].out);
-      p.grad_em = chains[i].calc_grad() ? gem->as<float>(eo[k]) : nullptr;
+      p.grad_em = chains[i].calc_grad() ? (dest[k] ? dest[k] : gem->as<float>(eo[k])) : nullptr;
       p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
       tab.push_back(p);
-      if (p.grad_em) sink.add(chains[i], gem, p.grad_em);
+      if (p.grad_em) sink.add(chains[i], dest[k] ? dest_mem[k] : gem, p.grad_em);
       if (p.grad_fixed) sink.add(fixed[i], gfx, p.grad_fixed);
       ms[k].out.g->inputs[0].g->grad_propagated = true;
     }
@@ -2255,11 +2272,20 @@ struct BandSdOp : OpRecord {
     Runtime& rt = Runtime::get();
     size_t eb = 0, fb = 0;
     std::vector<size_t> eo(ms.size(), 0), fo(ms.size(), 0);
+    std::vector<float*> dest(ms.size(), nullptr);
+    std::vector<DevMemP> dest_mem(ms.size());
     for (size_t k = 0; k < ms.size(); ++k) {
       const int i = ms[k].idx;
       if (chains[i].calc_grad()) {
-        eo[k] = eb;
-        eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+        GradState& cg = *chains[i].g;
+        if (cg.grad_dest && !chains[i].is_grad_available()) {  // first gradient: straight into the caller's tensor
+          dest[k] = cg.grad_dest;
+          dest_mem[k] = cg.grad_dest_mem;
+          cg.grad_dest = nullptr;  // (a second sweep over the same chain accumulates onto it)
+        } else {
+          eo[k] = eb;
+          eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+        }
       }
       if (fixed[i].calc_grad()) {
         fo[k] = fb;
@@ -2283,10 +2309,10 @@ struct BandSdOp : OpRecord {
       BandPair p = pairs[i];
       p.delta = grad_dev_ptr(ms[k].out);
       p.delta_norm = nullptr;
-      p.grad_em = chains[i].calc_grad() ? gem->as<float>(eo[k]) : nullptr;
+      p.grad_em = chains[i].calc_grad() ? (dest[k] ? dest[k] : gem->as<float>(eo[k])) : nullptr;
       p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
       plan.band.push_back({p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0, band_vec(p), p, chains[i].w.get()});
-      if (p.grad_em) plan.sink.add(chains[i], gem, p.grad_em);
+      if (p.grad_em) plan.sink.add(chains[i], dest[k] ? dest_mem[k] : gem, p.grad_em);
       if (p.grad_fixed) plan.sink.add(fixed[i], gfx, p.grad_fixed);
       ms[k].out.g->inputs[0].g->grad_propagated = true;
       // algorithmic bytes: emissions in, emission gradient out, alpha back in, G's arc gradients out
@@ -2836,14 +2862,29 @@ void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets)
   std::vector<Weights*> ws;
   for (auto& g : gs) ws.push_back(g.grad().w.get());
   ensure_weights_device_batch(ws);
-  std::vector<AxpyArgs> ax(n);
+  std::vector<AxpyArgs> ax;
+  ax.reserve(n);
   int64_t maxn = 0;
   for (size_t i = 0; i < n; ++i) {
-    ax[i] = {static_cast<float*>(dev_out) + offsets[i], gs[i].g->grad->w->dev, gs[i].num_arcs(), 1.0f};
+    float* dst = static_cast<float*>(dev_out) + offsets[i];
+    if (gs[i].g->grad->w->dev == dst) continue;  // written in place (grads_bind_device)
+    ax.push_back({dst, gs[i].g->grad->w->dev, gs[i].num_arcs(), 1.0f});
     maxn = std::max(maxn, gs[i].num_arcs());
   }
+  if (ax.empty()) return;
   DevMemP d = upload_vec(ax);
-  launch_axpy_batch(d->as<AxpyArgs>(), int(n), maxn, /*copy mode*/ 2, rt.stream());
+  launch_axpy_batch(d->as<AxpyArgs>(), int(ax.size()), maxn, /*copy mode*/ 2, rt.stream());
+}
+
+void grads_bind_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets) {
+  if (gs.empty()) return;
+  auto mem = std::make_shared<DevMem>();
+  mem->ptr = dev_out;
+  mem->borrowed = true;
+  for (size_t i = 0; i < gs.size(); ++i) {
+    gs[i].g->grad_dest_mem = mem;
+    gs[i].g->grad_dest = static_cast<float*>(dev_out) + offsets[i];
+  }
 }
 
 } // namespace gtnx

@@ -64,13 +64,14 @@ void realize(Graph& g);
 
 Graph make_scalar_graph(float v, bool calc_grad);
 Graph make_linear_graph(int M, int N, bool calc_grad);
-std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev);
+std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev, bool borrow = false);
 Graph make_user_op(std::vector<Graph>& inputs, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*));
 void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(void*));
 
 void items_host(std::vector<Graph>& gs, float* out);
 void items_device(std::vector<Graph>& gs, void* dev_out);
 void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets);
+void grads_bind_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets);
 
 template <class T>
 DevMemP upload_vec(const std::vector<T>& v) {

@@ -17,7 +17,7 @@ size_t round_size(size_t b) {
 } // namespace
 
 DevMem::~DevMem() {
-  if (ptr && g_rt) g_rt->release_dev(ptr, bytes);
+  if (ptr && g_rt && !borrowed) g_rt->release_dev(ptr, bytes);
 }
 PinnedMem::~PinnedMem() {
   if (ptr && g_rt) g_rt->release_pinned(ptr, bytes);

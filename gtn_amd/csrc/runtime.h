@@ -22,6 +22,7 @@ namespace gtnx {
 struct DevMem {
   void* ptr = nullptr;
   size_t bytes = 0;
+  bool borrowed = false;  // the caller's memory (a tensor that outlives the graphs over it): never pooled
   ~DevMem();
   template <class T>
   T* as(size_t byte_off = 0) const { return reinterpret_cast<T*>(static_cast<char*>(ptr) + byte_off); }

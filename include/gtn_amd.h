@@ -156,6 +156,12 @@ gtnx_status_t gtnx_linear_graph(int M, int N, int calc_grad, gtnx_graph_t* out);
  * [B][M][N] (the (B,T,C) emissions of pytorch_loss.py:46-71), one launch. */
 gtnx_status_t gtnx_linear_graph_n(int B, int M, int N, int calc_grad,
                                   const void* device_weights, gtnx_graph_t* out /* B handles */);
+/* The same without the copy: the graphs' weights ARE the caller's tensor (what a
+ * torch.autograd.Function holds on to between forward and backward anyway,
+ * pytorch_loss.py:46-71).  The caller keeps it alive and unchanged while any of the
+ * handles -- or a result computed from them -- is in use. */
+gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int calc_grad,
+                                         const void* device_weights, gtnx_graph_t* out /* B handles */);
 
 /* ------------------------------------------------------------------ functions
  * gtn/functions.h:19-152.  Single-graph forms, then batched forms. */
@@ -184,6 +190,11 @@ gtnx_status_t gtnx_items_device_n(const gtnx_graph_t* g, int n, void* device_out
  * byte offset offsets[i]*4 (replaces pytorch_loss.py:94-102's per-sample
  * weights_to_numpy + torch.from_numpy + .to(device)) */
 gtnx_status_t gtnx_grads_device_n(const gtnx_graph_t* g, int n, void* device_out, const int64_t* offsets);
+/* Called BEFORE backward: names the device buffer gtnx_grads_device_n will be asked to
+ * fill, so that kernels which produce graph i's first gradient may store it at
+ * device_out + offsets[i] directly (the later gtnx_grads_device_n then finds it in
+ * place and copies nothing).  A hint: results are the same without it. */
+gtnx_status_t gtnx_grads_bind_device_n(const gtnx_graph_t* g, int n, void* device_out, const int64_t* offsets);
 
 /* ------------------------------------------------------------------ autograd
  * gtn/autograd.h:27,37 */

@@ -183,7 +183,8 @@ def main():
             rc = native.gtn_bench_ctc_step(em_dev.data_ptr(), tg.ctypes.data, B, T, Cn, U, loss_dev.data_ptr(),
                                            grad_dev.data_ptr())
             if rc != 0:
-                raise RuntimeError("native step failed: " + gtn._lib.gtnx_last_error().decode())
+                native.gtn_bench_last_error.restype = C.c_char_p
+                raise RuntimeError("native step failed: " + native.gtn_bench_last_error().decode())
             if world > 1:
                 dist.all_gather(gathered, loss_dev)
         return None

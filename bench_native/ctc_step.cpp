@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "gtn/gtn.h"
@@ -17,6 +18,8 @@ using namespace gtn;
 // host milliseconds of the last step's phases on the calling thread: target graphs (parallelMap), emissions
 // graphs, intersect, the two forwardScores + subtract, backward -- what bounds a step once the GPU work is short
 static double g_last[5] = {0, 0, 0, 0, 0};
+static std::string g_error;
+extern "C" __attribute__((visibility("default"))) const char* gtn_bench_last_error() { return g_error.c_str(); }
 extern "C" __attribute__((visibility("default"))) void gtn_bench_last_host_ms(double* out5) {
   for (int i = 0; i < 5; ++i) out5[i] = g_last[i];
 }
@@ -34,12 +37,11 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
   decltype(tq) t_tail0 = tq, t_tail1 = tq;
   int rc = 0;
   try {
-    std::vector<std::vector<int>> tg(B);
-    for (int b = 0; b < B; ++b) tg[b].assign(targets + (size_t)b * U, targets + (size_t)(b + 1) * U);
+    std::vector<int> len(B, U);
     // fwd + bwd of benchmarks/ctc.cpp:150-165, batched (gtn_amd/criteria/ctc_criterion.h)
     criteria::CtcStepTimes tm;
     t_tail0 = now();
-    criteria::ctcLossBatch(emissions, tg, T, C, /*blank=*/0, loss_dev, grad_dev, /*targetGrad=*/true, &tm);
+    criteria::ctcLossBatch(emissions, targets, len.data(), B, T, C, /*blank=*/0, loss_dev, grad_dev, /*targetGrad=*/true, &tm);
     g_last[0] = tm.build;
     g_last[1] = tm.linear;
     g_last[2] = tm.intersect;
@@ -50,6 +52,7 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
                    tm.intersect, tm.forward, tm.backward);
     t_tail1 = now();
   } catch (const std::exception& e) {
+    g_error = e.what();
     rc = -1;
   }
   auto t_end = now();

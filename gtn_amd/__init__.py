@@ -14,6 +14,7 @@ _lib = _capi.load()
 _api = make_api(_lib)
 
 Graph = _api.Graph
+Batch = _api.Batch
 epsilon = _api.epsilon
 negate = _api.negate
 add = _api.add

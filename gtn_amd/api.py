@@ -630,6 +630,115 @@ def make_api(lib):
     ns.items_to_device = items_to_device
     ns.grads_to_device = grads_to_device
 
+    # ---------------------------------------------------------------- batch records (gtnx_batch_*)
+    class Batch:
+        """B graphs held as one record: what the list forms of the functions return when
+        nobody looks at the elements (one object and one tape node per call).  `b[i]` is
+        element i as an ordinary Graph.  The module-level functions (intersect, forward_score,
+        subtract, backward, ...) accept Batch arguments."""
+
+        __slots__ = ("_h", "__weakref__")
+
+        def __init__(self, graphs=None):
+            self._h = None
+            if graphs is not None:
+                graphs = list(graphs)
+                h = C.c_void_p()
+                check(lib.gtnx_batch_from_graphs(_harr(graphs), len(graphs), C.byref(h)))
+                self._h = h.value
+
+        @classmethod
+        def _from_handle(cls, h):
+            b = cls.__new__(cls)
+            b._h = h
+            return b
+
+        @classmethod
+        def ctc_targets(cls, targets, blank=0, calc_grad=True):
+            """CTC target acceptors (benchmarks/ctc.cpp:40-58) of label sequences, built on the device"""
+            lens = np.asarray([len(t) for t in targets], dtype=np.int32)
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in targets])
+                                        if len(targets) else np.zeros(0, np.int32), dtype=np.int32)
+            h = C.c_void_p()
+            check(lib.gtnx_batch_ctc_targets(flat.ctypes.data, lens.ctypes.data, len(lens), int(blank),
+                                             int(bool(calc_grad)), C.byref(h)))
+            return cls._from_handle(h.value)
+
+        @classmethod
+        def linear(cls, B, M, N, device_weights, calc_grad=True, borrow=False):
+            """B linear graphs over one device tensor [B, M, N]; borrow: read in place"""
+            h = C.c_void_p()
+            check(lib.gtnx_batch_linear(int(B), int(M), int(N), int(bool(calc_grad)), _as_dev_ptr(device_weights),
+                                        int(bool(borrow)), C.byref(h)))
+            return cls._from_handle(h.value)
+
+        def __del__(self):
+            h, self._h = getattr(self, "_h", None), None
+            if h:
+                try:
+                    lib.gtnx_batch_destroy(h)
+                except Exception:
+                    pass
+
+        def __len__(self):
+            v = C.c_int()
+            check(lib.gtnx_batch_size(self._h, C.byref(v)))
+            return v.value
+
+        def __getitem__(self, i):
+            h = C.c_void_p()
+            check(lib.gtnx_batch_get(self._h, int(i), C.byref(h)))
+            return Graph._from_handle(h.value)
+
+        def items(self):
+            out = np.empty(len(self), dtype=np.float32)
+            if len(out):
+                check(lib.gtnx_batch_items(self._h, out.ctypes.data))
+            return out
+
+        def items_to_device(self, device_out):
+            check(lib.gtnx_batch_items_device(self._h, _as_dev_ptr(device_out)))
+
+        def bind_grads(self, device_out, offsets):
+            off = np.ascontiguousarray(offsets, dtype=np.int64)
+            check(lib.gtnx_batch_grads_bind_device(self._h, _as_dev_ptr(device_out), off.ctypes.data))
+
+        def grads_to_device(self, device_out, offsets):
+            off = np.ascontiguousarray(offsets, dtype=np.int64)
+            check(lib.gtnx_batch_grads_device(self._h, _as_dev_ptr(device_out), off.ctypes.data))
+
+    ns.Batch = Batch
+
+    def _batch_fn(cfn, *args):
+        h = C.c_void_p()
+        check(cfn(*[a._h for a in args], C.byref(h)))
+        return Batch._from_handle(h.value)
+
+    def _with_batches(plain, cfn):
+        def f(*args, **kw):
+            if args and all(isinstance(a, Batch) for a in args) and not kw:
+                return _batch_fn(cfn, *args)
+            return plain(*args, **kw)
+        f.__doc__ = plain.__doc__
+        f.__name__ = getattr(plain, "__name__", "f")
+        return f
+
+    if hasattr(lib, "gtnx_batch_negate"):  # (not in the reference-backed shim the CPU tests load)
+        for _name in ("negate", "add", "subtract", "compose", "intersect", "forward_score", "viterbi_score",
+                      "viterbi_path"):
+            setattr(ns, _name, _with_batches(getattr(ns, _name), getattr(lib, "gtnx_batch_" + _name)))
+
+    _plain_backward = ns.backward
+
+    def backward(g, grad_or_retain=None, retain_graph=False):
+        if isinstance(g, Batch):
+            r = grad_or_retain if isinstance(grad_or_retain, bool) else retain_graph
+            check(lib.gtnx_batch_backward(g._h, int(bool(r))))
+            return
+        return _plain_backward(g, grad_or_retain, retain_graph)
+
+    ns.backward = backward
+
     def parallel_for(fn, iterable):
         """gtn.parallel_for (_parallel.cpp:20-26).  The device engine batches
         through list arguments instead; this runs the callable serially."""

@@ -23,13 +23,7 @@ extern "C" __attribute__((visibility("default"))) int gtn_ctc_loss_n(const void*
                                                                      const int* lengths, int B, int T, int C,
                                                                      int blank, void* loss, void* grad) {
   try {
-    std::vector<std::vector<int>> tg(B);
-    size_t o = 0;
-    for (int b = 0; b < B; ++b) {
-      tg[b].assign(targets + o, targets + o + lengths[b]);
-      o += size_t(lengths[b]);
-    }
-    gtn::criteria::ctcLossBatch(emissions, tg, T, C, blank, loss, grad, /*targetGrad=*/false);
+    gtn::criteria::ctcLossBatch(emissions, targets, lengths, B, T, C, blank, loss, grad, /*targetGrad=*/false);
     return 0;
   } catch (const std::exception& e) {
     g_err = e.what();

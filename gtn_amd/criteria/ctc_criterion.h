@@ -46,8 +46,48 @@ struct CtcStepTimes {
 };
 
 /** forward + backward of  loss_b = forwardScore(emissions_b) - forwardScore(target_b ∩ emissions_b)
- *  for a batch.  `emissions`: device [B][T][C]; `lossDev`: device [B]; `gradDev`: device
- *  [B][T][C] (d loss / d emissions) or null.  Targets may have different lengths. */
+ *  for a batch -- benchmarks/ctc.cpp:150-165 with one Batch per call instead of parallelMap over
+ *  per-utterance graphs.  `emissions`: device [B][T][C], read in place; `lossDev`: device [B];
+ *  `gradDev`: device [B][T][C] (d loss / d emissions, written in place) or null.  Targets may have
+ *  different lengths. */
+inline void ctcLossBatch(
+    const void* emissions,
+    const int* labels,   // target sequences back to back
+    const int* lengths,  // [B]
+    int B,
+    int T,
+    int C,
+    int blank,
+    void* lossDev,
+    void* gradDev,
+    bool targetGrad = true,  // benchmarks/ctc.cpp builds its targets with calcGrad = true
+    CtcStepTimes* times = nullptr) {
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  auto t0 = now();
+  Batch ctcs = Batch::ctcTargets(labels, lengths, B, blank, targetGrad);
+  auto t1 = now();
+  Batch ems = Batch::linear(B, T, C, emissions, gradDev != nullptr, /*borrow=*/true);
+  std::vector<int64_t> off(B);
+  for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
+  if (gradDev) ems.bindGrads(gradDev, off.data());
+  auto t2 = now();
+  // only forwardScore of the lattices is taken: they are never built (band.hip sweeps them)
+  Batch comp = intersect(ctcs, ems);
+  auto t3 = now();
+  // (C++ leaves the evaluation order of benchmarks/ctc.cpp:157's call arguments open; this order lets the
+  //  sweep over target o emissions, which reads every emission anyway, leave forwardScore(emissions) behind)
+  Batch score = forwardScore(comp);
+  Batch norm = forwardScore(ems);
+  Batch losses = subtract(norm, score);
+  auto t4 = now();
+  if (gradDev) backward(losses);
+  auto t5 = now();
+  if (times) *times = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5)};
+  losses.itemsToDevice(lossDev);
+  if (gradDev) ems.gradsToDevice(gradDev, off.data());  // (nothing to copy when the rows were written in place)
+}
+
 inline void ctcLossBatch(
     const void* emissions,
     const std::vector<std::vector<int>>& targets,
@@ -56,44 +96,14 @@ inline void ctcLossBatch(
     int blank,
     void* lossDev,
     void* gradDev,
-    bool targetGrad = true,  // benchmarks/ctc.cpp builds its targets with calcGrad = true
+    bool targetGrad = true,
     CtcStepTimes* times = nullptr) {
-  const int B = (int)targets.size();
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  auto t0 = now();
-  auto ctcs =
-      parallelMap([blank, targetGrad](const std::vector<int>& t) { return ctcTargetGraph(t, blank, targetGrad); }, targets);
-  auto t1 = now();
-  // the emissions are read in place (the caller's tensor outlives the step) and their gradient is
-  // written straight into the caller's tensor: no copy of either [B][T][C] block
-  auto ems = linearGraphs(B, T, C, emissions, gradDev != nullptr, /*borrow=*/true);
-  std::vector<int64_t> off(B);
-  for (int b = 0; b < B; ++b) off[b] = (int64_t)b * T * C;
-  if (gradDev) {
-    auto he = detail::handles(ems);
-    detail::check(gtnx_grads_bind_device_n(he.data(), B, gradDev, off.data()));
+  std::vector<int> flat, len;
+  for (auto& t : targets) {
+    flat.insert(flat.end(), t.begin(), t.end());
+    len.push_back((int)t.size());
   }
-  auto t2 = now();
-  // only forwardScore of the lattices is taken: they need not be built (lazy_pair.hip sweeps them)
-  SymbolicCompose symbolic;
-  auto comp = batched::intersect(ctcs, ems);
-  auto t3 = now();
-  // (C++ leaves the evaluation order of benchmarks/ctc.cpp:157's call arguments open; this order lets the
-  //  sweep over target o emissions, which reads every emission anyway, leave forwardScore(emissions) behind)
-  auto score = batched::forwardScore(comp);
-  auto norm = batched::forwardScore(ems);
-  auto losses = batched::subtract(norm, score);
-  auto t4 = now();
-  if (gradDev) batched::backward(losses);
-  auto t5 = now();
-  if (times) *times = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5)};
-  auto h = detail::handles(losses);
-  detail::check(gtnx_items_device_n(h.data(), B, lossDev));
-  if (gradDev) {
-    auto he = detail::handles(ems);
-    detail::check(gtnx_grads_device_n(he.data(), B, gradDev, off.data()));  // (no-op for rows already in place)
-  }
+  ctcLossBatch(emissions, flat.data(), len.data(), (int)targets.size(), T, C, blank, lossDev, gradDev, targetGrad, times);
 }
 
 } // namespace criteria

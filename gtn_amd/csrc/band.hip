@@ -1051,6 +1051,47 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
   }
 }
 
+
+// ==========================================================================================
+// CTC target acceptors built where they are used: the graph of benchmarks/ctc.cpp:40-58 /
+// examples/ctc.cpp:21-41 (2U+1 nodes, blank at even nodes, self-loop + arc from the previous
+// node everywhere, a skip arc between different labels; arc ids in the reference's addArc
+// order) as the band records the sweeps read -- one workgroup per label sequence, nothing but
+// the labels crosses PCIe.  Lists sorted by (label, node) as band_info() makes them on the host.
+// ==========================================================================================
+__global__ __launch_bounds__(512) void ctc_targets_kernel(const CtcTargetArgs* __restrict__ args, int blank) {
+  const CtcTargetArgs a = args[blockIdx.x];
+  __shared__ int lab[512];
+  __shared__ int cnt[512];
+  const int N = a.N, m = threadIdx.x;
+  int my = blank, skip = 0;
+  if (m < N) {
+    if (m & 1) {
+      my = a.labels[(m - 1) >> 1];
+      skip = (m > 1 && my != a.labels[((m - 1) >> 1) - 1]) ? 1 : 0;
+    }
+    lab[m] = my;
+    cnt[m] = 1 + (m > 0 ? 1 : 0) + skip;
+  }
+  __syncthreads();
+  if (m >= N) return;
+  int rank = 0, base = 0;
+  for (int o = 0; o < N; ++o) {
+    const int lo = lab[o];
+    rank += (lo < my || (lo == my && o < m)) ? 1 : 0;
+    base += o < m ? cnt[o] : 0;
+  }
+  GTNX_G BandNode* nd = const_cast<GTNX_G BandNode*>(a.nodes);
+  nd[m].lab = my;
+  nd[m].aid[0] = base;
+  nd[m].aid[1] = m > 0 ? base + 1 : -1;
+  nd[m].aid[2] = skip ? base + 2 : -1;
+  a.nflags[m] = uint8_t((m == 0 ? NF_START : 0) | (m + 2 >= N ? NF_ACCEPT : 0));
+  a.snode[rank] = m;
+  a.slab[rank] = my;
+  if (m == N - 1 && a.n_arcs) a.n_arcs[0] = base + cnt[m];
+}
+
 template <class K>
 void big_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
@@ -1147,6 +1188,10 @@ void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int ma
     if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
     else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
   }
+}
+
+void launch_ctc_targets(const CtcTargetArgs* d_args, int n, int blank, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(ctc_targets_kernel, dim3(n), dim3(512), 0, st, d_args, blank);
 }
 
 } // namespace gtnx

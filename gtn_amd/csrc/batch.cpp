@@ -1,0 +1,679 @@
+// batch.cpp -- see batch.h.  Reference semantics per element: functions.cpp:18-64 (scalar ops),
+// :225-251 (compose / intersect), :320-326 (forwardScore) over creations.cpp:20-33 chains and the
+// target acceptor of benchmarks/ctc.cpp:40-58; autograd.cpp:17-67 for backward.
+#include "batch.h"
+
+#include <algorithm>
+#include <atomic>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace gtnx {
+
+namespace {
+
+std::atomic<uint64_t> g_batch_seq{1};
+
+struct CompMode {  // compositions made while materialising stay symbolic until somebody looks inside
+  int old;
+  CompMode() : old(compose_mode_hint(2)) {}
+  ~CompMode() { compose_mode_hint(old); }
+};
+
+BatchP make_batch(Batch::Kind k, int n, bool cg) {
+  auto b = std::make_shared<Batch>();
+  b->kind = k;
+  b->n = n;
+  b->calc_grad = cg;
+  return b;
+}
+
+BatchP result(Batch::Kind k, int n, std::shared_ptr<BatchOp> op) {
+  bool cg = false;
+  for (auto& i : op->inputs) cg |= i->calc_grad;
+  BatchP r = make_batch(k, n, cg);
+  op->seq = g_batch_seq.fetch_add(1);
+  r->op = std::move(op);  // kept without calc_grad too: it says how to rebuild the elements as graphs
+  return r;
+}
+
+bool native(const Batch& b, Batch::Kind k) { return b.kind == k; }
+
+// ---- the gradient array of a batch: bound destination, else a fresh block
+void alloc_grad(Batch& b, bool zero) {
+  Runtime& rt = Runtime::get();
+  b.g_off.resize(size_t(b.n) + 1);
+  b.g_off[0] = 0;
+  for (int i = 0; i < b.n; ++i) b.g_off[size_t(i) + 1] = b.g_off[size_t(i)] + b.elem_size(i);
+  const size_t bytes = sizeof(float) * size_t(b.g_off[size_t(b.n)]);
+  if (b.dest) {
+    b.g_mem = b.dest_mem;
+    b.g_dev = b.dest;
+    b.dest = nullptr;
+    if (zero && bytes) HIP_CHECK(hipMemsetAsync(b.g_dev, 0, bytes, rt.stream()));
+  } else {
+    b.g_mem = zero ? rt.alloc_zero(bytes ? bytes : 4) : rt.alloc(bytes ? bytes : 4);
+    b.g_dev = b.g_mem->as<float>();
+  }
+}
+
+// a block the kernels may overwrite: the batch's own gradient when it has none yet, else a scratch
+// block that add_scratch() folds in afterwards (addGrad semantics, graph.cpp:108-129)
+struct GradTarget {
+  float* ptr = nullptr;
+  DevMemP scratch;
+};
+GradTarget grad_target(Batch& b, bool zero) {
+  GradTarget t;
+  if (!b.g_dev) {
+    alloc_grad(b, zero);
+    t.ptr = b.g_dev;
+    return t;
+  }
+  Runtime& rt = Runtime::get();
+  const size_t bytes = sizeof(float) * size_t(b.g_off[size_t(b.n)]);
+  t.scratch = zero ? rt.alloc_zero(bytes ? bytes : 4) : rt.alloc(bytes ? bytes : 4);
+  t.ptr = t.scratch->as<float>();
+  return t;
+}
+void add_scratch(Batch& b, const GradTarget& t) {
+  if (!t.scratch) return;
+  launch_vec_axpby(b.g_dev, t.ptr, nullptr, size_t(b.g_off[size_t(b.n)]), 1.0f, 0.0f, 1, Runtime::get().stream());
+}
+
+// ---- ops -------------------------------------------------------------------------------------
+struct BScalarOp : BatchOp {
+  ScalarKind kind;
+  void backward(Batch& out) override {
+    Runtime& rt = Runtime::get();
+    for (size_t i = 0; i < inputs.size(); ++i) {
+      Batch& in = *inputs[i];
+      if (!in.calc_grad) continue;  // subtract only feeds input 1 when it wants a gradient (functions.cpp:55-57)
+      const float s = (kind == SK_NEGATE || (kind == SK_SUBTRACT && i == 1)) ? -1.0f : 1.0f;
+      const bool have = in.g_dev != nullptr;
+      if (!have) alloc_grad(in, false);
+      launch_vec_axpby(in.g_dev, out.g_dev, nullptr, size_t(in.n), s, 0.0f, have ? 1 : 0, rt.stream());
+    }
+  }
+};
+
+// launches registered by one backward() over the same chains, gathered so that the normaliser's
+// softmax term and the sweep's posteriors leave in one kernel (ops.cpp: ChainGradPlan, per batch)
+struct BackwardPlan {
+  std::unordered_map<Batch*, Batch*> lin;  // chain batch -> output of forwardScore(chain) waiting for a sweep
+  std::unordered_set<Batch*> fused;
+};
+thread_local BackwardPlan* t_plan = nullptr;
+
+struct BFsLinearOp : BatchOp {
+  void backward(Batch& out) override {
+    Batch& e = *inputs[0];
+    if (!e.calc_grad) return;
+    if (t_plan && e.nc_rowlse && !t_plan->lin.count(&e)) {
+      t_plan->lin[&e] = &out;  // rides with the sweep over the same chains, if one comes
+      return;
+    }
+    run(out);
+  }
+  void run(Batch& out) {
+    Batch& e = *inputs[0];
+    Runtime& rt = Runtime::get();
+    const bool have = e.g_dev != nullptr;
+    if (!have) alloc_grad(e, false);
+    std::vector<LinArgs> args;
+    args.resize(size_t(e.n));
+    const size_t A = size_t(e.M) * size_t(e.C);
+    for (int b = 0; b < e.n; ++b) {
+      LinArgs& a = args[size_t(b)];
+      a.w = e.w_dev + size_t(b) * A;
+      a.M = e.M;
+      a.C = e.C;
+      a.out_score = nullptr;
+      a.partial = nullptr;
+      a.delta = out.g_dev + b;
+      a.grad = e.g_dev + size_t(b) * A;
+      a.accumulate = have ? 1 : 0;
+    }
+    DevMemP d = upload_vec(args);
+    const bool vec_rows = e.C % 4 == 0 && e.C <= 1024 && (reinterpret_cast<uintptr_t>(e.w_dev) & 15) == 0 &&
+                          (reinterpret_cast<uintptr_t>(e.g_dev) & 15) == 0;
+    GTNX_PROF("linear_forward_grad", (have ? 12.0 : 8.0) * double(A) * e.n);
+    launch_linear_backward(d->as<LinArgs>(), e.n, 0, vec_rows ? 1 : 0, rt.stream());
+  }
+};
+
+struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
+  std::vector<BandPair> pairs;
+  DevMemP arena;
+  void backward(Batch& out) override {
+    Batch& prod = *inputs[0];
+    Batch& fx = *prod.fixed;
+    Batch& ch = *prod.chain;
+    Runtime& rt = Runtime::get();
+    GradTarget ge, gf;
+    if (ch.calc_grad) ge = grad_target(ch, false);  // every row is written by the kernel
+    if (fx.calc_grad) gf = grad_target(fx, true);   // arcs that never match stay 0
+    Batch* lin_out = nullptr;
+    if (t_plan && ch.calc_grad && !ge.scratch) {
+      auto it = t_plan->lin.find(&ch);
+      if (it != t_plan->lin.end() && !t_plan->fused.count(&ch)) {
+        lin_out = it->second;
+        t_plan->fused.insert(&ch);
+      }
+    }
+    std::vector<std::pair<BandLaunchKey, BandPair>> tab;
+    tab.reserve(pairs.size());
+    double bytes = 0;
+    const size_t A = size_t(ch.M) * size_t(ch.C);
+    for (int b = 0; b < prod.n; ++b) {
+      BandPair p = pairs[size_t(b)];
+      p.delta = out.g_dev + b;
+      p.delta_norm = lin_out ? lin_out->g_dev + b : nullptr;
+      p.rowlse = lin_out ? ch.nc_rowlse + size_t(b) * size_t(ch.M) : nullptr;
+      p.norm = nullptr;
+      p.grad_em = ge.ptr ? ge.ptr + size_t(b) * A : nullptr;
+      p.grad_fixed = gf.ptr ? gf.ptr + fx.g_off[size_t(b)] : nullptr;
+      tab.push_back({BandLaunchKey{p.C, band_npl(p.N), 1, p.grad_fixed ? 1 : 0, band_vec_ok(p)}, p});
+      bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
+               (p.grad_fixed ? 4.0 * double(fx.elem_size(b)) : 0.0);
+    }
+    {
+      GTNX_PROF("band_forward_score_grad", bytes);
+      band_launch(tab, true);
+    }
+    if (ch.calc_grad) add_scratch(ch, ge);
+    if (fx.calc_grad) add_scratch(fx, gf);
+    (void)rt;
+  }
+};
+
+}  // namespace
+
+int64_t Batch::elem_size(int b) const {
+  switch (kind) {
+    case SCALAR: return 1;
+    case LINEAR: return int64_t(M) * C;
+    case CTC_TARGETS: return 3 * int64_t(2 * (lab_off[size_t(b) + 1] - lab_off[size_t(b)]) + 1);
+    default: return 0;
+  }
+}
+
+// ---- creation --------------------------------------------------------------------------------
+BatchP batch_from_graphs(std::vector<Graph> gs) {
+  bool cg = false;
+  for (auto& g : gs) cg |= g.calc_grad();
+  BatchP b = make_batch(Batch::GRAPHS, int(gs.size()), cg);
+  b->graphs = std::move(gs);
+  b->materialised = true;
+  return b;
+}
+
+namespace {
+Graph ctc_target_graph_host(const int* t, int U, int blank, bool cg) {
+  // benchmarks/ctc.cpp:40-58, same node and arc order
+  const int L = 2 * U + 1;
+  std::vector<uint8_t> st(size_t(L), 0), ac(size_t(L), 0);
+  std::vector<int> src, dst, lab;
+  src.reserve(size_t(3 * L));
+  dst.reserve(size_t(3 * L));
+  lab.reserve(size_t(3 * L));
+  for (int l = 0; l < L; ++l) {
+    const int idx = (l - 1) / 2;
+    st[size_t(l)] = l == 0;
+    ac[size_t(l)] = l == L - 1 || l + 2 == L;
+    const int label = l % 2 ? t[idx] : blank;
+    src.push_back(l), dst.push_back(l), lab.push_back(label);
+    if (l > 0) src.push_back(l - 1), dst.push_back(l), lab.push_back(label);
+    if (l % 2 && l > 1 && label != t[idx - 1]) src.push_back(l - 2), dst.push_back(l), lab.push_back(label);
+  }
+  Graph g(cg);
+  g.add_nodes(L, st.data(), ac.data());
+  g.add_arcs(int(src.size()), src.data(), dst.data(), lab.data(), lab.data(), nullptr);
+  g.arc_sort(false);
+  return g;
+}
+}  // namespace
+
+BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, bool calc_grad) {
+  if (n < 0) throw_invalid("[gtnx_batch_ctc_targets] negative batch size");
+  BatchP b = make_batch(Batch::CTC_TARGETS, n, calc_grad);
+  b->blank = blank;
+  b->lab_off.resize(size_t(n) + 1);
+  b->lab_off[0] = 0;
+  for (int i = 0; i < n; ++i) {
+    if (lengths[i] < 0) throw_invalid("[gtnx_batch_ctc_targets] negative length");
+    b->lab_off[size_t(i) + 1] = b->lab_off[size_t(i)] + lengths[i];
+    b->max_nodes = std::max(b->max_nodes, 2 * lengths[i] + 1);
+  }
+  const size_t total = size_t(b->lab_off[size_t(n)]);
+  b->labels.assign(labels, labels + total);
+  int mn = blank;
+  b->max_label = blank;
+  for (size_t i = 0; i < total; ++i) {
+    b->max_label = std::max(b->max_label, labels[i]);
+    mn = std::min(mn, labels[i]);
+  }
+  if (mn < 0 || b->max_nodes > band_max_nodes() || n == 0) {
+    // epsilon / negative labels or targets wider than a workgroup: ordinary graphs
+    std::vector<Graph> gs;
+    gs.reserve(size_t(n));
+    for (int i = 0; i < n; ++i)
+      gs.push_back(ctc_target_graph_host(labels + b->lab_off[size_t(i)], lengths[i], blank, calc_grad));
+    return batch_from_graphs(std::move(gs));
+  }
+  // records on the device: labels | per element {nodes, flags, snode, slab, n_arcs}
+  Runtime& rt = Runtime::get();
+  size_t bytes = align_up(sizeof(int) * (total ? total : 1), 256);
+  b->rec_off.resize(size_t(n));
+  for (int i = 0; i < n; ++i) {
+    const size_t N = size_t(2 * lengths[i] + 1);
+    b->rec_off[size_t(i)] = bytes;
+    bytes += align_up(sizeof(BandNode) * N, 64) + align_up(N, 64) + 2 * align_up(4 * N, 64) + 64;
+  }
+  b->rec_mem = rt.alloc(bytes);
+  {
+    PinnedMemP pin = rt.alloc_pinned(sizeof(int) * (total ? total : 1));
+    std::memcpy(pin->ptr, labels, sizeof(int) * total);
+    rt.h2d(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
+  }
+  std::vector<CtcTargetArgs> args;
+  args.resize(size_t(n));
+  for (int i = 0; i < n; ++i) {
+    const size_t N = size_t(2 * lengths[i] + 1);
+    char* base = b->rec_mem->as<char>(b->rec_off[size_t(i)]);
+    CtcTargetArgs& a = args[size_t(i)];
+    a.labels = b->rec_mem->as<int>() + b->lab_off[size_t(i)];
+    a.nodes = reinterpret_cast<BandNode*>(base);
+    base += align_up(sizeof(BandNode) * N, 64);
+    a.nflags = reinterpret_cast<uint8_t*>(base);
+    base += align_up(N, 64);
+    a.snode = reinterpret_cast<int*>(base);
+    base += align_up(4 * N, 64);
+    a.slab = reinterpret_cast<int*>(base);
+    base += align_up(4 * N, 64);
+    a.n_arcs = reinterpret_cast<int*>(base);
+    a.N = int(N);
+    a.pad = 0;
+  }
+  DevMemP d = upload_vec(args);
+  launch_ctc_targets(d->as<CtcTargetArgs>(), n, blank, rt.stream());
+  return b;
+}
+
+BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool borrow) {
+  if (n < 0 || M < 0 || C < 0) throw_invalid("[gtnx_batch_linear] negative size");
+  Runtime& rt = Runtime::get();
+  BatchP b = make_batch(Batch::LINEAR, n, calc_grad);
+  b->M = M;
+  b->C = C;
+  const size_t bytes = sizeof(float) * size_t(n) * size_t(M) * size_t(C);
+  if (borrow && dev) {
+    b->w_mem = std::make_shared<DevMem>();
+    b->w_mem->ptr = const_cast<void*>(dev);
+    b->w_mem->bytes = bytes;
+    b->w_mem->borrowed = true;
+  } else {
+    b->w_mem = dev ? rt.alloc(bytes ? bytes : 4) : rt.alloc_zero(bytes ? bytes : 4);
+    if (dev && bytes) rt.d2d(b->w_mem->ptr, dev, bytes);
+  }
+  b->w_dev = b->w_mem->as<float>();
+  return b;
+}
+
+// ---- elements as graphs ------------------------------------------------------------------------
+void batch_materialise(Batch& x) {
+  if (x.materialised) return;
+  std::vector<Graph> gs;
+  switch (x.kind) {
+    case Batch::GRAPHS: break;
+    case Batch::CTC_TARGETS:
+      gs.reserve(size_t(x.n));
+      for (int i = 0; i < x.n; ++i)
+        gs.push_back(ctc_target_graph_host(x.labels.data() + x.lab_off[size_t(i)],
+                                           x.lab_off[size_t(i) + 1] - x.lab_off[size_t(i)], x.blank, x.calc_grad));
+      break;
+    case Batch::LINEAR: {
+      gs.reserve(size_t(x.n));
+      const int64_t A = int64_t(x.M) * x.C;
+      for (int i = 0; i < x.n; ++i) {
+        Graph g(x.calc_grad);
+        Structure& s = *g.s;
+        s.kind = KIND_LINEAR;
+        s.M = x.M;
+        s.C = x.C;
+        s.N = int64_t(x.M) + 1;
+        s.A = A;
+        s.ilabel_sorted = s.olabel_sorted = true;
+        Weights& w = *g.w;
+        w.n = A;
+        w.dev_mem = x.w_mem;
+        w.dev = x.w_dev + size_t(i) * size_t(A);
+        w.dev_valid = true;
+        w.host_valid = false;
+        w.version++;
+        gs.push_back(std::move(g));
+      }
+      break;
+    }
+    case Batch::PRODUCT: {
+      batch_materialise(*x.fixed);
+      batch_materialise(*x.chain);
+      CompMode symbolic;
+      gs = x.chain_first ? op_compose(x.chain->graphs, x.fixed->graphs, x.intersect)
+                         : op_compose(x.fixed->graphs, x.chain->graphs, x.intersect);
+      break;
+    }
+    case Batch::SCALAR: {
+      if (!x.op) {  // the tape is gone (backward without retain): plain values
+        gs.reserve(size_t(x.n));
+        for (int i = 0; i < x.n; ++i) {
+          Graph g(false);
+          Structure& s = *g.s;
+          s.kind = KIND_LINEAR;
+          s.M = s.C = 1;
+          s.N = 2;
+          s.A = 1;
+          Weights& w = *g.w;
+          w.n = 1;
+          w.dev_mem = x.v_mem;
+          w.dev = x.v_dev + i;
+          w.dev_valid = true;
+          w.host_valid = false;
+          w.version++;
+          gs.push_back(std::move(g));
+        }
+        break;
+      }
+      for (auto& in : x.op->inputs) batch_materialise(*in);
+      if (auto* so = dynamic_cast<BScalarOp*>(x.op.get())) {
+        std::vector<Graph> none;
+        gs = op_scalar(so->kind, so->inputs[0]->graphs, so->inputs.size() > 1 ? so->inputs[1]->graphs : none);
+      } else {
+        gs = op_shortest_distance(x.op->inputs[0]->graphs, false);
+      }
+      break;
+    }
+  }
+  if (x.kind != Batch::GRAPHS) x.graphs = std::move(gs);
+  x.materialised = true;
+  // what the batch-level backward already produced moves into the element graphs
+  if (x.g_dev && (x.kind == Batch::CTC_TARGETS || x.kind == Batch::LINEAR)) {
+    for (int i = 0; i < x.n; ++i) x.graphs[size_t(i)].add_grad_device(x.g_mem, x.g_dev + x.g_off[size_t(i)], true);
+    x.g_dev = nullptr;  // (the graphs hold the block now)
+    x.g_mem.reset();
+  }
+}
+
+Graph batch_get(const BatchP& x, int i) {
+  if (i < 0 || i >= x->n) throw_range("[gtnx_batch_get] element index out of range");
+  batch_materialise(*x);
+  return x->graphs[size_t(i)];
+}
+
+// ---- functions -------------------------------------------------------------------------------
+BatchP batch_compose(const BatchP& a, const BatchP& b, bool intersect) {
+  const Batch *fx = nullptr, *ch = nullptr;
+  bool chain_first = false;
+  if (native(*a, Batch::CTC_TARGETS) && native(*b, Batch::LINEAR)) fx = a.get(), ch = b.get();
+  if (native(*a, Batch::LINEAR) && native(*b, Batch::CTC_TARGETS)) fx = b.get(), ch = a.get(), chain_first = true;
+  if (fx && a->n == b->n && ch->C >= 1 && ch->C <= band_max_labels() && fx->max_label < ch->C && ch->M <= (1 << 20)) {
+    struct Op : BatchOp {
+      void backward(Batch&) override {}  // a symbolic product has no gradient of its own
+    };
+    auto op = std::make_shared<Op>();
+    op->inputs = {a, b};
+    BatchP r = result(Batch::PRODUCT, a->n, op);
+    r->fixed = chain_first ? b : a;
+    r->chain = chain_first ? a : b;
+    r->chain_first = chain_first;
+    r->intersect = intersect;
+    return r;
+  }
+  batch_materialise(*a);
+  batch_materialise(*b);
+  return batch_from_graphs(op_compose(a->graphs, b->graphs, intersect));
+}
+
+BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
+  Runtime& rt = Runtime::get();
+  if (!tropical && native(*x, Batch::PRODUCT) && !x->materialised) {
+    Batch& fx = *x->fixed;
+    Batch& ch = *x->chain;
+    const int n = x->n, T = ch.M, C = ch.C;
+    auto op = std::make_shared<BFsBandOp>();
+    op->inputs = {x};
+    const bool want_norm = ch.nc_norm == nullptr;
+    // scores [n] | norm [n] | rowlse [n][T] | per element: shifts, alpha plane
+    size_t bytes = align_up(4 * size_t(n), 256);
+    const size_t o_norm = bytes;
+    bytes = align_up(bytes + 4 * size_t(n), 256);
+    const size_t o_lse = bytes;
+    bytes = align_up(bytes + 4 * size_t(n) * size_t(T > 0 ? T : 1), 256);
+    std::vector<size_t> oo, ao;
+    oo.resize(size_t(n));
+    ao.resize(size_t(n));
+    for (int b = 0; b < n; ++b) {
+      const int N = 2 * (fx.lab_off[size_t(b) + 1] - fx.lab_off[size_t(b)]) + 1;
+      const int ns = band_row_stride(N, band_npl(N));
+      oo[size_t(b)] = bytes;
+      bytes = align_up(bytes + 8 * (4 * size_t(T) + 16), 256);
+      ao[size_t(b)] = bytes;
+      bytes = align_up(bytes + 4 * size_t(T + 1) * size_t(ns), 256);
+    }
+    op->arena = rt.alloc(bytes);
+    op->pairs.resize(size_t(n));
+    std::vector<std::pair<BandLaunchKey, BandPair>> tab;
+    tab.reserve(size_t(n));
+    double abytes = 0;
+    for (int b = 0; b < n; ++b) {
+      BandPair& p = op->pairs[size_t(b)];
+      p = BandPair{};
+      const int U = fx.lab_off[size_t(b) + 1] - fx.lab_off[size_t(b)];
+      const size_t N = size_t(2 * U + 1);
+      char* base = fx.rec_mem->as<char>(fx.rec_off[size_t(b)]);
+      p.nodes = reinterpret_cast<BandNode*>(base);
+      base += align_up(sizeof(BandNode) * N, 64);
+      p.nflags = reinterpret_cast<uint8_t*>(base);
+      base += align_up(N, 64);
+      p.snode = reinterpret_cast<int*>(base);
+      base += align_up(4 * N, 64);
+      p.slab = reinterpret_cast<int*>(base);
+      p.n_lab = int(N);
+      p.w = nullptr;  // all-zero weights
+      p.em = ch.w_dev + size_t(b) * size_t(T) * size_t(C);
+      p.N = int(N);
+      p.T = T;
+      p.C = C;
+      p.NS = band_row_stride(p.N, band_npl(p.N));
+      p.alpha = op->arena->as<float>(ao[size_t(b)]);
+      p.aoff = op->arena->as<double>(oo[size_t(b)]);
+      p.score = op->arena->as<float>(4 * size_t(b));
+      if (want_norm) {
+        p.norm = op->arena->as<float>(o_norm + 4 * size_t(b));
+        p.rowlse = op->arena->as<float>(o_lse + 4 * size_t(b) * size_t(T));
+      }
+      p.hot = U + 1 >= 8 ? fx.blank : -1;
+      p.lgrn = band_forward_lgrn(C);
+      tab.push_back({BandLaunchKey{C, band_npl(p.N), 1, 0, band_vec_ok(p)}, p});
+      abytes += 4.0 * T * C + 4.0 * double(T + 1) * p.NS;
+    }
+    {
+      GTNX_PROF("band_forward_score", abytes);
+      band_launch(tab, false);
+    }
+    if (want_norm) {
+      ch.nc_mem = op->arena;
+      ch.nc_norm = op->arena->as<float>(o_norm);
+      ch.nc_rowlse = op->arena->as<float>(o_lse);
+    }
+    DevMemP arena = op->arena;
+    BatchP r = result(Batch::SCALAR, n, op);
+    r->v_mem = arena;
+    r->v_dev = arena->as<float>();
+    return r;
+  }
+  if (!tropical && native(*x, Batch::LINEAR) && !x->materialised && x->nc_norm) {
+    // left behind by the sweep over the same chains: nothing to launch
+    auto op = std::make_shared<BFsLinearOp>();
+    op->inputs = {x};
+    BatchP r = result(Batch::SCALAR, x->n, op);
+    r->v_mem = x->nc_mem;
+    r->v_dev = x->nc_norm;
+    return r;
+  }
+  batch_materialise(*x);
+  return batch_from_graphs(op_shortest_distance(x->graphs, tropical));
+}
+
+BatchP batch_viterbi_path(const BatchP& x) {
+  batch_materialise(*x);
+  return batch_from_graphs(op_viterbi_path(x->graphs));
+}
+
+BatchP batch_scalar(ScalarKind k, const BatchP& a, const BatchP& b) {
+  const bool binary = k != SK_NEGATE;
+  if (native(*a, Batch::SCALAR) && !a->materialised &&
+      (!binary || (native(*b, Batch::SCALAR) && !b->materialised && b->n == a->n))) {
+    Runtime& rt = Runtime::get();
+    auto op = std::make_shared<BScalarOp>();
+    op->kind = k;
+    op->inputs = binary ? std::vector<BatchP>{a, b} : std::vector<BatchP>{a};
+    BatchP r = result(Batch::SCALAR, a->n, op);
+    r->v_mem = rt.alloc(sizeof(float) * size_t(a->n ? a->n : 1));
+    r->v_dev = r->v_mem->as<float>();
+    launch_vec_axpby(r->v_dev, a->v_dev, binary ? b->v_dev : nullptr, size_t(a->n), k == SK_NEGATE ? -1.0f : 1.0f,
+                     k == SK_SUBTRACT ? -1.0f : 1.0f, 0, rt.stream());
+    return r;
+  }
+  batch_materialise(*a);
+  std::vector<Graph> none;
+  if (binary) batch_materialise(*b);
+  return batch_from_graphs(op_scalar(k, a->graphs, binary ? b->graphs : none));
+}
+
+// ---- autograd --------------------------------------------------------------------------------
+void batch_backward(const BatchP& root, bool retain) {
+  if (root->tape_cleared)
+    throw_invalid("[autograd::backward] Cannot Backward twice without retaining the graph.");  // autograd.cpp:44-47
+  if (root->materialised || !root->op || root->kind != Batch::SCALAR) {
+    batch_materialise(*root);
+    op_backward(root->graphs, nullptr, retain);
+    return;
+  }
+  Runtime& rt = Runtime::get();
+  // reachable producers, newest first (creation order is a topological order: autograd.cpp:17-67)
+  std::vector<Batch*> order;
+  std::unordered_set<Batch*> seen;
+  std::vector<BatchP> hold;  // (dropping a producer at the end must not take its inputs away under us)
+  std::vector<BatchP> stack{root};
+  while (!stack.empty()) {
+    BatchP b = stack.back();
+    stack.pop_back();
+    if (!b->calc_grad || !seen.insert(b.get()).second) continue;
+    hold.push_back(b);
+    if (b->op) {
+      order.push_back(b.get());
+      for (auto& in : b->op->inputs) stack.push_back(in);
+    }
+  }
+  std::sort(order.begin(), order.end(), [](Batch* a, Batch* b) { return a->op->seq > b->op->seq; });
+  // seed: addGrad(ones) (autograd.cpp:57-62) -- onto whatever an earlier, retained backward left there
+  if (!root->g_dev) {
+    alloc_grad(*root, false);
+    launch_fill_f32(root->g_dev, 1.0f, size_t(root->n), rt.stream());
+  } else {
+    DevMemP ones = rt.alloc(sizeof(float) * size_t(root->n ? root->n : 1));
+    launch_fill_f32(ones->as<float>(), 1.0f, size_t(root->n), rt.stream());
+    launch_vec_axpby(root->g_dev, ones->as<float>(), nullptr, size_t(root->n), 1.0f, 0.0f, 1, rt.stream());
+  }
+  BackwardPlan plan;
+  t_plan = &plan;
+  try {
+    for (Batch* b : order) {
+      if (!b->g_dev) continue;  // no gradient reached it (a symbolic product never holds one)
+      b->op->backward(*b);
+    }
+    // normalisers that found no sweep to ride with
+    for (auto& kv : plan.lin)
+      if (!plan.fused.count(kv.first)) static_cast<BFsLinearOp*>(kv.second->op.get())->run(*kv.second);
+  } catch (...) {
+    t_plan = nullptr;
+    throw;
+  }
+  t_plan = nullptr;
+  // leaves whose elements were taken out as graphs: those carry the gradient
+  for (Batch* b : seen)
+    if (b->materialised && b->g_dev && !b->op) {
+      for (int i = 0; i < b->n; ++i) b->graphs[size_t(i)].add_grad_device(b->g_mem, b->g_dev + b->g_off[size_t(i)], false);
+      b->g_dev = nullptr;
+      b->g_mem.reset();
+    }
+  if (!retain)
+    for (Batch* b : order) {
+      if (b != root.get()) {
+        b->g_dev = nullptr;  // gradients of intermediate results go with the tape (autograd.cpp:58-64)
+        b->g_mem.reset();
+      }
+      b->op.reset();
+      b->tape_cleared = true;
+    }
+}
+
+// ---- gathers ---------------------------------------------------------------------------------
+void batch_items_device(const BatchP& x, void* dev_out) {
+  if (x->kind == Batch::SCALAR && !x->materialised) {
+    Runtime::get().d2d(dev_out, x->v_dev, sizeof(float) * size_t(x->n));
+    return;
+  }
+  batch_materialise(*x);
+  items_device(x->graphs, dev_out);
+}
+void batch_items_host(const BatchP& x, float* out) {
+  if (x->kind == Batch::SCALAR && !x->materialised) {
+    Runtime::get().d2h_sync(out, x->v_dev, sizeof(float) * size_t(x->n));
+    return;
+  }
+  batch_materialise(*x);
+  items_host(x->graphs, out);
+}
+void batch_grads_bind(const BatchP& x, void* dev_out, const int64_t* offsets) {
+  if (x->materialised) {
+    grads_bind_device(x->graphs, dev_out, offsets);
+    return;
+  }
+  if (x->kind != Batch::LINEAR && x->kind != Batch::SCALAR) return;  // a hint
+  int64_t o = 0;
+  for (int i = 0; i < x->n; ++i) {
+    if (offsets[i] != offsets[0] + o) return;  // not back to back: gathered afterwards
+    o += x->elem_size(i);
+  }
+  if (x->n == 0) return;
+  x->dest_mem = std::make_shared<DevMem>();
+  x->dest_mem->ptr = dev_out;
+  x->dest_mem->borrowed = true;
+  x->dest = static_cast<float*>(dev_out) + offsets[0];
+}
+void batch_grads_device(const BatchP& x, void* dev_out, const int64_t* offsets) {
+  if (x->kind == Batch::CTC_TARGETS) batch_materialise(*x);  // exact arc counts live with the element graphs
+  if (x->materialised) {
+    grads_device(x->graphs, dev_out, offsets);
+    return;
+  }
+  if (!x->g_dev) throw_logic("[gtn::Graph::grad] Gradient not calculated yet.");  // graph.cpp:131-140
+  Runtime& rt = Runtime::get();
+  std::vector<AxpyArgs> ax;
+  int64_t maxn = 0;
+  for (int i = 0; i < x->n; ++i) {
+    float* dst = static_cast<float*>(dev_out) + offsets[i];
+    float* src = x->g_dev + x->g_off[size_t(i)];
+    if (dst == src) continue;  // written in place
+    const int64_t len = x->g_off[size_t(i) + 1] - x->g_off[size_t(i)];
+    ax.push_back({dst, src, len, 1.0f});
+    maxn = std::max(maxn, len);
+  }
+  if (ax.empty()) return;
+  DevMemP d = upload_vec(ax);
+  launch_axpy_batch(d->as<AxpyArgs>(), int(ax.size()), maxn, /*copy*/ 2, rt.stream());
+}
+
+} // namespace gtnx

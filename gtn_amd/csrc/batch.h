@@ -1,0 +1,92 @@
+// batch.h -- B graphs held as ONE record.
+//
+// The reference runs a criterion as parallelMap over per-utterance graphs
+// (benchmarks/ctc.cpp:136-168, bindings/python/examples/pytorch_loss.py:46-102); the vector
+// overloads of ops.h already turn that into one launch per function, but they still hand back B
+// graph objects per call (structure + weights + autograd node each), and at C3 the host spent
+// four times the GPU's time creating and destroying them.  A Batch is what such a call returns
+// when nobody looks at the elements: one object, one tape node, dense device arrays.  Taking an
+// element out (batch_get) builds the ordinary per-graph expression once, tape included, so
+// anything the batch functions do not cover natively still works -- through the vector ops.
+//
+// Native (no per-element objects):   CTC target acceptors built on the device from label
+// sequences, linear chains over one [B][M][C] tensor, their composition (kept symbolic),
+// forwardScore of both, negate / add / subtract, backward, item / gradient gathers.
+#pragma once
+
+#include <memory>
+#include <vector>
+
+#include "ops.h"
+
+namespace gtnx {
+
+struct Batch;
+using BatchP = std::shared_ptr<Batch>;
+
+struct BatchOp {
+  uint64_t seq = 0;
+  std::vector<BatchP> inputs;
+  virtual void backward(Batch& out) = 0;
+  virtual ~BatchOp() {}
+};
+
+struct Batch {
+  enum Kind { GRAPHS, CTC_TARGETS, LINEAR, PRODUCT, SCALAR };
+  Kind kind = GRAPHS;
+  int n = 0;
+  bool calc_grad = false;
+
+  // the elements as graphs: always there for GRAPHS, built on demand otherwise (then THEY carry the
+  // gradients: batch-level results are pushed into them)
+  bool materialised = false;
+  std::vector<Graph> graphs;
+
+  // ---- CTC_TARGETS: label sequences back to back; records (BandNode, flags, sorted lists) on the device
+  std::vector<int> labels, lab_off;  // lab_off[n + 1]
+  int blank = 0;
+  int max_label = -1, max_nodes = 0;
+  DevMemP rec_mem;
+  std::vector<size_t> rec_off;       // byte offset of element b's records
+  // ---- LINEAR: [n][M][C] device tensor (owned copy or the caller's)
+  int M = 0, C = 0;
+  DevMemP w_mem;
+  float* w_dev = nullptr;
+  DevMemP nc_mem;                    // forwardScore of every chain + per-row log-sum-exps, left behind by a sweep
+  float* nc_norm = nullptr;
+  float* nc_rowlse = nullptr;
+  // ---- PRODUCT: compose(fixed, chain) / compose(chain, fixed), never built
+  BatchP fixed, chain;
+  bool chain_first = false, intersect = false;
+  // ---- SCALAR: one float per element
+  DevMemP v_mem;
+  float* v_dev = nullptr;
+
+  // ---- autograd
+  std::shared_ptr<BatchOp> op;
+  bool tape_cleared = false;         // backward without retain went through here (autograd.cpp:48-51)
+  DevMemP g_mem;                     // gradient, elements back to back at g_off[b] (floats)
+  float* g_dev = nullptr;
+  std::vector<int64_t> g_off;        // n + 1
+  DevMemP dest_mem;                  // batch_grads_bind: where the first gradient should be written
+  float* dest = nullptr;
+
+  int64_t elem_size(int b) const;    // gradient floats of element b (arcs; an upper bound for CTC_TARGETS)
+};
+
+BatchP batch_from_graphs(std::vector<Graph> gs);
+BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, bool calc_grad);
+BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool borrow);
+BatchP batch_compose(const BatchP& a, const BatchP& b, bool intersect);
+BatchP batch_shortest_distance(const BatchP& x, bool tropical);
+BatchP batch_viterbi_path(const BatchP& x);
+BatchP batch_scalar(ScalarKind k, const BatchP& a, const BatchP& b);
+void batch_backward(const BatchP& root, bool retain);
+void batch_items_host(const BatchP& x, float* out);
+void batch_items_device(const BatchP& x, void* dev_out);
+void batch_grads_device(const BatchP& x, void* dev_out, const int64_t* offsets);
+void batch_grads_bind(const BatchP& x, void* dev_out, const int64_t* offsets);
+Graph batch_get(const BatchP& x, int i);
+void batch_materialise(Batch& x);
+
+} // namespace gtnx

@@ -4,6 +4,7 @@
 #include <string>
 #include <vector>
 
+#include "batch.h"
 #include "ops.h"
 
 #define GTNX_API extern "C" __attribute__((visibility("default")))
@@ -532,6 +533,73 @@ GTNX_API gtnx_status_t gtnx_grads_bind_device_n(const gtnx_graph_t* g, int n, vo
     auto v = vec(g, n);
     grads_bind_device(v, out, offsets);
   });
+}
+
+// ------------------------------------------------------------------ batch records
+namespace {
+inline BatchP& BH(gtnx_batch_t h) {
+  if (!h) throw_invalid("null batch handle");
+  return *reinterpret_cast<BatchP*>(h);
+}
+inline gtnx_batch_t HB(BatchP b) { return reinterpret_cast<gtnx_batch_t>(new BatchP(std::move(b))); }
+} // namespace
+GTNX_API gtnx_status_t gtnx_batch_from_graphs(const gtnx_graph_t* g, int n, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_from_graphs(vec(g, n, true))); });
+}
+GTNX_API gtnx_status_t gtnx_batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, int cg,
+                                              gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_ctc_targets(labels, lengths, n, blank, cg != 0)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_linear(int n, int M, int N, int cg, const void* dev, int borrow, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_linear(n, M, N, cg != 0, dev, borrow != 0)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_destroy(gtnx_batch_t b) {
+  return guard([&] { delete reinterpret_cast<BatchP*>(b); });
+}
+GTNX_API gtnx_status_t gtnx_batch_size(gtnx_batch_t b, int* out) {
+  return guard([&] { *out = BH(b)->n; });
+}
+GTNX_API gtnx_status_t gtnx_batch_get(gtnx_batch_t b, int i, gtnx_graph_t* out) {
+  return guard([&] { *out = H(batch_get(BH(b), i)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_negate(gtnx_batch_t a, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_scalar(SK_NEGATE, BH(a), nullptr)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_add(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_scalar(SK_ADD, BH(a), BH(b))); });
+}
+GTNX_API gtnx_status_t gtnx_batch_subtract(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_scalar(SK_SUBTRACT, BH(a), BH(b))); });
+}
+GTNX_API gtnx_status_t gtnx_batch_compose(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_compose(BH(a), BH(b), false)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_intersect(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_compose(BH(a), BH(b), true)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_forward_score(gtnx_batch_t a, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_shortest_distance(BH(a), false)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_viterbi_score(gtnx_batch_t a, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_shortest_distance(BH(a), true)); });
+}
+GTNX_API gtnx_status_t gtnx_batch_viterbi_path(gtnx_batch_t a, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_viterbi_path(BH(a))); });
+}
+GTNX_API gtnx_status_t gtnx_batch_backward(gtnx_batch_t a, int retain) {
+  return guard([&] { batch_backward(BH(a), retain != 0); });
+}
+GTNX_API gtnx_status_t gtnx_batch_items(gtnx_batch_t a, float* out) {
+  return guard([&] { batch_items_host(BH(a), out); });
+}
+GTNX_API gtnx_status_t gtnx_batch_items_device(gtnx_batch_t a, void* out) {
+  return guard([&] { batch_items_device(BH(a), out); });
+}
+GTNX_API gtnx_status_t gtnx_batch_grads_bind_device(gtnx_batch_t a, void* out, const int64_t* offsets) {
+  return guard([&] { batch_grads_bind(BH(a), out, offsets); });
+}
+GTNX_API gtnx_status_t gtnx_batch_grads_device(gtnx_batch_t a, void* out, const int64_t* offsets) {
+  return guard([&] { batch_grads_device(BH(a), out, offsets); });
 }
 
 // ------------------------------------------------------------------ autograd

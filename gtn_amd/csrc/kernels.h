@@ -394,6 +394,17 @@ struct BandPair {
   int lgrn;                        // log2 of the rows per shift period of the forward launch
   int n_lab, pad;
 };
+// one CTC target acceptor per label sequence, written as band records on the device (band.hip)
+struct CtcTargetArgs {
+  const GTNX_G int* labels;   // [U]
+  GTNX_G BandNode* nodes;     // [N = 2U + 1]
+  GTNX_G uint8_t* nflags;     // [N]
+  GTNX_G int* snode;          // [N]
+  GTNX_G int* slab;           // [N]
+  GTNX_G int* n_arcs;         // [1] or null
+  int N, pad;
+};
+void launch_ctc_targets(const CtcTargetArgs* d_args, int n, int blank, hipStream_t st);
 int band_max_nodes();
 int band_max_labels();
 int band_npl(int max_nodes);               // nodes per lane: 1 or 2
@@ -433,6 +444,8 @@ struct AxpyArgs {
 void launch_axpy_batch(const AxpyArgs* d_args, int n, int64_t maxn, int atomic, hipStream_t st);
 // gather n scalars at arbitrary addresses into a dense array
 void launch_gather_scalars(const float* const* d_ptrs, float* out, int n, hipStream_t st);
+// out[i] = (accumulate ? out[i] : 0) + sa * a[i] + sb * b[i]  (b may be null) -- dense vectors of a batch record
+void launch_vec_axpby(float* out, const float* a, const float* b, size_t n, float sa, float sb, int accumulate, hipStream_t st);
 // viterbiPath grad: grad[arcs[a]] += delta[a]
 struct ScatterArgs {
   const GTNX_G int* idx;

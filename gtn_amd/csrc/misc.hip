@@ -321,6 +321,18 @@ void launch_linear_backward(const LinArgs* d, int n, int tropical, int vec_rows,
     hipLaunchKernelGGL(linear_backward_kernel<false>, dim3(n * kSplits), dim3(kBlock), 0, st, d);
 }
 
+namespace {
+__global__ void vec_axpby_kernel(float* out, const float* a, const float* b, size_t n, float sa, float sb, int accumulate) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    float v = sa * a[i];
+    if (b) v += sb * b[i];
+    out[i] = accumulate ? out[i] + v : v;
+  }
+}
+} // namespace
+void launch_vec_axpby(float* out, const float* a, const float* b, size_t n, float sa, float sb, int accumulate, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(vec_axpby_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, a, b, n, sa, sb, accumulate);
+}
 void launch_fill_i32(int* p, int v, size_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
 }

@@ -2200,6 +2200,31 @@ std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
   return outs;
 }
 
+} // namespace
+int band_vec_ok(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
+// launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward) {
+  Runtime& rt = Runtime::get();
+  if (tab.empty()) return;
+  std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  std::vector<BandPair> flat;
+  flat.reserve(tab.size());
+  for (auto& e : tab) flat.push_back(e.second);
+  DevMemP d = upload_vec(flat);
+  const BandPair* dp = d->as<BandPair>();
+  for (size_t i0 = 0; i0 < tab.size();) {
+    size_t i1 = i0;
+    int max_ns = 0;
+    while (i1 < tab.size() && tab[i1].first == tab[i0].first) max_ns = std::max(max_ns, tab[i1++].second.NS);
+    const BandLaunchKey& k = tab[i0].first;
+    if (backward)
+      launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, k.vec != 0, rt.stream());
+    else
+      launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.vec != 0, rt.stream());
+    i0 = i1;
+  }
+}
+namespace {
 // ---- one workgroup per (chain, BANDED G) pair: band.hip.  CTC targets and force-alignment
 // acceptors: a single wave carries the whole recursion, the other waves stage.
 bool band_shape_ok(const Structure& cs, Structure& fs, bool chain_first) {
@@ -2237,36 +2262,9 @@ struct BandSdOp : OpRecord {
   std::vector<uint8_t> unit;    // unit-shaped G with all-zero weights
   DevMemP arena;                // alpha planes, row shifts, scores
 
-  struct Key {
-    int C, npl, unit, gradg, vec;
-    bool operator<(const Key& o) const {
-      return std::tie(C, npl, unit, gradg, vec) < std::tie(o.C, o.npl, o.unit, o.gradg, o.vec);
-    }
-    bool operator==(const Key& o) const { return !(*this < o) && !(o < *this); }
-  };
-  static int band_vec(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
-  // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
-  static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward) {
-    Runtime& rt = Runtime::get();
-    if (tab.empty()) return;
-    std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
-    std::vector<BandPair> flat;
-    flat.reserve(tab.size());
-    for (auto& e : tab) flat.push_back(e.second);
-    DevMemP d = upload_vec(flat);
-    const BandPair* dp = d->as<BandPair>();
-    for (size_t i0 = 0; i0 < tab.size();) {
-      size_t i1 = i0;
-      int max_ns = 0;
-      while (i1 < tab.size() && tab[i1].first == tab[i0].first) max_ns = std::max(max_ns, tab[i1++].second.NS);
-      const Key& k = tab[i0].first;
-      if (backward)
-        launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, k.vec != 0, rt.stream());
-      else
-        launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.vec != 0, rt.stream());
-      i0 = i1;
-    }
-  }
+  using Key = BandLaunchKey;
+  static int band_vec(const BandPair& p) { return band_vec_ok(p); }
+  static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward) { band_launch(tab, backward); }
 
   void backward(std::vector<Member>& ms) override {
     Runtime& rt = Runtime::get();
@@ -2334,8 +2332,7 @@ struct BandSdOp : OpRecord {
 void flush_chain_plan() {
   ChainGradPlan* plan = t_chain_plan;
   if (!plan || plan->empty()) return;
-  Runtime& rt = Runtime::get();
-  std::vector<std::pair<BandSdOp::Key, BandPair>> tab;
+    std::vector<std::pair<BandSdOp::Key, BandPair>> tab;
   tab.reserve(plan->band.size());
   for (auto& b : plan->band) {
     auto it = b.p.grad_em ? plan->lin.find(b.chain_w) : plan->lin.end();

@@ -14,6 +14,7 @@
 #pragma once
 
 #include <cstring>
+#include <tuple>
 #include <vector>
 
 #include "graph.h"
@@ -49,6 +50,17 @@ struct GradSink {
   }
   void flush();
 };
+
+// band.hip launches are grouped by these (one kernel instantiation per group)
+struct BandLaunchKey {
+  int C, npl, unit, gradg, vec;
+  bool operator<(const BandLaunchKey& o) const {
+    return std::tie(C, npl, unit, gradg, vec) < std::tie(o.C, o.npl, o.unit, o.gradg, o.vec);
+  }
+  bool operator==(const BandLaunchKey& o) const { return !(*this < o) && !(o < *this); }
+};
+int band_vec_ok(const BandPair& p);
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward);
 
 enum ScalarKind { SK_NEGATE = 0, SK_ADD = 1, SK_SUBTRACT = 2 };
 

@@ -15,6 +15,7 @@
 //   utils.h      equal / isomorphic, text and binary graph files, operator<<, draw
 //   rand.h       sample, randEquivalent
 //   parallel.h   parallelMap for host-side work (target-graph construction)
+//   batch.h      Batch: B graphs as one record, the same functions over it (criteria)
 #pragma once
 
 #include "gtn/graph.h"
@@ -28,3 +29,5 @@
 #include "gtn/rand.h"
 
 #include "gtn/parallel.h"
+
+#include "gtn/batch.h"

@@ -196,6 +196,41 @@ gtnx_status_t gtnx_grads_device_n(const gtnx_graph_t* g, int n, void* device_out
  * place and copies nothing).  A hint: results are the same without it. */
 gtnx_status_t gtnx_grads_bind_device_n(const gtnx_graph_t* g, int n, void* device_out, const int64_t* offsets);
 
+/* ------------------------------------------------------------------ batch records
+ * B graphs held as ONE object: what gtn::parallelMap over the per-graph functions
+ * (parallel/parallel_map.h:153-188; benchmarks/ctc.cpp:150-165) returns when nobody looks at
+ * the elements -- one record and one tape node per call instead of B graphs.  Elements can be
+ * taken out as ordinary graphs at any time (gtnx_batch_get): the per-graph expression is then
+ * built once, tape included, and everything the batch functions do not cover natively runs
+ * through the vector functions above.  Results per element equal the per-graph functions'. */
+typedef struct gtnx_batch_s* gtnx_batch_t;
+gtnx_status_t gtnx_batch_from_graphs(const gtnx_graph_t* g, int n, gtnx_batch_t* out);
+/* the CTC target acceptor of benchmarks/ctc.cpp:40-58 / examples/ctc.cpp:21-41 for n label
+ * sequences (labels back to back, lengths[i] each), built on the device */
+gtnx_status_t gtnx_batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, int calc_grad,
+                                     gtnx_batch_t* out);
+/* n linear graphs (creations.cpp:20-33) over one device tensor [n][M][N]; borrow != 0: read in
+ * place (see gtnx_linear_graph_borrow_n) */
+gtnx_status_t gtnx_batch_linear(int n, int M, int N, int calc_grad, const void* device_weights, int borrow,
+                                gtnx_batch_t* out);
+gtnx_status_t gtnx_batch_destroy(gtnx_batch_t b);
+gtnx_status_t gtnx_batch_size(gtnx_batch_t b, int* out);
+gtnx_status_t gtnx_batch_get(gtnx_batch_t b, int i, gtnx_graph_t* out);               /* new handle */
+gtnx_status_t gtnx_batch_negate(gtnx_batch_t a, gtnx_batch_t* out);                   /* functions.cpp:18-30 */
+gtnx_status_t gtnx_batch_add(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out);      /* functions.cpp:32-46 */
+gtnx_status_t gtnx_batch_subtract(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out); /* functions.cpp:48-64 */
+gtnx_status_t gtnx_batch_compose(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out);  /* functions.cpp:225-237 */
+gtnx_status_t gtnx_batch_intersect(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out);/* functions.cpp:239-251 */
+gtnx_status_t gtnx_batch_forward_score(gtnx_batch_t a, gtnx_batch_t* out);            /* functions.cpp:320-322 */
+gtnx_status_t gtnx_batch_viterbi_score(gtnx_batch_t a, gtnx_batch_t* out);            /* functions.cpp:324-326 */
+gtnx_status_t gtnx_batch_viterbi_path(gtnx_batch_t a, gtnx_batch_t* out);             /* functions.cpp:328-330 */
+gtnx_status_t gtnx_batch_backward(gtnx_batch_t a, int retain_graph);                  /* autograd.cpp:17-67 */
+gtnx_status_t gtnx_batch_items(gtnx_batch_t a, float* out);                           /* graph.h:143, n floats */
+gtnx_status_t gtnx_batch_items_device(gtnx_batch_t a, void* device_out);
+/* as gtnx_grads_bind_device_n / gtnx_grads_device_n, for the elements of a batch */
+gtnx_status_t gtnx_batch_grads_bind_device(gtnx_batch_t a, void* device_out, const int64_t* offsets);
+gtnx_status_t gtnx_batch_grads_device(gtnx_batch_t a, void* device_out, const int64_t* offsets);
+
 /* ------------------------------------------------------------------ autograd
  * gtn/autograd.h:27,37 */
 gtnx_status_t gtnx_backward(gtnx_graph_t g, int retain_graph);

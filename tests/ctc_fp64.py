@@ -36,8 +36,8 @@ def ctc_loss_fp64(emissions, target, blank=0):
     e = em[:, lab]  # [T, S]
     for t in range(T):
         a = alpha[t]
-        x1 = np.concatenate([[NEG], a[:-1]])
-        x2 = np.where(skip, np.concatenate([[NEG, NEG], a[:-2]]), NEG)
+        x1 = np.concatenate([[NEG], a])[:S]
+        x2 = np.where(skip, np.concatenate([[NEG, NEG], a])[:S], NEG)
         alpha[t + 1] = _lse(np.stack([a, x1, x2]), axis=0) + e[t]
     acc = [S - 1] if S == 1 else [S - 1, S - 2]
     z = _lse(alpha[T, acc])
@@ -48,11 +48,11 @@ def ctc_loss_fp64(emissions, target, blank=0):
         return loss, grad, None
     beta = np.full((T + 1, S), NEG)
     beta[T, acc] = 0.0
-    skip_out = np.concatenate([skip[2:], [False, False]])  # arc s -> s+2
+    skip_out = np.concatenate([skip, [False, False]])[2:S + 2]  # arc s -> s+2
     for t in range(T - 1, -1, -1):
         q = e[t] + beta[t + 1]
-        y1 = np.concatenate([q[1:], [NEG]])
-        y2 = np.where(skip_out, np.concatenate([q[2:], [NEG, NEG]]), NEG)
+        y1 = np.concatenate([q, [NEG]])[1:S + 1]
+        y2 = np.where(skip_out, np.concatenate([q, [NEG, NEG]])[2:S + 2], NEG)
         beta[t] = _lse(np.stack([q, y1, y2]), axis=0)
     occ = np.exp(alpha[1:] + beta[1:] - z)  # node posteriors after consuming frame t
     for s in range(S):

@@ -1,0 +1,185 @@
+"""Batch records (gtnx_batch_*, gtn_amd.Batch): B graphs as one object.
+
+Parity = the per-element results of the reference's per-graph functions: the C oracle
+(oracle/gtn_oracle.c, pinned on the reference in tests/test_oracle.py) for the CTC loss and
+its gradients, and this engine's own per-graph path -- itself oracle-checked in
+tests/test_parity_gpu.py -- for everything the batch functions hand over to it.
+Reference: benchmarks/ctc.cpp:40-58,150-165; functions.cpp:18-64,225-251,320-330.
+"""
+import numpy as np
+import pytest
+
+import graphgen as gg
+from oracle_lib import ctc_loss
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(x):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+
+
+def _ragged_inputs(seed, B, T, C, Umax, Umin=0):
+    rng = np.random.default_rng(seed)
+    em = (rng.random((B, T, C), dtype=np.float32) * 10 - 5).astype(np.float32)
+    tg = [rng.integers(1, C, size=int(rng.integers(Umin, Umax + 1))).astype(np.int32) for _ in range(B)]
+    return em, tg
+
+
+def _batch_ctc(gtn, em_dev, tg, T, C, target_grad=True, bind=None):
+    B = len(tg)
+    ctcs = gtn.Batch.ctc_targets(tg, 0, target_grad)
+    ems = gtn.Batch.linear(B, T, C, em_dev, True, True)
+    if bind is not None:
+        ems.bind_grads(bind, np.arange(B, dtype=np.int64) * T * C)
+    score = gtn.forward_score(gtn.intersect(ctcs, ems))
+    loss = gtn.subtract(gtn.forward_score(ems), score)
+    return ctcs, ems, loss
+
+
+@pytest.mark.parametrize("B,T,C,Umax", [(5, 40, 12, 9), (3, 150, 29, 40), (4, 64, 260, 30), (2, 33, 7, 140)])
+def test_batch_ctc_loss_vs_oracle(gtn, B, T, C, Umax):
+    """losses and emission gradients of the batch path against the oracle, ragged targets (empty
+    ones included), odd and wide alphabets, targets of more than 256 nodes"""
+    import torch
+    em, tg = _ragged_inputs(11 + B, B, T, C, Umax)
+    tg[0] = tg[0][:0] if B > 2 else tg[0]  # an empty target
+    em_dev = _dev(em)
+    grad = torch.full((B, T, C), float("nan"), device="cuda:0")
+    ctcs, ems, loss = _batch_ctc(gtn, em_dev, tg, T, C, bind=grad)
+    gtn.backward(loss)
+    got = loss.items()
+    ems.grads_to_device(grad, np.arange(B, dtype=np.int64) * T * C)
+    g = grad.cpu().numpy()
+    from ctc_fp64 import ctc_loss_fp64
+    for b in range(B):
+        want, wgrad = ctc_loss(em[b], tg[b])
+        if np.isinf(want):
+            assert np.isinf(got[b])
+            continue
+        assert abs(got[b] - want) <= 1e-4 * max(1.0, abs(want)), (b, got[b], want)
+        # gradients against float64: the float32 oracle restates the reference's unnormalised running
+        # scores and carries ~8 eps |score| of relative noise itself -- the batch
+        # path has to be at least as close to exact arithmetic as the oracle is
+        _, exact, _ = ctc_loss_fp64(em[b], tg[b])
+        err = np.abs(g[b] - exact).max()
+        assert err <= 2e-5, err
+        assert err <= np.abs(wgrad - exact).max() + 2e-6
+
+
+def test_batch_elements_are_the_reference_graphs(gtn):
+    """elements taken out of a target batch are the graphs of benchmarks/ctc.cpp:40-58: same nodes,
+    arc ids and labels; the device-built records give them the gradients the per-graph path gives"""
+    B, T, C = 6, 50, 20
+    em, tg = _ragged_inputs(5, B, T, C, 12, Umin=1)
+    tg[1] = np.array([3, 3, 3, 4, 4], np.int32)  # repeated labels: no skip arcs there
+    em_dev = _dev(em)
+    ctcs, ems, loss = _batch_ctc(gtn, em_dev, tg, T, C)
+    gtn.backward(loss)
+    # per-graph path on the same inputs
+    ref_t = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    ref_e = gtn.linear_graph_n(B, T, C, em_dev)
+    prev = gtn.compose_mode(2)
+    try:
+        ref_l = gtn.subtract(gtn.forward_score(ref_e), gtn.forward_score(gtn.intersect(ref_t, ref_e)))
+    finally:
+        gtn.compose_mode(prev)
+    gtn.backward(ref_l)
+    for b in range(B):
+        el = ctcs[b]
+        assert gtn.equal(el, ref_t[b])
+        np.testing.assert_allclose(el.grad().weights_to_numpy(), ref_t[b].grad().weights_to_numpy(), rtol=2e-4, atol=2e-5)
+        np.testing.assert_allclose(ems[b].grad().weights_to_numpy(), ref_e[b].grad().weights_to_numpy(), rtol=2e-4,
+                                   atol=2e-5)
+        assert abs(loss[b].item() - ref_l[b].item()) <= 1e-4 * max(1.0, abs(ref_l[b].item()))
+
+
+def test_batch_fallbacks_match_per_graph_path(gtn):
+    """what the batch functions do not cover natively runs through the vector functions on the
+    elements: viterbi of a product batch, labels outside the alphabet, target-first and
+    emissions-first products, batches made from ordinary graphs"""
+    B, T, C = 4, 30, 9
+    em, tg = _ragged_inputs(21, B, T, C, 6, Umin=1)
+    em_dev = _dev(em)
+    ctcs = gtn.Batch.ctc_targets(tg, 0, False)
+    ems = gtn.Batch.linear(B, T, C, em_dev, True, False)
+    ref_t = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist()), calc_grad=False) for t in tg]
+    ref_e = gtn.linear_graph_n(B, T, C, em_dev)
+    # viterbi score and path of the product
+    vs = gtn.viterbi_score(gtn.intersect(ctcs, ems)).items()
+    want = gtn.items(gtn.viterbi_score(gtn.intersect(ref_t, ref_e)))
+    np.testing.assert_allclose(vs, want, rtol=1e-5)
+    vp = gtn.viterbi_path(gtn.compose(ems, ctcs))
+    rp = gtn.viterbi_path(gtn.compose(ref_e, ref_t))
+    for b in range(B):
+        assert vp[b].labels_to_list() == rp[b].labels_to_list()
+    # emissions-first product, forward score, backward through the batch tape
+    fs = gtn.forward_score(gtn.compose(ems, ctcs))
+    gtn.backward(gtn.negate(fs))
+    rf = gtn.forward_score(gtn.compose(ref_e, ref_t))
+    gtn.backward(gtn.negate(rf))
+    np.testing.assert_allclose(fs.items(), gtn.items(rf), rtol=1e-5)
+    for b in range(B):
+        np.testing.assert_allclose(ems[b].grad().weights_to_numpy(), ref_e[b].grad().weights_to_numpy(), rtol=2e-4,
+                                   atol=2e-5)
+    # a label outside the alphabet: the product is built by the ordinary compose (it matches nothing)
+    bad = gtn.Batch.ctc_targets([np.array([C + 3], np.int32)], 0, False)
+    one = gtn.Batch.linear(1, T, C, em_dev, False, False)
+    assert np.isinf(gtn.forward_score(gtn.intersect(bad, one)).items()[0])
+    # a batch made from ordinary graphs
+    wrapped = gtn.Batch(ref_t)
+    fs2 = gtn.forward_score(gtn.intersect(wrapped, gtn.Batch.linear(B, T, C, em_dev, False, False)))
+    np.testing.assert_allclose(fs2.items(), gtn.items(rf), rtol=1e-5)
+
+
+def test_batch_backward_twice_accumulates(gtn):
+    """a second backward over a retained tape adds to every gradient on the way, the seed included
+    (autograd.cpp:44-62, graph.cpp:108-129): same numbers as the per-graph path; without retain a
+    second backward throws as the reference's does (autograd_test.cpp:57-60)"""
+    import torch
+    B, T, C = 3, 25, 8
+    em, tg = _ragged_inputs(3, B, T, C, 5, Umin=1)
+    em_dev = _dev(em)
+    ctcs, ems, loss = _batch_ctc(gtn, em_dev, tg, T, C)
+    gtn.backward(loss, True)
+    gtn.backward(loss)
+    off = np.arange(B, dtype=np.int64) * T * C
+    g2 = torch.empty(B, T, C, device="cuda:0")
+    ems.grads_to_device(g2, off)
+    ref_t = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    ref_e = gtn.linear_graph_n(B, T, C, em_dev)
+    prev = gtn.compose_mode(2)
+    try:
+        ref_l = gtn.subtract(gtn.forward_score(ref_e), gtn.forward_score(gtn.intersect(ref_t, ref_e)))
+    finally:
+        gtn.compose_mode(prev)
+    gtn.backward(ref_l, True)
+    gtn.backward(ref_l)
+    want = np.stack([ref_e[b].grad().weights_to_numpy().reshape(T, C) for b in range(B)])
+    np.testing.assert_allclose(g2.cpu().numpy(), want, rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(ctcs[0].grad().weights_to_numpy(), ref_t[0].grad().weights_to_numpy(), rtol=2e-4, atol=2e-5)
+    with pytest.raises(ValueError):
+        gtn.backward(loss)
+
+
+def test_batch_ctc_full_size_c3_invariants(gtn):
+    """BASELINE config C3 through the batch path (what bench.py times): four utterances against the
+    float64 forward-backward, every gradient row sums to zero, losses finite"""
+    import torch
+    from ctc_fp64 import ctc_loss_fp64
+    B, T, C, U = 64, 1000, 256, 100
+    em, tg = gg.ctc_inputs(77, B, T, C, U)
+    em_dev = _dev(em)
+    grad = torch.empty(B, T, C, device="cuda:0")
+    ctcs, ems, loss = _batch_ctc(gtn, em_dev, list(tg), T, C, bind=grad)
+    gtn.backward(loss)
+    got = loss.items()
+    assert np.all(np.isfinite(got))
+    rows = grad.sum(dim=2).abs().max().item()
+    assert rows < 5e-4, rows
+    g = grad[:4].cpu().numpy()
+    for b in range(4):
+        want, wgrad, _ = ctc_loss_fp64(em[b], tg[b])
+        assert abs(got[b] - want) <= 1e-5 * abs(want), (got[b], want)
+        assert np.abs(g[b] - wgrad).max() <= 1e-4

@@ -121,6 +121,28 @@ def cpu_baseline(B, T, Cn, U, seed):
             "sample": f"4 utterances (T={T}, C={Cn}, U={U}) through the scalar C oracle"}
 
 
+def unmodified_caller(B):
+    """The reference's own benchmark program, benchmarks/ctc.cpp:136-168, compiled UNMODIFIED against
+    include/gtn and linked to libgtn_amd.so (tests/dropin/Makefile): per-utterance graph functions called
+    from parallelMap threads, which the engine gathers into batched launches (gtnx_parallel_enter).  Its
+    own configuration (T=1000, U=100, alphabet 28), its own timing loop (5 + 100 iterations)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "dropin", "_bin", "bm_ctc")
+    if not os.path.exists(exe):
+        return None
+    try:
+        r = subprocess.run([exe, str(B)], capture_output=True, text=True, timeout=240)
+        times = {k: float(v) for k, v in re.findall(r"Timing (\w+) \.\.\.\s+([0-9.e+-]+) msec", r.stdout)}
+        if "ctcBatched" not in times:
+            return {"error": (r.stdout + r.stderr)[-300:]}
+        return {"program": "benchmarks/ctc.cpp (reference, unmodified) with batch size %d: T=1000, U=100, alphabet 28" % B,
+                "ctcBatched_ms": times["ctcBatched"], "losses_per_s": B / (times["ctcBatched"] * 1e-3),
+                "other_timings_ms": {k: v for k, v in times.items() if k != "ctcBatched"}}
+    except Exception as e:  # a diagnostic must not cost the bench line
+        return {"error": str(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +158,8 @@ def main():
                          "backward) and report its kernels as built_lattice_path")
     ap.add_argument("--config", choices=["c3", "c5"], default=None,
                     help="BASELINE.json configs: c3 = T 1000, C 256, U 100 (default); c5 = T 2000, C 1024, U 200")
+    ap.add_argument("--no-unmodified-caller", action="store_true",
+                    help="skip timing the reference's own benchmarks/ctc.cpp (built unmodified against include/gtn)")
     ap.add_argument("--python-host", action="store_true",
                     help="drive the step through the Python interface instead of the C++ one")
     args = ap.parse_args()
@@ -371,6 +395,8 @@ def main():
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
             "loss_mean": float(np.mean(losses)),
         }
+        if world == 1 and not args.no_unmodified_caller:
+            out["unmodified_caller"] = unmodified_caller(B)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234)
         print(json.dumps(out))

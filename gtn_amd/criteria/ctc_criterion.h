@@ -73,15 +73,15 @@ inline void ctcLossBatch(
   if (gradDev) ems.bindGrads(gradDev, off.data());
   auto t2 = now();
   // only forwardScore of the lattices is taken: they are never built (band.hip sweeps them)
-  Batch comp = intersect(ctcs, ems);
+  Batch comp = batched::intersect(ctcs, ems);
   auto t3 = now();
   // (C++ leaves the evaluation order of benchmarks/ctc.cpp:157's call arguments open; this order lets the
   //  sweep over target o emissions, which reads every emission anyway, leave forwardScore(emissions) behind)
-  Batch score = forwardScore(comp);
-  Batch norm = forwardScore(ems);
-  Batch losses = subtract(norm, score);
+  Batch score = batched::forwardScore(comp);
+  Batch norm = batched::forwardScore(ems);
+  Batch losses = batched::subtract(norm, score);
   auto t4 = now();
-  if (gradDev) backward(losses);
+  if (gradDev) batched::backward(losses);
   auto t5 = now();
   if (times) *times = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5)};
   losses.itemsToDevice(lossDev);

@@ -1,6 +1,9 @@
 // capi.cpp -- the extern "C" boundary declared in include/gtn_amd.h.
 // Thin: argument checks, handle <-> Graph, exception -> status mapping.
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -63,6 +66,141 @@ void check_arc(Graph& g, int a) {
   if (a < 0 || a >= g.num_arcs()) throw_range("arc index out of range");
 }
 } // namespace
+
+// ------------------------------------------------------------------ call gathering
+// A caller that maps the per-graph functions over a batch on host threads (gtn::parallelMap:
+// parallel/parallel_map.h:153-188; benchmarks/ctc.cpp:150-165) issues B calls of batch size one.
+// Threads that announced themselves (gtnx_parallel_enter, made by include/gtn/parallel.h) have their
+// calls GATHERED: a call waits until every thread of the region is waiting in some call too -- nobody
+// else can join -- and one of them runs the whole group through the vector form.  Same results per
+// graph (the vector forms are element-wise); if the group call throws, the calls are run one by one
+// so that every caller gets its own result or exception.
+namespace {
+enum GatherOp { GO_NEG, GO_ADD, GO_SUB, GO_COMPOSE, GO_INTERSECT, GO_FS, GO_VS, GO_VP, GO_BWD, GO_BWD_RETAIN, GO_COUNT };
+struct GatherReq {
+  Graph a, b;
+  Graph out;
+  std::exception_ptr err;
+  bool done = false;
+};
+struct Gatherer {
+  std::mutex m;
+  std::condition_variable cv_lead;           // leaders: "everybody is waiting somewhere"
+  std::condition_variable cv_done[GO_COUNT];  // followers of one function: "the group has run"
+  std::vector<GatherReq*> pending[GO_COUNT];
+  bool leader[GO_COUNT] = {};
+  int waiting = 0;  // requests queued and not yet taken by a leader
+  int active = 0;   // threads inside a region
+};
+Gatherer& gatherer() {
+  static Gatherer* g = new Gatherer();  // never destroyed: worker threads may outlive static destruction
+  return *g;
+}
+thread_local int t_region_depth = 0;
+
+std::vector<Graph> run_group(GatherOp op, std::vector<Graph>& a, std::vector<Graph>& b) {
+  std::vector<Graph> none;
+  switch (op) {
+    case GO_NEG: return op_scalar(SK_NEGATE, a, none);
+    case GO_ADD: return op_scalar(SK_ADD, a, b);
+    case GO_SUB: return op_scalar(SK_SUBTRACT, a, b);
+    case GO_COMPOSE:
+    case GO_INTERSECT: {
+      // the lattices of such a loop are looked at by forwardScore only: keep them symbolic where
+      // the sweep kernels apply (looking inside one still builds it)
+      const int old = compose_mode_hint(2);
+      try {
+        auto r = op_compose(a, b, op == GO_INTERSECT);
+        compose_mode_hint(old);
+        return r;
+      } catch (...) {
+        compose_mode_hint(old);
+        throw;
+      }
+    }
+    case GO_FS: return op_shortest_distance(a, false);
+    case GO_VS: return op_shortest_distance(a, true);
+    case GO_VP: return op_viterbi_path(a);
+    case GO_BWD:
+    case GO_BWD_RETAIN: op_backward(a, nullptr, op == GO_BWD_RETAIN); return {};
+    default: return {};
+  }
+}
+
+// true: the call was gathered (req.out / req.err are set); false: the caller runs it itself
+bool gather(GatherOp op, GatherReq& req) {
+  if (t_region_depth <= 0) return false;
+  Gatherer& G0 = gatherer();
+  std::unique_lock<std::mutex> lk(G0.m);
+  if (G0.active <= 1) return false;
+  G0.pending[op].push_back(&req);
+  ++G0.waiting;
+  if (G0.leader[op]) {
+    if (G0.waiting >= G0.active) G0.cv_lead.notify_all();  // the last one in wakes the leaders (one wake-up, not one per arrival)
+    G0.cv_done[op].wait(lk, [&] { return req.done; });
+    return true;
+  }
+  G0.leader[op] = true;
+  // (the time limit only guards against a thread of the region that blocks outside the engine)
+  if (G0.waiting >= G0.active) G0.cv_lead.notify_all();
+  G0.cv_lead.wait_for(lk, std::chrono::milliseconds(20), [&] { return G0.waiting >= G0.active; });
+  std::vector<GatherReq*> group;
+  group.swap(G0.pending[op]);
+  G0.leader[op] = false;
+  G0.waiting -= int(group.size());
+  lk.unlock();
+  const bool binary = op == GO_ADD || op == GO_SUB || op == GO_COMPOSE || op == GO_INTERSECT;
+  bool ok = true;
+  try {
+    std::vector<Graph> a, b;
+    a.reserve(group.size());
+    for (auto* r : group) {
+      a.push_back(r->a);
+      if (binary) b.push_back(r->b);
+    }
+    std::vector<Graph> out = run_group(op, a, b);
+    for (size_t i = 0; i < out.size(); ++i) group[i]->out = std::move(out[i]);
+  } catch (...) {
+    ok = false;
+  }
+  if (!ok) {  // one by one: every caller gets its own result or exception
+    for (auto* r : group) {
+      try {
+        std::vector<Graph> a{r->a}, b;
+        if (binary) b.push_back(r->b);
+        std::vector<Graph> out = run_group(op, a, b);
+        if (!out.empty()) r->out = std::move(out[0]);
+      } catch (...) {
+        r->err = std::current_exception();
+      }
+    }
+  }
+  lk.lock();
+  for (auto* r : group) r->done = true;
+  G0.cv_done[op].notify_all();
+  return true;
+}
+} // namespace
+
+GTNX_API gtnx_status_t gtnx_parallel_enter(void) {
+  return guard([&] {
+    if (t_region_depth++ == 0) {
+      Gatherer& G0 = gatherer();
+      std::lock_guard<std::mutex> lk(G0.m);
+      ++G0.active;
+    }
+  });
+}
+GTNX_API gtnx_status_t gtnx_parallel_leave(void) {
+  return guard([&] {
+    if (t_region_depth > 0 && --t_region_depth == 0) {
+      Gatherer& G0 = gatherer();
+      std::lock_guard<std::mutex> lk(G0.m);
+      --G0.active;
+      if (G0.waiting >= G0.active) G0.cv_lead.notify_all();  // the ones waiting for company may go now
+    }
+  });
+}
 
 // ------------------------------------------------------------------ runtime
 GTNX_API const char* gtnx_last_error(void) { return g_err.c_str(); }
@@ -465,10 +603,17 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
 }
 
 // ------------------------------------------------------------------ functions
-#define UNARY_FN(name, expr, LAZY_OK)                                       \
+#define UNARY_FN(name, expr, LAZY_OK, GOP)                                  \
   GTNX_API gtnx_status_t name(gtnx_graph_t g, gtnx_graph_t* out) {          \
     return guard([&] {                                                      \
       std::vector<Graph> v{LAZY_OK ? GL(g) : G(g)};                         \
+      GatherReq req;                                                        \
+      req.a = v[0];                                                         \
+      if (gather(GOP, req)) {                                               \
+        if (req.err) std::rethrow_exception(req.err);                       \
+        *out = H(std::move(req.out));                                       \
+        return;                                                             \
+      }                                                                     \
       auto r = expr;                                                        \
       *out = H(std::move(r[0]));                                            \
     });                                                                     \
@@ -480,10 +625,18 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
       put(r, out);                                                          \
     });                                                                     \
   }
-#define BINARY_FN(name, expr)                                                           \
+#define BINARY_FN(name, expr, GOP)                                                      \
   GTNX_API gtnx_status_t name(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out) {      \
     return guard([&] {                                                                  \
       std::vector<Graph> va{G(a)}, vb{G(b)};                                            \
+      GatherReq req;                                                                    \
+      req.a = va[0];                                                                    \
+      req.b = vb[0];                                                                    \
+      if (gather(GOP, req)) {                                                           \
+        if (req.err) std::rethrow_exception(req.err);                                   \
+        *out = H(std::move(req.out));                                                   \
+        return;                                                                         \
+      }                                                                                 \
       auto r = expr;                                                                    \
       *out = H(std::move(r[0]));                                                        \
     });                                                                                 \
@@ -501,14 +654,14 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
 namespace {
 std::vector<Graph> g_empty;
 }
-UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false)
-BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb))
-BINARY_FN(gtnx_subtract, op_scalar(SK_SUBTRACT, va, vb))
-BINARY_FN(gtnx_compose, op_compose(va, vb, false))
-BINARY_FN(gtnx_intersect, op_compose(va, vb, true))
-UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false), true)
-UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true), true)
-UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v), true)
+UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false, GO_NEG)
+BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb), GO_ADD)
+BINARY_FN(gtnx_subtract, op_scalar(SK_SUBTRACT, va, vb), GO_SUB)
+BINARY_FN(gtnx_compose, op_compose(va, vb, false), GO_COMPOSE)
+BINARY_FN(gtnx_intersect, op_compose(va, vb, true), GO_INTERSECT)
+UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false), true, GO_FS)
+UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true), true, GO_VS)
+UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v), true, GO_VP)
 
 GTNX_API gtnx_status_t gtnx_items_n(const gtnx_graph_t* g, int n, float* out) {
   return guard([&] {
@@ -606,6 +759,12 @@ GTNX_API gtnx_status_t gtnx_batch_grads_device(gtnx_batch_t a, void* out, const 
 GTNX_API gtnx_status_t gtnx_backward(gtnx_graph_t g, int retain) {
   return guard([&] {
     std::vector<Graph> v{G(g)};
+    GatherReq req;
+    req.a = v[0];
+    if (gather(retain ? GO_BWD_RETAIN : GO_BWD, req)) {
+      if (req.err) std::rethrow_exception(req.err);
+      return;
+    }
     op_backward(v, nullptr, retain != 0);
   });
 }

@@ -2,6 +2,7 @@
 //
 // What the reference writes as parallelMap over per-utterance graphs
 // (benchmarks/ctc.cpp:150-165) reads the same here with one Batch per call:
+//   using namespace gtn::batched;
 //   auto loss = subtract(forwardScore(ems), forwardScore(intersect(targets, ems)));
 //   backward(loss);
 // Elements are ordinary graphs whenever somebody asks for one (operator[]).
@@ -114,6 +115,9 @@ Batch batchBinary(F f, const Batch& a, const Batch& b) {
 }
 } // namespace detail
 
+// (in gtn::batched like the vector forms: the plain names stay un-overloaded, reference callers
+//  pass them as function pointers -- parallelMap(compose, a, b))
+namespace batched {
 inline Batch negate(const Batch& a) { return detail::batchUnary(&gtnx_batch_negate, a); }
 inline Batch add(const Batch& a, const Batch& b) { return detail::batchBinary(&gtnx_batch_add, a, b); }
 inline Batch subtract(const Batch& a, const Batch& b) { return detail::batchBinary(&gtnx_batch_subtract, a, b); }
@@ -123,5 +127,6 @@ inline Batch forwardScore(const Batch& a) { return detail::batchUnary(&gtnx_batc
 inline Batch viterbiScore(const Batch& a) { return detail::batchUnary(&gtnx_batch_viterbi_score, a); }
 inline Batch viterbiPath(const Batch& a) { return detail::batchUnary(&gtnx_batch_viterbi_path, a); }
 inline void backward(const Batch& a, bool retainGraph = false) { detail::check(gtnx_batch_backward(a.handle(), retainGraph)); }
+} // namespace batched
 
 } // namespace gtn

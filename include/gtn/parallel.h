@@ -115,8 +115,9 @@ inline void noPrelude() {}
 
 template <class Body, class Pre = void (*)()>
 void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst = &noPrelude) {
-  // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped:
-  // host-side graph building saturates long before 64 of them
+  // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped.  The engine gathers
+  // the graph-function calls of the region's threads into one launch each (gtnx_parallel_enter), so
+  // more threads mean larger launches: they spend their time waiting for one another, not computing
   // One process per GPU: the ranks of a node share its cores (torchrun exports LOCAL_WORLD_SIZE),
   // and a step is host-bound, so each rank takes its share instead of oversubscribing.
   static const size_t hw = [] {
@@ -132,6 +133,16 @@ void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst =
   std::exception_ptr first;
   std::mutex mu;
   auto worker = [&]() {
+    // graph functions called from here are gathered across the region's threads (gtn_amd.h)
+    struct Region {
+      bool on;
+      explicit Region(bool o) : on(o) {
+        if (on) gtnx_parallel_enter();
+      }
+      ~Region() {
+        if (on) gtnx_parallel_leave();
+      }
+    } region(nt > 1);
     // a few indices per grab: tasks are small (one target graph each)
     const size_t grain = std::max<size_t>(1, n / (nt * 4));
     for (size_t i0 = next.fetch_add(grain); i0 < n; i0 = next.fetch_add(grain)) {
@@ -161,10 +172,10 @@ auto parallelMap(FuncType&& function, Args&&... inputs) {
     if (size >= 64) gtnx_reclaim();
   };
   if constexpr (std::is_void<OutType>::value) {
-    detail::runIndexed(size, [&](size_t i) { function(detail::pickElem(size, i, inputs)...); }, 64, prelude);
+    detail::runIndexed(size, [&](size_t i) { function(detail::pickElem(size, i, inputs)...); }, 256, prelude);
   } else {
     std::vector<OutType> out(size);
-    detail::runIndexed(size, [&](size_t i) { out[i] = function(detail::pickElem(size, i, inputs)...); }, 64, prelude);
+    detail::runIndexed(size, [&](size_t i) { out[i] = function(detail::pickElem(size, i, inputs)...); }, 256, prelude);
     return out;
   }
 }

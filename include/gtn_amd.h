@@ -74,6 +74,13 @@ gtnx_status_t gtnx_empty_cache(void);
  * would wait for the device; a host loop with idle time of its own (the caller of parallelMap while the
  * workers build graphs -- include/gtn/parallel.h does this) can offer it here. */
 gtnx_status_t gtnx_reclaim(void);
+/* The calling thread is one of several host threads mapping per-graph functions over a batch
+ * (gtn::parallelMap, parallel/parallel_map.h:153-188) from here until gtnx_parallel_leave: its
+ * function calls (negate .. viterbiPath, backward) are gathered with those of the region's other
+ * threads and run as ONE batched launch each.  Results per graph are unchanged.  Made by
+ * include/gtn/parallel.h; a hint -- without it every call is a batch of one. */
+gtnx_status_t gtnx_parallel_enter(void);
+gtnx_status_t gtnx_parallel_leave(void);
 
 /* ------------------------------------------------------------------ Graph
  * class Graph, gtn/graph.h:75-415 */

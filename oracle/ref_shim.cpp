@@ -91,6 +91,8 @@ gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
 }
 gtnx_status_t gtnx_empty_cache(void) { return GTNX_OK; }
 gtnx_status_t gtnx_reclaim(void) { return GTNX_OK; }
+gtnx_status_t gtnx_parallel_enter(void) { return GTNX_OK; }
+gtnx_status_t gtnx_parallel_leave(void) { return GTNX_OK; }
 
 gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph(calc_grad != 0)); });

@@ -18,6 +18,7 @@ PROGRAMS = [
     "parallel_test",
     "rand_test",
     "utils_test",
+    "gather_test",  # own program (tests/native/gather_test.cpp): calls gathered from parallelMap threads
 ]
 
 
@@ -31,3 +32,35 @@ def test_reference_test_program(name):
     tail = (r.stdout + r.stderr)[-4000:]
     assert r.returncode == 0, f"{name} failed:\n{tail}"
     assert "All tests passed" in r.stdout, tail
+
+
+EXPECTED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "examples_expected.json")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ex_ctc", "ex_asg"])
+def test_reference_example_program(name):
+    """the reference's CTC / ASG criteria (examples/ctc.cpp, examples/asg.cpp), unmodified, on the engine:
+    same output as built against the reference itself (tests/golden/make_examples_expected.py)"""
+    import json
+    exe = os.path.join(BIN, name)
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run __graft_entry__.build() where /root/reference is available")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    assert r.stdout == json.load(open(EXPECTED))[name]
+
+
+@pytest.mark.gpu
+def test_reference_ctc_benchmark_runs():
+    """benchmarks/ctc.cpp, unmodified (per-utterance calls from parallelMap threads, gathered by the
+    engine into batched launches): all five timings come out"""
+    import re
+    exe = os.path.join(BIN, "bm_ctc")
+    if not os.path.exists(exe):
+        pytest.fail(f"{exe} missing: run __graft_entry__.build() where /root/reference is available")
+    r = subprocess.run([exe, "16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    times = dict(re.findall(r"Timing (\w+) \.\.\.\s+([0-9.e+-]+) msec", r.stdout))
+    assert set(times) == {"ctcLoss", "ctcGrad", "ngramCtcLoss", "ngramCtcGrad", "ctcBatched"}, r.stdout
+    assert all(float(v) > 0 for v in times.values())

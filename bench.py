@@ -143,6 +143,85 @@ def unmodified_caller(B):
         return {"error": str(e)[:300]}
 
 
+def pin_to_gpu_numa_node(local_rank):
+    """One process per GPU: keep this rank's host threads (the engine's worker pool inherits the mask)
+    on the cores of the NUMA node its GPU hangs off.  Returns what it did, for the per-rank report."""
+    try:
+        import torch
+        bdf = torch.cuda.get_device_properties(local_rank).pci_bus_id.lower() \
+            if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
+        if not bdf:
+            return None
+        base = "/sys/bus/pci/devices/" + bdf
+        node = int(open(base + "/numa_node").read())
+        cpus = set()
+        for part in open(base + "/local_cpulist").read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"numa_node": node, "cpus": len(cpus)}
+    except Exception:
+        return None
+
+
+def per_rank_report(dist, torch, world, dev, host_ms, dt):
+    """every rank's host phases, wall time and host-thread budget, gathered on rank 0: what makes a
+    scaling run diagnosable (a slow rank, a starved host)"""
+    mine = [float(dt)] + [float(host_ms.get(k, 0.0)) for k in ("target_graphs", "emission_graphs", "intersect",
+                                                                   "forward_scores", "backward")] + \
+           [float(len(os.sched_getaffinity(0)))]
+    t = torch.tensor(mine, dtype=torch.float64, device=dev)
+    if world > 1:
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+    else:
+        parts = [t]
+    out = []
+    for r, p in enumerate(parts):
+        v = p.cpu().tolist()
+        out.append({"rank": r, "seconds": v[0], "host_ms_last_step": {"target_graphs": v[1], "emission_graphs": v[2],
+                    "intersect": v[3], "forward_scores": v[4], "backward": v[5]}, "host_threads": int(v[6])})
+    return out
+
+
+def dry_run(args, dist, torch, world, rank, dev):
+    """--dry-run-cpu: the collective / timing skeleton of main() over gloo, with a stand-in for the step
+    (losses = rank-tagged constants).  Nothing is measured; the line says so."""
+    from gtn_amd.distributed import max_over_ranks
+    B = args.batch
+    loss_dev = torch.full((B,), float(rank), dtype=torch.float32)
+    gathered = [torch.empty(B, dtype=torch.float32) for _ in range(world)] if world > 1 else None
+
+    def step():
+        if world > 1:
+            dist.all_gather(gathered, loss_dev)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt_local = time.perf_counter() - t0
+    dt = max_over_ranks(dt_local, dev)
+    ranks = per_rank_report(dist, torch, world, dev, {}, dt_local)
+    if rank == 0:
+        ok = gathered is None or all(float(g[0]) == float(r) for r, g in enumerate(gathered))
+        print(json.dumps({"metric": "CTC forward+backward losses/sec (T=%d, C=%d)" % (args.T, args.C), "value": None,
+                          "unit": "losses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "dry_run": True, "data": "none (stand-in step: collectives and timing skeleton only)",
+                          "gather_ok": bool(ok), "per_rank": ranks}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +235,9 @@ def main():
     ap.add_argument("--built-lattice", action="store_true",
                     help="also run the step with every lattice built (compose -> forwardScore kernel -> fused "
                          "backward) and report its kernels as built_lattice_path")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="no GPU: drive this script's multi-rank branch (rendezvous, all_gather of the losses, barrier, "
+                         "max-over-ranks timing, per-rank report) over gloo with a stand-in step -- tests/test_distributed_cpu.py")
     ap.add_argument("--config", choices=["c3", "c5"], default=None,
                     help="BASELINE.json configs: c3 = T 1000, C 256, U 100 (default); c5 = T 2000, C 1024, U 200")
     ap.add_argument("--no-unmodified-caller", action="store_true",
@@ -173,15 +255,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    dry = args.dry_run_cpu
+    numa = pin_to_gpu_numa_node(local) if (world > 1 and not dry) else None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        gtn.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    else:
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local)
+            gtn.set_device(local)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    elif not dry:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cpu") if dry else torch.device("cuda", local if world > 1 else 0)
     B, T, Cn, U = args.batch, args.T, args.C, args.U
+    if dry:
+        return dry_run(args, dist, torch, world, rank, dev)
 
     import graphgen as gg
     em, tg = gg.ctc_inputs(1234 + rank, B, T, Cn, U)
@@ -248,7 +337,7 @@ def main():
     for _ in range(args.steps):
         keep = step()
     fence()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     gtn.prof_enable(False)
     from gtn_amd.distributed import max_over_ranks
     dt = max_over_ranks(dt, dev)
@@ -363,6 +452,7 @@ def main():
                      "max_abs_grad_diff_vs_timed_path": gdiff}
         finally:
             os.environ.pop("GTNX_LAZY_COMPOSE", None)
+    ranks = per_rank_report(dist, torch, world, dev, host_ms or {}, dt_local)
     if rank == 0:
         losses = losses_timed
         out = {
@@ -393,6 +483,9 @@ def main():
             # with the sweep kernels the step is host-bound
             "host_ms_last_step": host_ms,
             "kernel_ms_per_step": {k: v["total_ms"] / args.steps for k, v in prof.items()},
+            # one entry per rank: its own wall time, host phases and host-thread budget (NUMA-pinned when N > 1)
+            "per_rank": ranks,
+            "numa": numa,
             "loss_mean": float(np.mean(losses)),
         }
         if world == 1 and not args.no_unmodified_caller:

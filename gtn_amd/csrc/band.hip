@@ -1092,6 +1092,143 @@ __global__ __launch_bounds__(512) void ctc_targets_kernel(const CtcTargetArgs* _
   if (m == N - 1 && a.n_arcs) a.n_arcs[0] = base + cnt[m];
 }
 
+// ==========================================================================================
+// viterbiScore / viterbiPath of chain o G (never built), G banded: the tropical recursion
+// shortest.cpp:86-170 / :190-272 would run over the product compose.cpp:377-522 builds, with
+// one back-pointer (which of the <= 3 in-arcs) per (time, node), the pointer chase and the
+// path's arcs in one launch.  Arithmetic as the reference's on the built lattice: a composed
+// arc weighs w_G + em (compose.cpp:431-434), a candidate is score(src) + weight, maxima are
+// exact -- so scores are bit-identical to the built path's.  Which of two EQUAL candidates wins
+// depends on the built lattice's node numbering (in-list order for viterbiScore, queue order
+// for viterbiPath); an exact tie between finite candidates only raises `tie`, and the host runs
+// that utterance through the built lattice instead (ops.cpp: band_viterbi).
+// One workgroup of 512 lanes per utterance (lane = node), emission rows staged through LDS.
+// ==========================================================================================
+__global__ __launch_bounds__(512) void band_viterbi_kernel(const BandDecode* __restrict__ pairs) {
+  const BandDecode P = pairs[blockIdx.x];
+  const int T = P.T, C = P.C, N = P.N, NS = P.NS;
+  extern __shared__ float lds[];
+  const float NINF = -__builtin_inff();
+  float* a0 = lds;               // [2 + 512] two pads in front: nodes -1 and -2
+  float* a1 = lds + 516;
+  float* stage = lds + 1032;     // emission rows / back-pointer rows
+  const int m = threadIdx.x;
+  const GTNX_G gtnx_i4* nodes = reinterpret_cast<const GTNX_G gtnx_i4*>(P.nodes);
+  int lab = 0;
+  float wi[3] = {NINF, NINF, NINF};
+  bool accept = false, start = false;
+  if (m < N) {
+    const gtnx_i4 q = nodes[m];
+    lab = q.x >= 0 ? q.x : 0;
+    const int a[3] = {q.y, q.z, q.w};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (a[k] >= 0) wi[k] = P.w ? P.w[a[k]] : 0.0f;
+    const uint8_t f = P.nflags[m];
+    start = (f & NF_START) != 0;
+    accept = (f & NF_ACCEPT) != 0;
+  }
+  if (m < 2) a0[m] = a1[m] = NINF;
+  a0[2 + m] = start ? 0.0f : NINF;  // shortest.cpp:201-207 (paths begin at start nodes, time 0)
+  a1[2 + m] = NINF;
+  int tie = 0;
+  const int R = max(1, min(64, P.stage_floats / C));  // emission rows per chunk
+  float* cur = a0;
+  float* nxt = a1;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += R) {
+    const int rows = min(R, T - t0);
+    for (int e = threadIdx.x; e < rows * C; e += blockDim.x) stage[e] = P.em[int64_t(t0) * C + e];
+    __syncthreads();
+    for (int i = 0; i < rows; ++i) {
+      const float e = stage[i * C + lab];
+      const float c0 = cur[2 + m] + (wi[0] + e), c1 = cur[1 + m] + (wi[1] + e), c2 = cur[m] + (wi[2] + e);
+      float best = c0;
+      int k = 0;
+      if (c1 > best) best = c1, k = 1;
+      if (c2 > best) best = c2, k = 2;
+      if (best > NINF && ((k != 0 && c0 == best) || (k != 1 && c1 == best) || (k != 2 && c2 == best))) tie = 1;
+      if (m < NS) P.bp[int64_t(t0 + i) * NS + m] = uint8_t(best > NINF ? k : 3);
+      nxt[2 + m] = m < N ? best : NINF;
+      __syncthreads();
+      float* sw = cur;
+      cur = nxt;
+      nxt = sw;
+    }
+  }
+  // the best accept node (shortest.cpp:153-167 / :233-244): block maximum, smallest node among equals
+  __shared__ float red_v[8];
+  __shared__ int red_m[8], s_best, s_tie;
+  float v = accept ? cur[2 + m] : NINF;
+  int bm = (m < N && accept && v > NINF) ? m : 1 << 30;
+  const float wmx = wave_max(v);
+  if (!(v == wmx)) bm = 1 << 30;
+  int cnt = (bm != (1 << 30)) ? 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) {
+    bm = min(bm, __shfl_xor(bm, o));
+    cnt += __shfl_xor(cnt, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red_v[threadIdx.x >> 6] = wmx;
+    red_m[threadIdx.x >> 6] = bm;
+  }
+  if (cnt > 1) tie = 1;
+  if (threadIdx.x == 0) s_tie = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float bv = NINF;
+    int bn = -1;
+    for (int w = 0; w < 8; ++w) {
+      if (red_m[w] == (1 << 30)) continue;
+      if (red_v[w] > bv) bv = red_v[w], bn = red_m[w];
+      else if (red_v[w] == bv && bv > NINF) s_tie = 1;
+    }
+    s_best = bn;
+    P.score[0] = bv;
+  }
+  if (tie) atomicOr(&s_tie, 1);
+  __syncthreads();
+  const int best = s_best;
+  if (threadIdx.x == 0) {
+    P.tie[0] = s_tie;
+    P.path_len[0] = best >= 0 ? T : -1;
+  }
+  if (best < 0 || T == 0) return;
+  // ---- chase the pointers, back-pointer rows staged through LDS (coalesced), one lane walking
+  uint8_t* bst = reinterpret_cast<uint8_t*>(stage);
+  const int RB = max(1, min(T, P.stage_floats * 4 / NS));
+  __shared__ int s_node;
+  if (threadIdx.x == 0) {
+    s_node = best;
+    P.pnode[T] = best;
+  }
+  for (int hi = T; hi > 0; hi -= RB) {
+    const int lo = max(0, hi - RB);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (hi - lo) * NS; e += blockDim.x) bst[e] = P.bp[int64_t(lo) * NS + e];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int node = s_node;
+      for (int t = hi - 1; t >= lo; --t) {
+        node -= bst[(t - lo) * NS + node] & 3;
+        P.pnode[t] = node;
+      }
+      s_node = node;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- the path's arcs: arc t enters node pnode[t+1] from pnode[t]
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const int m1 = P.pnode[t + 1], k = m1 - P.pnode[t];
+    const gtnx_i4 q = nodes[m1];
+    const int arc = k == 0 ? q.y : (k == 1 ? q.z : q.w);
+    P.path_arc[t] = arc;
+    P.path_lab[t] = q.x;
+    P.path_w[t] = (P.w ? P.w[arc] : 0.0f) + P.em[int64_t(t) * C + q.x];
+  }
+}
+
 template <class K>
 void big_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
@@ -1188,6 +1325,13 @@ void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int ma
     if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
     else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
   }
+}
+
+void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hipStream_t st) {
+  if (n <= 0) return;
+  static bool attr = (big_lds(band_viterbi_kernel), true);
+  (void)attr;
+  hipLaunchKernelGGL(band_viterbi_kernel, dim3(n), dim3(512), 4 * size_t(1032 + stage_floats) + 64, st, d_pairs);
 }
 
 void launch_ctc_targets(const CtcTargetArgs* d_args, int n, int blank, hipStream_t st) {

@@ -394,6 +394,24 @@ struct BandPair {
   int lgrn;                        // log2 of the rows per shift period of the forward launch
   int n_lab, pad;
 };
+// viterbiScore / viterbiPath of chain o (banded G): one workgroup per pair (band.hip)
+struct BandDecode {
+  const GTNX_G BandNode* nodes;  // [N]
+  const GTNX_G uint8_t* nflags;  // [N]
+  const GTNX_G float* w;         // G's weights (natural log), arc-id order; null: all zero
+  const GTNX_G float* em;        // [T][C]
+  GTNX_G uint8_t* bp;            // [T][NS] which in-arc won (0: from n, 1: n-1, 2: n-2; 3: none)
+  GTNX_G int* pnode;             // [T + 1] nodes of the best path
+  GTNX_G int* path_arc;          // [T] arcs of G along it, first-arc-first
+  GTNX_G int* path_lab;          // [T] matched labels
+  GTNX_G float* path_w;          // [T] weights of the product's arcs
+  GTNX_G int* path_len;          // [1] T, or -1 when no accepting path exists
+  GTNX_G float* score;           // [1]
+  GTNX_G int* tie;               // [1] an exact tie between finite candidates was seen
+  int N, T, C, NS;
+  int stage_floats, pad;         // LDS staging area of the launch (floats)
+};
+void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hipStream_t st);
 // one CTC target acceptor per label sequence, written as band records on the device (band.hip)
 struct CtcTargetArgs {
   const GTNX_G int* labels;   // [U]

@@ -2477,6 +2477,7 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
   return outs;
 }
 
+std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path);
 std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical) {
   if (!tropical && !getenv("GTNX_NO_LAZY_PAIRS")) {
     std::vector<Graph> br, pr, gr;
@@ -2496,6 +2497,24 @@ std::vector<Graph> lazy_shortest_distance(std::vector<Graph>& gs, bool tropical)
       }
       std::vector<Graph> po = pr.empty() ? std::vector<Graph>() : lazy_pair_forward_score(pr);
       for (size_t k = 0; k < pi.size(); ++k) outs[pi[k]] = std::move(po[k]);
+      if (!gr.empty()) {
+        std::vector<Graph> go = lazy_group_shortest_distance(gr, tropical);
+        for (size_t k = 0; k < gi.size(); ++k) outs[gi[k]] = std::move(go[k]);
+      }
+      return outs;
+    }
+  }
+  if (tropical && !getenv("GTNX_NO_BAND")) {  // banded partners: one launch per batch, back-pointers and all
+    std::vector<Graph> br, gr;
+    std::vector<size_t> bi, gi;
+    for (size_t i = 0; i < gs.size(); ++i) {
+      if (band_ok(*gs[i].s->lazy)) { br.push_back(gs[i]); bi.push_back(i); }
+      else { gr.push_back(gs[i]); gi.push_back(i); }
+    }
+    if (!br.empty()) {
+      std::vector<Graph> outs(gs.size(), Graph(false));
+      std::vector<Graph> bo = band_viterbi(br, false);
+      for (size_t k = 0; k < bi.size(); ++k) outs[bi[k]] = std::move(bo[k]);
       if (!gr.empty()) {
         std::vector<Graph> go = lazy_group_shortest_distance(gr, tropical);
         for (size_t k = 0; k < gi.size(); ++k) outs[gi[k]] = std::move(go[k]);
@@ -2553,7 +2572,239 @@ struct LazyPathOp : OpRecord {
   }
 };
 
+// ---- viterbiScore / viterbiPath of a symbolic chain o (banded G): band_viterbi_kernel
+// gradient of viterbiScore: the best path's arcs, d score each (shortest.cpp:64-81 on the built lattice)
+struct BandViterbiScoreOp : OpRecord {
+  struct Saved {
+    DevMemP mem;
+    const int *arc = nullptr, *lab = nullptr;
+    int len = -1, C = 0, chain_first = 0;
+  };
+  std::vector<Saved> saved;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    GradSink sink;
+    for (auto& m : ms) {
+      const Saved& sv = saved[m.idx];
+      Graph& comp = m.out.g->inputs[0];
+      comp.g->grad_propagated = true;
+      if (sv.len <= 0 || comp.g->inputs.size() != 2) continue;
+      Graph& chain = comp.g->inputs[sv.chain_first ? 0 : 1];
+      Graph& fixed = comp.g->inputs[sv.chain_first ? 1 : 0];
+      size_t bytes = 0;
+      const size_t oc = bytes;
+      if (chain.calc_grad()) bytes = align_up(bytes + 4 * size_t(chain.num_arcs()), 256);
+      const size_t of = bytes;
+      if (fixed.calc_grad()) bytes = align_up(bytes + 4 * size_t(fixed.num_arcs()), 256);
+      if (!bytes) continue;
+      DevMemP gm = rt.alloc_zero(bytes);
+      LazyPathGrad a{};
+      a.delta = grad_dev_ptr(m.out);
+      a.delta_stride = 0;
+      a.path_arc = sv.arc;
+      a.il = a.ol = sv.lab;  // the matched label either way
+      a.len = sv.len;
+      a.C = sv.C;
+      a.chain_first = sv.chain_first;
+      a.grad_chain = chain.calc_grad() ? gm->as<float>(oc) : nullptr;
+      a.grad_fixed = fixed.calc_grad() ? gm->as<float>(of) : nullptr;
+      launch_lazy_path_grad(a, rt.stream());
+      if (a.grad_chain) sink.add(chain, gm, a.grad_chain);
+      if (a.grad_fixed) sink.add(fixed, gm, a.grad_fixed);
+    }
+    sink.flush();
+  }
+};
+
+std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs);
+std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
+  Runtime& rt = Runtime::get();
+  const size_t n = gs.size();
+  std::vector<BandInfo*> bis;
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  std::vector<std::shared_ptr<BandInfo>> infos(n);
+  {
+    std::vector<Graph*> fx(n);
+    std::vector<uint8_t> cf(n);
+    for (size_t i = 0; i < n; ++i) {
+      fx[i] = &gs[i].s->lazy->fixed;
+      cf[i] = gs[i].s->lazy->chain_side == 1;
+    }
+    band_prepare(fx, cf);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    LazyProduct& lp = *gs[i].s->lazy;
+    band_ok(lp, &infos[i]);
+    bis.push_back(infos[i].get());
+    ss.push_back(lp.fixed.s.get());
+    if (!lp.fixed.w->is_all_zero()) ws.push_back(lp.fixed.w.get());
+    ws.push_back(lp.chain.w.get());
+  }
+  ensure_band_device_batch(bis, ss);
+  ensure_weights_device_batch(ws);
+  // per pair: back-pointers [T][NS] bytes | pnode [T+1] | path arc, label, weight [T] each | len, score, tie
+  size_t bytes = 0;
+  std::vector<size_t> o_bp(n), o_pn(n), o_pa(n), o_hd(n);
+  int max_c = 1;
+  for (size_t i = 0; i < n; ++i) {
+    const LazyProduct& lp = *gs[i].s->lazy;
+    const size_t T = size_t(lp.chain.s->M), N = size_t(lp.fixed.s->N);
+    const size_t ns = size_t(band_row_stride(int(N), band_npl(int(N))));
+    o_bp[i] = bytes;
+    bytes = align_up(bytes + T * ns + 1, 256);
+    o_pn[i] = bytes;
+    bytes = align_up(bytes + 4 * (T + 1), 256);
+    o_pa[i] = bytes;
+    bytes = align_up(bytes + 12 * (T ? T : 1), 256);
+    o_hd[i] = bytes;
+    bytes = align_up(bytes + 16, 256);
+    max_c = std::max(max_c, lp.chain.s->C);
+  }
+  DevMemP arena = rt.alloc(bytes);
+  const int stage_floats = std::max(4096, max_c);
+  std::vector<BandDecode> tab(n);
+  for (size_t i = 0; i < n; ++i) {
+    const LazyProduct& lp = *gs[i].s->lazy;
+    const BandInfo& b = *infos[i];
+    BandDecode& p = tab[i];
+    p = BandDecode{};
+    p.nodes = b.dev;
+    p.nflags = b.dev_flags;
+    p.w = lp.fixed.w->is_all_zero() ? nullptr : lp.fixed.w->dev;
+    p.em = lp.chain.w->dev;
+    p.N = int(lp.fixed.s->N);
+    p.T = lp.chain.s->M;
+    p.C = lp.chain.s->C;
+    p.NS = band_row_stride(p.N, band_npl(p.N));
+    p.bp = arena->as<uint8_t>(o_bp[i]);
+    p.pnode = arena->as<int>(o_pn[i]);
+    p.path_arc = arena->as<int>(o_pa[i]);
+    p.path_lab = p.path_arc + (p.T ? p.T : 1);
+    p.path_w = reinterpret_cast<float*>(p.path_lab + (p.T ? p.T : 1));
+    p.path_len = arena->as<int>(o_hd[i]);
+    p.score = reinterpret_cast<float*>(p.path_len + 1);
+    p.tie = p.path_len + 2;
+    p.stage_floats = stage_floats;
+  }
+  {
+    DevMemP d = upload_vec(tab);
+    GTNX_PROF(want_path ? "band_viterbi_path" : "band_viterbi_score", 0.0);
+    launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, rt.stream());
+  }
+  // heads (length, score, tie) of every pair; the paths themselves only when they become graphs
+  std::vector<char> host(bytes);
+  if (want_path) {
+    rt.d2h_sync(host.data(), arena->ptr, bytes);
+  } else {
+    DevMemP heads = rt.alloc(16 * n);
+    std::vector<AxpyArgs> ax;
+    for (size_t i = 0; i < n; ++i) ax.push_back({heads->as<float>(16 * i), reinterpret_cast<float*>(tab[i].path_len), 3, 1.0f});
+    DevMemP d = upload_vec(ax);
+    launch_axpy_batch(d->as<AxpyArgs>(), int(n), 3, /*copy*/ 2, rt.stream());
+    std::vector<char> hh(16 * n);
+    rt.d2h_sync(hh.data(), heads->ptr, 16 * n);
+    for (size_t i = 0; i < n; ++i) std::memcpy(host.data() + o_hd[i], hh.data() + 16 * i, 12);
+  }
+  std::vector<Graph> outs(n, Graph(false));
+  std::vector<size_t> tied;
+  std::shared_ptr<LazyPathOp> pop;
+  std::shared_ptr<BandViterbiScoreOp> sop;
+  if (want_path) {
+    pop = std::make_shared<LazyPathOp>();
+    pop->seq = next_seq();
+    pop->saved.resize(n);
+  } else {
+    sop = std::make_shared<BandViterbiScoreOp>();
+    sop->seq = next_seq();
+    sop->saved.resize(n);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const int* hd = reinterpret_cast<const int*>(host.data() + o_hd[i]);
+    const int len = hd[0];
+    if (hd[2] && len >= 0) {  // an exact tie: the built lattice decides (its node numbering breaks it)
+      tied.push_back(i);
+      continue;
+    }
+    LazyProduct& lp = *gs[i].s->lazy;
+    const int chain_first = lp.chain_side == 1;
+    if (want_path) {
+      Graph out = make_output(pop, int(i), {gs[i]});
+      if (len >= 0) {
+        const int* harc = reinterpret_cast<const int*>(host.data() + o_pa[i]);
+        const int* hlab = harc + (tab[i].T ? tab[i].T : 1);
+        const float* hw = reinterpret_cast<const float*>(hlab + (tab[i].T ? tab[i].T : 1));
+        // labels of the product's arcs: the chain's on its side, G's arc label on the other
+        lp.fixed.s->ensure_host();
+        std::vector<int> il, ol;
+        il.resize(size_t(len));
+        ol.resize(size_t(len));
+        for (int t = 0; t < len; ++t) {
+          il[size_t(t)] = chain_first ? hlab[t] : lp.fixed.s->il[size_t(harc[t])];
+          ol[size_t(t)] = chain_first ? lp.fixed.s->ol[size_t(harc[t])] : hlab[t];
+        }
+        fill_path_graph(out, len, true, il.data(), ol.data(), hw);
+        LazyPathOp::Saved& sv = pop->saved[i];
+        sv.arcs.assign(harc, harc + len);
+        sv.il = std::move(il);
+        sv.ol = std::move(ol);
+      }
+      pop->saved[i].C = tab[i].C;
+      pop->saved[i].chain_first = chain_first;
+      outs[i] = std::move(out);
+    } else {
+      Graph out = make_output(sop, int(i), {gs[i]});
+      init_scalar_result(out);
+      set_dev_weights(out, arena, tab[i].score, 1);
+      BandViterbiScoreOp::Saved& sv = sop->saved[i];
+      sv.mem = arena;
+      sv.arc = tab[i].path_arc;
+      sv.lab = tab[i].path_lab;
+      sv.len = len;
+      sv.C = tab[i].C;
+      sv.chain_first = chain_first;
+      outs[i] = std::move(out);
+    }
+  }
+  if (!tied.empty()) {
+    std::vector<Graph> tg;
+    for (size_t i : tied) {
+      // The lattice is built and its level schedule taken by replaying the reference's queue on it
+      // (graph.cpp: build_host_schedule, as for any host-built graph) instead of the id-order schedule a
+      // layered product normally gets for free: under exact ties the winner is the arc whose source left
+      // the queue first (shortest.cpp:212-227), and that order is not the node-id order.
+      realize(gs[i]);
+      gs[i].s->resolve_sizes();
+      gs[i].s->ensure_full();
+      gs[i].s->ensure_host();
+      gs[i].s->sched.reset();
+      tg.push_back(gs[i]);
+    }
+    std::vector<Graph> to = want_path ? op_viterbi_path(tg) : op_shortest_distance(tg, true);
+    for (size_t k = 0; k < tied.size(); ++k) outs[tied[k]] = std::move(to[k]);
+  }
+  return outs;
+}
+
 std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
+  if (!getenv("GTNX_NO_BAND")) {
+    std::vector<Graph> br, gr;
+    std::vector<size_t> bi, gi;
+    for (size_t i = 0; i < gs.size(); ++i) {
+      if (band_ok(*gs[i].s->lazy)) { br.push_back(gs[i]); bi.push_back(i); }
+      else { gr.push_back(gs[i]); gi.push_back(i); }
+    }
+    if (!br.empty()) {
+      std::vector<Graph> outs(gs.size(), Graph(false));
+      std::vector<Graph> bo = band_viterbi(br, true);
+      for (size_t k = 0; k < bi.size(); ++k) outs[bi[k]] = std::move(bo[k]);
+      if (!gr.empty()) {
+        std::vector<Graph> go = lazy_viterbi_path(gr);
+        for (size_t k = 0; k < gi.size(); ++k) outs[gi[k]] = std::move(go[k]);
+      }
+      return outs;
+    }
+  }
   Runtime& rt = Runtime::get();
   std::vector<std::pair<int, int>> slot;
   auto groups = lazy_forward(gs, SD_TROPICAL, slot);

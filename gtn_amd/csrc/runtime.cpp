@@ -68,8 +68,17 @@ void Runtime::set_device(int d) {
 }
 
 void Runtime::set_stream(hipStream_t s) {
-  sync();  // everything queued so far completes before buffers are reused on another stream
-  stream_ = s ? s : own_stream_;
+  hipStream_t next = s ? s : own_stream_;
+  if (next == stream_) return;  // (a loss called every step names the same stream every time)
+  // what was queued on the old stream is ordered before anything the new one gets: an event, not a
+  // host wait -- pooled buffers are handed out in enqueue order, which now spans both streams
+  drain_deferred();
+  hipEvent_t ev;
+  HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(ev, stream_));
+  HIP_CHECK(hipStreamWaitEvent(next, ev, 0));
+  HIP_CHECK(hipEventDestroy(ev));
+  stream_ = next;
 }
 
 void Runtime::sync() {

@@ -59,6 +59,8 @@ class _CTCLoss(torch.autograd.Function):
     def forward(ctx, log_probs, targets, blank, reduction):
         assert log_probs.is_cuda and log_probs.dtype == torch.float32 and log_probs.dim() == 3
         B, T, C = log_probs.shape
+        if len(targets) != B:
+            raise ValueError(f"ctc_loss: {len(targets)} target sequences for a batch of {B}")
         x = log_probs.contiguous()
         stream = torch.cuda.current_stream(x.device)
         gtn.set_stream(stream.cuda_stream if stream.cuda_stream else None)
@@ -136,6 +138,8 @@ class _ASGLoss(torch.autograd.Function):
         assert emissions.is_cuda and emissions.dtype == torch.float32 and emissions.dim() == 3
         B, T, N = emissions.shape
         assert transitions.shape == (N, N) and start.shape == (N,)
+        if len(targets) != B:
+            raise ValueError(f"asg_loss: {len(targets)} target sequences for a batch of {B}")
         lib = _native()
         if not lib:
             raise RuntimeError("asg_loss needs gtn_amd/lib/libgtn_criteria.so (run __graft_entry__.build())")

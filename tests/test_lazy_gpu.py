@@ -547,3 +547,87 @@ def test_band_kernels_extreme_dynamic_range(gtn):
         ok32 = np.isfinite(g32)
         err_ref = np.abs(g32[ok32] - g64[ok32]).max()
         assert np.abs(ge[b] - g64).max() <= max(2e-4, err_ref)
+
+
+def _oracle_viterbi(em, target, chain_first=False):
+    """viterbiScore, the best path's labels and the tropical gradients from the oracle, on the lattice the
+    reference would build (shortest.cpp:86-272 over compose.cpp:377-522)"""
+    T, C = em.shape
+    tgt = gg.ctc_target_graph(list(target))
+    a, b = OGraph.from_dict(tgt), OGraph.linear(T, C, em)
+    o = b.compose(a, "compose") if chain_first else a.compose(b, "intersect")
+    score = o.shortest_distance(tropical=True)
+    arcs, has = o.shortest_path()
+    d = o.to_dict()
+    labels = [d["il"][x] for x in arcs]
+    A1, A2 = (T * C, len(tgt["src"])) if chain_first else (len(tgt["src"]), T * C)
+    g1, g2 = o.compose_grad(o.shortest_distance_grad(tropical=True), A1, A2)
+    g_t, g_e = (g2, g1) if chain_first else (g1, g2)
+    return score, labels, has, np.asarray(g_e).reshape(T, C), np.asarray(g_t)
+
+
+@pytest.mark.parametrize("B,T,C,U,chain_first", [
+    (4, 60, 9, 7, False),
+    (3, 200, 64, 40, True),
+    (2, 300, 20, 140, False),   # 281-node targets: two nodes per lane on the sweeps, 512 lanes here
+    (2, 33, 300, 5, False),
+    (1, 1, 4, 1, False),
+])
+def test_band_viterbi_vs_oracle(gtn, B, T, C, U, chain_first):
+    """viterbiScore / viterbiPath of a SYMBOLIC CTC composition (band_viterbi_kernel: tropical sweep with
+    back-pointers, never built): scores bit-equal to the oracle's on the built lattice, path labels equal,
+    gradients of viterbiScore one-hot along the same path"""
+    import torch
+    rng = np.random.default_rng(T * 7 + C)
+    em = rng.normal(0, 2, (B, T, C)).astype(np.float32)
+    tg = [rng.integers(1, C, int(rng.integers(max(1, U // 2), U + 1))).tolist() for _ in range(B)]
+    prev = gtn.compose_mode(2)
+    try:
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t)) for t in tg]
+        comp = gtn.compose(ems, ctcs) if chain_first else gtn.intersect(ctcs, ems)
+        vs = gtn.viterbi_score(comp)
+        paths = gtn.viterbi_path(comp)
+        gtn.backward(vs)
+        got = gtn.items(vs)
+    finally:
+        gtn.compose_mode(prev)
+    for b in range(B):
+        score, labels, has, g_e, g_t = _oracle_viterbi(em[b], tg[b], chain_first)
+        if score is None or np.isinf(score):
+            assert np.isinf(got[b])
+            continue
+        assert got[b] == np.float32(score) or abs(got[b] - score) <= 1e-6 * abs(score)
+        assert paths[b].labels_to_list() == labels
+        assert abs(float(np.sum(paths[b].weights_to_numpy())) - score) <= 1e-3 * max(1.0, abs(score))
+        np.testing.assert_array_equal(ems[b].grad().weights_to_numpy().reshape(T, C), g_e)
+        np.testing.assert_array_equal(ctcs[b].grad().weights_to_numpy(), g_t)
+
+
+def test_band_viterbi_exact_ties_follow_the_reference(gtn):
+    """integer-valued emissions make exact ties: which arc wins then depends on the built lattice's node
+    numbering (in-list order for viterbiScore's gradient, queue order for viterbiPath) -- the kernel flags
+    the tie and the utterance runs through the built lattice, so labels and gradients are the oracle's"""
+    import torch
+    B, T, C = 5, 12, 5
+    rng = np.random.default_rng(3)
+    em = rng.integers(-1, 2, (B, T, C)).astype(np.float32)
+    em[0] = 0.0
+    tg = [[1, 2], [3, 3, 1], [4], [1, 2, 3, 4], [2, 2]]
+    prev = gtn.compose_mode(2)
+    try:
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t)) for t in tg]
+        comp = gtn.intersect(ctcs, ems)
+        paths = gtn.viterbi_path(comp)
+        ems2 = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        vs = gtn.viterbi_score(gtn.intersect(ctcs, ems2))
+        gtn.backward(vs)
+        got = gtn.items(vs)
+    finally:
+        gtn.compose_mode(prev)
+    for b in range(B):
+        score, labels, has, g_e, g_t = _oracle_viterbi(em[b], tg[b])
+        assert got[b] == np.float32(score)
+        assert paths[b].labels_to_list() == labels
+        np.testing.assert_array_equal(ems2[b].grad().weights_to_numpy().reshape(T, C), g_e)

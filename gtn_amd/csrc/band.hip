@@ -49,6 +49,7 @@ constexpr int BW = 256;  // lanes of one role: 4 sweeper waves + 4 helper waves 
 constexpr int WG = 512;
 constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
 constexpr int NBG = 7;   // blocks the backward sweep keeps: one landing, four in use, one being summed, one draining
+constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest of their chunk
 
 #ifdef GTNX_BAND_TIMING
 // diagnostic build (tools/ubench/band_bench.hip): cycles per phase of a tick, wave 0 of workgroup 0
@@ -321,7 +322,7 @@ __host__ __device__ inline BandLds band_lds(int C, int K, int NSmax, bool backwa
   L.CS = C + 4;
   int o = 0;
   L.o_ering = o;  // the backward sweep keeps a block's emissions until its gradient rows are out
-  o += (backward ? NBG : NBE) * K * L.CS;
+  o += (backward ? NBGE : NBE) * K * L.CS;
   o = (o + 3) & ~3;
   L.o_aring = o;  // alpha rows
   o += backward ? NBE * K * NSmax : 0;
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
   const BandLds L = band_lds(C, K, NSmax, true);
-  float* ering = lds + L.o_ering;  // [NBG blocks][K][CS]    emissions (kept until the block's gradient is out)
+  float* ering = lds + L.o_ering;  // [NBGE blocks][K][CS]   emissions (kept until the block's gradient is out)
   float* aring = lds + L.o_aring;  // [NBE blocks][K][NSmax] alpha rows
   float* oring = lds + L.o_oring;  // [NBG blocks][K][NSmax] node posteriors
   int* snode = reinterpret_cast<int*>(lds + L.o_snode);  // [n_lab] nodes sorted by (label, node)
@@ -750,7 +751,7 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
       gtnx_f4 v[NPL];
 #pragma unroll
       for (int q = 0; q < NPL; ++q) v[q] = *reinterpret_cast<const gtnx_f4*>(ob + min(256 * q + 4 * l, NSmax - 4));
-      const float em_hot = ering[((c % NBG) * K + r) * CS + max(P.hot, 0)];
+      const float em_hot = ering[((c % NBGE) * K + r) * CS + max(P.hot, 0)];
       const float ls_hot = lser[(c % NBG) * K + r];
       float all = 0.0f, hotp = 0.0f;
 #pragma unroll
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
       const int beta = tau - lag;
       if (beta >= 0 && beta < nblocks && !dead) {
         const int v0 = beta * K, rows = min(K, T - v0);
-        const float* eb = ering + (beta % NBG) * K * CS;
+        const float* eb = ering + (beta % NBGE) * K * CS;
         const float* ab = aring + (beta % NBE) * K * NSmax;
         const double* Ab = M.aofr + ((beta % NBE) * K) * 4 + w;
         float* ob = oring + (beta % NBG) * K * NSmax + m0;
@@ -928,16 +929,18 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
         af_s = ao[1 + ((T - 1 - c * K - min(l >> 2, rows - 1)) >> P.lgrn) * 4 + (l & 3)];
       }
     };
-    // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block
-    auto land = [&](int c) {
+    // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block.  A chunk lands in two
+    // halves a tick apart -- emissions during tick c-2 (their ring has a block to spare), alpha rows and
+    // the rows' scalars during tick c-1 -- so that no wave carries a whole chunk's landing in one tick:
+    // the landing wave was the critical path of a tick
+    auto land_em = [&](int c) {
       const int rows = rows_of(c);
       se.settle_all();
       sa.settle_all();
       asm volatile("" : "+v"(lse_s), "+v"(af_s));
       GTNX_TM(4);
       if (rows <= 0) return;
-      float* eb = ering + (c % NBG) * K * CS;
-      float* ab = aring + (c % NBE) * K * NSmax;
+      float* eb = ering + (c % NBGE) * K * CS;
       if constexpr (VEC) {
         se.each_vec(rows * C, (K - rows) * CS, l, [&](int, int o, gtnx_f4 q) {
           *reinterpret_cast<gtnx_f4*>(eb + o) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
@@ -947,16 +950,25 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
           eb[(rows - 1 - r) * CS + col] = em2(q.x);
         });
       }
+    };
+    auto land_rest = [&](int c) {
+      const int rows = rows_of(c);
+      sa.settle_all();
+      asm volatile("" : "+v"(lse_s), "+v"(af_s));
+      if (rows <= 0) return;
+      float* ab = aring + (c % NBE) * K * NSmax;
       sa.each_vec(rows * NS, (K - rows) * NSmax, l, [&](int, int o, gtnx_f4 q) { *reinterpret_cast<gtnx_f4*>(ab + o) = q; });
       if (l < rows) lser[(c % NBG) * K + rows - 1 - l] = lse_s;
       if (l < 4 * rows) M.aofr[((c % NBE) * K) * 4 + l] = af_s;
     };
-    // prologue: chunk 0 landed, chunks 1 .. 4 requested
+    // prologue: chunk 0 landed, the emissions of chunk 1 too, chunks 1 .. 4 requested
     issue(h);
     if (h == 0) {
-      land(0);
+      land_em(0);
+      land_rest(0);
       issue(4);
     }
+    if (h == 1) land_em(1);
     lds_barrier();
     // gradient rows of block c (every sweeper is through with it, its rows are summed): helper lane
     // cc GATHERS the posteriors of the nodes that carry label cc, adds the normaliser's softmax
@@ -985,7 +997,7 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
       const int rows = rows_of(c);
       if (!want_em || rows <= 0) return;
       const float* ob = oring + (c % NBG) * K * NSmax;
-      const float* eb = ering + (c % NBG) * K * CS;
+      const float* eb = ering + (c % NBGE) * K * CS;
       const float* lb = lser + (c % NBG) * K;
       const float* fb = rnorm + (c % NBG) * K;
       GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
@@ -1036,10 +1048,14 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
       // (landing first: its s_waitcnt vmcnt(0) also covers this wave's gradient stores -- stores count
       //  in vmcnt -- and the ones of the drain below would be a tick old instead of just issued)
       if (((tau + 1) & 3) == h) {  // uniform
-        land(tau + 1);
+        land_rest(tau + 1);
         GTNX_TM(1);
         issue(tau + 5);
         GTNX_TM(2);
+      }
+      if (((tau + 2) & 3) == h) {  // uniform
+        land_em(tau + 2);
+        GTNX_TM(1);
       }
       if (tau >= 5) drain(tau - 5);
       GTNX_TM(3);

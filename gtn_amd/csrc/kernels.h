@@ -324,6 +324,11 @@ struct LazyGroup {          // utterances that share one explicit graph G
   // by a few ulps of |score| over T steps, and normalising each time step by its own sum keeps
   // every step's posterior mass at 1 (the standard alpha-beta remedy).  Null: use `score`.
   const float* zt;
+  // matrix-core form of the dense regime (lazy.hip: lazy_mfma_*)
+  float* xt[2];               // [Kpad / 4][nbpad][4] the contraction input, exponentiated, in operand layout (two planes)
+  const float* Ep;            // [Kpad / 4][Npad2][4] E zero-padded
+  const float* ETp;           // [Kpad / 4][Npad2][4] its transpose
+  int Kpad, Npad2, nbpad;     // N rounded up to 4 / to 32; nb rounded up to 32
 };
 size_t lazy_step_lds_bytes(const LazyGroup& g);
 int lazy_tile_nodes();
@@ -439,6 +444,10 @@ void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream
 void launch_lazy_dense_step(const LazyGroup& g, int t, int backward, hipStream_t st, const float* vin = nullptr,
                             float* vout = nullptr);
 void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st);                   // R zero-filled
+void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st);                // Ep / ETp from E
+void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st);     // keys, first input (0 forward, 1 backward)
+void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st);
+void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // row-maximum keys -> floats
 
 // ---------------------------------------------------------------------------
 // small elementwise helpers

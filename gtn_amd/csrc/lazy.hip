@@ -545,6 +545,192 @@ __global__ __launch_bounds__(kDense) void lazy_dense_step_kernel(LazyGroup g, in
   }
 }
 
+
+// =====================================================================================
+// dense regime on the matrix cores.  The step above is a [nb x N] . [N x N] float32 product
+// per time step; this form runs it as v_mfma_f32_32x32x2_f32 tiles (exact float32: the same
+// fmaf chain as the VALU loop) with the exp / log epilogue fused:
+//   * the contraction input arrives ALREADY exponentiated and TRANSPOSED, X[k][b] = exp(x[b][k] -
+//     ref[b]) -- written by the previous step's epilogue -- so both MFMA operands are 128-byte
+//     coalesced rows (A: X[k][b0 ..], B: E[k][o0 ..]; E zero-padded, and transposed once for beta);
+//   * ref[b] is the row maximum ONE STEP BACK (complete when the launch starts), not of the row
+//     itself: the largest operand is then exp(one step's growth), not 1 -- harmless in float32 as
+//     long as a step moves a row's best score by less than ~80 nats, and no pass over the row is
+//     needed before exponentiating;
+//   * the true row maxima (the gradient kernels balance their factors around them) come out of
+//     the epilogues through an atomic max on an order-preserving integer key.
+// One wave per 32 x 32 output tile; 17 x 16 tiles at C4 keep 272 of the chip's 1024 SIMDs'
+// matrix cores busy for 257 MFMAs each.
+// =====================================================================================
+typedef float gtnx_f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ int fkey(float x) {
+  const int b = __float_as_int(x);
+  return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// Layout of both MFMA operands: [k / 4][column][k % 4] -- a lane's 16-byte load brings the four
+// consecutive k of ITS column (two MFMAs' worth), 32 lanes cover 512 contiguous bytes.
+// X_0 = exp(alpha[0]) (ref 0), amax key of row 0; or, backward, the input of step T-1:
+// q = beta[T] + em[T-1] + cmax, X = exp(q) (ref 0), bmax key of row T-1
+template <bool BWD>
+__global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
+  const int b = blockIdx.x, N = g.N;
+  float* X = g.xt[BWD ? (g.T & 1) : 0];
+  float m = NEG_INF;
+  for (int k = threadIdx.x; k < g.Kpad; k += blockDim.x) {
+    float v = NEG_INF;
+    if (k < N && b < g.nb) {
+      const uint8_t f = g.g.nflags[k];
+      if (!BWD) {
+        v = (f & NF_START) ? 0.0f : NEG_INF;
+      } else if ((f & NF_ACCEPT) && g.T > 0) {
+        const int lab = g.nlab[k];
+        v = lab < 0 ? NEG_INF : g.em[b][int64_t(g.T - 1) * g.C + lab] + g.cmax[k];
+      }
+    }
+    X[(int64_t(k >> 2) * g.nbpad + b) * 4 + (k & 3)] = v == NEG_INF ? 0.0f : __expf(v);
+    m = fmaxf(m, v);
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0 && b < g.nb) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    int* keys = reinterpret_cast<int*>(BWD ? g.bmax : g.amax);
+    if (!BWD) keys[b] = fkey(m);
+    else if (g.T > 0) keys[int64_t(g.T - 1) * g.nb + b] = fkey(m);
+  }
+}
+
+// one workgroup of four waves per 32 x 32 output tile: each wave runs a quarter of the contraction,
+// the four partial tiles are summed through LDS and each wave finishes eight of the tile's rows
+template <bool BWD>
+__global__ __launch_bounds__(256) void lazy_mfma_step_kernel(LazyGroup g, int t) {
+  __shared__ float part[4][16][64];
+  __shared__ float tr[32][36];
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
+  const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  const int nbp = g.nbpad, Np = g.Npad2;
+  const int N = g.N, C = g.C, nb = g.nb;
+  // FWD: step t turns alpha[t] (X in plane t & 1) into alpha[t+1] (plane (t+1) & 1)
+  // BWD: step t turns q[t] (plane (t+1) & 1) into beta[t] and q[t-1] (plane t & 1)
+  const gtnx_f4* X = reinterpret_cast<const gtnx_f4*>(g.xt[BWD ? ((t + 1) & 1) : (t & 1)]);
+  float* Xn = g.xt[BWD ? (t & 1) : ((t + 1) & 1)];
+  const gtnx_f4* Em = reinterpret_cast<const gtnx_f4*>(BWD ? g.ETp : g.Ep);
+  // the epilogue's per-row scalars are requested before the product starts: their latency hides under it
+  int* keys = reinterpret_cast<int*>(BWD ? g.bmax : g.amax);
+  const int64_t plane = int64_t(nb) * N;
+  const int o = o0 + lo;
+  const bool ocol = o < N;
+  const int lab = ocol ? g.nlab[o] : -1;
+  const float cm = ocol ? g.cmax[o] : NEG_INF;
+  const int te = BWD ? t - 1 : t;
+  const float* erow[4];
+  int k_in[4], k_out[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {  // this wave's rows after the reduction: 8 wv + v + 4 hi
+    const int b = b0 + 8 * wv + v + 4 * hi;
+    const int bb = b < nb ? b : 0;
+    erow[v] = g.em[bb];
+    // reference the input was exponentiated against / the one the next input will be
+    if (!BWD) k_in[v] = t > 0 ? keys[int64_t(t - 1) * nb + bb] : fkey(0.0f);
+    else k_in[v] = t < g.T - 1 ? keys[int64_t(t + 1) * nb + bb] : fkey(0.0f);
+    k_out[v] = keys[int64_t(t) * nb + bb];
+  }
+  float emv[4];
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int b = b0 + 8 * wv + v + 4 * hi;
+    emv[v] = (b < nb && lab >= 0 && te >= 0) ? erow[v][int64_t(te) * C + lab] : 0.0f;
+  }
+  // ---- this wave's quarter of the k groups (4 k each = two MFMAs), eight groups' operands in flight
+  const int groups = g.Kpad >> 2;
+  const int g_lo = (groups * wv) / 4, g_hi = (groups * (wv + 1)) / 4;
+  gtnx_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const gtnx_f4* ap = X + b0 + lo;
+  const gtnx_f4* bp = Em + o0 + lo;
+  auto mm = [&](const gtnx_f4& a, const gtnx_f4& b) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a.y : a.x, hi ? b.y : b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a.w : a.z, hi ? b.w : b.z, acc, 0, 0, 0);
+  };
+  int q = g_lo;
+  for (; q + 8 <= g_hi; q += 8) {
+    gtnx_f4 av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      av[u] = ap[int64_t(q + u) * nbp];
+      bv[u] = bp[int64_t(q + u) * Np];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) mm(av[u], bv[u]);
+  }
+  for (; q < g_hi; ++q) mm(ap[int64_t(q) * nbp], bp[int64_t(q) * Np]);
+#pragma unroll
+  for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
+  __syncthreads();
+  // ---- epilogue: registers 4 wv .. 4 wv + 3 of the summed tile: rows 8 wv + v + 4 hi, column lo
+  float* outp = BWD ? g.beta + int64_t(t) * plane : g.alpha + int64_t(t + 1) * plane;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int i = 8 * wv + v + 4 * hi;
+    const int b = b0 + i;
+    const bool on = b < nb;
+    const float a = (part[0][4 * wv + v][l] + part[1][4 * wv + v][l]) + (part[2][4 * wv + v][l] + part[3][4 * wv + v][l]);
+    const float m_in = funkey(k_in[v]), m_out = funkey(k_out[v]);
+    float val = NEG_INF, nxt = NEG_INF;  // alpha[t+1] / beta[t]; the next step's contraction input
+    if (on && ocol && a > 0.0f && m_in != NEG_INF) {
+      val = __logf(a) + m_in;
+      if (!BWD) {
+        val = lab < 0 ? NEG_INF : val + cm + emv[v];
+        nxt = val;
+      } else if (t >= 1 && lab >= 0) {
+        nxt = val + emv[v] + cm;
+      }
+    }
+    if (on && ocol) outp[int64_t(b) * N + o] = val;
+    // row maximum of the next input over this tile's 32 columns -> its key
+    float rm = nxt;
+#pragma unroll
+    for (int s = 16; s > 0; s >>= 1) rm = fmaxf(rm, __shfl_xor(rm, s, 32));
+    if (lo == 0 && on && rm != NEG_INF && (!BWD || t >= 1))
+      atomicMax(&keys[int64_t(BWD ? t - 1 : t + 1) * nb + b], fkey(rm));
+    tr[i][lo] = (nxt == NEG_INF || m_out == NEG_INF) ? 0.0f : __expf(nxt - m_out);
+  }
+  __syncthreads();
+  // the next input in operand layout: k group (o0 / 4 + kg), column b0 + bl: one 16-byte store per thread
+  if (!BWD || t >= 1) {
+    const int kg = threadIdx.x >> 5, bl = threadIdx.x & 31;  // 8 k groups x 32 columns
+    const int k = o0 + 4 * kg;
+    if (k < g.Kpad) {
+      gtnx_f4 w4;
+      w4.x = (k + 0 < N) ? tr[bl][4 * kg + 0] : 0.0f;
+      w4.y = (k + 1 < N) ? tr[bl][4 * kg + 1] : 0.0f;
+      w4.z = (k + 2 < N) ? tr[bl][4 * kg + 2] : 0.0f;
+      w4.w = (k + 3 < N) ? tr[bl][4 * kg + 3] : 0.0f;
+      reinterpret_cast<gtnx_f4*>(Xn)[int64_t(k >> 2) * nbp + b0 + bl] = w4;
+    }
+  }
+}
+
+// keys -> floats, once a pass is through
+__global__ void lazy_mfma_keys_kernel(float* p, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = funkey(__float_as_int(p[i]));
+}
+// E zero-padded in operand layout [k / 4][column][k % 4], and its transpose
+__global__ void lazy_mfma_pad_kernel(LazyGroup g, float* Ep, float* ETp) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= int64_t(g.Kpad) * g.Npad2) return;
+  const int k = int(i / g.Npad2), c = int(i % g.Npad2);
+  const bool in = k < g.N && c < g.N;
+  const int64_t at = (int64_t(k >> 2) * g.Npad2 + c) * 4 + (k & 3);
+  Ep[at] = in ? g.E[int64_t(k) * g.N + c] : 0.0f;
+  ETp[at] = in ? g.E[int64_t(c) * g.N + k] : 0.0f;
+}
+
 // R[s][d] += sum over a slice of (t, b) pairs of A'[s] * Q'[d], with the pair's two
 // factors balanced around c = amax + bmax - Z so that neither side over- or underflows:
 //   A' = exp(alpha[t][b][s] - amax + c/2),  Q' = exp(em + beta[t+1][b][d] - bmax + c/2) * delta
@@ -744,6 +930,29 @@ void launch_lazy_dense_step(const LazyGroup& g, int t, int backward, hipStream_t
   else
     hipLaunchKernelGGL(lazy_dense_step_kernel<false>, grid, dim3(kDense), 0, st, g, t, (const float*)nullptr,
                        (float*)nullptr);
+}
+
+void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st) {
+  const int64_t n = int64_t(g.Kpad) * g.Npad2;
+  hipLaunchKernelGGL(lazy_mfma_pad_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, g, const_cast<float*>(g.Ep),
+                     const_cast<float*>(g.ETp));
+}
+// which 0: before the forward steps (all keys "-inf", X_0); 1: before the backward steps
+void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st) {
+  const int64_t nk = int64_t(g.T + 1) * g.nb;
+  launch_fill_i32(reinterpret_cast<int*>(which ? g.bmax : g.amax), int(0x807fffff), size_t(nk), st);  // key of -inf
+  (void)hipMemsetAsync(g.xt[0], 0, sizeof(float) * size_t(g.Kpad) * size_t(g.nbpad), st);
+  (void)hipMemsetAsync(g.xt[1], 0, sizeof(float) * size_t(g.Kpad) * size_t(g.nbpad), st);
+  if (which) hipLaunchKernelGGL(lazy_mfma_init_kernel<true>, dim3(g.nbpad), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL(lazy_mfma_init_kernel<false>, dim3(g.nbpad), dim3(256), 0, st, g);
+}
+void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st) {
+  const dim3 grid(unsigned(g.Npad2 / 32), unsigned(g.nbpad / 32));
+  if (backward) hipLaunchKernelGGL(lazy_mfma_step_kernel<true>, grid, dim3(256), 0, st, g, t);
+  else hipLaunchKernelGGL(lazy_mfma_step_kernel<false>, grid, dim3(256), 0, st, g, t);
+}
+void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(lazy_mfma_keys_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, keys, n);
 }
 void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st) {
   if (g.N <= 0 || g.T <= 0 || g.nb <= 0 || !g.grad_fixed) return;

@@ -1741,6 +1741,7 @@ struct LazyGroupState {
   const int* node_label = nullptr;
   int max_in_deg = 0;
   bool dense = false;               // probability-domain products (lazy.hip "dense regime")
+  bool mfma = false;                // ... on the matrix cores (v_mfma_f32_32x32x2_f32)
   DevMemP dense_mem;
   Graph fixed;                      // keeps G alive
   std::vector<Graph> chains;        // per member
@@ -1871,13 +1872,24 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     };
     const size_t o_E = add(4 * nn), o_c = add(4 * size_t(v.N)), o_am = add(4 * size_t(v.T + 1) * size_t(v.nb)),
                  o_bm = add(4 * size_t(v.T + 1) * size_t(v.nb));
+    // matrix-core form (lazy.hip: lazy_mfma_*): padded E and its transpose, two transposed input planes
+    v.Kpad = (v.N + 3) & ~3;  // k groups of four (two MFMAs)
+    v.Npad2 = (v.N + 31) & ~31;
+    v.nbpad = (v.nb + 31) & ~31;
+    const size_t o_Ep = add(4 * size_t(v.Kpad) * size_t(v.Npad2)), o_ETp = add(4 * size_t(v.Kpad) * size_t(v.Npad2)),
+                 o_x0 = add(4 * size_t(v.Kpad) * size_t(v.nbpad)), o_x1 = add(4 * size_t(v.Kpad) * size_t(v.nbpad));
     st.dense_mem = rt.alloc(bytes);
     v.E = st.dense_mem->as<float>(o_E);
     v.cmax = st.dense_mem->as<float>(o_c);
     v.nlab = st.node_label;
     v.amax = st.dense_mem->as<float>(o_am);
     v.bmax = st.dense_mem->as<float>(o_bm);
+    v.Ep = st.dense_mem->as<float>(o_Ep);
+    v.ETp = st.dense_mem->as<float>(o_ETp);
+    v.xt[0] = st.dense_mem->as<float>(o_x0);
+    v.xt[1] = st.dense_mem->as<float>(o_x1);
     st.dense = true;
+    st.mfma = getenv("GTNX_DENSE_VALU") == nullptr;
   }
   // chain_first comes from the products themselves (same for a whole group by key)
   for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
@@ -1888,7 +1900,14 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     launch_lazy_init(st.view, 0, rt.stream());
     if (st.dense) {
       launch_lazy_dense_prep(st.view, const_cast<float*>(st.view.E), const_cast<float*>(st.view.cmax), rt.stream());
-      for (int t = 0; t < st.view.T; ++t) launch_lazy_dense_step(st.view, t, 0, rt.stream());
+      if (st.mfma) {
+        launch_lazy_mfma_prep(st.view, rt.stream());
+        launch_lazy_mfma_init(st.view, 0, rt.stream());
+        for (int t = 0; t < st.view.T; ++t) launch_lazy_mfma_step(st.view, t, 0, rt.stream());
+        launch_lazy_mfma_keys(st.view.amax, int64_t(st.view.T + 1) * st.view.nb, rt.stream());
+      } else {
+        for (int t = 0; t < st.view.T; ++t) launch_lazy_dense_step(st.view, t, 0, rt.stream());
+      }
     } else {
       for (int t = 0; t < st.view.T; ++t) launch_lazy_step(st.view, t, mode, 0, rt.stream());
     }
@@ -1971,7 +1990,11 @@ struct LazySdOp : OpRecord {
         v.beta = beta->as<float>();
         GTNX_PROF("lazy_forward_score_grad", 0.0);
         launch_lazy_init(v, 1, rt.stream());
-        if (st.dense) {
+        if (st.dense && st.mfma) {
+          launch_lazy_mfma_init(v, 1, rt.stream());
+          for (int t = T - 1; t >= 0; --t) launch_lazy_mfma_step(v, t, 1, rt.stream());
+          launch_lazy_mfma_keys(v.bmax, int64_t(T + 1) * nb, rt.stream());
+        } else if (st.dense) {
           DevMemP vs = rt.alloc(8 * plane);  // two planes: input of this step / of the next
           float* vb[2] = {vs->as<float>(), vs->as<float>() + plane};
           for (int t = T - 1; t >= 0; --t)

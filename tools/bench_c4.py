@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--T", type=int, default=1000)
     ap.add_argument("--C", type=int, default=512)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     import torch
     import gtn_amd as gtn
@@ -115,8 +116,70 @@ def main():
     lv = gtn.items(loss)
     out["asg_loss_mean"] = float(lv.mean())
     out["asg_loss_min"] = float(lv.min())  # a loss is a -log probability ratio: never negative
-    out["kernels"] = {n: gtn.prof_get(n) for n in gtn.prof_names() if n.startswith("lazy")}
+    # ---- roofline of the dominant kernel family: the dense-regime time steps on the matrix cores
+    # (lazy.hip: lazy_mfma_step_kernel, v_mfma_f32_32x32x2_f32).  Algorithmic work of one pass: T products
+    # [B x N] . [N x N] in float32 = 2 B N^2 T flops (N = C + 1 nodes of the transitions graph); hipEvent
+    # time of the whole pass (T launches) from the engine's profiler; peak = 157.3 TFLOP/s float32 MFMA
+    # (MI355X_MICROARCH.md)
+    gtn.prof_reset()
+    gtn.prof_enable(True)
+    trans.zero_grad()
+    ems = gtn.linear_graph_n(B, T, C, em)
+    fcc = gtn.forward_score(gtn.compose(ems, [trans]))
+    gtn.backward(fcc)
+    sync()
+    gtn.prof_enable(False)
+    prof = {n: gtn.prof_get(n) for n in gtn.prof_names() if n.startswith("lazy")}
+    out["kernels"] = prof
+    N = C + 1
+    flops = 2.0 * B * N * N * T
+    if prof.get("lazy_forward_score", {}).get("total_ms"):
+        ms = prof["lazy_forward_score"]["total_ms"]
+        tf = flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": "lazy_mfma_step_kernel<false> x T (+ prep)", "achieved": tf,
+                           "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+                           "ms_per_pass": ms, "flops_per_pass": flops}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(C)
     print(json.dumps(out))
+
+
+def cpu_baseline(C):
+    """the unmodified reference (oracle/_ref) on this host: forwardScore(compose(emissions, transitions)) +
+    backward for ONE utterance at T = 20 (the product has C^2 (T - 1) + C arcs: 5 M at C = 512; T = 1000 would
+    take minutes and ~20 GB per utterance), one thread -- reported per utterance and per product arc so that it
+    can be set against the full-size numbers above (262 M arcs per utterance)"""
+    import ctypes as Ct
+    path = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
+    if not os.path.exists(path):
+        return None
+    try:
+        import subprocess
+        code = (
+            "import os, sys, time, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import gtn_amd as gtn\n"
+            "C, T = %d, 20\n"
+            "rng = np.random.default_rng(0)\n"
+            "g = gtn.Graph(); n = np.arange(C)\n"
+            "g.add_nodes(np.array([1] + [0] * C, np.uint8), np.array([0] + [1] * C, np.uint8))\n"
+            "src = np.concatenate([np.zeros(C, np.int32), np.tile(n + 1, C).astype(np.int32)])\n"
+            "dst = np.concatenate([n + 1, np.repeat(n + 1, C)]).astype(np.int32)\n"
+            "lab = np.concatenate([n, np.repeat(n, C)]).astype(np.int32)\n"
+            "g.add_arcs(src, dst, lab, lab, rng.random(C * C + C).astype(np.float32))\n"
+            "e = gtn.linear_graph(T, C); e.set_weights((rng.random(T * C) * 10 - 5).astype(np.float32).tolist())\n"
+            "t0 = time.perf_counter(); f = gtn.forward_score(gtn.compose(e, g)); gtn.backward(f); dt = time.perf_counter() - t0\n"
+            "print(dt)\n" % (ROOT, C))
+        env = dict(os.environ, GTN_AMD_LIB=path)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        dt = float(r.stdout.strip().splitlines()[-1])
+        arcs = C * C * 19 + C
+        return {"kind": "reference", "cores": 1, "seconds_per_utterance_T20": dt, "product_arcs": arcs,
+                "ns_per_product_arc": dt / arcs * 1e9,
+                "sample": f"forwardScore(compose(emissions, transitions)) + backward of ONE utterance, T=20, C={C}, "
+                          "unmodified reference on one host thread; T=1000 extrapolates linearly in arcs"}
+    except Exception as e:
+        return {"error": str(e)[:200]}
 
 
 if __name__ == "__main__":

@@ -448,6 +448,7 @@ void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st);                /
 void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st);     // keys, first input (0 forward, 1 backward)
 void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st);
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // row-maximum keys -> floats
+void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x T x nb */, hipStream_t st);  // R zero-filled
 
 // ---------------------------------------------------------------------------
 // small elementwise helpers

@@ -791,6 +791,87 @@ __global__ __launch_bounds__(kDense) void lazy_dense_fixed_grad_kernel(LazyGroup
       if (s < N && d < N && acc[i][j] != 0.0f) atomicAdd(&g.R[int64_t(s) * N + d], acc[i][j]);
     }
 }
+
+// ---- gradient of G's arcs on the matrix cores: R[s][d] += sum over (t, utterance) pairs of
+// A'[pair][s] * Q'[pair][d] is a product with the PAIRS as the contraction index, and both factors
+// lie in HBM pair-major (alpha[t][b][.], beta[t+1][b][.]): the MFMA operand rows are the planes' own
+// rows, exponentiated on the way in (two v_exp_f32 per MFMA, under its 64 cycles).
+// per-pair constants once: {half - amax, half - bmax, delta, valid}, half = (amax + bmax - Z) / 2
+__global__ void lazy_mfma_pairs_kernel(LazyGroup g, gtnx_f4* pc) {
+  const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (p >= int64_t(g.T) * g.nb) return;
+  const int b = int(p % g.nb);
+  const float z = g.zt ? g.zt[p] : g.score[b];
+  const float am = g.amax[p], bm = g.bmax[p];
+  gtnx_f4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (z != NEG_INF && z != -NEG_INF && am != NEG_INF && bm != NEG_INF) {
+    const float half = 0.5f * (am + bm - z);
+    c = gtnx_f4{half - am, half - bm, *g.delta[b], 1.0f};
+  }
+  pc[p] = c;
+}
+
+__global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_kernel(LazyGroup g, const gtnx_f4* __restrict__ pc,
+                                                                  int pairs_per_block) {
+  __shared__ float part[4][16][64];
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
+  const int s0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
+  const int N = g.N, C = g.C, nb = g.nb;
+  const int64_t plane = int64_t(nb) * N;
+  const int64_t npairs = int64_t(g.T) * nb;
+  const int64_t p0 = int64_t(blockIdx.z) * pairs_per_block, p1 = min(npairs, p0 + pairs_per_block);
+  const int s = s0 + lo, d = d0 + lo;
+  const bool sok = s < N;
+  const int lab = d < N ? g.nlab[d] : -1;
+  gtnx_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // wave wv takes the pairs p0 + 2 wv + hi, + 8, + 16, ...: one MFMA contracts two pairs.  (t, b) of a
+  // lane's pair advance incrementally (no division in the loop); loads are unconditional (clamped) so
+  // that four MFMAs' operands are in flight together
+  const int sc = sok ? s : N - 1, dc = d < N ? d : N - 1, labc = lab >= 0 ? lab : 0;
+  int pp = int(p0) + 2 * wv + hi;
+  int t = pp / nb, b = pp - t * nb;
+  const int pend = int(p1), plast = int(npairs) - 1;
+  for (; pp - hi < pend; ) {
+    float al[4], be[4], ev[4];
+    gtnx_f4 c[4];
+    int tt = t, bb = b, pq = pp;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = pq < pend;
+      const int tc = in ? tt : 0, bc = in ? bb : 0;
+      c[u] = pc[in ? pq : plast];
+      if (!in) c[u].w = 0.0f;
+      al[u] = g.alpha[int64_t(tc) * plane + int64_t(bc) * N + sc];
+      be[u] = g.beta[int64_t(tc + 1) * plane + int64_t(bc) * N + dc];
+      ev[u] = g.em[bc][int64_t(tc) * C + labc];
+      pq += 8;
+      bb += 8;
+      while (bb >= nb) {
+        bb -= nb;
+        ++tt;
+      }
+    }
+    t = tt;
+    b = bb;
+    pp = pq;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool on = c[u].w != 0.0f;
+      const float a = (on && sok && al[u] != NEG_INF) ? __expf(al[u] + c[u].x) : 0.0f;
+      const float bq = (on && lab >= 0 && be[u] != NEG_INF) ? __expf(ev[u] + be[u] + c[u].y) * c[u].z : 0.0f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int i = 8 * wv + v + 4 * hi;  // row (source node) of register 4 wv + v
+    const float a = (part[0][4 * wv + v][l] + part[1][4 * wv + v][l]) + (part[2][4 * wv + v][l] + part[3][4 * wv + v][l]);
+    if (s0 + i < N && d < N && a != 0.0f) atomicAdd(&g.R[int64_t(s0 + i) * N + d], a);
+  }
+}
 // grad[a] += exp(w[a]) * R[src][dst]  (the balancing shifts of A' and Q' cancel exactly:
 // A' * Q' = exp(alpha + em + beta - Z) * delta)
 __global__ void lazy_dense_arc_grad_kernel(LazyGroup g) {
@@ -953,6 +1034,16 @@ void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t 
 }
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(lazy_mfma_keys_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, keys, n);
+}
+void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStream_t st) {
+  if (g.N <= 0 || g.T <= 0 || g.nb <= 0 || !g.grad_fixed) return;
+  const int64_t npairs = int64_t(g.T) * g.nb;
+  gtnx_f4* pc = static_cast<gtnx_f4*>(pair_consts);
+  hipLaunchKernelGGL(lazy_mfma_pairs_kernel, dim3(unsigned((npairs + 255) / 256)), dim3(256), 0, st, g, pc);
+  const int pairs_per_block = 16384;
+  const dim3 grid(unsigned((g.N + 31) / 32), unsigned((g.N + 31) / 32), unsigned((npairs + pairs_per_block - 1) / pairs_per_block));
+  hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
+  if (g.g.A > 0) hipLaunchKernelGGL(lazy_dense_arc_grad_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g);
 }
 void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st) {
   if (g.N <= 0 || g.T <= 0 || g.nb <= 0 || !g.grad_fixed) return;

@@ -2018,7 +2018,12 @@ struct LazySdOp : OpRecord {
         if (want_fixed && st.dense) {
           DevMemP rmem = rt.alloc_zero(4 * size_t(N) * size_t(N));
           v.R = rmem->as<float>();
-          launch_lazy_dense_fixed_grad(v, rt.stream());
+          if (st.mfma) {
+            DevMemP pcm = rt.alloc(16 * size_t(T > 0 ? T : 1) * size_t(nb));
+            launch_lazy_mfma_fixed_grad(v, pcm->ptr, rt.stream());
+          } else {
+            launch_lazy_dense_fixed_grad(v, rt.stream());
+          }
         } else if (want_fixed) {
           const size_t lds = lazy_step_lds_bytes(v) + 4 * size_t(lazy_tile_nodes()) * size_t(st.max_in_deg);
           if (lds > size_t(lazy_lds_limit()))

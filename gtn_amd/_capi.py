@@ -104,6 +104,7 @@ _SIGS = {
     "gtnx_grads_bind_device_n": [c_graph_p, C.c_int, C.c_void_p, C.c_void_p],
     "gtnx_batch_from_graphs": [c_graph_p, C.c_int, c_graph_p],
     "gtnx_batch_ctc_targets": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_graph_p],
+    "gtnx_batch_asg_force_align": [C.c_void_p, C.c_void_p, C.c_int, c_graph, C.c_int, c_graph_p],
     "gtnx_batch_linear": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, c_graph_p],
     "gtnx_batch_destroy": [c_graph],
     "gtnx_batch_size": [c_graph, c_i32_p],

@@ -665,6 +665,18 @@ def make_api(lib):
             return cls._from_handle(h.value)
 
         @classmethod
+        def asg_force_align(cls, targets, transitions, n_labels):
+            """compose(forceAlign(target), transitions) of examples/asg.cpp:50-68 for every label sequence, built on
+            the device; `transitions`: a Graph in the arc layout of examples/asg.cpp:36-47 over n_labels labels"""
+            lens = np.asarray([len(t) for t in targets], dtype=np.int32)
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(t, dtype=np.int32).reshape(-1) for t in targets])
+                                        if len(targets) else np.zeros(0, np.int32), dtype=np.int32)
+            h = C.c_void_p()
+            check(lib.gtnx_batch_asg_force_align(flat.ctypes.data, lens.ctypes.data, len(lens), transitions._h,
+                                                 int(n_labels), C.byref(h)))
+            return cls._from_handle(h.value)
+
+        @classmethod
         def linear(cls, B, M, N, device_weights, calc_grad=True, borrow=False):
             """B linear graphs over one device tensor [B, M, N]; borrow: read in place"""
             h = C.c_void_p()

@@ -50,13 +50,7 @@ extern "C" __attribute__((visibility("default"))) int gtn_asg_loss_n(const void*
     trans.setCalcGrad(grad_trans != nullptr);
     trans.zeroGrad();
     trans.setWeightsDevice(trans_w);  // arc ids are creation order: arcSort permutes lists, not ids
-    std::vector<std::vector<int>> tg(B);
-    size_t o = 0;
-    for (int b = 0; b < B; ++b) {
-      tg[b].assign(targets + o, targets + o + lengths[b]);
-      o += size_t(lengths[b]);
-    }
-    gtn::criteria::asgLossBatch(emissions, tg, T, N, trans, loss, grad_em);
+    gtn::criteria::asgLossBatch(emissions, targets, lengths, B, T, N, trans, loss, grad_em);
     if (grad_trans) {
       gtnx_graph_t h = trans.handle();
       int64_t off = 0;

@@ -1245,6 +1245,50 @@ __global__ __launch_bounds__(512) void band_viterbi_kernel(const BandDecode* __r
   }
 }
 
+// Force-alignment acceptors composed with an ASG transitions graph, as band records: what
+// compose(forceAlign(target), transitions) of examples/asg.cpp:50-68 builds -- a chain of U + 1
+// nodes, node m carrying label l_m, arc 2m-2 the step m-1 -> m and arc 2m-1 the self-loop at m (the
+// reference's compose numbers them in this order) -- with the arcs' weights GATHERED from the
+// transitions' weights (asgTransitions layout: arc i = <s> -> label i, arc N + i N + j = label j ->
+// label i) and the map arc -> transitions arc kept for the gradient's way back.
+__global__ __launch_bounds__(512) void asg_fal_targets_kernel(const AsgFalArgs* __restrict__ args, int NL) {
+  const AsgFalArgs a = args[blockIdx.x];
+  __shared__ int lab[512];
+  const int U = a.U, m = threadIdx.x;  // nodes 0 .. U
+  int my = -1;
+  if (m >= 1 && m <= U) my = a.labels[m - 1];
+  lab[m] = my;
+  __syncthreads();
+  if (m > U) return;
+  GTNX_G BandNode* nd = const_cast<GTNX_G BandNode*>(a.nodes);
+  nd[m].lab = my;
+  nd[m].aid[0] = m >= 1 ? 2 * m - 1 : -1;
+  nd[m].aid[1] = m >= 1 ? 2 * m - 2 : -1;
+  nd[m].aid[2] = -1;
+  a.nflags[m] = uint8_t((m == 0 ? NF_START : 0) | (m == U ? NF_ACCEPT : 0));
+  if (m >= 1) {
+    int rank = 0;
+    for (int o = 1; o <= U; ++o) {
+      const int lo = lab[o];
+      rank += (lo < my || (lo == my && o < m)) ? 1 : 0;
+    }
+    a.snode[rank] = m;
+    a.slab[rank] = my;
+    const int step = m == 1 ? my : NL + my * NL + lab[m - 1];
+    const int self = NL + my * NL + my;
+    a.arc_map[2 * m - 2] = step;
+    a.arc_map[2 * m - 1] = self;
+    a.w[2 * m - 2] = a.trans_w[step];
+    a.w[2 * m - 1] = a.trans_w[self];
+  }
+}
+// d loss / d transitions: every force-alignment arc hands its gradient to the transitions arc it came from
+__global__ void asg_fal_scatter_kernel(const float* __restrict__ g, const int* __restrict__ arc_map, int64_t n,
+                                       float* __restrict__ trans_grad) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n && arc_map[i] >= 0 && g[i] != 0.0f) atomicAdd(trans_grad + arc_map[i], g[i]);
+}
+
 template <class K>
 void big_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
@@ -1350,6 +1394,12 @@ void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hip
   hipLaunchKernelGGL(band_viterbi_kernel, dim3(n), dim3(512), 4 * size_t(1032 + stage_floats) + 64, st, d_pairs);
 }
 
+void launch_asg_fal_targets(const AsgFalArgs* d_args, int n, int n_labels, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(asg_fal_targets_kernel, dim3(n), dim3(512), 0, st, d_args, n_labels);
+}
+void launch_asg_fal_scatter(const float* g, const int* arc_map, int64_t n, float* trans_grad, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(asg_fal_scatter_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, g, arc_map, n, trans_grad);
+}
 void launch_ctc_targets(const CtcTargetArgs* d_args, int n, int blank, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(ctc_targets_kernel, dim3(n), dim3(512), 0, st, d_args, blank);
 }

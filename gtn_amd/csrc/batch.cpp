@@ -173,7 +173,7 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
       p.norm = nullptr;
       p.grad_em = ge.ptr ? ge.ptr + size_t(b) * A : nullptr;
       p.grad_fixed = gf.ptr ? gf.ptr + fx.g_off[size_t(b)] : nullptr;
-      tab.push_back({BandLaunchKey{p.C, band_npl(p.N), 1, p.grad_fixed ? 1 : 0, band_vec_ok(p)}, p});
+      tab.push_back({BandLaunchKey{p.C, band_npl(p.N), fx.fal ? 0 : 1, p.grad_fixed ? 1 : 0, band_vec_ok(p)}, p});
       bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
                (p.grad_fixed ? 4.0 * double(fx.elem_size(b)) : 0.0);
     }
@@ -187,13 +187,50 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
   }
 };
 
+
+// the force-alignment acceptors were cut out of the transitions graph: their arc gradients go back into it
+struct BFalOp : BatchOp {
+  void backward(Batch& out) override {
+    Graph& tr = out.trans;
+    if (!tr.calc_grad() || !out.g_dev) return;
+    Runtime& rt = Runtime::get();
+    const int64_t A = tr.num_arcs();
+    DevMemP gm = rt.alloc_zero(sizeof(float) * size_t(A ? A : 1));
+    for (int b = 0; b < out.n; ++b) {
+      const int64_t len = out.g_off[size_t(b) + 1] - out.g_off[size_t(b)];
+      launch_asg_fal_scatter(out.g_dev + out.g_off[size_t(b)], out.rec_mem->as<int>(out.map_off[size_t(b)]), len, gm->as<float>(),
+                             rt.stream());
+    }
+    tr.add_grad_device(gm, gm->as<float>(), /*adopt=*/true);  // (accumulates when the graph holds a gradient already)
+  }
+};
+
+// scalar graphs (results of the per-graph functions) taken into a batch expression: forward gathers their
+// values, backward hands every graph its own delta and runs the per-graph tape from there
+struct BFromGraphsOp : BatchOp {
+  void backward(Batch& out) override {
+    Batch& src = *inputs[0];
+    std::vector<Graph> roots;
+    for (int b = 0; b < src.n; ++b) {
+      Graph& r = src.graphs[size_t(b)];
+      if (!r.calc_grad()) continue;
+      r.add_grad_device(out.g_mem, out.g_dev + b, /*adopt=*/true);
+      roots.push_back(r);
+    }
+    if (!roots.empty()) op_backward(roots, nullptr, retain, /*seed=*/false);
+  }
+  bool retain = false;
+};
+
 }  // namespace
 
 int64_t Batch::elem_size(int b) const {
   switch (kind) {
     case SCALAR: return 1;
     case LINEAR: return int64_t(M) * C;
-    case CTC_TARGETS: return 3 * int64_t(2 * (lab_off[size_t(b) + 1] - lab_off[size_t(b)]) + 1);
+    case CTC_TARGETS:
+      if (fal) return 2 * int64_t(lab_off[size_t(b) + 1] - lab_off[size_t(b)]);
+      return 3 * int64_t(2 * (lab_off[size_t(b) + 1] - lab_off[size_t(b)]) + 1);
     default: return 0;
   }
 }
@@ -300,6 +337,87 @@ BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank
   return b;
 }
 
+
+BatchP batch_asg_force_align(const int* labels, const int* lengths, int n, Graph& transitions, int n_labels) {
+  if (n < 0) throw_invalid("[gtnx_batch_asg_force_align] negative batch size");
+  // the arc layout the gather relies on (gtn_amd/criteria/asg_criterion.h: asgTransitions; examples/asg.cpp:36-47)
+  if (transitions.num_nodes() != int64_t(n_labels) + 1 || transitions.num_arcs() != int64_t(n_labels) * (n_labels + 1))
+    throw_invalid("[gtnx_batch_asg_force_align] the transitions graph must have the asgTransitions(N) layout");
+  BatchP b = make_batch(Batch::CTC_TARGETS, n, transitions.calc_grad());
+  b->fal = true;
+  b->trans = transitions;
+  b->trans_labels = n_labels;
+  b->lab_off.resize(size_t(n) + 1);
+  b->lab_off[0] = 0;
+  int max_u = 0;
+  for (int i = 0; i < n; ++i) {
+    if (lengths[i] < 0) throw_invalid("[gtnx_batch_asg_force_align] negative length");
+    b->lab_off[size_t(i) + 1] = b->lab_off[size_t(i)] + lengths[i];
+    max_u = std::max(max_u, lengths[i]);
+  }
+  b->max_nodes = max_u + 1;
+  const size_t total = size_t(b->lab_off[size_t(n)]);
+  b->labels.assign(labels, labels + total);
+  int mn = 0;
+  for (size_t i = 0; i < total; ++i) {
+    b->max_label = std::max(b->max_label, labels[i]);
+    mn = std::min(mn, labels[i]);
+  }
+  if (mn < 0 || b->max_label >= n_labels || b->max_nodes > band_max_nodes() || n == 0) {
+    b->kind = Batch::GRAPHS;  // labels outside the transitions / too long for a workgroup: the per-graph way
+    batch_materialise(*b);
+    return b;
+  }
+  Runtime& rt = Runtime::get();
+  std::vector<Weights*> ws{transitions.w.get()};
+  ensure_weights_device_batch(ws);
+  size_t bytes = align_up(sizeof(int) * (total ? total : 1), 256);
+  b->rec_off.resize(size_t(n));
+  b->w_off.resize(size_t(n));
+  b->map_off.resize(size_t(n));
+  for (int i = 0; i < n; ++i) {
+    const size_t N = size_t(lengths[i]) + 1, A = 2 * size_t(lengths[i]);
+    b->rec_off[size_t(i)] = bytes;
+    bytes += align_up(sizeof(BandNode) * N, 64) + align_up(N, 64) + 2 * align_up(4 * N, 64);
+    b->w_off[size_t(i)] = bytes;
+    bytes += align_up(4 * (A ? A : 1), 64);
+    b->map_off[size_t(i)] = bytes;
+    bytes += align_up(4 * (A ? A : 1), 64);
+  }
+  b->rec_mem = rt.alloc(bytes);
+  {
+    PinnedMemP pin = rt.alloc_pinned(sizeof(int) * (total ? total : 1));
+    std::memcpy(pin->ptr, labels, sizeof(int) * total);
+    rt.h2d(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
+  }
+  std::vector<AsgFalArgs> args;
+  args.resize(size_t(n));
+  for (int i = 0; i < n; ++i) {
+    const size_t N = size_t(lengths[i]) + 1;
+    char* base = b->rec_mem->as<char>(b->rec_off[size_t(i)]);
+    AsgFalArgs& a = args[size_t(i)];
+    a.labels = b->rec_mem->as<int>() + b->lab_off[size_t(i)];
+    a.trans_w = transitions.w->dev;
+    a.nodes = reinterpret_cast<BandNode*>(base);
+    base += align_up(sizeof(BandNode) * N, 64);
+    a.nflags = reinterpret_cast<uint8_t*>(base);
+    base += align_up(N, 64);
+    a.snode = reinterpret_cast<int*>(base);
+    base += align_up(4 * N, 64);
+    a.slab = reinterpret_cast<int*>(base);
+    a.w = b->rec_mem->as<float>(b->w_off[size_t(i)]);
+    a.arc_map = b->rec_mem->as<int>(b->map_off[size_t(i)]);
+    a.U = lengths[i];
+    a.pad = 0;
+  }
+  DevMemP d = upload_vec(args);
+  launch_asg_fal_targets(d->as<AsgFalArgs>(), n, n_labels, rt.stream());
+  auto op = std::make_shared<BFalOp>();
+  op->seq = g_batch_seq.fetch_add(1);
+  b->op = op;  // (its one input, the transitions graph, is an ordinary graph: kept in `trans`)
+  return b;
+}
+
 BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool borrow) {
   if (n < 0 || M < 0 || C < 0) throw_invalid("[gtnx_batch_linear] negative size");
   Runtime& rt = Runtime::get();
@@ -324,10 +442,28 @@ BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool b
 void batch_materialise(Batch& x) {
   if (x.materialised) return;
   std::vector<Graph> gs;
-  switch (x.kind) {
+  switch (x.fal && x.kind == Batch::GRAPHS ? Batch::CTC_TARGETS : x.kind) {
     case Batch::GRAPHS: break;
     case Batch::CTC_TARGETS:
       gs.reserve(size_t(x.n));
+      if (x.fal) {  // compose(forceAlign(target), transitions), examples/asg.cpp:50-68
+        std::vector<Graph> fals;
+        for (int i = 0; i < x.n; ++i) {
+          const int* t = x.labels.data() + x.lab_off[size_t(i)];
+          const int U = x.lab_off[size_t(i) + 1] - x.lab_off[size_t(i)];
+          Graph f(false);
+          f.add_node(true, U == 0);
+          for (int l = 1; l <= U; ++l) {
+            f.add_node(false, l == U);
+            f.add_arc(l - 1, l, t[l - 1], t[l - 1], 0.0f);
+            f.add_arc(l, l, t[l - 1], t[l - 1], 0.0f);
+          }
+          fals.push_back(std::move(f));
+        }
+        std::vector<Graph> tr{x.trans};
+        gs = op_compose(fals, tr, false);
+        break;
+      }
       for (int i = 0; i < x.n; ++i)
         gs.push_back(ctc_target_graph_host(x.labels.data() + x.lab_off[size_t(i)],
                                            x.lab_off[size_t(i) + 1] - x.lab_off[size_t(i)], x.blank, x.calc_grad));
@@ -394,10 +530,10 @@ void batch_materialise(Batch& x) {
       break;
     }
   }
-  if (x.kind != Batch::GRAPHS) x.graphs = std::move(gs);
+  if (x.kind != Batch::GRAPHS || x.fal) x.graphs = std::move(gs);
   x.materialised = true;
   // what the batch-level backward already produced moves into the element graphs
-  if (x.g_dev && (x.kind == Batch::CTC_TARGETS || x.kind == Batch::LINEAR)) {
+  if (x.g_dev && ((x.kind == Batch::CTC_TARGETS && !x.fal) || x.kind == Batch::LINEAR)) {
     for (int i = 0; i < x.n; ++i) x.graphs[size_t(i)].add_grad_device(x.g_mem, x.g_dev + x.g_off[size_t(i)], true);
     x.g_dev = nullptr;  // (the graphs hold the block now)
     x.g_mem.reset();
@@ -453,7 +589,8 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
     oo.resize(size_t(n));
     ao.resize(size_t(n));
     for (int b = 0; b < n; ++b) {
-      const int N = 2 * (fx.lab_off[size_t(b) + 1] - fx.lab_off[size_t(b)]) + 1;
+      const int Ub = fx.lab_off[size_t(b) + 1] - fx.lab_off[size_t(b)];
+      const int N = fx.fal ? Ub + 1 : 2 * Ub + 1;
       const int ns = band_row_stride(N, band_npl(N));
       oo[size_t(b)] = bytes;
       bytes = align_up(bytes + 8 * (4 * size_t(T) + 16), 256);
@@ -469,7 +606,7 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
       BandPair& p = op->pairs[size_t(b)];
       p = BandPair{};
       const int U = fx.lab_off[size_t(b) + 1] - fx.lab_off[size_t(b)];
-      const size_t N = size_t(2 * U + 1);
+      const size_t N = fx.fal ? size_t(U) + 1 : size_t(2 * U + 1);
       char* base = fx.rec_mem->as<char>(fx.rec_off[size_t(b)]);
       p.nodes = reinterpret_cast<BandNode*>(base);
       base += align_up(sizeof(BandNode) * N, 64);
@@ -478,8 +615,8 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
       p.snode = reinterpret_cast<int*>(base);
       base += align_up(4 * N, 64);
       p.slab = reinterpret_cast<int*>(base);
-      p.n_lab = int(N);
-      p.w = nullptr;  // all-zero weights
+      p.n_lab = fx.fal ? U : int(N);
+      p.w = fx.fal ? fx.rec_mem->as<float>(fx.w_off[size_t(b)]) : nullptr;  // CTC targets: all-zero weights
       p.em = ch.w_dev + size_t(b) * size_t(T) * size_t(C);
       p.N = int(N);
       p.T = T;
@@ -492,9 +629,9 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
         p.norm = op->arena->as<float>(o_norm + 4 * size_t(b));
         p.rowlse = op->arena->as<float>(o_lse + 4 * size_t(b) * size_t(T));
       }
-      p.hot = U + 1 >= 8 ? fx.blank : -1;
+      p.hot = (!fx.fal && U + 1 >= 8) ? fx.blank : -1;
       p.lgrn = band_forward_lgrn(C);
-      tab.push_back({BandLaunchKey{C, band_npl(p.N), 1, 0, band_vec_ok(p)}, p});
+      tab.push_back({BandLaunchKey{C, band_npl(p.N), fx.fal ? 0 : 1, 0, band_vec_ok(p)}, p});
       abytes += 4.0 * T * C + 4.0 * double(T + 1) * p.NS;
     }
     {
@@ -530,8 +667,36 @@ BatchP batch_viterbi_path(const BatchP& x) {
   return batch_from_graphs(op_viterbi_path(x->graphs));
 }
 
-BatchP batch_scalar(ScalarKind k, const BatchP& a, const BatchP& b) {
+
+namespace {
+// a GRAPHS batch of one-arc graphs as a native SCALAR batch (values gathered; backward continues on the graphs' tape)
+BatchP scalars_from_graphs(const BatchP& gsb) {
+  Runtime& rt = Runtime::get();
+  for (auto& g : gsb->graphs)
+    if (g.num_arcs() != 1) return nullptr;
+  auto op = std::make_shared<BFromGraphsOp>();
+  op->inputs = {gsb};
+  BatchP r = result(Batch::SCALAR, gsb->n, op);
+  r->v_mem = rt.alloc(sizeof(float) * size_t(gsb->n ? gsb->n : 1));
+  r->v_dev = r->v_mem->as<float>();
+  items_device(gsb->graphs, r->v_dev);
+  return r;
+}
+}  // namespace
+
+BatchP batch_scalar(ScalarKind k, const BatchP& a0, const BatchP& b0) {
+  BatchP a = a0, b = b0;
   const bool binary = k != SK_NEGATE;
+  // one side native, the other the per-graph functions' results: take those in, do not rebuild the native side
+  if (binary && a->n == b->n) {
+    const bool an = a->kind == Batch::SCALAR && !a->materialised, bn = b->kind == Batch::SCALAR && !b->materialised;
+    if (an && !bn && b->kind == Batch::GRAPHS) {
+      if (BatchP w = scalars_from_graphs(b)) b = w;
+    } else if (bn && !an && a->kind == Batch::GRAPHS) {
+      if (BatchP w = scalars_from_graphs(a)) a = w;
+    }
+  }
+
   if (native(*a, Batch::SCALAR) && !a->materialised &&
       (!binary || (native(*b, Batch::SCALAR) && !b->materialised && b->n == a->n))) {
     Runtime& rt = Runtime::get();
@@ -591,6 +756,7 @@ void batch_backward(const BatchP& root, bool retain) {
   try {
     for (Batch* b : order) {
       if (!b->g_dev) continue;  // no gradient reached it (a symbolic product never holds one)
+      if (auto* f = dynamic_cast<BFromGraphsOp*>(b->op.get())) f->retain = retain;
       b->op->backward(*b);
     }
     // normalisers that found no sweep to ride with
@@ -604,7 +770,9 @@ void batch_backward(const BatchP& root, bool retain) {
   // leaves whose elements were taken out as graphs: those carry the gradient
   for (Batch* b : seen)
     if (b->materialised && b->g_dev && !b->op) {
-      for (int i = 0; i < b->n; ++i) b->graphs[size_t(i)].add_grad_device(b->g_mem, b->g_dev + b->g_off[size_t(i)], false);
+      GradSink sink;  // first gradients are adopted in place, the others folded in by ONE launch
+      for (int i = 0; i < b->n; ++i) sink.add(b->graphs[size_t(i)], b->g_mem, b->g_dev + b->g_off[size_t(i)]);
+      sink.flush();
       b->g_dev = nullptr;
       b->g_mem.reset();
     }

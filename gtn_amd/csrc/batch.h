@@ -48,6 +48,12 @@ struct Batch {
   int max_label = -1, max_nodes = 0;
   DevMemP rec_mem;
   std::vector<size_t> rec_off;       // byte offset of element b's records
+  // ... or force-alignment acceptors composed with an ASG transitions graph (examples/asg.cpp:50-68):
+  // U + 1 nodes and 2U weighted arcs per sequence, weights gathered from the transitions on the device
+  bool fal = false;
+  Graph trans;                       // the transitions graph (its gradient is scattered back into it)
+  int trans_labels = 0;
+  std::vector<size_t> w_off, map_off;  // byte offsets of element b's arc weights / arc -> transitions arc map
   // ---- LINEAR: [n][M][C] device tensor (owned copy or the caller's)
   int M = 0, C = 0;
   DevMemP w_mem;
@@ -76,6 +82,7 @@ struct Batch {
 
 BatchP batch_from_graphs(std::vector<Graph> gs);
 BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, bool calc_grad);
+BatchP batch_asg_force_align(const int* labels, const int* lengths, int n, Graph& transitions, int n_labels);
 BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool borrow);
 BatchP batch_compose(const BatchP& a, const BatchP& b, bool intersect);
 BatchP batch_shortest_distance(const BatchP& x, bool tropical);

@@ -703,6 +703,10 @@ GTNX_API gtnx_status_t gtnx_batch_ctc_targets(const int* labels, const int* leng
                                               gtnx_batch_t* out) {
   return guard([&] { *out = HB(batch_ctc_targets(labels, lengths, n, blank, cg != 0)); });
 }
+GTNX_API gtnx_status_t gtnx_batch_asg_force_align(const int* labels, const int* lengths, int n, gtnx_graph_t transitions,
+                                                  int n_labels, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_asg_force_align(labels, lengths, n, G(transitions), n_labels)); });
+}
 GTNX_API gtnx_status_t gtnx_batch_linear(int n, int M, int N, int cg, const void* dev, int borrow, gtnx_batch_t* out) {
   return guard([&] { *out = HB(batch_linear(n, M, N, cg != 0, dev, borrow != 0)); });
 }

@@ -428,6 +428,20 @@ struct CtcTargetArgs {
   int N, pad;
 };
 void launch_ctc_targets(const CtcTargetArgs* d_args, int n, int blank, hipStream_t st);
+// one force-alignment acceptor o transitions per label sequence (examples/asg.cpp:50-68), as band records
+struct AsgFalArgs {
+  const GTNX_G int* labels;      // [U]
+  const GTNX_G float* trans_w;   // weights of the transitions graph, asgTransitions arc layout
+  GTNX_G BandNode* nodes;        // [U + 1]
+  GTNX_G uint8_t* nflags;        // [U + 1]
+  GTNX_G int* snode;             // [U]
+  GTNX_G int* slab;              // [U]
+  GTNX_G float* w;               // [2U] arc weights (gathered)
+  GTNX_G int* arc_map;           // [2U] transitions arc of every arc
+  int U, pad;
+};
+void launch_asg_fal_targets(const AsgFalArgs* d_args, int n, int n_labels, hipStream_t st);
+void launch_asg_fal_scatter(const float* g, const int* arc_map, int64_t n, float* trans_grad, hipStream_t st);
 int band_max_nodes();
 int band_max_labels();
 int band_npl(int max_nodes);               // nodes per lane: 1 or 2

@@ -2995,12 +2995,13 @@ void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(voi
 // ======================================================================
 // backward (autograd.cpp:17-67)
 // ======================================================================
-void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain) {
+void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed) {
   GTNX_HOST_T("backward.total");
   Runtime& rt = Runtime::get();
   for (auto& r : roots) realize(r);
-  // ---- seed (autograd.cpp:57-67)
-  if (grad) {
+  // ---- seed (autograd.cpp:57-67); seed == false: the roots hold their deltas already (batch.cpp)
+  if (!seed) {
+  } else if (grad) {
     for (auto& r : roots) {
       if (!r.calc_grad()) continue;
       if (grad->num_arcs() != r.num_arcs()) throw_logic("[Graph::addGrad] Invalid grad size.");

@@ -68,7 +68,7 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
 std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical);
 std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs);
 std::vector<Graph> op_compose(std::vector<Graph>& a, std::vector<Graph>& b, bool intersect);
-void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain);
+void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed = true);
 // per-thread hint of gtnx_compose_mode (include/gtn_amd.h); returns the previous value
 int compose_mode_hint(int mode);
 // build a symbolic (lazy) chain product for real, in place; no-op otherwise

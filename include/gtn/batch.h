@@ -54,6 +54,13 @@ class Batch {
     detail::check(gtnx_batch_ctc_targets(labels, lengths, n, blank, calcGrad, &b.h_));
     return b;
   }
+  /** compose(forceAlign(target), transitions) of examples/asg.cpp:50-68 for every label sequence, built on the
+   *  device; `transitions` in the arc layout of examples/asg.cpp:36-47 over `numLabels` labels */
+  static Batch asgForceAlign(const int* labels, const int* lengths, int n, const Graph& transitions, int numLabels) {
+    Batch b;
+    detail::check(gtnx_batch_asg_force_align(labels, lengths, n, transitions.handle(), numLabels, &b.h_));
+    return b;
+  }
   /** n linear graphs over one device tensor [n][M][N] (see linearGraphs) */
   static Batch linear(int n, int M, int N, const void* deviceWeights, bool calcGrad = true, bool borrow = false) {
     Batch b;

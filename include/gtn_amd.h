@@ -216,6 +216,12 @@ gtnx_status_t gtnx_batch_from_graphs(const gtnx_graph_t* g, int n, gtnx_batch_t*
  * sequences (labels back to back, lengths[i] each), built on the device */
 gtnx_status_t gtnx_batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, int calc_grad,
                                      gtnx_batch_t* out);
+/* compose(forceAlign(target), transitions) of examples/asg.cpp:50-68 for n label sequences, built
+ * on the device: `transitions` must have the arc layout of examples/asg.cpp:36-47 over n_labels labels
+ * (arc i: start -> label i; arc n_labels + i * n_labels + j: label j -> label i); its weights are
+ * gathered into the acceptors' arcs and their gradients are added back into its gradient */
+gtnx_status_t gtnx_batch_asg_force_align(const int* labels, const int* lengths, int n, gtnx_graph_t transitions,
+                                         int n_labels, gtnx_batch_t* out);
 /* n linear graphs (creations.cpp:20-33) over one device tensor [n][M][N]; borrow != 0: read in
  * place (see gtnx_linear_graph_borrow_n) */
 gtnx_status_t gtnx_batch_linear(int n, int M, int N, int calc_grad, const void* device_weights, int borrow,

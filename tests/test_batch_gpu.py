@@ -183,3 +183,67 @@ def test_batch_ctc_full_size_c3_invariants(gtn):
         want, wgrad, _ = ctc_loss_fp64(em[b], tg[b])
         assert abs(got[b] - want) <= 1e-5 * abs(want), (got[b], want)
         assert np.abs(g[b] - wgrad).max() <= 1e-4
+
+
+def _asg_transitions(gtn, N, w):
+    """examples/asg.cpp:36-47 / gtn_amd/criteria/asg_criterion.h: arc i = start -> label i, arc N + i N + j = j -> i"""
+    g = gtn.Graph()
+    g.add_nodes(np.array([1] + [0] * N, np.uint8), np.array([0] + [1] * N, np.uint8))
+    n = np.arange(N)
+    src = np.concatenate([np.zeros(N, np.int32), np.tile(n + 1, N).astype(np.int32)])
+    dst = np.concatenate([n + 1, np.repeat(n + 1, N)]).astype(np.int32)
+    lab = np.concatenate([n, np.repeat(n, N)]).astype(np.int32)
+    g.add_arcs(src, dst, lab, lab, w.astype(np.float32))
+    g.arc_sort()
+    return g
+
+
+def test_batch_asg_criterion_vs_per_graph_path(gtn):
+    """the ASG criterion of examples/asg.cpp:59-68 on batch records -- force-alignment acceptors composed with the
+    transitions built on the device, the full-connect term through the per-graph functions on the elements, the two
+    mixed in one batch expression -- against the same criterion written with the per-graph functions: losses,
+    emission gradients and the (batch-summed) transitions gradient"""
+    import torch
+    B, T, N = 5, 40, 7
+    rng = np.random.default_rng(9)
+    em = (rng.random((B, T, N), dtype=np.float32) * 6 - 3).astype(np.float32)
+    tw = rng.normal(0, 1, N + N * N).astype(np.float32)
+    tg = [rng.integers(0, N, size=int(rng.integers(1, 9))).astype(np.int32) for _ in range(B)]
+    tg[2] = np.array([3, 3, 3], np.int32)
+    em_dev = _dev(em)
+    res = {}
+    for batch in (True, False):
+        trans = _asg_transitions(gtn, N, tw)
+        prev = gtn.compose_mode(2)
+        try:
+            if batch:
+                ems = gtn.Batch.linear(B, T, N, em_dev, True, True)
+                fcc = gtn.forward_score(gtn.compose(ems, gtn.Batch([trans])))
+                fals = gtn.Batch.asg_force_align(tg, trans, N)
+                loss = gtn.subtract(fcc, gtn.forward_score(gtn.compose(ems, fals)))
+                gtn.backward(loss)
+                lv = loss.items()
+                ge = np.stack([ems[b].grad().weights_to_numpy().reshape(T, N) for b in range(B)])
+            else:
+                ems = gtn.linear_graph_n(B, T, N, em_dev)
+                fals = []
+                for t in tg:
+                    f = gtn.Graph(False)
+                    f.add_node(True, len(t) == 0)
+                    for l in range(1, len(t) + 1):
+                        f.add_node(False, l == len(t))
+                        f.add_arc(l - 1, l, int(t[l - 1]))
+                        f.add_arc(l, l, int(t[l - 1]))
+                    fals.append(f)
+                fcc = gtn.forward_score(gtn.compose(ems, [trans]))
+                loss = gtn.subtract(fcc, gtn.forward_score(gtn.compose(ems, gtn.compose(fals, [trans]))))
+                gtn.backward(loss)
+                lv = gtn.items(loss)
+                ge = np.stack([ems[b].grad().weights_to_numpy().reshape(T, N) for b in range(B)])
+        finally:
+            gtn.compose_mode(prev)
+        res[batch] = (lv, ge, trans.grad().weights_to_numpy().copy())
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(res[True][1], res[False][1], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(res[True][2], res[False][2], rtol=2e-4, atol=5e-5)
+    assert np.all(res[True][0] >= -1e-4)  # a loss is a -log probability ratio

@@ -116,6 +116,29 @@ def main():
     lv = gtn.items(loss)
     out["asg_loss_mean"] = float(lv.mean())
     out["asg_loss_min"] = float(lv.min())  # a loss is a -log probability ratio: never negative
+    # (d) the same criterion as shipped: gtn_amd.torch_loss.asg_loss over libgtn_criteria.so (batch records:
+    # the force-alignment acceptors composed with the transitions are built on the device)
+    try:
+        from gtn_amd.torch_loss import asg_loss
+        emt = em.clone().requires_grad_(True)
+        trt = torch.from_numpy(tw[C:].reshape(C, C).copy()).cuda().requires_grad_(True)
+        stt = torch.from_numpy(tw[:C].copy()).cuda().requires_grad_(True)
+        tl = [t.tolist() for t in tgts]
+        times = []
+        for _ in range(args.steps):
+            for x in (emt, trt, stt):
+                x.grad = None
+            sync()
+            t0 = time.perf_counter()
+            l = asg_loss(emt, trt, tl, stt, reduction="none")
+            l.sum().backward()
+            sync()
+            times.append(time.perf_counter() - t0)
+        out["asg_criterion_fwd_bwd_ms"] = min(times) * 1e3
+        out["asg_criterion_utt_per_s"] = B / min(times)
+        out["asg_criterion_loss_mean"] = float(l.mean().item())
+    except Exception as e:  # keep the line
+        out["asg_criterion_error"] = str(e)[:200]
     # ---- roofline of the dominant kernel family: the dense-regime time steps on the matrix cores
     # (lazy.hip: lazy_mfma_step_kernel, v_mfma_f32_32x32x2_f32).  Algorithmic work of one pass: T products
     # [B x N] . [N x N] in float32 = 2 B N^2 T flops (N = C + 1 nodes of the transitions graph); hipEvent

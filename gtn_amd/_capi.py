@@ -102,6 +102,10 @@ _SIGS = {
     "gtnx_items_device_n": [c_graph_p, C.c_int, C.c_void_p],
     "gtnx_grads_device_n": [c_graph_p, C.c_int, C.c_void_p, C.c_void_p],
     "gtnx_grads_bind_device_n": [c_graph_p, C.c_int, C.c_void_p, C.c_void_p],
+    "gtnx_clone": [c_graph, C.c_int, c_graph_p],
+    "gtnx_concat": [c_graph_p, C.c_int, c_graph_p],
+    "gtnx_closure": [c_graph, c_graph_p],
+    "gtnx_union": [c_graph_p, C.c_int, c_graph_p],
     "gtnx_batch_from_graphs": [c_graph_p, C.c_int, c_graph_p],
     "gtnx_batch_ctc_targets": [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, c_graph_p],
     "gtnx_batch_asg_force_align": [C.c_void_p, C.c_void_p, C.c_int, c_graph, C.c_int, c_graph_p],

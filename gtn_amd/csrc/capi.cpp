@@ -688,6 +688,33 @@ GTNX_API gtnx_status_t gtnx_grads_bind_device_n(const gtnx_graph_t* g, int n, vo
   });
 }
 
+// ------------------------------------------------------------------ rational operations (device-built)
+GTNX_API gtnx_status_t gtnx_clone(gtnx_graph_t g, int projection, gtnx_graph_t* out) {
+  return guard([&] {
+    if (projection < 0 || projection > 2) throw_invalid("[gtnx_clone] projection must be 0, 1 or 2");
+    std::vector<Graph> v{G(g)};
+    *out = H(op_rational(RAT_CLONE, v, projection));
+  });
+}
+GTNX_API gtnx_status_t gtnx_concat(const gtnx_graph_t* g, int n, gtnx_graph_t* out) {
+  return guard([&] {
+    auto v = vec(g, n);
+    *out = H(op_rational(RAT_CONCAT, v, 0));
+  });
+}
+GTNX_API gtnx_status_t gtnx_closure(gtnx_graph_t g, gtnx_graph_t* out) {
+  return guard([&] {
+    std::vector<Graph> v{G(g)};
+    *out = H(op_rational(RAT_CLOSURE, v, 0));
+  });
+}
+GTNX_API gtnx_status_t gtnx_union(const gtnx_graph_t* g, int n, gtnx_graph_t* out) {
+  return guard([&] {
+    auto v = vec(g, n);
+    *out = H(op_rational(RAT_UNION, v, 0));
+  });
+}
+
 // ------------------------------------------------------------------ batch records
 namespace {
 inline BatchP& BH(gtnx_batch_t h) {

@@ -417,6 +417,35 @@ struct BandDecode {
   int stage_floats, pad;         // LDS staging area of the launch (floats)
 };
 void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hipStream_t st);
+// ---------------------------------------------------------------------------
+// rational.hip: clone / concat / closure / union_ (functions.cpp:66-223) built on the device
+// ---------------------------------------------------------------------------
+struct RationalSeg {      // one input graph's place in the output
+  DGraph g;               // its device view, weights included (implicit chains: n_start = n_accept = 1)
+  int node_off, arc_off;  // where its nodes / arcs start
+  int conn_off;           // where the epsilon connectors INTO it (concat) / around it (closure) start
+  int keep_start, keep_accept;
+  int pad;
+};
+struct RationalOut {
+  int N, A;
+  GTNX_G int* src;
+  GTNX_G int* dst;
+  GTNX_G int* il;
+  GTNX_G int* ol;
+  GTNX_G float* w;
+  GTNX_G uint8_t* nflags;
+  GTNX_G int* start_list;
+  GTNX_G int* accept_list;
+  GTNX_G int* out_off;
+  GTNX_G int* out_list;
+  GTNX_G int* in_off;
+  GTNX_G int* in_list;
+};
+size_t rational_csr_temp_bytes(int N, int A);
+// projection: 0 none, 1 input, 2 output (functions.h Projection); closure != 0: node 0 is the new start / accept node
+void launch_rational_build(const RationalSeg* d_segs, int nseg, int max_A, int max_N, int max_conn, const RationalOut& out,
+                           int projection, int closure, void* temp, hipStream_t st);
 // one CTC target acceptor per label sequence, written as band records on the device (band.hip)
 struct CtcTargetArgs {
   const GTNX_G int* labels;   // [U]

@@ -3132,6 +3132,162 @@ void items_device(std::vector<Graph>& gs, void* dev_out) {
   launch_gather_scalars(dp->as<const float*>(), static_cast<float*>(dev_out), int(n), rt.stream());
 }
 
+
+// ======================================================================
+// rational operations (functions.cpp:66-223), built on the device: rational.hip
+// ======================================================================
+namespace {
+struct RationalOp : OpRecord {
+  // per output: where each input's arcs start in the output's arc order (functions.cpp:98-110, 159-164, 191-200:
+  // the gradient of an input is a slice of the deltas)
+  std::vector<std::vector<int64_t>> arc_off;
+  void backward(std::vector<Member>& ms) override {
+    GradSink sink;
+    for (auto& m : ms) {
+      Graph& gr = m.out.grad();
+      if (!gr.w->dev_valid || gr.w->host_escaped) {
+        std::vector<Weights*> v{gr.w.get()};
+        ensure_weights_device_batch(v);
+      }
+      auto& ins = m.out.g->inputs;
+      for (size_t i = 0; i < ins.size(); ++i)
+        if (ins[i].calc_grad()) sink.add(ins[i], gr.w->dev_mem, gr.w->dev + arc_off[m.idx][i]);
+    }
+    sink.flush();
+  }
+};
+}  // namespace
+
+Graph op_rational(int kind, std::vector<Graph>& ins, int projection) {
+  Runtime& rt = Runtime::get();
+  const bool closure = kind == RAT_CLOSURE, concat = kind == RAT_CONCAT;
+  auto op = std::make_shared<RationalOp>();
+  op->seq = next_seq();
+  if (ins.empty()) {  // a^0 accepts the empty string (functions.cpp:117-121); the empty union is the empty graph
+    Graph out = make_output(op, 0, {});
+    if (concat) out.add_node(true, true);
+    op->arc_off.push_back({});
+    return out;
+  }
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  for (auto& g : ins) {
+    g.s->resolve_sizes();
+    if (g.s->kind != KIND_LINEAR) ss.push_back(g.s.get());
+    ws.push_back(g.w.get());
+  }
+  ensure_device_batch(ss);
+  ensure_weights_device_batch(ws);
+  const int k = int(ins.size());
+  std::vector<RationalSeg> segs;
+  segs.resize(size_t(k));
+  int64_t N = closure ? 1 : 0, A = 0;
+  int max_A = 0, max_N = 0, max_conn = 0;
+  bool eps_free = true;
+  std::vector<int64_t> offs;
+  for (int i = 0; i < k; ++i) {
+    RationalSeg& s = segs[size_t(i)];
+    s = RationalSeg{};
+    s.g = device_view(ins[size_t(i)]);
+    if (s.g.kind == KIND_LINEAR) {
+      s.g.N = int(ins[size_t(i)].s->N);
+      s.g.A = int(ins[size_t(i)].s->A);
+      s.g.M = ins[size_t(i)].s->M;
+      s.g.C = ins[size_t(i)].s->C;
+      s.g.n_start = s.g.n_accept = 1;
+    } else if (!(s.g.flags & 4)) {
+      eps_free = false;
+    }
+    s.node_off = int(N);
+    if (concat && i > 0) {  // the connectors into graph i come right after graph i's own arcs (functions.cpp:139-149)
+      s.arc_off = int(A);
+      s.conn_off = int(A) + s.g.A;
+    } else {
+      s.arc_off = int(A);
+      s.conn_off = int(A) + s.g.A;
+    }
+    offs.push_back(A);
+    int conn = 0;
+    if (concat && i > 0) conn = segs[size_t(i) - 1].g.n_accept * s.g.n_start;
+    if (closure) conn = s.g.n_start + s.g.n_accept;
+    if (conn) eps_free = false;
+    s.keep_start = closure ? 0 : (concat ? i == 0 : 1);
+    s.keep_accept = closure ? 0 : (concat ? i == k - 1 : 1);
+    N += s.g.N;
+    A += int64_t(s.g.A) + conn;
+    max_A = std::max(max_A, s.g.A);
+    max_N = std::max(max_N, s.g.N);
+    max_conn = std::max(max_conn, conn);
+  }
+  if (N > (int64_t(1) << 30) || A > (int64_t(1) << 30)) throw_runtime("[gtn] rational operation: result too large");
+  // one arena: arc arrays, weights, flags, lists, adjacency
+  size_t bytes = 0;
+  auto add = [&](size_t b) {
+    const size_t at = bytes;
+    bytes = align_up(bytes + (b ? b : 4), 256);
+    return at;
+  };
+  const size_t a4 = 4 * size_t(A), n4 = 4 * size_t(N);
+  const size_t o_src = add(a4), o_dst = add(a4), o_il = add(a4), o_ol = add(a4), o_w = add(a4), o_fl = add(size_t(N)),
+               o_st = add(n4), o_ac = add(n4), o_oo = add(n4 + 4), o_ol2 = add(a4), o_io = add(n4 + 4), o_il2 = add(a4);
+  DevMemP arena = rt.alloc(bytes);
+  RationalOut ro{};
+  ro.N = int(N);
+  ro.A = int(A);
+  ro.src = arena->as<int>(o_src);
+  ro.dst = arena->as<int>(o_dst);
+  ro.il = arena->as<int>(o_il);
+  ro.ol = arena->as<int>(o_ol);
+  ro.w = arena->as<float>(o_w);
+  ro.nflags = arena->as<uint8_t>(o_fl);
+  ro.start_list = arena->as<int>(o_st);
+  ro.accept_list = arena->as<int>(o_ac);
+  ro.out_off = arena->as<int>(o_oo);
+  ro.out_list = arena->as<int>(o_ol2);
+  ro.in_off = arena->as<int>(o_io);
+  ro.in_list = arena->as<int>(o_il2);
+  DevMemP dsegs = upload_vec(segs);
+  DevMemP temp = rt.alloc(rational_csr_temp_bytes(int(N), int(A)));
+  launch_rational_build(dsegs->as<RationalSeg>(), k, max_A, max_N, max_conn, ro, projection, closure ? 1 : 0, temp->ptr, rt.stream());
+  // counts of the output's start / accept nodes follow from the inputs'
+  int n_start = 0, n_accept = 0;
+  if (closure) n_start = n_accept = 1;
+  else if (concat) n_start = segs.front().g.n_start, n_accept = segs.back().g.n_accept;
+  else
+    for (auto& s : segs) n_start += s.g.n_start, n_accept += s.g.n_accept;
+  Graph out = make_output(op, 0, ins);
+  Structure& st = *out.s;
+  st.kind = KIND_EXPLICIT;
+  st.N = N;
+  st.A = A;
+  st.host_valid = false;
+  st.csr_valid = false;
+  st.dev_valid = true;
+  st.dev_mem = arena;
+  DGraph& v = st.dview;
+  v = DGraph{};
+  v.kind = KIND_EXPLICIT;
+  v.N = int(N);
+  v.A = int(A);
+  v.n_start = n_start;
+  v.n_accept = n_accept;
+  v.flags = eps_free ? 4 : 0;
+  v.src = ro.src;
+  v.dst = ro.dst;
+  v.il = ro.il;
+  v.ol = ro.ol;
+  v.nflags = ro.nflags;
+  v.start_list = ro.start_list;
+  v.accept_list = ro.accept_list;
+  v.out_off = ro.out_off;
+  v.out_list = ro.out_list;
+  v.in_off = ro.in_off;
+  v.in_list = ro.in_list;
+  set_dev_weights(out, arena, ro.w, A);
+  op->arc_off.push_back(std::move(offs));
+  return out;
+}
+
 void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets) {
   const size_t n = gs.size();
   if (n == 0) return;

@@ -68,6 +68,9 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
 std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical);
 std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs);
 std::vector<Graph> op_compose(std::vector<Graph>& a, std::vector<Graph>& b, bool intersect);
+// rational operations built on the device (rational.hip): clone / projections, concat, closure, union_
+enum RationalKind { RAT_CLONE = 0, RAT_CONCAT = 1, RAT_CLOSURE = 2, RAT_UNION = 3 };
+Graph op_rational(int kind, std::vector<Graph>& inputs, int projection);
 void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed = true);
 // per-thread hint of gtnx_compose_mode (include/gtn_amd.h); returns the previous value
 int compose_mode_hint(int mode);

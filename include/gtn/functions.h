@@ -97,102 +97,40 @@ inline std::vector<Graph> viterbiPath(const std::vector<Graph>& g) { return deta
 } // namespace batched
 
 // ---------------------------------------------------------------------------
-// Rational / structural operations (reference gtn/functions.h:45-123).  They are
-// off the hot path (graph-construction utilities run once on tiny
-// graphs), so they are plain host-side constructions over the public Graph API;
-// they exist so reference callers and the reference's own tests compile
-// unchanged.  Gradients are slices / copies of the output's deltas, as there.
+// Rational / structural operations (reference gtn/functions.h:45-123).  clone, the projections,
+// concat, closure and union_ are built by the engine on the device (gtnx_clone / gtnx_concat /
+// gtnx_closure / gtnx_union: rational.hip), node and arc ids as functions.cpp:66-223 numbers them,
+// gradients of the inputs as slices of the output's; remove stays a host-side construction.
 // ---------------------------------------------------------------------------
 enum class Projection { NONE = 0, INPUT = 1, OUTPUT = 2 };
 
 inline Graph clone(const Graph& g, Projection projection = Projection::NONE) {
-  // functions.cpp:66-83
-  Graph out([](std::vector<Graph>& inputs, Graph& deltas) { inputs[0].addGrad(deltas); }, {g});
-  for (size_t n = 0; n < g.numNodes(); ++n) out.addNode(g.isStart(n), g.isAccept(n));
-  for (size_t a = 0; a < g.numArcs(); ++a) {
-    const int il = projection == Projection::OUTPUT ? g.olabel(a) : g.ilabel(a);
-    const int ol = projection == Projection::INPUT ? g.ilabel(a) : g.olabel(a);
-    out.addArc(g.srcNode(a), g.dstNode(a), il, ol, g.weight(a));
-  }
-  return out;
+  gtnx_graph_t h;
+  detail::check(gtnx_clone(g.handle(), static_cast<int>(projection), &h));
+  return Graph::fromHandle(h);
 }
 inline Graph projectInput(const Graph& g) { return clone(g, Projection::INPUT); }
 inline Graph projectOutput(const Graph& g) { return clone(g, Projection::OUTPUT); }
 
 inline Graph concat(const std::vector<Graph>& graphs) {
-  // functions.cpp:97-153: graph i's accept nodes are joined to graph i+1's start
-  // nodes by epsilon arcs, which sit between the two graphs' arcs in arc order
-  auto gradFunc = [](std::vector<Graph>& inputs, Graph& deltas) {
-    const float* grad = deltas.weights();
-    for (size_t i = 0; i < inputs.size(); ++i) {
-      Graph& in = inputs[i];
-      if (in.calcGrad()) in.addGrad(std::vector<float>(grad, grad + in.numArcs()));
-      grad += in.numArcs();
-      if (i > 0) grad += inputs[i - 1].numAccept() * in.numStart();
-    }
-  };
-  Graph out(gradFunc, graphs);
-  if (graphs.empty()) {
-    out.addNode(true, true);  // a^0 accepts the empty string
-    return out;
-  }
-  size_t offset = 0;
-  for (size_t i = 0; i < graphs.size(); ++i) {
-    const Graph& g = graphs[i];
-    for (size_t n = 0; n < g.numNodes(); ++n)
-      out.addNode(i == 0 && g.isStart(n), i + 1 == graphs.size() && g.isAccept(n));
-    for (size_t a = 0; a < g.numArcs(); ++a)
-      out.addArc(offset + g.srcNode(a), offset + g.dstNode(a), g.ilabel(a), g.olabel(a), g.weight(a));
-    if (i > 0) {
-      const Graph& prev = graphs[i - 1];
-      const size_t prevOffset = offset - prev.numNodes();
-      const std::vector<int> accepts = prev.accept();
-      const std::vector<int> starts = g.start();
-      for (int acc : accepts)
-        for (int st : starts) out.addArc(acc + prevOffset, st + offset, epsilon);
-    }
-    offset += g.numNodes();
-  }
-  return out;
+  auto hs = detail::handles(graphs);
+  gtnx_graph_t h;
+  detail::check(gtnx_concat(hs.data(), static_cast<int>(hs.size()), &h));
+  return Graph::fromHandle(h);
 }
 inline Graph concat(const Graph& g1, const Graph& g2) { return concat(std::vector<Graph>{g1, g2}); }
 
 inline Graph closure(const Graph& g) {
-  // functions.cpp:155-186: new start/accept node 0, old graph shifted by one
-  auto gradFunc = [](std::vector<Graph>& inputs, Graph& deltas) {
-    const float* grad = deltas.weights();
-    inputs[0].addGrad(std::vector<float>(grad, grad + inputs[0].numArcs()));
-  };
-  Graph closed(gradFunc, {g});
-  closed.addNode(true, true);
-  for (size_t n = 0; n < g.numNodes(); ++n) closed.addNode();
-  for (size_t a = 0; a < g.numArcs(); ++a)
-    closed.addArc(g.srcNode(a) + 1, g.dstNode(a) + 1, g.ilabel(a), g.olabel(a), g.weight(a));
-  const std::vector<int> starts = g.start();
-  const std::vector<int> accepts = g.accept();
-  for (int s : starts) closed.addArc(0, s + 1, epsilon);
-  for (int a : accepts) closed.addArc(a + 1, 0, epsilon);
-  return closed;
+  gtnx_graph_t h;
+  detail::check(gtnx_closure(g.handle(), &h));
+  return Graph::fromHandle(h);
 }
 
 inline Graph union_(const std::vector<Graph>& graphs) {
-  // functions.cpp:188-223
-  auto gradFunc = [](std::vector<Graph>& inputs, Graph& deltas) {
-    const float* grad = deltas.weights();
-    for (auto& in : inputs) {
-      if (in.calcGrad()) in.addGrad(std::vector<float>(grad, grad + in.numArcs()));
-      grad += in.numArcs();
-    }
-  };
-  Graph out(gradFunc, graphs);
-  size_t offset = 0;
-  for (const Graph& g : graphs) {
-    for (size_t n = 0; n < g.numNodes(); ++n) out.addNode(g.isStart(n), g.isAccept(n));
-    for (size_t a = 0; a < g.numArcs(); ++a)
-      out.addArc(offset + g.srcNode(a), offset + g.dstNode(a), g.ilabel(a), g.olabel(a), g.weight(a));
-    offset += g.numNodes();
-  }
-  return out;
+  auto hs = detail::handles(graphs);
+  gtnx_graph_t h;
+  detail::check(gtnx_union(hs.data(), static_cast<int>(hs.size()), &h));
+  return Graph::fromHandle(h);
 }
 
 inline Graph remove(const Graph& g, int ilabel, int olabel) {

@@ -203,6 +203,16 @@ gtnx_status_t gtnx_grads_device_n(const gtnx_graph_t* g, int n, void* device_out
  * place and copies nothing).  A hint: results are the same without it. */
 gtnx_status_t gtnx_grads_bind_device_n(const gtnx_graph_t* g, int n, void* device_out, const int64_t* offsets);
 
+/* ------------------------------------------------------------------ rational operations
+ * gtn/functions.h:45-123, functions.cpp:66-223 -- built on the device: the output's arrays are the inputs'
+ * arrays copied with node offsets, epsilon connectors written from the inputs' start / accept lists,
+ * adjacency lists rebuilt by a stable sort of the arc ids.  Node and arc ids as the reference numbers them;
+ * gradients of the inputs are slices of the output's. */
+gtnx_status_t gtnx_clone(gtnx_graph_t g, int projection /* 0 none, 1 input, 2 output */, gtnx_graph_t* out); /* functions.cpp:66-92 */
+gtnx_status_t gtnx_concat(const gtnx_graph_t* g, int n, gtnx_graph_t* out);                                  /* functions.cpp:97-153 */
+gtnx_status_t gtnx_closure(gtnx_graph_t g, gtnx_graph_t* out);                                               /* functions.cpp:155-189 */
+gtnx_status_t gtnx_union(const gtnx_graph_t* g, int n, gtnx_graph_t* out);                                   /* functions.cpp:191-223 */
+
 /* ------------------------------------------------------------------ batch records
  * B graphs held as ONE object: what gtn::parallelMap over the per-graph functions
  * (parallel/parallel_map.h:153-188; benchmarks/ctc.cpp:150-165) returns when nobody looks at

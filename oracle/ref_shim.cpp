@@ -91,6 +91,18 @@ gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
 }
 gtnx_status_t gtnx_empty_cache(void) { return GTNX_OK; }
 gtnx_status_t gtnx_reclaim(void) { return GTNX_OK; }
+gtnx_status_t gtnx_clone(gtnx_graph_t g, int projection, gtnx_graph_t* out) {
+  return guard([&] { *out = H(gtn::clone(G(g), static_cast<gtn::Projection>(projection))); });
+}
+gtnx_status_t gtnx_concat(const gtnx_graph_t* g, int n, gtnx_graph_t* out) {
+  return guard([&] { *out = H(gtn::concat(vec(g, n))); });
+}
+gtnx_status_t gtnx_closure(gtnx_graph_t g, gtnx_graph_t* out) {
+  return guard([&] { *out = H(gtn::closure(G(g))); });
+}
+gtnx_status_t gtnx_union(const gtnx_graph_t* g, int n, gtnx_graph_t* out) {
+  return guard([&] { *out = H(gtn::union_(vec(g, n))); });
+}
 gtnx_status_t gtnx_parallel_enter(void) { return GTNX_OK; }
 gtnx_status_t gtnx_parallel_leave(void) { return GTNX_OK; }
 

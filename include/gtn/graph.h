@@ -13,6 +13,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -193,14 +194,16 @@ class Graph {
   Graph withoutWeights() const { return *this; }
 
   const std::vector<int>& start() const {
-    cacheA_.resize(numStart());
-    detail::check(gtnx_graph_get_start(h_, cacheA_.data()));
-    return cacheA_;
+    std::vector<int>& v = listSlot(0, 0);
+    v.resize(numStart());
+    detail::check(gtnx_graph_get_start(h_, v.data()));
+    return v;
   }
   const std::vector<int>& accept() const {
-    cacheB_.resize(numAccept());
-    detail::check(gtnx_graph_get_accept(h_, cacheB_.data()));
-    return cacheB_;
+    std::vector<int>& v = listSlot(1, 0);
+    v.resize(numAccept());
+    detail::check(gtnx_graph_get_accept(h_, v.data()));
+    return v;
   }
   bool isStart(size_t i) const {
     int v;
@@ -219,9 +222,10 @@ class Graph {
     return (size_t)v;
   }
   const std::vector<int>& out(size_t i) const {
-    cacheC_.resize(numOut(i));
-    detail::check(gtnx_graph_get_out(h_, (int)i, cacheC_.data()));
-    return cacheC_;
+    std::vector<int>& v = listSlot(2, i);
+    v.resize(numOut(i));
+    detail::check(gtnx_graph_get_out(h_, (int)i, v.data()));
+    return v;
   }
   int out(size_t i, size_t j) const { return out(i)[j]; }
   size_t numIn(size_t i) const {
@@ -230,9 +234,10 @@ class Graph {
     return (size_t)v;
   }
   const std::vector<int>& in(size_t i) const {
-    cacheD_.resize(numIn(i));
-    detail::check(gtnx_graph_get_in(h_, (int)i, cacheD_.data()));
-    return cacheD_;
+    std::vector<int>& v = listSlot(3, i);
+    v.resize(numIn(i));
+    detail::check(gtnx_graph_get_in(h_, (int)i, v.data()));
+    return v;
   }
   size_t in(size_t i, size_t j) const { return (size_t)in(i)[j]; }
 
@@ -297,7 +302,15 @@ class Graph {
   gtnx_graph_t h_{nullptr};
   mutable std::unique_ptr<Graph> grad_;
   mutable std::vector<Graph> inputs_;
-  mutable std::vector<int> cacheA_, cacheB_, cacheC_, cacheD_;
+  // start() / accept() / out(i) / in(i) hand out references like the reference does (graph.h:293-325 there):
+  // one host copy per (list, node), refreshed on every call, so `g.out(n).begin(), g.out(n).end()` and nested
+  // loops over different nodes see stable storage.  Slots of one Graph object are not shared with its copies.
+  std::vector<int>& listSlot(int which, size_t node) const {
+    std::lock_guard<std::mutex> lk(listMutex_);
+    return lists_[(uint64_t(node) << 2) | uint64_t(which)];
+  }
+  mutable std::mutex listMutex_;
+  mutable std::unordered_map<uint64_t, std::vector<int>> lists_;
 };
 
 } // namespace gtn

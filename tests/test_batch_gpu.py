@@ -247,3 +247,23 @@ def test_batch_asg_criterion_vs_per_graph_path(gtn):
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(res[True][2], res[False][2], rtol=2e-4, atol=5e-5)
     assert np.all(res[True][0] >= -1e-4)  # a loss is a -log probability ratio
+
+
+def test_batch_ctc_c5_shape_vs_fp64(gtn):
+    """BASELINE config 5's shape through the batch path (T = 2000, C = 1024, U = 200: two nodes per lane, one
+    workgroup per CU, 32 staging registers per stream): losses and emission gradients against float64"""
+    import torch
+    from ctc_fp64 import ctc_loss_fp64
+    B, T, C, U = 4, 2000, 1024, 200
+    em, tg = gg.ctc_inputs(5, B, T, C, U)
+    em_dev = _dev(em)
+    grad = torch.empty(B, T, C, device="cuda:0")
+    ctcs, ems, loss = _batch_ctc(gtn, em_dev, list(tg), T, C, bind=grad)
+    gtn.backward(loss)
+    got = loss.items()
+    g = grad.cpu().numpy()
+    for b in range(2):
+        want, wgrad, _ = ctc_loss_fp64(em[b], tg[b])
+        assert abs(got[b] - want) <= 1e-5 * abs(want), (got[b], want)
+        assert np.abs(g[b] - wgrad).max() <= 2e-4
+    assert grad.sum(dim=2).abs().max().item() < 2e-3

@@ -328,7 +328,13 @@ struct LazyGroup {          // utterances that share one explicit graph G
   float* xt[2];               // [Kpad / 4][nbpad][4] the contraction input, exponentiated, in operand layout (two planes)
   const float* Ep;            // [Kpad / 4][Npad2][4] E zero-padded
   const float* ETp;           // [Kpad / 4][Npad2][4] its transpose
-  int Kpad, Npad2, nbpad;     // N rounded up to 4 / to 32; nb rounded up to 32
+  int Kpad, Npad2, nbpad;     // N rounded up to 4 / to 32; nb rounded up to 32 (max-plus form: to 64)
+  // max-plus form of the dense regime (tropical semiring; maxplus.hip): xt holds alpha itself
+  const float* mp_Wq;         // [dblock][Kpad / 2][16][2] largest weight per (source, destination column), -inf: no arc
+  const int* mp_colidx;       // [N] node -> destination column, -1 for nodes without a matched in-arc
+  const int* mp_colnode;      // [mp_ncol] column -> node
+  const int* mp_dead;         // [mp_ndead] the nodes without a matched in-arc
+  int mp_ncol, mp_ndead;
 };
 size_t lazy_step_lds_bytes(const LazyGroup& g);
 int lazy_tile_nodes();
@@ -487,6 +493,11 @@ void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream
 void launch_lazy_dense_step(const LazyGroup& g, int t, int backward, hipStream_t st, const float* vin = nullptr,
                             float* vout = nullptr);
 void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st);                   // R zero-filled
+size_t maxplus_w_floats(const LazyGroup& g);                                   // mp_ncol / Kpad set
+void launch_maxplus_prep(const LazyGroup& g, hipStream_t st);                  // mp_Wq, both input planes
+void launch_maxplus_step(const LazyGroup& g, int t, hipStream_t st);           // alpha[t] -> alpha[t+1]
+void launch_maxplus_path(const LazyGroup& g, int* path_arc, int* path_il, int* path_ol, float* path_w, int* path_len,
+                         hipStream_t st);
 void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st);                // Ep / ETp from E
 void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st);     // keys, first input (0 forward, 1 backward)
 void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st);

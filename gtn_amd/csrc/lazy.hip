@@ -605,13 +605,21 @@ __global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
   }
 }
 
-// one workgroup of four waves per 32 x 32 output tile: each wave runs a quarter of the contraction,
-// the four partial tiles are summed through LDS and each wave finishes eight of the tile's rows
+// one workgroup of four waves per 32 x 32 output tile: each wave runs a quarter of the contraction, the
+// partial tiles are summed through LDS and each wave finishes eight of the tile's rows.  (Eight waves would
+// halve the chain again but need the whole CU's registers: 272 tiles on 256 CUs would then run in two rounds.)  A step is a chain of
+// latencies, not of throughput (257 MFMAs per tile against several trips to memory that the kernel
+// boundary has just flushed out of L2): the operands of a wave's k groups are requested in two
+// alternating batches, the next batch before the current one is multiplied, and the epilogue's scalars
+// before either.
+constexpr int MF_WAVES = 4;
+constexpr int MF_ROWS = 16 / MF_WAVES;  // accumulator registers (tile rows per half-wave) a wave finishes
+constexpr int MF_BATCH = 9;  // k groups (two MFMAs each) per operand batch: two batches cover a wave's 16-17 groups at C4
 template <bool BWD>
-__global__ __launch_bounds__(256) void lazy_mfma_step_kernel(LazyGroup g, int t) {
-  __shared__ float part[4][16][64];
+__global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup g, int t) {
+  __shared__ float part[MF_WAVES][16][64];
   __shared__ float tr[32][36];
-  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
   const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
   const int nbp = g.nbpad, Np = g.Npad2;
   const int N = g.N, C = g.C, nb = g.nb;
@@ -620,65 +628,102 @@ __global__ __launch_bounds__(256) void lazy_mfma_step_kernel(LazyGroup g, int t)
   const gtnx_f4* X = reinterpret_cast<const gtnx_f4*>(g.xt[BWD ? ((t + 1) & 1) : (t & 1)]);
   float* Xn = g.xt[BWD ? (t & 1) : ((t + 1) & 1)];
   const gtnx_f4* Em = reinterpret_cast<const gtnx_f4*>(BWD ? g.ETp : g.Ep);
-  // the epilogue's per-row scalars are requested before the product starts: their latency hides under it
   int* keys = reinterpret_cast<int*>(BWD ? g.bmax : g.amax);
   const int64_t plane = int64_t(nb) * N;
   const int o = o0 + lo;
   const bool ocol = o < N;
-  const int lab = ocol ? g.nlab[o] : -1;
-  const float cm = ocol ? g.cmax[o] : NEG_INF;
   const int te = BWD ? t - 1 : t;
-  const float* erow[4];
-  int k_in[4], k_out[4];
+  // ---- this wave's rows after the reduction: registers MF_ROWS wv .. of the summed tile
+  int rowi[MF_ROWS];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {  // this wave's rows after the reduction: 8 wv + v + 4 hi
-    const int b = b0 + 8 * wv + v + 4 * hi;
+  for (int v = 0; v < MF_ROWS; ++v) {
+    const int reg = MF_ROWS * wv + v;
+    rowi[v] = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+  }
+  // the epilogue's per-row scalars are requested first: pointers and keys now, the emission once its row
+  // pointer is there (by then the first operand batch is in flight behind it)
+  const int oc = ocol ? o : N - 1;
+  const int lab_ = g.nlab[oc];
+  const float cm_ = g.cmax[oc];
+  const int lab = ocol ? lab_ : -1;
+  const float cm = ocol ? cm_ : NEG_INF;
+  const float* erow[MF_ROWS];
+  int k_in[MF_ROWS], k_out[MF_ROWS];
+#pragma unroll
+  for (int v = 0; v < MF_ROWS; ++v) {
+    const int b = b0 + rowi[v];
     const int bb = b < nb ? b : 0;
     erow[v] = g.em[bb];
     // reference the input was exponentiated against / the one the next input will be
-    if (!BWD) k_in[v] = t > 0 ? keys[int64_t(t - 1) * nb + bb] : fkey(0.0f);
-    else k_in[v] = t < g.T - 1 ? keys[int64_t(t + 1) * nb + bb] : fkey(0.0f);
+    // (first step of a pass: any valid row, value replaced)
+    const int tk = !BWD ? (t > 0 ? t - 1 : 0) : (t < g.T - 1 ? t + 1 : t);
+    const int kv = keys[int64_t(tk) * nb + bb];
+    k_in[v] = (!BWD ? t > 0 : t < g.T - 1) ? kv : fkey(0.0f);
     k_out[v] = keys[int64_t(t) * nb + bb];
   }
-  float emv[4];
-#pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int b = b0 + 8 * wv + v + 4 * hi;
-    emv[v] = (b < nb && lab >= 0 && te >= 0) ? erow[v][int64_t(te) * C + lab] : 0.0f;
-  }
-  // ---- this wave's quarter of the k groups (4 k each = two MFMAs), eight groups' operands in flight
+  // ---- this wave's share of the k groups (4 k each = two MFMAs)
   const int groups = g.Kpad >> 2;
-  const int g_lo = (groups * wv) / 4, g_hi = (groups * (wv + 1)) / 4;
+  const int g_lo = (groups * wv) / MF_WAVES, g_hi = (groups * (wv + 1)) / MF_WAVES;
   gtnx_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const gtnx_f4* ap = X + b0 + lo;
   const gtnx_f4* bp = Em + o0 + lo;
-  auto mm = [&](const gtnx_f4& a, const gtnx_f4& b) {
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a.y : a.x, hi ? b.y : b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a.w : a.z, hi ? b.w : b.z, acc, 0, 0, 0);
-  };
-  int q = g_lo;
-  for (; q + 8 <= g_hi; q += 8) {
-    gtnx_f4 av[8], bv[8];
+  gtnx_f4 a0[MF_BATCH], e0[MF_BATCH], a1[MF_BATCH], e1[MF_BATCH];
+  // Everything below is straight-line on purpose: a conditional request (or a conditional load of the
+  // emission) would leave the wait before the next multiply at a branch join, where the counter has to be
+  // assumed zero.  Kpad is a multiple of 4 * MF_WAVES * 2 MF_BATCH (zero rows in both operands), so a wave
+  // owns a whole, even number of batches.
+  auto request = [&](gtnx_f4(&a)[MF_BATCH], gtnx_f4(&e)[MF_BATCH], int q0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      av[u] = ap[int64_t(q + u) * nbp];
-      bv[u] = bp[int64_t(q + u) * Np];
+    for (int u = 0; u < MF_BATCH; ++u) {
+      a[u] = ap[int64_t(q0 + u) * nbp];
+      e[u] = bp[int64_t(q0 + u) * Np];
     }
+  };
+  auto multiply = [&](const gtnx_f4(&a)[MF_BATCH], const gtnx_f4(&e)[MF_BATCH]) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) mm(av[u], bv[u]);
+    for (int u = 0; u < MF_BATCH; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a[u].y : a[u].x, hi ? e[u].y : e[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a[u].w : a[u].z, hi ? e[u].w : e[u].z, acc, 0, 0, 0);
+    }
+  };
+  request(a0, e0, g_lo);
+  __builtin_amdgcn_sched_barrier(0);
+  float emv[MF_ROWS];
+#pragma unroll
+  for (int v = 0; v < MF_ROWS; ++v) {  // always a valid address; the value is dropped where it does not apply
+    // (the row pointer came out of memory: typed global here, or it becomes a flat load, which any later
+    // wait on the vector counter would have to treat as zero)
+    const float x = ((const GTNX_G float*)erow[v])[int64_t(te >= 0 ? te : 0) * C + (lab >= 0 ? lab : 0)];
+    emv[v] = (lab >= 0 && te >= 0) ? x : 0.0f;
   }
-  for (; q < g_hi; ++q) mm(ap[int64_t(q) * nbp], bp[int64_t(q) * Np]);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int q = g_lo;;) {  // an even number of batches per wave: the last multiply is outside
+    request(a1, e1, q + MF_BATCH);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(a0, e0);
+    __builtin_amdgcn_sched_barrier(0);
+    q += 2 * MF_BATCH;
+    if (q >= g_hi) break;
+    request(a0, e0, q);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(a1, e1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  multiply(a1, e1);
 #pragma unroll
   for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
   __syncthreads();
-  // ---- epilogue: registers 4 wv .. 4 wv + 3 of the summed tile: rows 8 wv + v + 4 hi, column lo
+  // ---- epilogue: registers MF_ROWS wv .. of the summed tile, column lo
   float* outp = BWD ? g.beta + int64_t(t) * plane : g.alpha + int64_t(t + 1) * plane;
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int i = 8 * wv + v + 4 * hi;
+  for (int v = 0; v < MF_ROWS; ++v) {
+    const int reg = MF_ROWS * wv + v;
+    const int i = rowi[v];
     const int b = b0 + i;
     const bool on = b < nb;
-    const float a = (part[0][4 * wv + v][l] + part[1][4 * wv + v][l]) + (part[2][4 * wv + v][l] + part[3][4 * wv + v][l]);
+    float a = 0.0f;
+#pragma unroll
+    for (int p = 0; p < MF_WAVES; p += 2) a += part[p][reg][l] + part[p + 1][reg][l];
     const float m_in = funkey(k_in[v]), m_out = funkey(k_out[v]);
     float val = NEG_INF, nxt = NEG_INF;  // alpha[t+1] / beta[t]; the next step's contraction input
     if (on && ocol && a > 0.0f && m_in != NEG_INF) {
@@ -701,7 +746,7 @@ __global__ __launch_bounds__(256) void lazy_mfma_step_kernel(LazyGroup g, int t)
   }
   __syncthreads();
   // the next input in operand layout: k group (o0 / 4 + kg), column b0 + bl: one 16-byte store per thread
-  if (!BWD || t >= 1) {
+  if ((!BWD || t >= 1) && threadIdx.x < 256) {
     const int kg = threadIdx.x >> 5, bl = threadIdx.x & 31;  // 8 k groups x 32 columns
     const int k = o0 + 4 * kg;
     if (k < g.Kpad) {
@@ -955,6 +1000,10 @@ void launch_lazy_final(const LazyGroup& g, int mode, hipStream_t st) {
 void launch_lazy_path(const LazyGroup& g, int* path_arc, int* path_il, int* path_ol, float* path_w, int* path_len,
                       hipStream_t st) {
   if (g.nb <= 0) return;
+  if (!g.bp) {  // max-plus regime: the path is re-derived from alpha
+    launch_maxplus_path(g, path_arc, path_il, path_ol, path_w, path_len, st);
+    return;
+  }
   hipLaunchKernelGGL(lazy_path_kernel, dim3((g.nb + 63) / 64), dim3(64), 0, st, g, path_arc, path_il, path_ol, path_w,
                      path_len);
 }
@@ -1029,8 +1078,8 @@ void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st) {
 }
 void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st) {
   const dim3 grid(unsigned(g.Npad2 / 32), unsigned(g.nbpad / 32));
-  if (backward) hipLaunchKernelGGL(lazy_mfma_step_kernel<true>, grid, dim3(256), 0, st, g, t);
-  else hipLaunchKernelGGL(lazy_mfma_step_kernel<false>, grid, dim3(256), 0, st, g, t);
+  if (backward) hipLaunchKernelGGL(lazy_mfma_step_kernel<true>, grid, dim3(MF_WAVES * 64), 0, st, g, t);
+  else hipLaunchKernelGGL(lazy_mfma_step_kernel<false>, grid, dim3(MF_WAVES * 64), 0, st, g, t);
 }
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(lazy_mfma_keys_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, keys, n);

@@ -1742,6 +1742,7 @@ struct LazyGroupState {
   int max_in_deg = 0;
   bool dense = false;               // probability-domain products (lazy.hip "dense regime")
   bool mfma = false;                // ... on the matrix cores (v_mfma_f32_32x32x2_f32)
+  bool maxplus = false;             // tropical semiring over a dense G (maxplus.hip): no back-pointer planes
   DevMemP dense_mem;
   Graph fixed;                      // keeps G alive
   std::vector<Graph> chains;        // per member
@@ -1791,6 +1792,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
       it = index.emplace(k, int(groups.size())).first;
       auto st = std::make_shared<LazyGroupState>();
       st->fixed = lp.fixed;
+      st->view.chain_first = lp.chain_side == 1;
       groups.push_back(st);
       ss.push_back(lp.fixed.s.get());
       ws.push_back(lp.fixed.w.get());
@@ -1827,8 +1829,23 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
       bytes = align_up(bytes + b, 256);
       return o;
     };
+    // tropical semiring over a dense G whose nodes' in-arcs share one matched label: the max-plus sweeps of
+    // maxplus.hip (decided here because they need no back-pointer planes)
+    std::vector<int> mp_lab;
+    if (mode == SD_TROPICAL && !getenv("GTNX_NO_DENSE") && N <= 1024 && N >= 8 && T >= 1) {
+      const bool cf = st.view.chain_first != 0;
+      mp_lab = lazy_node_labels(fs, cf, C, &st.max_in_deg);
+      int64_t valid = 0;
+      const std::vector<int>& ml = cf ? fs.il : fs.ol;
+      for (int l : ml) valid += (l >= 0 && l < C);
+      if (2 * valid < int64_t(N) * N) mp_lab.clear();
+      int ncol = 0;
+      for (int l : mp_lab) ncol += l >= 0;
+      if (ncol == 0) mp_lab.clear();
+    }
+    st.maxplus = !mp_lab.empty();
     const size_t o_alpha = add(4 * plane * size_t(T + 1));
-    const size_t o_bp = mode == SD_LOG ? 0 : add(4 * plane * size_t(T + 1));
+    const size_t o_bp = (mode == SD_LOG || st.maxplus) ? 0 : add(4 * plane * size_t(T + 1));
     const size_t o_score = add(4 * size_t(nb));
     const size_t o_best = add(4 * size_t(nb));
     const size_t o_em = add(8 * size_t(nb));
@@ -1838,7 +1855,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     v.lrec_in = st.arena->as<gtnx_i4>(o_lin);
     v.lrec_out = st.arena->as<gtnx_i4>(o_lout);
     v.alpha = st.arena->as<float>(o_alpha);
-    v.bp = mode == SD_LOG ? nullptr : st.arena->as<int>(o_bp);
+    v.bp = (mode == SD_LOG || st.maxplus) ? nullptr : st.arena->as<int>(o_bp);
     v.score = st.arena->as<float>(o_score);
     v.best = st.arena->as<int>(o_best);
     std::vector<const float*> em(nb);
@@ -1847,6 +1864,38 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     std::memcpy(pin->ptr, em.data(), 8 * size_t(nb));
     rt.h2d(st.arena->as<char>(o_em), pin->ptr, 8 * size_t(nb));
     v.em = reinterpret_cast<const float* const*>(st.arena->as<char>(o_em));
+    if (st.maxplus) {
+      // columns = nodes with a matched in-arc; the others (an ASG start node) are -inf from step 1 on
+      std::vector<int> tab(size_t(N), -1), colnode, dead;
+      for (int n = 0; n < N; ++n) {
+        if (mp_lab[size_t(n)] >= 0) {
+          tab[size_t(n)] = int(colnode.size());
+          colnode.push_back(n);
+        } else {
+          dead.push_back(n);
+        }
+      }
+      v.mp_ncol = int(colnode.size());
+      v.mp_ndead = int(dead.size());
+      v.Kpad = (N + 3) & ~3;
+      v.nbpad = (nb + 63) & ~63;
+      std::vector<int> ints(mp_lab);  // [N] labels | [N] node -> column | columns | dead nodes
+      ints.insert(ints.end(), tab.begin(), tab.end());
+      ints.insert(ints.end(), colnode.begin(), colnode.end());
+      ints.insert(ints.end(), dead.begin(), dead.end());
+      st.labels = upload_vec(ints);
+      st.node_label = st.labels->as<int>();
+      v.nlab = st.node_label;
+      v.mp_colidx = st.node_label + N;
+      v.mp_colnode = v.mp_colidx + N;
+      v.mp_dead = v.mp_colnode + v.mp_ncol;
+      const size_t wf = maxplus_w_floats(v), xf = size_t(v.Kpad) * size_t(v.nbpad);
+      st.dense_mem = rt.alloc(4 * (align_up(wf, 64) + 2 * align_up(xf, 64)));
+      float* base = st.dense_mem->as<float>();
+      v.mp_Wq = base;
+      v.xt[0] = base + align_up(wf, 64);
+      v.xt[1] = v.xt[0] + align_up(xf, 64);
+    }
   }
   // dense regime? (log semiring, one label per node's in-arcs, G nearly complete)
   for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
@@ -1873,7 +1922,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     const size_t o_E = add(4 * nn), o_c = add(4 * size_t(v.N)), o_am = add(4 * size_t(v.T + 1) * size_t(v.nb)),
                  o_bm = add(4 * size_t(v.T + 1) * size_t(v.nb));
     // matrix-core form (lazy.hip: lazy_mfma_*): padded E and its transpose, two transposed input planes
-    v.Kpad = (v.N + 3) & ~3;  // k groups of four (two MFMAs)
+    v.Kpad = (v.N + 287) / 288 * 288;  // zero rows up to an even number of operand batches per wave (lazy.hip: 4 k x 4 waves x 2 x 9 groups)
     v.Npad2 = (v.N + 31) & ~31;
     v.nbpad = (v.nb + 31) & ~31;
     const size_t o_Ep = add(4 * size_t(v.Kpad) * size_t(v.Npad2)), o_ETp = add(4 * size_t(v.Kpad) * size_t(v.Npad2)),
@@ -1895,7 +1944,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
   for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
   for (auto& gp : groups) {
     LazyGroupState& st = *gp;
-    GTNX_PROF(mode == SD_LOG ? "lazy_forward_score" : "lazy_viterbi", 0.0);
+    GTNX_PROF(mode == SD_LOG ? "lazy_forward_score" : (st.maxplus ? "maxplus_viterbi" : "lazy_viterbi"), 0.0);
     launch_lazy_pack(st.view, const_cast<gtnx_i4*>(st.view.lrec_in), const_cast<gtnx_i4*>(st.view.lrec_out), rt.stream());
     launch_lazy_init(st.view, 0, rt.stream());
     if (st.dense) {
@@ -1908,6 +1957,9 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
       } else {
         for (int t = 0; t < st.view.T; ++t) launch_lazy_dense_step(st.view, t, 0, rt.stream());
       }
+    } else if (st.maxplus) {
+      launch_maxplus_prep(st.view, rt.stream());
+      for (int t = 0; t < st.view.T; ++t) launch_maxplus_step(st.view, t, rt.stream());
     } else {
       for (int t = 0; t < st.view.T; ++t) launch_lazy_step(st.view, t, mode, 0, rt.stream());
     }

@@ -631,3 +631,74 @@ def test_band_viterbi_exact_ties_follow_the_reference(gtn):
         assert got[b] == np.float32(score)
         assert paths[b].labels_to_list() == labels
         np.testing.assert_array_equal(ems2[b].grad().weights_to_numpy().reshape(T, C), g_e)
+
+
+def _moore_graph(gtn, N, C, rng, density, integer, dup):
+    """nearly complete graph whose nodes' in-arcs share one label (the dense regime's shape), with
+    missing arcs, parallel arcs of different weight, several start and accept nodes and a node
+    nobody enters"""
+    g = gtn.Graph()
+    for n in range(N):
+        g.add_node(n < 2, n >= N - 3 or n == 1)
+    src, dst, lab, w = [], [], [], []
+    for d in range(1, N):  # node 0 has no in-arc
+        for s in range(N):
+            if rng.random() > density:
+                continue
+            for _ in range(2 if rng.random() < dup else 1):
+                src.append(s)
+                dst.append(d)
+                lab.append(d % C)
+                w.append(float(rng.integers(-2, 3)) if integer else float(rng.normal()))
+    order = rng.permutation(len(src))  # arc ids (and with them in-row order) are not sorted by source
+    a = lambda v, t: np.asarray(v, t)[order]
+    g.add_arcs(a(src, np.int32), a(dst, np.int32), a(lab, np.int32), None, a(w, np.float32))
+    return g
+
+
+@pytest.mark.parametrize("B,T,N,C,integer", [(70, 33, 21, 7, True), (3, 1, 16, 16, False), (130, 20, 40, 40, False),
+                                             (9, 50, 64, 11, True)])
+def test_maxplus_viterbi_matches_the_record_walking_kernels(gtn, B, T, N, C, integer):
+    """maxplus.hip (dense G, tropical semiring: max-plus sweeps without back-pointer planes + back-trace
+    from alpha) against the record-walking kernels of lazy.hip (GTNX_NO_DENSE=1), which the oracle pins:
+    scores, path labels and weights, and the one-hot gradients must be IDENTICAL, exact ties (integer
+    weights), parallel arcs, missing arcs and -inf weights included"""
+    res = {}
+    for name in ("walk", "maxplus"):
+        if name == "walk":
+            os.environ["GTNX_NO_DENSE"] = "1"
+        try:
+            with lazy_mode("1"):
+                rng = np.random.default_rng(1234 + N)
+                g = _moore_graph(gtn, N, C, rng, 0.85, integer, 0.15)
+                w = g.weights_to_numpy()
+                w[rng.integers(0, len(w), 5)] = -np.inf
+                g.set_weights(w)
+                em = (rng.integers(-3, 4, (B, T, C)) if integer else rng.normal(0, 2, (B, T, C))).astype(np.float32)
+                em[0, 0, : C // 2] = -np.inf
+                ems = []
+                for b in range(B):
+                    e = gtn.linear_graph(T, C)
+                    e.set_weights(em[b])
+                    ems.append(e)
+                comp = gtn.compose(ems, [g])
+                gtn.prof_reset()
+                gtn.prof_enable(True)
+                vs = gtn.viterbi_score(comp)
+                paths = gtn.viterbi_path(comp)
+                gtn.prof_enable(False)
+                assert ("maxplus_viterbi" in gtn.prof_names()) == (name == "maxplus")
+                gtn.backward(vs)
+                res[name] = (gtn.items(vs), [p.labels_to_list() for p in paths], [p.weights_to_numpy() for p in paths],
+                             [e.grad().weights_to_numpy() for e in ems], g.grad().weights_to_numpy())
+        finally:
+            os.environ.pop("GTNX_NO_DENSE", None)
+    a, b = res["walk"], res["maxplus"]
+    np.testing.assert_array_equal(b[0], a[0])
+    assert b[1] == a[1]
+    for x, y in zip(b[2], a[2]):
+        np.testing.assert_array_equal(x, y)
+    for x, y in zip(b[3], a[3]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(b[4], a[4])
+    assert np.isfinite(a[0]).sum() > 0

@@ -328,7 +328,8 @@ struct LazyGroup {          // utterances that share one explicit graph G
   float* xt[2];               // [Kpad / 4][nbpad][4] the contraction input, exponentiated, in operand layout (two planes)
   const float* Ep;            // [Kpad / 4][Npad2][4] E zero-padded
   const float* ETp;           // [Kpad / 4][Npad2][4] its transpose
-  int Kpad, Npad2, nbpad;     // N rounded up to 4 / to 32; nb rounded up to 32 (max-plus form: to 64)
+  int Kpad, Npad2, nbpad;     // N rounded up to operand batches / to 32; nb rounded up to 32 (max-plus form: to 64)
+  int rot;                    // leading nodes without a matched in-arc: the planes index nodes rotated by this many
   // max-plus form of the dense regime (tropical semiring; maxplus.hip): xt holds alpha itself
   const float* mp_Wq;         // [dblock][Kpad / 2][16][2] largest weight per (source, destination column), -inf: no arc
   const int* mp_colidx;       // [N] node -> destination column, -1 for nodes without a matched in-arc

@@ -563,13 +563,21 @@ __global__ __launch_bounds__(kDense) void lazy_dense_step_kernel(LazyGroup g, in
 // matrix cores busy for 257 MFMAs each.
 // =====================================================================================
 typedef float gtnx_f16v __attribute__((ext_vector_type(16)));
+typedef float mf_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int fkey(float x) {
   const int b = __float_as_int(x);
   return b >= 0 ? b : b ^ 0x7fffffff;
 }
 __device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
 
-// Layout of both MFMA operands: [k / 4][column][k % 4] -- a lane's 16-byte load brings the four
+// Slots.  Leading nodes without a matched in-arc (the start node of an ASG transitions graph) are dead
+// from step 1 on in both sweeps: alpha is -inf there, and beta only ever meets that alpha.  The operand
+// planes index nodes ROTATED by their number (g.rot): live nodes first, so that C4's 513 nodes are 16
+// column tiles of 32, one per CU, not 17 (the odd tile would double the time of the CUs that get two).
+__device__ __forceinline__ int mf_node(const LazyGroup& g, int slot) { return slot + g.rot < g.N ? slot + g.rot : slot + g.rot - g.N; }
+__device__ __forceinline__ int mf_slot(const LazyGroup& g, int node) { return node >= g.rot ? node - g.rot : node + g.N - g.rot; }
+
+// Layout of both MFMA operands: [k / 4][column][k % 4] -- a lane's 8-byte load brings two of the four
 // consecutive k of ITS column (two MFMAs' worth), 32 lanes cover 512 contiguous bytes.
 // X_0 = exp(alpha[0]) (ref 0), amax key of row 0; or, backward, the input of step T-1:
 // q = beta[T] + em[T-1] + cmax, X = exp(q) (ref 0), bmax key of row T-1
@@ -589,7 +597,8 @@ __global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
         v = lab < 0 ? NEG_INF : g.em[b][int64_t(g.T - 1) * g.C + lab] + g.cmax[k];
       }
     }
-    X[(int64_t(k >> 2) * g.nbpad + b) * 4 + (k & 3)] = v == NEG_INF ? 0.0f : __expf(v);
+    const int j = k < N ? mf_slot(g, k) : k;
+    X[(int64_t(j >> 2) * g.nbpad + b) * 4 + (j & 3)] = v == NEG_INF ? 0.0f : __expf(v);
     m = fmaxf(m, v);
   }
   __shared__ float red[4];
@@ -614,13 +623,20 @@ __global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
 // before either.
 constexpr int MF_WAVES = 4;
 constexpr int MF_ROWS = 16 / MF_WAVES;  // accumulator registers (tile rows per half-wave) a wave finishes
-constexpr int MF_BATCH = 9;  // k groups (two MFMAs each) per operand batch: two batches cover a wave's 16-17 groups at C4
+constexpr int MF_BATCH = 18;  // k groups (two MFMAs each) per operand batch: two batches are a wave's quarter of C4's 576 padded sources
 template <bool BWD>
 __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup g, int t) {
   __shared__ float part[MF_WAVES][16][64];
   __shared__ float tr[32][36];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
-  const int o0 = blockIdx.x * 32, b0 = blockIdx.y * 32;
+  // Workgroups go to the 8 XCDs in turn, and every kernel boundary empties their L2s: XCD x takes a
+  // contiguous run of tiles in row-major order (all column tiles of its two row tiles at C4), so it
+  // re-fetches only its own rows of the input plane, not all of it
+  const int Nl = g.N - g.rot;  // live slots
+  const int ncol = (Nl + 31) >> 5, total = gridDim.x;
+  const int xcd = blockIdx.x & 7, per = total >> 3, rem = total & 7;
+  const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int o0 = (tile % ncol) * 32, b0 = (tile / ncol) * 32;
   const int nbp = g.nbpad, Np = g.Npad2;
   const int N = g.N, C = g.C, nb = g.nb;
   // FWD: step t turns alpha[t] (X in plane t & 1) into alpha[t+1] (plane (t+1) & 1)
@@ -630,8 +646,9 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
   const gtnx_f4* Em = reinterpret_cast<const gtnx_f4*>(BWD ? g.ETp : g.Ep);
   int* keys = reinterpret_cast<int*>(BWD ? g.bmax : g.amax);
   const int64_t plane = int64_t(nb) * N;
-  const int o = o0 + lo;
-  const bool ocol = o < N;
+  const int o = o0 + lo;      // slot
+  const bool ocol = o < Nl;
+  const int on_ = mf_node(g, ocol ? o : 0);  // its node: labels, column maxima and the score planes are by node
   const int te = BWD ? t - 1 : t;
   // ---- this wave's rows after the reduction: registers MF_ROWS wv .. of the summed tile
   int rowi[MF_ROWS];
@@ -642,9 +659,8 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
   }
   // the epilogue's per-row scalars are requested first: pointers and keys now, the emission once its row
   // pointer is there (by then the first operand batch is in flight behind it)
-  const int oc = ocol ? o : N - 1;
-  const int lab_ = g.nlab[oc];
-  const float cm_ = g.cmax[oc];
+  const int lab_ = g.nlab[on_];
+  const float cm_ = g.cmax[on_];
   const int lab = ocol ? lab_ : -1;
   const float cm = ocol ? cm_ : NEG_INF;
   const float* erow[MF_ROWS];
@@ -664,26 +680,31 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
   // ---- this wave's share of the k groups (4 k each = two MFMAs)
   const int groups = g.Kpad >> 2;
   const int g_lo = (groups * wv) / MF_WAVES, g_hi = (groups * (wv + 1)) / MF_WAVES;
+  // Operand layout [k / 4][column][k % 4]: the half-wave hi reads the 8 bytes holding k slots 2 hi, 2 hi + 1
+  // of ITS column -- the first MFMA of a group contracts slots {0, 2}, the second {1, 3} (same split in
+  // both operands, so the four slots are summed once each) -- no lane loads a value it does not multiply.
+  // Two accumulators: consecutive MFMAs do not wait for each other's result.
   gtnx_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const gtnx_f4* ap = X + b0 + lo;
-  const gtnx_f4* bp = Em + o0 + lo;
-  gtnx_f4 a0[MF_BATCH], e0[MF_BATCH], a1[MF_BATCH], e1[MF_BATCH];
+  gtnx_f16v acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const mf_f2* ap = reinterpret_cast<const mf_f2*>(X) + (b0 + lo) * 2 + hi;
+  const mf_f2* bp = reinterpret_cast<const mf_f2*>(Em) + (o0 + lo) * 2 + hi;
+  mf_f2 a0[MF_BATCH], e0[MF_BATCH], a1[MF_BATCH], e1[MF_BATCH];
   // Everything below is straight-line on purpose: a conditional request (or a conditional load of the
   // emission) would leave the wait before the next multiply at a branch join, where the counter has to be
   // assumed zero.  Kpad is a multiple of 4 * MF_WAVES * 2 MF_BATCH (zero rows in both operands), so a wave
   // owns a whole, even number of batches.
-  auto request = [&](gtnx_f4(&a)[MF_BATCH], gtnx_f4(&e)[MF_BATCH], int q0) {
+  auto request = [&](mf_f2(&a)[MF_BATCH], mf_f2(&e)[MF_BATCH], int q0) {
 #pragma unroll
     for (int u = 0; u < MF_BATCH; ++u) {
-      a[u] = ap[int64_t(q0 + u) * nbp];
-      e[u] = bp[int64_t(q0 + u) * Np];
+      a[u] = ap[int64_t(q0 + u) * nbp * 2];
+      e[u] = bp[int64_t(q0 + u) * Np * 2];
     }
   };
-  auto multiply = [&](const gtnx_f4(&a)[MF_BATCH], const gtnx_f4(&e)[MF_BATCH]) {
+  auto multiply = [&](const mf_f2(&a)[MF_BATCH], const mf_f2(&e)[MF_BATCH]) {
 #pragma unroll
     for (int u = 0; u < MF_BATCH; ++u) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a[u].y : a[u].x, hi ? e[u].y : e[u].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(hi ? a[u].w : a[u].z, hi ? e[u].w : e[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, e[u].x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, e[u].y, acc2, 0, 0, 0);
     }
   };
   request(a0, e0, g_lo);
@@ -710,6 +731,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     __builtin_amdgcn_sched_barrier(0);
   }
   multiply(a1, e1);
+  acc += acc2;
 #pragma unroll
   for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
   __syncthreads();
@@ -735,7 +757,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
         nxt = val + emv[v] + cm;
       }
     }
-    if (on && ocol) outp[int64_t(b) * N + o] = val;
+    if (on && ocol) outp[int64_t(b) * N + on_] = val;
     // row maximum of the next input over this tile's 32 columns -> its key
     float rm = nxt;
 #pragma unroll
@@ -751,13 +773,25 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     const int k = o0 + 4 * kg;
     if (k < g.Kpad) {
       gtnx_f4 w4;
-      w4.x = (k + 0 < N) ? tr[bl][4 * kg + 0] : 0.0f;
-      w4.y = (k + 1 < N) ? tr[bl][4 * kg + 1] : 0.0f;
-      w4.z = (k + 2 < N) ? tr[bl][4 * kg + 2] : 0.0f;
-      w4.w = (k + 3 < N) ? tr[bl][4 * kg + 3] : 0.0f;
+      w4.x = (k + 0 < Nl) ? tr[bl][4 * kg + 0] : 0.0f;
+      w4.y = (k + 1 < Nl) ? tr[bl][4 * kg + 1] : 0.0f;
+      w4.z = (k + 2 < Nl) ? tr[bl][4 * kg + 2] : 0.0f;
+      w4.w = (k + 3 < Nl) ? tr[bl][4 * kg + 3] : 0.0f;
       reinterpret_cast<gtnx_f4*>(Xn)[int64_t(k >> 2) * nbp + b0 + bl] = w4;
     }
   }
+  // the dead leading nodes' scores, by the first column tile of every row tile
+  if (o0 == 0 && threadIdx.x < 32 && b0 + int(threadIdx.x) < nb)
+    for (int n = 0; n < g.rot; ++n) outp[int64_t(b0 + threadIdx.x) * N + n] = NEG_INF;
+}
+
+// after the first forward step: the dead slots of plane 0 still hold exp(alpha[0]) (a start node's 1)
+__global__ void lazy_mfma_dead_rows_kernel(LazyGroup g, float* X, int j_lo) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t n = int64_t(g.Kpad - j_lo) * g.nbpad;
+  if (i >= n) return;
+  const int j = j_lo + int(i / g.nbpad), b = int(i % g.nbpad);
+  X[(int64_t(j >> 2) * g.nbpad + b) * 4 + (j & 3)] = 0.0f;
 }
 
 // keys -> floats, once a pass is through
@@ -772,8 +806,9 @@ __global__ void lazy_mfma_pad_kernel(LazyGroup g, float* Ep, float* ETp) {
   const int k = int(i / g.Npad2), c = int(i % g.Npad2);
   const bool in = k < g.N && c < g.N;
   const int64_t at = (int64_t(k >> 2) * g.Npad2 + c) * 4 + (k & 3);
-  Ep[at] = in ? g.E[int64_t(k) * g.N + c] : 0.0f;
-  ETp[at] = in ? g.E[int64_t(c) * g.N + k] : 0.0f;
+  const int kn = in ? mf_node(g, k) : 0, cn = in ? mf_node(g, c) : 0;  // slots -> nodes
+  Ep[at] = in ? g.E[int64_t(kn) * g.N + cn] : 0.0f;
+  ETp[at] = in ? g.E[int64_t(cn) * g.N + kn] : 0.0f;
 }
 
 // R[s][d] += sum over a slice of (t, b) pairs of A'[s] * Q'[d], with the pair's two
@@ -1077,9 +1112,14 @@ void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st) {
   else hipLaunchKernelGGL(lazy_mfma_init_kernel<false>, dim3(g.nbpad), dim3(256), 0, st, g);
 }
 void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st) {
-  const dim3 grid(unsigned(g.Npad2 / 32), unsigned(g.nbpad / 32));
+  const int Nl = g.N - g.rot;
+  const dim3 grid(unsigned((Nl + 31) / 32) * unsigned(g.nbpad / 32));
   if (backward) hipLaunchKernelGGL(lazy_mfma_step_kernel<true>, grid, dim3(MF_WAVES * 64), 0, st, g, t);
   else hipLaunchKernelGGL(lazy_mfma_step_kernel<false>, grid, dim3(MF_WAVES * 64), 0, st, g, t);
+  if (!backward && t == 0 && g.rot > 0) {
+    const int64_t n = int64_t(g.Kpad - Nl) * g.nbpad;
+    hipLaunchKernelGGL(lazy_mfma_dead_rows_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, g, g.xt[0], Nl);
+  }
 }
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(lazy_mfma_keys_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, keys, n);

@@ -186,28 +186,40 @@ __global__ __launch_bounds__(MP_WAVES * 64) void maxplus_step_kernel(LazyGroup g
   }
 }
 
-// ---- back-trace (shortest.cpp:239-260): one wave per utterance.  The previous step's alpha row is
-// requested one step ahead and parked in LDS, so the per-step chain is in_off -> records -> LDS.
+// ---- back-trace (shortest.cpp:239-260): one wave per utterance.  A step's chain is kept to ONE trip to
+// memory (the visited node's in-records): row offsets and labels of G sit in LDS, the alpha row and the
+// emission row of the step after next are requested while the current step is reduced and parked in LDS,
+// and the winner's source / arc come from the winning lane by cross-lane read instead of a second load.
+constexpr int MP_EMROW = 1024;  // emission rows up to this many labels are staged (else one load per step)
 __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path_arc, int* path_il, int* path_ol,
                                                          float* path_w, int* path_len) {
-  extern __shared__ float rows[];  // [2][N]
+  extern __shared__ float lds[];
   const int b = blockIdx.x, l = threadIdx.x;
   const int N = g.N, C = g.C, T = g.T;
+  const bool stage_em = C <= MP_EMROW;
+  float* rows = lds;                                   // [2][N] alpha[t-1] / alpha[t-2]
+  float* erows = rows + 2 * N;                         // [2][C] (stage_em)
+  int* ioff = reinterpret_cast<int*>(erows + (stage_em ? 2 * C : 0));  // [N + 1]
+  int* nlab = ioff + N + 1;                            // [N]
   const int64_t plane = int64_t(g.nb) * N;
   int node = g.best[b];
-  if (node < 0) {  // no accepting path: the trimmed product is the empty graph
-    if (l == 0) path_len[b] = -1;
+  if (node < 0 || T < 1) {  // no accepting path: the trimmed product is the empty graph
+    if (l == 0) path_len[b] = node < 0 ? -1 : 0;
     return;
   }
-  const float* em = g.em[b];
+  for (int n = l; n <= N; n += 64) ioff[n] = g.g.in_off[n];
+  for (int n = l; n < N; n += 64) nlab[n] = g.nlab[n];
+  const GTNX_G float* em = (const GTNX_G float*)g.em[b];
   const float* arow = g.alpha + int64_t(b) * N;
   constexpr int RMAX = 16;  // N <= 1024 in this regime
-  float pre[RMAX];
-  auto fetch = [&](int t) {  // alpha[t]
+  constexpr int RB = 8;
+  float pre[RMAX], pe[RMAX];
+  auto fetch = [&](int t) {  // alpha[t] and the emission row of step t
 #pragma unroll
     for (int i = 0; i < RMAX; ++i) {
       const int n = l + 64 * i;
       pre[i] = n < N ? arow[int64_t(t) * plane + n] : NEG_INF;
+      pe[i] = (stage_em && n < C) ? em[int64_t(t) * C + n] : 0.0f;
     }
   };
   auto park = [&](int buf) {
@@ -215,28 +227,40 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     for (int i = 0; i < RMAX; ++i) {
       const int n = l + 64 * i;
       if (n < N) rows[buf * N + n] = pre[i];
+      if (stage_em && n < C) erows[buf * C + n] = pe[i];
     }
   };
-  if (T >= 1) {
-    fetch(T - 1);
-    park((T - 1) & 1);
-  }
+  fetch(T - 1);
+  park((T - 1) & 1);
   __syncthreads();
   for (int t = T; t >= 1; --t) {
     if (t >= 2) fetch(t - 2);
     const float* prev = rows + ((t - 1) & 1) * N;
-    const int lab = g.nlab[node];  // every matched in-arc of `node` carries this label
-    const float e = lab >= 0 ? em[int64_t(t - 1) * C + lab] : 0.0f;
-    const int k0 = g.g.in_off[node], k1 = g.g.in_off[node + 1];
+    const int lab = nlab[node];  // every matched in-arc of `node` carries this label
+    const float e = lab < 0 ? 0.0f : (stage_em ? erows[((t - 1) & 1) * C + lab] : em[int64_t(t - 1) * C + lab]);
+    const int k0 = ioff[node], k1 = ioff[node + 1];
     float m = NEG_INF;
-    int arg = INT_MAX;
-    for (int k = k0 + l; k < k1; k += 64) {
-      const gtnx_i4 r = g.lrec_in[k];
-      if (r.y >= 0) {
-        const float x = prev[r.x] + __int_as_float(r.z) + e;
-        if (x > m) {
-          m = x;
-          arg = k;
+    int arg = INT_MAX, bsrc = 0, barc = 0;
+    // the in-row, eight records per lane at a time, all requested before the first is looked at (one
+    // exposed trip to memory per 512 records, not one per record)
+    for (int kb = k0; kb < k1; kb += 64 * RB) {
+      gtnx_i4 r[RB];
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int k = kb + l + 64 * i;
+        r[i] = g.lrec_in[k < k1 ? k : k1 - 1];
+      }
+#pragma unroll
+      for (int i = 0; i < RB; ++i) {
+        const int k = kb + l + 64 * i;
+        if (k < k1 && r[i].y >= 0) {
+          const float x = prev[r[i].x] + __int_as_float(r[i].z) + e;
+          if (x > m) {
+            m = x;
+            arg = k;
+            bsrc = r[i].x;
+            barc = r[i].w;
+          }
         }
       }
     }
@@ -253,18 +277,19 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
       if (l == 0) path_len[b] = -1;
       return;
     }
-    const gtnx_i4 r = g.lrec_in[arg];
+    const int wl = (arg - k0) & 63;  // record k sits with lane (k - k0) mod 64
+    bsrc = __shfl(bsrc, wl, 64);
+    barc = __shfl(barc, wl, 64);
     if (l == 0) {
-      const int arc = r.w;
       const int64_t o = int64_t(b) * T + (t - 1);
-      path_arc[o] = arc;
-      path_il[o] = g.chain_first ? r.y : g.g.il[arc];
-      path_ol[o] = g.chain_first ? g.g.ol[arc] : r.y;
-      path_w[o] = g.g.w[arc] + e;
+      path_arc[o] = barc;
+      path_il[o] = g.chain_first ? lab : g.g.il[barc];
+      path_ol[o] = g.chain_first ? g.g.ol[barc] : lab;
+      path_w[o] = g.g.w[barc] + e;
     }
-    node = r.x;
+    node = bsrc;
     if (t >= 2) {
-      park(t & 1);  // alpha[t-2] -> the buffer alpha[t] sat in ((t - 2) & 1 == t & 1)
+      park(t & 1);  // step t-2's rows -> the buffers step t's sat in ((t - 2) & 1 == t & 1)
       __syncthreads();
     }
   }
@@ -297,8 +322,8 @@ void launch_maxplus_step(const LazyGroup& g, int t, hipStream_t st) {
 void launch_maxplus_path(const LazyGroup& g, int* path_arc, int* path_il, int* path_ol, float* path_w, int* path_len,
                          hipStream_t st) {
   if (g.nb <= 0) return;
-  hipLaunchKernelGGL(maxplus_path_kernel, dim3(g.nb), dim3(64), size_t(2) * g.N * sizeof(float), st, g, path_arc, path_il,
-                     path_ol, path_w, path_len);
+  const size_t lds = sizeof(float) * (size_t(4) * g.N + 1 + (g.C <= MP_EMROW ? size_t(2) * g.C : 0));
+  hipLaunchKernelGGL(maxplus_path_kernel, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
 }
 
 }  // namespace gtnx

@@ -1922,7 +1922,9 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     const size_t o_E = add(4 * nn), o_c = add(4 * size_t(v.N)), o_am = add(4 * size_t(v.T + 1) * size_t(v.nb)),
                  o_bm = add(4 * size_t(v.T + 1) * size_t(v.nb));
     // matrix-core form (lazy.hip: lazy_mfma_*): padded E and its transpose, two transposed input planes
-    v.Kpad = (v.N + 287) / 288 * 288;  // zero rows up to an even number of operand batches per wave (lazy.hip: 4 k x 4 waves x 2 x 9 groups)
+    v.rot = 0;
+    while (v.rot < v.N - 1 && lab[size_t(v.rot)] < 0) ++v.rot;
+    v.Kpad = (v.N + 575) / 576 * 576;  // zero rows up to an even number of operand batches per wave (lazy.hip: 4 k x 4 waves x 2 x 18 groups)
     v.Npad2 = (v.N + 31) & ~31;
     v.nbpad = (v.nb + 31) & ~31;
     const size_t o_Ep = add(4 * size_t(v.Kpad) * size_t(v.Npad2)), o_ETp = add(4 * size_t(v.Kpad) * size_t(v.Npad2)),
@@ -2904,9 +2906,9 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
     float* pw = reinterpret_cast<float*>(pol + nT);
     int* plen = reinterpret_cast<int*>(pw + nT);
     launch_lazy_path(v, parc, pil, pol, pw, plen, rt.stream());
-    std::vector<char> host(pbytes);
-    rt.d2h_sync(host.data(), pm->ptr, pbytes);
-    const int* harc = reinterpret_cast<const int*>(host.data());
+    PinnedMemP host = rt.alloc_pinned(pbytes ? pbytes : 1);  // 16 B per path arc: pageable memory would be staged and slow
+    rt.d2h_sync(host->ptr, pm->ptr, pbytes);
+    const int* harc = host->as<int>();
     const int* hil = harc + nT;
     const int* hol = hil + nT;
     const float* hw = reinterpret_cast<const float*>(hol + nT);

@@ -891,39 +891,64 @@ __global__ void lazy_mfma_pairs_kernel(LazyGroup g, gtnx_f4* pc) {
   pc[p] = c;
 }
 
+// One wave owns a 64 x 64 block of R (2 x 2 MFMA tiles: every exponentiated operand feeds two MFMAs, so a
+// pair costs 6 loads + 4 v_exp_f32 per FOUR MFMAs) and an interleaved quarter of the workgroup's pairs; the
+// four waves' partial blocks meet in LDS.  Blocks are taken in SLOT space (mf_slot: live nodes first):
+// a destination block of dead nodes has nothing to add, a source block of dead nodes (an ASG start node)
+// only the pairs of step 0 -- at C4 that leaves 8 x 8 full blocks instead of 9 x 9 ragged ones.
 __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_kernel(LazyGroup g, const gtnx_f4* __restrict__ pc,
                                                                   int pairs_per_block) {
-  __shared__ float part[4][16][64];
+  __shared__ float part[4][32][64];
   const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
-  const int s0 = blockIdx.x * 32, d0 = blockIdx.y * 32;
-  const int N = g.N, C = g.C, nb = g.nb;
+  const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+  const int N = g.N, C = g.C, nb = g.nb, Nl = g.N - g.rot;
   const int64_t plane = int64_t(nb) * N;
-  const int64_t npairs = int64_t(g.T) * nb;
+  int64_t npairs = int64_t(g.T) * nb;
+  if (d0 >= Nl) return;                 // destinations without a matched in-arc: no arc, no gradient
+  if (s0 >= Nl) npairs = nb;            // sources that are dead from step 1 on: alpha is -inf beyond step 0
   const int64_t p0 = int64_t(blockIdx.z) * pairs_per_block, p1 = min(npairs, p0 + pairs_per_block);
-  const int s = s0 + lo, d = d0 + lo;
-  const bool sok = s < N;
-  const int lab = d < N ? g.nlab[d] : -1;
-  gtnx_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (p0 >= p1) return;
+  // this lane's two source nodes and two destination nodes (slots s0 + lo, s0 + 32 + lo; likewise d)
+  int sn[2], dn[2], lab[2];
+  bool sok[2], dok[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ss = s0 + 32 * h + lo, dd = d0 + 32 * h + lo;
+    sok[h] = ss < N;
+    dok[h] = dd < N;
+    sn[h] = mf_node(g, sok[h] ? ss : 0);
+    dn[h] = mf_node(g, dok[h] ? dd : 0);
+    const int lb = g.nlab[dn[h]];
+    lab[h] = dok[h] ? lb : -1;
+  }
+  const int labc[2] = {lab[0] >= 0 ? lab[0] : 0, lab[1] >= 0 ? lab[1] : 0};
+  gtnx_f16v acc00 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, acc01 = acc00, acc10 = acc00, acc11 = acc00;
   // wave wv takes the pairs p0 + 2 wv + hi, + 8, + 16, ...: one MFMA contracts two pairs.  (t, b) of a
   // lane's pair advance incrementally (no division in the loop); loads are unconditional (clamped) so
-  // that four MFMAs' operands are in flight together
-  const int sc = sok ? s : N - 1, dc = d < N ? d : N - 1, labc = lab >= 0 ? lab : 0;
+  // that two rounds' operands are in flight together
   int pp = int(p0) + 2 * wv + hi;
   int t = pp / nb, b = pp - t * nb;
-  const int pend = int(p1), plast = int(npairs) - 1;
-  for (; pp - hi < pend; ) {
-    float al[4], be[4], ev[4];
-    gtnx_f4 c[4];
+  const int pend = int(p1), plast = int(p1) - 1;
+  constexpr int UR = 2;
+  for (; pp - hi < pend;) {
+    float al[UR][2], be[UR][2], ev[UR][2];
+    gtnx_f4 c[UR];
     int tt = t, bb = b, pq = pp;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UR; ++u) {
       const bool in = pq < pend;
       const int tc = in ? tt : 0, bc = in ? bb : 0;
       c[u] = pc[in ? pq : plast];
       if (!in) c[u].w = 0.0f;
-      al[u] = g.alpha[int64_t(tc) * plane + int64_t(bc) * N + sc];
-      be[u] = g.beta[int64_t(tc + 1) * plane + int64_t(bc) * N + dc];
-      ev[u] = g.em[bc][int64_t(tc) * C + labc];
+      const float* ar = g.alpha + int64_t(tc) * plane + int64_t(bc) * N;
+      const float* br = g.beta + int64_t(tc + 1) * plane + int64_t(bc) * N;
+      const GTNX_G float* er = (const GTNX_G float*)g.em[bc] + int64_t(tc) * C;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        al[u][h] = ar[sn[h]];
+        be[u][h] = br[dn[h]];
+        ev[u][h] = er[labc[h]];
+      }
       pq += 8;
       bb += 8;
       while (bb >= nb) {
@@ -935,21 +960,40 @@ __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_kernel(LazyGroup g, 
     b = bb;
     pp = pq;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < UR; ++u) {
       const bool on = c[u].w != 0.0f;
-      const float a = (on && sok && al[u] != NEG_INF) ? __expf(al[u] + c[u].x) : 0.0f;
-      const float bq = (on && lab >= 0 && be[u] != NEG_INF) ? __expf(ev[u] + be[u] + c[u].y) * c[u].z : 0.0f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc, 0, 0, 0);
+      float a[2], q[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        a[h] = (on && sok[h] && al[u][h] != NEG_INF) ? __expf(al[u][h] + c[u].x) : 0.0f;
+        q[h] = (on && lab[h] >= 0 && be[u][h] != NEG_INF) ? __expf(ev[u][h] + be[u][h] + c[u].y) * c[u].z : 0.0f;
+      }
+      acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc00, 0, 0, 0);
+      acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[1], acc01, 0, 0, 0);
+      acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[0], acc10, 0, 0, 0);
+      acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc11, 0, 0, 0);
     }
   }
+  // ---- the four waves' partial blocks, two tiles (32 registers) at a time through LDS; wave wv then adds
+  // registers 8 wv .. 8 wv + 7 of the pair of tiles into R
 #pragma unroll
-  for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
-  __syncthreads();
+  for (int half = 0; half < 2; ++half) {  // half: source rows s0 + 32 half ..
+    if (half) __syncthreads();
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int i = 8 * wv + v + 4 * hi;  // row (source node) of register 4 wv + v
-    const float a = (part[0][4 * wv + v][l] + part[1][4 * wv + v][l]) + (part[2][4 * wv + v][l] + part[3][4 * wv + v][l]);
-    if (s0 + i < N && d < N && a != 0.0f) atomicAdd(&g.R[int64_t(s0 + i) * N + d], a);
+    for (int v = 0; v < 16; ++v) {
+      part[wv][v][l] = half ? acc10[v] : acc00[v];
+      part[wv][16 + v][l] = half ? acc11[v] : acc01[v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const int r = 8 * wv + v;            // 0..15: destination tile 0, 16..31: tile 1
+      const int reg = r & 15, dh = r >> 4;
+      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hi;  // row of the tile
+      const float a = (part[0][r][l] + part[1][r][l]) + (part[2][r][l] + part[3][r][l]);
+      const int ss = s0 + 32 * half + i;
+      if (ss < N && dok[dh] && a != 0.0f) atomicAdd(&g.R[int64_t(mf_node(g, ss)) * N + dn[dh]], a);
+    }
   }
 }
 // grad[a] += exp(w[a]) * R[src][dst]  (the balancing shifts of A' and Q' cancel exactly:
@@ -1130,7 +1174,7 @@ void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStrea
   gtnx_f4* pc = static_cast<gtnx_f4*>(pair_consts);
   hipLaunchKernelGGL(lazy_mfma_pairs_kernel, dim3(unsigned((npairs + 255) / 256)), dim3(256), 0, st, g, pc);
   const int pairs_per_block = 16384;
-  const dim3 grid(unsigned((g.N + 31) / 32), unsigned((g.N + 31) / 32), unsigned((npairs + pairs_per_block - 1) / pairs_per_block));
+  const dim3 grid(unsigned((g.N + 63) / 64), unsigned((g.N + 63) / 64), unsigned((npairs + pairs_per_block - 1) / pairs_per_block));
   hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
   if (g.g.A > 0) hipLaunchKernelGGL(lazy_dense_arc_grad_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g);
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kTile) void lazy_step_kernel(LazyGroup g, int t) {
     if (k + RC < k1) fetch(k + RC);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int cnt = min(RC, k1 - k);
-    constexpr int UR = 4;  // arcs whose LDS gathers are in flight together
+    constexpr int UR = 2;  // arcs whose LDS gathers are in flight together
     for (int u0 = 0; u0 < cnt; u0 += UR) {
       gtnx_i4 r[UR];
       float x[UR];

@@ -190,6 +190,22 @@ __global__ __launch_bounds__(MP_WAVES * 64) void maxplus_step_kernel(LazyGroup g
 // memory (the visited node's in-records): row offsets and labels of G sit in LDS, the alpha row and the
 // emission row of the step after next are requested while the current step is reduced and parked in LDS,
 // and the winner's source / arc come from the winning lane by cross-lane read instead of a second load.
+// wave-wide reductions by DPP (result in every lane)
+#define MP_DPP6(op)                                            \
+  "s_nop 1\n\t" op " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"  \
+  op " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+  op " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+  op " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+  op " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"             \
+  op " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"
+__device__ __forceinline__ float wave_max63(float x) {
+  asm volatile(MP_DPP6("v_max_f32_dpp") : "+v"(x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ int wave_min63(int x) {
+  asm volatile(MP_DPP6("v_min_i32_dpp") : "+v"(x));
+  return __builtin_amdgcn_readlane(x, 63);
+}
 constexpr int MP_EMROW = 1024;  // emission rows up to this many labels are staged (else one load per step)
 __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path_arc, int* path_il, int* path_ol,
                                                          float* path_w, int* path_len) {
@@ -214,12 +230,14 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
   constexpr int RMAX = 16;  // N <= 1024 in this regime
   constexpr int RB = 8;
   float pre[RMAX], pe[RMAX];
+  // (always valid addresses, no branches: a conditional request would turn the counted wait for the
+  // records, which are requested BEFORE these rows and so return before them, into a wait for everything)
   auto fetch = [&](int t) {  // alpha[t] and the emission row of step t
 #pragma unroll
     for (int i = 0; i < RMAX; ++i) {
       const int n = l + 64 * i;
-      pre[i] = n < N ? arow[int64_t(t) * plane + n] : NEG_INF;
-      pe[i] = (stage_em && n < C) ? em[int64_t(t) * C + n] : 0.0f;
+      pre[i] = arow[int64_t(t) * plane + (n < N ? n : N - 1)];
+      pe[i] = stage_em ? em[int64_t(t) * C + (n < C ? n : C - 1)] : 0.0f;
     }
   };
   auto park = [&](int buf) {
@@ -234,7 +252,6 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
   park((T - 1) & 1);
   __syncthreads();
   for (int t = T; t >= 1; --t) {
-    if (t >= 2) fetch(t - 2);
     const float* prev = rows + ((t - 1) & 1) * N;
     const int lab = nlab[node];  // every matched in-arc of `node` carries this label
     const float e = lab < 0 ? 0.0f : (stage_em ? erows[((t - 1) & 1) * C + lab] : em[int64_t(t - 1) * C + lab]);
@@ -242,13 +259,19 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     float m = NEG_INF;
     int arg = INT_MAX, bsrc = 0, barc = 0;
     // the in-row, eight records per lane at a time, all requested before the first is looked at (one
-    // exposed trip to memory per 512 records, not one per record)
-    for (int kb = k0; kb < k1; kb += 64 * RB) {
+    // exposed trip to memory per 512 records, not one per record); the rows of the step after next queue
+    // up behind the first batch
+    for (int kb = k0; kb == k0 || kb < k1; kb += 64 * RB) {
       gtnx_i4 r[RB];
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
         const int k = kb + l + 64 * i;
-        r[i] = g.lrec_in[k < k1 ? k : k1 - 1];
+        r[i] = g.lrec_in[k < k1 ? k : (k1 > 0 ? k1 - 1 : 0)];
+      }
+      if (kb == k0) {
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(t >= 2 ? t - 2 : 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
       for (int i = 0; i < RB; ++i) {
@@ -264,22 +287,16 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float m2 = __shfl_xor(m, o, 64);
-      const int a2 = __shfl_xor(arg, o, 64);
-      if (m2 > m || (m2 == m && a2 < arg)) {
-        m = m2;
-        arg = a2;
-      }
-    }
+    // first maximum in in-row order: the wave's maximum, then the smallest record index holding it
+    const float mx = wave_max63(m);
+    arg = wave_min63(m == mx ? arg : INT_MAX);
     if (arg == INT_MAX) {  // cannot happen below a finite best score
       if (l == 0) path_len[b] = -1;
       return;
     }
-    const int wl = (arg - k0) & 63;  // record k sits with lane (k - k0) mod 64
-    bsrc = __shfl(bsrc, wl, 64);
-    barc = __shfl(barc, wl, 64);
+    const int wl = (arg - k0) & 63;  // record k sits with lane (k - k0) mod 64, whose own best it is
+    bsrc = __builtin_amdgcn_readlane(bsrc, wl);
+    barc = __builtin_amdgcn_readlane(barc, wl);
     if (l == 0) {
       const int64_t o = int64_t(b) * T + (t - 1);
       path_arc[o] = barc;
@@ -288,10 +305,8 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
       path_w[o] = g.g.w[barc] + e;
     }
     node = bsrc;
-    if (t >= 2) {
-      park(t & 1);  // step t-2's rows -> the buffers step t's sat in ((t - 2) & 1 == t & 1)
-      __syncthreads();
-    }
+    park(t & 1);  // step t-2's rows -> the buffers step t's sat in ((t - 2) & 1 == t & 1)
+    __syncthreads();
   }
   if (l == 0) path_len[b] = T;
 }

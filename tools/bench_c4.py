@@ -151,8 +151,10 @@ def main():
     fcc = gtn.forward_score(gtn.compose(ems, [trans]))
     gtn.backward(fcc)
     sync()
+    paths = gtn.viterbi_path(gtn.compose(ems, [trans]))
+    sync()
     gtn.prof_enable(False)
-    prof = {n: gtn.prof_get(n) for n in gtn.prof_names() if n.startswith("lazy")}
+    prof = {n: gtn.prof_get(n) for n in gtn.prof_names() if n.startswith("lazy") or n.startswith("maxplus")}
     out["kernels"] = prof
     N = C + 1
     flops = 2.0 * B * N * N * T
@@ -162,6 +164,14 @@ def main():
         out["roofline"] = {"bound": "mfma", "kernel": "lazy_mfma_step_kernel<false> x T (+ prep)", "achieved": tf,
                            "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
                            "ms_per_pass": ms, "flops_per_pass": flops}
+    # the tropical sweeps (maxplus.hip) are vector-ALU work: one packed add + one max3 per pair of product arcs,
+    # i.e. one lane-instruction per arc at best; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+    if prof.get("maxplus_viterbi", {}).get("total_ms"):
+        ms = prof["maxplus_viterbi"]["total_ms"]
+        arcs = float(B) * T * (C * C) + float(B) * C
+        out["decode_sweep"] = {"kernel": "maxplus_step_kernel x T (+ prep)", "ms_per_pass": ms,
+                               "arc_relaxations_per_s": arcs / (ms * 1e-3), "valu_lane_instr_peak_per_s": 39.3e12,
+                               "frac_of_valu_peak": arcs / (ms * 1e-3) / 39.3e12}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C)
     print(json.dumps(out))

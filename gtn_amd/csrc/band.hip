@@ -1283,10 +1283,15 @@ __global__ __launch_bounds__(512) void asg_fal_targets_kernel(const AsgFalArgs* 
   }
 }
 // d loss / d transitions: every force-alignment arc hands its gradient to the transitions arc it came from
-__global__ void asg_fal_scatter_kernel(const float* __restrict__ g, const int* __restrict__ arc_map, int64_t n,
-                                       float* __restrict__ trans_grad) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < n && arc_map[i] >= 0 && g[i] != 0.0f) atomicAdd(trans_grad + arc_map[i], g[i]);
+// (blockIdx.y: the sequence; tab: {gradient offset, arc-map offset, arcs} per sequence)
+__global__ void asg_fal_scatter_kernel(const float* __restrict__ g, const int* __restrict__ maps,
+                                       const int64_t* __restrict__ tab, float* __restrict__ trans_grad) {
+  const int64_t* e = tab + int64_t(blockIdx.y) * 3;
+  const int64_t n = e[2];
+  const float* gb = g + e[0];
+  const int* mb = maps + e[1];
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += int64_t(gridDim.x) * blockDim.x)
+    if (mb[i] >= 0 && gb[i] != 0.0f) atomicAdd(trans_grad + mb[i], gb[i]);
 }
 
 template <class K>
@@ -1397,8 +1402,11 @@ void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hip
 void launch_asg_fal_targets(const AsgFalArgs* d_args, int n, int n_labels, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(asg_fal_targets_kernel, dim3(n), dim3(512), 0, st, d_args, n_labels);
 }
-void launch_asg_fal_scatter(const float* g, const int* arc_map, int64_t n, float* trans_grad, hipStream_t st) {
-  if (n > 0) hipLaunchKernelGGL(asg_fal_scatter_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, g, arc_map, n, trans_grad);
+void launch_asg_fal_scatter(const float* g, const int* maps, const int64_t* tab, int n_seq, int64_t longest, float* trans_grad,
+                            hipStream_t st) {
+  if (n_seq > 0 && longest > 0)
+    hipLaunchKernelGGL(asg_fal_scatter_kernel, dim3(unsigned(std::min<int64_t>((longest + 255) / 256, 64)), unsigned(n_seq)),
+                       dim3(256), 0, st, g, maps, tab, trans_grad);
 }
 void launch_ctc_targets(const CtcTargetArgs* d_args, int n, int blank, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(ctc_targets_kernel, dim3(n), dim3(512), 0, st, d_args, blank);

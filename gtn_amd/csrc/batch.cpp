@@ -196,11 +196,18 @@ struct BFalOp : BatchOp {
     Runtime& rt = Runtime::get();
     const int64_t A = tr.num_arcs();
     DevMemP gm = rt.alloc_zero(sizeof(float) * size_t(A ? A : 1));
+    // one launch for the whole batch: {gradient offset, arc-map offset (ints), arcs} per sequence
+    std::vector<int64_t> tab(size_t(out.n) * 3);
+    int64_t longest = 0;
     for (int b = 0; b < out.n; ++b) {
       const int64_t len = out.g_off[size_t(b) + 1] - out.g_off[size_t(b)];
-      launch_asg_fal_scatter(out.g_dev + out.g_off[size_t(b)], out.rec_mem->as<int>(out.map_off[size_t(b)]), len, gm->as<float>(),
-                             rt.stream());
+      tab[size_t(b) * 3 + 0] = out.g_off[size_t(b)];
+      tab[size_t(b) * 3 + 1] = int64_t(out.map_off[size_t(b)] / sizeof(int));
+      tab[size_t(b) * 3 + 2] = len;
+      longest = std::max(longest, len);
     }
+    DevMemP dt = upload_vec(tab);
+    launch_asg_fal_scatter(out.g_dev, out.rec_mem->as<int>(), dt->as<int64_t>(), out.n, longest, gm->as<float>(), rt.stream());
     tr.add_grad_device(gm, gm->as<float>(), /*adopt=*/true);  // (accumulates when the graph holds a gradient already)
   }
 };

@@ -477,7 +477,8 @@ struct AsgFalArgs {
   int U, pad;
 };
 void launch_asg_fal_targets(const AsgFalArgs* d_args, int n, int n_labels, hipStream_t st);
-void launch_asg_fal_scatter(const float* g, const int* arc_map, int64_t n, float* trans_grad, hipStream_t st);
+void launch_asg_fal_scatter(const float* g, const int* maps, const int64_t* tab /* 3 per sequence */, int n_seq, int64_t longest,
+                            float* trans_grad, hipStream_t st);
 int band_max_nodes();
 int band_max_labels();
 int band_npl(int max_nodes);               // nodes per lane: 1 or 2

@@ -156,10 +156,14 @@ struct PathArgs {
   GTNX_G int* path_il;            // [cap]
   GTNX_G int* path_ol;            // [cap]
   GTNX_G float* path_w;           // [cap]
-  GTNX_G int* path_len;           // [2]: length, has_node
+  GTNX_G int* path_len;           // [4]: length, has_node, exact tie on the path, -
   int cap;
+  // exact-tie check of the visited nodes (path_tie_kernel): node scores by position, weights by arc id
+  const GTNX_G float* scores;
+  const GTNX_G float* w;
+  GTNX_G int* path_pos;           // [cap] position of the node each path arc enters
 };
-void launch_path_chase(const PathArgs* d_args, int n, hipStream_t st);
+void launch_path_chase(const PathArgs* d_args, int n, int max_cap, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // linear-chain emissions graphs: forwardScore / viterbiScore and their grads

@@ -894,11 +894,12 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     off_r[k] = bytes;
     bytes += 256;
     off_p[k] = bytes;
-    bytes = align_up(bytes + 16 * size_t(cap[k]) + 8, 256);
+    bytes = align_up(bytes + 20 * size_t(cap[k]) + 16, 256);
   }
   DevMemP arena = rt.alloc(bytes);
   std::vector<SdArgs> args(m);
   std::vector<PathArgs> pargs(m);
+  int max_cap = 1;
   int64_t tot_in = 0, tot_p = 0;
   for (int k = 0; k < m; ++k) {
     Graph& g = gs[k];
@@ -924,11 +925,15 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     p.result = a.result;
     char* pb = arena->as<char>(off_p[k]);
     p.path_len = reinterpret_cast<int*>(pb);
-    p.path_arcs = reinterpret_cast<int*>(pb + 8);
+    p.path_arcs = reinterpret_cast<int*>(pb + 16);
     p.path_il = p.path_arcs + cap[k];
     p.path_ol = p.path_il + cap[k];
     p.path_w = reinterpret_cast<float*>(p.path_ol + cap[k]);
+    p.path_pos = reinterpret_cast<int*>(p.path_w + cap[k]);
     p.cap = cap[k];
+    p.scores = a.scores;
+    p.w = a.w;
+    max_cap = std::max(max_cap, cap[k]);
     tot_in += g.s->sched->n_in;
     tot_p += a.s.P;
   }
@@ -947,19 +952,44 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     }
     narrow = narrow && tot_levels >= 32 * int64_t(m);
     launch_sd_forward(d->as<SdArgs>(), m, SD_PATH, narrow ? 2 : 0, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
-    launch_path_chase(dp->as<PathArgs>(), m, rt.stream());
+    launch_path_chase(dp->as<PathArgs>(), m, max_cap, rt.stream());
   }
   // the path is at most L arcs: bring it to the host and build the chain graph there
   std::vector<char> host(bytes);
   rt.d2h_sync(host.data(), arena->ptr, bytes);
+  // Exact ties on a path through a product that carries compose's own schedule (ties by arc id, positions =
+  // node ids): rerun those on the schedule that replays the reference's queue (graph.cpp:
+  // build_host_schedule), whose rank IS the reference's relaxation order.  Host-built graphs have it already.
+  std::vector<int> tied;
+  for (int k = 0; k < m; ++k) {
+    const int* pl = reinterpret_cast<const int*>(host.data() + off_p[k]);
+    if (pl[2] && (gs[k].s->sched->view.flags & SCHED_TIE_BY_ARC) && !getenv("GTNX_NO_TIE_RERUN")) tied.push_back(k);
+  }
+  std::vector<Graph> redo;
+  if (!tied.empty()) {
+    std::vector<Graph> tg;
+    for (int k : tied) {
+      gs[k].s->resolve_sizes();
+      gs[k].s->ensure_full();
+      gs[k].s->ensure_host();
+      gs[k].s->sched.reset();
+      tg.push_back(gs[k]);
+    }
+    redo = op_viterbi_path(tg);
+  }
   auto op = std::make_shared<PathOp>();
   op->seq = next_seq();
   op->arcs_rev.resize(m);
+  size_t next_tied = 0;
   for (int k = 0; k < m; ++k) {
+    if (next_tied < tied.size() && tied[next_tied] == k) {
+      outs.push_back(std::move(redo[next_tied++]));
+      continue;
+    }
     const char* pb = host.data() + off_p[k];
     const int* pl = reinterpret_cast<const int*>(pb);
     const int len = pl[0], has_node = pl[1];
-    const int* arcs = reinterpret_cast<const int*>(pb + 8);
+    const int* arcs = reinterpret_cast<const int*>(pb + 16);
     const int* il = arcs + cap[k];
     const int* ol = il + cap[k];
     const float* w = reinterpret_cast<const float*>(ol + cap[k]);

@@ -862,6 +862,7 @@ __global__ void path_chase_kernel(const PathArgs* __restrict__ args, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const PathArgs a = args[i];
+  a.path_len[2] = 0;  // path_tie_kernel only ever sets it
   int cur = a.result->argmax_final;
   const int has_node = cur != -1;
   int len = 0;
@@ -885,10 +886,32 @@ __global__ void path_chase_kernel(const PathArgs* __restrict__ args, int n) {
       a.path_ol[pos] = a.g.ol[arc];
     }
     a.path_w[pos] = a.g.w[arc];
+    a.path_pos[pos] = c;
     c = a.s.in_srcpos[k];
   }
   a.path_len[0] = len;
   a.path_len[1] = has_node;
+}
+
+// Exact ties on the path.  The reference's shortestPath relaxes a node's in-arcs in the order their sources
+// leave its queue (shortest.cpp:212-227) and keeps the FIRST maximum; the sweeps above break ties by the
+// schedule's rank, which for a product numbered by compose (positions = node ids) is not that order.  Scores
+// are unaffected; the chosen arc can differ only where two finite candidates of a visited node are EQUAL.
+// One lane per path arc recounts its node's candidates; a flagged graph is rerun on a schedule that replays
+// the queue (ops.cpp: op_viterbi_path).
+__global__ void path_tie_kernel(const PathArgs* __restrict__ args) {
+  const PathArgs a = args[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.path_len[0]) return;
+  const int c = a.path_pos[i];
+  const float target = a.scores[c];
+  if (!(target > NEG_INF)) return;
+  int equal = 0;
+  for (int k = a.s.row_off[c]; k < a.s.row_off[c + 1]; ++k) {
+    const float wt = a.s.in_w ? a.s.in_w[k] : a.w[a.s.in_arc[k]];
+    equal += (a.scores[a.s.in_srcpos[k]] + wt == target) ? 1 : 0;
+  }
+  if (equal > 1) a.path_len[2] = 1;
 }
 
 template <int MODE>
@@ -970,9 +993,10 @@ void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int a
     launch_bwd_mode<SD_TROPICAL>(d_args, n, g, st);
 }
 
-void launch_path_chase(const PathArgs* d_args, int n, hipStream_t st) {
+void launch_path_chase(const PathArgs* d_args, int n, int max_cap, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(path_chase_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_args, n);
+  hipLaunchKernelGGL(path_tie_kernel, dim3(unsigned((std::max(max_cap, 1) + 255) / 256), unsigned(n)), dim3(256), 0, st, d_args);
 }
 
 } // namespace gtnx

@@ -702,3 +702,33 @@ def test_maxplus_viterbi_matches_the_record_walking_kernels(gtn, B, T, N, C, int
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(b[4], a[4])
     assert np.isfinite(a[0]).sum() > 0
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5, 6])
+@pytest.mark.parametrize("chain_first", [False, True])
+def test_built_lattice_viterbi_path_exact_ties_follow_the_reference(gtn, seed, chain_first):
+    """the same ties on the BUILT lattice (compose mode 0): compose's own schedule breaks them by arc id,
+    the reference's shortestPath by the order sources leave its queue -- path_tie_kernel flags an exact tie
+    on the path and the graph is rerun on the queue-replaying schedule, so the labels are the oracle's"""
+    import torch
+    B, T, C = 6, 14, 5
+    rng = np.random.default_rng(seed)
+    em = rng.integers(-1, 2, (B, T, C)).astype(np.float32)
+    em[0] = 0.0
+    tg = [[1, 2], [3, 3, 1], [4], [1, 2, 3, 4], [2, 2], [1, 1, 1]]
+    prev = gtn.compose_mode(0)
+    try:
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t)) for t in tg]
+        comp = gtn.compose(ems, ctcs) if chain_first else gtn.intersect(ctcs, ems)
+        gtn.prof_reset()
+        gtn.prof_enable(True)
+        paths = gtn.viterbi_path(comp)
+        gtn.prof_enable(False)
+        assert "viterbi_path" in gtn.prof_names(), "the built-lattice path kernels did not run"
+    finally:
+        gtn.compose_mode(prev)
+    for b in range(B):
+        score, labels, has, g_e, g_t = _oracle_viterbi(em[b], tg[b], chain_first)
+        assert paths[b].labels_to_list() == labels
+        assert float(paths[b].weights_to_numpy().sum()) == np.float32(score)

@@ -732,3 +732,83 @@ def test_built_lattice_viterbi_path_exact_ties_follow_the_reference(gtn, seed, c
         score, labels, has, g_e, g_t = _oracle_viterbi(em[b], tg[b], chain_first)
         assert paths[b].labels_to_list() == labels
         assert float(paths[b].weights_to_numpy().sum()) == np.float32(score)
+
+
+def _asg_fp64(em, tw):
+    """float64 restatement of the ASG full-connect term on the dense transitions graph of
+    test_parity_gpu.asg_transitions (start arcs tw[:C], arc j -> i at tw[C + i * C + j]): score, d/d emissions,
+    d/d transitions (same layout as tw), and the max-plus optimum with its labels"""
+    T, C = em.shape
+    em = em.astype(np.float64)
+    st, W = tw[:C].astype(np.float64), tw[C:].astype(np.float64).reshape(C, C)  # W[i][j]: j -> i
+    lse = lambda x, ax: (lambda m: m + np.log(np.exp(x - np.expand_dims(m, ax)).sum(ax)))(x.max(ax))
+    alpha = np.zeros((T + 1, C))
+    alpha[1] = st + em[0]
+    for t in range(1, T):
+        alpha[t + 1] = em[t] + lse(alpha[t][None, :] + W, 1)
+    Z = lse(alpha[T], 0)
+    beta = np.zeros((T + 1, C))
+    for t in range(T - 1, 0, -1):
+        beta[t] = lse(W + (em[t] + beta[t + 1])[:, None], 0)
+    g_em = np.exp(alpha[1:] + beta[1:] - Z)
+    g_st = np.exp(st + em[0] + beta[1] - Z)
+    g_W = np.zeros((C, C))
+    for t in range(1, T):
+        g_W += np.exp(alpha[t][None, :] + W + (em[t] + beta[t + 1])[:, None] - Z)
+    v = st + em[0]
+    back = []
+    for t in range(1, T):
+        cand = v[None, :] + W
+        back.append(cand.argmax(1))
+        v = em[t] + cand.max(1)
+    lab = [int(v.argmax())]
+    for bp in reversed(back):
+        lab.append(int(bp[lab[-1]]))
+    return Z, g_em, np.concatenate([g_st, g_W.reshape(-1)]), float(v.max()), lab[::-1]
+
+
+@pytest.mark.parametrize("T", [1, 17])
+def test_dense_regime_at_the_real_alphabet_vs_fp64(gtn, T):
+    """the matrix-core and max-plus kernels at C4's real shape (C = 512: 513 nodes = 16 column tiles after the
+    rotation past the start node, 576 padded sources, 8 x 8 gradient blocks) against a float64 DP: scores,
+    emission gradients, the shared transitions' gradient, Viterbi score and path"""
+    import torch
+    B, C = 3, 512
+    rng = np.random.default_rng(7)
+    em = rng.normal(0, 2, (B, T, C)).astype(np.float32)
+    tw = rng.normal(0, 1, C * C + C).astype(np.float32)
+    n = np.arange(C)
+    trans = gtn.Graph()
+    trans.add_nodes(np.array([1] + [0] * C, np.uint8), np.array([0] + [1] * C, np.uint8))
+    trans.add_arcs(np.concatenate([np.zeros(C, np.int32), np.tile(n + 1, C)]).astype(np.int32),
+                   np.concatenate([n + 1, np.repeat(n + 1, C)]).astype(np.int32),
+                   np.concatenate([n, np.repeat(n, C)]).astype(np.int32), None, tw)
+    with lazy_mode("1"):
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        comp = gtn.compose(ems, [trans])
+        gtn.prof_reset()
+        gtn.prof_enable(True)
+        fs = gtn.forward_score(comp)
+        vs = gtn.viterbi_score(comp)
+        paths = gtn.viterbi_path(comp)
+        gtn.prof_enable(False)
+        assert "maxplus_viterbi" in gtn.prof_names() and "lazy_forward_score" in gtn.prof_names()
+        gtn.backward(fs)
+        f, v = gtn.items(fs), gtn.items(vs)
+        ge = [e.grad().weights_to_numpy().reshape(T, C) for e in ems]
+        gt = trans.grad().weights_to_numpy()
+    want_gt = np.zeros(C * C + C)
+    for b in range(B):
+        Z, g_em, g_tw, vbest, lab = _asg_fp64(em[b], tw)
+        want_gt += g_tw
+        assert f[b] == pytest.approx(Z, rel=2e-6, abs=1e-4)
+        assert np.abs(ge[b] - g_em).max() <= 2e-5
+        assert v[b] == pytest.approx(vbest, rel=2e-6, abs=1e-4)
+        got_lab = paths[b].labels_to_list()
+        assert len(got_lab) == T
+        if got_lab != lab:  # float32 may prefer a path within rounding of the float64 optimum
+            w64 = tw[got_lab[0]] + em[b][0][got_lab[0]] + sum(
+                float(tw[C + got_lab[t] * C + got_lab[t - 1]]) + float(em[b][t][got_lab[t]]) for t in range(1, T))
+            assert w64 == pytest.approx(vbest, abs=1e-3)
+        assert float(paths[b].weights_to_numpy().sum()) == pytest.approx(v[b], rel=1e-5)
+    assert np.abs(gt - want_gt).max() <= 1e-4

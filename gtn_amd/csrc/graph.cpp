@@ -31,6 +31,8 @@ void Structure::touch() {
   max_deg = -1;
   band[0].reset();
   band[1].reset();
+  dense[0].reset();
+  dense[1].reset();
   ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65
 }
 

@@ -102,6 +102,19 @@ struct Structure {
   // made by band_info() on first use as the fixed side of a symbolic chain product
   std::shared_ptr<struct BandInfo> band[2];
 
+  // Cached facts for the dense regime of the never-built products (ops.cpp: lazy_forward), per matched-label
+  // side (0: ilabel, 1: olabel) and alphabet size: the shared in-arc label of every node (empty: they differ),
+  // the count of matchable arcs, and the device tables of maxplus.hip
+  struct DenseInfo {
+    int C = -1;
+    std::vector<int> lab;
+    int max_in_deg = 0;
+    int64_t valid = 0;
+    int ncol = 0, ndead = 0;
+    DevMemP tables;  // [N] labels | [N] node -> column | [ncol] column -> node | [ndead] dead nodes
+  };
+  std::shared_ptr<DenseInfo> dense[2];
+
   int max_deg = -1;     // widest in- or out-row (cached; touch() forgets it)
   int max_degree();
 

@@ -306,6 +306,8 @@ struct LazyGroup {          // utterances that share one explicit graph G
   const gtnx_i4* lrec_in;
   const gtnx_i4* lrec_out;
   const float* const* em;   // [nb] chain weights, T*C each
+  const float* em_base;     // ... or, when the chains are slices of one tensor at a constant stride (floats),
+  int64_t em_stride;        //     em[b] == em_base + b * em_stride (null / 0: use the table)
   float* alpha;             // [T+1][nb][N]
   float* beta;              // [T+1][nb][N] (gradients only)
   int* bp;                  // [T+1][nb][N] back-pointers (arc of G), tropical only

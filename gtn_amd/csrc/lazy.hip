@@ -896,6 +896,7 @@ __global__ void lazy_mfma_pairs_kernel(LazyGroup g, gtnx_f4* pc) {
 // four waves' partial blocks meet in LDS.  Blocks are taken in SLOT space (mf_slot: live nodes first):
 // a destination block of dead nodes has nothing to add, a source block of dead nodes (an ASG start node)
 // only the pairs of step 0 -- at C4 that leaves 8 x 8 full blocks instead of 9 x 9 ragged ones.
+template <bool STRIDED>  // the emission rows are slices of one tensor: no row-pointer load in the loop
 __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_kernel(LazyGroup g, const gtnx_f4* __restrict__ pc,
                                                                   int pairs_per_block) {
   __shared__ float part[4][32][64];
@@ -930,49 +931,68 @@ __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_kernel(LazyGroup g, 
   int t = pp / nb, b = pp - t * nb;
   const int pend = int(p1), plast = int(p1) - 1;
   constexpr int UR = 2;
-  for (; pp - hi < pend;) {
+  const int step_t = 8 / nb, step_b = 8 % nb;  // eight pairs on
+  struct Round {
     float al[UR][2], be[UR][2], ev[UR][2];
     gtnx_f4 c[UR];
-    int tt = t, bb = b, pq = pp;
+  };
+  // the operands of the NEXT round are requested before the current one is exponentiated and multiplied
+  // (rounds past the end re-read the last pair with weight 0: no branch around a load)
+  auto request = [&](Round& r) {
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const bool in = pq < pend;
-      const int tc = in ? tt : 0, bc = in ? bb : 0;
-      c[u] = pc[in ? pq : plast];
-      if (!in) c[u].w = 0.0f;
+      const bool in = pp < pend;
+      const int tc = in ? t : 0, bc = in ? b : 0;
+      r.c[u] = pc[in ? pp : plast];
+      if (!in) r.c[u].w = 0.0f;
       const float* ar = g.alpha + int64_t(tc) * plane + int64_t(bc) * N;
       const float* br = g.beta + int64_t(tc + 1) * plane + int64_t(bc) * N;
-      const GTNX_G float* er = (const GTNX_G float*)g.em[bc] + int64_t(tc) * C;
+      const GTNX_G float* er =
+          (STRIDED ? (const GTNX_G float*)g.em_base + int64_t(bc) * g.em_stride : (const GTNX_G float*)g.em[bc]) + int64_t(tc) * C;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        al[u][h] = ar[sn[h]];
-        be[u][h] = br[dn[h]];
-        ev[u][h] = er[labc[h]];
+        r.al[u][h] = ar[sn[h]];
+        r.be[u][h] = br[dn[h]];
+        r.ev[u][h] = er[labc[h]];
       }
-      pq += 8;
-      bb += 8;
-      while (bb >= nb) {
-        bb -= nb;
-        ++tt;
-      }
+      pp += 8;
+      b += step_b;  // (selects, not a loop: a branch between requests would zero the counted waits)
+      t += step_t;
+      const bool wrap = b >= nb;
+      b -= wrap ? nb : 0;
+      t += wrap ? 1 : 0;
     }
-    t = tt;
-    b = bb;
-    pp = pq;
+  };
+  auto multiply = [&](const Round& r) {
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
-      const bool on = c[u].w != 0.0f;
+      const bool on = r.c[u].w != 0.0f;
       float a[2], q[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        a[h] = (on && sok[h] && al[u][h] != NEG_INF) ? __expf(al[u][h] + c[u].x) : 0.0f;
-        q[h] = (on && lab[h] >= 0 && be[u][h] != NEG_INF) ? __expf(ev[u][h] + be[u][h] + c[u].y) * c[u].z : 0.0f;
+        a[h] = (on && sok[h] && r.al[u][h] != NEG_INF) ? __expf(r.al[u][h] + r.c[u].x) : 0.0f;
+        q[h] = (on && lab[h] >= 0 && r.be[u][h] != NEG_INF) ? __expf(r.ev[u][h] + r.be[u][h] + r.c[u].y) * r.c[u].z : 0.0f;
       }
       acc00 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[0], acc00, 0, 0, 0);
       acc01 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], q[1], acc01, 0, 0, 0);
       acc10 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[0], acc10, 0, 0, 0);
       acc11 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], q[1], acc11, 0, 0, 0);
     }
+  };
+  // rounds of this wave (uniform): its pairs start at p0 + 2 wv and advance by 8 UR per round
+  const int first = int(p0) + 2 * wv;
+  const int rounds = first < pend ? (pend - first + 8 * UR - 1) / (8 * UR) : 0;
+  Round ra, rb;
+  request(ra);
+  for (int it = 0; it < rounds; it += 2) {
+    request(rb);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(ra);
+    __builtin_amdgcn_sched_barrier(0);
+    request(ra);
+    __builtin_amdgcn_sched_barrier(0);
+    multiply(rb);  // (an odd count's last round is all weight 0)
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- the four waves' partial blocks, two tiles (32 registers) at a time through LDS; wave wv then adds
   // registers 8 wv .. 8 wv + 7 of the pair of tiles into R
@@ -1175,7 +1195,8 @@ void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStrea
   hipLaunchKernelGGL(lazy_mfma_pairs_kernel, dim3(unsigned((npairs + 255) / 256)), dim3(256), 0, st, g, pc);
   const int pairs_per_block = 16384;
   const dim3 grid(unsigned((g.N + 63) / 64), unsigned((g.N + 63) / 64), unsigned((npairs + pairs_per_block - 1) / pairs_per_block));
-  hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
+  if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<true>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
+  else hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<false>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
   if (g.g.A > 0) hipLaunchKernelGGL(lazy_dense_arc_grad_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g);
 }
 void launch_lazy_dense_fixed_grad(const LazyGroup& g, hipStream_t st) {

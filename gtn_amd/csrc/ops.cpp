@@ -1806,6 +1806,40 @@ struct LazyKey {
 // forward pass (log or tropical) of every lazy product in `gs`; returns one state per
 // group and, through `slot`, (group, member) of each input
 std::vector<int> lazy_node_labels(Structure& fs, bool chain_first, int C, int* max_in_deg);
+// host facts about a fixed partner G for the dense regime, taken once per structure (a trainer keeps its
+// transitions graph; only the weights move)
+std::shared_ptr<Structure::DenseInfo> dense_info(Structure& fs, bool chain_first, int C) {
+  std::shared_ptr<Structure::DenseInfo>& slot = fs.dense[chain_first ? 0 : 1];
+  if (slot && slot->C == C) return slot;
+  auto di = std::make_shared<Structure::DenseInfo>();
+  di->C = C;
+  fs.ensure_host();
+  fs.ensure_csr();
+  di->lab = lazy_node_labels(fs, chain_first, C, &di->max_in_deg);
+  const std::vector<int>& ml = chain_first ? fs.il : fs.ol;
+  for (int l : ml) di->valid += (l >= 0 && l < C);
+  if (!di->lab.empty()) {
+    const int N = int(fs.N);
+    std::vector<int> tab(size_t(N), -1), colnode, dead;
+    for (int n = 0; n < N; ++n) {
+      if (di->lab[size_t(n)] >= 0) {
+        tab[size_t(n)] = int(colnode.size());
+        colnode.push_back(n);
+      } else {
+        dead.push_back(n);
+      }
+    }
+    di->ncol = int(colnode.size());
+    di->ndead = int(dead.size());
+    std::vector<int> ints(di->lab);
+    ints.insert(ints.end(), tab.begin(), tab.end());
+    ints.insert(ints.end(), colnode.begin(), colnode.end());
+    ints.insert(ints.end(), dead.begin(), dead.end());
+    di->tables = upload_vec(ints);
+  }
+  slot = di;
+  return di;
+}
 std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs, int mode,
                                                           std::vector<std::pair<int, int>>& slot) {
   Runtime& rt = Runtime::get();
@@ -1861,19 +1895,11 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     };
     // tropical semiring over a dense G whose nodes' in-arcs share one matched label: the max-plus sweeps of
     // maxplus.hip (decided here because they need no back-pointer planes)
-    std::vector<int> mp_lab;
-    if (mode == SD_TROPICAL && !getenv("GTNX_NO_DENSE") && N <= 1024 && N >= 8 && T >= 1) {
-      const bool cf = st.view.chain_first != 0;
-      mp_lab = lazy_node_labels(fs, cf, C, &st.max_in_deg);
-      int64_t valid = 0;
-      const std::vector<int>& ml = cf ? fs.il : fs.ol;
-      for (int l : ml) valid += (l >= 0 && l < C);
-      if (2 * valid < int64_t(N) * N) mp_lab.clear();
-      int ncol = 0;
-      for (int l : mp_lab) ncol += l >= 0;
-      if (ncol == 0) mp_lab.clear();
-    }
-    st.maxplus = !mp_lab.empty();
+    std::shared_ptr<Structure::DenseInfo> di;
+    if (!getenv("GTNX_NO_DENSE") && N <= 1024 && N >= 8) di = dense_info(fs, st.view.chain_first != 0, C);
+    const bool dense_ok = di && !di->lab.empty() && 2 * di->valid >= int64_t(N) * N;
+    if (di) st.max_in_deg = di->max_in_deg;
+    st.maxplus = mode == SD_TROPICAL && dense_ok && T >= 1 && di->ncol > 0;
     const size_t o_alpha = add(4 * plane * size_t(T + 1));
     const size_t o_bp = (mode == SD_LOG || st.maxplus) ? 0 : add(4 * plane * size_t(T + 1));
     const size_t o_score = add(4 * size_t(nb));
@@ -1894,26 +1920,26 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     std::memcpy(pin->ptr, em.data(), 8 * size_t(nb));
     rt.h2d(st.arena->as<char>(o_em), pin->ptr, 8 * size_t(nb));
     v.em = reinterpret_cast<const float* const*>(st.arena->as<char>(o_em));
+    // slices of one tensor (linearGraphs over a [B][T][C] tensor, the criteria): the kernels' inner loops
+    // compute the row address instead of loading it
+    v.em_base = nullptr;
+    v.em_stride = 0;
+    if (nb >= 1 && em[0]) {
+      const int64_t stride = nb > 1 ? em[1] - em[0] : int64_t(T) * C;
+      bool strided = stride >= int64_t(T) * C;
+      for (int b = 1; b < nb && strided; ++b) strided = em[b] - em[b - 1] == stride;
+      if (strided) {
+        v.em_base = em[0];
+        v.em_stride = stride;
+      }
+    }
     if (st.maxplus) {
       // columns = nodes with a matched in-arc; the others (an ASG start node) are -inf from step 1 on
-      std::vector<int> tab(size_t(N), -1), colnode, dead;
-      for (int n = 0; n < N; ++n) {
-        if (mp_lab[size_t(n)] >= 0) {
-          tab[size_t(n)] = int(colnode.size());
-          colnode.push_back(n);
-        } else {
-          dead.push_back(n);
-        }
-      }
-      v.mp_ncol = int(colnode.size());
-      v.mp_ndead = int(dead.size());
+      v.mp_ncol = di->ncol;
+      v.mp_ndead = di->ndead;
       v.Kpad = (N + 3) & ~3;
       v.nbpad = (nb + 63) & ~63;
-      std::vector<int> ints(mp_lab);  // [N] labels | [N] node -> column | columns | dead nodes
-      ints.insert(ints.end(), tab.begin(), tab.end());
-      ints.insert(ints.end(), colnode.begin(), colnode.end());
-      ints.insert(ints.end(), dead.begin(), dead.end());
-      st.labels = upload_vec(ints);
+      st.labels = di->tables;
       st.node_label = st.labels->as<int>();
       v.nlab = st.node_label;
       v.mp_colidx = st.node_label + N;
@@ -1934,13 +1960,12 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     LazyGroup& v = st.view;
     Structure& fs = *st.fixed.s;
     if (mode != SD_LOG || getenv("GTNX_NO_DENSE") || v.N > 1024 || v.N < 8) continue;
-    std::vector<int> lab = lazy_node_labels(fs, v.chain_first != 0, v.C, &st.max_in_deg);
+    std::shared_ptr<Structure::DenseInfo> di = dense_info(fs, v.chain_first != 0, v.C);
+    st.max_in_deg = di->max_in_deg;
+    const std::vector<int>& lab = di->lab;
     if (lab.empty()) continue;
-    int64_t valid = 0;
-    const std::vector<int>& ml = v.chain_first ? fs.il : fs.ol;
-    for (int l : ml) valid += (l >= 0 && l < v.C);
-    if (2 * valid < int64_t(v.N) * v.N) continue;
-    st.labels = upload_vec(lab);
+    if (2 * di->valid < int64_t(v.N) * v.N) continue;
+    st.labels = di->tables;
     st.node_label = st.labels->as<int>();
     const size_t nn = size_t(v.N) * size_t(v.N);
     size_t bytes = 0;
@@ -2943,8 +2968,10 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
     const int* hol = hil + nT;
     const float* hw = reinterpret_cast<const float*>(hol + nT);
     const int* hlen = reinterpret_cast<const int*>(hw + nT);
-    for (size_t i = 0; i < gs.size(); ++i) {
-      if (slot[i].first != int(gi)) continue;
+    // the path graphs (8 host arrays of T entries each per utterance): every element touches only its own
+    // objects, so a large batch is built by a few threads (3.5 -> <1 ms of a 17 ms decode at C4)
+    auto build = [&](size_t i) {
+      if (slot[i].first != int(gi)) return;
       const int b = slot[i].second;
       const int len = hlen[b];
       Graph out = make_output(op, int(i), {gs[i]});
@@ -2960,6 +2987,28 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
       op->saved[i].C = v.C;
       op->saved[i].chain_first = v.chain_first;
       outs[i] = std::move(out);
+    };
+    const size_t n_out = gs.size();
+    const size_t nthreads = (n_out * size_t(v.T) >= (size_t(1) << 16)) ? std::min<size_t>(8, n_out) : 1;
+    if (nthreads <= 1) {
+      for (size_t i = 0; i < n_out; ++i) build(i);
+    } else {
+      std::atomic<size_t> next{0};
+      std::exception_ptr err;
+      std::mutex err_mu;
+      auto worker = [&] {
+        try {
+          for (size_t i = next.fetch_add(1); i < n_out; i = next.fetch_add(1)) build(i);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (!err) err = std::current_exception();
+        }
+      };
+      std::vector<std::thread> pool;
+      for (size_t k = 1; k < nthreads; ++k) pool.emplace_back(worker);
+      worker();
+      for (auto& th : pool) th.join();
+      if (err) std::rethrow_exception(err);
     }
   }
   return outs;

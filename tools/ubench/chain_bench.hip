@@ -37,6 +37,13 @@ __global__ void k_readwrite(const float* __restrict__ in, float* out, int kb, in
   out[size_t(blockIdx.x) * blockDim.x + threadIdx.x] = acc + float(it);
 }
 
+// a kernel that is busy for about `us` microseconds (wall clock counter at 100 MHz), then writes 4 KB per workgroup
+__global__ void k_busy(float* p, int it, int us) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < 100ll * us) __builtin_amdgcn_s_sleep(2);
+  p[(size_t(blockIdx.x) * blockDim.x + threadIdx.x) * 4 + (it & 3)] = float(it);
+}
+
 // persistent: `steps` rounds of (write 4 KB, grid barrier, read what a neighbour wrote)
 __global__ void k_persistent(float* buf, unsigned* counter, int steps, float* sink) {
   const unsigned nwg = gridDim.x;
@@ -112,6 +119,25 @@ int main(int argc, char** argv) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     printf("%-44s %8.2f us per launch\n", "write 4 KB, chain of 100 as a graph", ms * 1e3 / (n / 100 * 100));
+  }
+  // does a graph still pay when the kernels are long enough for the host to keep up?  (7 us busy + 4 KB writes)
+  {
+    timeit("busy 7 us + write, stream launches", [&](int i) { hipLaunchKernelGGL(k_busy, dim3(wgs), dim3(256), 0, st, a, i, 7); });
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < 100; ++i) hipLaunchKernelGGL(k_busy, dim3(wgs), dim3(256), 0, st, a, i, 7);
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventRecord(e0, st));
+    for (int r = 0; r < n / 100; ++r) CK(hipGraphLaunch(ge, st));
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s %8.2f us per launch\n", "busy 7 us + write, chain of 100 as a graph", ms * 1e3 / (n / 100 * 100));
   }
   // persistent kernel with a grid barrier per step (all workgroups must be resident: cooperative launch)
   for (int th : {256, 512}) {

@@ -355,6 +355,9 @@ void launch_lazy_path(const LazyGroup& g, int* path_arc, int* path_il, int* path
 // node_label != null: every node's in-arcs share one matched label (no arc loop)
 void launch_lazy_local_z(const LazyGroup& g, float* zt, hipStream_t st);  // [T][nb]
 void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st);
+// local z + chain gradient in one pass (shared in-arc labels, N <= 1024): writes zt like launch_lazy_local_z
+bool lazy_z_chain_grad_ok(const LazyGroup& g);
+void launch_lazy_z_chain_grad(const LazyGroup& g, const int* node_label, float* zt, hipStream_t st);
 void launch_lazy_fixed_grad(const LazyGroup& g, int max_in_deg, hipStream_t st);
 struct LazyPathGrad {
   const float* delta;   // [len] (stride 1) or one scalar (stride 0)

@@ -271,6 +271,73 @@ __global__ __launch_bounds__(kBlock) void lazy_chain_grad_nodes_kernel(LazyGroup
   for (int c = tid; c < g.C; c += kBlock) out[int64_t(t) * g.C + c] = row[c];
 }
 
+// The two kernels above and lazy_local_z_kernel in one pass (N <= 1024, so a wave holds a (t, utterance) pair's
+// alpha + beta row in registers): the step's own normaliser z = log sum_n exp(alpha + beta), written for the arc
+// gradients, then the posteriors binned by label in the wave's LDS row and the row stored once.  One wave per
+// pair, four pairs per wave: alpha and beta are read once instead of twice, by 16 x fewer workgroups.
+constexpr int ZG_PAIRS = 4;
+__global__ __launch_bounds__(kBlock) void lazy_z_chain_grad_kernel(LazyGroup g, const int* __restrict__ node_label, float* zt) {
+  extern __shared__ float rows[];  // [4 waves][C]
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* row = rows + wv * g.C;
+  const int64_t npairs = int64_t(g.T) * g.nb;
+  int lab[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int n = lane + 64 * i;
+    const int l0 = node_label[n < g.N ? n : g.N - 1];
+    lab[i] = n < g.N ? l0 : -1;
+  }
+  for (int j = 0; j < ZG_PAIRS; ++j) {
+    const int64_t p = (int64_t(blockIdx.x) * 4 + wv) * ZG_PAIRS + j;
+    if (p >= npairs) return;  // (per wave: nothing below synchronises across waves)
+    const int t = int(p / g.nb), b = int(p % g.nb);
+    const int64_t o = int64_t(t + 1) * g.nb * g.N + int64_t(b) * g.N;
+    float x[16];
+    float m = NEG_INF;
+    // (clamped, unconditional loads: a load under a lane mask is followed by a wait for everything, and the
+    // row would arrive one trip to memory at a time)
+    float av[16], bv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = lane + 64 * i;
+      const int nc = n < g.N ? n : g.N - 1;
+      av[i] = g.alpha[o + nc];
+      bv[i] = g.beta[o + nc];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int n = lane + 64 * i;
+      x[i] = n < g.N ? av[i] + bv[i] : NEG_INF;
+      m = fmaxf(m, x[i]);
+    }
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    float sum = 0.0f;
+    const bool mfin = m != NEG_INF && m != -NEG_INF;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sum += (mfin && x[i] != NEG_INF) ? __expf(x[i] - m) : 0.0f;
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) sum += __shfl_xor(sum, k, 64);
+    const float z0 = (m == NEG_INF || m == -NEG_INF) ? m : m + logf(sum);
+    if (lane == 0) zt[p] = z0;
+    float* out = g.grad_em[b];
+    if (!out) continue;
+    for (int c = lane; c < g.C; c += 64) row[c] = 0.0f;
+    // an utterance without any accepting path (score -inf) has an empty product: no gradient
+    const bool zfin = z0 != NEG_INF && z0 != -NEG_INF;
+    const float z = zfin ? z0 : 0.0f, dl = zfin ? *g.delta[b] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (lab[i] < 0) continue;
+      const float xv = x[i] - z;
+      if (xv != NEG_INF) atomicAdd(&row[lab[i]], __expf(xv) * dl);
+    }
+    // (one wave: its LDS operations complete in order, no barrier)
+    for (int c = lane; c < g.C; c += 64) out[int64_t(t) * g.C + c] = row[c];
+  }
+}
+
 // general chain gradient: per (t, utterance) loop over all arcs of G
 __global__ __launch_bounds__(kBlock) void lazy_chain_grad_arcs_kernel(LazyGroup g) {
   extern __shared__ float row[];
@@ -1111,6 +1178,15 @@ void launch_lazy_local_z(const LazyGroup& g, float* zt, hipStream_t st) {
   const int64_t rows = int64_t(g.T) * g.nb;
   if (rows <= 0) return;
   hipLaunchKernelGGL(lazy_local_z_kernel, dim3(unsigned((rows + 3) / 4)), dim3(256), 0, st, g, zt);
+}
+
+bool lazy_z_chain_grad_ok(const LazyGroup& g) { return g.N <= 1024 && g.C <= 4096; }
+void launch_lazy_z_chain_grad(const LazyGroup& g, const int* node_label, float* zt, hipStream_t st) {
+  const int64_t npairs = int64_t(g.T) * g.nb;
+  if (npairs <= 0) return;
+  const int64_t per_wg = 4 * ZG_PAIRS;
+  hipLaunchKernelGGL(lazy_z_chain_grad_kernel, dim3(unsigned((npairs + per_wg - 1) / per_wg)), dim3(kBlock),
+                     sizeof(float) * 4 * size_t(g.C), st, g, node_label, zt);
 }
 
 void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st) {

@@ -2121,9 +2121,14 @@ struct LazySdOp : OpRecord {
           }
         }
         DevMemP ztm = rt.alloc(4 * size_t(T > 0 ? T : 1) * size_t(nb));
-        launch_lazy_local_z(v, ztm->as<float>(), rt.stream());
-        v.zt = ztm->as<float>();
-        launch_lazy_chain_grad(v, st.node_label, rt.stream());
+        if (st.node_label && lazy_z_chain_grad_ok(v)) {
+          launch_lazy_z_chain_grad(v, st.node_label, ztm->as<float>(), rt.stream());
+          v.zt = ztm->as<float>();
+        } else {
+          launch_lazy_local_z(v, ztm->as<float>(), rt.stream());
+          v.zt = ztm->as<float>();
+          launch_lazy_chain_grad(v, st.node_label, rt.stream());
+        }
         if (want_fixed && st.dense) {
           DevMemP rmem = rt.alloc_zero(4 * size_t(N) * size_t(N));
           v.R = rmem->as<float>();

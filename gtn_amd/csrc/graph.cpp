@@ -970,13 +970,80 @@ void build_host_schedule(Structure& s, HostSched& h, bool need_rank) {
 }
 } // namespace
 
+// The schedule of a structure that only exists on the device (a composition result that is not layered),
+// built there (levelize.hip).  Without the queue's order inside a level, so not for viterbiPath (need_rank).
+// GTNX_DEVICE_LEVELIZE=1 takes this way for every explicit structure (parity suite), =0 never.
+namespace {
+bool device_schedule_wanted(const Structure& s, bool need_rank) {
+  if (need_rank || s.kind == KIND_LINEAR) return false;
+  static const char* env = getenv("GTNX_DEVICE_LEVELIZE");
+  if (env) return env[0] == '1';
+  return !s.host_valid && s.dev_valid;
+}
+void build_device_schedule(Structure& s) {
+  Runtime& rt = Runtime::get();
+  GTNX_PROF("device_levelize", 0.0);
+  if (!s.dev_valid) {
+    std::vector<Structure*> one{&s};
+    ensure_device_batch(one);
+  }
+  s.ensure_full();
+  const DGraph g = s.dview;
+  const size_t N = size_t(g.N), A = size_t(g.A), na = size_t(g.n_accept);
+  Packer pk;
+  const size_t o_lv = pk.add(4 * (N + 2)), o_ro = pk.add(4 * (N + 1)), o_sp = pk.add(4 * (A ? A : 1)), o_ia = pk.add(4 * (A ? A : 1)),
+               o_pf = pk.add(N ? N : 1), o_ap = pk.add(4 * (na ? na : 1)), o_oo = pk.add(4 * (N + 1)), o_od = pk.add(4 * (A ? A : 1)),
+               o_oa = pk.add(4 * (A ? A : 1));
+  DevMemP dev = rt.alloc(pk.total);
+  char* db = dev->as<char>();
+  LevelizeOut out{reinterpret_cast<int*>(db + o_lv), reinterpret_cast<int*>(db + o_ro), reinterpret_cast<int*>(db + o_sp),
+                  reinterpret_cast<int*>(db + o_ia), reinterpret_cast<uint8_t*>(db + o_pf), reinterpret_cast<int*>(db + o_ap),
+                  reinterpret_cast<int*>(db + o_oo), reinterpret_cast<int*>(db + o_od), reinterpret_cast<int*>(db + o_oa)};
+  DevMemP scratch = rt.alloc(levelize_scratch_bytes(int(N), int(A)));
+  int info[LV_INFO_INTS];
+  device_levelize(g, out, scratch->ptr, info, rt.stream());
+  auto sc = std::make_shared<Schedule>();
+  sc->error = info[LV_ERROR] != 0;
+  sc->mem = dev;
+  sc->max_level_width = info[LV_MAX_WIDTH];
+  sc->max_level_arcs = info[LV_MAX_LEVEL_ARCS];
+  sc->max_reach = info[LV_MAX_REACH];
+  sc->n_in = info[LV_N_IN];
+  sc->n_out = info[LV_N_OUT];
+  sc->all_written = info[LV_P] == int(N) && info[LV_N_OUT] == int(A);
+  sc->has_rank = false;
+  DSched& v = sc->view;
+  v.P = info[LV_P];
+  v.L = info[LV_L];
+  v.n_accept = int(na);
+  // rows are copies of the device in-lists: the reference's list order for an uploaded host graph (ties by row
+  // slot), but UNORDERED for a composition result (compose fills them through atomic cursors): ties by arc id,
+  // which is the order the reference's lists would have
+  v.flags = g.in_rec ? 0 : SCHED_TIE_BY_ARC;
+  v.level_off = out.level_off;
+  v.row_off = out.row_off;
+  v.in_srcpos = out.in_srcpos;
+  v.in_arc = out.in_arc;
+  v.in_rank = nullptr;
+  v.in_w = nullptr;
+  v.pflags = out.pflags;
+  v.acc_pos = out.acc_pos;
+  v.out_off = out.out_off;
+  v.out_dstpos = out.out_dstpos;
+  v.out_arc = out.out_arc;
+  s.sched = sc;
+}
+}  // namespace
+
 void ensure_schedule_batch(const std::vector<Structure*>& ss, bool need_rank) {
   Runtime& rt = Runtime::get();
   std::vector<Structure*> todo;
   for (Structure* s : ss) {
     if (s->kind == KIND_LINEAR) continue;
     if (s->sched && (!need_rank || s->sched->has_rank || (s->sched->view.flags & SCHED_TIE_BY_ARC))) continue;
-    if (std::find(todo.begin(), todo.end(), s) == todo.end()) todo.push_back(s);
+    if (std::find(todo.begin(), todo.end(), s) != todo.end()) continue;
+    if (device_schedule_wanted(*s, need_rank)) build_device_schedule(*s);
+    else todo.push_back(s);
   }
   if (todo.empty()) return;
   std::vector<HostSched> hs(todo.size());

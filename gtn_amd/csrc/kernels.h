@@ -89,6 +89,23 @@ struct DSched {
 };
 enum : int { SCHED_TIE_BY_ARC = 1, SCHED_OUT_IDENTITY = 2 };
 
+// the same schedule built on the device from the graph's CSR arrays (levelize.hip); positions inside a level
+// are in node-id order (no queue replay: not for viterbiPath's tie-break)
+struct LevelizeOut {
+  int* level_off;    // [N + 2]
+  int* row_off;      // [N + 1]
+  int* in_srcpos;    // [A]
+  int* in_arc;       // [A]
+  uint8_t* pflags;   // [N]
+  int* acc_pos;      // [n_accept]
+  int* out_off;      // [N + 1]
+  int* out_dstpos;   // [A]
+  int* out_arc;      // [A]
+};
+enum : int { LV_P = 0, LV_L, LV_N_IN, LV_N_OUT, LV_ERROR, LV_MAX_WIDTH, LV_MAX_LEVEL_ARCS, LV_MAX_REACH, LV_INFO_INTS };
+size_t levelize_scratch_bytes(int N, int A);
+void device_levelize(const DGraph& g, const LevelizeOut& out, void* scratch, int* info_host /* LV_INFO_INTS */, hipStream_t st);
+
 // per-graph result of the forward sweep (kept for the backward sweep)
 struct SdResult {
   float score;      // shortest.cpp:159

@@ -871,3 +871,43 @@ def test_python_host_side_builders_and_formats(gtn, tmp_path):
         save(p, g1)
         assert gtn.equal(load(p), g1)
     assert "0 1 2 3 0.5" in repr(g1)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_non_layered_product_is_levelized_on_the_device(gtn, seed):
+    """compose of two DAGs with level-skipping arcs: the product is built on the device and is NOT layered, so
+    forwardScore / viterbiScore need a level schedule for a structure that only exists there -- levelize.hip
+    (Kahn reachability as a pull fixpoint, both directions) builds it without downloading the graph.  Scores
+    and the gradients of both inputs against the oracle run on the oracle's own composition."""
+    rng = np.random.default_rng(100 + seed)
+    d1 = gg.random_dag(rng, 14, avg_deg=3.0, nlabels=3, n_start=2, n_accept=2)
+    d2 = gg.random_dag(rng, 11, avg_deg=3.0, nlabels=3, n_start=1, n_accept=2)
+    d1["ol"] = d1["il"] = rng.integers(0, 3, len(d1["src"])).tolist()
+    d2["il"] = d2["ol"] = rng.integers(0, 3, len(d2["src"])).tolist()
+    o1, o2 = OGraph.from_dict(d1), OGraph.from_dict(d2)
+    oc = o1.compose(o2)
+    for tropical in (False, True):
+        g1, g2 = gg.to_api(gtn, d1), gg.to_api(gtn, d2)
+        gtn.prof_reset()
+        gtn.prof_enable(True)
+        comp = gtn.compose(g1, g2)
+        sc = gtn.viterbi_score(comp) if tropical else gtn.forward_score(comp)
+        gtn.prof_enable(False)
+        names = gtn.prof_names()
+        if oc.A == 0:
+            continue
+        want = oc.shortest_distance(tropical)
+        assert sc.item() == pytest.approx(want, rel=1e-5, abs=1e-5)
+        if np.isfinite(want):
+            gtn.backward(sc)
+            deltas = oc.shortest_distance_grad(tropical)
+            w1, w2 = oc.compose_grad(deltas, len(d1["src"]), len(d2["src"]))
+            np.testing.assert_allclose(g1.grad().weights_to_numpy(), w1, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(g2.grad().weights_to_numpy(), w2, rtol=1e-4, atol=1e-5)
+        # (a product that happens to be layered takes compose's own schedule: count the seeds that did not)
+        test_non_layered_product_is_levelized_on_the_device.hits += "device_levelize" in names
+    if seed == 5:
+        assert test_non_layered_product_is_levelized_on_the_device.hits > 0, "no seed exercised levelize.hip"
+
+
+test_non_layered_product_is_levelized_on_the_device.hits = 0

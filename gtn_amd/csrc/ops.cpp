@@ -2949,7 +2949,12 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
   }
   Runtime& rt = Runtime::get();
   std::vector<std::pair<int, int>> slot;
-  auto groups = lazy_forward(gs, SD_TROPICAL, slot);
+  GTNX_HOST_T("lazy_viterbi_path.total");
+  std::vector<std::shared_ptr<LazyGroupState>> groups;
+  {
+    GTNX_HOST_T("lazy_viterbi_path.1_forward_enqueue");
+    groups = lazy_forward(gs, SD_TROPICAL, slot);
+  }
   auto op = std::make_shared<LazyPathOp>();
   op->seq = next_seq();
   op->saved.resize(gs.size());
@@ -2967,7 +2972,11 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
     int* plen = reinterpret_cast<int*>(pw + nT);
     launch_lazy_path(v, parc, pil, pol, pw, plen, rt.stream());
     PinnedMemP host = rt.alloc_pinned(pbytes ? pbytes : 1);  // 16 B per path arc: pageable memory would be staged and slow
-    rt.d2h_sync(host->ptr, pm->ptr, pbytes);
+    {
+      GTNX_HOST_T("lazy_viterbi_path.2_wait_download");
+      rt.d2h_sync(host->ptr, pm->ptr, pbytes);
+    }
+    GTNX_HOST_T("lazy_viterbi_path.3_path_graphs");
     const int* harc = host->as<int>();
     const int* hil = harc + nT;
     const int* hol = hil + nT;

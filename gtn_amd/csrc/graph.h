@@ -111,6 +111,7 @@ struct Structure {
     int max_in_deg = 0;
     int64_t valid = 0;
     int ncol = 0, ndead = 0;
+    bool uniq = false;  // no two nodes share a label
     DevMemP tables;  // [N] labels | [N] node -> column | [ncol] column -> node | [ndead] dead nodes
   };
   std::shared_ptr<DenseInfo> dense[2];

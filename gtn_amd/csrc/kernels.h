@@ -339,6 +339,7 @@ struct LazyGroup {          // utterances that share one explicit graph G
   const float* E;             // [N][N] row = source, col = destination (0: no arc)
   const float* cmax;          // [N] largest in-arc weight per destination (-inf: none)
   const int* nlab;            // [N] matched label of the node's in-arcs (-1: none)
+  int lab_unique;             // no two nodes share a matched label (gradient rows need no atomics)
   float* amax;                // [T+1][nb] row max of alpha[t]   (written by the forward steps)
   float* bmax;                // [T][nb]   row max of em + beta[t+1] + cmax (backward steps)
   float* R;                   // [N][N] sum over (t, utterance) of the arc posteriors / exp(w)

@@ -276,6 +276,9 @@ __global__ __launch_bounds__(kBlock) void lazy_chain_grad_nodes_kernel(LazyGroup
 // gradients, then the posteriors binned by label in the wave's LDS row and the row stored once.  One wave per
 // pair, four pairs per wave: alpha and beta are read once instead of twice, by 16 x fewer workgroups.
 constexpr int ZG_PAIRS = 4;
+// UNIQ: no two nodes share a label (ASG transitions): plain LDS stores -- float atomics go through the LDS
+// one lane at a time (measured: 1.2 of this kernel's 1.56 ms at C4 were its 16 ds_add_f32 per pair)
+template <bool UNIQ>
 __global__ __launch_bounds__(kBlock) void lazy_z_chain_grad_kernel(LazyGroup g, const int* __restrict__ node_label, float* zt) {
   extern __shared__ float rows[];  // [4 waves][C]
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -331,7 +334,10 @@ __global__ __launch_bounds__(kBlock) void lazy_z_chain_grad_kernel(LazyGroup g, 
     for (int i = 0; i < 16; ++i) {
       if (lab[i] < 0) continue;
       const float xv = x[i] - z;
-      if (xv != NEG_INF) atomicAdd(&row[lab[i]], __expf(xv) * dl);
+      if (xv != NEG_INF) {
+        if (UNIQ) row[lab[i]] = __expf(xv) * dl;
+        else atomicAdd(&row[lab[i]], __expf(xv) * dl);
+      }
     }
     // (one wave: its LDS operations complete in order, no barrier)
     for (int c = lane; c < g.C; c += 64) out[int64_t(t) * g.C + c] = row[c];
@@ -1185,8 +1191,10 @@ void launch_lazy_z_chain_grad(const LazyGroup& g, const int* node_label, float* 
   const int64_t npairs = int64_t(g.T) * g.nb;
   if (npairs <= 0) return;
   const int64_t per_wg = 4 * ZG_PAIRS;
-  hipLaunchKernelGGL(lazy_z_chain_grad_kernel, dim3(unsigned((npairs + per_wg - 1) / per_wg)), dim3(kBlock),
-                     sizeof(float) * 4 * size_t(g.C), st, g, node_label, zt);
+  const dim3 grid(unsigned((npairs + per_wg - 1) / per_wg));
+  const size_t lds = sizeof(float) * 4 * size_t(g.C);
+  if (g.lab_unique) hipLaunchKernelGGL(lazy_z_chain_grad_kernel<true>, grid, dim3(kBlock), lds, st, g, node_label, zt);
+  else hipLaunchKernelGGL(lazy_z_chain_grad_kernel<false>, grid, dim3(kBlock), lds, st, g, node_label, zt);
 }
 
 void launch_lazy_chain_grad(const LazyGroup& g, const int* node_label, hipStream_t st) {

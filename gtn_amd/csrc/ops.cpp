@@ -1773,6 +1773,7 @@ struct LazyGroupState {
   bool dense = false;               // probability-domain products (lazy.hip "dense regime")
   bool mfma = false;                // ... on the matrix cores (v_mfma_f32_32x32x2_f32)
   bool maxplus = false;             // tropical semiring over a dense G (maxplus.hip): no back-pointer planes
+  bool lab_unique = false;          // no two nodes of G share a matched label
   DevMemP dense_mem;
   Graph fixed;                      // keeps G alive
   std::vector<Graph> chains;        // per member
@@ -1808,6 +1809,12 @@ struct LazyKey {
 std::vector<int> lazy_node_labels(Structure& fs, bool chain_first, int C, int* max_in_deg);
 // host facts about a fixed partner G for the dense regime, taken once per structure (a trainer keeps its
 // transitions graph; only the weights move)
+bool labels_unique(const std::vector<int>& lab) {
+  std::unordered_set<int> seen;
+  for (int l : lab)
+    if (l >= 0 && !seen.insert(l).second) return false;
+  return true;
+}
 std::shared_ptr<Structure::DenseInfo> dense_info(Structure& fs, bool chain_first, int C) {
   std::shared_ptr<Structure::DenseInfo>& slot = fs.dense[chain_first ? 0 : 1];
   if (slot && slot->C == C) return slot;
@@ -1831,6 +1838,7 @@ std::shared_ptr<Structure::DenseInfo> dense_info(Structure& fs, bool chain_first
     }
     di->ncol = int(colnode.size());
     di->ndead = int(dead.size());
+    di->uniq = labels_unique(di->lab);
     std::vector<int> ints(di->lab);
     ints.insert(ints.end(), tab.begin(), tab.end());
     ints.insert(ints.end(), colnode.begin(), colnode.end());
@@ -1899,6 +1907,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     if (!getenv("GTNX_NO_DENSE") && N <= 1024 && N >= 8) di = dense_info(fs, st.view.chain_first != 0, C);
     const bool dense_ok = di && !di->lab.empty() && 2 * di->valid >= int64_t(N) * N;
     if (di) st.max_in_deg = di->max_in_deg;
+    if (di) st.lab_unique = di->uniq;
     st.maxplus = mode == SD_TROPICAL && dense_ok && T >= 1 && di->ncol > 0;
     const size_t o_alpha = add(4 * plane * size_t(T + 1));
     const size_t o_bp = (mode == SD_LOG || st.maxplus) ? 0 : add(4 * plane * size_t(T + 1));
@@ -1962,6 +1971,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     if (mode != SD_LOG || getenv("GTNX_NO_DENSE") || v.N > 1024 || v.N < 8) continue;
     std::shared_ptr<Structure::DenseInfo> di = dense_info(fs, v.chain_first != 0, v.C);
     st.max_in_deg = di->max_in_deg;
+    st.lab_unique = di->uniq;
     const std::vector<int>& lab = di->lab;
     if (lab.empty()) continue;
     if (2 * di->valid < int64_t(v.N) * v.N) continue;
@@ -2116,12 +2126,14 @@ struct LazySdOp : OpRecord {
           fixed.s->ensure_csr();
           std::vector<int> lab = lazy_node_labels(*fixed.s, v.chain_first != 0, C, &st.max_in_deg);
           if (!lab.empty()) {
+            st.lab_unique = labels_unique(lab);
             st.labels = upload_vec(lab);
             st.node_label = st.labels->as<int>();
           }
         }
         DevMemP ztm = rt.alloc(4 * size_t(T > 0 ? T : 1) * size_t(nb));
         if (st.node_label && lazy_z_chain_grad_ok(v)) {
+          v.lab_unique = st.lab_unique ? 1 : 0;
           launch_lazy_z_chain_grad(v, st.node_label, ztm->as<float>(), rt.stream());
           v.zt = ztm->as<float>();
         } else {

@@ -26,6 +26,7 @@
 // real in-row (parallel arcs and missing arcs included) -- same arc, same path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 
 #include "kernels.h"
@@ -207,6 +208,7 @@ __device__ __forceinline__ int wave_min63(int x) {
   return __builtin_amdgcn_readlane(x, 63);
 }
 constexpr int MP_EMROW = 1024;  // emission rows up to this many labels are staged (else one load per step)
+template <int RMAX>  // 64-lane slices of the staged rows: ceil(max(N, staged C) / 64), rounded up to 4 / 8 / 12 / 16
 __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path_arc, int* path_il, int* path_ol,
                                                          float* path_w, int* path_len) {
   extern __shared__ float lds[];
@@ -227,31 +229,39 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
   for (int n = l; n < N; n += 64) nlab[n] = g.nlab[n];
   const GTNX_G float* em = (const GTNX_G float*)g.em[b];
   const float* arow = g.alpha + int64_t(b) * N;
-  constexpr int RMAX = 16;  // N <= 1024 in this regime
   constexpr int RB = 8;
-  float pre[RMAX], pe[RMAX];
+  struct Rows {
+    float a[RMAX], e[RMAX];
+  };
   // (always valid addresses, no branches: a conditional request would turn the counted wait for the
   // records, which are requested BEFORE these rows and so return before them, into a wait for everything)
-  auto fetch = [&](int t) {  // alpha[t] and the emission row of step t
+  auto fetch = [&](Rows& r, int t) {  // alpha[t] and the emission row of step t
 #pragma unroll
     for (int i = 0; i < RMAX; ++i) {
       const int n = l + 64 * i;
-      pre[i] = arow[int64_t(t) * plane + (n < N ? n : N - 1)];
-      pe[i] = stage_em ? em[int64_t(t) * C + (n < C ? n : C - 1)] : 0.0f;
+      r.a[i] = arow[int64_t(t) * plane + (n < N ? n : N - 1)];
+      r.e[i] = stage_em ? em[int64_t(t) * C + (n < C ? n : C - 1)] : 0.0f;
     }
   };
-  auto park = [&](int buf) {
+  auto park = [&](const Rows& r, int buf) {
 #pragma unroll
     for (int i = 0; i < RMAX; ++i) {
       const int n = l + 64 * i;
-      if (n < N) rows[buf * N + n] = pre[i];
-      if (stage_em && n < C) erows[buf * C + n] = pe[i];
+      if (n < N) rows[buf * N + n] = r.a[i];
+      if (stage_em && n < C) erows[buf * C + n] = r.e[i];
     }
   };
-  fetch(T - 1);
-  park((T - 1) & 1);
+  // Rows are requested TWO steps before they are parked (a step's own chain is shorter than a trip to HBM),
+  // into two register sets that alternate: step t requests the rows of step t - 3 and parks those of t - 2.
+  Rows r0, r1;
+  fetch(r0, T - 1);
+  park(r0, (T - 1) & 1);
+  fetch(r1, T >= 2 ? T - 2 : 0);
   __syncthreads();
-  for (int t = T; t >= 1; --t) {
+  bool failed = false;
+  int keep_arc = 0, keep_lab = 0;
+  float keep_e = 0.0f;
+  auto step = [&](int t, Rows& rq, const Rows& rp) {  // rq: set to request into, rp: set to park
     const float* prev = rows + ((t - 1) & 1) * N;
     const int lab = nlab[node];  // every matched in-arc of `node` carries this label
     const float e = lab < 0 ? 0.0f : (stage_em ? erows[((t - 1) & 1) * C + lab] : em[int64_t(t - 1) * C + lab]);
@@ -270,7 +280,7 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
       }
       if (kb == k0) {
         __builtin_amdgcn_sched_barrier(0);
-        fetch(t >= 2 ? t - 2 : 0);
+        fetch(rq, t >= 3 ? t - 3 : 0);
         __builtin_amdgcn_sched_barrier(0);
       }
 #pragma unroll
@@ -291,22 +301,40 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     const float mx = wave_max63(m);
     arg = wave_min63(m == mx ? arg : INT_MAX);
     if (arg == INT_MAX) {  // cannot happen below a finite best score
-      if (l == 0) path_len[b] = -1;
+      failed = true;
       return;
     }
     const int wl = (arg - k0) & 63;  // record k sits with lane (k - k0) mod 64, whose own best it is
     bsrc = __builtin_amdgcn_readlane(bsrc, wl);
     barc = __builtin_amdgcn_readlane(barc, wl);
-    if (l == 0) {
-      const int64_t o = int64_t(b) * T + (t - 1);
-      path_arc[o] = barc;
-      path_il[o] = g.chain_first ? lab : g.g.il[barc];
-      path_ol[o] = g.chain_first ? g.g.ol[barc] : lab;
-      path_w[o] = g.g.w[barc] + e;
-    }
+    // the step's arc goes to the lane that owns path index t - 1 (selects: a lane-0 store here would put a
+    // branch join between the requests above and the counted wait of park() below); every 64 steps the lanes
+    // write their entries out together
+    const bool mine = ((t - 1) & 63) == l;
+    keep_arc = mine ? barc : keep_arc;
+    keep_lab = mine ? lab : keep_lab;
+    keep_e = mine ? e : keep_e;
     node = bsrc;
-    park(t & 1);  // step t-2's rows -> the buffers step t's sat in ((t - 2) & 1 == t & 1)
+    park(rp, t & 1);  // step t-2's rows -> the buffers step t's sat in ((t - 2) & 1 == t & 1)
     __syncthreads();
+    if (((t - 1) & 63) == 0) {
+      const int idx = (t - 1) + l;
+      if (idx < T) {
+        const int64_t o = int64_t(b) * T + idx;
+        path_arc[o] = keep_arc;
+        path_il[o] = g.chain_first ? keep_lab : g.g.il[keep_arc];
+        path_ol[o] = g.chain_first ? g.g.ol[keep_arc] : keep_lab;
+        path_w[o] = g.g.w[keep_arc] + keep_e;
+      }
+    }
+  };
+  for (int t = T; t >= 1 && !failed; t -= 2) {
+    step(t, r0, r1);
+    if (t >= 2 && !failed) step(t - 1, r1, r0);
+  }
+  if (failed) {
+    if (l == 0) path_len[b] = -1;
+    return;
   }
   if (l == 0) path_len[b] = T;
 }
@@ -338,7 +366,13 @@ void launch_maxplus_path(const LazyGroup& g, int* path_arc, int* path_il, int* p
                          hipStream_t st) {
   if (g.nb <= 0) return;
   const size_t lds = sizeof(float) * (size_t(4) * g.N + 1 + (g.C <= MP_EMROW ? size_t(2) * g.C : 0));
-  hipLaunchKernelGGL(maxplus_path_kernel, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
+  // (every staged slice is a load per lane per step: 513 nodes and 512 labels need 9, not 16)
+  const int slices = (std::max(g.N, g.C <= MP_EMROW ? g.C : 0) + 63) / 64;
+  if (slices <= 4) hipLaunchKernelGGL(maxplus_path_kernel<4>, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
+  else if (slices <= 8) hipLaunchKernelGGL(maxplus_path_kernel<8>, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
+  else if (slices <= 10) hipLaunchKernelGGL(maxplus_path_kernel<10>, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
+  else if (slices <= 12) hipLaunchKernelGGL(maxplus_path_kernel<12>, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
+  else hipLaunchKernelGGL(maxplus_path_kernel<16>, dim3(g.nb), dim3(64), lds, st, g, path_arc, path_il, path_ol, path_w, path_len);
 }
 
 }  // namespace gtnx

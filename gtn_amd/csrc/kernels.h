@@ -342,6 +342,9 @@ struct LazyGroup {          // utterances that share one explicit graph G
   int lab_unique;             // no two nodes share a matched label (gradient rows need no atomics)
   float* amax;                // [T+1][nb] row max of alpha[t]   (written by the forward steps)
   float* bmax;                // [T][nb]   row max of em + beta[t+1] + cmax (backward steps)
+  float* amaxp;               // [T+1][nb][ntp] the same, one partial per column tile (matrix-core form: reduced into
+  float* bmaxp;               //                amax / bmax once a pass is through, launch_lazy_mfma_rowmax)
+  int ntp;                    // partials per row: column tiles rounded up to 4
   float* R;                   // [N][N] sum over (t, utterance) of the arc posteriors / exp(w)
   // gradients: per (t, utterance) normaliser log sum_n exp(alpha[t+1][n] + beta[t+1][n]).  It
   // equals the total score exactly in exact arithmetic; in float32 the two sweeps drift apart
@@ -530,7 +533,8 @@ void launch_maxplus_path(const LazyGroup& g, int* path_arc, int* path_il, int* p
 void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st);                // Ep / ETp from E
 void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st);     // keys, first input (0 forward, 1 backward)
 void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st);
-void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // row-maximum keys -> floats
+void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // order-preserving integer keys -> floats
+void launch_lazy_mfma_rowmax(const LazyGroup& g, int which, hipStream_t st);   // amaxp -> amax (0) / bmaxp -> bmax (1)
 void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x T x nb */, hipStream_t st);  // R zero-filled
 
 // ---------------------------------------------------------------------------

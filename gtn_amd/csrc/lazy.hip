@@ -630,8 +630,9 @@ __global__ __launch_bounds__(kDense) void lazy_dense_step_kernel(LazyGroup g, in
 //     itself: the largest operand is then exp(one step's growth), not 1 -- harmless in float32 as
 //     long as a step moves a row's best score by less than ~80 nats, and no pass over the row is
 //     needed before exponentiating;
-//   * the true row maxima (the gradient kernels balance their factors around them) come out of
-//     the epilogues through an atomic max on an order-preserving integer key.
+//   * the true row maxima (the gradient kernels balance their factors around them) leave the epilogues as
+//     one partial per (row, column tile) -- a plain store -- and every consumer takes the maximum of a
+//     row's partials itself (an atomic max per row and tile cost 2 of a step's 10 microseconds).
 // One wave per 32 x 32 output tile; 17 x 16 tiles at C4 keep 272 of the chip's 1024 SIMDs'
 // matrix cores busy for 257 MFMAs each.
 // =====================================================================================
@@ -642,6 +643,17 @@ __device__ __forceinline__ int fkey(float x) {
   return b >= 0 ? b : b ^ 0x7fffffff;
 }
 __device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+// maximum over each aligned group of 32 lanes, in every lane of the group
+__device__ __forceinline__ float half32_max(float x) {
+#define GTNX_ROR_MAX(ctrl) x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false)))
+  GTNX_ROR_MAX(0x128);  // row_ror:8
+  GTNX_ROR_MAX(0x124);  // row_ror:4
+  GTNX_ROR_MAX(0x122);  // row_ror:2
+  GTNX_ROR_MAX(0x121);  // row_ror:1
+#undef GTNX_ROR_MAX
+  return fmaxf(x, __shfl_xor(x, 16, 64));
+}
 
 // Slots.  Leading nodes without a matched in-arc (the start node of an ASG transitions graph) are dead
 // from step 1 on in both sweeps: alpha is -inf there, and beta only ever meets that alpha.  The operand
@@ -679,11 +691,11 @@ __global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0 && b < g.nb) {
+  if (threadIdx.x == 0 && b < g.nb) {  // partial 0 of the row; the others stay -inf
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    int* keys = reinterpret_cast<int*>(BWD ? g.bmax : g.amax);
-    if (!BWD) keys[b] = fkey(m);
-    else if (g.T > 0) keys[int64_t(g.T - 1) * g.nb + b] = fkey(m);
+    float* mp = BWD ? g.bmaxp : g.amaxp;
+    if (!BWD) mp[int64_t(b) * g.ntp] = m;
+    else if (g.T > 0) mp[(int64_t(g.T - 1) * g.nb + b) * g.ntp] = m;
   }
 }
 
@@ -701,6 +713,7 @@ template <bool BWD>
 __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup g, int t) {
   __shared__ float part[MF_WAVES][16][64];
   __shared__ float tr[32][36];
+  __shared__ float refp[32][2][8];  // row maxima, partially reduced (ntp <= 32: eight 16-byte pieces)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
   // Workgroups go to the 8 XCDs in turn, and every kernel boundary empties their L2s: XCD x takes a
   // contiguous run of tiles in row-major order (all column tiles of its two row tiles at C4), so it
@@ -717,7 +730,8 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
   const gtnx_f4* X = reinterpret_cast<const gtnx_f4*>(g.xt[BWD ? ((t + 1) & 1) : (t & 1)]);
   float* Xn = g.xt[BWD ? (t & 1) : ((t + 1) & 1)];
   const gtnx_f4* Em = reinterpret_cast<const gtnx_f4*>(BWD ? g.ETp : g.Ep);
-  int* keys = reinterpret_cast<int*>(BWD ? g.bmax : g.amax);
+  float* Mp = BWD ? g.bmaxp : g.amaxp;  // [T + 1][nb][ntp] row maxima, one partial per column tile
+  const int ntp = g.ntp;
   const int64_t plane = int64_t(nb) * N;
   const int o = o0 + lo;      // slot
   const bool ocol = o < Nl;
@@ -730,25 +744,37 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     const int reg = MF_ROWS * wv + v;
     rowi[v] = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
   }
-  // the epilogue's per-row scalars are requested first: pointers and keys now, the emission once its row
+  // the epilogue's per-row scalars are requested first: pointers and row maxima now, the emission once its row
   // pointer is there (by then the first operand batch is in flight behind it)
   const int lab_ = g.nlab[on_];
   const float cm_ = g.cmax[on_];
   const int lab = ocol ? lab_ : -1;
   const float cm = ocol ? cm_ : NEG_INF;
   const float* erow[MF_ROWS];
-  int k_in[MF_ROWS], k_out[MF_ROWS];
 #pragma unroll
   for (int v = 0; v < MF_ROWS; ++v) {
     const int b = b0 + rowi[v];
-    const int bb = b < nb ? b : 0;
-    erow[v] = g.em[bb];
-    // reference the input was exponentiated against / the one the next input will be
-    // (first step of a pass: any valid row, value replaced)
-    const int tk = !BWD ? (t > 0 ? t - 1 : 0) : (t < g.T - 1 ? t + 1 : t);
-    const int kv = keys[int64_t(tk) * nb + bb];
-    k_in[v] = (!BWD ? t > 0 : t < g.T - 1) ? kv : fkey(0.0f);
-    k_out[v] = keys[int64_t(t) * nb + bb];
+    erow[v] = g.em[b < nb ? b : 0];
+  }
+  // Row maxima of the tile's 32 rows: the reference the input was exponentiated against (one step back) and the
+  // one the next input will be (this step's own row): 2 x ntp partials per row, fetched 16 bytes per thread and
+  // combined through LDS on the way to the barrier the partial tiles meet at anyway.
+  const bool has_in = !BWD ? t > 0 : t < g.T - 1;
+  const int t_in = !BWD ? (t > 0 ? t - 1 : 0) : (t < g.T - 1 ? t + 1 : t);
+  // (requested here, parked in LDS only after the product: the request must not be waited for up front)
+  const int Q = ntp >> 2;  // 16-byte pieces per row
+  const int npieces = 32 * 2 * Q;  // <= 512: at most two per thread
+  gtnx_f4 rv[2];
+  int ri[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i0 = int(threadIdx.x) + u * MF_WAVES * 64;
+    const int i = i0 < npieces ? i0 : int(threadIdx.x) % npieces;
+    ri[u] = i0 < npieces ? i : -1;
+    const int r = i / (2 * Q), j = (i / Q) & 1, q = i % Q;
+    const int b = b0 + r;
+    const int64_t row = int64_t(j ? t : t_in) * nb + (b < nb ? b : 0);
+    rv[u] = reinterpret_cast<const gtnx_f4*>(Mp + row * ntp)[q];
   }
   // ---- this wave's share of the k groups (4 k each = two MFMAs)
   const int groups = g.Kpad >> 2;
@@ -807,6 +833,13 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
   acc += acc2;
 #pragma unroll
   for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (ri[u] >= 0) {
+      const int i = ri[u];
+      refp[i / (2 * Q)][(i / Q) & 1][i % Q] = fmaxf(fmaxf(rv[u].x, rv[u].y), fmaxf(rv[u].z, rv[u].w));
+    }
+  }
   __syncthreads();
   // ---- epilogue: registers MF_ROWS wv .. of the summed tile, column lo
   float* outp = BWD ? g.beta + int64_t(t) * plane : g.alpha + int64_t(t + 1) * plane;
@@ -819,7 +852,12 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     float a = 0.0f;
 #pragma unroll
     for (int p = 0; p < MF_WAVES; p += 2) a += part[p][reg][l] + part[p + 1][reg][l];
-    const float m_in = funkey(k_in[v]), m_out = funkey(k_out[v]);
+    float m_in = refp[i][0][0], m_out = refp[i][1][0];
+    for (int q = 1; q < (ntp >> 2); ++q) {
+      m_in = fmaxf(m_in, refp[i][0][q]);
+      m_out = fmaxf(m_out, refp[i][1][q]);
+    }
+    if (!has_in) m_in = 0.0f;  // the first input of a pass is exponentiated against 0
     float val = NEG_INF, nxt = NEG_INF;  // alpha[t+1] / beta[t]; the next step's contraction input
     if (on && ocol && a > 0.0f && m_in != NEG_INF) {
       val = __logf(a) + m_in;
@@ -832,11 +870,10 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     }
     if (on && ocol) outp[int64_t(b) * N + on_] = val;
     // row maximum of the next input over this tile's 32 columns -> its key
-    float rm = nxt;
-#pragma unroll
-    for (int s = 16; s > 0; s >>= 1) rm = fmaxf(rm, __shfl_xor(rm, s, 32));
-    if (lo == 0 && on && rm != NEG_INF && (!BWD || t >= 1))
-      atomicMax(&keys[int64_t(BWD ? t - 1 : t + 1) * nb + b], fkey(rm));
+    // (over the half-wave's 32 columns: rotations inside the two 16-lane DPP rows, then ONE cross-lane read --
+    // five ds_bpermute per row were 2 of a step's 10 microseconds)
+    const float rm = half32_max(nxt);
+    if (lo == 0 && on && (!BWD || t >= 1)) Mp[(int64_t(BWD ? t - 1 : t + 1) * nb + b) * ntp + (o0 >> 5)] = rm;
     tr[i][lo] = (nxt == NEG_INF || m_out == NEG_INF) ? 0.0f : __expf(nxt - m_out);
   }
   __syncthreads();
@@ -867,10 +904,18 @@ __global__ void lazy_mfma_dead_rows_kernel(LazyGroup g, float* X, int j_lo) {
   X[(int64_t(j >> 2) * g.nbpad + b) * 4 + (j & 3)] = 0.0f;
 }
 
-// keys -> floats, once a pass is through
+// keys -> floats (maxplus.hip builds its W through integer keys)
 __global__ void lazy_mfma_keys_kernel(float* p, int64_t n) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i < n) p[i] = funkey(__float_as_int(p[i]));
+}
+// the row maxima of a pass, once it is through: the maximum of every row's partials
+__global__ void lazy_mfma_rowmax_kernel(const float* __restrict__ mp, float* __restrict__ out, int64_t rows, int ntp) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= rows) return;
+  float m = NEG_INF;
+  for (int q = 0; q < ntp; ++q) m = fmaxf(m, mp[i * ntp + q]);
+  out[i] = m;
 }
 // E zero-padded in operand layout [k / 4][column][k % 4], and its transpose
 __global__ void lazy_mfma_pad_kernel(LazyGroup g, float* Ep, float* ETp) {
@@ -1251,9 +1296,15 @@ void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st) {
                      const_cast<float*>(g.ETp));
 }
 // which 0: before the forward steps (all keys "-inf", X_0); 1: before the backward steps
+void launch_lazy_mfma_rowmax(const LazyGroup& g, int which, hipStream_t st) {
+  const int64_t rows = int64_t(g.T + 1) * g.nb;
+  if (rows > 0)
+    hipLaunchKernelGGL(lazy_mfma_rowmax_kernel, dim3(unsigned((rows + 255) / 256)), dim3(256), 0, st,
+                       (const float*)(which ? g.bmaxp : g.amaxp), which ? g.bmax : g.amax, rows, g.ntp);
+}
 void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st) {
-  const int64_t nk = int64_t(g.T + 1) * g.nb;
-  launch_fill_i32(reinterpret_cast<int*>(which ? g.bmax : g.amax), int(0x807fffff), size_t(nk), st);  // key of -inf
+  const int64_t nk = int64_t(g.T + 1) * g.nb * g.ntp;
+  launch_fill_i32(reinterpret_cast<int*>(which ? g.bmaxp : g.amaxp), int(0xff800000), size_t(nk), st);  // -inf
   (void)hipMemsetAsync(g.xt[0], 0, sizeof(float) * size_t(g.Kpad) * size_t(g.nbpad), st);
   (void)hipMemsetAsync(g.xt[1], 0, sizeof(float) * size_t(g.Kpad) * size_t(g.nbpad), st);
   if (which) hipLaunchKernelGGL(lazy_mfma_init_kernel<true>, dim3(g.nbpad), dim3(256), 0, st, g);

@@ -1994,7 +1994,13 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     v.nbpad = (v.nb + 31) & ~31;
     const size_t o_Ep = add(4 * size_t(v.Kpad) * size_t(v.Npad2)), o_ETp = add(4 * size_t(v.Kpad) * size_t(v.Npad2)),
                  o_x0 = add(4 * size_t(v.Kpad) * size_t(v.nbpad)), o_x1 = add(4 * size_t(v.Kpad) * size_t(v.nbpad));
+    // row maxima as one partial per column tile (the step kernels store, the consumers reduce: no atomics)
+    v.ntp = (((v.N - v.rot + 31) / 32) + 3) & ~3;
+    const size_t o_amp = add(4 * size_t(v.T + 1) * size_t(v.nb) * size_t(v.ntp)),
+                 o_bmp = add(4 * size_t(v.T + 1) * size_t(v.nb) * size_t(v.ntp));
     st.dense_mem = rt.alloc(bytes);
+    v.amaxp = st.dense_mem->as<float>(o_amp);
+    v.bmaxp = st.dense_mem->as<float>(o_bmp);
     v.E = st.dense_mem->as<float>(o_E);
     v.cmax = st.dense_mem->as<float>(o_c);
     v.nlab = st.node_label;
@@ -2020,7 +2026,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
         launch_lazy_mfma_prep(st.view, rt.stream());
         launch_lazy_mfma_init(st.view, 0, rt.stream());
         for (int t = 0; t < st.view.T; ++t) launch_lazy_mfma_step(st.view, t, 0, rt.stream());
-        launch_lazy_mfma_keys(st.view.amax, int64_t(st.view.T + 1) * st.view.nb, rt.stream());
+        launch_lazy_mfma_rowmax(st.view, 0, rt.stream());
       } else {
         for (int t = 0; t < st.view.T; ++t) launch_lazy_dense_step(st.view, t, 0, rt.stream());
       }
@@ -2112,7 +2118,7 @@ struct LazySdOp : OpRecord {
         if (st.dense && st.mfma) {
           launch_lazy_mfma_init(v, 1, rt.stream());
           for (int t = T - 1; t >= 0; --t) launch_lazy_mfma_step(v, t, 1, rt.stream());
-          launch_lazy_mfma_keys(v.bmax, int64_t(T + 1) * nb, rt.stream());
+          launch_lazy_mfma_rowmax(v, 1, rt.stream());
         } else if (st.dense) {
           DevMemP vs = rt.alloc(8 * plane);  // two planes: input of this step / of the next
           float* vb[2] = {vs->as<float>(), vs->as<float>() + plane};

@@ -387,6 +387,7 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
   GTNX_TM_INIT(0);
 
   if (sweeper) {
+    __builtin_amdgcn_s_setprio(1);  // the recursion is the critical path; the staging waves of the CU's other workgroup yield (2 %)
     // ------------------------------------------------------------------ the recursion: no global loads
     const int w = wv;
     const int m0 = threadIdx.x * NPL;
@@ -677,6 +678,7 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
   GTNX_TM_INIT(64);
 
   if (sweeper) {
+    __builtin_amdgcn_s_setprio(1);  // the recursion is the critical path; the staging waves of the CU's other workgroup yield (2 %)
     // ------------------------------------------------------------------ the recursion: no global loads in the loop
     const int w = wv;
     const int lag = 3 - w;

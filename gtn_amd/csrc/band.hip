@@ -1079,25 +1079,29 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
 // ==========================================================================================
 __global__ __launch_bounds__(512) void ctc_targets_kernel(const CtcTargetArgs* __restrict__ args, int blank) {
   const CtcTargetArgs a = args[blockIdx.x];
-  __shared__ int lab[512];
-  __shared__ int cnt[512];
+  __shared__ __attribute__((aligned(16))) int lab[512];
+  __shared__ __attribute__((aligned(16))) int cnt[512];
   const int N = a.N, m = threadIdx.x;
   int my = blank, skip = 0;
-  if (m < N) {
-    if (m & 1) {
-      my = a.labels[(m - 1) >> 1];
-      skip = (m > 1 && my != a.labels[((m - 1) >> 1) - 1]) ? 1 : 0;
-    }
-    lab[m] = my;
-    cnt[m] = 1 + (m > 0 ? 1 : 0) + skip;
+  if (m < N && (m & 1)) {
+    my = a.labels[(m - 1) >> 1];
+    skip = (m > 1 && my != a.labels[((m - 1) >> 1) - 1]) ? 1 : 0;
   }
+  // (padding past N: a label above every real one and no arcs, so the 16-byte reads below need no bound)
+  lab[m] = m < N ? my : 0x7fffffff;
+  cnt[m] = m < N ? 1 + (m > 0 ? 1 : 0) + skip : 0;
   __syncthreads();
   if (m >= N) return;
+  // rank among the (label, node) pairs and first arc id: N comparisons per node, four per LDS read
   int rank = 0, base = 0;
-  for (int o = 0; o < N; ++o) {
-    const int lo = lab[o];
-    rank += (lo < my || (lo == my && o < m)) ? 1 : 0;
-    base += o < m ? cnt[o] : 0;
+  for (int o = 0; o < N; o += 4) {
+    const gtnx_i4 l4 = *reinterpret_cast<const gtnx_i4*>(lab + o), c4 = *reinterpret_cast<const gtnx_i4*>(cnt + o);
+    const int lo[4] = {l4.x, l4.y, l4.z, l4.w}, co[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      rank += (lo[k] < my || (lo[k] == my && o + k < m)) ? 1 : 0;
+      base += o + k < m ? co[k] : 0;
+    }
   }
   GTNX_G BandNode* nd = const_cast<GTNX_G BandNode*>(a.nodes);
   nd[m].lab = my;

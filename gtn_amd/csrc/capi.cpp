@@ -143,7 +143,10 @@ bool gather(GatherOp op, GatherReq& req) {
   G0.leader[op] = true;
   // (the time limit only guards against a thread of the region that blocks outside the engine)
   if (G0.waiting >= G0.active) G0.cv_lead.notify_all();
-  G0.cv_lead.wait_for(lk, std::chrono::milliseconds(20), [&] { return G0.waiting >= G0.active; });
+  {
+    GTNX_HOST_T("gather.leader_waits_for_all");
+    G0.cv_lead.wait_for(lk, std::chrono::milliseconds(20), [&] { return G0.waiting >= G0.active; });
+  }
   std::vector<GatherReq*> group;
   group.swap(G0.pending[op]);
   G0.leader[op] = false;
@@ -158,6 +161,7 @@ bool gather(GatherOp op, GatherReq& req) {
       a.push_back(r->a);
       if (binary) b.push_back(r->b);
     }
+    GTNX_HOST_T("gather.run_group");
     std::vector<Graph> out = run_group(op, a, b);
     for (size_t i = 0; i < out.size(); ++i) group[i]->out = std::move(out[i]);
   } catch (...) {

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cstdlib>
 
 #include "kernels.h"
 
@@ -1134,6 +1135,140 @@ __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_kernel(LazyGroup g, 
     }
   }
 }
+// The same contraction with WIDE operand loads, for graphs whose live slots come in whole groups of four (C4:
+// 512).  A lane holds four consecutive source slots (one 16-byte load of alpha) and two consecutive destination
+// slots (one 8-byte load of beta): row tile j of a wave's 128 x 64 block takes source slots s0 + 4 lo + j, column tile
+// c destination slots d0 + 2 lo + c -- which rows of R a tile holds is free as long as the write-out agrees.  Five
+// load instructions per EIGHT MFMAs instead of fourteen: the 4-byte version was bound by the number of its loads.
+typedef float mf_f2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float mf_f4u __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int FG_DEPTH = 6;
+template <bool STRIDED>
+__global__ __launch_bounds__(256) void lazy_mfma_fixed_grad4_kernel(LazyGroup g, const gtnx_f4* __restrict__ pc,
+                                                                   int pairs_per_block) {
+  __shared__ float part[4][32][64];
+  const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
+  const int sb = blockIdx.x, db = blockIdx.y, zb = blockIdx.z;
+  const int s0 = sb * 128, d0 = db * 64;
+  const int N = g.N, C = g.C, nb = g.nb, Nl = g.N - g.rot;
+  const int64_t plane = int64_t(nb) * N;
+  int64_t npairs = int64_t(g.T) * nb;
+  if (d0 >= Nl) return;       // destinations without a matched in-arc: no arc, no gradient
+  if (s0 >= Nl) npairs = nb;  // sources that are dead from step 1 on: alpha is -inf beyond step 0
+  const int64_t p0 = int64_t(zb) * pairs_per_block, p1 = min(npairs, p0 + pairs_per_block);
+  if (p0 >= p1) return;
+  // this lane's four source slots s0 + 4 lo + j and two destination slots d0 + 2 lo + c.  Live groups are
+  // whole (Nl is a multiple of 4) and map to consecutive nodes; a group at or past Nl holds the dead nodes
+  // (slots Nl .. N-1 = nodes 0 ..), again consecutive, the rest of it past the end of the graph
+  const int sg = s0 + 4 * lo, dg = d0 + 2 * lo;
+  bool sok[4], dok[2];
+  int lab[2], labc[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sok[j] = sg + j < N;
+  const int sn0 = mf_node(g, sok[0] ? sg : 0);  // node of the group's first slot: the four are sn0 .. sn0 + 3
+  const int sn0c = min(sn0, N - 4);             // (the load stays inside the row; components are shifted back below)
+  const int dn0 = mf_node(g, dg < N ? dg : 0), dn0c = min(dn0, N - 2);
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    dok[c] = dg + c < N;
+    const int lb = g.nlab[dok[c] ? dn0 + c : 0];
+    lab[c] = dok[c] ? lb : -1;
+    labc[c] = lab[c] >= 0 ? lab[c] : 0;
+  }
+  const int sshift = sn0 - sn0c, dshift = dn0 - dn0c;  // 0 except in the graph's last, partial group
+  gtnx_f16v acc[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) acc[j][c] = gtnx_f16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int pp = int(p0) + 2 * wv + hi;
+  int t = pp / nb, b = pp - t * nb;
+  const int pend = int(p1), plast = int(p1) - 1;
+  const int step_t = 8 / nb, step_b = 8 % nb;  // eight pairs on
+  struct Round {
+    mf_f4u al;
+    mf_f2u be;
+    float ev[2];
+    gtnx_f4 c;
+  };
+  auto request = [&](Round& r) {
+    const bool in = pp < pend;
+    const int tc = in ? t : 0, bc = in ? b : 0;
+    r.c = pc[in ? pp : plast];
+    if (!in) r.c.w = 0.0f;
+    const float* ar = g.alpha + int64_t(tc) * plane + int64_t(bc) * N;
+    const float* br = g.beta + int64_t(tc + 1) * plane + int64_t(bc) * N;
+    const GTNX_G float* er =
+        (STRIDED ? (const GTNX_G float*)g.em_base + int64_t(bc) * g.em_stride : (const GTNX_G float*)g.em[bc]) + int64_t(tc) * C;
+    r.al = *reinterpret_cast<const mf_f4u*>(ar + sn0c);
+    r.be = *reinterpret_cast<const mf_f2u*>(br + dn0c);
+    r.ev[0] = er[labc[0]];
+    r.ev[1] = er[labc[1]];
+    pp += 8;
+    b += step_b;  // (selects, not a loop: a branch between requests would zero the counted waits)
+    t += step_t;
+    const bool wrap = b >= nb;
+    b -= wrap ? nb : 0;
+    t += wrap ? 1 : 0;
+  };
+  auto multiply = [&](const Round& r) {
+    const bool on = r.c.w != 0.0f;
+    const float alv[4] = {r.al.x, r.al.y, r.al.z, r.al.w}, bev[2] = {r.be.x, r.be.y};
+    float a[4], q[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = alv[(j + sshift) & 3];  // (sshift != 0 only where sok[j + ...] fails anyway, except the shifted ones)
+      a[j] = (on && sok[j] && x != NEG_INF) ? __expf(x + r.c.x) : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float x = bev[(c + dshift) & 1];
+      q[c] = (on && lab[c] >= 0 && x != NEG_INF) ? __expf(r.ev[c] + x + r.c.y) * r.c.z : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[j][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], q[c], acc[j][c], 0, 0, 0);
+  };
+  // A round's eight MFMAs are 512 cycles, a trip to memory ten times that, and the accumulators leave room for
+  // two waves per SIMD only: FG_DEPTH - 1 rounds are in flight behind the one being multiplied (rounds past
+  // the end are weight-0 re-reads of the last pair)
+  const int first = int(p0) + 2 * wv;
+  const int rounds = first < pend ? (pend - first + 7) / 8 : 0;
+  Round rr[FG_DEPTH];
+#pragma unroll
+  for (int k = 0; k < FG_DEPTH - 1; ++k) request(rr[k]);
+  for (int it = 0; it < rounds; it += FG_DEPTH) {
+#pragma unroll
+    for (int k = 0; k < FG_DEPTH; ++k) {
+      request(rr[(k + FG_DEPTH - 1) % FG_DEPTH]);
+      __builtin_amdgcn_sched_barrier(0);
+      multiply(rr[k]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // ---- the four waves' partial blocks, one row tile (two tiles = 32 registers) at a time through LDS; wave wv
+  // then adds registers 8 wv .. 8 wv + 7 of the pair into R
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j) __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+      part[wv][v][l] = acc[j][0][v];
+      part[wv][16 + v][l] = acc[j][1][v];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const int r = 8 * wv + v;  // 0..15: column tile 0, 16..31: tile 1
+      const int reg = r & 15, c = r >> 4;
+      const int i = (reg & 3) + 8 * (reg >> 2) + 4 * hi;  // row of the tile = lane lo' of the A operand
+      const float a = (part[0][r][l] + part[1][r][l]) + (part[2][r][l] + part[3][r][l]);
+      const int ss = s0 + 4 * i + j;  // the slot row i of row tile j stands for
+      if (ss < N && dok[c] && a != 0.0f) atomicAdd(&g.R[int64_t(mf_node(g, ss)) * N + dn0 + c], a);
+    }
+  }
+}
 // grad[a] += exp(w[a]) * R[src][dst]  (the balancing shifts of A' and Q' cancel exactly:
 // A' * Q' = exp(alpha + em + beta - Z) * delta)
 __global__ void lazy_dense_arc_grad_kernel(LazyGroup g) {
@@ -1328,9 +1463,17 @@ void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStrea
   const int64_t npairs = int64_t(g.T) * g.nb;
   gtnx_f4* pc = static_cast<gtnx_f4*>(pair_consts);
   hipLaunchKernelGGL(lazy_mfma_pairs_kernel, dim3(unsigned((npairs + 255) / 256)), dim3(256), 0, st, g, pc);
-  const int pairs_per_block = 16384;
+  static const int ppb_env = getenv("GTNX_FG_PPB") ? atoi(getenv("GTNX_FG_PPB")) : 0;
+  const int pairs_per_block = ppb_env > 0 ? ppb_env : 2048;  // (the 4-byte version: 5.2 ms at 16384, 4.95 ms at 2048)
   const dim3 grid(unsigned((g.N + 63) / 64), unsigned((g.N + 63) / 64), unsigned((npairs + pairs_per_block - 1) / pairs_per_block));
-  if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<true>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
+  if (((g.N - g.rot) & 3) == 0 && g.N >= 8 && !getenv("GTNX_FIXED_GRAD_NARROW")) {  // whole groups of four live slots: wide loads
+    // (slices of 4096 pairs: the 40 blocks of a slice run together and re-read the same rows of the planes while
+    // they are still cached -- 5.7 ms at 16384, 4.5 ms at 4096; ordering the blocks by XCD on top changed nothing)
+    const int ppb = ppb_env > 0 ? ppb_env : 4096;
+    const dim3 grid4(unsigned((g.N + 127) / 128), unsigned((g.N + 63) / 64), unsigned((npairs + ppb - 1) / ppb));
+    if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<true>, grid4, dim3(256), 0, st, g, (const gtnx_f4*)pc, ppb);
+    else hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<false>, grid4, dim3(256), 0, st, g, (const gtnx_f4*)pc, ppb);
+  } else if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<true>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
   else hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<false>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
   if (g.g.A > 0) hipLaunchKernelGGL(lazy_dense_arc_grad_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g);
 }

@@ -700,16 +700,17 @@ __global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
   }
 }
 
-// one workgroup of four waves per 32 x 32 output tile: each wave runs a quarter of the contraction, the
-// partial tiles are summed through LDS and each wave finishes eight of the tile's rows.  (Eight waves would
-// halve the chain again but need the whole CU's registers: 272 tiles on 256 CUs would then run in two rounds.)  A step is a chain of
-// latencies, not of throughput (257 MFMAs per tile against several trips to memory that the kernel
+// one workgroup of EIGHT waves per 32 x 32 output tile: each wave runs an eighth of the contraction, the
+// partial tiles are summed through LDS and each wave finishes four of the tile's rows.  (With the planes rotated
+// past the dead start node there are exactly as many tiles as CUs at C4, so a workgroup may take its CU's whole
+// register file: 9.85 -> 9.1 microseconds per step against four waves.)  A step is a chain of
+// latencies, not of throughput (288 MFMAs per tile against several trips to memory that the kernel
 // boundary has just flushed out of L2): the operands of a wave's k groups are requested in two
 // alternating batches, the next batch before the current one is multiplied, and the epilogue's scalars
 // before either.
-constexpr int MF_WAVES = 4;
+constexpr int MF_WAVES = 8;
 constexpr int MF_ROWS = 16 / MF_WAVES;  // accumulator registers (tile rows per half-wave) a wave finishes
-constexpr int MF_BATCH = 18;  // k groups (two MFMAs each) per operand batch: two batches are a wave's quarter of C4's 576 padded sources
+constexpr int MF_BATCH = 9;  // k groups (two MFMAs each) per operand batch: two batches are a wave's eighth of C4's 576 padded sources
 template <bool BWD>
 __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup g, int t) {
   __shared__ float part[MF_WAVES][16][64];

@@ -1989,7 +1989,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     // matrix-core form (lazy.hip: lazy_mfma_*): padded E and its transpose, two transposed input planes
     v.rot = 0;
     while (v.rot < v.N - 1 && lab[size_t(v.rot)] < 0) ++v.rot;
-    v.Kpad = (v.N + 575) / 576 * 576;  // zero rows up to an even number of operand batches per wave (lazy.hip: 4 k x 4 waves x 2 x 18 groups)
+    v.Kpad = (v.N + 575) / 576 * 576;  // zero rows up to an even number of operand batches per wave (lazy.hip: 4 k x 8 waves x 2 x 9 groups)
     v.Npad2 = (v.N + 31) & ~31;
     v.nbpad = (v.nb + 31) & ~31;
     const size_t o_Ep = add(4 * size_t(v.Kpad) * size_t(v.Npad2)), o_ETp = add(4 * size_t(v.Kpad) * size_t(v.Npad2)),

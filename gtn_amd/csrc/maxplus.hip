@@ -11,13 +11,13 @@
 // sweep has to write and nobody but T of them per utterance is ever read).
 //
 // Step kernel.  512 x 513 outputs per step is a small problem for 1024 SIMDs, so the tile is chosen for
-// operand traffic, not for size: a wave owns 64 utterances (one per lane) x 16 destinations and an eighth
-// of the sources.  alpha[t] arrives TRANSPOSED ([s / 4][b][4], written by the previous step's epilogue):
+// operand traffic, not for size: a wave owns 64 utterances (one per lane) x 16 destinations and a sixteenth
+// of the sources (16 waves per workgroup: four per SIMD cover one another's scalar waits).  alpha[t] arrives TRANSPOSED ([s / 4][b][4], written by the previous step's epilogue):
 // one 16-byte load per lane brings four sources.  W arrives through the SCALAR path: its 16 values per
 // source are wave-uniform, so they are s_load'ed into SGPRs (pairs of sources interleaved, so that
 // v_pk_add_f32 takes {x[s], x[s+1]} + {W[s][d], W[s+1][d]} with an SGPR pair as operand) and never touch
-// LDS or VGPRs.  Per pair of product arcs: one v_pk_add_f32 + one v_max3_f32.  The eight partial tiles
-// meet in LDS; each wave finishes two destinations (emission added once per destination: all in-arcs
+// LDS or VGPRs.  Per pair of product arcs: one v_pk_add_f32 + one v_max3_f32.  The sixteen partial tiles
+// meet in LDS; each wave finishes one destination (emission added once per destination: all in-arcs
 // of a node share their label in this regime).
 //
 // Ties.  The generic kernel (lazy.hip: lazy_step_kernel<SD_TROPICAL>) keeps the FIRST maximal in-arc in
@@ -35,8 +35,10 @@ namespace gtnx {
 namespace {
 
 constexpr float NEG_INF = -__builtin_inff();
-constexpr int MP_WAVES = 8;   // source split inside a workgroup
+constexpr int MP_WAVES = 16;  // source split inside a workgroup
+constexpr int MP_FIN = 1;     // destinations a wave finishes (MP_COLS / MP_WAVES)
 constexpr int MP_COLS = 16;   // destinations per workgroup
+static_assert(MP_FIN * MP_WAVES == MP_COLS, "every destination of the tile is finished by one wave");
 
 typedef float mp_f2 __attribute__((ext_vector_type(2)));
 typedef float mp_f16 __attribute__((ext_vector_type(16)));
@@ -97,13 +99,13 @@ __global__ __launch_bounds__(MP_WAVES * 64) void maxplus_step_kernel(LazyGroup g
   const bool on = b < g.nb;
   const int N = g.N, C = g.C, nbp = g.nbpad;
   // ---- the two destinations this wave finishes: their emission terms are requested now
-  int dn[2];
-  float ev[2];
+  int dn[MP_FIN];
+  float ev[MP_FIN];
   {
     const float* erow = g.em[on ? b : 0];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
-      const int j = dblk * MP_COLS + 2 * wv + v;
+    for (int v = 0; v < MP_FIN; ++v) {
+      const int j = dblk * MP_COLS + MP_FIN * wv + v;
       dn[v] = j < g.mp_ncol ? g.mp_colnode[j] : -1;
       const int lab = dn[v] >= 0 ? g.nlab[dn[v]] : -1;
       ev[v] = (on && lab >= 0) ? erow[int64_t(t) * C + lab] : 0.0f;
@@ -166,8 +168,8 @@ __global__ __launch_bounds__(MP_WAVES * 64) void maxplus_step_kernel(LazyGroup g
   float* outp = g.alpha + int64_t(t + 1) * plane + int64_t(b) * N;
   float* Xn = g.xt[(t + 1) & 1];
 #pragma unroll
-  for (int v = 0; v < 2; ++v) {
-    const int r = 2 * wv + v;
+  for (int v = 0; v < MP_FIN; ++v) {
+    const int r = MP_FIN * wv + v;
     float m = part[0][r][l];
 #pragma unroll
     for (int p = 1; p < MP_WAVES; ++p) m = __builtin_fmaxf(m, part[p][r][l]);

@@ -19,6 +19,7 @@ PROGRAMS = [
     "rand_test",
     "utils_test",
     "gather_test",  # own program (tests/native/gather_test.cpp): calls gathered from parallelMap threads
+    "adjacency_refs_test",  # own program: references into out(n) / in(n) / start() / accept() stay valid across calls
 ]
 
 

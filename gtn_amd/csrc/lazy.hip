@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256) void lazy_mfma_init_kernel(LazyGroup g) {
 // before either.
 constexpr int MF_WAVES = 8;
 constexpr int MF_ROWS = 16 / MF_WAVES;  // accumulator registers (tile rows per half-wave) a wave finishes
-constexpr int MF_BATCH = 9;  // k groups (two MFMAs each) per operand batch: two batches are a wave's eighth of C4's 576 padded sources
+constexpr int MF_BATCH = 3;  // k groups (two MFMAs each) per operand batch, two alternating: six batches are a wave's eighth of C4's 576 padded sources (batches of 9: 9.1 us per step, of 3: 8.3, of 1: 9.1)
 template <bool BWD>
 __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup g, int t) {
   __shared__ float part[MF_WAVES][16][64];

@@ -231,7 +231,7 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
   for (int n = l; n < N; n += 64) nlab[n] = g.nlab[n];
   const GTNX_G float* em = (const GTNX_G float*)g.em[b];
   const float* arow = g.alpha + int64_t(b) * N;
-  constexpr int RB = 8;
+  constexpr int RB = 9;  // records per lane per batch: 576 cover the 513-arc in-rows of C4 in ONE trip to memory
   struct Rows {
     float a[RMAX], e[RMAX];
   };
@@ -270,8 +270,8 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     const int k0 = ioff[node], k1 = ioff[node + 1];
     float m = NEG_INF;
     int arg = INT_MAX, bsrc = 0, barc = 0;
-    // the in-row, eight records per lane at a time, all requested before the first is looked at (one
-    // exposed trip to memory per 512 records, not one per record); the rows of the step after next queue
+    // the in-row, nine records per lane at a time, all requested before the first is looked at (one
+    // exposed trip to memory per 576 records, not one per record); the rows of the step after next queue
     // up behind the first batch
     for (int kb = k0; kb == k0 || kb < k1; kb += 64 * RB) {
       gtnx_i4 r[RB];

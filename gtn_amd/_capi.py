@@ -133,6 +133,7 @@ _SIGS = {
     "gtnx_isomorphic": [c_graph, c_graph, c_i32_p],
     "gtnx_parallel_enter": [],
     "gtnx_parallel_leave": [],
+    "gtnx_parallel_flush": [],
     "gtnx_prof_enable": [C.c_int],
     "gtnx_prof_reset": [],
     "gtnx_prof_get": [C.c_char_p, C.POINTER(C.c_double), c_i64_p, C.POINTER(C.c_double)],
@@ -172,7 +173,7 @@ def load(path=None):
             # engine extensions (batch records, borrowed tensors): absent from the reference-backed
             # test shim (oracle/ref_shim.cpp), which only the CPU tests load through GTN_AMD_LIB
             if name.startswith("gtnx_batch_") or name in ("gtnx_linear_graph_borrow_n", "gtnx_grads_bind_device_n",
-                                                             "gtnx_parallel_enter", "gtnx_parallel_leave"):
+                                                             "gtnx_parallel_enter", "gtnx_parallel_leave", "gtnx_parallel_flush"):
                 continue
             raise
         fn.argtypes = args

@@ -231,6 +231,21 @@ struct BFromGraphsOp : BatchOp {
 
 }  // namespace
 
+Batch::~Batch() {
+  // taken apart off the caller's critical path, a few dozen graphs per entry so that the threads of the next
+  // parallelMap region share them (runtime.cpp: drain_some)
+  if (graphs.size() < 64 || !Runtime::initialized()) return;
+  Runtime& rt = Runtime::get();
+  for (size_t i = 0; i < graphs.size(); i += 32) {
+    auto* part = new std::vector<Graph>();
+    const size_t e = std::min(graphs.size(), i + 32);
+    part->reserve(e - i);
+    for (size_t k = i; k < e; ++k) part->push_back(std::move(graphs[k]));
+    rt.defer_delete(part, [](void* q) { delete static_cast<std::vector<Graph>*>(q); });
+  }
+  graphs.clear();
+}
+
 int64_t Batch::elem_size(int b) const {
   switch (kind) {
     case SCALAR: return 1;
@@ -445,9 +460,101 @@ BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool b
   return b;
 }
 
+// ---- the caller's graphs as native leaves --------------------------------------------------------
+BatchP batch_ctc_targets_from_graphs(const std::vector<Graph>& gs) {
+  const int n = int(gs.size());
+  if (n == 0) return nullptr;
+  detect_ctc_shape(*gs[0].s);
+  const Structure& s0 = *gs[0].s;
+  if (!s0.ctc_labels) return nullptr;
+  const bool cg = gs[0].calc_grad();
+  std::vector<int> flat, len;
+  len.reserve(size_t(n));
+  flat.reserve(size_t(n) * s0.ctc_labels->size());
+  for (auto& g : gs) {
+    detect_ctc_shape(*g.s);
+    const Structure& s = *g.s;
+    // (arcSort by input label is what benchmarks/ctc.cpp:56 asks for; a CTC acceptor's lists are the same either way)
+    if (!s.ctc_labels || s.ctc_blank != s0.ctc_blank || g.calc_grad() != cg || s.N > band_max_nodes() ||
+        !g.w->is_all_zero())
+      return nullptr;
+    flat.insert(flat.end(), s.ctc_labels->begin(), s.ctc_labels->end());
+    len.push_back(int(s.ctc_labels->size()));
+  }
+  BatchP b = batch_ctc_targets(flat.data(), len.data(), n, s0.ctc_blank, cg);
+  if (b->kind != Batch::CTC_TARGETS) return nullptr;  // (labels the records cannot hold: the per-graph way)
+  b->graphs = gs;
+  b->leaf = true;
+  return b;
+}
+
+BatchP batch_linear_from_graphs(const std::vector<Graph>& gs) {
+  const int n = int(gs.size());
+  if (n == 0) return nullptr;
+  const Structure& s0 = *gs[0].s;
+  if (s0.kind != KIND_LINEAR || s0.M < 1 || s0.C < 1) return nullptr;
+  const bool cg = gs[0].calc_grad();
+  std::vector<Weights*> ws;
+  ws.reserve(size_t(n));
+  std::unordered_set<Weights*> distinct;
+  for (auto& g : gs) {
+    const Structure& s = *g.s;
+    if (s.kind != KIND_LINEAR || s.M != s0.M || s.C != s0.C || g.calc_grad() != cg || g.w->host_escaped ||
+        !distinct.insert(g.w.get()).second)
+      return nullptr;
+    ws.push_back(g.w.get());
+  }
+  ensure_weights_device_batch(ws);
+  Runtime& rt = Runtime::get();
+  const size_t A = size_t(s0.M) * size_t(s0.C);
+  BatchP b = make_batch(Batch::LINEAR, n, cg);
+  b->M = s0.M;
+  b->C = s0.C;
+  bool contiguous = true;
+  for (int i = 0; i < n && contiguous; ++i)
+    contiguous = ws[size_t(i)]->dev == ws[0]->dev + size_t(i) * A && ws[size_t(i)]->dev_mem == ws[0]->dev_mem;
+  if (contiguous) {
+    b->w_mem = ws[0]->dev_mem;
+    b->w_dev = ws[0]->dev;
+  } else {
+    // one [n][M][C] tensor: gather the graphs' weights and let the graphs read it from now on (same values)
+    b->w_mem = rt.alloc(sizeof(float) * A * size_t(n));
+    b->w_dev = b->w_mem->as<float>();
+    std::vector<CopySeg> segs;
+    segs.resize(size_t(n));
+    for (int i = 0; i < n; ++i) segs[size_t(i)] = {b->w_dev + size_t(i) * A, ws[size_t(i)]->dev, int64_t(4 * A)};
+    DevMemP d = upload_vec(segs);
+    launch_copy_segments(d->as<CopySeg>(), n, int64_t(4 * A), rt.stream());
+    for (int i = 0; i < n; ++i) {
+      ws[size_t(i)]->dev_mem = b->w_mem;
+      ws[size_t(i)]->dev = b->w_dev + size_t(i) * A;
+    }
+  }
+  b->graphs = gs;
+  b->leaf = true;
+  return b;
+}
+
 // ---- elements as graphs ------------------------------------------------------------------------
+namespace {
+// what the batch-level backward produced moves into the element graphs
+void push_grads_to_graphs(Batch& x) {
+  if (!x.g_dev) return;
+  GradSink sink;  // first gradients are adopted in place, the others folded in by ONE launch
+  for (int i = 0; i < x.n; ++i) sink.add(x.graphs[size_t(i)], x.g_mem, x.g_dev + x.g_off[size_t(i)]);
+  sink.flush();
+  x.g_dev = nullptr;  // (the graphs hold the block now)
+  x.g_mem.reset();
+}
+}  // namespace
+
 void batch_materialise(Batch& x) {
   if (x.materialised) return;
+  if (x.leaf) {  // the elements have been graphs all along
+    x.materialised = true;
+    push_grads_to_graphs(x);
+    return;
+  }
   std::vector<Graph> gs;
   switch (x.fal && x.kind == Batch::GRAPHS ? Batch::CTC_TARGETS : x.kind) {
     case Batch::GRAPHS: break;
@@ -776,13 +883,7 @@ void batch_backward(const BatchP& root, bool retain) {
   t_plan = nullptr;
   // leaves whose elements were taken out as graphs: those carry the gradient
   for (Batch* b : seen)
-    if (b->materialised && b->g_dev && !b->op) {
-      GradSink sink;  // first gradients are adopted in place, the others folded in by ONE launch
-      for (int i = 0; i < b->n; ++i) sink.add(b->graphs[size_t(i)], b->g_mem, b->g_dev + b->g_off[size_t(i)]);
-      sink.flush();
-      b->g_dev = nullptr;
-      b->g_mem.reset();
-    }
+    if ((b->materialised || b->leaf) && b->g_dev && !b->op) push_grads_to_graphs(*b);
   if (!retain)
     for (Batch* b : order) {
       if (b != root.get()) {
@@ -802,6 +903,15 @@ void batch_items_device(const BatchP& x, void* dev_out) {
   }
   batch_materialise(*x);
   items_device(x->graphs, dev_out);
+}
+float batch_item_host(const BatchP& x, int i) {
+  if (i < 0 || i >= x->n) throw_range("[gtnx_batch_get] element index out of range");
+  if (!x->host_vals_valid) {
+    x->host_vals.resize(size_t(x->n));
+    Runtime::get().d2h_sync(x->host_vals.data(), x->v_dev, sizeof(float) * size_t(x->n));
+    x->host_vals_valid = true;
+  }
+  return x->host_vals[size_t(i)];
 }
 void batch_items_host(const BatchP& x, float* out) {
   if (x->kind == Batch::SCALAR && !x->materialised) {

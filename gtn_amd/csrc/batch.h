@@ -41,6 +41,13 @@ struct Batch {
   // gradients: batch-level results are pushed into them)
   bool materialised = false;
   std::vector<Graph> graphs;
+  // CTC_TARGETS / LINEAR made FROM the caller's graphs (region.cpp: the leaves of a parallelMap region): `graphs`
+  // are those graphs from the start, the native arrays describe the same values, and every gradient the batch
+  // functions produce is pushed into the graphs (that is where the caller looks)
+  bool leaf = false;
+  // SCALAR: the values on the host, fetched once when an element's item() is asked for (batch_item_host)
+  std::vector<float> host_vals;
+  bool host_vals_valid = false;
 
   // ---- CTC_TARGETS: label sequences back to back; records (BandNode, flags, sorted lists) on the device
   std::vector<int> labels, lab_off;  // lab_off[n + 1]
@@ -78,6 +85,7 @@ struct Batch {
   float* dest = nullptr;
 
   int64_t elem_size(int b) const;    // gradient floats of element b (arcs; an upper bound for CTC_TARGETS)
+  ~Batch();                          // the element graphs go to the runtime's deferred list in chunks
 };
 
 BatchP batch_from_graphs(std::vector<Graph> gs);
@@ -94,6 +102,12 @@ void batch_items_device(const BatchP& x, void* dev_out);
 void batch_grads_device(const BatchP& x, void* dev_out, const int64_t* offsets);
 void batch_grads_bind(const BatchP& x, void* dev_out, const int64_t* offsets);
 Graph batch_get(const BatchP& x, int i);
+float batch_item_host(const BatchP& x, int i);  // x SCALAR and not materialised
+// the caller's graphs as native leaves (nullptr when they do not qualify): acceptors that are each exactly
+// ctcGraph(labels) of benchmarks/ctc.cpp:40-58 (Structure::ctc_labels) / linear chains of one shape whose
+// weights are (made) one [n][M][C] device tensor
+BatchP batch_ctc_targets_from_graphs(const std::vector<Graph>& gs);
+BatchP batch_linear_from_graphs(const std::vector<Graph>& gs);
 void batch_materialise(Batch& x);
 
 } // namespace gtnx

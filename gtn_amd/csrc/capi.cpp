@@ -9,6 +9,7 @@
 
 #include "batch.h"
 #include "ops.h"
+#include "region.h"
 
 #define GTNX_API extern "C" __attribute__((visibility("default")))
 
@@ -38,9 +39,16 @@ gtnx_status_t guard(F&& f) {
 
 // GL: the handle as it is (a composition may still be symbolic, ops.cpp "lazy chain
 // products"); G: for everything that looks inside the graph -- builds it first
-inline Graph& GL(gtnx_graph_t h) {
+// RAW: the handle's own pieces, whatever they are (a placeholder of a parallelMap region included: region.h);
+// GL: the graph behind the handle -- a placeholder's call runs now if it has not yet
+inline Graph& RAW(gtnx_graph_t h) {
   if (!h) throw_invalid("null graph handle");
   return *reinterpret_cast<Graph*>(h);
+}
+inline Graph& GL(gtnx_graph_t h) {
+  Graph& g = RAW(h);
+  if (g.s->pending) return region_value(g);
+  return g;
 }
 inline Graph& G(gtnx_graph_t h) {
   Graph& g = GL(h);
@@ -59,6 +67,17 @@ std::vector<Graph> vec(const gtnx_graph_t* a, int n, bool lazy_ok = false) {
 void put(std::vector<Graph>& r, gtnx_graph_t* out) {
   for (size_t i = 0; i < r.size(); ++i) out[i] = H(std::move(r[i]));
 }
+// Is p a HIP device address?  (hipPointerGetAttributes fails for ordinary host memory.)
+bool is_device_pointer(const void* p) {
+  static const bool have_gpu = Runtime::device_count() > 0;
+  if (!have_gpu || !p) return false;
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice;
+}
 void check_node(Graph& g, int n) {
   if (n < 0 || n >= g.num_nodes()) throw_range("node index out of range");
 }
@@ -67,143 +86,20 @@ void check_arc(Graph& g, int a) {
 }
 } // namespace
 
-// ------------------------------------------------------------------ call gathering
+// ------------------------------------------------------------------ parallelMap regions
 // A caller that maps the per-graph functions over a batch on host threads (gtn::parallelMap:
-// parallel/parallel_map.h:153-188; benchmarks/ctc.cpp:150-165) issues B calls of batch size one.
-// Threads that announced themselves (gtnx_parallel_enter, made by include/gtn/parallel.h) have their
-// calls GATHERED: a call waits until every thread of the region is waiting in some call too -- nobody
-// else can join -- and one of them runs the whole group through the vector form.  Same results per
-// graph (the vector forms are element-wise); if the group call throws, the calls are run one by one
-// so that every caller gets its own result or exception.
-namespace {
-enum GatherOp { GO_NEG, GO_ADD, GO_SUB, GO_COMPOSE, GO_INTERSECT, GO_FS, GO_VS, GO_VP, GO_BWD, GO_BWD_RETAIN, GO_COUNT };
-struct GatherReq {
-  Graph a, b;
-  Graph out;
-  std::exception_ptr err;
-  bool done = false;
-};
-struct Gatherer {
-  std::mutex m;
-  std::condition_variable cv_lead;           // leaders: "everybody is waiting somewhere"
-  std::condition_variable cv_done[GO_COUNT];  // followers of one function: "the group has run"
-  std::vector<GatherReq*> pending[GO_COUNT];
-  bool leader[GO_COUNT] = {};
-  int waiting = 0;  // requests queued and not yet taken by a leader
-  int active = 0;   // threads inside a region
-};
-Gatherer& gatherer() {
-  static Gatherer* g = new Gatherer();  // never destroyed: worker threads may outlive static destruction
-  return *g;
-}
-thread_local int t_region_depth = 0;
-
-std::vector<Graph> run_group(GatherOp op, std::vector<Graph>& a, std::vector<Graph>& b) {
-  std::vector<Graph> none;
-  switch (op) {
-    case GO_NEG: return op_scalar(SK_NEGATE, a, none);
-    case GO_ADD: return op_scalar(SK_ADD, a, b);
-    case GO_SUB: return op_scalar(SK_SUBTRACT, a, b);
-    case GO_COMPOSE:
-    case GO_INTERSECT: {
-      // the lattices of such a loop are looked at by forwardScore only: keep them symbolic where
-      // the sweep kernels apply (looking inside one still builds it)
-      const int old = compose_mode_hint(2);
-      try {
-        auto r = op_compose(a, b, op == GO_INTERSECT);
-        compose_mode_hint(old);
-        return r;
-      } catch (...) {
-        compose_mode_hint(old);
-        throw;
-      }
-    }
-    case GO_FS: return op_shortest_distance(a, false);
-    case GO_VS: return op_shortest_distance(a, true);
-    case GO_VP: return op_viterbi_path(a);
-    case GO_BWD:
-    case GO_BWD_RETAIN: op_backward(a, nullptr, op == GO_BWD_RETAIN); return {};
-    default: return {};
-  }
-}
-
-// true: the call was gathered (req.out / req.err are set); false: the caller runs it itself
-bool gather(GatherOp op, GatherReq& req) {
-  if (t_region_depth <= 0) return false;
-  Gatherer& G0 = gatherer();
-  std::unique_lock<std::mutex> lk(G0.m);
-  if (G0.active <= 1) return false;
-  G0.pending[op].push_back(&req);
-  ++G0.waiting;
-  if (G0.leader[op]) {
-    if (G0.waiting >= G0.active) G0.cv_lead.notify_all();  // the last one in wakes the leaders (one wake-up, not one per arrival)
-    G0.cv_done[op].wait(lk, [&] { return req.done; });
-    return true;
-  }
-  G0.leader[op] = true;
-  // (the time limit only guards against a thread of the region that blocks outside the engine)
-  if (G0.waiting >= G0.active) G0.cv_lead.notify_all();
-  {
-    GTNX_HOST_T("gather.leader_waits_for_all");
-    G0.cv_lead.wait_for(lk, std::chrono::milliseconds(20), [&] { return G0.waiting >= G0.active; });
-  }
-  std::vector<GatherReq*> group;
-  group.swap(G0.pending[op]);
-  G0.leader[op] = false;
-  G0.waiting -= int(group.size());
-  lk.unlock();
-  const bool binary = op == GO_ADD || op == GO_SUB || op == GO_COMPOSE || op == GO_INTERSECT;
-  bool ok = true;
-  try {
-    std::vector<Graph> a, b;
-    a.reserve(group.size());
-    for (auto* r : group) {
-      a.push_back(r->a);
-      if (binary) b.push_back(r->b);
-    }
-    GTNX_HOST_T("gather.run_group");
-    std::vector<Graph> out = run_group(op, a, b);
-    for (size_t i = 0; i < out.size(); ++i) group[i]->out = std::move(out[i]);
-  } catch (...) {
-    ok = false;
-  }
-  if (!ok) {  // one by one: every caller gets its own result or exception
-    for (auto* r : group) {
-      try {
-        std::vector<Graph> a{r->a}, b;
-        if (binary) b.push_back(r->b);
-        std::vector<Graph> out = run_group(op, a, b);
-        if (!out.empty()) r->out = std::move(out[0]);
-      } catch (...) {
-        r->err = std::current_exception();
-      }
-    }
-  }
-  lk.lock();
-  for (auto* r : group) r->done = true;
-  G0.cv_done[op].notify_all();
-  return true;
-}
-} // namespace
-
+// parallel/parallel_map.h:153-188; benchmarks/ctc.cpp:150-165) issues B calls of batch size one.  Threads that
+// announced themselves (gtnx_parallel_enter, made by include/gtn/parallel.h) have their calls DEFERRED: the
+// functions return placeholder handles at once and the region's join (gtnx_parallel_flush) runs all of them as
+// one batched launch per function -- region.h.  No thread waits for another one inside the region.
 GTNX_API gtnx_status_t gtnx_parallel_enter(void) {
-  return guard([&] {
-    if (t_region_depth++ == 0) {
-      Gatherer& G0 = gatherer();
-      std::lock_guard<std::mutex> lk(G0.m);
-      ++G0.active;
-    }
-  });
+  return guard([&] { region_enter(); });
 }
 GTNX_API gtnx_status_t gtnx_parallel_leave(void) {
-  return guard([&] {
-    if (t_region_depth > 0 && --t_region_depth == 0) {
-      Gatherer& G0 = gatherer();
-      std::lock_guard<std::mutex> lk(G0.m);
-      --G0.active;
-      if (G0.waiting >= G0.active) G0.cv_lead.notify_all();  // the ones waiting for company may go now
-    }
-  });
+  return guard([&] { region_leave(); });
+}
+GTNX_API gtnx_status_t gtnx_parallel_flush(void) {
+  return guard([&] { region_flush(); });
 }
 
 // ------------------------------------------------------------------ runtime
@@ -262,7 +158,7 @@ GTNX_API gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph(calc_grad != 0)); });
 }
 GTNX_API gtnx_status_t gtnx_graph_copy(gtnx_graph_t g, gtnx_graph_t* out) {
-  return guard([&] { *out = H(GL(g)); });
+  return guard([&] { *out = H(RAW(g)); });  // (a placeholder's copies share its call)
 }
 GTNX_API gtnx_status_t gtnx_graph_deep_copy(gtnx_graph_t g, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph::deep_copy(G(g))); });
@@ -271,7 +167,9 @@ GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
   return guard([&] {
     Graph* p = reinterpret_cast<Graph*>(g);
     if (!p) return;
-    if (Runtime::initialized())
+    if (region_active())
+      region_trash(p);  // handed over when the thread leaves the region (one lock instead of one per handle)
+    else if (Runtime::initialized())
       Runtime::get().defer_delete(p, [](void* q) { delete static_cast<Graph*>(q); });
     else
       delete p;
@@ -279,25 +177,33 @@ GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
 }
 GTNX_API gtnx_status_t gtnx_graph_add_node(gtnx_graph_t g, int s, int a, int* id) {
   return guard([&] {
-    int i = G(g).add_node(s != 0, a != 0);
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    int i = gr.add_node(s != 0, a != 0);
     if (id) *id = i;
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_arc(gtnx_graph_t g, int src, int dst, int il, int ol, float w, int* id) {
   return guard([&] {
-    int i = G(g).add_arc(src, dst, il, ol, w);
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    int i = gr.add_arc(src, dst, il, ol, w);
     if (id) *id = i;
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_nodes(gtnx_graph_t g, int n, const uint8_t* s, const uint8_t* a) {
   return guard([&] {
-    G(g).add_nodes(n, s, a);
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    gr.add_nodes(n, s, a);
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_arcs(gtnx_graph_t g, int n, const int* src, const int* dst, const int* il,
                                            const int* ol, const float* w) {
   return guard([&] {
-    G(g).add_arcs(n, src, dst, il, ol, w);
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    gr.add_arcs(n, src, dst, il, ol, w);
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_num_nodes(gtnx_graph_t g, int64_t* out) {
@@ -316,13 +222,22 @@ GTNX_API gtnx_status_t gtnx_graph_num_inputs(gtnx_graph_t g, int64_t* out) {
   return guard([&] { *out = int64_t(GL(g).g->inputs.size()); });
 }
 GTNX_API gtnx_status_t gtnx_graph_item(gtnx_graph_t g, float* out) {
-  return guard([&] { *out = G(g).item(); });
+  return guard([&] {
+    Graph& raw = RAW(g);
+    if (raw.s->pending && region_item(raw, out)) return;  // a batch record's scalar: no graph is built for it
+    *out = G(g).item();
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_arc_sort(gtnx_graph_t g, int ol) {
-  return guard([&] { G(g).arc_sort(ol != 0); });
+  return guard([&] {
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    gr.arc_sort(ol != 0);
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_mark_arc_sorted(gtnx_graph_t g, int ol) {
   return guard([&] {
+    region_before_mutation(G(g));
     Structure& s = *G(g).s;
     bool& flag = ol ? s.olabel_sorted : s.ilabel_sorted;
     if (!flag) {
@@ -338,7 +253,11 @@ GTNX_API gtnx_status_t gtnx_graph_olabel_sorted(gtnx_graph_t g, int* out) {
   return guard([&] { *out = G(g).s->olabel_sorted; });
 }
 GTNX_API gtnx_status_t gtnx_graph_weights(gtnx_graph_t g, int mut, float** out) {
-  return guard([&] { *out = const_cast<float*>(G(g).weights_host(mut != 0)); });
+  return guard([&] {
+    Graph& gr = G(g);
+    if (mut) region_before_mutation(gr);
+    *out = const_cast<float*>(gr.weights_host(mut != 0));
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_get_weights(gtnx_graph_t g, float* out) {
   return guard([&] {
@@ -348,10 +267,26 @@ GTNX_API gtnx_status_t gtnx_graph_get_weights(gtnx_graph_t g, float* out) {
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_set_weights(gtnx_graph_t g, const float* w) {
-  return guard([&] { G(g).set_weights_host(w); });
+  return guard([&] {
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    // a DEVICE address (e.g. a row of a torch tensor) is taken as one: the reference's one setWeights serves
+    // both (pytorch_loss.py:53-61 has to go through .cpu() there)
+    const bool dev = is_device_pointer(w);
+    if (region_stage_weights(gr, w, dev)) return;
+    if (dev)
+      gr.set_weights_device(w);
+    else
+      gr.set_weights_host(w);
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_set_weights_device(gtnx_graph_t g, const void* w) {
-  return guard([&] { G(g).set_weights_device(w); });
+  return guard([&] {
+    Graph& gr = G(g);
+    region_before_mutation(gr);
+    if (region_stage_weights(gr, static_cast<const float*>(w), true)) return;
+    gr.set_weights_device(w);
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_weights_device(gtnx_graph_t g, void** out) {
   return guard([&] {
@@ -424,6 +359,7 @@ GTNX_API gtnx_status_t gtnx_graph_make_accept(gtnx_graph_t g, int n) {
   return guard([&] {
     Graph& gr = G(g);
     check_node(gr, n);
+    region_before_mutation(gr);
     Structure& s = *gr.s;
     s.materialize();
     s.ensure_host();
@@ -518,6 +454,7 @@ GTNX_API gtnx_status_t gtnx_graph_set_weight(gtnx_graph_t g, int a, float w) {
   return guard([&] {
     Graph& gr = G(g);
     check_arc(gr, a);
+    region_before_mutation(gr);
     gr.w->ensure_host();
     gr.w->host[a] = w;
     gr.w->dev_valid = false;
@@ -528,22 +465,38 @@ GTNX_API gtnx_status_t gtnx_graph_calc_grad(gtnx_graph_t g, int* out) {
   return guard([&] { *out = GL(g).calc_grad(); });
 }
 GTNX_API gtnx_status_t gtnx_graph_set_calc_grad(gtnx_graph_t g, int c) {
-  return guard([&] { GL(g).set_calc_grad(c != 0); });
+  return guard([&] {
+    region_sync_thread();
+    GL(g).set_calc_grad(c != 0);
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_is_grad_available(gtnx_graph_t g, int* out) {
-  return guard([&] { *out = GL(g).is_grad_available(); });
+  return guard([&] {
+    region_sync_thread();  // (a backward queued by this thread inside a parallelMap region runs first)
+    *out = GL(g).is_grad_available();
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_grad(gtnx_graph_t g, gtnx_graph_t* out) {
-  return guard([&] { *out = H(G(g).grad()); });
+  return guard([&] {
+    region_sync_thread();
+    *out = H(G(g).grad());
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_zero_grad(gtnx_graph_t g) {
-  return guard([&] { GL(g).zero_grad(); });
+  return guard([&] {
+    region_sync_thread();
+    GL(g).zero_grad();
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_grad(gtnx_graph_t g, const float* v, int64_t n) {
-  return guard([&] { G(g).add_grad_host(v, n); });
+  return guard([&] {
+    region_sync_thread();
+    G(g).add_grad_host(v, n);
+  });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_grad_graph(gtnx_graph_t g, gtnx_graph_t o) {
   return guard([&] {
+    region_sync_thread();
     Graph& other = G(o);
     Graph& gr = G(g);
     if (!gr.calc_grad()) return;
@@ -607,17 +560,14 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
 }
 
 // ------------------------------------------------------------------ functions
-#define UNARY_FN(name, expr, LAZY_OK, GOP)                                  \
+#define UNARY_FN(name, expr, LAZY_OK, ROP)                                  \
   GTNX_API gtnx_status_t name(gtnx_graph_t g, gtnx_graph_t* out) {          \
     return guard([&] {                                                      \
-      std::vector<Graph> v{LAZY_OK ? GL(g) : G(g)};                         \
-      GatherReq req;                                                        \
-      req.a = v[0];                                                         \
-      if (gather(GOP, req)) {                                               \
-        if (req.err) std::rethrow_exception(req.err);                       \
-        *out = H(std::move(req.out));                                       \
+      if (region_active()) {                                                \
+        *out = H(region_record(ROP, RAW(g), nullptr));                      \
         return;                                                             \
       }                                                                     \
+      std::vector<Graph> v{LAZY_OK ? GL(g) : G(g)};                         \
       auto r = expr;                                                        \
       *out = H(std::move(r[0]));                                            \
     });                                                                     \
@@ -629,18 +579,14 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
       put(r, out);                                                          \
     });                                                                     \
   }
-#define BINARY_FN(name, expr, GOP)                                                      \
+#define BINARY_FN(name, expr, ROP)                                                      \
   GTNX_API gtnx_status_t name(gtnx_graph_t a, gtnx_graph_t b, gtnx_graph_t* out) {      \
     return guard([&] {                                                                  \
-      std::vector<Graph> va{G(a)}, vb{G(b)};                                            \
-      GatherReq req;                                                                    \
-      req.a = va[0];                                                                    \
-      req.b = vb[0];                                                                    \
-      if (gather(GOP, req)) {                                                           \
-        if (req.err) std::rethrow_exception(req.err);                                   \
-        *out = H(std::move(req.out));                                                   \
+      if (region_active()) {                                                            \
+        *out = H(region_record(ROP, RAW(a), &RAW(b)));                                  \
         return;                                                                         \
       }                                                                                 \
+      std::vector<Graph> va{G(a)}, vb{G(b)};                                            \
       auto r = expr;                                                                    \
       *out = H(std::move(r[0]));                                                        \
     });                                                                                 \
@@ -658,14 +604,14 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
 namespace {
 std::vector<Graph> g_empty;
 }
-UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false, GO_NEG)
-BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb), GO_ADD)
-BINARY_FN(gtnx_subtract, op_scalar(SK_SUBTRACT, va, vb), GO_SUB)
-BINARY_FN(gtnx_compose, op_compose(va, vb, false), GO_COMPOSE)
-BINARY_FN(gtnx_intersect, op_compose(va, vb, true), GO_INTERSECT)
-UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false), true, GO_FS)
-UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true), true, GO_VS)
-UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v), true, GO_VP)
+UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false, RO_NEG)
+BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb), RO_ADD)
+BINARY_FN(gtnx_subtract, op_scalar(SK_SUBTRACT, va, vb), RO_SUB)
+BINARY_FN(gtnx_compose, op_compose(va, vb, false), RO_COMPOSE)
+BINARY_FN(gtnx_intersect, op_compose(va, vb, true), RO_INTERSECT)
+UNARY_FN(gtnx_forward_score, op_shortest_distance(v, false), true, RO_FS)
+UNARY_FN(gtnx_viterbi_score, op_shortest_distance(v, true), true, RO_VS)
+UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v), true, RO_VP)
 
 GTNX_API gtnx_status_t gtnx_items_n(const gtnx_graph_t* g, int n, float* out) {
   return guard([&] {
@@ -793,13 +739,11 @@ GTNX_API gtnx_status_t gtnx_batch_grads_device(gtnx_batch_t a, void* out, const 
 // ------------------------------------------------------------------ autograd
 GTNX_API gtnx_status_t gtnx_backward(gtnx_graph_t g, int retain) {
   return guard([&] {
-    std::vector<Graph> v{G(g)};
-    GatherReq req;
-    req.a = v[0];
-    if (gather(retain ? GO_BWD_RETAIN : GO_BWD, req)) {
-      if (req.err) std::rethrow_exception(req.err);
+    if (region_active()) {
+      region_record_backward(RAW(g), retain != 0);
       return;
     }
+    std::vector<Graph> v{G(g)};
     op_backward(v, nullptr, retain != 0);
   });
 }

@@ -33,10 +33,49 @@ void Structure::touch() {
   band[1].reset();
   dense[0].reset();
   dense[1].reset();
+  ctc_labels.reset();
+  ctc_checked = false;
   ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65
 }
 
+// Is this exactly ctcGraph(labels) of benchmarks/ctc.cpp:40-58 (same nodes, same arcs in the same order,
+// blank = the label of node 0's self-loop)?  O(A) integer compares on the host arrays.
+void detect_ctc_shape(Structure& s) {
+  if (s.ctc_checked) return;
+  s.ctc_checked = true;
+  s.ctc_labels.reset();
+  if (s.kind != KIND_EXPLICIT || !s.host_valid || s.N < 1 || (s.N & 1) == 0 || s.A < s.N) return;
+  const int L = int(s.N), U = (L - 1) / 2;
+  if (s.il[0] < 0 || s.src[0] != 0 || s.dst[0] != 0) return;
+  const int blank = s.il[0];
+  auto lab = std::make_shared<std::vector<int>>(size_t(U));
+  size_t a = 0;
+  const size_t A = size_t(s.A);
+  for (int l = 0; l < L; ++l) {
+    if (a >= A || s.src[a] != l || s.dst[a] != l) return;
+    const int label = s.il[a];
+    if (label < 0 || s.ol[a] != label) return;
+    if (l % 2) (*lab)[size_t(l / 2)] = label;
+    else if (label != blank) return;
+    const uint8_t want = uint8_t((l == 0 ? NF_START : 0) | ((l == L - 1 || l == L - 2) ? NF_ACCEPT : 0));
+    if (s.nflags[size_t(l)] != want) return;
+    ++a;
+    if (l > 0) {
+      if (a >= A || s.src[a] != l - 1 || s.dst[a] != l || s.il[a] != label || s.ol[a] != label) return;
+      ++a;
+    }
+    if (l % 2 && l > 1 && label != (*lab)[size_t(l / 2) - 1]) {
+      if (a >= A || s.src[a] != l - 2 || s.dst[a] != l || s.il[a] != label || s.ol[a] != label) return;
+      ++a;
+    }
+  }
+  if (a != A) return;
+  s.ctc_labels = std::move(lab);
+  s.ctc_blank = blank;
+}
+
 bool Weights::is_all_zero() {
+  if (zero) return true;
   if (!host_valid || host_escaped) return false;
   if (zero_version != version) {
     all_zero = true;
@@ -355,6 +394,26 @@ int Structure::num_out(int n) {
 // ======================================================================
 void Weights::ensure_host() {
   if (host_valid) return;
+  if (zero) {
+    host.assign(size_t(n), 0.0f);
+    zero = false;
+    host_valid = true;
+    return;
+  }
+  if (staged && !staged->on_device) {  // handed over inside a parallelMap region, not uploaded yet
+    host.assign(staged->src, staged->src + n);
+    staged.reset();
+    host_valid = true;
+    return;
+  }
+  if (staged) {  // the caller's device buffer: take the copy now
+    Runtime& rt = Runtime::get();
+    dev_mem = rt.alloc(sizeof(float) * size_t(n ? n : 1));
+    dev = dev_mem->as<float>();
+    rt.d2d(dev, staged->src, sizeof(float) * size_t(n));
+    staged.reset();
+    dev_valid = true;
+  }
   host.resize(n);
   if (n) Runtime::get().d2h_sync(host.data(), dev, sizeof(float) * size_t(n));
   host_valid = true;
@@ -479,6 +538,7 @@ void Graph::arc_sort(bool olabel) {
     // graphs on many threads (parallelMap): take the band records now, on this thread, instead of
     // on the one thread that later calls the batched compose.
     if (s->N <= band_max_nodes()) {
+      detect_ctc_shape(*s);
       band_info(*s, true);
       if (s->il == s->ol) s->band[1] = s->band[0];  // an acceptor matches the same labels either way round
       (void)w->is_all_zero();
@@ -553,6 +613,8 @@ void Graph::set_weights_host(const float* p) {
   // graph.cpp:179-181
   w->host.assign(p, p + s->A);
   w->n = s->A;
+  w->zero = false;
+  w->staged.reset();
   w->host_valid = true;
   w->dev_valid = false;
   w->version++;
@@ -567,6 +629,8 @@ void Graph::set_weights_device(const void* p) {
   }
   w->n = n;
   rt.d2d(w->dev, p, sizeof(float) * size_t(n));
+  w->zero = false;
+  w->staged.reset();
   w->dev_valid = true;
   w->host_valid = false;
   w->host_escaped = false;
@@ -791,14 +855,34 @@ void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
   Packer pk;
   std::vector<size_t> offs(todo.size());
   for (size_t i = 0; i < todo.size(); ++i) {
-    if (!todo[i]->host_valid) throw_logic("weights valid on neither host nor device");
-    offs[i] = pk.add(4 * size_t(todo[i]->n));
+    Weights* w = todo[i];
+    if (w->staged && w->staged->on_device) {  // region.cpp: the caller's device buffer, not copied yet
+      w->dev_mem = rt.alloc(sizeof(float) * size_t(w->n ? w->n : 1));
+      w->dev = w->dev_mem->as<float>();
+      rt.d2d(w->dev, w->staged->src, sizeof(float) * size_t(w->n));
+      w->staged.reset();
+      w->dev_valid = true;
+      todo[i] = nullptr;
+      continue;
+    }
+    if (!w->host_valid && !w->zero && !w->staged) throw_logic("weights valid on neither host nor device");
+    offs[i] = pk.add(4 * size_t(w->n));
   }
+  if (pk.total == 0) return;
   PinnedMemP pin = rt.alloc_pinned(pk.total);
   DevMemP dev = rt.alloc(pk.total);
   for (size_t i = 0; i < todo.size(); ++i) {
     Weights* w = todo[i];
-    std::memcpy(pin->as<char>(offs[i]), w->host.data(), 4 * size_t(w->n));
+    if (!w) continue;
+    if (w->zero) {
+      std::memset(pin->as<char>(offs[i]), 0, 4 * size_t(w->n));
+      w->zero = false;  // (the device copy is the live one now; the host copy is made on demand)
+    } else if (w->staged) {
+      std::memcpy(pin->as<char>(offs[i]), w->staged->src, 4 * size_t(w->n));
+      w->staged.reset();
+    } else {
+      std::memcpy(pin->as<char>(offs[i]), w->host.data(), 4 * size_t(w->n));
+    }
     w->dev_mem = dev;
     w->dev = dev->as<float>(offs[i]);
     w->dev_valid = true;

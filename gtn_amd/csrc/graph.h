@@ -55,6 +55,16 @@ struct Schedule {
 };
 
 struct Structure {
+  // Non-null: the RESULT of a graph function called inside a parallelMap region that has not run yet, or
+  // has run as part of a batch record (region.cpp).  Nothing else in this structure is valid; every access
+  // through the C ABI goes to region_value() first.
+  std::shared_ptr<struct Pending> pending;
+  std::atomic<int> pending_uses{0};  // as Weights::pending_uses
+  // The graph is exactly the CTC target acceptor of benchmarks/ctc.cpp:40-58 over these labels (checked at
+  // arcSort, O(A)): a batch of such graphs takes the device-built band records (batch.cpp: CTC_TARGETS)
+  std::shared_ptr<std::vector<int>> ctc_labels;
+  int ctc_blank = 0;
+  bool ctc_checked = false;  // detect_ctc_shape ran on the current arcs
   int kind = KIND_EXPLICIT;
   int64_t N = 0, A = 0;
   int M = 0, C = 0;  // KIND_LINEAR
@@ -136,10 +146,25 @@ struct NormCache {
   float* rowlse = nullptr;
 };
 
+// Weights handed over inside a parallelMap region (region.cpp): the values sit in a pinned staging
+// chunk (host source, copied at the call like graph.cpp:179-181) or are still the caller's device buffer
+// (device source: read at the region's join); the join moves the whole region's weights with one copy.
+struct StagedWeights {
+  PinnedMemP chunk;            // keeps the staging chunk alive (host source)
+  const float* src = nullptr;  // pinned host address or the caller's device address
+  bool on_device = false;
+};
+
 struct Weights {
   int64_t n = 0;
   std::vector<float> host;
   bool host_valid = true;
+  // n zeros that nobody has stored yet (linearGraph before setWeights, creations.cpp:20-33): neither copy is
+  // valid, ensure_host() / ensure_weights_device_batch() write them out on first use
+  bool zero = false;
+  std::shared_ptr<StagedWeights> staged;  // set: neither copy is valid yet (see StagedWeights)
+  // queued calls of a parallelMap region that will read these weights (region.cpp): a mutation flushes them first
+  std::atomic<int> pending_uses{0};
   bool host_escaped = false;  // a mutable host pointer was handed out (Graph::weights())
   uint64_t version = 0;       // bumped on every mutation
   uint64_t zero_version = ~uint64_t(0);  // version all_zero was taken at
@@ -171,6 +196,7 @@ struct BandInfo {
   const int* dev_slab = nullptr;
 };
 std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel);   // host part, cached
+void detect_ctc_shape(Structure& s);                                  // fills Structure::ctc_labels; cached
 void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vector<Structure*>& ss);
 
 struct GradState;
@@ -181,6 +207,8 @@ struct Graph {
   std::shared_ptr<GradState> g;
 
   explicit Graph(bool calc_grad = true);
+  struct Empty {};
+  explicit Graph(Empty) {}  // no pieces at all (region.cpp: placeholders carry a structure only)
   Graph(bool calc_grad, std::shared_ptr<Structure> shared);  // fresh weights / grad state over an existing structure
   static Graph make_result(bool calc_grad);  // fresh pieces, for op outputs
 

@@ -557,6 +557,13 @@ struct AxpyArgs {
   float scale;
 };
 void launch_axpy_batch(const AxpyArgs* d_args, int n, int64_t maxn, int atomic, hipStream_t st);
+// dst[0 .. bytes) = src[0 .. bytes) for a batch of segments (16-byte accesses where both ends allow it)
+struct CopySeg {
+  void* dst;
+  const void* src;
+  int64_t bytes;  // a multiple of 4
+};
+void launch_copy_segments(const CopySeg* d_segs, int n, int64_t max_bytes, hipStream_t st);
 // gather n scalars at arbitrary addresses into a dense array
 void launch_gather_scalars(const float* const* d_ptrs, float* out, int n, hipStream_t st);
 // out[i] = (accumulate ? out[i] : 0) + sa * a[i] + sb * b[i]  (b may be null) -- dense vectors of a batch record

@@ -267,6 +267,25 @@ __global__ void axpy_batch_kernel(const AxpyArgs* __restrict__ args, int atomic)
   }
 }
 
+// one grid row per segment: HBM-bound copy, 16 bytes per lane when both addresses are 16-byte aligned
+__global__ void copy_segments_kernel(const CopySeg* __restrict__ segs) {
+  const CopySeg sg = segs[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (((reinterpret_cast<uintptr_t>(sg.dst) | reinterpret_cast<uintptr_t>(sg.src)) & 15) == 0) {
+    const int64_t n16 = sg.bytes >> 4;
+    const uint4* s = static_cast<const uint4*>(sg.src);
+    uint4* d = static_cast<uint4*>(sg.dst);
+    for (int64_t k = i; k < n16; k += stride) d[k] = s[k];
+    const int64_t n4 = sg.bytes >> 2;
+    for (int64_t k = (n16 << 2) + i; k < n4; k += stride)
+      static_cast<uint32_t*>(sg.dst)[k] = static_cast<const uint32_t*>(sg.src)[k];
+  } else {
+    const int64_t n4 = sg.bytes >> 2;
+    for (int64_t k = i; k < n4; k += stride) static_cast<uint32_t*>(sg.dst)[k] = static_cast<const uint32_t*>(sg.src)[k];
+  }
+}
+
 __global__ void gather_scalars_kernel(const float* const* __restrict__ ptrs, float* out, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = *ptrs[i];
@@ -345,6 +364,11 @@ void launch_scalar_combine(const ScalarArgs* d, int n, float sa, float sb, hipSt
 void launch_axpy_batch(const AxpyArgs* d, int n, int64_t maxn, int atomic, hipStream_t st) {
   if (n <= 0 || maxn <= 0) return;
   hipLaunchKernelGGL(axpy_batch_kernel, dim3(grid_for((size_t)maxn, 256, 1024), n), dim3(256), 0, st, d, atomic);
+}
+void launch_copy_segments(const CopySeg* d, int n, int64_t max_bytes, hipStream_t st) {
+  if (n <= 0 || max_bytes <= 0) return;
+  // ~8 workgroups per segment at most: a region's batch has hundreds of segments
+  hipLaunchKernelGGL(copy_segments_kernel, dim3(grid_for((size_t)(max_bytes >> 4) + 1, 256, 8), n), dim3(256), 0, st, d);
 }
 void launch_gather_scalars(const float* const* d_ptrs, float* out, int n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(gather_scalars_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_ptrs, out, n);

@@ -93,6 +93,8 @@ void set_dev_weights(Graph& g, const DevMemP& owner, float* ptr, int64_t n) {
   w.dev = ptr;
   w.dev_valid = true;
   w.host_valid = false;
+  w.zero = false;
+  w.staged.reset();
   w.version++;
 }
 
@@ -183,7 +185,10 @@ Graph make_linear_graph(int M, int N, bool calc_grad) {
   s.A = int64_t(M) * N;
   s.ilabel_sorted = s.olabel_sorted = true;  // creations.cpp:30-31
   s.host_valid = true;                       // implicit
-  g.w->host.assign(size_t(s.A), 0.0f);
+  // zero weights (creations.cpp:24-28), not stored until somebody reads them: an emissions graph gets its
+  // weights from setWeights right away, and T*C zeros per utterance were a page-fault storm on the host
+  g.w->host_valid = false;
+  g.w->zero = true;
   g.w->n = s.A;
   return g;
 }
@@ -3160,6 +3165,35 @@ void set_user_grad_fn(Graph& g, gtnx_grad_fn fn, void* ctx, void (*ctx_free)(voi
 // ======================================================================
 // backward (autograd.cpp:17-67)
 // ======================================================================
+namespace {
+using Tape = std::map<uint64_t, std::pair<std::shared_ptr<OpRecord>, std::vector<Member>>, std::greater<uint64_t>>;
+// reachable graphs grouped by producing record; throws (before anything has been changed) when part of the
+// tape is gone already -- autograd.cpp:42-45
+void collect_tape(std::vector<Graph>& roots, Tape& tape) {
+  std::unordered_set<GradState*> seen;
+  std::vector<Graph> stack(roots.begin(), roots.end());
+  while (!stack.empty()) {
+    Graph g = stack.back();
+    stack.pop_back();
+    if (!seen.insert(g.g.get()).second) continue;
+    for (auto& in : g.g->inputs) stack.push_back(in);
+    if (g.g->has_grad_fn) {
+      if (!g.g->op || g.g->inputs.empty())  // autograd.cpp:42-45
+        throw_invalid("[autograd::backward] Cannot Backward twice without retaining the graph.");
+      auto& slot = tape[g.g->op->seq];
+      slot.first = g.g->op;
+      slot.second.push_back({g.g->op_idx, g});
+    }
+  }
+}
+}  // namespace
+
+void backward_validate(Graph& root) {
+  std::vector<Graph> roots{root};
+  Tape tape;
+  collect_tape(roots, tape);
+}
+
 void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed) {
   GTNX_HOST_T("backward.total");
   Runtime& rt = Runtime::get();
@@ -3187,23 +3221,10 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
     }
     sink.flush();
   }
-  // ---- collect the tape: reachable graphs grouped by producing record
-  std::unordered_set<GradState*> seen;
-  std::map<uint64_t, std::pair<std::shared_ptr<OpRecord>, std::vector<Member>>, std::greater<uint64_t>> tape;
-  std::vector<Graph> stack(roots.begin(), roots.end());
-  while (!stack.empty()) {
-    Graph g = stack.back();
-    stack.pop_back();
-    if (!seen.insert(g.g.get()).second) continue;
-    for (auto& in : g.g->inputs) stack.push_back(in);
-    if (g.g->has_grad_fn) {
-      if (!g.g->op || g.g->inputs.empty())  // autograd.cpp:42-45
-        throw_invalid("[autograd::backward] Cannot Backward twice without retaining the graph.");
-      auto& slot = tape[g.g->op->seq];
-      slot.first = g.g->op;
-      slot.second.push_back({g.g->op_idx, g});
-    }
-  }
+  // ---- collect the tape (after the seed, like autograd.cpp:57-67: a second backward without retain throws
+  // with the seed added; region.cpp validates the roots of a gathered backward beforehand)
+  Tape tape;
+  collect_tape(roots, tape);
   // ---- reverse sweep: creation order is a topological order
   ChainGradPlan plan;
   struct PlanScope {
@@ -3258,6 +3279,7 @@ void items_host(std::vector<Graph>& gs, float* out) {
     if (gs[i].num_arcs() != 1)
       throw_invalid("[Graph::item] Cannot convert Graph with more than 1 arc to a scalar.");
     Weights& w = *gs[i].w;
+    if (!w.host_valid && !w.dev_valid) w.ensure_host();  // unwritten zeros / weights staged by a parallelMap region
     if (w.host_valid) {
       out[i] = w.host[0];
     } else {

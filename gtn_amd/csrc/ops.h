@@ -72,6 +72,8 @@ std::vector<Graph> op_compose(std::vector<Graph>& a, std::vector<Graph>& b, bool
 enum RationalKind { RAT_CLONE = 0, RAT_CONCAT = 1, RAT_CLOSURE = 2, RAT_UNION = 3 };
 Graph op_rational(int kind, std::vector<Graph>& inputs, int projection);
 void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed = true);
+// throws what op_backward would throw before changing anything (a tape that is gone: autograd.cpp:42-45)
+void backward_validate(Graph& root);
 // per-thread hint of gtnx_compose_mode (include/gtn_amd.h); returns the previous value
 int compose_mode_hint(int mode);
 // build a symbolic (lazy) chain product for real, in place; no-op otherwise

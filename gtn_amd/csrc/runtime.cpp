@@ -82,7 +82,7 @@ void Runtime::set_stream(hipStream_t s) {
 }
 
 void Runtime::sync() {
-  drain_deferred();  // the GPU is (usually) still busy: reclaim while we would wait
+  drain_while_busy();  // the GPU is (usually) still busy: reclaim while we would wait
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
@@ -98,15 +98,42 @@ void Runtime::defer_delete(void* p, void (*del)(void*)) {
 
 void Runtime::drain_deferred() {
   GTNX_HOST_T("runtime.drain_deferred");
+  while (drain_some(256)) {
+  }
+}
+
+// destroys up to `max_items` of what is waiting; false when nothing was.  Several threads may share the work
+// (the threads entering a parallelMap region do: region.cpp).
+bool Runtime::drain_some(size_t max_items) {
+  std::vector<std::pair<void*, void (*)(void*)>> batch;
+  {
+    std::lock_guard<std::mutex> lk(defer_mu_);
+    if (deferred_.empty()) return false;
+    const size_t n = std::min(max_items, deferred_.size());
+    batch.assign(deferred_.end() - n, deferred_.end());
+    deferred_.resize(deferred_.size() - n);
+  }
+  for (auto& e : batch) e.second(e.first);  // (destructors may defer more)
+  return true;
+}
+
+// reclaim while the GPU is busy and the host would only wait for it; what is left waits for the next such
+// moment or for the threads of the next parallelMap region
+void Runtime::drain_while_busy() {
+  GTNX_HOST_T("runtime.drain_while_busy");
   for (;;) {
-    std::vector<std::pair<void*, void (*)(void*)>> batch;
     {
       std::lock_guard<std::mutex> lk(defer_mu_);
-      batch.swap(deferred_);
+      if (deferred_.empty()) return;
+      if (deferred_.size() >= (1u << 14)) break;  // too much waiting: all of it, now
     }
-    if (batch.empty()) return;
-    for (auto& e : batch) e.second(e.first);  // destructors may defer more: loop
+    if (hipStreamQuery(stream_) != hipErrorNotReady) {
+      (void)hipGetLastError();
+      return;
+    }
+    drain_some(32);
   }
+  drain_deferred();
 }
 
 DevMemP Runtime::alloc(size_t bytes) {
@@ -229,8 +256,8 @@ void Runtime::h2d(void* dst, const void* src, size_t bytes) {
 void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
   // reclaim first: a device->host copy into pageable memory blocks inside the copy
   // call until the stream gets there, so this is the last moment the GPU is busy
-  drain_deferred();
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
+  drain_while_busy();
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
 void Runtime::d2d(void* dst, const void* src, size_t bytes) {

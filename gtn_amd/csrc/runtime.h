@@ -68,6 +68,8 @@ class Runtime {
   // for the GPU anyway (sync / blocking copy), off the caller's critical path.
   void defer_delete(void* p, void (*del)(void*));
   void drain_deferred();
+  bool drain_some(size_t max_items);
+  void drain_while_busy();
 
   // copies (async on the engine stream; h2d source must be pinned or outlive sync())
   void h2d(void* dst, const void* src, size_t bytes);

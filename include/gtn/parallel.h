@@ -1,8 +1,10 @@
 // gtn/parallel.h -- parallelMap (reference gtn/parallel/parallel_map.h:153-188).
 // Same contract: maps `function` over the inputs element-wise on host threads,
 // size-1 inputs broadcast, results in input order, the first exception is
-// rethrown after every task finished.  On this engine it is for HOST-side work
-// (building target graphs); graph functions batch through their vector overloads.
+// rethrown after every task finished.  The host threads do the HOST-side work of the
+// tasks (building target graphs, handing weights over); the graph functions the tasks
+// call are deferred by the engine and run at the join as one batched launch each
+// (gtnx_parallel_enter / gtnx_parallel_flush, include/gtn_amd.h).
 #pragma once
 
 #include "gtn_amd.h"
@@ -16,6 +18,7 @@
 #include <exception>
 #include <mutex>
 #include <stdexcept>
+#include <string>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -115,9 +118,9 @@ inline void noPrelude() {}
 
 template <class Body, class Pre = void (*)()>
 void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst = &noPrelude) {
-  // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped.  The engine gathers
-  // the graph-function calls of the region's threads into one launch each (gtnx_parallel_enter), so
-  // more threads mean larger launches: they spend their time waiting for one another, not computing
+  // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped.  The engine defers
+  // the graph-function calls of the region's threads to the join (gtnx_parallel_enter), so the threads
+  // only build graphs: a few dozen of them finish a batch of targets in well under a millisecond.
   // One process per GPU: the ranks of a node share its cores (torchrun exports LOCAL_WORLD_SIZE),
   // and a step is host-bound, so each rank takes its share instead of oversubscribing.
   static const size_t hw = [] {
@@ -128,12 +131,18 @@ void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst =
     }
     return h;
   }();
-  const size_t nt = std::min<size_t>(std::min(n, hw), maxThreads);
+  // (GTN_AMD_THREADS caps the pool: the tasks of a region only do host-side work here)
+  static const size_t cap = [] {
+    const char* e = std::getenv("GTN_AMD_THREADS");
+    const long v = e ? std::atol(e) : 0;
+    return v > 0 ? size_t(v) : size_t(0);
+  }();
+  const size_t nt = std::min<size_t>(std::min(n, hw), cap ? cap : maxThreads);
   std::atomic<size_t> next{0};
   std::exception_ptr first;
   std::mutex mu;
   auto worker = [&]() {
-    // graph functions called from here are gathered across the region's threads (gtn_amd.h)
+    // graph functions called from here are deferred to the join below (gtn_amd.h)
     struct Region {
       bool on;
       explicit Region(bool o) : on(o) {
@@ -157,6 +166,20 @@ void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst =
     }
   };
   Pool::get().run(nt, worker, callerFirst);
+  // the join: everything the tasks asked the engine for runs now, batched (no-op when nothing was deferred)
+  if (nt > 1) {
+    const gtnx_status_t st = gtnx_parallel_flush();
+    if (st != GTNX_OK && !first) {
+      // the first failed call's error, as the exception its own function throws (gtn/graph.h: detail::check)
+      const std::string msg = gtnx_last_error();
+      switch (st) {
+        case GTNX_INVALID_ARGUMENT: throw std::invalid_argument(msg);
+        case GTNX_LOGIC_ERROR: throw std::logic_error(msg);
+        case GTNX_OUT_OF_RANGE: throw std::out_of_range(msg);
+        default: throw std::runtime_error(msg);
+      }
+    }
+  }
   if (first) std::rethrow_exception(first);
 }
 } // namespace detail

@@ -76,11 +76,20 @@ gtnx_status_t gtnx_empty_cache(void);
 gtnx_status_t gtnx_reclaim(void);
 /* The calling thread is one of several host threads mapping per-graph functions over a batch
  * (gtn::parallelMap, parallel/parallel_map.h:153-188) from here until gtnx_parallel_leave: its
- * function calls (negate .. viterbiPath, backward) are gathered with those of the region's other
- * threads and run as ONE batched launch each.  Results per graph are unchanged.  Made by
- * include/gtn/parallel.h; a hint -- without it every call is a batch of one. */
+ * function calls (negate .. viterbiPath, backward) are DEFERRED -- they return placeholder handles at
+ * once, no thread waits for another -- and gtnx_parallel_flush, called by the thread that joins the
+ * region (parallel_map.h:182-186), runs the calls of all the region's threads as ONE batched launch per
+ * function; a criterion step over CTC-shaped targets and linear emission graphs runs as the batch records
+ * below.  Results per graph are unchanged: a placeholder that is looked at before the join (sizes, arcs,
+ * item(), a gradient) runs what it depends on right then, and a graph that is changed while a deferred call
+ * still reads it has those calls run first.  What moves is when an error surfaces: at the first look at the
+ * result, or from gtnx_parallel_flush (parallelMap rethrows after its join either way).  setWeights inside
+ * a region copies a host source at the call (graph.cpp:179-181) and reads a DEVICE source at the join: the
+ * caller keeps a device source unchanged until then.  Made by include/gtn/parallel.h; a hint -- without it
+ * every call is a batch of one. */
 gtnx_status_t gtnx_parallel_enter(void);
 gtnx_status_t gtnx_parallel_leave(void);
+gtnx_status_t gtnx_parallel_flush(void);
 
 /* ------------------------------------------------------------------ Graph
  * class Graph, gtn/graph.h:75-415 */
@@ -111,7 +120,8 @@ gtnx_status_t gtnx_graph_olabel_sorted(gtnx_graph_t g, int* out);   /* graph.h:1
  * non-const form marks the host copy authoritative. */
 gtnx_status_t gtnx_graph_weights(gtnx_graph_t g, int mutable_, float** out);
 gtnx_status_t gtnx_graph_get_weights(gtnx_graph_t g, float* out);   /* copy-out of the above */
-gtnx_status_t gtnx_graph_set_weights(gtnx_graph_t g, const float* host_weights); /* graph.h:210 */
+/* graph.h:210; `weights` may also be a DEVICE address (detected: hipPointerGetAttributes) -- then as below */
+gtnx_status_t gtnx_graph_set_weights(gtnx_graph_t g, const float* weights);
 /* the same copy from a DEVICE buffer of numArcs floats (no host round-trip;
  * replaces pytorch_loss.py:53-61's inputs.cpu() + set_weights(data_ptr)) */
 gtnx_status_t gtnx_graph_set_weights_device(gtnx_graph_t g, const void* device_weights);

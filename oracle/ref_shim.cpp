@@ -105,6 +105,7 @@ gtnx_status_t gtnx_union(const gtnx_graph_t* g, int n, gtnx_graph_t* out) {
 }
 gtnx_status_t gtnx_parallel_enter(void) { return GTNX_OK; }
 gtnx_status_t gtnx_parallel_leave(void) { return GTNX_OK; }
+gtnx_status_t gtnx_parallel_flush(void) { return GTNX_OK; }
 
 gtnx_status_t gtnx_graph_create(int calc_grad, gtnx_graph_t* out) {
   return guard([&] { *out = H(Graph(calc_grad != 0)); });

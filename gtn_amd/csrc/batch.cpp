@@ -294,6 +294,7 @@ Graph ctc_target_graph_host(const int* t, int U, int blank, bool cg) {
 }  // namespace
 
 BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank, bool calc_grad) {
+  GTNX_HOST_T("batch.ctc_targets");
   if (n < 0) throw_invalid("[gtnx_batch_ctc_targets] negative batch size");
   BatchP b = make_batch(Batch::CTC_TARGETS, n, calc_grad);
   b->blank = blank;
@@ -462,6 +463,7 @@ BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool b
 
 // ---- the caller's graphs as native leaves --------------------------------------------------------
 BatchP batch_ctc_targets_from_graphs(const std::vector<Graph>& gs) {
+  GTNX_HOST_T("batch.ctc_targets_from_graphs");
   const int n = int(gs.size());
   if (n == 0) return nullptr;
   detect_ctc_shape(*gs[0].s);
@@ -489,6 +491,7 @@ BatchP batch_ctc_targets_from_graphs(const std::vector<Graph>& gs) {
 }
 
 BatchP batch_linear_from_graphs(const std::vector<Graph>& gs) {
+  GTNX_HOST_T("batch.linear_from_graphs");
   const int n = int(gs.size());
   if (n == 0) return nullptr;
   const Structure& s0 = *gs[0].s;
@@ -540,6 +543,7 @@ namespace {
 // what the batch-level backward produced moves into the element graphs
 void push_grads_to_graphs(Batch& x) {
   if (!x.g_dev) return;
+  GTNX_HOST_T("batch.push_grads_to_graphs");
   GradSink sink;  // first gradients are adopted in place, the others folded in by ONE launch
   for (int i = 0; i < x.n; ++i) sink.add(x.graphs[size_t(i)], x.g_mem, x.g_dev + x.g_off[size_t(i)]);
   sink.flush();
@@ -685,6 +689,7 @@ BatchP batch_compose(const BatchP& a, const BatchP& b, bool intersect) {
 }
 
 BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
+  GTNX_HOST_T("batch.shortest_distance");
   Runtime& rt = Runtime::get();
   if (!tropical && native(*x, Batch::PRODUCT) && !x->materialised) {
     Batch& fx = *x->fixed;
@@ -832,6 +837,7 @@ BatchP batch_scalar(ScalarKind k, const BatchP& a0, const BatchP& b0) {
 
 // ---- autograd --------------------------------------------------------------------------------
 void batch_backward(const BatchP& root, bool retain) {
+  GTNX_HOST_T("batch.backward");
   if (root->tape_cleared)
     throw_invalid("[autograd::backward] Cannot Backward twice without retaining the graph.");  // autograd.cpp:44-47
   if (root->materialised || !root->op || root->kind != Batch::SCALAR) {

@@ -144,7 +144,10 @@ GTNX_API gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
 }
 GTNX_API gtnx_status_t gtnx_reclaim(void) {
   return guard([&] {
-    if (Runtime::initialized()) Runtime::get().drain_deferred();
+    // (a few entries per lock round: several threads of a parallelMap pool share the list)
+    if (Runtime::initialized())
+      while (Runtime::get().drain_some(8)) {
+      }
   });
 }
 GTNX_API gtnx_status_t gtnx_empty_cache(void) {

@@ -539,8 +539,10 @@ void Graph::arc_sort(bool olabel) {
     // on the one thread that later calls the batched compose.
     if (s->N <= band_max_nodes()) {
       detect_ctc_shape(*s);
-      band_info(*s, true);
-      if (s->il == s->ol) s->band[1] = s->band[0];  // an acceptor matches the same labels either way round
+      if (!s->ctc_labels) {  // (a CTC target acceptor's records are built on the device from its labels: batch.cpp)
+        band_info(*s, true);
+        if (s->il == s->ol) s->band[1] = s->band[0];  // an acceptor matches the same labels either way round
+      }
       (void)w->is_all_zero();
     }
     return;
@@ -640,6 +642,10 @@ void Graph::set_weights_device(const void* p) {
 Graph& Graph::grad() {
   // graph.cpp:81-89
   if (!g->calc_grad) throw_logic("[Graph::grad] Gradient calculation disabled.");
+  if (g->lazy_ptr) {
+    std::lock_guard<std::mutex> lk(s->grad_lock);
+    materialize_grad();
+  }
   if (!g->grad) throw_logic("[Graph::grad] Gradient not calculated yet.");
   return *g->grad;
 }
@@ -651,7 +657,7 @@ void Graph::set_calc_grad(bool c) {
     g->op.reset();
     g->has_grad_fn = false;
     g->inputs.clear();
-    g->grad.reset();
+    zero_grad();
   }
 }
 
@@ -659,10 +665,24 @@ static void make_grad_graph(Graph& self) {
   self.g->grad = std::unique_ptr<Graph>(new Graph(false, self.s));  // shares the structure (graph.cpp:102-103)
 }
 
+// (caller holds grad_lock)
+void Graph::materialize_grad() {
+  if (!g->lazy_ptr) return;
+  make_grad_graph(*this);
+  Weights& gw = *g->grad->w;
+  gw.n = s->A;
+  gw.host_valid = false;
+  gw.dev_mem = std::move(g->lazy_owner);
+  gw.dev = g->lazy_ptr;
+  gw.dev_valid = true;
+  g->lazy_ptr = nullptr;
+}
+
 void Graph::add_grad_host(const float* v, int64_t n) {
   if (!calc_grad()) return;
   if (n != s->A) throw_logic("[Graph::addGrad] Invalid grad size.");  // graph.cpp:93-95
   std::lock_guard<std::mutex> lk(s->grad_lock);
+  materialize_grad();
   if (is_grad_available()) {
     Weights& gw = *g->grad->w;
     gw.ensure_host();
@@ -684,6 +704,12 @@ void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
   if (s->deferred && !(adopt && !is_grad_available())) s->resolve_sizes();
   int64_t n = s->A;
   std::lock_guard<std::mutex> lk(s->grad_lock);
+  if (!is_grad_available() && adopt && !s->deferred) {  // noted only: materialize_grad() builds the graph on demand
+    g->lazy_owner = owner;
+    g->lazy_ptr = dev;
+    return;
+  }
+  materialize_grad();
   if (!is_grad_available()) {
     make_grad_graph(*this);
     Weights& gw = *g->grad->w;

@@ -58,7 +58,7 @@ struct Structure {
   // Non-null: the RESULT of a graph function called inside a parallelMap region that has not run yet, or
   // has run as part of a batch record (region.cpp).  Nothing else in this structure is valid; every access
   // through the C ABI goes to region_value() first.
-  std::shared_ptr<struct Pending> pending;
+  struct Pending* pending = nullptr;  // (lives in the same allocation: region.cpp PlaceholderStructure)
   std::atomic<int> pending_uses{0};  // as Weights::pending_uses
   // The graph is exactly the CTC target acceptor of benchmarks/ctc.cpp:40-58 over these labels (checked at
   // arcSort, O(A)): a batch of such graphs takes the device-built band records (batch.cpp: CTC_TARGETS)
@@ -239,6 +239,10 @@ struct Graph {
   // floats; when `adopt` the buffer becomes the grad without a copy.
   void add_grad_host(const float* v, int64_t n);
   void add_grad_device(const DevMemP& owner, float* dev, bool adopt);
+  // A FIRST gradient adopted in place: only the buffer is noted (GradState::lazy_*); the gradient graph is
+  // built when somebody asks for it (grad(), an accumulation).  A criterion step hands out two gradients per
+  // utterance that the next step usually throws away unread.
+  void materialize_grad();
 };
 
 struct GradState {
@@ -248,6 +252,8 @@ struct GradState {
   bool has_grad_fn = false;      // mirrors `gradFunc != nullptr`
   std::vector<Graph> inputs;
   std::unique_ptr<Graph> grad;
+  DevMemP lazy_owner;            // a first gradient that has no graph yet (Graph::materialize_grad)
+  float* lazy_ptr = nullptr;
   std::atomic<int> n_consumers{0};  // op outputs that list this graph as an input (two threads may reclaim at once)
   bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
   // gtnx_grads_bind_device_n: caller-owned device memory the FIRST gradient of this graph is to be
@@ -257,8 +263,12 @@ struct GradState {
   ~GradState();                  // gives the consumer counts of `inputs` back
 };
 inline bool Graph::calc_grad() const { return g->calc_grad; }
-inline bool Graph::is_grad_available() const { return g->grad != nullptr; }
-inline void Graph::zero_grad() { g->grad.reset(); }
+inline bool Graph::is_grad_available() const { return g->grad != nullptr || g->lazy_ptr != nullptr; }
+inline void Graph::zero_grad() {
+  g->grad.reset();
+  g->lazy_owner.reset();
+  g->lazy_ptr = nullptr;
+}
 
 // Sizes of one compose batch left on the device.  For a chain product whose partner is
 // epsilon-free, no wider than a workgroup, with at most KC out-arcs per node, every

@@ -141,7 +141,7 @@ void GradSink::flush() {
       continue;
     }
     g.s->resolve_sizes();  // accumulating into an existing gradient needs the arc count
-    Weights& gw = *g.g->grad->w;
+    Weights& gw = *g.grad().w;
     if (!gw.dev_valid || gw.host_escaped) {
       std::vector<Weights*> v{&gw};
       ensure_weights_device_batch(v);
@@ -401,7 +401,7 @@ struct LinearSdOp : OpRecord {
       // instead of write + read-modify-write); addGrad semantics, graph.cpp:108-129
       const bool first_use = seen_in.insert(in.g.get()).second;
       if (first_use && in.calc_grad() && in.is_grad_available()) {
-        Weights& gw = *in.g->grad->w;
+        Weights& gw = *in.grad().w;
         if (gw.dev_valid && !(gw.host_escaped && gw.host_valid) && gw.n == in.num_arcs()) {
           a.grad = gw.dev;
           a.accumulate = 1;
@@ -554,7 +554,7 @@ struct SdOp : OpRecord {
         // run earlier in the sweep) is accumulated into in place: one pass, no axpy
         bool in_place = false;
         if (a.grad_chain && chain.is_grad_available() && fused_chain_seen.insert(chain.g.get()).second) {
-          Weights& gw = *chain.g->grad->w;
+          Weights& gw = *chain.grad().w;
           if (gw.dev_valid && !(gw.host_escaped && gw.host_valid) && gw.n == chain.num_arcs()) {
             a.grad_chain = gw.dev;
             a.chain_accumulate = 1;
@@ -3487,8 +3487,8 @@ void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets)
   int64_t maxn = 0;
   for (size_t i = 0; i < n; ++i) {
     float* dst = static_cast<float*>(dev_out) + offsets[i];
-    if (gs[i].g->grad->w->dev == dst) continue;  // written in place (grads_bind_device)
-    ax.push_back({dst, gs[i].g->grad->w->dev, gs[i].num_arcs(), 1.0f});
+    if (gs[i].grad().w->dev == dst) continue;  // written in place (grads_bind_device)
+    ax.push_back({dst, gs[i].grad().w->dev, gs[i].num_arcs(), 1.0f});
     maxn = std::max(maxn, gs[i].num_arcs());
   }
   if (ax.empty()) return;

@@ -4,6 +4,7 @@
 #include "region.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -58,15 +59,24 @@ void count_use(const Graph& g, int d) {
 
 // a call's value as the batch functions see it
 struct Val {
-  BatchP batch;  // element `idx` of this record, or
+  Batch* batch = nullptr;     // element `idx` of this record (kept alive by its call), or
+  const BatchP* batch_p = nullptr;
   int idx = -1;
-  Graph g{Graph::Empty{}};  // an ordinary graph
+  const Graph* g = nullptr;   // an ordinary graph (the call's own input, or an earlier call's result)
   std::exception_ptr err;
 };
+
+// inputs of calls that have run: let go of in one piece, off the joining thread (a placeholder whose handle
+// is gone already dies with its last reference -- that is here)
+thread_local std::vector<Graph>* t_released = nullptr;
 
 void finish(Pending& p, int state) {
   count_use(p.a, -1);
   count_use(p.b, -1);
+  if (t_released) {
+    if (p.a.s) t_released->push_back(std::move(p.a));
+    if (p.b.s) t_released->push_back(std::move(p.b));
+  }
   p.a = Graph(Graph::Empty{});
   p.b = Graph(Graph::Empty{});
   p.state.store(state, std::memory_order_release);
@@ -194,10 +204,10 @@ struct Run {
   Val value_of(Graph& x) {
     Val v;
     if (!is_placeholder(x)) {
-      v.g = x;
+      v.g = &x;
       return v;
     }
-    std::shared_ptr<Pending> q = x.s->pending;
+    std::shared_ptr<Pending> q(x.s, x.s->pending);
     if (q->state.load(std::memory_order_acquire) == 0) {
       if (q->group >= 0) {
         run_group(groups[size_t(q->group)]);
@@ -212,23 +222,24 @@ struct Run {
       return v;
     }
     if (q->has_res.load(std::memory_order_acquire)) {
-      v.g = q->res;
+      v.g = &q->res;
     } else {
-      v.batch = q->batch;
+      v.batch = q->batch.get();
+      v.batch_p = &q->batch;
       v.idx = q->idx;
     }
     return v;
   }
 
   static Graph graph_of(Val& v) {
-    if (v.g.s) return v.g;
-    return batch_get(v.batch, v.idx);
+    if (v.g) return *v.g;
+    return batch_get(*v.batch_p, v.idx);
   }
 
   // all values are the elements of ONE record, each exactly once: that record and the element of each call
   static BatchP aligned(std::vector<Val>& vs, std::vector<int>& perm) {
     if (vs.empty() || !vs[0].batch) return nullptr;
-    const BatchP& x = vs[0].batch;
+    Batch* x = vs[0].batch;
     if (size_t(x->n) != vs.size()) return nullptr;
     std::vector<uint8_t> seen(vs.size(), 0);
     perm.resize(vs.size());
@@ -237,7 +248,7 @@ struct Run {
       seen[size_t(vs[k].idx)] = 1;
       perm[k] = vs[k].idx;
     }
-    return x;
+    return *vs[0].batch_p;
   }
 
   // the inputs of a group as ONE batch record + the element each call reads
@@ -246,7 +257,7 @@ struct Run {
     perm.resize(vs.size());
     for (size_t k = 0; k < vs.size(); ++k) perm[k] = int(k);
     bool all_graphs = true;
-    for (auto& v : vs) all_graphs = all_graphs && v.g.s;
+    for (auto& v : vs) all_graphs = all_graphs && v.g;
     std::vector<Graph> gs;
     gs.reserve(vs.size());
     for (auto& v : vs) gs.push_back(graph_of(v));
@@ -308,21 +319,25 @@ struct Run {
 
   void run_calls(RegionOp op, std::vector<Pending*>& cs, bool retry_singly) {
     const size_t n = cs.size();
-    std::vector<Val> va(n), vb;
-    if (binary(op)) vb.resize(n);
     std::vector<Pending*> live;
     std::vector<Val> la, lb;
-    for (size_t k = 0; k < n; ++k) {
-      Pending& p = *cs[k];
-      Val a = value_of(p.a), b;
-      if (binary(op)) b = value_of(p.b);
-      if (a.err || b.err) {  // an input failed: so does this call, with the same error
-        fail(p, a.err ? a.err : b.err);
-        continue;
+    live.reserve(n);
+    la.reserve(n);
+    if (binary(op)) lb.reserve(n);
+    {
+      GTNX_HOST_T("region.run_calls.resolve");
+      for (size_t k = 0; k < n; ++k) {
+        Pending& p = *cs[k];
+        Val a = value_of(p.a), b;
+        if (binary(op)) b = value_of(p.b);
+        if (a.err || b.err) {  // an input failed: so does this call, with the same error
+          fail(p, a.err ? a.err : b.err);
+          continue;
+        }
+        live.push_back(&p);
+        la.push_back(std::move(a));
+        if (binary(op)) lb.push_back(std::move(b));
       }
-      live.push_back(&p);
-      la.push_back(std::move(a));
-      if (binary(op)) lb.push_back(std::move(b));
     }
     if (live.empty()) return;
     try {
@@ -344,6 +359,7 @@ struct Run {
         }
       }
       BatchP R = apply(op, A, B);
+      GTNX_HOST_T("region.run_calls.results");
       for (size_t k = 0; k < live.size(); ++k) set_result(*live[k], R, pa[k]);
     } catch (...) {
       if (!retry_singly || live.size() == 1) {
@@ -453,6 +469,10 @@ std::exception_ptr execute(std::vector<std::shared_ptr<Pending>>& calls, std::ve
   GTNX_HOST_T("region.execute");
   ExecScope es;
   std::exception_ptr err;
+  std::vector<Graph>* outer = t_released;
+  auto* released = new std::vector<Graph>();
+  released->reserve(2 * calls.size());
+  t_released = released;
   try {
     apply_stage(stage);
     Run run(calls);
@@ -463,7 +483,18 @@ std::exception_ptr execute(std::vector<std::shared_ptr<Pending>>& calls, std::ve
     for (auto& sp : calls)
       if (sp->state.load(std::memory_order_acquire) == 0) fail(*sp, err);
   }
-  calls.clear();
+  t_released = outer;
+  // the calls themselves and what they held: taken apart by the pool's threads (gtnx_reclaim), not here
+  auto* dead = new std::vector<std::shared_ptr<Pending>>();
+  dead->swap(calls);
+  if (Runtime::initialized()) {
+    Runtime& rt = Runtime::get();
+    rt.defer_delete(released, [](void* q) { delete static_cast<std::vector<Graph>*>(q); });
+    rt.defer_delete(dead, [](void* q) { delete static_cast<std::vector<std::shared_ptr<Pending>>*>(q); });
+  } else {
+    delete released;
+    delete dead;
+  }
   return err;
 }
 
@@ -484,7 +515,18 @@ void take_shared(std::vector<std::shared_ptr<Pending>>& q, std::vector<std::shar
 
 bool region_active() { return t_depth > 0 && t_exec == 0; }
 
+namespace {
+std::atomic<int64_t> g_first_enter_us{0};  // GTNX_HOST_TIMING: when the current region's first thread arrived
+int64_t now_us() {
+  return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
 void region_enter() {
+  if (HostTimer::enabled() && t_depth == 0) {
+    int64_t zero = 0;
+    g_first_enter_us.compare_exchange_strong(zero, now_us());
+  }
   // what earlier steps let go of is taken apart by the region's threads together (a batch's graphs were built
   // by such threads too), not by the one thread that joins them
   // (a handful of them: the allocator's locks are what more threads would wait on)
@@ -492,7 +534,7 @@ void region_enter() {
     Shared& sh = shared();
     static const int max_drainers = [] {
       const char* e = std::getenv("GTNX_DRAIN_THREADS");
-      return e ? std::atoi(e) : 8;
+      return e ? std::atoi(e) : 0;
     }();
     if (sh.draining.fetch_add(1) < max_drainers) Runtime::get().drain_deferred();
     sh.draining.fetch_sub(1);
@@ -527,6 +569,10 @@ void region_leave() {
 }
 
 void region_flush() {
+  if (HostTimer::enabled() && t_depth == 0) {
+    const int64_t t0 = g_first_enter_us.exchange(0);
+    if (t0) host_timer_add("region.pool_phase(first enter -> join)", double(now_us() - t0) * 1e-3);
+  }
   std::vector<std::shared_ptr<Pending>> q;
   std::vector<std::shared_ptr<Weights>> st;
   std::exception_ptr stored;
@@ -548,8 +594,16 @@ void region_flush() {
   if (err) std::rethrow_exception(err);
 }
 
+namespace {
+// a placeholder's structure and its call in one allocation
+struct PlaceholderStructure : Structure {
+  Pending call;
+};
+}  // namespace
+
 Graph region_record(RegionOp op, const Graph& a, const Graph* b) {
-  auto p = std::make_shared<Pending>();
+  auto ps = std::make_shared<PlaceholderStructure>();
+  std::shared_ptr<Pending> p(ps, &ps->call);
   p->op = op;
   p->a = a;
   if (b) p->b = *b;
@@ -567,8 +621,8 @@ Graph region_record(RegionOp op, const Graph& a, const Graph* b) {
   p->depth = d + 1;
   t_queue.push_back(p);
   Graph ph{Graph::Empty{}};
-  ph.s = std::make_shared<Structure>();
-  ph.s->pending = std::move(p);
+  ps->pending = &ps->call;
+  ph.s = std::move(ps);
   return ph;
 }
 
@@ -610,13 +664,13 @@ void force(const std::shared_ptr<Pending>& p) {
 }  // namespace
 
 Graph& region_value(Graph& ph) {
-  std::shared_ptr<Pending> p = ph.s->pending;
+  std::shared_ptr<Pending> p(ph.s, ph.s->pending);
   force(p);
   return result_graph(*p);
 }
 
 bool region_item(Graph& ph, float* out) {
-  std::shared_ptr<Pending> p = ph.s->pending;
+  std::shared_ptr<Pending> p(ph.s, ph.s->pending);
   force(p);
   if (p->has_res.load(std::memory_order_acquire)) return false;
   BatchP x = p->batch;

@@ -1,6 +1,8 @@
 // runtime.cpp -- see runtime.h
 #include "runtime.h"
 
+#include <malloc.h>
+
 #include <cstring>
 
 namespace gtnx {
@@ -47,6 +49,15 @@ Runtime& Runtime::get() {
 }
 
 Runtime::Runtime() {
+  // The host side of a step allocates and frees a few hundred KB of scratch (launch tables, per-utterance
+  // records); with glibc's defaults the heap top is trimmed after every step and grown again in the next
+  // (brk + page faults on the thread that joins the region: 17 % of its time in the stack samples of
+  // tools/nullhip/region_step).  Keep freed heap in the process instead.  GTNX_NO_MALLOPT=1 leaves malloc alone.
+  if (!std::getenv("GTNX_NO_MALLOPT")) {
+    mallopt(M_TRIM_THRESHOLD, 256 << 20);
+    mallopt(M_TOP_PAD, 16 << 20);
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);
+  }
   HIP_CHECK(hipGetDevice(&device_));
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device_));
@@ -358,6 +369,14 @@ double now_ms() {
 bool HostTimer::enabled() {
   static const bool e = std::getenv("GTNX_HOST_TIMING") != nullptr;
   return e;
+}
+void host_timer_add(const char* name, double ms) {
+  if (!HostTimer::enabled()) return;
+  HostTable& h = host_table();
+  std::lock_guard<std::mutex> lk(h.mu);
+  auto& e = h.t[name];
+  e.first += ms;
+  e.second += 1;
 }
 HostTimer::HostTimer(const char* n) : name(n), t0(enabled() ? now_ms() : 0.0) {}
 HostTimer::~HostTimer() {

@@ -132,6 +132,7 @@ struct HostTimer {
   ~HostTimer();
   static bool enabled();
 };
+void host_timer_add(const char* name, double ms);  // one sample for the GTNX_HOST_TIMING table
 #define GTNX_HT_CAT2(a, b) a##b
 #define GTNX_HT_CAT(a, b) GTNX_HT_CAT2(a, b)
 #define GTNX_HOST_T(name) ::gtnx::HostTimer GTNX_HT_CAT(_host_t_, __LINE__)(name)

@@ -5,6 +5,7 @@
 #pragma once
 
 // (the standard headers the reference's graph.h:10-16 pulls in: callers rely on them transitively)
+#include <atomic>
 #include <cassert>
 #include <climits>
 #include <cstdint>
@@ -42,23 +43,33 @@ class Graph {
   using GradFunc = std::function<void(std::vector<Graph>& inputs, Graph& deltas)>;
 
   /** Graph(GradFunc, inputs), reference graph.h:78 */
-  Graph(GradFunc gradFunc, std::vector<Graph> inputs) {
+  Graph(GradFunc gradFunc, std::vector<Graph> inputs) : fresh_(true) {
     std::vector<gtnx_graph_t> hs;
-    for (auto& g : inputs) hs.push_back(g.h_);
+    for (auto& g : inputs) hs.push_back(g.handle());
     auto* ctx = gradFunc ? new GradFunc(std::move(gradFunc)) : nullptr;
     detail::check(gtnx_graph_create_op(hs.data(), static_cast<int>(hs.size()), ctx ? &Graph::trampoline : nullptr,
                                        ctx, ctx ? &Graph::freeCtx : nullptr, &h_));
   }
   /** Graph(bool calcGrad = true), reference graph.h:89 */
-  Graph(bool calcGrad = true) { detail::check(gtnx_graph_create(calcGrad ? 1 : 0, &h_)); }
-  Graph(const Graph& o) { detail::check(gtnx_graph_copy(o.h_, &h_)); }  // aliases, like the reference
-  Graph(Graph&& o) noexcept : h_(o.h_) { o.h_ = nullptr; }
+  Graph(bool calcGrad = true) : fresh_(true) { detail::check(gtnx_graph_create(calcGrad ? 1 : 0, &h_)); }
+  Graph(const Graph& o) {  // aliases, like the reference
+    detail::check(gtnx_graph_copy(o.h(), &h_));
+    o.aliased_ = aliased_ = true;  // two objects over one graph: neither may keep arcs to itself any more
+  }
+  Graph(Graph&& o) noexcept
+      : h_(o.h_), fresh_(o.fresh_), aliased_(o.aliased_), baseN_(o.baseN_), baseA_(o.baseA_), build_(std::move(o.build_)) {
+    dirty_.store(o.dirty_.load(std::memory_order_relaxed), std::memory_order_relaxed);
+    o.h_ = nullptr;
+    o.dirty_.store(false, std::memory_order_relaxed);
+  }
   Graph& operator=(const Graph& o) {
     if (this != &o) {
       gtnx_graph_t n;
-      detail::check(gtnx_graph_copy(o.h_, &n));
+      detail::check(gtnx_graph_copy(o.h(), &n));
       reset();
       h_ = n;
+      o.aliased_ = aliased_ = true;
+      fresh_ = false;
     }
     return *this;
   }
@@ -66,19 +77,49 @@ class Graph {
     if (this != &o) {
       reset();
       h_ = o.h_;
+      fresh_ = o.fresh_;
+      aliased_ = o.aliased_;
+      baseN_ = o.baseN_;
+      baseA_ = o.baseA_;
+      build_ = std::move(o.build_);
+      dirty_.store(o.dirty_.load(std::memory_order_relaxed), std::memory_order_relaxed);
       o.h_ = nullptr;
+      o.dirty_.store(false, std::memory_order_relaxed);
     }
     return *this;
   }
   ~Graph() { reset(); }
 
+  // addNode / addArc on a graph that only this object refers to are COLLECTED here and handed to the engine in
+  // two bulk calls (gtnx_graph_add_nodes / gtnx_graph_add_arcs: same ids, same order) the first time anything
+  // else is asked of the graph -- a target graph is several hundred of these calls, and a call across the ABI
+  // costs ten times what the append does.  Ids are known without asking (a fresh graph starts at 0 and nobody
+  // else adds to it).  What moves: an invalid arc (node out of range, label < epsilon -- the reference only
+  // asserts both, graph.h:423-433) is reported by the call that hands the arcs over, not by its own addArc.
   int addNode(bool start = false, bool accept = false) {
+    if (collecting()) {
+      build_->start.push_back(start);
+      build_->accept.push_back(accept);
+      dirty_.store(true, std::memory_order_release);
+      return baseN_ + static_cast<int>(build_->start.size()) - 1;
+    }
     int id;
     detail::check(gtnx_graph_add_node(h_, start, accept, &id));
     return id;
   }
   size_t addArc(size_t srcNode, size_t dstNode, int label) { return addArc(srcNode, dstNode, label, label); }
   size_t addArc(size_t srcNode, size_t dstNode, int ilabel, int olabel, float weight = 0.0) {
+    if (collecting()) {
+      Build& b = *build_;
+      b.src.push_back(static_cast<int>(srcNode));
+      b.dst.push_back(static_cast<int>(dstNode));
+      b.il.push_back(ilabel);
+      b.ol.push_back(olabel);
+      if (weight != 0.0f && b.w.empty()) b.w.assign(b.src.size() - 1, 0.0f);
+      if (weight != 0.0f || !b.w.empty()) b.w.push_back(weight);
+      dirty_.store(true, std::memory_order_release);
+      return static_cast<size_t>(baseA_) + b.src.size() - 1;
+    }
     int id;
     detail::check(gtnx_graph_add_arc(h_, static_cast<int>(srcNode), static_cast<int>(dstNode), ilabel, olabel,
                                      weight, &id));
@@ -90,80 +131,80 @@ class Graph {
   size_t numAccept() const { return count(&gtnx_graph_num_accept); }
   float item() const {
     float v;
-    detail::check(gtnx_graph_item(h_, &v));
+    detail::check(gtnx_graph_item(h(), &v));
     return v;
   }
   static Graph deepCopy(const Graph& src) {
     gtnx_graph_t n;
-    detail::check(gtnx_graph_deep_copy(src.h_, &n));
+    detail::check(gtnx_graph_deep_copy(src.h(), &n));
     return Graph(n);
   }
-  void arcSort(bool olabel = false) { detail::check(gtnx_graph_arc_sort(h_, olabel)); }
-  void markArcSorted(bool olabel = false) { detail::check(gtnx_graph_mark_arc_sorted(h_, olabel)); }
+  void arcSort(bool olabel = false) { detail::check(gtnx_graph_arc_sort(h(), olabel)); }
+  void markArcSorted(bool olabel = false) { detail::check(gtnx_graph_mark_arc_sorted(h(), olabel)); }
   bool ilabelSorted() const {
     int v;
-    detail::check(gtnx_graph_ilabel_sorted(h_, &v));
+    detail::check(gtnx_graph_ilabel_sorted(h(), &v));
     return v != 0;
   }
   bool olabelSorted() const {
     int v;
-    detail::check(gtnx_graph_olabel_sorted(h_, &v));
+    detail::check(gtnx_graph_olabel_sorted(h(), &v));
     return v != 0;
   }
   float* weights() {
     float* p;
-    detail::check(gtnx_graph_weights(h_, 1, &p));
+    detail::check(gtnx_graph_weights(h(), 1, &p));
     return p;
   }
   const float* weights() const {
     float* p;
-    detail::check(gtnx_graph_weights(h_, 0, &p));
+    detail::check(gtnx_graph_weights(h(), 0, &p));
     return p;
   }
-  void setWeights(const float* weights) { detail::check(gtnx_graph_set_weights(h_, weights)); }
+  void setWeights(const float* weights) { detail::check(gtnx_graph_set_weights(h(), weights)); }
   /** extension: copy numArcs floats from a DEVICE buffer (no host round trip) */
-  void setWeightsDevice(const void* deviceWeights) { detail::check(gtnx_graph_set_weights_device(h_, deviceWeights)); }
-  void labelsToArray(int* out, bool ilabel = true) { detail::check(gtnx_graph_labels_to_array(h_, out, ilabel)); }
+  void setWeightsDevice(const void* deviceWeights) { detail::check(gtnx_graph_set_weights_device(h(), deviceWeights)); }
+  void labelsToArray(int* out, bool ilabel = true) { detail::check(gtnx_graph_labels_to_array(h(), out, ilabel)); }
   std::vector<int> labelsToVector(bool ilabel = true) {
     std::vector<int> out(numArcs());
     labelsToArray(out.data(), ilabel);
     return out;
   }
 
-  void addGrad(std::vector<float>&& other) { detail::check(gtnx_graph_add_grad(h_, other.data(), (int64_t)other.size())); }
+  void addGrad(std::vector<float>&& other) { detail::check(gtnx_graph_add_grad(h(), other.data(), (int64_t)other.size())); }
   void addGrad(const std::vector<float>& other) {
-    detail::check(gtnx_graph_add_grad(h_, other.data(), (int64_t)other.size()));
+    detail::check(gtnx_graph_add_grad(h(), other.data(), (int64_t)other.size()));
   }
-  void addGrad(const Graph& other) { detail::check(gtnx_graph_add_grad_graph(h_, other.h_)); }
+  void addGrad(const Graph& other) { detail::check(gtnx_graph_add_grad_graph(h(), other.h())); }
   bool calcGrad() const {
     int v;
-    detail::check(gtnx_graph_calc_grad(h_, &v));
+    detail::check(gtnx_graph_calc_grad(h(), &v));
     return v != 0;
   }
   bool isGradAvailable() const {
     int v;
-    detail::check(gtnx_graph_is_grad_available(h_, &v));
+    detail::check(gtnx_graph_is_grad_available(h(), &v));
     return v != 0;
   }
   Graph& grad() { return const_cast<Graph&>(static_cast<const Graph&>(*this).grad()); }
   const Graph& grad() const {
     gtnx_graph_t n;
-    detail::check(gtnx_graph_grad(h_, &n));
+    detail::check(gtnx_graph_grad(h(), &n));
     grad_.reset(new Graph(n));
     return *grad_;
   }
-  void setCalcGrad(bool calcGrad) { detail::check(gtnx_graph_set_calc_grad(h_, calcGrad)); }
-  void zeroGrad() { detail::check(gtnx_graph_zero_grad(h_)); }
+  void setCalcGrad(bool calcGrad) { detail::check(gtnx_graph_set_calc_grad(h(), calcGrad)); }
+  void zeroGrad() { detail::check(gtnx_graph_zero_grad(h())); }
   std::uintptr_t id() {
     std::uintptr_t v;
-    detail::check(gtnx_graph_id(h_, &v));
+    detail::check(gtnx_graph_id(h(), &v));
     return v;
   }
   /** non-null iff a gradient function is attached (reference graph.h:286); the
    *  engine owns the function, so the returned callable only reports presence */
   GradFunc gradFunc() {
     int v;
-    detail::check(gtnx_graph_has_grad_fn(h_, &v));
+    detail::check(gtnx_graph_has_grad_fn(h(), &v));
     if (!v) return nullptr;
     return [](std::vector<Graph>&, Graph&) {
       throw std::logic_error("[Graph::gradFunc] engine-owned gradient functions run through gtn::backward");
@@ -171,23 +212,23 @@ class Graph {
   }
   void setGradFunc(GradFunc gradFunc) {
     auto* ctx = gradFunc ? new GradFunc(std::move(gradFunc)) : nullptr;
-    detail::check(gtnx_graph_set_grad_fn(h_, ctx ? &Graph::trampoline : nullptr, ctx, ctx ? &Graph::freeCtx : nullptr));
+    detail::check(gtnx_graph_set_grad_fn(h(), ctx ? &Graph::trampoline : nullptr, ctx, ctx ? &Graph::freeCtx : nullptr));
   }
   std::vector<Graph>& inputs() const {
     int64_t n;
-    detail::check(gtnx_graph_num_inputs(h_, &n));
+    detail::check(gtnx_graph_num_inputs(h(), &n));
     inputs_.clear();
     for (int64_t i = 0; i < n; ++i) {
-      gtnx_graph_t h;
-      detail::check(gtnx_graph_get_input(h_, (int)i, &h));
-      inputs_.push_back(Graph(h));
+      gtnx_graph_t in;
+      detail::check(gtnx_graph_get_input(h(), (int)i, &in));
+      inputs_.push_back(Graph(in));
     }
     return inputs_;
   }
   void setInputs(std::vector<Graph> inputs) {
     std::vector<gtnx_graph_t> hs;
-    for (auto& g : inputs) hs.push_back(g.h_);
-    detail::check(gtnx_graph_set_inputs(h_, hs.data(), (int)hs.size()));
+    for (auto& g : inputs) hs.push_back(g.handle());
+    detail::check(gtnx_graph_set_inputs(h(), hs.data(), (int)hs.size()));
   }
   /** reference graph.h:317-321 drops the weights to save memory on the tape; the
    *  engine keeps device buffers alive through the tape itself, so this aliases */
@@ -196,47 +237,47 @@ class Graph {
   const std::vector<int>& start() const {
     std::vector<int>& v = listSlot(0, 0);
     v.resize(numStart());
-    detail::check(gtnx_graph_get_start(h_, v.data()));
+    detail::check(gtnx_graph_get_start(h(), v.data()));
     return v;
   }
   const std::vector<int>& accept() const {
     std::vector<int>& v = listSlot(1, 0);
     v.resize(numAccept());
-    detail::check(gtnx_graph_get_accept(h_, v.data()));
+    detail::check(gtnx_graph_get_accept(h(), v.data()));
     return v;
   }
   bool isStart(size_t i) const {
     int v;
-    detail::check(gtnx_graph_is_start(h_, (int)i, &v));
+    detail::check(gtnx_graph_is_start(h(), (int)i, &v));
     return v != 0;
   }
   bool isAccept(size_t i) const {
     int v;
-    detail::check(gtnx_graph_is_accept(h_, (int)i, &v));
+    detail::check(gtnx_graph_is_accept(h(), (int)i, &v));
     return v != 0;
   }
-  void makeAccept(size_t i) { detail::check(gtnx_graph_make_accept(h_, (int)i)); }
+  void makeAccept(size_t i) { detail::check(gtnx_graph_make_accept(h(), (int)i)); }
   size_t numOut(size_t i) const {
     int64_t v;
-    detail::check(gtnx_graph_num_out(h_, (int)i, &v));
+    detail::check(gtnx_graph_num_out(h(), (int)i, &v));
     return (size_t)v;
   }
   const std::vector<int>& out(size_t i) const {
     std::vector<int>& v = listSlot(2, i);
     v.resize(numOut(i));
-    detail::check(gtnx_graph_get_out(h_, (int)i, v.data()));
+    detail::check(gtnx_graph_get_out(h(), (int)i, v.data()));
     return v;
   }
   int out(size_t i, size_t j) const { return out(i)[j]; }
   size_t numIn(size_t i) const {
     int64_t v;
-    detail::check(gtnx_graph_num_in(h_, (int)i, &v));
+    detail::check(gtnx_graph_num_in(h(), (int)i, &v));
     return (size_t)v;
   }
   const std::vector<int>& in(size_t i) const {
     std::vector<int>& v = listSlot(3, i);
     v.resize(numIn(i));
-    detail::check(gtnx_graph_get_in(h_, (int)i, v.data()));
+    detail::check(gtnx_graph_get_in(h(), (int)i, v.data()));
     return v;
   }
   size_t in(size_t i, size_t j) const { return (size_t)in(i)[j]; }
@@ -248,13 +289,16 @@ class Graph {
   int olabel(size_t i) const { return arcField(i, 3); }
   float weight(size_t i) const {
     float w;
-    detail::check(gtnx_graph_get_arc(h_, (int)i, nullptr, nullptr, nullptr, nullptr, &w));
+    detail::check(gtnx_graph_get_arc(h(), (int)i, nullptr, nullptr, nullptr, nullptr, &w));
     return w;
   }
-  void setWeight(size_t i, float weight) { detail::check(gtnx_graph_set_weight(h_, (int)i, weight)); }
+  void setWeight(size_t i, float weight) { detail::check(gtnx_graph_set_weight(h(), (int)i, weight)); }
 
   /** the C-ABI handle (for the batched free functions) */
-  gtnx_graph_t handle() const { return h_; }
+  gtnx_graph_t handle() const {
+    aliased_ = true;  // the engine may keep a reference of its own from here on (an op's inputs)
+    return h();
+  }
   /** adopt a handle returned by the C ABI */
   static Graph fromHandle(gtnx_graph_t h) { return Graph(h); }
 
@@ -263,17 +307,61 @@ class Graph {
   size_t addArc(size_t srcNode, size_t dstNode, int label, double) = delete;
   explicit Graph(gtnx_graph_t h) : h_(h) {}
   void reset() {
-    if (h_) gtnx_graph_destroy(h_);
+    if (h_) gtnx_graph_destroy(h_);  // (collected nodes / arcs of a graph nobody ever looked at go with it)
     h_ = nullptr;
+    build_.reset();
+    dirty_.store(false, std::memory_order_relaxed);
+  }
+  // ---- collected addNode / addArc calls (see addNode)
+  struct Build {
+    std::vector<uint8_t> start, accept;
+    std::vector<int> src, dst, il, ol;
+    std::vector<float> w;  // empty while every weight so far is 0
+  };
+  bool collecting() {
+    if (aliased_ || !fresh_) return false;
+    if (!build_) {
+      build_.reset(new Build());
+      build_->src.reserve(64), build_->dst.reserve(64), build_->il.reserve(64), build_->ol.reserve(64);
+      build_->start.reserve(32), build_->accept.reserve(32);
+    }
+    return true;
+  }
+  /** the handle, with everything collected so far handed over */
+  gtnx_graph_t h() const {
+    if (dirty_.load(std::memory_order_acquire)) handOver();
+    return h_;
+  }
+  void handOver() const {
+    std::lock_guard<std::mutex> lk(listMutex_);  // (const readers on several threads may arrive together)
+    if (!dirty_.load(std::memory_order_acquire)) return;
+    Build& b = *build_;
+    const int nn = static_cast<int>(b.start.size()), na = static_cast<int>(b.src.size());
+    // (counted as handed over even if the engine refuses them: the error is reported once)
+    baseN_ += nn;
+    baseA_ += na;
+    std::vector<uint8_t> st, ac;
+    std::vector<int> src, dst, il, ol;
+    std::vector<float> w;
+    st.swap(b.start), ac.swap(b.accept), src.swap(b.src), dst.swap(b.dst), il.swap(b.il), ol.swap(b.ol), w.swap(b.w);
+    struct Done {  // readers on other threads wait (listMutex_) until the engine HAS the arcs
+      std::atomic<bool>& d;
+      ~Done() { d.store(false, std::memory_order_release); }
+    } done{dirty_};
+    if (nn) detail::check(gtnx_graph_add_nodes(h_, nn, st.data(), ac.data()));
+    if (na) detail::check(gtnx_graph_add_arcs(h_, na, src.data(), dst.data(), il.data(), ol.data(), w.empty() ? nullptr : w.data()));
+    // keep the capacity for the next round
+    st.clear(), ac.clear(), src.clear(), dst.clear(), il.clear(), ol.clear(), w.clear();
+    b.start.swap(st), b.accept.swap(ac), b.src.swap(src), b.dst.swap(dst), b.il.swap(il), b.ol.swap(ol);
   }
   size_t count(gtnx_status_t (*fn)(gtnx_graph_t, int64_t*)) const {
     int64_t v;
-    detail::check(fn(h_, &v));
+    detail::check(fn(h(), &v));
     return (size_t)v;
   }
   int arcField(size_t i, int which) const {
     int v[4];
-    detail::check(gtnx_graph_get_arc(h_, (int)i, &v[0], &v[1], &v[2], &v[3], nullptr));
+    detail::check(gtnx_graph_get_arc(h(), (int)i, &v[0], &v[1], &v[2], &v[3], nullptr));
     return v[which];
   }
   static gtnx_status_t trampoline(void* ctx, gtnx_graph_t* inputs, int n, gtnx_graph_t deltas) {
@@ -300,6 +388,11 @@ class Graph {
   static void freeCtx(void* ctx) { delete static_cast<GradFunc*>(ctx); }
 
   gtnx_graph_t h_{nullptr};
+  bool fresh_{false};             // created empty by this object: node / arc ids are known without asking
+  mutable bool aliased_{false};   // another Graph object refers to the same graph
+  mutable int baseN_{0}, baseA_{0};
+  mutable std::unique_ptr<Build> build_;
+  mutable std::atomic<bool> dirty_{false};
   mutable std::unique_ptr<Graph> grad_;
   mutable std::vector<Graph> inputs_;
   // start() / accept() / out(i) / in(i) hand out references like the reference does (graph.h:293-325 there):

@@ -17,6 +17,7 @@
 #include <functional>
 #include <exception>
 #include <mutex>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -40,8 +41,9 @@ class Pool {
     static Pool p;
     return p;
   }
-  /** run `job` on `nthreads` threads (caller included; it runs `callerFirst` before
-   *  joining in).  Nested or concurrent calls run on the calling thread only. */
+  /** run `job` on `nthreads` pool threads (the caller runs `callerFirst` and waits: what it allocates -- it
+   *  runs the region's deferred calls afterwards -- stays apart from what the pool's threads build and take
+   *  down).  Nested or concurrent calls run on the calling thread only. */
   template <class Job, class Pre>
   void run(size_t nthreads, Job&& job, Pre&& callerFirst) {
     std::unique_lock<std::mutex> call(callMutex_, std::try_to_lock);
@@ -50,17 +52,16 @@ class Pool {
       job();
       return;
     }
-    grow(nthreads - 1);
+    grow(nthreads);
     {
       std::lock_guard<std::mutex> lk(mutex_);
       job_ = [&job] { job(); };
-      want_ = nthreads - 1;
-      pending_ = nthreads - 1;
+      want_ = nthreads;
+      pending_ = nthreads;
       ++epoch_;
     }
     wake_.notify_all();
     callerFirst();  // the workers are already running
-    job();
     std::unique_lock<std::mutex> lk(mutex_);
     done_.wait(lk, [&] { return pending_ == 0; });
     job_ = nullptr;
@@ -101,6 +102,10 @@ class Pool {
             --pending_;
           }
           done_.notify_one();
+          // the caller goes on (the engine runs the region's deferred calls now); this thread takes apart
+          // what earlier steps let go of meanwhile -- off the caller's critical path, shared with the
+          // pool's other threads
+          gtnx_reclaim();
         }
       });
     }
@@ -131,13 +136,16 @@ void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst =
     }
     return h;
   }();
-  // (GTN_AMD_THREADS caps the pool: the tasks of a region only do host-side work here)
-  static const size_t cap = [] {
+  // The tasks of a region only do host-side work here (a target graph is a few tens of microseconds), so a
+  // thread per 16 tasks is plenty and every further thread is only another wake-up; GTN_AMD_THREADS sets
+  // the pool size for callers whose tasks do heavy work of their own.
+  static const size_t fixed = [] {
     const char* e = std::getenv("GTN_AMD_THREADS");
     const long v = e ? std::atol(e) : 0;
     return v > 0 ? size_t(v) : size_t(0);
   }();
-  const size_t nt = std::min<size_t>(std::min(n, hw), cap ? cap : maxThreads);
+  const size_t light = std::max<size_t>(n >= 2 ? 2 : 1, n / 16);
+  const size_t nt = std::min<size_t>(std::min(n, hw), fixed ? fixed : std::min(light, maxThreads));
   std::atomic<size_t> next{0};
   std::exception_ptr first;
   std::mutex mu;
@@ -189,16 +197,35 @@ auto parallelMap(FuncType&& function, Args&&... inputs) {
   size_t size = 0;
   (void)std::initializer_list<int>{(size = std::max(size, inputs.size()), 0)...};
   using OutType = decltype(function(detail::pickElem(1, 0, inputs)...));
-  // While the workers map a big batch the caller first tears down what the previous step let go of
-  // (gtnx_reclaim: ~10 graph objects per utterance) -- host time that otherwise sits on the critical path.
-  auto prelude = [size] {
-    if (size >= 64) gtnx_reclaim();
-  };
+  auto prelude = [] {};
   if constexpr (std::is_void<OutType>::value) {
-    detail::runIndexed(size, [&](size_t i) { function(detail::pickElem(size, i, inputs)...); }, 256, prelude);
+    detail::runIndexed(size, [&](size_t i) { function(detail::pickElem(size, i, inputs)...); }, 64, prelude);
   } else {
-    std::vector<OutType> out(size);
-    detail::runIndexed(size, [&](size_t i) { out[i] = function(detail::pickElem(size, i, inputs)...); }, 256, prelude);
+    // results are constructed in place by the tasks (no default-constructed OutType per element first: for a
+    // Graph that would be a graph created and thrown away per task), then moved into the vector in order
+    struct Slots {
+      size_t n;
+      typename std::aligned_storage<sizeof(OutType), alignof(OutType)>::type* raw;
+      std::vector<unsigned char> made;
+      explicit Slots(size_t k)
+          : n(k), raw(new typename std::aligned_storage<sizeof(OutType), alignof(OutType)>::type[k ? k : 1]), made(k, 0) {}
+      OutType& at(size_t i) { return *reinterpret_cast<OutType*>(&raw[i]); }
+      ~Slots() {
+        for (size_t i = 0; i < n; ++i)
+          if (made[i]) at(i).~OutType();
+        delete[] raw;
+      }
+    } slots(size);
+    detail::runIndexed(
+        size,
+        [&](size_t i) {
+          new (&slots.raw[i]) OutType(function(detail::pickElem(size, i, inputs)...));
+          slots.made[i] = 1;
+        },
+        64, prelude);
+    std::vector<OutType> out;
+    out.reserve(size);
+    for (size_t i = 0; i < size; ++i) out.emplace_back(std::move(slots.at(i)));
     return out;
   }
 }

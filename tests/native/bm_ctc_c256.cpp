@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
       return 2;
     }
     for (int b = 0; b < B; ++b) {
-      hipMemcpy(dev + size_t(b) * T * M, hostScores[b].data(), sizeof(float) * size_t(T) * M, hipMemcpyHostToDevice);
+      (void)hipMemcpy(dev + size_t(b) * T * M, hostScores[b].data(), sizeof(float) * size_t(T) * M, hipMemcpyHostToDevice);
       scores[b] = dev + size_t(b) * T * M;
     }
   } else {
@@ -162,6 +162,6 @@ int main(int argc, char** argv) {
       if (!(worstLoss <= 1e-5) || !(worstGrad <= tol)) rc = 1;
     }
   }
-  if (dev) hipFree(dev);
+  if (dev) (void)hipFree(dev);
   return rc;
 }

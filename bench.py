@@ -81,7 +81,7 @@ def build_ctc_graphs(gtn, targets):
     return out
 
 
-def cpu_baseline(B, T, Cn, U, seed):
+def cpu_baseline(B, T, Cn, U, seed, budget_s=45.0):
     """reference CPU path timed on this host (rank 0, N=1 only), bounded sample"""
     import graphgen as gg
     cores = os.cpu_count() or 1
@@ -101,7 +101,7 @@ def cpu_baseline(B, T, Cn, U, seed):
         thr = C.c_int()
         t0 = time.time()
         secs = []
-        while len(secs) < 3 and (not secs or time.time() - t0 + secs[-1] < 45.0):
+        while len(secs) < 3 and (not secs or time.time() - t0 + secs[-1] < budget_s):
             secs.append(lib.ref_ctc_batch(em.ctypes.data, tg.ctypes.data, nb, T, Cn, U, 0, 1, losses.ctypes.data, None,
                                           C.byref(thr)))
         iters = len(secs)
@@ -143,6 +143,50 @@ def unmodified_caller(B):
         return {"error": str(e)[:300]}
 
 
+def run_json(cmd, timeout):
+    """one JSON line from a child process (the last line that parses)"""
+    import subprocess
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        for ln in reversed(r.stdout.strip().splitlines()):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+        return {"error": (r.stdout + r.stderr)[-400:]}
+    except Exception as e:  # a sub-record must not cost the bench line
+        return {"error": str(e)[:300]}
+
+
+def reference_loop(B, Cn, mode):
+    """tests/native/bm_ctc_c256.cpp: timeBatchedCtc of benchmarks/ctc.cpp:136-168 written with the reference's
+    names only (ctcGraph via addNode / addArc / arcSort, linearGraph + setWeights per utterance, parallelMap(fwd)
+    then parallelMap(bwd)) at this alphabet size; emissions in device memory (`device`) or host vectors (`host`)."""
+    exe = os.path.join(ROOT, "tests", "dropin", "_bin", "bm_ctc_c256")
+    if not os.path.exists(exe):
+        return None
+    return run_json([exe, str(B), str(Cn), "100", mode], 300)
+
+
+def other_configs(args):
+    """BASELINE.json configs[0], [1], [3], [4] (C3 is the line itself): short timed loops, each with its own roofline
+    and cpu_baseline, run as child processes so that their memory is gone before the next one starts"""
+    py = sys.executable
+    out = {}
+    out["C1"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c1"], 300)
+    out["C2"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c2"], 300)
+    out["C4"] = run_json([py, os.path.join(ROOT, "tools", "bench_c4.py"), "--steps", "2"], 600)
+    c5 = run_json([py, os.path.join(ROOT, "bench.py"), "--config", "c5", "--steps", "10", "--warmup", "2", "--no-configs",
+                   "--no-reference-api", "--no-unmodified-caller", "--no-built-lattice", "--cpu-baseline-seconds", "20"], 600)
+    if "error" not in c5:
+        c5 = {k: c5.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "roofline_other",
+                                     "kernel_ms_per_step", "host_ms_last_step", "loss_mean", "cpu_baseline")}
+        c5["note"] = ("one rank's shard of BASELINE config C5 (T=2000, C=1024, U=200, 4096 utterances over 8 GPUs = 512 "
+                      "per GPU), timed on one MI355X")
+    out["C5_shard"] = c5
+    return out
+
+
 def pin_to_gpu_numa_node(local_rank):
     """One process per GPU: keep this rank's host threads (the engine's worker pool inherits the mask)
     on the cores of the NUMA node its GPU hangs off.  Returns what it did, for the per-rank report."""
@@ -172,7 +216,7 @@ def per_rank_report(dist, torch, world, dev, host_ms, dt):
                                                                    "forward_scores", "backward")] + \
            [float(len(os.sched_getaffinity(0)))]
     t = torch.tensor(mine, dtype=torch.float64, device=dev)
-    if world > 1:
+    if world > 1 or (dist.is_initialized() and os.environ.get("GTN_AMD_FORCE_COLLECTIVES") == "1"):
         parts = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(parts, t)
     else:
@@ -232,9 +276,15 @@ def main():
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--U", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--built-lattice", action="store_true",
-                    help="also run the step with every lattice built (compose -> forwardScore kernel -> fused "
+    ap.add_argument("--built-lattice", action="store_true", default=True,
+                    help="(default) also run the step with every lattice built (compose -> forwardScore kernel -> fused "
                          "backward) and report its kernels as built_lattice_path")
+    ap.add_argument("--no-built-lattice", dest="built_lattice", action="store_false")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the sub-records of BASELINE.json's other configurations (C1, C2, C4, C5 shard)")
+    ap.add_argument("--no-reference-api", action="store_true",
+                    help="skip timing the same step through the vector overloads and through the reference's own loop")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=45.0, help="bound of the cpu_baseline leg")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="no GPU: drive this script's multi-rank branch (rendezvous, all_gather of the losses, barrier, "
                          "max-over-ranks timing, per-rank report) over gloo with a stand-in step -- tests/test_distributed_cpu.py")
@@ -256,8 +306,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dry = args.dry_run_cpu
-    numa = pin_to_gpu_numa_node(local) if (world > 1 and not dry) else None
-    if world > 1:
+    # GTN_BENCH_FORCE_DIST=1: take the multi-rank branch (RCCL process group, all_gather of the losses, barrier,
+    # max over ranks) with whatever world size the environment gives -- ONE on a single-GPU box, so that the
+    # first 8-GPU run is not also the first time these calls execute (tests/test_distributed_gpu.py)
+    forced = os.environ.get("GTN_BENCH_FORCE_DIST") == "1"
+    if forced:
+        os.environ["GTN_AMD_FORCE_COLLECTIVES"] = "1"
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    world_dist = world > 1 or forced
+    numa = pin_to_gpu_numa_node(local) if (world_dist and not dry) else None
+    if world_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -279,13 +337,15 @@ def main():
     with torch.cuda.stream(stream):
         em_dev = torch.from_numpy(em).to(dev)
         loss_dev = torch.empty(B, dtype=torch.float32, device=dev)
-        gathered = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
+        gathered = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(world)] if world_dist else None
 
     native = None
     if not args.python_host:
         native = C.CDLL(os.path.join(ROOT, "bench_native", "libgtn_bench.so"))
         native.gtn_bench_ctc_step.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_void_p]
         native.gtn_bench_ctc_step.restype = C.c_int
+        native.gtn_bench_ctc_step_vector.argtypes = native.gtn_bench_ctc_step.argtypes
+        native.gtn_bench_ctc_step_vector.restype = C.c_int
         with torch.cuda.stream(stream):
             grad_dev = torch.empty(B, T, Cn, dtype=torch.float32, device=dev)
 
@@ -298,9 +358,17 @@ def main():
             if rc != 0:
                 native.gtn_bench_last_error.restype = C.c_char_p
                 raise RuntimeError("native step failed: " + native.gtn_bench_last_error().decode())
-            if world > 1:
+            if world_dist:
                 dist.all_gather(gathered, loss_dev)
         return None
+
+    def vector_step():
+        # the same step through the vector overloads of the per-graph functions (bench_native: gtn_bench_ctc_step_vector)
+        with torch.cuda.stream(stream):
+            if native.gtn_bench_ctc_step_vector(em_dev.data_ptr(), tg.ctypes.data, B, T, Cn, U, loss_dev.data_ptr(),
+                                                grad_dev.data_ptr()) != 0:
+                native.gtn_bench_last_error.restype = C.c_char_p
+                raise RuntimeError("vector step failed: " + native.gtn_bench_last_error().decode())
 
     def step():
         if native is not None:
@@ -312,12 +380,12 @@ def main():
             loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))  # Python: left to right
             gtn.backward(loss)
             gtn.items_to_device(loss, loss_dev)
-            if world > 1:
+            if world_dist:
                 dist.all_gather(gathered, loss_dev)
         return ems, comp
 
     def fence():
-        if world > 1:
+        if world_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -410,9 +478,12 @@ def main():
             # linear_rows_kernel<false>, whose bytes are known exactly: FETCH_SIZE reads half the
             # fetched KiB on gfx950, WRITE_SIZE is exact (profiles/README.md)
             traffic = (2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024 if k else None
+            # (NOT measured by this run: read from the committed PMC passes of the same command and kernel)
+            src = ("profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                   "`python bench.py`, tools/profile_gpu.sh; 2*FETCH_SIZE + WRITE_SIZE KiB per launch)") if k else None
             gbs = per / (ms * 1e-3) / 1e9
             out[name] = {"bound": "hbm", "kernel": KERNEL_OF[name], "achieved": gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "ms_per_launch": ms,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": ms,
                          "algorithmic_bytes_per_launch": per}
         return out
 
@@ -420,20 +491,22 @@ def main():
     dominant = max(roofs, key=lambda k: roofs[k]["ms_per_launch"]) if roofs else None
     roof = roofs.get(dominant)
 
-    # ---- the same step with every lattice BUILT (the path graphs that are not CTC-shaped take,
-    # and what GTNX_LAZY_COMPOSE=0 selects): untimed for `value`, profiled for its kernels
+    # ---- the same step with every lattice BUILT (the path graphs that are not CTC-shaped take, and what
+    # GTNX_LAZY_COMPOSE=0 selects; through the vector overloads -- a batch record's product is symbolic by
+    # construction): untimed for `value`, profiled for its kernels (compose_kernel, the forwardScore kernel over the
+    # built lattices, its fused backward)
     built = None
     if native is not None and args.built_lattice and not os.environ.get("GTNX_LAZY_COMPOSE"):
         os.environ["GTNX_LAZY_COMPOSE"] = "0"
         try:
             for _ in range(3):
-                step()
+                vector_step()
             fence()
             gtn.prof_reset()
             gtn.prof_enable(True)
             t1 = time.perf_counter()
             for _ in range(5):
-                step()
+                vector_step()
             fence()
             dt_built = (time.perf_counter() - t1) / 5
             gtn.prof_enable(False)
@@ -452,6 +525,35 @@ def main():
                      "max_abs_grad_diff_vs_timed_path": gdiff}
         finally:
             os.environ.pop("GTNX_LAZY_COMPOSE", None)
+    # ---- the SAME step through the reference's own API forms, same inputs, same device tensors (world == 1):
+    #   batch_records    gtn::Batch (the timed loop above: `value`)
+    #   vector_overloads gtn::batched::* on std::vector<Graph> (bench_native: gtn_bench_ctc_step_vector)
+    #   reference_loop   parallelMap(fwd) + parallelMap(bwd) over per-utterance lambdas, reference names only
+    #                    (tests/native/bm_ctc_c256.cpp; its per-graph calls are deferred to the join: region.cpp)
+    reference_api = None
+    if world == 1 and native is not None and not args.no_reference_api:
+        reference_api = {"batch_records": {"losses_per_s": B * args.steps / dt, "ms_per_batch": dt / args.steps * 1e3,
+                                           "host": "bench_native/ctc_step.cpp over gtn::Batch (include/gtn/batch.h)"}}
+        try:
+            vstep = vector_step
+            for _ in range(3):
+                vstep()
+            fence()
+            nv = max(5, min(args.steps, 30))
+            t1 = time.perf_counter()
+            for _ in range(nv):
+                vstep()
+            fence()
+            dv = (time.perf_counter() - t1) / nv
+            lv = loss_dev.cpu().numpy()
+            reference_api["vector_overloads"] = {
+                "losses_per_s": B / dv, "ms_per_batch": dv * 1e3,
+                "max_rel_diff_vs_batch_records": float(np.max(np.abs(lv - losses_timed) / np.maximum(np.abs(losses_timed), 1e-30))),
+                "host": "bench_native/ctc_step.cpp: gtn_bench_ctc_step_vector (gtn::batched on vectors of graphs)"}
+        except Exception as e:  # a diagnostic must not cost the bench line
+            reference_api["vector_overloads"] = {"error": str(e)[:300]}
+        reference_api["reference_loop"] = reference_loop(B, Cn, "device")
+        reference_api["reference_loop_host_emissions"] = reference_loop(B, Cn, "host")
     ranks = per_rank_report(dist, torch, world, dev, host_ms or {}, dt_local)
     if rank == 0:
         losses = losses_timed
@@ -486,19 +588,26 @@ def main():
             # one entry per rank: its own wall time, host phases and host-thread budget (NUMA-pinned when N > 1)
             "per_rank": ranks,
             "numa": numa,
+            "collectives": ("RCCL (nccl backend): all_gather of the losses per step, barrier + all_reduce(MAX) around the timed "
+                            "region" + (" -- forced at world size 1 (GTN_BENCH_FORCE_DIST=1)" if forced and world == 1 else ""))
+            if world_dist else None,
             "loss_mean": float(np.mean(losses)),
         }
         if world == 1 and not args.no_unmodified_caller:
             out["unmodified_caller"] = unmodified_caller(B)
+        if world == 1 and native is not None and not args.no_reference_api:
+            out["reference_api"] = reference_api
+        if world == 1 and not args.no_configs and (B, T, Cn, U) == (512, 1000, 256, 100):
+            out["configs"] = other_configs(args)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234)
+            out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234, args.cpu_baseline_seconds)
         print(json.dumps(out))
     # orderly teardown: drop every graph, return pooled memory, then let HIP exit
     del keep, ems, comp, e0
     gtn.set_stream(None)
     gtn.synchronize()
     gtn.empty_cache()
-    if world > 1:
+    if world_dist:
         dist.destroy_process_group()
 
 

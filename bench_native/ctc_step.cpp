@@ -19,6 +19,7 @@ using namespace gtn;
 // graphs, intersect, the two forwardScores + subtract, backward -- what bounds a step once the GPU work is short
 static double g_last[5] = {0, 0, 0, 0, 0};
 static std::string g_error;
+static bool g_vector_symbolic = true;
 extern "C" __attribute__((visibility("default"))) const char* gtn_bench_last_error() { return g_error.c_str(); }
 extern "C" __attribute__((visibility("default"))) void gtn_bench_last_host_ms(double* out5) {
   for (int i = 0; i < 5; ++i) out5[i] = g_last[i];
@@ -61,4 +62,93 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step(const v
                  ms(t_tail1, t_end), ms(t_prev_end, tq));
   t_prev_end = now();
   return rc;
+}
+
+// The same step through the VECTOR overloads of the per-graph functions (gtn::batched, the device analogue of the
+// binding's std::vector<Graph> forms, bindings/python/gtn/_functions.cpp:84-135): B target graphs built on host
+// threads, B emission graphs over the device tensor, one batched launch per function, B result graphs per call.
+// What a caller gets who batches by hand but keeps per-utterance graphs; bench.py reports it next to the batch
+// records above and the reference's own loop (tests/native/bm_ctc_c256.cpp).
+extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step_vector(const void* emissions, const int* targets,
+                                                                                int B, int T, int C, int U,
+                                                                                void* loss_dev, void* grad_dev) {
+  static const bool timing = std::getenv("GTN_BENCH_TIMING") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  try {
+    const auto t0 = now();
+    std::vector<std::vector<int>> tg(static_cast<size_t>(B));
+    for (int b = 0; b < B; ++b) tg[b].assign(targets + size_t(b) * U, targets + size_t(b + 1) * U);
+    auto ctcs = parallelMap([](const std::vector<int>& t) { return criteria::ctcTargetGraph(t); }, tg);
+    const auto t1 = now();
+    auto ems = linearGraphs(B, T, C, emissions);
+    std::vector<gtnx_graph_t> he(static_cast<size_t>(B));
+    std::vector<int64_t> off(static_cast<size_t>(B));
+    for (int b = 0; b < B; ++b) {
+      he[b] = ems[b].handle();
+      off[b] = int64_t(b) * T * C;
+    }
+    if (grad_dev) detail::check(gtnx_grads_bind_device_n(he.data(), B, grad_dev, off.data()));
+    const auto t2 = now();
+    double t_int, t_fs, t_bw, t_out;
+    {
+      SymbolicCompose symbolic(g_vector_symbolic ? 2 : 0);  // (2: only forwardScore of the lattices is taken)
+      auto comp = batched::intersect(ctcs, ems);
+      const auto t3 = now();
+      auto score = batched::forwardScore(comp);
+      auto norm = batched::forwardScore(ems);
+      auto losses = batched::subtract(norm, score);
+      const auto t4 = now();
+      if (grad_dev) batched::backward(losses);
+      const auto t5 = now();
+      std::vector<gtnx_graph_t> hl(static_cast<size_t>(B));
+      for (int b = 0; b < B; ++b) hl[b] = losses[b].handle();
+      detail::check(gtnx_items_device_n(hl.data(), B, loss_dev));
+      if (grad_dev) detail::check(gtnx_grads_device_n(he.data(), B, grad_dev, off.data()));
+      const auto t6 = now();
+      t_int = ms(t2, t3), t_fs = ms(t3, t4), t_bw = ms(t4, t5), t_out = ms(t5, t6);
+    }
+    const auto t7 = now();
+    if (timing)
+      std::fprintf(stderr, "vector step host ms: targets %.2f emissions %.2f intersect %.2f scores %.2f backward %.2f outputs %.2f\n",
+                   ms(t0, t1), ms(t1, t2), t_int, t_fs, t_bw, t_out);
+    (void)t7;
+    return 0;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return -1;
+  }
+}
+// 0: the lattices of the vector step are BUILT (compose_kernel, the forwardScore kernel over the built lattice and its
+// fused backward: bench.py's built_lattice_path); 1 (default): kept symbolic
+extern "C" __attribute__((visibility("default"))) void gtn_bench_vector_symbolic(int on) { g_vector_symbolic = on != 0; }
+
+// BASELINE config C1 (benchmarks/ctc.cpp with batch = 1: T = 100, alphabet 28, U = 20): ONE utterance through the
+// per-graph functions, reference names only, nothing batched, nothing kept symbolic -- the lattice is built
+// (compose_kernel), scored, differentiated; `iters` repetitions, each ended by reading the loss (item()).
+// Returns the mean milliseconds per repetition (< 0: error).  emissions: DEVICE [T][C].
+extern "C" __attribute__((visibility("default"))) double gtn_bench_single_utterance(const void* emissions, const int* target,
+                                                                                  int T, int C, int U, int iters,
+                                                                                  float* loss_out) {
+  try {
+    std::vector<int> tg(target, target + U);
+    auto once = [&]() {
+      Graph ctc = criteria::ctcTargetGraph(tg);  // (the graph of benchmarks/ctc.cpp:40-58)
+      Graph em = linearGraph(T, C);
+      em.setWeights(static_cast<const float*>(emissions));
+      Graph loss = subtract(forwardScore(em), forwardScore(intersect(ctc, em)));
+      backward(loss);
+      return loss.item();
+    };
+    float l = 0;
+    for (int i = 0; i < 10; ++i) l = once();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) l = once();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (loss_out) *loss_out = l;
+    return std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return -1.0;
+  }
 }

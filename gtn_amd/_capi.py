@@ -151,9 +151,8 @@ ALL_SYMBOLS = sorted(list(_SIGS) + list(_RESTYPE))
 
 
 def default_library_path():
-    env = os.environ.get("GTN_AMD_LIB")
-    if env:
-        return env
+    # the HIP engine, built in-tree; nothing else (the reference-backed test shim is bound by
+    # tests/refbackend/gtn_ref.py, test infrastructure, by passing its path to load())
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libgtn_amd.so")
 
 
@@ -171,7 +170,7 @@ def load(path=None):
             fn = getattr(lib, name)
         except AttributeError:
             # engine extensions (batch records, borrowed tensors): absent from the reference-backed
-            # test shim (oracle/ref_shim.cpp), which only the CPU tests load through GTN_AMD_LIB
+            # test shim (oracle/ref_shim.cpp), which only tests/refbackend/gtn_ref.py loads
             if name.startswith("gtnx_batch_") or name in ("gtnx_linear_graph_borrow_n", "gtnx_grads_bind_device_n",
                                                              "gtnx_parallel_enter", "gtnx_parallel_leave", "gtnx_parallel_flush"):
                 continue

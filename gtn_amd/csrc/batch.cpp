@@ -487,6 +487,7 @@ BatchP batch_ctc_targets_from_graphs(const std::vector<Graph>& gs) {
   if (b->kind != Batch::CTC_TARGETS) return nullptr;  // (labels the records cannot hold: the per-graph way)
   b->graphs = gs;
   b->leaf = true;
+  for (auto& g : gs) g.s->leaf_batch = b;
   return b;
 }
 
@@ -535,6 +536,21 @@ BatchP batch_linear_from_graphs(const std::vector<Graph>& gs) {
   }
   b->graphs = gs;
   b->leaf = true;
+  for (auto& g : gs) {
+    g.w->leaf_batch = b;
+    g.w->leaf_version = g.w->version;
+  }
+  // gtnx_grads_bind_device_n on the graphs: their first gradients go straight to the caller's tensor when
+  // that is one block in element order
+  if (cg && gs[0].g->grad_dest && !gs[0].is_grad_available()) {
+    bool block = true;
+    for (int i = 0; i < n && block; ++i)
+      block = gs[size_t(i)].g->grad_dest == gs[0].g->grad_dest + size_t(i) * A && !gs[size_t(i)].is_grad_available();
+    if (block) {
+      b->dest_mem = gs[0].g->grad_dest_mem;
+      b->dest = gs[0].g->grad_dest;
+    }
+  }
   return b;
 }
 

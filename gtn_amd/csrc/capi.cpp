@@ -1,7 +1,9 @@
 // capi.cpp -- the extern "C" boundary declared in include/gtn_amd.h.
 // Thin: argument checks, handle <-> Graph, exception -> status mapping.
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -144,10 +146,29 @@ GTNX_API gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
 }
 GTNX_API gtnx_status_t gtnx_reclaim(void) {
   return guard([&] {
-    // (a few entries per lock round: several threads of a parallelMap pool share the list)
-    if (Runtime::initialized())
-      while (Runtime::get().drain_some(8)) {
+    // A FEW threads at a time (GTNX_RECLAIMERS, default 2): the pool threads of a parallelMap all offer to reclaim
+    // when their job is done (include/gtn/parallel.h), and what they would free was largely allocated by the
+    // caller's thread -- a crowd of them only queues on that allocator arena's lock and slows the caller down
+    // (1.4 us per malloc measured with 32 reclaimers); the others go back to sleep.
+    static const int max_reclaimers = [] {
+      const char* e = std::getenv("GTNX_RECLAIMERS");
+      const int v = e ? std::atoi(e) : 2;
+      return v > 0 ? v : 1;
+    }();
+    static std::atomic<int> active{0};
+    if (!Runtime::initialized()) return;
+    if (active.fetch_add(1, std::memory_order_acquire) >= max_reclaimers) {
+      active.fetch_sub(1, std::memory_order_release);
+      return;
+    }
+    try {
+      while (Runtime::get().drain_some(16)) {
       }
+    } catch (...) {
+      active.fetch_sub(1, std::memory_order_release);
+      throw;
+    }
+    active.fetch_sub(1, std::memory_order_release);
   });
 }
 GTNX_API gtnx_status_t gtnx_empty_cache(void) {
@@ -577,6 +598,10 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
   }                                                                         \
   GTNX_API gtnx_status_t name##_n(const gtnx_graph_t* g, int n, gtnx_graph_t* out) { \
     return guard([&] {                                                      \
+      if (n >= 2) {                                                         \
+        run_vector(ROP, g, n, nullptr, 0, out);                             \
+        return;                                                             \
+      }                                                                     \
       auto v = vec(g, n, LAZY_OK);                                          \
       auto r = expr;                                                        \
       put(r, out);                                                          \
@@ -597,6 +622,10 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
   GTNX_API gtnx_status_t name##_n(const gtnx_graph_t* a, int na, const gtnx_graph_t* b, \
                                   int nb, gtnx_graph_t* out) {                          \
     return guard([&] {                                                                  \
+      if (na >= 2 || nb >= 2) {                                                         \
+        run_vector(ROP, a, na, b, nb, out);                                             \
+        return;                                                                         \
+      }                                                                                 \
       auto va = vec(a, na);                                                             \
       auto vb = vec(b, nb);                                                             \
       auto r = expr;                                                                    \
@@ -606,6 +635,17 @@ GTNX_API gtnx_status_t gtnx_linear_graph_borrow_n(int B, int M, int N, int cg, c
 
 namespace {
 std::vector<Graph> g_empty;
+// a vector form with more than one element: through the machinery of the parallelMap regions, joined at once
+// (region.h: region_run_vector) -- results over one batch record where the elements allow it
+void run_vector(RegionOp op, const gtnx_graph_t* a, int na, const gtnx_graph_t* b, int nb, gtnx_graph_t* out) {
+  std::vector<Graph*> pa(static_cast<size_t>(na > 0 ? na : 0)), pb(static_cast<size_t>(b && nb > 0 ? nb : 0));
+  for (int i = 0; i < na; ++i) pa[size_t(i)] = &RAW(a[i]);
+  for (size_t i = 0; i < pb.size(); ++i) pb[i] = &RAW(b[i]);
+  const int n = b ? std::max(na, nb) : na;
+  std::vector<Graph> res(static_cast<size_t>(n), Graph(Graph::Empty{}));
+  region_run_vector(op, pa.data(), na, b ? pb.data() : nullptr, nb, res.data());
+  for (int i = 0; i < n; ++i) out[i] = H(std::move(res[size_t(i)]));
+}
 }
 UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false, RO_NEG)
 BINARY_FN(gtnx_add, op_scalar(SK_ADD, va, vb), RO_ADD)
@@ -618,12 +658,23 @@ UNARY_FN(gtnx_viterbi_path, op_viterbi_path(v), true, RO_VP)
 
 GTNX_API gtnx_status_t gtnx_items_n(const gtnx_graph_t* g, int n, float* out) {
   return guard([&] {
+    // results of a vector form / a parallelMap region held as batch-record scalars: read from the record (one
+    // device->host copy per record, cached), no graph is built for them
+    bool all = n > 0;
+    for (int i = 0; i < n && all; ++i) {
+      Graph& raw = RAW(g[i]);
+      all = raw.s->pending && region_item(raw, out + i);
+    }
+    if (all) return;
     auto v = vec(g, n);
     items_host(v, out);
   });
 }
 GTNX_API gtnx_status_t gtnx_items_device_n(const gtnx_graph_t* g, int n, void* out) {
   return guard([&] {
+    std::vector<Graph*> hs(static_cast<size_t>(n > 0 ? n : 0));
+    for (int i = 0; i < n; ++i) hs[size_t(i)] = &RAW(g[i]);
+    if (region_items_device(hs.data(), n, out)) return;
     auto v = vec(g, n);
     items_device(v, out);
   });
@@ -758,6 +809,12 @@ GTNX_API gtnx_status_t gtnx_backward_with_grad(gtnx_graph_t g, gtnx_graph_t grad
 }
 GTNX_API gtnx_status_t gtnx_backward_n(const gtnx_graph_t* g, int n, int retain) {
   return guard([&] {
+    if (n >= 2) {
+      std::vector<Graph*> roots(static_cast<size_t>(n));
+      for (int i = 0; i < n; ++i) roots[size_t(i)] = &RAW(g[i]);
+      region_run_backward_vector(roots.data(), n, retain != 0);
+      return;
+    }
     auto v = vec(g, n);
     op_backward(v, nullptr, retain != 0);
   });

@@ -34,6 +34,7 @@ void Structure::touch() {
   dense[0].reset();
   dense[1].reset();
   ctc_labels.reset();
+  leaf_batch.reset();
   ctc_checked = false;
   ilabel_sorted = olabel_sorted = false;  // graph.cpp:42-43, 64-65
 }

@@ -63,6 +63,7 @@ struct Structure {
   // The graph is exactly the CTC target acceptor of benchmarks/ctc.cpp:40-58 over these labels (checked at
   // arcSort, O(A)): a batch of such graphs takes the device-built band records (batch.cpp: CTC_TARGETS)
   std::shared_ptr<std::vector<int>> ctc_labels;
+  std::weak_ptr<struct Batch> leaf_batch;  // the CTC_TARGETS record this graph is an element of (as Weights::leaf_batch)
   int ctc_blank = 0;
   bool ctc_checked = false;  // detect_ctc_shape ran on the current arcs
   int kind = KIND_EXPLICIT;
@@ -165,6 +166,10 @@ struct Weights {
   std::shared_ptr<StagedWeights> staged;  // set: neither copy is valid yet (see StagedWeights)
   // queued calls of a parallelMap region that will read these weights (region.cpp): a mutation flushes them first
   std::atomic<int> pending_uses{0};
+  // the LINEAR batch record these weights are an element of (batch.cpp: batch_linear_from_graphs), at `leaf_version`:
+  // a later call over the same graphs finds the record -- and what a sweep left behind in it -- again
+  std::weak_ptr<struct Batch> leaf_batch;
+  uint64_t leaf_version = 0;
   bool host_escaped = false;  // a mutable host pointer was handed out (Graph::weights())
   uint64_t version = 0;       // bumped on every mutation
   uint64_t zero_version = ~uint64_t(0);  // version all_zero was taken at

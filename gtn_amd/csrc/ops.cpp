@@ -194,6 +194,7 @@ Graph make_linear_graph(int M, int N, bool calc_grad) {
 }
 
 std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad, const void* dev, bool borrow) {
+  GTNX_HOST_T("linear_graphs_device.total");
   Runtime& rt = Runtime::get();
   std::vector<Graph> out;
   out.reserve(B);
@@ -206,6 +207,7 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
     arena->borrowed = true;
   } else {
     arena = rt.alloc(sizeof(float) * size_t(A) * size_t(B > 0 ? B : 1));
+    GTNX_HOST_T("linear_graphs_device.d2d");
     if (dev && A && B) rt.d2d(arena->ptr, dev, sizeof(float) * size_t(A) * size_t(B));
   }
   for (int b = 0; b < B; ++b) {

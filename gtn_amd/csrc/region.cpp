@@ -27,6 +27,7 @@ thread_local int t_exec = 0;   // > 0: this thread is running queued calls (its 
 thread_local std::vector<std::shared_ptr<Pending>> t_queue;
 thread_local std::vector<std::shared_ptr<Weights>> t_stage;
 thread_local std::vector<Graph*> t_trash;
+thread_local bool t_vector_call = false;  // recording the calls of a gtnx_*_n vector form (region_run_vector)
 thread_local std::shared_ptr<StageArena> t_arena;
 
 struct Shared {
@@ -266,6 +267,11 @@ struct Run {
       if (s0.kind == KIND_LINEAR && !s0.lazy) {
         auto it = linear_of.find(gs[0].w.get());
         if (it != linear_of.end() && same_leaves(*it->second, gs)) return it->second;
+        if (BatchP old = gs[0].w->leaf_batch.lock())  // made by an earlier call over the same graphs, unchanged since
+          if (old->kind == Batch::LINEAR && same_leaves(*old, gs)) {
+            linear_of[gs[0].w.get()] = old;
+            return old;
+          }
         if (BatchP b = batch_linear_from_graphs(gs)) {
           linear_of[gs[0].w.get()] = b;
           return b;
@@ -273,6 +279,11 @@ struct Run {
       } else if (want_targets && s0.kind == KIND_EXPLICIT && s0.host_valid && !s0.lazy && s0.N <= band_max_nodes()) {
         auto it = targets_of.find(gs[0].s.get());
         if (it != targets_of.end() && same_leaves(*it->second, gs)) return it->second;
+        if (BatchP old = gs[0].s->leaf_batch.lock())
+          if (old->kind == Batch::CTC_TARGETS && same_leaves(*old, gs)) {
+            targets_of[gs[0].s.get()] = old;
+            return old;
+          }
         if (BatchP b = batch_ctc_targets_from_graphs(gs)) {
           targets_of[gs[0].s.get()] = b;
           return b;
@@ -283,16 +294,22 @@ struct Run {
   }
 
   static bool same_leaves(const Batch& b, const std::vector<Graph>& gs) {
-    if (size_t(b.n) != gs.size()) return false;
-    for (size_t i = 0; i < gs.size(); ++i)
+    if (size_t(b.n) != gs.size() || b.graphs.size() != gs.size()) return false;
+    for (size_t i = 0; i < gs.size(); ++i) {
       if (b.graphs[i].s != gs[i].s || b.graphs[i].w != gs[i].w || b.graphs[i].g != gs[i].g) return false;
+      if (gs[i].calc_grad() != b.calc_grad) return false;
+      // (a LINEAR record holds the weights' values: they must not have changed since; a target record holds
+      //  labels only -- touch() forgets it when the structure changes -- and needs all-zero weights)
+      if (b.kind == Batch::LINEAR && gs[i].w->leaf_version != gs[i].w->version) return false;
+      if (b.kind == Batch::CTC_TARGETS && !gs[i].w->is_all_zero()) return false;
+    }
     return true;
   }
 
   static bool binary(RegionOp op) { return op == RO_ADD || op == RO_SUB || op == RO_COMPOSE || op == RO_INTERSECT; }
 
   // the batch function of a group over whole records
-  BatchP apply(RegionOp op, const BatchP& a, const BatchP& b) {
+  BatchP apply(RegionOp op, const BatchP& a, const BatchP& b, int mode) {
     switch (op) {
       case RO_NEG: return batch_scalar(SK_NEGATE, a, nullptr);
       case RO_ADD: return batch_scalar(SK_ADD, a, b);
@@ -303,11 +320,9 @@ struct Run {
         // apply (gtnx_compose_mode 2; looking inside one still builds it)
         struct Mode {
           int old;
-          Mode() : old(compose_mode_hint(2)) {
-            if (old == 1) compose_mode_hint(1);
-          }
+          explicit Mode(int m) : old(compose_mode_hint(m)) {}
           ~Mode() { compose_mode_hint(old); }
-        } mode;
+        } scope(mode);
         return batch_compose(a, b, op == RO_INTERSECT);
       }
       case RO_FS: return batch_shortest_distance(a, false);
@@ -346,9 +361,19 @@ struct Run {
         return;
       }
       std::vector<int> pa, pb;
-      BatchP A = as_batch(la, pa, op == RO_COMPOSE || op == RO_INTERSECT), B;
+      // compose / intersect: the mode the calls were made under (a parallelMap region: symbolic where the sweep
+      // kernels apply); target records (always symbolic) only when the mode allows symbolic results
+      int mode = 0;
+      const bool comp = op == RO_COMPOSE || op == RO_INTERSECT;
+      if (comp) {
+        mode = live[0]->mode < 0 ? 2 : live[0]->mode;
+        const char* env = std::getenv("GTNX_LAZY_COMPOSE");  // (the process-wide override, read per call: ops.cpp)
+        if (env && env[0] >= '0' && env[0] <= '2') mode = env[0] - '0';
+      }
+      const bool records = comp && mode >= 1 && !std::getenv("GTNX_NO_BAND");
+      BatchP A = as_batch(la, pa, records), B;
       if (binary(op)) {
-        B = as_batch(lb, pb, op == RO_COMPOSE || op == RO_INTERSECT);
+        B = as_batch(lb, pb, records);
         if (pa != pb) {  // the two sides are elements of records in different orders: line them up as graphs
           std::vector<Graph> ga, gb;
           for (auto& v : la) ga.push_back(graph_of(v));
@@ -358,7 +383,7 @@ struct Run {
           for (size_t k = 0; k < pa.size(); ++k) pa[k] = int(k);
         }
       }
-      BatchP R = apply(op, A, B);
+      BatchP R = apply(op, A, B, mode);
       GTNX_HOST_T("region.run_calls.results");
       for (size_t k = 0; k < live.size(); ++k) set_result(*live[k], R, pa[k]);
     } catch (...) {
@@ -428,7 +453,7 @@ struct Run {
       Pending& p = *sp;
       if (p.state.load(std::memory_order_acquire) != 0) continue;  // ran already (somebody looked at it)
       const bool bwd = p.op == RO_BWD || p.op == RO_BWD_RETAIN;
-      const uint64_t key = (uint64_t(bwd ? 0xffffff : uint32_t(p.depth)) << 8) | uint64_t(p.op);
+      const uint64_t key = (uint64_t(bwd ? 0xffffff : uint32_t(p.depth)) << 16) | (uint64_t(uint8_t(p.mode)) << 8) | uint64_t(p.op);
       auto it = index.find(key);
       if (it == index.end()) {
         it = index.emplace(key, int(groups.size())).first;
@@ -601,8 +626,14 @@ struct PlaceholderStructure : Structure {
 };
 }  // namespace
 
-Graph region_record(RegionOp op, const Graph& a, const Graph* b) {
-  auto ps = std::make_shared<PlaceholderStructure>();
+namespace {
+using PlaceholderSlab = std::vector<PlaceholderStructure>;
+
+// the structure + call of one placeholder: its own allocation, or element i of a slab made for a whole vector form
+// (one allocation and one release for its n results)
+Graph record_into(const std::shared_ptr<PlaceholderSlab>& slab, size_t i, RegionOp op, const Graph& a, const Graph* b) {
+  std::shared_ptr<PlaceholderStructure> ps =
+      slab ? std::shared_ptr<PlaceholderStructure>(slab, &(*slab)[i]) : std::make_shared<PlaceholderStructure>();
   std::shared_ptr<Pending> p(ps, &ps->call);
   p->op = op;
   p->a = a;
@@ -619,11 +650,64 @@ Graph region_record(RegionOp op, const Graph& a, const Graph* b) {
   look(a);
   if (b) look(*b);
   p->depth = d + 1;
+  if (op == RO_COMPOSE || op == RO_INTERSECT) {
+    const int hint = compose_mode_hint(0);
+    compose_mode_hint(hint);
+    p->mode = t_vector_call ? int8_t(hint) : int8_t(hint == 1 ? 1 : -1);
+  }
   t_queue.push_back(p);
   Graph ph{Graph::Empty{}};
   ps->pending = &ps->call;
   ph.s = std::move(ps);
   return ph;
+}
+}  // namespace
+
+Graph region_record(RegionOp op, const Graph& a, const Graph* b) { return record_into(nullptr, 0, op, a, b); }
+
+namespace {
+// the calls of one vector form: recorded on this thread's queue (whatever was there before stays in front of
+// them, in order) and joined at once
+struct VectorCall {
+  int depth0;
+  bool exec0;
+  VectorCall() : depth0(t_depth), exec0(t_vector_call) {
+    ++t_depth;  // (record even when the thread is not inside a parallelMap region)
+    t_vector_call = true;
+  }
+  ~VectorCall() {
+    t_vector_call = exec0;
+    t_depth = depth0;
+  }
+};
+void join_now() {
+  std::vector<std::shared_ptr<Pending>> q;
+  std::vector<std::shared_ptr<Weights>> st;
+  q.swap(t_queue);
+  st.swap(t_stage);
+  std::exception_ptr err = execute(q, st);
+  if (err) std::rethrow_exception(err);
+}
+}  // namespace
+
+void region_run_vector(RegionOp op, Graph* const* a, int na, Graph* const* b, int nb, Graph* out) {
+  const int n = b ? std::max(na, nb) : na;
+  if ((na != n && na != 1) || (b && nb != n && nb != 1))  // parallel_map.h:85-88
+    throw_runtime("parallelMap getIdxOrBroadcast got invalid size or unbroadcastable vector");
+  {
+    VectorCall scope;
+    auto slab = std::make_shared<PlaceholderSlab>(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) out[i] = record_into(slab, size_t(i), op, *a[na == 1 ? 0 : i], b ? b[nb == 1 ? 0 : i] : nullptr);
+  }
+  join_now();
+}
+
+void region_run_backward_vector(Graph* const* roots, int n, bool retain) {
+  {
+    VectorCall scope;
+    for (int i = 0; i < n; ++i) region_record_backward(*roots[i], retain);
+  }
+  join_now();
 }
 
 void region_record_backward(const Graph& root, bool retain) {
@@ -677,6 +761,36 @@ bool region_item(Graph& ph, float* out) {
   if (!x || x->kind != Batch::SCALAR || x->materialised) return false;
   std::lock_guard<std::recursive_mutex> lk(shared().exec);
   *out = batch_item_host(x, p->idx);
+  return true;
+}
+
+bool region_items_device(Graph* const* hs, int n, void* dev_out) {
+  if (n <= 0) return true;
+  bool any = false;
+  for (int i = 0; i < n && !any; ++i) any = is_placeholder(*hs[i]);
+  if (!any) return false;
+  std::vector<const float*> ptrs(static_cast<size_t>(n));
+  Batch* first = nullptr;
+  bool dense = true;  // element i of one record at position i: a plain copy
+  for (int i = 0; i < n; ++i) {
+    Graph& h = *hs[i];
+    if (!is_placeholder(h)) return false;
+    std::shared_ptr<Pending> p(h.s, h.s->pending);
+    force(p);
+    if (p->has_res.load(std::memory_order_acquire)) return false;
+    Batch* x = p->batch.get();
+    if (!x || x->kind != Batch::SCALAR || x->materialised) return false;
+    ptrs[size_t(i)] = x->v_dev + p->idx;
+    if (i == 0) first = x;
+    dense = dense && x == first && p->idx == i;
+  }
+  Runtime& rt = Runtime::get();
+  if (dense) {
+    rt.d2d(dev_out, first->v_dev, sizeof(float) * size_t(n));
+    return true;
+  }
+  DevMemP dp = upload_vec(ptrs);
+  launch_gather_scalars(dp->as<const float*>(), static_cast<float*>(dev_out), n, rt.stream());
   return true;
 }
 

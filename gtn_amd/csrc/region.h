@@ -50,6 +50,8 @@ struct Pending {
   BatchP batch;
   int idx = -1;
   int group = -1;             // scratch of one run
+  int8_t mode = -1;           // compose / intersect: the compose mode to run under (-1: a parallelMap region's default,
+                              // symbolic where the sweep kernels apply)
 };
 
 bool region_active();  // the calling thread is inside a region (and not running queued calls itself)
@@ -58,9 +60,19 @@ void region_leave();   // hands the thread's queue to the region
 void region_flush();   // the join: runs everything handed in (and the caller's own queue); throws the first error
 
 Graph region_record(RegionOp op, const Graph& a, const Graph* b);  // -> placeholder
+// The vector forms of the C ABI (gtnx_*_n, n >= 2) run through the same machinery AT ONCE: the n calls are
+// recorded and joined on the spot, so a vector of CTC-shaped targets and linear emission graphs takes the batch
+// records too and the n results are placeholders over one record instead of n graphs.  `na` / `nb` of 1 broadcast
+// (parallel_map.h:77-89).  compose / intersect keep the calling thread's compose mode (gtnx_compose_mode).
+void region_run_vector(RegionOp op, Graph* const* a, int na, Graph* const* b, int nb, Graph* out /* max(na, nb) */);
+void region_run_backward_vector(Graph* const* roots, int n, bool retain);
 void region_record_backward(const Graph& root, bool retain);
 Graph& region_value(Graph& placeholder);        // the graph behind a placeholder handle (runs what it needs)
 bool region_item(Graph& placeholder, float* out);  // item() of a batch-record scalar without building its graph
+// item() of n graphs, some of which may be placeholders over batch-record scalars (no graph is built for those):
+// gathered to `dev_out` (n floats, device) with one launch.  false: not applicable (an input is not a one-arc graph
+// resident as a scalar) -- the caller takes the ordinary path.
+bool region_items_device(Graph* const* hs, int n, void* dev_out);
 void region_before_mutation(Graph& g);          // runs queued calls that still read g
 void region_sync_thread();                      // runs the calling thread's queue (gradient accessors)
 // setWeights inside a region: host source copied to pinned staging now, device source read at the join

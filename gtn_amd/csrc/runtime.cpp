@@ -161,6 +161,7 @@ DevMemP Runtime::alloc(size_t bytes) {
     }
   }
   if (!p) {
+    GTNX_HOST_T("runtime.alloc.hipMalloc (pool miss)");
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
       (void)hipGetLastError();
@@ -218,7 +219,10 @@ PinnedMemP Runtime::alloc_pinned(size_t bytes) {
       free_pinned_.erase(it);
     }
   }
-  if (!p) HIP_CHECK(hipHostMalloc(&p, sz, hipHostMallocDefault));
+  if (!p) {
+    GTNX_HOST_T("runtime.alloc_pinned.hipHostMalloc (pool miss)");
+    HIP_CHECK(hipHostMalloc(&p, sz, hipHostMallocDefault));
+  }
   auto m = std::make_shared<PinnedMem>();
   m->ptr = p;
   m->bytes = sz;

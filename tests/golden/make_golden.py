@@ -20,9 +20,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["GTN_AMD_LIB"] = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
+sys.path.insert(0, os.path.join(ROOT, "tests", "refbackend"))
 
-import gtn_amd as ref  # noqa: E402  (bound to the reference shim via GTN_AMD_LIB)
+import gtn_ref as ref  # noqa: E402  (the Python mirror bound to the reference shim: tests/refbackend/gtn_ref.py)
 import graphgen as gg  # noqa: E402
 
 assert ref.backend() == "reference-cpu"

@@ -24,7 +24,7 @@ ALL = ["graph_test", "functions_test", "autograd_test", "creations_test", "crite
        "rand_test", "utils_test"]
 
 
-@pytest.mark.parametrize("name", ALL + ["adjacency_refs_test"])
+@pytest.mark.parametrize("name", ALL + ["adjacency_refs_test", "region_test", "gather_test"])
 def test_headers_and_abi_over_the_unmodified_reference(name, tmp_path):
     """The boundary itself, without the engine: the same eight binaries (reference test sources compiled
     against include/gtn) with oracle/_ref/libgtn_ref.so -- the UNMODIFIED reference behind the C ABI of

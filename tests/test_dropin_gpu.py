@@ -18,7 +18,8 @@ PROGRAMS = [
     "parallel_test",
     "rand_test",
     "utils_test",
-    "gather_test",  # own program (tests/native/gather_test.cpp): calls gathered from parallelMap threads
+    "gather_test",  # own program (tests/native/gather_test.cpp): the calls of parallelMap threads vs one at a time
+    "region_test",  # own program (tests/native/region_test.cpp): deferred calls behave like immediate ones
     "adjacency_refs_test",  # own program: references into out(n) / in(n) / start() / accept() stay valid across calls
 ]
 

@@ -1,7 +1,7 @@
 """The Python side of the drop-in, on the CPU-only host: the reference's OWN Python binding tests
 (bindings/python/test/test_*.py, 47 tests: graph construction, weights, formats, functions incl. the
 rational ops, autograd, criteria, parallel forms) run UNMODIFIED with `import gtn` resolving to this
-repo's `gtn_amd` package, bound to oracle/_ref/libgtn_ref.so -- the unmodified reference behind the C ABI
+repo's Python mirror (gtn_amd/api.py) bound by tests/refbackend/gtn_ref.py to oracle/_ref/libgtn_ref.so -- the unmodified reference behind the C ABI
 of include/gtn_amd.h.  What this pins is the Python mirror (gtn_amd/api.py + gtn_amd/hostops): same names,
 overloads, keyword arguments, broadcasting and exception types as the pybind11 binding.  Needs
 /root/reference (test sources are read where they lie) -- skipped elsewhere."""
@@ -23,9 +23,9 @@ def test_reference_python_binding_tests_run_on_the_mirror(tmp_path):
     pkg = tmp_path / "gtn"
     pkg.mkdir()
     (pkg / "__init__.py").write_text(
-        "import gtn_amd as _g\n"
+        "import gtn_ref as _g\n"
         "globals().update({k: getattr(_g, k) for k in dir(_g) if not k.startswith('__')})\n")
-    env = dict(os.environ, GTN_AMD_LIB=ref_lib, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(ROOT, "tests", "refbackend"), ROOT]))
     r = subprocess.run([sys.executable, "-m", "unittest", "discover", "-s", REF_TESTS], capture_output=True, text=True,
                        timeout=600, env=env, cwd=str(tmp_path))
     tail = (r.stdout + r.stderr)[-3000:]
@@ -45,9 +45,9 @@ def test_reference_python_examples_run_on_the_mirror(script, expect, tmp_path):
     pkg = tmp_path / "gtn"
     pkg.mkdir()
     (pkg / "__init__.py").write_text(
-        "import gtn_amd as _g\n"
+        "import gtn_ref as _g\n"
         "globals().update({k: getattr(_g, k) for k in dir(_g) if not k.startswith('__')})\n")
-    env = dict(os.environ, GTN_AMD_LIB=ref_lib, PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT]))
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(tmp_path), os.path.join(ROOT, "tests", "refbackend"), ROOT]))
     r = subprocess.run([sys.executable, src], capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert expect in r.stdout, r.stdout[-2000:]

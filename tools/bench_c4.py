@@ -191,7 +191,8 @@ def cpu_baseline(C):
         code = (
             "import os, sys, time, numpy as np\n"
             "sys.path.insert(0, %r)\n"
-            "import gtn_amd as gtn\n"
+            "sys.path.insert(0, os.path.join(%r, 'tests', 'refbackend'))\n"
+            "import gtn_ref as gtn\n"
             "C, T = %d, 20\n"
             "rng = np.random.default_rng(0)\n"
             "g = gtn.Graph(); n = np.arange(C)\n"
@@ -202,8 +203,8 @@ def cpu_baseline(C):
             "g.add_arcs(src, dst, lab, lab, rng.random(C * C + C).astype(np.float32))\n"
             "e = gtn.linear_graph(T, C); e.set_weights((rng.random(T * C) * 10 - 5).astype(np.float32).tolist())\n"
             "t0 = time.perf_counter(); f = gtn.forward_score(gtn.compose(e, g)); gtn.backward(f); dt = time.perf_counter() - t0\n"
-            "print(dt)\n" % (ROOT, C))
-        env = dict(os.environ, GTN_AMD_LIB=path)
+            "print(dt)\n" % (ROOT, ROOT, C))
+        env = dict(os.environ)
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
         dt = float(r.stdout.strip().splitlines()[-1])
         arcs = C * C * 19 + C

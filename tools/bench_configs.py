@@ -1,0 +1,158 @@
+"""BASELINE.json configs C1 and C2 on one MI355X, one JSON line each (bench.py embeds them as `configs`):
+
+  c1  benchmarks/ctc.cpp with batch = 1: T = 100, alphabet 28, U = 20 -- one utterance through the per-graph
+      functions (reference names, bench_native/ctc_step.cpp: gtn_bench_single_utterance): latency per loss
+  c2  forwardScore on 256 linear-chain emission graphs (T = 150, C = 32), one batched launch
+
+Each line carries `value` (losses/s resp. graphs/s), `ms`, a `roofline` for the dominant kernel family (bytes
+from the engine's own accounting, hipEvent time) and a `cpu_baseline`: the UNMODIFIED reference
+(oracle/_ref/libgtn_ref.so through tests/refbackend/gtn_ref.py) doing the same on the host cores.
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+HBM_PEAK_GBS = 8000.0
+
+
+def roofline_of(gtn, steps):
+    prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+    fams = {k: v for k, v in prof.items() if v["launches"] and v["total_ms"] > 0}
+    if not fams:
+        return None, {}
+    dom = max(fams, key=lambda k: fams[k]["total_ms"])
+    e = fams[dom]
+    ms = e["total_ms"] / e["launches"]
+    per = e["algorithmic_bytes"] / e["launches"]
+    gbs = per / (ms * 1e-3) / 1e9 if per > 0 else None
+    roof = {"bound": "hbm", "kernel_family": dom, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (gbs / HBM_PEAK_GBS) if gbs else None, "traffic": None, "traffic_source": None,
+            "ms_per_launch": ms, "algorithmic_bytes_per_launch": per,
+            "note": "latency-bound at this size: a launch moves kilobytes"}
+    return roof, {k: {"ms_per_step": v["total_ms"] / steps, "launches_per_step": v["launches"] / steps} for k, v in fams.items()}
+
+
+def ref_api():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "refbackend"))
+    import gtn_ref
+    return gtn_ref
+
+
+def c1():
+    import torch
+    import gtn_amd as gtn
+    import graphgen as gg
+    T, Cn, U = 100, 28, 20
+    em, tg = gg.ctc_inputs(1234, 1, T, Cn, U)
+    em_dev = torch.from_numpy(em).cuda()
+    tg = np.ascontiguousarray(tg, np.int32)
+    native = C.CDLL(os.path.join(ROOT, "bench_native", "libgtn_bench.so"))
+    native.gtn_bench_single_utterance.restype = C.c_double
+    native.gtn_bench_single_utterance.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p]
+    loss = C.c_float()
+    iters = 300
+    native.gtn_bench_single_utterance(em_dev.data_ptr(), tg.ctypes.data, T, Cn, U, 20, C.byref(loss))
+    gtn.prof_reset()
+    gtn.prof_enable(True)
+    ms = native.gtn_bench_single_utterance(em_dev.data_ptr(), tg.ctypes.data, T, Cn, U, iters, C.byref(loss))
+    gtn.prof_enable(False)
+    if ms < 0:
+        native.gtn_bench_last_error.restype = C.c_char_p
+        raise RuntimeError(native.gtn_bench_last_error().decode())
+    roof, kernels = roofline_of(gtn, iters + 10)
+    out = {"config": "C1: benchmarks/ctc.cpp CPU reference shape, batch=1, T=100, alphabet=28, target_len=20 "
+                     "(ctcGraph, linearGraph + setWeights, intersect, 2 forwardScore, subtract, backward, item)",
+           "metric": "CTC forward+backward losses/sec", "value": 1e3 / ms, "unit": "losses/s", "ms_per_loss": ms,
+           "loss": float(loss.value), "host": "C++ per-graph functions, reference names (bench_native/ctc_step.cpp)",
+           "roofline": roof, "kernels": kernels}
+    # the unmodified reference, one thread (its benchmark's own case): same utterance
+    try:
+        ref = ref_api()
+        g = gg.to_api(ref, gg.ctc_target_graph(tg[0].tolist()))
+        t0 = time.perf_counter()
+        n = 0
+        while n < 50 or time.perf_counter() - t0 < 3.0:
+            e = ref.linear_graph(T, Cn)
+            e.set_weights(em[0].reshape(-1))
+            l = ref.subtract(ref.forward_score(e), ref.forward_score(ref.intersect(g, e)))
+            ref.backward(l)
+            n += 1
+        sec = (time.perf_counter() - t0) / n
+        out["cpu_baseline"] = {"value": 1.0 / sec, "unit": "losses/s", "cores": 1, "kind": "reference", "ms_per_loss": sec * 1e3,
+                               "loss": float(l.item()),
+                               "sample": f"{n} repetitions of the same utterance through the unmodified reference (Python mirror "
+                                         "over oracle/_ref), one host thread; the target graph is built once outside the loop"}
+    except Exception as e:  # a baseline must not cost the line
+        out["cpu_baseline"] = {"error": str(e)[:200]}
+    print(json.dumps(out))
+
+
+def c2():
+    import torch
+    import gtn_amd as gtn
+    B, T, Cn = 256, 150, 32
+    rng = np.random.default_rng(1234)
+    em = (rng.random((B, T, Cn), dtype=np.float32) * 10 - 5).astype(np.float32)
+    em_dev = torch.from_numpy(em).cuda()
+    out_dev = torch.empty(B, dtype=torch.float32, device="cuda")
+
+    def step():
+        ems = gtn.linear_graph_n(B, T, Cn, em_dev)
+        s = gtn.forward_score(ems)
+        gtn.items_to_device(s, out_dev)
+        return s
+
+    for _ in range(10):
+        step()
+    gtn.synchronize()
+    torch.cuda.synchronize()
+    iters = 200
+    gtn.prof_reset()
+    gtn.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    gtn.synchronize()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    gtn.prof_enable(False)
+    roof, kernels = roofline_of(gtn, iters)
+    scores = out_dev.cpu().numpy()
+    # fp64 log-sum-exp per row, summed: the exact answer
+    want = np.logaddexp.reduce(em.astype(np.float64), axis=2).sum(axis=1)
+    out = {"config": "C2: forwardScore on batch=256 linear-chain emission graphs (T=150, C=32), one batched launch "
+                     "(linear_graph_n over one device tensor, forward_score on the list, scores left on the device)",
+           "metric": "forwardScore graphs/sec", "value": B / (ms * 1e-3), "unit": "graphs/s", "ms_per_batch": ms,
+           "max_rel_err_vs_fp64": float(np.max(np.abs(scores - want) / np.abs(want))),
+           "host": "python (gtn_amd/api.py)", "roofline": roof, "kernels": kernels}
+    try:
+        ref = ref_api()
+        gs = []
+        for b in range(B):
+            e = ref.linear_graph(T, Cn)
+            e.set_weights(em[b].reshape(-1))
+            gs.append(e)
+        t0 = time.perf_counter()
+        n = 0
+        while n < 5 or time.perf_counter() - t0 < 3.0:
+            r = ref.forward_score(gs)  # the binding's vector overload: parallelMap over the host cores
+            n += 1
+        sec = (time.perf_counter() - t0) / n
+        out["cpu_baseline"] = {"value": B / sec, "unit": "graphs/s", "cores": os.cpu_count(), "kind": "reference",
+                               "ms_per_batch": sec * 1e3,
+                               "sample": f"{n} repetitions of forward_score over the same 256 graphs through the unmodified "
+                                         "reference's vector overload (parallelMap on all host cores); graphs built once"}
+    except Exception as e:
+        out["cpu_baseline"] = {"error": str(e)[:200]}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    {"c1": c1, "c2": c2}[sys.argv[1]]()

@@ -8,7 +8,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --no-cpu-baseline --no-unmodified-caller"
+BENCH="python $REPO/bench.py --no-cpu-baseline --no-unmodified-caller --no-configs --no-reference-api --no-built-lattice"
 timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 5 --warmup 2 > $OUT/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -s KILL 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- $BENCH --steps 2 --warmup 1 > $OUT/pmc_$c.log 2>&1

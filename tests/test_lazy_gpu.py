@@ -3,6 +3,7 @@ path (itself pinned to the reference/oracle by test_parity_gpu.py) and the oracl
 scores within 1e-4 relative, best-path labels exact, gradients at the tolerance
 test_parity_gpu.py documents."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -804,11 +805,53 @@ def test_dense_regime_at_the_real_alphabet_vs_fp64(gtn, T):
         assert f[b] == pytest.approx(Z, rel=2e-6, abs=1e-4)
         assert np.abs(ge[b] - g_em).max() <= 2e-5
         assert v[b] == pytest.approx(vbest, rel=2e-6, abs=1e-4)
+        # (labels are pinned bit-exact to the unmodified reference at this alphabet in
+        #  test_c4_alphabet_pinned_to_the_reference; against float64 only the path's own weight is checked: the
+        #  float32 optimum may be another path within rounding of the float64 one)
         got_lab = paths[b].labels_to_list()
         assert len(got_lab) == T
-        if got_lab != lab:  # float32 may prefer a path within rounding of the float64 optimum
-            w64 = tw[got_lab[0]] + em[b][0][got_lab[0]] + sum(
-                float(tw[C + got_lab[t] * C + got_lab[t - 1]]) + float(em[b][t][got_lab[t]]) for t in range(1, T))
-            assert w64 == pytest.approx(vbest, abs=1e-3)
+        w64 = tw[got_lab[0]] + em[b][0][got_lab[0]] + sum(
+            float(tw[C + got_lab[t] * C + got_lab[t - 1]]) + float(em[b][t][got_lab[t]]) for t in range(1, T))
+        assert w64 == pytest.approx(vbest, abs=1e-3)
         assert float(paths[b].weights_to_numpy().sum()) == pytest.approx(v[b], rel=1e-5)
     assert np.abs(gt - want_gt).max() <= 1e-4
+
+
+@pytest.mark.parametrize("T", [17, 100])
+def test_c4_alphabet_pinned_to_the_reference(gtn, T):
+    """BASELINE config C4's alphabet (ASG, dense transitions, C = 512) against the UNMODIFIED reference compiled
+    here: tests/golden/asg_c512.npz (tests/golden/make_golden_c4.py over oracle/_ref; 5 M / 26 M product arcs per
+    utterance).  forwardScore / viterbiScore within the north-star's 1e-4 relative, viterbiPath's labels EQUAL,
+    emission gradients and the shared transitions' gradient (summed over the utterances) within the reference's
+    own float32 rounding, max(1e-4, 8 eps |score|) -- every product kept symbolic (matrix-core and max-plus
+    kernels).  Mirrors examples/asg.cpp:59-68 and test/criterion_test.cpp:308-345."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_c4 as mk
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "asg_c512.npz"))
+    key = f"T{T}"
+    B = gold[key + "_forward"].shape[0]
+    C = mk.C
+    em, tw = mk.inputs(T, B, int(gold[key + "_seed"]))
+    assert em.astype(np.float64).sum() + 3.0 * tw.astype(np.float64).sum() == pytest.approx(
+        float(gold[key + "_input_checksum"]), rel=1e-12), "the seeded inputs are not the ones the fixture was made from"
+    trans = mk.transitions(gtn, tw)
+    with lazy_mode("1"):
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        comp = gtn.compose(ems, [trans])
+        fs = gtn.forward_score(comp)
+        vs = gtn.viterbi_score(comp)
+        paths = gtn.viterbi_path(comp)
+        gtn.backward(fs)
+        f, v = gtn.items(fs), gtn.items(vs)
+        ge = np.stack([e.grad().weights_to_numpy().reshape(T, C) for e in ems])
+        gt = trans.grad().weights_to_numpy()
+    np.testing.assert_allclose(f, gold[key + "_forward"], rtol=1e-4)
+    np.testing.assert_allclose(v, gold[key + "_viterbi"], rtol=1e-4)
+    for b in range(B):
+        assert paths[b].labels_to_list() == gold[key + "_labels"][b].tolist(), f"utterance {b}: Viterbi labels differ from the reference's"
+        assert float(paths[b].weights_to_numpy().sum()) == pytest.approx(float(gold[key + "_viterbi"][b]), rel=1e-5)
+    tol = max(1e-4, 8 * np.finfo(np.float32).eps * float(np.abs(gold[key + "_forward"]).max()))
+    np.testing.assert_allclose(ge, gold[key + "_grad_emissions"], rtol=tol, atol=tol)
+    # (an arc of the transitions collects up to B * T posteriors)
+    np.testing.assert_allclose(gt, gold[key + "_grad_transitions"], rtol=tol, atol=tol)

@@ -200,6 +200,7 @@ def sorted_arcs(d):
 
 def test_golden_compose(gtn, golden):
     n_exact = 0
+    differs = []
     for c in golden["compose"]:
         fn = gtn.compose if c["mode"] == "compose" else gtn.intersect
         g1, g2 = gg.to_api(gtn, c["g1"]), gg.to_api(gtn, c["g2"])
@@ -209,6 +210,8 @@ def test_golden_compose(gtn, golden):
         assert sorted_arcs(d) == sorted_arcs(e), c["name"]          # == gtn::equal
         same = (d["src"], d["dst"], d["il"], d["ol"]) == (e["src"], e["dst"], e["il"], e["ol"])
         n_exact += same
+        if not same:
+            differs.append(c["name"])
         if "grad1" in c and same:
             gtn.backward(out)
             assert g1.grad().weights_to_list() == c["grad1"], c["name"]
@@ -224,9 +227,9 @@ def test_golden_compose(gtn, golden):
                 gtn.backward(s)
                 assert close(g1.grad().weights_to_numpy(), c["fgrad1"], RTOL, 1e-6), c["name"]
                 assert close(g2.grad().weights_to_numpy(), c["fgrad2"], RTOL, 1e-6), c["name"]
-    # arc ORDER may differ from the reference only where std::sort's unspecified
-    # order among equal labels shows through
-    assert n_exact >= 0.9 * len(golden["compose"])
+    # node ids, arc ids and arc ORDER are the reference build's in every case (96 cases x each sort state; measured
+    # on the MI355X: no exception, std::sort's freedom among equal labels does not show in these fixtures)
+    assert differs == [], differs
 
 
 def test_golden_ctc(gtn, golden):

@@ -131,6 +131,8 @@ _SIGS = {
     "gtnx_backward_n": [c_graph_p, C.c_int, C.c_int],
     "gtnx_equal": [c_graph, c_graph, c_i32_p],
     "gtnx_isomorphic": [c_graph, c_graph, c_i32_p],
+    "gtnx_remove": [c_graph, C.c_int, C.c_int, c_graph_p],
+    "gtnx_graph_load_buffer": [C.c_void_p, C.c_size_t, c_graph_p],
     "gtnx_parallel_enter": [],
     "gtnx_parallel_leave": [],
     "gtnx_parallel_flush": [],

@@ -719,6 +719,10 @@ GTNX_API gtnx_status_t gtnx_union(const gtnx_graph_t* g, int n, gtnx_graph_t* ou
   });
 }
 
+GTNX_API gtnx_status_t gtnx_remove(gtnx_graph_t g, int ilabel, int olabel, gtnx_graph_t* out) {
+  return guard([&] { *out = H(op_remove(G(g), ilabel, olabel)); });
+}
+
 // ------------------------------------------------------------------ batch records
 namespace {
 inline BatchP& BH(gtnx_batch_t h) {
@@ -742,7 +746,14 @@ GTNX_API gtnx_status_t gtnx_batch_linear(int n, int M, int N, int cg, const void
   return guard([&] { *out = HB(batch_linear(n, M, N, cg != 0, dev, borrow != 0)); });
 }
 GTNX_API gtnx_status_t gtnx_batch_destroy(gtnx_batch_t b) {
-  return guard([&] { delete reinterpret_cast<BatchP*>(b); });
+  return guard([&] {
+    auto* p = reinterpret_cast<BatchP*>(b);
+    if (!p) return;
+    if (Runtime::initialized())  // like gtnx_graph_destroy: taken apart off the caller's critical path
+      Runtime::get().defer_delete(p, [](void* q) { delete static_cast<BatchP*>(q); });
+    else
+      delete p;
+  });
 }
 GTNX_API gtnx_status_t gtnx_batch_size(gtnx_batch_t b, int* out) {
   return guard([&] { *out = BH(b)->n; });
@@ -826,6 +837,14 @@ GTNX_API gtnx_status_t gtnx_equal(gtnx_graph_t a, gtnx_graph_t b, int* out) {
 }
 GTNX_API gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out) {
   return guard([&] { *out = graphs_isomorphic(G(a), G(b)); });
+}
+
+// ------------------------------------------------------------------ formats
+GTNX_API gtnx_status_t gtnx_graph_load_buffer(const void* data, size_t bytes, gtnx_graph_t* out) {
+  return guard([&] {
+    if (!data) throw_invalid("[gtnx_graph_load_buffer] null buffer");
+    *out = H(op_load_buffer(data, bytes));
+  });
 }
 
 // ------------------------------------------------------------------ profiling

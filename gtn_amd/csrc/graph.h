@@ -176,7 +176,10 @@ struct Weights {
   bool all_zero = false;
   bool is_all_zero();         // host-valid weights only; cached per version
   std::shared_ptr<NormCache> norm_cache;
+  // (not while a mutable host pointer is out and the host copy is the live one: writes through it do not bump
+  //  `version` -- the cache is of the last upload, and so may be stale)
   const NormCache* valid_norm_cache() const {
+    if (host_escaped && host_valid) return nullptr;
     return norm_cache && norm_cache->version == version && dev_valid ? norm_cache.get() : nullptr;
   }
   DevMemP dev_mem;

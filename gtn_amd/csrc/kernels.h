@@ -483,6 +483,31 @@ size_t rational_csr_temp_bytes(int N, int A);
 // projection: 0 none, 1 input, 2 output (functions.h Projection); closure != 0: node 0 is the new start / accept node
 void launch_rational_build(const RationalSeg* d_segs, int nseg, int max_A, int max_N, int max_conn, const RationalOut& out,
                            int projection, int closure, void* temp, hipStream_t st);
+void launch_rational_adjacency(const RationalOut& out, void* temp, hipStream_t st);
+// remove (functions.cpp:253-318): kept nodes = start nodes and nodes with an in-arc that does not carry the removed
+// label pair; per kept node the reference's breadth-first walk over the removed arcs (queue order, out-list order),
+// one lane per kept node, in batches of `rows` nodes that share the stamp / queue scratch
+struct RemoveArgs {
+  DGraph g;                 // explicit, adjacency resident
+  int ilabel, olabel;
+  const GTNX_G int* new_id;  // [N] kept node -> its id in the result (exclusive scan of the keep flags)
+  const GTNX_G int* roots;   // [K] result node -> node of g
+  int K, root0, rows;
+  GTNX_G int* stamp;         // [rows][N], zero before the first batch
+  GTNX_G int* queue;         // [rows][N]
+  GTNX_G int* arc_cnt;       // [K] (count pass)
+  const GTNX_G int* arc_off; // [K + 1] (emit pass)
+  RationalOut out;
+};
+void launch_remove_keep(const DGraph& g, int ilabel, int olabel, int* keep, hipStream_t st);
+void launch_remove_roots(const int* keep, const int* new_id, int N, int* roots, hipStream_t st);
+void launch_remove_walk(const RemoveArgs& a, bool emit, hipStream_t st);
+size_t scan_temp_bytes(int n);
+void launch_exclusive_scan(const int* in, int* out, int n, void* temp, size_t temp_bytes, hipStream_t st);
+// the binary graph format's arc table ({src, dst, ilabel, olabel} x A, 16-byte aligned), weights and node flags, all
+// on the device, into a structure's arrays + adjacency (the device side of gtnx_graph_load_buffer)
+void launch_rational_load(const void* rows, const float* w, const uint8_t* flags, const RationalOut& out, void* temp,
+                          hipStream_t st);
 // one CTC target acceptor per label sequence, written as band records on the device (band.hip)
 struct CtcTargetArgs {
   const GTNX_G int* labels;   // [U]

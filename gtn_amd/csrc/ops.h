@@ -71,6 +71,12 @@ std::vector<Graph> op_compose(std::vector<Graph>& a, std::vector<Graph>& b, bool
 // rational operations built on the device (rational.hip): clone / projections, concat, closure, union_
 enum RationalKind { RAT_CLONE = 0, RAT_CONCAT = 1, RAT_CLOSURE = 2, RAT_UNION = 3 };
 Graph op_rational(int kind, std::vector<Graph>& inputs, int projection);
+// remove (functions.cpp:253-318) built on the device (rational.hip): node and arc ids, arc order and the start / accept
+// lists as the reference's breadth-first construction gives them; weights dropped; no gradient
+Graph op_remove(Graph& g, int ilabel, int olabel);
+// a graph in the binary format of utils.cpp:152-225 (the whole file image) built on the device: one staging copy,
+// the arc table split and the adjacency lists built by kernels (rational.hip)
+Graph op_load_buffer(const void* data, size_t bytes);
 void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed = true);
 // throws what op_backward would throw before changing anything (a tape that is gone: autograd.cpp:42-45)
 void backward_validate(Graph& root);

@@ -93,6 +93,80 @@ __global__ void rat_conn_kernel(const RationalSeg* __restrict__ segs, RationalOu
   out.w[o] = 0.0f;
 }
 
+// the arc table of the binary graph format (utils.cpp:152-225: {src, dst, ilabel, olabel} per arc, then the weights)
+// split into the structure's arrays; node flags copied
+__global__ void rat_load_kernel(const gtnx_i4* __restrict__ rows, const float* __restrict__ w, const uint8_t* __restrict__ flags,
+                                RationalOut out) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < out.A; a += stride) {
+    const gtnx_i4 r = rows[a];
+    out.src[a] = r.x;
+    out.dst[a] = r.y;
+    out.il[a] = r.z;
+    out.ol[a] = r.w;
+    out.w[a] = w[a];
+  }
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < out.N; n += stride) out.nflags[n] = flags[n];
+}
+
+// ---- remove (functions.cpp:253-318)
+__global__ void remove_keep_kernel(DGraph g, int ilabel, int olabel, int* keep) {
+  const int stride = gridDim.x * blockDim.x;
+  // (keep[] starts as the start flags: remove_keep_init_kernel)
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < g.A; a += stride)
+    if (!(g.il[a] == ilabel && g.ol[a] == olabel)) keep[g.dst[a]] = 1;
+}
+__global__ void remove_keep_init_kernel(DGraph g, int* keep) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < g.N) keep[n] = (g.nflags[n] & NF_START) ? 1 : 0;
+}
+__global__ void remove_roots_kernel(const int* __restrict__ keep, const int* __restrict__ new_id, int N, int* roots) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N && keep[n]) roots[new_id[n]] = n;
+}
+template <bool EMIT>
+__global__ void remove_walk_kernel(RemoveArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const int k = a.root0 + r;
+  if (r >= a.rows || k >= a.K) return;
+  const DGraph& g = a.g;
+  GTNX_G int* stamp = a.stamp + size_t(r) * g.N;
+  GTNX_G int* queue = a.queue + size_t(r) * g.N;
+  const int tag = k + 1;  // unique per kept node: the rows are reused by later batches without clearing
+  const int n0 = a.roots[k];
+  int head = 0, tail = 0, cnt = 0;
+  bool acc = false;
+  queue[tail++] = n0;
+  stamp[n0] = tag;
+  const int base = EMIT ? a.arc_off[k] : 0;
+  while (head < tail) {
+    const int next = queue[head++];
+    acc = acc || (g.nflags[next] & NF_ACCEPT);
+    for (int j = g.out_off[next]; j < g.out_off[next + 1]; ++j) {
+      const int arc = g.out_list[j];
+      const int dn = g.dst[arc], il = g.il[arc], ol = g.ol[arc];
+      if (il == a.ilabel && ol == a.olabel) {
+        if (stamp[dn] != tag) {
+          stamp[dn] = tag;
+          queue[tail++] = dn;
+        }
+      } else {
+        if (EMIT) {
+          const int o = base + cnt;
+          a.out.src[o] = k;
+          a.out.dst[o] = a.new_id[dn];
+          a.out.il[o] = il;
+          a.out.ol[o] = ol;
+          a.out.w[o] = 0.0f;  // (remove drops the weights: functions.cpp:308)
+        }
+        ++cnt;
+      }
+    }
+  }
+  if (EMIT) a.out.nflags[k] = uint8_t(((g.nflags[n0] & NF_START) ? NF_START : 0) | (acc ? NF_ACCEPT : 0));
+  else a.arc_cnt[k] = cnt;
+}
+
 __global__ void rat_iota_kernel(int* p, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = i;
@@ -141,6 +215,38 @@ int bits_for(int n) {
 
 }  // namespace
 
+void launch_remove_keep(const DGraph& g, int ilabel, int olabel, int* keep, hipStream_t st) {
+  if (g.N > 0) hipLaunchKernelGGL(remove_keep_init_kernel, dim3((g.N + 255) / 256), dim3(256), 0, st, g, keep);
+  if (g.A > 0)
+    hipLaunchKernelGGL(remove_keep_kernel, dim3(std::min((g.A + 255) / 256, 4096)), dim3(256), 0, st, g, ilabel, olabel, keep);
+}
+void launch_remove_roots(const int* keep, const int* new_id, int N, int* roots, hipStream_t st) {
+  if (N > 0) hipLaunchKernelGGL(remove_roots_kernel, dim3((N + 255) / 256), dim3(256), 0, st, keep, new_id, N, roots);
+}
+void launch_remove_walk(const RemoveArgs& a, bool emit, hipStream_t st) {
+  const int n = std::min(a.rows, a.K - a.root0);
+  if (n <= 0) return;
+  if (emit) hipLaunchKernelGGL(remove_walk_kernel<true>, dim3((n + 63) / 64), dim3(64), 0, st, a);
+  else hipLaunchKernelGGL(remove_walk_kernel<false>, dim3((n + 63) / 64), dim3(64), 0, st, a);
+}
+size_t scan_temp_bytes(int n) {
+  size_t b = 0;
+  (void)rocprim::exclusive_scan(nullptr, b, (const int*)nullptr, (int*)nullptr, 0, size_t(n > 0 ? n : 1), rocprim::plus<int>());
+  return b + 256;
+}
+void launch_exclusive_scan(const int* in, int* out, int n, void* temp, size_t temp_bytes, hipStream_t st) {
+  if (n > 0) (void)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0, size_t(n), rocprim::plus<int>(), st);
+}
+
+void launch_rational_load(const void* rows, const float* w, const uint8_t* flags, const RationalOut& out, void* temp,
+                          hipStream_t st) {
+  const int work = std::max(out.A, out.N);
+  if (work > 0)
+    hipLaunchKernelGGL(rat_load_kernel, dim3(std::min((work + 255) / 256, 4096)), dim3(256), 0, st,
+                       static_cast<const gtnx_i4*>(rows), w, flags, out);
+  launch_rational_adjacency(out, temp, st);
+}
+
 size_t rational_csr_temp_bytes(int N, int A) {
   size_t sort_b = 0, scan_b = 0;
   (void)rocprim::radix_sort_pairs(nullptr, sort_b, (const unsigned*)nullptr, (unsigned*)nullptr, (const int*)nullptr,
@@ -159,6 +265,12 @@ void launch_rational_build(const RationalSeg* d_segs, int nseg, int max_A, int m
                      out, closure);
   if (max_conn > 0)
     hipLaunchKernelGGL(rat_conn_kernel, dim3((max_conn + 255) / 256, nseg), dim3(256), 0, st, d_segs, out, closure);
+  launch_rational_adjacency(out, temp, st);
+}
+
+// adjacency lists + ordered start / accept lists of a structure whose arc arrays and node flags are in place
+void launch_rational_adjacency(const RationalOut& out, void* temp, hipStream_t st) {
+  const int N = out.N, A = out.A;
   // ---- adjacency: lists in arc-id order = stable sort of the arc ids by source / destination
   char* t = static_cast<char*>(temp);
   unsigned* keys_out = reinterpret_cast<unsigned*>(t);

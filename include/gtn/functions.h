@@ -100,7 +100,7 @@ inline std::vector<Graph> viterbiPath(const std::vector<Graph>& g) { return deta
 // Rational / structural operations (reference gtn/functions.h:45-123).  clone, the projections,
 // concat, closure and union_ are built by the engine on the device (gtnx_clone / gtnx_concat /
 // gtnx_closure / gtnx_union: rational.hip), node and arc ids as functions.cpp:66-223 numbers them,
-// gradients of the inputs as slices of the output's; remove stays a host-side construction.
+// gradients of the inputs as slices of the output's; remove (gtnx_remove) as well.
 // ---------------------------------------------------------------------------
 enum class Projection { NONE = 0, INPUT = 1, OUTPUT = 2 };
 
@@ -134,47 +134,11 @@ inline Graph union_(const std::vector<Graph>& graphs) {
 }
 
 inline Graph remove(const Graph& g, int ilabel, int olabel) {
-  // functions.cpp:257-318: contract arcs labelled (ilabel:olabel); no gradient
-  auto gradFunc = [](std::vector<Graph>&, Graph&) {
-    throw std::logic_error("[gtn::remove] gradient compuation not implemented");
-  };
-  auto matches = [&](int a) { return g.ilabel(a) == ilabel && g.olabel(a) == olabel; };
-  const int N = static_cast<int>(g.numNodes());
-  std::vector<int> newId(N, -1);
-  Graph out(gradFunc, {g});
-  for (int n = 0; n < N; ++n) {
-    bool keep = g.isStart(n);
-    if (!keep) {
-      const std::vector<int> ins = g.in(n);
-      for (int a : ins) keep = keep || !matches(a);
-    }
-    if (keep) newId[n] = out.addNode(g.isStart(n));
-  }
-  for (int n = 0; n < N; ++n) {
-    const int cur = newId[n];
-    if (cur < 0) continue;
-    // every node reachable from n through removable arcs folds into n
-    std::vector<int> todo{n};
-    std::vector<char> seen(N, 0);
-    seen[n] = 1;
-    for (size_t k = 0; k < todo.size(); ++k) {
-      const int next = todo[k];
-      if (g.isAccept(next)) out.makeAccept(cur);
-      const std::vector<int> outs = g.out(next);
-      for (int a : outs) {
-        const int dn = g.dstNode(a);
-        if (matches(a)) {
-          if (!seen[dn]) {
-            seen[dn] = 1;
-            todo.push_back(dn);
-          }
-        } else {
-          out.addArc(cur, newId[dn], g.ilabel(a), g.olabel(a));
-        }
-      }
-    }
-  }
-  return out;
+  // functions.cpp:257-318: arcs labelled (ilabel:olabel) are contracted; no gradient.  Built by the engine on the
+  // device (gtnx_remove: rational.hip), node and arc ids as the reference's breadth-first construction numbers them.
+  gtnx_graph_t h;
+  detail::check(gtnx_remove(g.handle(), ilabel, olabel, &h));
+  return Graph::fromHandle(h);
 }
 inline Graph remove(const Graph& g, int label = epsilon) { return remove(g, label, label); }
 

@@ -70,12 +70,18 @@ class Graph {
       h_ = n;
       o.aliased_ = aliased_ = true;
       fresh_ = false;
+      std::lock_guard<std::mutex> lk(listMutex_);
+      lists_.clear();  // (of the graph this object referred to before)
     }
     return *this;
   }
   Graph& operator=(Graph&& o) noexcept {
     if (this != &o) {
       reset();
+      {
+        std::lock_guard<std::mutex> lk(listMutex_);
+        lists_.clear();
+      }
       h_ = o.h_;
       fresh_ = o.fresh_;
       aliased_ = o.aliased_;
@@ -235,16 +241,10 @@ class Graph {
   Graph withoutWeights() const { return *this; }
 
   const std::vector<int>& start() const {
-    std::vector<int>& v = listSlot(0, 0);
-    v.resize(numStart());
-    detail::check(gtnx_graph_get_start(h(), v.data()));
-    return v;
+    return fillSlot(0, 0, numStart(), [this](int* p) { return gtnx_graph_get_start(h_, p); });
   }
   const std::vector<int>& accept() const {
-    std::vector<int>& v = listSlot(1, 0);
-    v.resize(numAccept());
-    detail::check(gtnx_graph_get_accept(h(), v.data()));
-    return v;
+    return fillSlot(1, 0, numAccept(), [this](int* p) { return gtnx_graph_get_accept(h_, p); });
   }
   bool isStart(size_t i) const {
     int v;
@@ -263,10 +263,7 @@ class Graph {
     return (size_t)v;
   }
   const std::vector<int>& out(size_t i) const {
-    std::vector<int>& v = listSlot(2, i);
-    v.resize(numOut(i));
-    detail::check(gtnx_graph_get_out(h(), (int)i, v.data()));
-    return v;
+    return fillSlot(2, i, numOut(i), [this, i](int* p) { return gtnx_graph_get_out(h_, (int)i, p); });
   }
   int out(size_t i, size_t j) const { return out(i)[j]; }
   size_t numIn(size_t i) const {
@@ -275,10 +272,7 @@ class Graph {
     return (size_t)v;
   }
   const std::vector<int>& in(size_t i) const {
-    std::vector<int>& v = listSlot(3, i);
-    v.resize(numIn(i));
-    detail::check(gtnx_graph_get_in(h(), (int)i, v.data()));
-    return v;
+    return fillSlot(3, i, numIn(i), [this, i](int* p) { return gtnx_graph_get_in(h_, (int)i, p); });
   }
   size_t in(size_t i, size_t j) const { return (size_t)in(i)[j]; }
 
@@ -398,9 +392,17 @@ class Graph {
   // start() / accept() / out(i) / in(i) hand out references like the reference does (graph.h:293-325 there):
   // one host copy per (list, node), refreshed on every call, so `g.out(n).begin(), g.out(n).end()` and nested
   // loops over different nodes see stable storage.  Slots of one Graph object are not shared with its copies.
-  std::vector<int>& listSlot(int which, size_t node) const {
+  // Looked up, sized AND filled under the lock: two threads reading the same node of one Graph object (a graph
+  // captured by reference in a parallelMap lambda) then write the same values into storage of the same size, and
+  // nobody reads a vector while it is being resized.  (`n` was asked for before the lock: the count functions hand
+  // collected arcs over first, under the same mutex.)
+  template <class Get>
+  const std::vector<int>& fillSlot(int which, size_t node, size_t n, Get&& get) const {
     std::lock_guard<std::mutex> lk(listMutex_);
-    return lists_[(uint64_t(node) << 2) | uint64_t(which)];
+    std::vector<int>& v = lists_[(uint64_t(node) << 2) | uint64_t(which)];
+    if (v.size() != n) v.resize(n);
+    detail::check(get(v.data()));
+    return v;
   }
   mutable std::mutex listMutex_;
   mutable std::unordered_map<uint64_t, std::vector<int>> lists_;

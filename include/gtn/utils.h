@@ -2,6 +2,7 @@
 // equal, isomorphic, load/save (binary), loadTxt/saveTxt, operator<<, draw.
 #pragma once
 
+#include <cstring>
 #include <fstream>
 #include <iostream>  // as utils.h:10-12 of the reference: examples print graphs with std::cout
 #include <istream>
@@ -117,12 +118,15 @@ inline void save(std::ostream& out, const Graph& g) {
   put(head, sizeof(head));
   put(g.start().data(), sizeof(int) * g.start().size());
   put(g.accept().data(), sizeof(int) * g.accept().size());
-  std::vector<int> rows(size_t(4) * g.numArcs());
-  for (size_t a = 0; a < g.numArcs(); ++a) {
-    rows[4 * a] = g.srcNode(a);
-    rows[4 * a + 1] = g.dstNode(a);
-    rows[4 * a + 2] = g.ilabel(a);
-    rows[4 * a + 3] = g.olabel(a);
+  // the arc table in one call (not four accessor calls per arc)
+  const size_t A = g.numArcs();
+  std::vector<int> src(A), dst(A), il(A), ol(A), rows(size_t(4) * A);
+  if (A) detail::check(gtnx_graph_get_arcs(g.handle(), src.data(), dst.data(), il.data(), ol.data()));
+  for (size_t a = 0; a < A; ++a) {
+    rows[4 * a] = src[a];
+    rows[4 * a + 1] = dst[a];
+    rows[4 * a + 2] = il[a];
+    rows[4 * a + 3] = ol[a];
   }
   put(rows.data(), sizeof(int) * rows.size());
   if (g.numArcs()) put(g.weights(), sizeof(float) * g.numArcs());
@@ -132,24 +136,19 @@ inline void save(const std::string& fileName, const Graph& g) {
   save(out, g);
 }
 inline Graph load(std::istream& in) {
-  auto get = [&](void* p, size_t bytes) { in.read(static_cast<char*>(p), (std::streamsize)bytes); };
+  // utils.cpp:185-225.  The file image goes to the engine in one piece (gtnx_graph_load_buffer): the arc table and the
+  // weights are copied to the device once and split into the graph's arrays there -- no call per node or arc.
   int head[4] = {0, 0, 0, 0};
-  get(head, sizeof(head));
-  std::vector<int> start(head[2]), accept(head[3]);
-  get(start.data(), sizeof(int) * start.size());
-  get(accept.data(), sizeof(int) * accept.size());
-  std::vector<uint8_t> isStart(head[0], 0), isAccept(head[0], 0);
-  for (int s : start) isStart.at(s) = 1;
-  for (int a : accept) isAccept.at(a) = 1;
-  Graph g;
-  for (int i = 0; i < head[0]; ++i) g.addNode(isStart[i], isAccept[i]);
-  std::vector<int> rows(size_t(4) * head[1]);
-  get(rows.data(), sizeof(int) * rows.size());
-  for (int a = 0; a < head[1]; ++a) g.addArc(rows[4 * a], rows[4 * a + 1], rows[4 * a + 2], rows[4 * a + 3]);
-  std::vector<float> w(head[1]);
-  get(w.data(), sizeof(float) * w.size());
-  if (head[1]) g.setWeights(w.data());
-  return g;
+  in.read(reinterpret_cast<char*>(head), sizeof(head));
+  if (!in || head[0] < 0 || head[1] < 0 || head[2] < 0 || head[3] < 0) throw std::invalid_argument("[gtn::load] not a graph file");
+  const size_t rest = sizeof(int) * (size_t(head[2]) + size_t(head[3])) + size_t(20) * size_t(head[1]);
+  std::vector<char> image(sizeof(head) + rest);
+  std::memcpy(image.data(), head, sizeof(head));
+  in.read(image.data() + sizeof(head), (std::streamsize)rest);
+  if (size_t(in.gcount()) != rest) throw std::invalid_argument("[gtn::load] truncated graph file");
+  gtnx_graph_t h;
+  detail::check(gtnx_graph_load_buffer(image.data(), image.size(), &h));
+  return Graph::fromHandle(h);
 }
 inline Graph load(std::istream&& in) { return load(in); }
 inline Graph load(const std::string& fileName) {

@@ -222,6 +222,9 @@ gtnx_status_t gtnx_clone(gtnx_graph_t g, int projection /* 0 none, 1 input, 2 ou
 gtnx_status_t gtnx_concat(const gtnx_graph_t* g, int n, gtnx_graph_t* out);                                  /* functions.cpp:97-153 */
 gtnx_status_t gtnx_closure(gtnx_graph_t g, gtnx_graph_t* out);                                               /* functions.cpp:155-189 */
 gtnx_status_t gtnx_union(const gtnx_graph_t* g, int n, gtnx_graph_t* out);                                   /* functions.cpp:191-223 */
+/* remove(g, ilabel, olabel): arcs carrying the label pair are contracted (breadth-first over them from every kept
+ * node, the reference's node / arc order); weights are dropped and backward through the result throws, as there */
+gtnx_status_t gtnx_remove(gtnx_graph_t g, int ilabel, int olabel, gtnx_graph_t* out);                        /* functions.cpp:253-318 */
 
 /* ------------------------------------------------------------------ batch records
  * B graphs held as ONE object: what gtn::parallelMap over the per-graph functions
@@ -274,6 +277,13 @@ gtnx_status_t gtnx_backward_n(const gtnx_graph_t* g, int n, int retain_graph);
  * gtn/utils.h:23-60 (test fixtures of the parity suite; host-side) */
 gtnx_status_t gtnx_equal(gtnx_graph_t a, gtnx_graph_t b, int* out);
 gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out);
+
+/* ------------------------------------------------------------------ formats
+ * gtn/utils.h:115-150, utils.cpp:152-225: the binary graph format -- int32 {numNodes, numArcs, numStart, numAccept},
+ * the start nodes, the accept nodes, {src, dst, ilabel, olabel} per arc, float32 weights.  `data` is the whole
+ * file image: the arc table and the weights go to the device in ONE copy and are split into the graph's SoA
+ * arrays there (adjacency lists built on the device as well); node and arc ids as load() numbers them. */
+gtnx_status_t gtnx_graph_load_buffer(const void* data, size_t bytes, gtnx_graph_t* out);
 
 /* ------------------------------------------------------------------ profiling
  * hipEvent timing of the engine's own kernel launches on the launch stream

@@ -14,6 +14,7 @@
  */
 #include <chrono>
 #include <cstring>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <thread>
@@ -443,6 +444,17 @@ gtnx_status_t gtnx_equal(gtnx_graph_t a, gtnx_graph_t b, int* out) {
 }
 gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out) {
   return guard([&] { *out = gtn::isomorphic(G(a), G(b)); });
+}
+
+gtnx_status_t gtnx_remove(gtnx_graph_t g, int ilabel, int olabel, gtnx_graph_t* out) {
+  return guard([&] { *out = H(gtn::remove(G(g), ilabel, olabel)); });
+}
+/* the reference's own load() (gtn/utils.cpp:185-225) over the file image */
+gtnx_status_t gtnx_graph_load_buffer(const void* data, size_t bytes, gtnx_graph_t* out) {
+  return guard([&] {
+    std::istringstream in(std::string(static_cast<const char*>(data), bytes), std::ios::binary);
+    *out = H(gtn::load(in));
+  });
 }
 
 gtnx_status_t gtnx_prof_enable(int) { return GTNX_OK; }

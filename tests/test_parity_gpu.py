@@ -914,3 +914,40 @@ def test_non_layered_product_is_levelized_on_the_device(gtn, seed):
 
 
 test_non_layered_product_is_levelized_on_the_device.hits = 0
+
+
+def test_rational_ops_retained_backward_twice(gtn):
+    """clone / concat / union_ on a retained tape run twice, a self-concat, and an addGrad on the input afterwards
+    (functions.cpp:66-223): an input's gradient is a COPY of its slice of the deltas (graph.cpp:91-129), never an
+    alias of the output's buffer.  Expected numbers pinned to the reference by tests/test_rational_grads_cpu.py."""
+    import rational_grad_cases as rc
+    got = rc.run(gtn)
+    for name, want in rc.EXPECTED.items():
+        for k, w in enumerate(want):
+            if w is not None:
+                assert got[name][k] == w, (name, k, got[name])
+    assert got["union_then_add_grad"][0] == got["union_then_add_grad"][1]
+
+
+def test_binary_format_loads_straight_into_device_buffers(gtn, tmp_path):
+    """gtn::save / gtn::load (utils.cpp:152-225) on a graph large enough for the device route of
+    gtnx_graph_load_buffer (>= 4096 arcs: arc table and weights copied once, split and indexed by kernels): node
+    and arc ids, labels (epsilon included), weights, start / accept lists and both adjacency orders are those of the
+    graph that was saved, and forwardScore over the loaded graph (device-built structure, never downloaded) agrees."""
+    rng = np.random.default_rng(42)
+    d = gg.random_dag(rng, 1500, avg_deg=4.5, nlabels=7, n_start=3, n_accept=4)
+    for k in range(0, len(d["il"]), 17):  # some epsilon labels
+        d["il"][k] = -1
+    assert len(d["src"]) >= 4096
+    g = gg.to_api(gtn, d)
+    path = str(tmp_path / "big.gtn")
+    gtn.save(path, g)
+    h = gtn.load(path)
+    want_score = gtn.forward_score(g).item()
+    assert gtn.forward_score(h).item() == pytest.approx(want_score, rel=1e-6)   # before anything pulls h to the host
+    e, f = gg.from_api(g), gg.from_api(h)
+    for key in ("start", "accept", "src", "dst", "il", "ol", "w"):
+        assert e[key] == f[key], key
+    for n in (0, 1, 7, 700, 1499):
+        assert g.out(n) == h.out(n) and g.in_(n) == h.in_(n)
+    assert gtn.equal(g, h)

@@ -237,23 +237,21 @@ struct Stage {
   template <bool VEC>
   __device__ __forceinline__ void issue(const GTNX_G float* src, int cnt, int tid) {
     if (cnt <= 0) return;  // uniform
-    if constexpr (VEC) {
+    // Both modes fetch the chunk -- K rows, contiguous in HBM -- with 16-byte loads (global_load_dwordx4 needs
+    // dword alignment only).  VEC: rows are a multiple of 4 floats and the source is 16-byte aligned, so a load
+    // never straddles two rows and lands with one 16-byte LDS store at a precomputed offset.  !VEC (any
+    // alphabet, any alignment): the same loads, landed element by element with the row found per element.
+    // (C = 255 used to take one 4-byte load per element: 2.6x the backward sweep's time at C = 256.)
+    // (cnt >= 4: the band path takes alphabets of at least 4 labels -- band_min_labels())
 #pragma unroll
-      for (int i = 0; i < NS / 4; ++i) {
-        if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
-        const int e = min(4 * (i * LN + tid), cnt - 4);
-        const gtnx_f4 q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
-        v[4 * i] = q.x;
-        v[4 * i + 1] = q.y;
-        v[4 * i + 2] = q.z;
-        v[4 * i + 3] = q.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        if (i > 0 && i * LN >= cnt) break;  // uniform
-        v[i] = src[min(i * LN + tid, cnt - 1)];
-      }
+    for (int i = 0; i < NS / 4; ++i) {
+      if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
+      const int e = min(4 * (i * LN + tid), cnt - 4);
+      const gtnx_f4 q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
+      v[4 * i] = q.x;
+      v[4 * i + 1] = q.y;
+      v[4 * i + 2] = q.z;
+      v[4 * i + 3] = q.w;
     }
   }
   // VEC mode: where slot i of a FULL chunk of K rows lands in a ring block whose rows are `stride`
@@ -284,7 +282,9 @@ struct Stage {
 #pragma unroll
     for (int i = 0; i < NS; ++i) asm volatile("" : "+v"(v[i]));
   }
-  // f(i, e, r, c, q): slot index, element, chunk row, column, values (4 in vec mode, else q.x)
+  // VEC: f(i, e, r, c, q) per 16-byte slot -- slot index, element, chunk row, column, the four values.
+  // !VEC: f(i, e, r, c, {x, 0, 0, 0}) per ELEMENT (a slot may straddle rows; the last slot of a chunk whose size
+  // is not a multiple of 4 was fetched from cnt - 4 and lands there: the overlap rewrites the same values)
   template <bool VEC, class F>
   __device__ __forceinline__ void each(int cnt, int W, int tid, F&& f) const {
     const float invW = 1.0f / float(W);
@@ -300,12 +300,22 @@ struct Stage {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        if (i > 0 && i * LN >= cnt) break;  // uniform
-        const int e = i * LN + tid;
-        if (e < cnt) {
-          const int r = row_of(e, W, invW);
-          f(i, e, r, e - r * W, gtnx_f4{v[i], 0.0f, 0.0f, 0.0f});
+      for (int i = 0; i < NS / 4; ++i) {
+        if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
+        if (4 * (i * LN + tid) < cnt) {
+          const int e = min(4 * (i * LN + tid), cnt - 4);
+          const int r0 = row_of(e, W, invW), c0 = e - r0 * W;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            // (W >= 4: an element is in row r0 or the next one.  No loop in here: anything the compiler cannot
+            //  unroll turns v[] into a runtime-indexed array in scratch memory)
+            int r = r0, col = c0 + k;
+            if (col >= W) {
+              col -= W;
+              ++r;
+            }
+            f(i, e + k, r, col, gtnx_f4{v[4 * i + k], 0.0f, 0.0f, 0.0f});
+          }
         }
       }
     }
@@ -1353,6 +1363,7 @@ constexpr size_t LDS_ONE = 156 * 1024;  // one
 int band_block_rows(int C, int max_NS, bool backward);
 int band_max_nodes() { return 512; }
 int band_max_labels() { return 1024; }
+int band_min_labels() { return 4; }  // a chunk of emission rows is fetched with 16-byte loads (Stage::issue)
 int band_npl(int max_nodes) { return max_nodes <= 256 ? 1 : 2; }
 int band_row_stride(int N, int) { return (N + 3) / 4 * 4; }
 int band_forward_lgrn(int C) { return band_block_rows(C, 0, false) >= 4 ? 2 : 1; }

@@ -686,7 +686,7 @@ BatchP batch_compose(const BatchP& a, const BatchP& b, bool intersect) {
   bool chain_first = false;
   if (native(*a, Batch::CTC_TARGETS) && native(*b, Batch::LINEAR)) fx = a.get(), ch = b.get();
   if (native(*a, Batch::LINEAR) && native(*b, Batch::CTC_TARGETS)) fx = b.get(), ch = a.get(), chain_first = true;
-  if (fx && a->n == b->n && ch->C >= 1 && ch->C <= band_max_labels() && fx->max_label < ch->C && ch->M <= (1 << 20)) {
+  if (fx && a->n == b->n && ch->C >= band_min_labels() && ch->C <= band_max_labels() && fx->max_label < ch->C && ch->M <= (1 << 20)) {
     struct Op : BatchOp {
       void backward(Batch&) override {}  // a symbolic product has no gradient of its own
     };

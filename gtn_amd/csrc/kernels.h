@@ -536,6 +536,7 @@ void launch_asg_fal_scatter(const float* g, const int* maps, const int64_t* tab 
                             float* trans_grad, hipStream_t st);
 int band_max_nodes();
 int band_max_labels();
+int band_min_labels();
 int band_npl(int max_nodes);               // nodes per lane: 1 or 2
 int band_row_stride(int N, int npl);       // NS
 int band_forward_lgrn(int C);

@@ -2395,7 +2395,7 @@ namespace {
 // ---- one workgroup per (chain, BANDED G) pair: band.hip.  CTC targets and force-alignment
 // acceptors: a single wave carries the whole recursion, the other waves stage.
 bool band_shape_ok(const Structure& cs, Structure& fs, bool chain_first) {
-  if (cs.kind != KIND_LINEAR || cs.C < 1 || cs.C > band_max_labels() || cs.M < 0 || cs.M > (1 << 20)) return false;
+  if (cs.kind != KIND_LINEAR || cs.C < band_min_labels() || cs.C > band_max_labels() || cs.M < 0 || cs.M > (1 << 20)) return false;
   std::shared_ptr<BandInfo> b = band_info(fs, chain_first);
   return b->ok && b->max_label < cs.C;
 }

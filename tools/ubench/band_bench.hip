@@ -16,7 +16,7 @@ using namespace gtnx;
 int main(int argc, char** argv) {
   int B = argc > 1 ? atoi(argv[1]) : 512, T = argc > 2 ? atoi(argv[2]) : 1000, C = argc > 3 ? atoi(argv[3]) : 256,
       U = argc > 4 ? atoi(argv[4]) : 100;
-  const int N = 2 * U + 1, npl = band_npl(N), NS = band_row_stride(N, npl);
+  const int N = 2 * U + 1, npl = getenv("BAND_NPL") ? atoi(getenv("BAND_NPL")) : band_npl(N), NS = band_row_stride(N, npl);
   std::mt19937 rng(1234);
   std::uniform_real_distribution<float> ud(-5.f, 5.f);
   std::vector<float> em(size_t(B) * T * C);

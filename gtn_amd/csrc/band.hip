@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -560,27 +561,35 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
     constexpr int LPR = BW / K, G16 = LPR / 16;
     const int EPL = (C + LPR - 1) / LPR;  // <= 16
     double normacc = 0.0;
-    auto lse_a = [&](int c) {
+    // (N = 4 / 8 / 16 elements per lane, chosen once per launch shape: a loop over 16 with a runtime bound costs
+    //  sixteen v_exp_f32 whatever the bound is -- at C = 256 half of the normaliser's transcendentals were wasted)
+    auto lse_a_n = [&](int c, auto nconst) {
+      constexpr int NE = decltype(nconst)::value;
       const int rows = rows_of(c), rr = hid / LPR, sub = hid - rr * LPR;
       if (rows <= 0) return;
       const float* e = ering + ((c % NBE) * K + min(rr, rows - 1)) * CS + sub * EPL;
-      float x[16];
+      float x[NE];
       float m = NEGF;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < NE; ++i) {
         x[i] = (i < EPL && sub * EPL + i < C) ? e[i] : NEGF;
         m = fmaxf(m, x[i]);
       }
       m = row16_max(m);
       float sum = 0.0f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) sum += (i < EPL) ? ex2(x[i] - m) : 0.0f;
+      for (int i = 0; i < NE; ++i) sum += (i < EPL) ? ex2(x[i] - m) : 0.0f;
       sum = row16_sum(sum);
       if ((hid & 15) == 0 && rr < rows) {
         float* p = M.lsep + (c & 1) * 256 + (rr * 8 + (sub >> 4)) * 2;
         p[0] = m;
         p[1] = sum;
       }
+    };
+    auto lse_a = [&](int c) {
+      if (EPL <= 4) lse_a_n(c, std::integral_constant<int, 4>{});        // uniform
+      else if (EPL <= 8) lse_a_n(c, std::integral_constant<int, 8>{});
+      else lse_a_n(c, std::integral_constant<int, 16>{});
     };
     auto lse_b = [&](int c) {
       const int rows = rows_of(c);

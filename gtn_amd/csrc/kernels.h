@@ -559,6 +559,10 @@ void launch_maxplus_path(const LazyGroup& g, int* path_arc, int* path_il, int* p
 void launch_lazy_mfma_prep(const LazyGroup& g, hipStream_t st);                // Ep / ETp from E
 void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st);     // keys, first input (0 forward, 1 backward)
 void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t st);
+// the whole pass (steps 0 .. T-1, or T-1 .. 0) as ONE cooperative launch: workgroups of a row tile hand their
+// step's output to each other through agent-scope stores / loads and a counter; false when not applicable
+size_t lazy_mfma_chain_sync_ints(const LazyGroup& g);
+bool launch_lazy_mfma_chain(const LazyGroup& g, int backward, int* zeroed_sync, int cus, hipStream_t st);
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // order-preserving integer keys -> floats
 void launch_lazy_mfma_rowmax(const LazyGroup& g, int which, hipStream_t st);   // amaxp -> amax (0) / bmaxp -> bmax (1)
 void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x T x nb */, hipStream_t st);  // R zero-filled

@@ -897,6 +897,216 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     for (int n = 0; n < g.rot; ++n) outp[int64_t(b0 + threadIdx.x) * N + n] = NEG_INF;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same T steps as ONE launch.  Utterance b at step t + 1 depends on utterance b at step t only, so no
+// grid-wide barrier is needed: the 32 rows of a row tile are produced by the `ncol` workgroups of that row tile
+// (one per column tile) and consumed by the same workgroups one step later -- they meet at a counter per row
+// tile.  What a step hands over (the next operand tile, 4 KB, and its row maxima) is written with 8-byte
+// agent-scope stores (write-through) and read with agent-scope loads (past the reader's L1), the valid hand-off
+// form without fences (MI355X_MICROARCH.md, "inter-workgroup visibility": correct for any workgroup placement;
+// same-XCD placement, which the tile order arranges when blocks go to the XCDs in turn, only makes it faster).
+// E -- the operand every step re-fetched after its kernel boundary -- lives in registers for the whole pass
+// (GPW k groups per wave: 36 registers at C4), and there is no launch per step.  Requires every workgroup to be
+// resident (one per CU): launched cooperatively, which refuses a grid that is not; the waits are bounded anyway.
+__device__ __forceinline__ mf_f2 ld_agent(const mf_f2* p) {
+  const unsigned long long v =
+      __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  mf_f2 r;
+  r.x = __uint_as_float(unsigned(v));
+  r.y = __uint_as_float(unsigned(v >> 32));
+  return r;
+}
+__device__ __forceinline__ void st_agent(float* p, float x, float y) {
+  const unsigned long long v = (unsigned long long)__float_as_uint(x) | ((unsigned long long)__float_as_uint(y) << 32);
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <bool BWD, int GPW>
+__global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_chain_kernel(LazyGroup g, int* sync) {
+  __shared__ float part[MF_WAVES][16][64];
+  __shared__ float tr[32][36];
+  __shared__ float refp[32][2][8];
+  __shared__ int sh_abort;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
+  const int Nl = g.N - g.rot;
+  const int ncol = (Nl + 31) >> 5, total = gridDim.x;
+  const int xcd = blockIdx.x & 7, per = total >> 3, rem = total & 7;
+  const int tile = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+  const int ct = tile % ncol, rt = tile / ncol;
+  const int o0 = ct * 32, b0 = rt * 32;
+  const int nbp = g.nbpad, Np = g.Npad2;
+  const int N = g.N, C = g.C, nb = g.nb, T = g.T;
+  int* arrive = sync + rt;                 // arrivals of this row tile's workgroups, all steps
+  int* abortp = sync + (total / ncol);     // set by a workgroup whose wait ran out
+  const gtnx_f4* Em = reinterpret_cast<const gtnx_f4*>(BWD ? g.ETp : g.Ep);
+  float* Mp = BWD ? g.bmaxp : g.amaxp;
+  const int ntp = g.ntp;
+  const int64_t plane = int64_t(nb) * N;
+  const int o = o0 + lo;
+  const bool ocol = o < Nl;
+  const int on_ = mf_node(g, ocol ? o : 0);
+  int rowi[MF_ROWS];
+#pragma unroll
+  for (int v = 0; v < MF_ROWS; ++v) {
+    const int reg = MF_ROWS * wv + v;
+    rowi[v] = (reg & 3) + 8 * (reg >> 2) + 4 * hi;
+  }
+  const int lab_ = g.nlab[on_];
+  const float cm_ = g.cmax[on_];
+  const int lab = ocol ? lab_ : -1;
+  const float cm = ocol ? cm_ : NEG_INF;
+  const GTNX_G float* erow[MF_ROWS];
+#pragma unroll
+  for (int v = 0; v < MF_ROWS; ++v) {
+    const int b = b0 + rowi[v];
+    erow[v] = (const GTNX_G float*)g.em[b < nb ? b : 0];
+  }
+  const int Q = ntp >> 2;
+  const int npieces = 32 * 2 * Q;
+  // this wave's k groups and its share of E, kept for the whole pass
+  const int g_lo = GPW * wv;
+  const mf_f2* bp = reinterpret_cast<const mf_f2*>(Em) + (o0 + lo) * 2 + hi;
+  mf_f2 ereg[GPW];
+#pragma unroll
+  for (int u = 0; u < GPW; ++u) ereg[u] = bp[int64_t(g_lo + u) * Np * 2];
+  if (threadIdx.x == 0) sh_abort = 0;
+  __syncthreads();
+
+  for (int s = 0; s < T; ++s) {
+    const int t = BWD ? T - 1 - s : s;
+    const gtnx_f4* X = reinterpret_cast<const gtnx_f4*>(g.xt[BWD ? ((t + 1) & 1) : (t & 1)]);
+    float* Xn = g.xt[BWD ? (t & 1) : ((t + 1) & 1)];
+    const int te = BWD ? t - 1 : t;
+    // ---- nothing another workgroup wrote: this step's emissions (their trip overlaps the wait below)
+    float emv[MF_ROWS];
+#pragma unroll
+    for (int v = 0; v < MF_ROWS; ++v) {
+      const float x = erow[v][int64_t(te >= 0 ? te : 0) * C + (lab >= 0 ? lab : 0)];
+      emv[v] = (lab >= 0 && te >= 0) ? x : 0.0f;
+    }
+    // ---- the row tile's workgroups have published step s - 1
+    if (s > 0) {
+      if (threadIdx.x == 0) {
+        const int want = ncol * s;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__hip_atomic_load(abortp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+              wall_clock64() - t0 > 300000000ll) {  // 3 s of the 100 MHz counter: somebody is not resident
+            __hip_atomic_store(abortp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            sh_abort = 1;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (sh_abort) return;
+    }
+    const bool has_in = !BWD ? t > 0 : t < T - 1;
+    const int t_in = !BWD ? (t > 0 ? t - 1 : 0) : (t < T - 1 ? t + 1 : t);
+    // row maxima (partials per column tile) of the input's reference row and of this step's own row
+    mf_f2 rv[2][2];
+    int ri[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int i0 = int(threadIdx.x) + u * MF_WAVES * 64;
+      const int i = i0 < npieces ? i0 : int(threadIdx.x) % npieces;
+      ri[u] = i0 < npieces ? i : -1;
+      const int r = i / (2 * Q), j = (i / Q) & 1, q = i % Q;
+      const int b = b0 + r;
+      const int64_t row = int64_t(j ? t : t_in) * nb + (b < nb ? b : 0);
+      const mf_f2* src = reinterpret_cast<const mf_f2*>(Mp + row * ntp) + 2 * q;
+      rv[u][0] = ld_agent(src);
+      rv[u][1] = ld_agent(src + 1);
+    }
+    // ---- the contraction: every operand of the wave requested at once, multiplied as they arrive
+    const mf_f2* ap = reinterpret_cast<const mf_f2*>(X) + (b0 + lo) * 2 + hi;
+    mf_f2 a[GPW];
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) a[u] = ld_agent(ap + int64_t(g_lo + u) * nbp * 2);
+    gtnx_f16v acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    gtnx_f16v acc2 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int u = 0; u < GPW; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, ereg[u].x, acc, 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, ereg[u].y, acc2, 0, 0, 0);
+    }
+    acc += acc2;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (ri[u] >= 0) {
+        const int i = ri[u];
+        refp[i / (2 * Q)][(i / Q) & 1][i % Q] = fmaxf(fmaxf(rv[u][0].x, rv[u][0].y), fmaxf(rv[u][1].x, rv[u][1].y));
+      }
+    }
+    __syncthreads();
+    // ---- epilogue (as lazy_mfma_step_kernel)
+    float* outp = BWD ? g.beta + int64_t(t) * plane : g.alpha + int64_t(t + 1) * plane;
+#pragma unroll
+    for (int v = 0; v < MF_ROWS; ++v) {
+      const int reg = MF_ROWS * wv + v;
+      const int i = rowi[v];
+      const int b = b0 + i;
+      const bool on = b < nb;
+      float av = 0.0f;
+#pragma unroll
+      for (int p = 0; p < MF_WAVES; p += 2) av += part[p][reg][l] + part[p + 1][reg][l];
+      float m_in = refp[i][0][0], m_out = refp[i][1][0];
+      for (int q = 1; q < (ntp >> 2); ++q) {
+        m_in = fmaxf(m_in, refp[i][0][q]);
+        m_out = fmaxf(m_out, refp[i][1][q]);
+      }
+      if (!has_in) m_in = 0.0f;
+      float val = NEG_INF, nxt = NEG_INF;
+      if (on && ocol && av > 0.0f && m_in != NEG_INF) {
+        val = __logf(av) + m_in;
+        if (!BWD) {
+          val = lab < 0 ? NEG_INF : val + cm + emv[v];
+          nxt = val;
+        } else if (t >= 1 && lab >= 0) {
+          nxt = val + emv[v] + cm;
+        }
+      }
+      if (on && ocol) outp[int64_t(b) * N + on_] = val;
+      const float rm = half32_max(nxt);
+      if (lo == 0 && on && (!BWD || t >= 1))
+        __hip_atomic_store(Mp + (int64_t(BWD ? t - 1 : t + 1) * nb + b) * ntp + (o0 >> 5), rm, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      tr[i][lo] = (nxt == NEG_INF || m_out == NEG_INF) ? 0.0f : __expf(nxt - m_out);
+    }
+    __syncthreads();
+    if ((!BWD || t >= 1) && threadIdx.x < 256) {
+      const int kg = threadIdx.x >> 5, bl = threadIdx.x & 31;
+      const int k = o0 + 4 * kg;
+      if (k < g.Kpad) {
+        const float w0 = (k + 0 < Nl) ? tr[bl][4 * kg + 0] : 0.0f, w1 = (k + 1 < Nl) ? tr[bl][4 * kg + 1] : 0.0f;
+        const float w2 = (k + 2 < Nl) ? tr[bl][4 * kg + 2] : 0.0f, w3 = (k + 3 < Nl) ? tr[bl][4 * kg + 3] : 0.0f;
+        float* dst = Xn + (int64_t(k >> 2) * nbp + b0 + bl) * 4;
+        st_agent(dst, w0, w1);
+        st_agent(dst + 2, w2, w3);
+      }
+    }
+    // after the first forward step the slots past the last column tile (the dead start node's) must read 0 in the
+    // plane step 0 took its input from: it is this step's output plane at s == 1 (lazy_mfma_dead_rows_kernel)
+    if (!BWD && s == 1 && ct == ncol - 1) {
+      const int k0 = ncol * 32;
+      for (int i = threadIdx.x; i < ((g.Kpad - k0) >> 2) * 32; i += MF_WAVES * 64) {
+        const int kg = i >> 5, bl = i & 31;
+        float* dst = Xn + (int64_t((k0 >> 2) + kg) * nbp + b0 + bl) * 4;
+        st_agent(dst, 0.0f, 0.0f);
+        st_agent(dst + 2, 0.0f, 0.0f);
+      }
+    }
+    if (o0 == 0 && threadIdx.x < 32 && b0 + int(threadIdx.x) < nb)
+      for (int n = 0; n < g.rot; ++n) outp[int64_t(b0 + threadIdx.x) * N + n] = NEG_INF;
+    // ---- publish: every store of this workgroup has left (stores count in vmcnt), then one arrival
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // after the first forward step: the dead slots of plane 0 still hold exp(alpha[0]) (a start node's 1)
 __global__ void lazy_mfma_dead_rows_kernel(LazyGroup g, float* X, int j_lo) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -1455,6 +1665,48 @@ void launch_lazy_mfma_step(const LazyGroup& g, int t, int backward, hipStream_t 
     const int64_t n = int64_t(g.Kpad - Nl) * g.nbpad;
     hipLaunchKernelGGL(lazy_mfma_dead_rows_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, g, g.xt[0], Nl);
   }
+}
+namespace {
+template <bool BWD, int GPW>
+bool launch_chain(const LazyGroup& g, int* sync, dim3 grid, hipStream_t st) {
+  LazyGroup gg = g;
+  void* args[] = {&gg, &sync};
+  const hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lazy_mfma_chain_kernel<BWD, GPW>), grid,
+                                                  dim3(MF_WAVES * 64), args, 0, st);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return true;
+}
+}  // namespace
+
+size_t lazy_mfma_chain_sync_ints(const LazyGroup& g) { return size_t(g.nbpad / 32) + 8; }
+// all T steps of a pass in one cooperative launch (lazy_mfma_chain_kernel); false: not applicable here (shape,
+// residency, GTNX_NO_CHAIN) -- the caller launches the steps one by one.  `sync`: zeroed ints (see above)
+bool launch_lazy_mfma_chain(const LazyGroup& g, int backward, int* sync, int cus, hipStream_t st) {
+  // OFF unless GTNX_CHAIN=1: measured on the MI355X at C4 (B = 512, T = 1000, C = 512) the pass takes 10.97 ms
+  // this way against 9.66 ms as T launches (profiles/r03_c4_chain.txt) -- a step's hand-off is four dependent
+  // trips (write-through acknowledged -> arrival atomic -> poll -> operand loads past L1), which costs more than
+  // the 2.9 us of launch + kernel boundary it removes.  Kept as the measured alternative, not as the default.
+  static const bool on = getenv("GTNX_CHAIN") != nullptr && getenv("GTNX_CHAIN")[0] == '1';
+  if (!on || g.T <= 0) return false;
+  const int Nl = g.N - g.rot;
+  const int ncol = (Nl + 31) / 32, nrow = g.nbpad / 32;
+  const int grid = ncol * nrow;
+  if (grid > cus || (g.Kpad & 31) != 0 || g.ntp > 32) return false;  // one workgroup per CU, all resident
+  const int gpw = (g.Kpad >> 2) / MF_WAVES;
+  if ((g.Kpad >> 2) % MF_WAVES != 0) return false;
+#define GTNX_CHAIN(N_)                                                                      \
+  if (gpw == N_)                                                                            \
+    return backward ? launch_chain<true, N_>(g, sync, dim3(unsigned(grid)), st)             \
+                    : launch_chain<false, N_>(g, sync, dim3(unsigned(grid)), st);
+  GTNX_CHAIN(6)
+  GTNX_CHAIN(12)
+  GTNX_CHAIN(18)
+  GTNX_CHAIN(24)
+#undef GTNX_CHAIN
+  return false;
 }
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(lazy_mfma_keys_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, keys, n);

@@ -2032,7 +2032,11 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
       if (st.mfma) {
         launch_lazy_mfma_prep(st.view, rt.stream());
         launch_lazy_mfma_init(st.view, 0, rt.stream());
-        for (int t = 0; t < st.view.T; ++t) launch_lazy_mfma_step(st.view, t, 0, rt.stream());
+        {
+          DevMemP sync = rt.alloc_zero(sizeof(int) * lazy_mfma_chain_sync_ints(st.view));
+          if (!launch_lazy_mfma_chain(st.view, 0, sync->as<int>(), rt.cu_count(), rt.stream()))
+            for (int t = 0; t < st.view.T; ++t) launch_lazy_mfma_step(st.view, t, 0, rt.stream());
+        }
         launch_lazy_mfma_rowmax(st.view, 0, rt.stream());
       } else {
         for (int t = 0; t < st.view.T; ++t) launch_lazy_dense_step(st.view, t, 0, rt.stream());
@@ -2124,7 +2128,11 @@ struct LazySdOp : OpRecord {
         launch_lazy_init(v, 1, rt.stream());
         if (st.dense && st.mfma) {
           launch_lazy_mfma_init(v, 1, rt.stream());
-          for (int t = T - 1; t >= 0; --t) launch_lazy_mfma_step(v, t, 1, rt.stream());
+          {
+            DevMemP sync = rt.alloc_zero(sizeof(int) * lazy_mfma_chain_sync_ints(v));
+            if (!launch_lazy_mfma_chain(v, 1, sync->as<int>(), rt.cu_count(), rt.stream()))
+              for (int t = T - 1; t >= 0; --t) launch_lazy_mfma_step(v, t, 1, rt.stream());
+          }
           launch_lazy_mfma_rowmax(v, 1, rt.stream());
         } else if (st.dense) {
           DevMemP vs = rt.alloc(8 * plane);  // two planes: input of this step / of the next

@@ -41,7 +41,8 @@ def main():
     torch.manual_seed(0)
     em = (torch.rand(B, T, C, device="cuda") * 10 - 5).contiguous()
     tw = np.random.default_rng(0).random(C * C + C).astype(np.float32)
-    out = {"workload": f"C4 ASG dense transitions B={B} T={T} C={C}", "product_arcs_per_utterance": C * C * (T - 1) + C}
+    out = {"config": "C4: ASG loss: compose with dense CxC transition WFST + viterbiPath, T=1000, C=512, batch=512, 1 MI355X",
+           "workload": f"C4 ASG dense transitions B={B} T={T} C={C}", "product_arcs_per_utterance": C * C * (T - 1) + C}
 
     def sync():
         gtn.synchronize()
@@ -174,6 +175,11 @@ def main():
                                "frac_of_valu_peak": arcs / (ms * 1e-3) / 39.3e12}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C)
+    # headline of the record: the shipped ASG criterion (full-connect minus force-align score, forward + backward) and
+    # the Viterbi decode, utterances per second
+    out["metric"] = "ASG criterion forward+backward utterances/sec (T=%d, C=%d); decode in decode_utt_per_s" % (T, C)
+    out["value"] = out.get("asg_criterion_utt_per_s")
+    out["unit"] = "utterances/s"
     print(json.dumps(out))
 
 

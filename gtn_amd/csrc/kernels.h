@@ -215,6 +215,9 @@ struct ComposeOut {
   int rep_levels;      // BFS levels emitted by stationary-level replication (not expanded one by one)
   int skipped;         // src / il / ol / in_list were NOT written (ComposeArgs::skip honoured); see compose_fill
   int t_b, t_f, t_rep; // 100 MHz ticks spent in phase B / phase F (total) / replication (diagnostics)
+  // compose_wide.hip: the hole its plan kernel left for the replication kernel -- levels wr_L + 1 .. wr_L + wr_K
+  // are level wr_L (frontier ids wr_lo .. wr_lo + wr_W, arcs wr_na .. wr_na + wr_Aw) moved in time
+  int wr_L, wr_K, wr_lo, wr_W, wr_na, wr_Aw;
 };
 
 constexpr int GF_EPS_FREE = 4;
@@ -272,6 +275,12 @@ int compose_lds_budget(int wide);
 // wide != 0 (fast chain products only): 512-lane workgroups, partners of up to 512 nodes
 void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int lin2, int dyn_lds_bytes,
                     int fast, int cache1, int wide, hipStream_t st);
+// compose_wide.hip: chain products (exactly one side KIND_LINEAR, chain length >= 1) with an epsilon-free partner
+// of at most compose_wide_node_cap() nodes whose arcs match in the partner's list order (see the file's header);
+// any out-degree.  All n pairs share `lin2` (the chain is the second graph).  Leaves ComposeOut::csr_built = 0:
+// launch_compose_transpose() follows.
+int compose_wide_node_cap();
+void launch_compose_wide(const ComposeArgs* d_args, int n, int lin2, int max_acap, hipStream_t st);
 struct ComposeFillArgs {
   int N, A;
   const GTNX_G int* out_off;

@@ -1383,6 +1383,26 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   std::vector<char> classic_ok(n, 0), full_window(n, 0);
   size_t fast_bm = 0, classic_bm = 0;
   bool fast_ok = true;
+  // Chain products whose partner has wide nodes (more candidate arcs per node than the lane-per-node kernel
+  // caches: transition graphs) go to compose_wide.hip: a wave per frontier node, stationary levels written by a
+  // grid.  Its arc order is the partner's list order, which is the reference's as long as a partner that is
+  // matched as "sorted" is sorted on the label being matched (g2: ilabel, g1: olabel; functions.cpp:225-251).
+  std::vector<char> wide_ok(n, 0), wide_pref(n, 0);
+  if (!getenv("GTNX_NO_WIDE_COMPOSE")) {
+    for (size_t i = 0; i < n; ++i) {
+      const Structure& s1 = *bcast(av, n, i).s;
+      const Structure& s2 = *bcast(bv, n, i).s;
+      const bool l1 = s1.kind == KIND_LINEAR, l2 = s2.kind == KIND_LINEAR;
+      if (l1 == l2) continue;
+      const Structure& ex = l1 ? s2 : s1;
+      const Structure& ch = l1 ? s1 : s2;
+      const bool sorted_claim = intersect ? (ex.ilabel_sorted || ex.olabel_sorted) : (l1 ? ex.ilabel_sorted : ex.olabel_sorted);
+      const bool sorted_on_match = l1 ? ex.ilabel_sorted : ex.olabel_sorted;
+      wide_ok[i] = (ex.dview.flags & GF_EPS_FREE) && ch.M >= 1 && ex.N >= 1 && ex.N <= compose_wide_node_cap() &&
+                   (!sorted_claim || sorted_on_match);
+      wide_pref[i] = wide_ok[i] && ex.A > 4 * ex.N;
+    }
+  }
   // 512-lane workgroups when some chain product's partner has 257..512 nodes (and none more)
   bool wide = false;
   {
@@ -1424,6 +1444,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
           mine = compose_chain_bitmap_bytes(No, slices);
         }
       }
+      if (wide_pref[i]) continue;  // never runs the FAST variant
       fast_ok = fast_ok && mine <= budget;
       fast_bm = std::max(fast_bm, mine);
     }
@@ -1470,7 +1491,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const bool full_env = getenv("GTNX_FULL_COMPOSE") != nullptr;
       const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
       const Structure& ex = l1 ? *b.s : *a.s;
-      x.skip = (!full_env && lds_state && l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) &&
+      x.skip = (!full_env && lds_state && !wide_pref[i] && l1 != l2 && ((l1 ? x.g2.flags : x.g1.flags) & GF_EPS_FREE) &&
                 ex.N <= (wide ? 512 : 256))
                    ? 1 : 0;
     }
@@ -1505,6 +1526,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   // wider than the workgroup), at most KC candidates per node (out-degree), a level's
   // arcs within the claim hash, a bitmap window over all times, arrays left out.
   bool defer = lds_state && n > 0 && !getenv("GTNX_SYNC_COMPOSE");
+  for (size_t i = 0; i < n && defer; ++i) defer = !wide_pref[i];
   for (size_t i = 0; i < n && defer; ++i) {
     Graph& a = const_cast<Graph&>(bcast(av, n, i));
     Graph& b = const_cast<Graph&>(bcast(bv, n, i));
@@ -1530,12 +1552,17 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   std::vector<char> hdr(hdr_cnt + 8 * n);
   const ComposeOut* res_out = reinterpret_cast<const ComposeOut*>(hdr.data() + hdr_out);
   const int* res_counts = reinterpret_cast<const int*>(hdr.data() + hdr_cnt);
-  double alg = 0;
-  for (size_t i = 0; i < n; ++i) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
   std::shared_ptr<DeferredSizes> deferred;
-  auto run = [&](std::vector<size_t> order, bool fast) {
+  // kind: 0 the general variant, 1 FAST, 2 compose_wide.hip
+  auto run = [&](std::vector<size_t> order, int kind) {
+    const bool fast = kind == 1;
     const size_t m = order.size();
-    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
+    double alg = 0;
+    for (size_t i : order) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
+    if (kind == 2)  // one launch per side the chain is on
+      std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return (key_of(x) & 1) < (key_of(y) & 1); });
+    else
+      std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return key_of(x) < key_of(y); });
     std::vector<ComposeArgs> sorted_args(m);
     for (size_t i = 0; i < m; ++i) {
       sorted_args[i] = args[order[i]];
@@ -1548,7 +1575,14 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(m), int(maxN)));
     {
       GTNX_PROF(intersect ? "intersect" : "compose", alg);
-      for (size_t g0 = 0; g0 < m;) {
+      for (size_t g0 = 0; g0 < m && kind == 2;) {
+        size_t g1 = g0;
+        int64_t acap = 0;
+        while (g1 < m && (key_of(order[g1]) & 1) == (key_of(order[g0]) & 1)) acap = std::max(acap, caps[order[g1++]].Acap);
+        launch_compose_wide(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key_of(order[g0]) & 1, int(acap), rt.stream());
+        g0 = g1;
+      }
+      for (size_t g0 = 0; g0 < m && kind != 2;) {
         size_t g1 = g0;
         while (g1 < m && key_of(order[g1]) == key_of(order[g0])) ++g1;
         const int key = key_of(order[g0]);
@@ -1590,18 +1624,27 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     }
   };
   {
-    std::vector<size_t> all(n);
-    for (size_t i = 0; i < n; ++i) all[i] = i;
+    std::vector<size_t> all, wides;
+    for (size_t i = 0; i < n; ++i) (wide_pref[i] ? wides : all).push_back(i);
     if (defer) deferred_limit(1);  // the host runs at most two batches ahead of the GPU
-    run(all, lds_state);
-    std::vector<size_t> redo;
+    if (!all.empty()) run(all, lds_state ? 1 : 0);
+    if (!wides.empty()) run(wides, 2);
+    // pairs the FAST variant handed back: chain products go to compose_wide.hip whatever their degrees (a node
+    // with many IN-arcs stops the FAST variant's backward pass too; bit rows per time do not care), the rest to
+    // the general variant
+    std::vector<size_t> redo, redo_wide;
     for (size_t i = 0; i < n && !deferred; ++i)
-      if (res_out[i].overflow == 2) redo.push_back(i);
+      if (res_out[i].overflow == 2) (wide_ok[i] && !wide_pref[i] ? redo_wide : redo).push_back(i);
+    if (!redo_wide.empty()) {
+      run(redo_wide, 2);
+      for (size_t i : redo_wide)
+        if (res_out[i].overflow == 2) redo.push_back(i);
+    }
     if (getenv("GTNX_COMPOSE_STATS") && !deferred)
       fprintf(stderr, "[gtnx] compose: n=%zu redo=%zu graph0: N=%d A=%d levels=%d replicated=%d  us: B=%.0f F=%.0f (rep %.0f)\n", n, redo.size(),
               res_out[0].N, res_out[0].A, res_out[0].L, res_out[0].rep_levels, res_out[0].t_b * 0.01,
               res_out[0].t_f * 0.01, res_out[0].t_rep * 0.01);
-    if (!redo.empty()) run(redo, false);
+    if (!redo.empty()) run(redo, 0);
   }
 
   ht_phase("compose.4_launch_wait");

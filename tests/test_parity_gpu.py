@@ -951,3 +951,88 @@ def test_binary_format_loads_straight_into_device_buffers(gtn, tmp_path):
     for n in (0, 1, 7, 700, 1499):
         assert g.out(n) == h.out(n) and g.in_(n) == h.in_(n)
     assert gtn.equal(g, h)
+
+
+def _wide_partner(rng, kind, C):
+    """explicit partners with wide nodes for chain products (compose_wide.hip)"""
+    if kind == "bench_bigram":      # benchmarks/ctc.cpp:66-81 with M = C, N = 2 (every arc ends in node 0)
+        N = C
+        src = [i for i in range(N) for m in range(C)]
+        dst = [0 for i in range(N) for m in range(C)]
+        il = [m for i in range(N) for m in range(C)]
+        return {"start": [1] * N, "accept": [1] * N, "src": src, "dst": dst, "il": il, "ol": list(il),
+                "w": gg._f32(rng.normal(0, 1, len(src))), "sort": "i"}
+    if kind == "bench_trigram":     # the same with N = 3: C*C nodes, C arcs each
+        N, mod = C * C, C
+        src = [i for i in range(N) for m in range(C)]
+        dst = [i % mod for i in range(N) for m in range(C)]
+        il = [m for i in range(N) for m in range(C)]
+        return {"start": [1] * N, "accept": [1] * N, "src": src, "dst": dst, "il": il, "ol": list(il),
+                "w": gg._f32(rng.normal(0, 1, len(src))), "sort": "i"}
+    if kind == "asg":               # examples/asg.cpp: a start node + one node per label, dense
+        N = C + 1
+        src = [0] * C + [1 + i for i in range(C) for m in range(C)]
+        dst = [1 + m for m in range(C)] + [1 + m for i in range(C) for m in range(C)]
+        il = list(range(C)) + [m for i in range(C) for m in range(C)]
+        acc = [0] + [int(x) for x in (rng.random(C) < 0.7)]
+        acc[-1] = 1
+        return {"start": [1] + [0] * C, "accept": acc, "src": src, "dst": dst, "il": il, "ol": list(il),
+                "w": gg._f32(rng.normal(0, 1, len(src))), "sort": None}
+    # random: distinct labels per node (some of them beyond the chain's alphabet), dead ends, several starts
+    N = int(rng.integers(20, 70))
+    src, dst, il, ol = [], [], [], []
+    for n in range(N):
+        deg = int(rng.integers(0, C + 3))
+        labs = rng.permutation(C + 3)[:deg]
+        olabs = rng.permutation(C + 3)[:deg]  # distinct per node: equal keys would expose std::sort's freedom
+        for l, o in zip(labs, olabs):
+            src.append(n)
+            dst.append(int(rng.integers(0, N)))
+            il.append(int(l))
+            ol.append(int(l) if kind != "transducer" else int(o))
+    start = [int(x) for x in (rng.random(N) < 0.2)]
+    accept = [int(x) for x in (rng.random(N) < 0.15)]
+    start[0] = 1
+    accept[-1] = 1
+    return {"start": start, "accept": accept, "src": src, "dst": dst, "il": il, "ol": ol,
+            "w": gg._f32(rng.normal(0, 1, len(src))), "sort": {"random_sorted": "i", "transducer": "i"}.get(kind)}
+
+
+@pytest.mark.parametrize("kind,T,C", [("bench_bigram", 40, 30), ("bench_trigram", 9, 12), ("asg", 14, 40), ("asg", 1, 9),
+                                      ("asg", 2, 70), ("random", 25, 20), ("random_sorted", 25, 20), ("random_sorted", 3, 33),
+                                      ("transducer", 16, 24), ("random", 60, 9)])
+@pytest.mark.parametrize("chain_first", [True, False])
+@pytest.mark.parametrize("mode", ["intersect", "compose"])
+def test_wide_chain_products_vs_oracle(gtn, kind, T, C, chain_first, mode):
+    """chain products with wide partner nodes (compose_wide.hip: a wave per frontier node, stationary levels written by
+    the replication kernel): node ids, arc order, labels, weights, forwardScore and both gradients as the oracle's"""
+    if kind == "transducer" and mode == "intersect":
+        pytest.skip("intersect of a transducer binary-searches labels it was not sorted on (functions.cpp:238-251)")
+    rng = np.random.default_rng(sum(map(ord, kind)) * 131 + T * 17 + C)
+    d = _wide_partner(rng, kind, C)
+    if kind == "transducer" and mode == "compose" and not chain_first:
+        d["sort"] = "o"   # compose(partner, chain) matches the partner's olabels
+    em = gg._f32(rng.normal(0, 1, T * C))
+    e = gtn.linear_graph(T, C)
+    e.set_weights(np.asarray(em, np.float32))
+    p = gg.to_api(gtn, d)
+    fn = gtn.intersect if mode == "intersect" else gtn.compose
+    comp = fn(e, p) if chain_first else fn(p, e)
+    oe, op = OGraph.linear(T, C, np.asarray(em, np.float32)), OGraph.from_dict(d)
+    oc = oe.compose(op, mode) if chain_first else op.compose(oe, mode)
+    assert (comp.num_nodes(), comp.num_arcs()) == (oc.N, oc.A)
+    got, want = gg.from_api(comp), oc.to_dict()
+    for k in ("start", "accept", "src", "dst", "il", "ol"):
+        assert got[k] == want[k], k
+    assert got["w"] == want["w"]
+    want_fs = oc.shortest_distance()
+    if want_fs is None or oc.A == 0:
+        return
+    fs = gtn.forward_score(comp)
+    assert fs.item() == pytest.approx(want_fs, rel=RTOL)
+    gtn.backward(fs)
+    A1, A2 = (T * C, len(d["src"])) if chain_first else (len(d["src"]), T * C)
+    g1, g2 = oc.compose_grad(oc.shortest_distance_grad(), A1, A2)
+    ge, gp = (g1, g2) if chain_first else (g2, g1)
+    np.testing.assert_allclose(e.grad().weights_to_numpy(), ge, rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(p.grad().weights_to_numpy(), gp, rtol=1e-3, atol=2e-4)

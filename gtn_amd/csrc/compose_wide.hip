@@ -439,6 +439,410 @@ __global__ __launch_bounds__(RB) void compose_wide_replicate_kernel(const Compos
     for (int k = 1 + tid; k <= K; k += RB) a.level_off[L0 + k] = lo + k * W;
 }
 
+
+// ================================================================================================================
+// General products (both graphs explicit) with wide nodes: a WAVE per frontier pair.
+//
+// compose.hip's general variant walks a pair's matches with one lane: "for q in the query list: binary search in
+// the search list, walk the equal-label run" (compose.cpp:211-374), each step a dependent L2 access -- 0.6 ms for
+// a 21-node CTC target against a 30-node bigram graph, 1.2 s for benchmarks/functions.cpp's compose of two
+// chains with 20 and 1000 arcs per node.  Here the 64 lanes of a wave take 64 query arcs at once (one binary
+// search each, in parallel), and the matches of the block -- equal-label runs of different lengths -- are
+// flattened by a prefix sum over the run lengths, so that every lane of the next step holds ONE candidate arc
+// pair, in the reference's order (query-major, then the search list's order).  A lane finds its (query, offset)
+// by a 6-step search over the prefix held in the wave's registers (ds_bpermute).
+//
+// The search side's list must be sorted on the label being matched.  Graphs that are not (UnsortedMatcher,
+// compose.cpp:211-236: for i in out(n1): for j in out(n2)) get a stable label-sorted VIEW of their lists, built
+// once per graph by sorted_view_kernel: q-major order over a stable view is exactly the double loop's order.
+//
+// Everything else follows compose.hip's general variant: pair table `state` in HBM (unreached / co-reachable /
+// claimed by arc rank / node id), level-synchronous BFS, arc slots by prefix sum, first-arc ownership by
+// atomicMax of the claim, epsilon moves after the matches (compose.cpp:449-490).
+// ================================================================================================================
+constexpr int ST_UNREACH = INT_MIN;
+constexpr int ST_REACH = INT_MIN + 1;
+constexpr int EPS = -1;
+__device__ __forceinline__ int claim_of(int r) { return -2 - r; }
+__device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// calls f(has, idx, i, j, il, ol) wave-uniformly, once per chunk of up to 64 candidate arc pairs of (n1, n2) in
+// the reference's order: dst pair id, arc of g1 (-1: none), arc of g2, labels of the composed arc
+template <bool IN, int MATCH, class F>
+__device__ __forceinline__ void wave_candidates(const ComposeArgs& a, int n1, int n2, bool eps1_ok, bool eps2_ok, F&& f) {
+  const int lane = threadIdx.x & 63;
+  const int N1 = a.g1.N;
+  const GTNX_G int* off1 = IN ? a.g1.in_off : a.g1.out_off;
+  const GTNX_G int* off2 = IN ? a.g2.in_off : a.g2.out_off;
+  const int b1 = off1[n1], d1 = off1[n1 + 1] - b1;
+  const int b2 = off2[n2], d2 = off2[n2 + 1] - b2;
+  // roles, functions.cpp:225-251 and compose.cpp:319
+  const bool sg1 = MATCH == MATCH_SINGLY_G1 || (MATCH == MATCH_DOUBLY && d1 > d2);
+  const GTNX_G gtnx_i4* qrec = sg1 ? (IN ? a.g2.in_rec : a.g2.out_rec) + b2 : (IN ? a.g1.in_rec : a.g1.out_rec) + b1;
+  const GTNX_G gtnx_i4* srec = sg1 ? (IN ? a.s1_in : a.s1_out) + b1 : (IN ? a.s2_in : a.s2_out) + b2;
+  const int dq = sg1 ? d2 : d1, ds = sg1 ? d1 : d2;
+  if (ds > 0)
+    for (int q0 = 0; q0 < dq; q0 += 64) {
+      gtnx_i4 qr{};
+      int lb = 0, c = 0;
+      if (q0 + lane < dq) {
+        qr = qrec[q0 + lane];
+        const int ql = sg1 ? qr.x : qr.y;  // g2's ilabel : g1's olabel
+        if (IN || ql != EPS) {             // direct eps:eps matches are skipped going forward (compose.cpp:425-428)
+          int lo = 0, hi = ds;
+          while (lo < hi) {  // std::lower_bound
+            const int mid = (lo + hi) >> 1;
+            const gtnx_i4 m = srec[mid];
+            if ((sg1 ? m.y : m.x) < ql) lo = mid + 1; else hi = mid;
+          }
+          lb = lo;
+          hi = ds;
+          while (lo < hi) {  // std::upper_bound
+            const int mid = (lo + hi) >> 1;
+            const gtnx_i4 m = srec[mid];
+            if ((sg1 ? m.y : m.x) <= ql) lo = mid + 1; else hi = mid;
+          }
+          c = lo - lb;
+        }
+      }
+      const int incl = wave_incl_scan(c);
+      const int P = incl - c;
+      const int tot = __shfl(incl, 63);
+      for (int k0 = 0; k0 < tot; k0 += 64) {
+        const int k = k0 + lane;
+        const bool has = k < tot;
+        int qi = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1) {
+          const int cand = qi + step;  // < 64
+          if (__shfl(P, cand) <= k) qi = cand;
+        }
+        const int s = __shfl(lb, qi) + k - __shfl(P, qi);
+        gtnx_i4 q4;
+        q4.x = __shfl(qr.x, qi); q4.y = __shfl(qr.y, qi); q4.z = __shfl(qr.z, qi); q4.w = __shfl(qr.w, qi);
+        gtnx_i4 s4{};
+        if (has) s4 = srec[s];
+        const gtnx_i4 r1 = sg1 ? s4 : q4, r2 = sg1 ? q4 : s4;
+        f(has, r1.z + N1 * r2.z, r1.w, r2.w, r1.x, r2.y);
+      }
+    }
+  // epsilon moves: g1's arcs with olabel eps, then g2's arcs with ilabel eps (lists sorted on that label have
+  // them first, compose.cpp:36-41)
+  if (!(a.g1.flags & GF_EPS_FREE) && (IN || eps1_ok)) {
+    const GTNX_G gtnx_i4* rec = (IN ? a.g1.in_rec : a.g1.out_rec) + b1;
+    for (int k0 = 0; k0 < d1; k0 += 64) {
+      gtnx_i4 r{};
+      bool e = false;
+      if (k0 + lane < d1) {
+        r = rec[k0 + lane];
+        e = r.y == EPS;
+      }
+      const unsigned long long m = __ballot(e);
+      if (m) f(e, r.z + N1 * n2, r.w, -1, r.x, EPS);
+      if ((a.g1.flags & 2) && m != ~0ull) break;
+    }
+  }
+  if (!(a.g2.flags & GF_EPS_FREE) && (IN || eps2_ok)) {
+    const GTNX_G gtnx_i4* rec = (IN ? a.g2.in_rec : a.g2.out_rec) + b2;
+    for (int k0 = 0; k0 < d2; k0 += 64) {
+      gtnx_i4 r{};
+      bool e = false;
+      if (k0 + lane < d2) {
+        r = rec[k0 + lane];
+        e = r.x == EPS;
+      }
+      const unsigned long long m = __ballot(e);
+      if (m) f(e, n1 + N1 * r.z, -1, r.w, EPS, r.y);
+      if ((a.g2.flags & 1) && m != ~0ull) break;
+    }
+  }
+}
+// does the out-list of `n` hold an arc whose matched label is epsilon? (wave-uniform result)
+__device__ __forceinline__ bool wave_has_eps(const DGraph& g, int n, bool second) {
+  if (g.flags & GF_EPS_FREE) return false;
+  const int lane = threadIdx.x & 63;
+  const int b = g.out_off[n], d = g.out_off[n + 1] - b;
+  bool any = false;
+  for (int k0 = 0; k0 < d && !any; k0 += 64) {
+    bool e = false;
+    if (k0 + lane < d) {
+      const gtnx_i4 r = g.out_rec[b + k0 + lane];
+      e = (second ? r.x : r.y) == EPS;
+    }
+    any = __ballot(e) != 0ull;
+  }
+  return any;
+}
+
+template <int MATCH>
+__global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __restrict__ args) {
+  const ComposeArgs a = args[blockIdx.x];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int N1 = a.g1.N, N2 = a.g2.N;
+  __shared__ int sh_scan[WW];
+  __shared__ int sh_w[WW];
+  __shared__ int sh_tail;
+  __shared__ int sh_flag[2];  // [0] layered, [1] overflow
+  if (tid == 0) {
+    sh_tail = 0;
+    sh_flag[0] = 1;
+    sh_flag[1] = 0;
+  }
+  __syncthreads();
+  const long long tk0 = wall_clock64();
+  if (N1 == 0 || N2 == 0) {
+    if (tid == 0) {
+      ComposeOut o{};
+      o.layered = 1;
+      o.csr_built = 1;
+      *a.out = o;
+      a.out_off[0] = 0;
+      a.level_off[0] = 0;
+      a.in_off[0] = 0;
+      a.counts[0] = a.counts[1] = 0;
+    }
+    return;
+  }
+  // ------------------------------------------------------------------ phase B (compose.cpp:64-104)
+  // `state` arrives filled with ST_UNREACH; the queue of pair ids is the reference's toExplore
+  {
+    const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
+    const int seeds = na1 * na2;
+    for (int t = tid; t < seeds; t += WB) {
+      const int idx = a.g1.accept_list[t / na2] + N1 * a.g2.accept_list[t % na2];
+      st_agent(a.state + idx, ST_REACH);
+      st_agent(a.queue + t, idx);
+    }
+    if (tid == 0) sh_tail = seeds;
+    __syncthreads();
+    int lo = 0, hi = seeds;
+    while (lo < hi) {
+      for (int f = lo + wave; f < hi; f += WW) {
+        const int idx = ld_agent(a.queue + f);
+        wave_candidates<true, MATCH>(a, idx % N1, idx / N1, true, true, [&](bool has, int pidx, int, int, int, int) {
+          const bool fresh = has && atomicCAS(a.state + pidx, ST_UNREACH, ST_REACH) == ST_UNREACH;
+          const unsigned long long m = __ballot(fresh);
+          if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_tail, __popcll(m));
+            base = __shfl(base, 0);
+            if (fresh) st_agent(a.queue + base + __popcll(m & lanes_below()), pidx);
+          }
+        });
+      }
+      __syncthreads();
+      lo = hi;
+      hi = sh_tail;
+      __syncthreads();
+    }
+  }
+  // ------------------------------------------------------------------ phase F (compose.cpp:392-493)
+  const long long tk1 = wall_clock64();
+  int nn = 0, na = 0;
+  {
+    const int ns1 = a.g1.n_start, ns2 = a.g2.n_start;
+    const int seeds = ns1 * ns2;  // (s1 outer, s2 inner), compose.cpp:392-401
+    for (int t0 = 0; t0 < seeds; t0 += WB) {
+      const int t = t0 + tid;
+      int idx = 0, ok = 0, s1 = 0, s2 = 0;
+      if (t < seeds) {
+        s1 = a.g1.start_list[t / ns2];
+        s2 = a.g2.start_list[t % ns2];
+        idx = s1 + N1 * s2;
+        ok = ld_agent(a.state + idx) == ST_REACH;
+      }
+      int tot;
+      const int off = block_scan(ok, sh_scan, tot);
+      if (ok) {
+        const int id = nn + off;
+        if (id < a.Ncap) {
+          a.pair_of[id] = idx;
+          a.nflags[id] = uint8_t(NF_START | (((a.g1.nflags[s1] & NF_ACCEPT) && (a.g2.nflags[s2] & NF_ACCEPT)) ? NF_ACCEPT : 0));
+        }
+      }
+      __syncthreads();  // every test of this chunk read ST_REACH before ids go in (a start pair is listed once)
+      if (ok && nn + off < a.Ncap) st_agent(a.state + idx, nn + off);
+      nn += tot;
+    }
+    if (nn > a.Ncap) sh_flag[1] = 1;
+  }
+  __syncthreads();
+  int lo = 0, hi = nn, L = 0, max_width = 0, max_level_arcs = 0;
+  while (lo < hi && !sh_flag[1]) {
+    if (tid == 0) a.level_off[L] = lo;
+    max_width = max(max_width, hi - lo);
+    // ---- pass A: valid candidates per frontier node (count kept in out_off until the scan)
+    for (int node = lo + wave; node < hi; node += WW) {
+      const int pr = a.pair_of[node];
+      const int n1 = pr % N1, n2 = pr / N1;
+      const bool em = wave_has_eps(a.g1, n1, false) && wave_has_eps(a.g2, n2, true);
+      const bool acc1 = (a.g1.nflags[n1] & NF_ACCEPT) != 0, acc2 = (a.g2.nflags[n2] & NF_ACCEPT) != 0;
+      const bool e1 = !em || acc2 || !acc1, e2 = !em || acc1;  // compose.cpp:461, :476
+      int c = 0;
+      wave_candidates<false, MATCH>(a, n1, n2, e1, e2, [&](bool has, int idx, int, int, int, int) {
+        const bool v = has && ld_agent(a.state + idx) != ST_UNREACH;
+        c += __popcll(__ballot(v));
+      });
+      if (lane == 0) st_agent(a.out_off + node, c);
+    }
+    __syncthreads();
+    int total = 0;
+    for (int c0 = lo; c0 < hi; c0 += 2 * WB) {
+      const int p0 = c0 + 2 * tid, p1 = p0 + 1;
+      const int v0 = p0 < hi ? ld_agent(a.out_off + p0) : 0, v1 = p1 < hi ? ld_agent(a.out_off + p1) : 0;
+      int tot;
+      const int base = block_scan(v0 + v1, sh_scan, tot);
+      if (p0 < hi) st_agent(a.out_off + p0, na + total + base);
+      if (p1 < hi) st_agent(a.out_off + p1, na + total + base + v0);
+      total += tot;
+    }
+    if (na + (long long)total > a.Acap) {
+      if (tid == 0) sh_flag[1] = 1;
+      __syncthreads();
+      break;
+    }
+    __syncthreads();
+    // ---- pass B: emit (dst provisionally the pair id), claim undiscovered destinations by arc rank
+    for (int node = lo + wave; node < hi; node += WW) {
+      const int pr = a.pair_of[node];
+      const int n1 = pr % N1, n2 = pr / N1;
+      const bool em = wave_has_eps(a.g1, n1, false) && wave_has_eps(a.g2, n2, true);
+      const bool acc1 = (a.g1.nflags[n1] & NF_ACCEPT) != 0, acc2 = (a.g2.nflags[n2] & NF_ACCEPT) != 0;
+      const bool e1 = !em || acc2 || !acc1, e2 = !em || acc1;
+      int run = ld_agent(a.out_off + node);
+      wave_candidates<false, MATCH>(a, n1, n2, e1, e2, [&](bool has, int idx, int i, int j, int il, int ol) {
+        int cur = ST_UNREACH;
+        if (has) cur = ld_agent(a.state + idx);
+        const bool v = cur != ST_UNREACH;
+        const unsigned long long m = __ballot(v);
+        if (v) {
+          const int ai = run + __popcll(m & lanes_below());
+          a.src[ai] = node;
+          a.dst[ai] = idx;
+          a.il[ai] = il;
+          a.ol[ai] = ol;
+          a.w[ai] = (i >= 0 ? a.g1.w[i] : 0.0f) + (j >= 0 ? a.g2.w[j] : 0.0f);
+          a.gi1[ai] = i;
+          a.gi2[ai] = j;
+          if (cur < 0) atomicMax(a.state + idx, claim_of(ai - na));
+        }
+        run += __popcll(m);
+      });
+    }
+    __syncthreads();
+    // ---- pass C: owners in arc order, a contiguous span of the level's arcs per wave
+    const int span = ((total + WW * 64 - 1) / (WW * 64)) * 64;
+    const int r_lo = min(wave * span, total), r_hi = min(r_lo + span, total);
+    {
+      int c = 0;
+      for (int r0 = r_lo; r0 < r_hi; r0 += 64) {
+        const int r = r0 + lane;
+        const bool own = r < r_hi && ld_agent(a.state + a.dst[na + r]) == claim_of(r);
+        c += __popcll(__ballot(own));
+      }
+      if (lane == 0) sh_w[wave] = c;
+    }
+    __syncthreads();
+    int newn = 0, obase = 0;
+#pragma unroll
+    for (int w = 0; w < WW; ++w) {
+      const int s = sh_w[w];
+      if (w < wave) obase += s;
+      newn += s;
+    }
+    if (nn + (long long)newn > a.Ncap) {
+      if (tid == 0) sh_flag[1] = 1;
+      __syncthreads();
+      break;
+    }
+    {
+      int run = obase;
+      for (int r0 = r_lo; r0 < r_hi; r0 += 64) {
+        const int r = r0 + lane;
+        int idx = 0;
+        bool own = false;
+        if (r < r_hi) {
+          idx = a.dst[na + r];
+          own = ld_agent(a.state + idx) == claim_of(r);
+        }
+        const unsigned long long mk = __ballot(own);
+        int id = -1;
+        if (own) {
+          id = nn + run + __popcll(mk & lanes_below());
+          const int d1 = idx % N1, d2 = idx / N1;
+          a.pair_of[id] = idx;
+          a.nflags[id] = uint8_t((((a.g1.nflags[d1] & NF_START) && (a.g2.nflags[d2] & NF_START)) ? NF_START : 0) |
+                                 (((a.g1.nflags[d1] & NF_ACCEPT) && (a.g2.nflags[d2] & NF_ACCEPT)) ? NF_ACCEPT : 0));
+        }
+        if (r < r_hi) a.in_list[na + r] = id;  // scratch: in_list is built by the transpose passes
+        run += __popcll(mk);
+      }
+    }
+    __syncthreads();  // every ownership test has read its claim
+    for (int r = tid; r < total; r += WB) {
+      const int id = a.in_list[na + r];
+      if (id >= 0) st_agent(a.state + a.dst[na + r], id);
+    }
+    __syncthreads();
+    bool lay = true;
+    for (int r = tid; r < total; r += WB) {
+      const int id = ld_agent(a.state + a.dst[na + r]);
+      a.dst[na + r] = id;
+      lay = lay && id >= hi;
+    }
+    if (!lay) sh_flag[0] = 0;
+    max_level_arcs = max(max_level_arcs, total);
+    na += total;
+    nn += newn;
+    lo = hi;
+    hi = nn;
+    ++L;
+    __syncthreads();
+  }
+  __syncthreads();
+  if (tid == 0) {
+    a.level_off[L] = nn;
+    a.out_off[nn < a.Ncap + 1 ? nn : a.Ncap] = na;
+    ComposeOut o{};
+    o.N = nn;
+    o.A = na;
+    o.L = L;
+    o.layered = sh_flag[0];
+    o.overflow = sh_flag[1];
+    o.max_width = max_width;
+    o.max_level_arcs = max_level_arcs;
+    o.csr_built = 0;
+    o.t_b = int(tk1 - tk0);
+    o.t_f = int(wall_clock64() - tk1);
+    *a.out = o;
+    if (sh_flag[1]) a.counts[0] = a.counts[1] = 0;
+  }
+}
+
+// stable label-sorted copy of every node's out- and in-records (key: olabel when the graph is searched as g1,
+// ilabel as g2): a workgroup per node, rank of an element = elements before it in (key, position) order
+__global__ __launch_bounds__(256) void sorted_view_kernel(DGraph g, int key_ol, gtnx_i4* __restrict__ out_view,
+                                                          gtnx_i4* __restrict__ in_view) {
+  const int n = blockIdx.x;
+  for (int side = 0; side < 2; ++side) {
+    const int b = (side ? g.in_off : g.out_off)[n], d = (side ? g.in_off : g.out_off)[n + 1] - b;
+    const GTNX_G gtnx_i4* rec = (side ? g.in_rec : g.out_rec) + b;
+    gtnx_i4* view = (side ? in_view : out_view) + b;
+    for (int e = threadIdx.x; e < d; e += blockDim.x) {
+      const gtnx_i4 r = rec[e];
+      const int key = key_ol ? r.y : r.x;
+      int rank = 0;
+      for (int x = 0; x < d; ++x) {
+        const gtnx_i4 o = rec[x];
+        const int k2 = key_ol ? o.y : o.x;
+        rank += (k2 < key) || (k2 == key && x < e);
+      }
+      view[rank] = r;
+    }
+  }
+}
+
 } // namespace
 
 int compose_wide_node_cap() { return NO_CAP; }
@@ -456,6 +860,22 @@ void launch_compose_wide(const ComposeArgs* d_args, int n, int lin2, int max_aca
     hipLaunchKernelGGL(compose_wide_plan_kernel<false>, dim3(n), dim3(WB), 0, st, d_args);
     hipLaunchKernelGGL(compose_wide_replicate_kernel<false>, dim3(g, n), dim3(RB), 0, st, d_args);
   }
+}
+
+void launch_compose_pairs(const ComposeArgs* d_args, int n, int matcher, hipStream_t st) {
+  if (n <= 0) return;
+  switch (matcher) {
+    case MATCH_UNSORTED: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_UNSORTED>, dim3(n), dim3(WB), 0, st, d_args); break;
+    case MATCH_SINGLY_G1: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_SINGLY_G1>, dim3(n), dim3(WB), 0, st, d_args); break;
+    case MATCH_SINGLY_G2: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_SINGLY_G2>, dim3(n), dim3(WB), 0, st, d_args); break;
+    default: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_DOUBLY>, dim3(n), dim3(WB), 0, st, d_args); break;
+  }
+}
+
+void launch_sorted_view(const DGraph& g, int key_olabel, void* out_view, void* in_view, hipStream_t st) {
+  if (g.N <= 0 || g.A <= 0) return;
+  hipLaunchKernelGGL(sorted_view_kernel, dim3(g.N), dim3(256), 0, st, g, key_olabel, static_cast<gtnx_i4*>(out_view),
+                     static_cast<gtnx_i4*>(in_view));
 }
 
 } // namespace gtnx

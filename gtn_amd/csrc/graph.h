@@ -85,6 +85,10 @@ struct Structure {
   DevMemP dev_mem;  // owner (may be shared by a whole batch)
   DGraph dview{};   // pointers into dev_mem (w unset)
   DevMemP rec_mem;  // packed adjacency records of a device-built structure (made on demand)
+  // stable label-sorted copies of the adjacency records ([0] by ilabel, [1] by olabel; out records then in
+  // records), made on demand for compose_pairs_kernel when this graph is searched without being sorted
+  DevMemP sview_mem[2];
+  const void* sview_of[2] = {nullptr, nullptr};  // the out_rec array the view was made from
 
   std::shared_ptr<Schedule> sched;  // valid while the structure is unchanged
   std::mutex grad_lock;             // graph.h:450

@@ -259,6 +259,13 @@ struct ComposeArgs {
   GTNX_G int* accept_list; // [Ncap]
   GTNX_G int* counts;      // [2] n_start, n_accept
   GTNX_G ComposeOut* out;
+  // compose_pairs_kernel only: the lists it binary-searches, sorted on the matched label -- g1's out / in
+  // records by olabel, g2's by ilabel (the graph's own records when it is sorted on that label, else a stable
+  // sorted view made by launch_sorted_view); null for a side the matcher never searches
+  const GTNX_G gtnx_i4* s1_out;
+  const GTNX_G gtnx_i4* s1_in;
+  const GTNX_G gtnx_i4* s2_out;
+  const GTNX_G gtnx_i4* s2_in;
 };
 // dyn_lds_bytes: 2 bitmaps of N1*N2 bits for the largest pair table of the batch
 // when every graph has lds_state set, else 0
@@ -281,6 +288,11 @@ void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int
 // launch_compose_transpose() follows.
 int compose_wide_node_cap();
 void launch_compose_wide(const ComposeArgs* d_args, int n, int lin2, int max_acap, hipStream_t st);
+// compose_wide.hip, general products (both graphs explicit, any degrees, epsilons allowed): a wave per frontier
+// pair.  `state` must arrive filled with INT_MIN; s1_* / s2_* set for the side(s) `matcher` searches (UNSORTED
+// searches g2 through its sorted view).  Leaves csr_built = 0.
+void launch_compose_pairs(const ComposeArgs* d_args, int n, int matcher, hipStream_t st);
+void launch_sorted_view(const DGraph& g, int key_olabel, void* out_view /* [A] 16-byte records */, void* in_view, hipStream_t st);
 struct ComposeFillArgs {
   int N, A;
   const GTNX_G int* out_off;

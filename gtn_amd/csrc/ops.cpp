@@ -112,6 +112,20 @@ void ensure_records(Structure& st) {
   st.dview.in_rec = irec;
 }
 
+// label-sorted view of an explicit structure's records (see Structure::sview_mem); needs ensure_records()
+static const gtnx_i4* sorted_view(Structure& st, bool key_ol, bool in_lists) {
+  if (st.A == 0) return nullptr;
+  const int k = key_ol ? 1 : 0;
+  if (!st.sview_mem[k] || st.sview_of[k] != st.dview.out_rec) {
+    Runtime& rt = Runtime::get();
+    st.sview_mem[k] = rt.alloc(32 * size_t(st.A));
+    gtnx_i4* ov = st.sview_mem[k]->as<gtnx_i4>();
+    launch_sorted_view(st.dview, k, ov, ov + st.A, rt.stream());
+    st.sview_of[k] = st.dview.out_rec;
+  }
+  return st.sview_mem[k]->as<gtnx_i4>() + (in_lists ? st.A : 0);
+}
+
 float* grad_dev_ptr(Graph& out) {
   // the incoming delta of an output graph, resident on the device
   Graph& gr = out.grad();
@@ -1400,7 +1414,28 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const bool sorted_on_match = l1 ? ex.ilabel_sorted : ex.olabel_sorted;
       wide_ok[i] = (ex.dview.flags & GF_EPS_FREE) && ch.M >= 1 && ex.N >= 1 && ex.N <= compose_wide_node_cap() &&
                    (!sorted_claim || sorted_on_match);
-      wide_pref[i] = wide_ok[i] && ex.A > 4 * ex.N;
+      wide_pref[i] = wide_ok[i] && (ex.A > 4 * ex.N || getenv("GTNX_FORCE_WIDE_COMPOSE"));
+    }
+  }
+  // Products of two explicit graphs with wide nodes take compose_wide.hip's wave-per-pair kernel.  It searches
+  // sorted lists only (an unsorted second graph through a stable sorted view), so a graph that is matched as
+  // "sorted" must be sorted on the label being matched.
+  std::vector<char> pairs_ok(n, 0), pairs_pref(n, 0);
+  auto matcher_of = [&](const Structure& s1, const Structure& s2) {
+    const bool c1 = intersect ? (s1.ilabel_sorted || s1.olabel_sorted) : s1.olabel_sorted;
+    const bool c2 = intersect ? (s2.ilabel_sorted || s2.olabel_sorted) : s2.ilabel_sorted;
+    return (c1 && c2) ? MATCH_DOUBLY : (c1 ? MATCH_SINGLY_G1 : (c2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
+  };
+  if (!getenv("GTNX_NO_WIDE_COMPOSE") && !getenv("GTNX_NO_PAIRS_COMPOSE")) {
+    for (size_t i = 0; i < n; ++i) {
+      const Structure& s1 = *bcast(av, n, i).s;
+      const Structure& s2 = *bcast(bv, n, i).s;
+      if (s1.kind != KIND_EXPLICIT || s2.kind != KIND_EXPLICIT) continue;
+      const int m = matcher_of(s1, s2);
+      const bool t1 = (m == MATCH_DOUBLY || m == MATCH_SINGLY_G1) ? s1.olabel_sorted : true;
+      const bool t2 = (m == MATCH_DOUBLY || m == MATCH_SINGLY_G2) ? s2.ilabel_sorted : true;
+      pairs_ok[i] = t1 && t2;
+      pairs_pref[i] = pairs_ok[i] && (s1.A > 4 * s1.N || s2.A > 4 * s2.N || getenv("GTNX_FORCE_WIDE_COMPOSE"));
     }
   }
   // 512-lane workgroups when some chain product's partner has 257..512 nodes (and none more)
@@ -1444,7 +1479,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
           mine = compose_chain_bitmap_bytes(No, slices);
         }
       }
-      if (wide_pref[i]) continue;  // never runs the FAST variant
+      if (wide_pref[i] || pairs_pref[i]) continue;  // never runs the FAST variant
       fast_ok = fast_ok && mine <= budget;
       fast_bm = std::max(fast_bm, mine);
     }
@@ -1526,7 +1561,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   // wider than the workgroup), at most KC candidates per node (out-degree), a level's
   // arcs within the claim hash, a bitmap window over all times, arrays left out.
   bool defer = lds_state && n > 0 && !getenv("GTNX_SYNC_COMPOSE");
-  for (size_t i = 0; i < n && defer; ++i) defer = !wide_pref[i];
+  for (size_t i = 0; i < n && defer; ++i) defer = !wide_pref[i] && !pairs_pref[i];
   for (size_t i = 0; i < n && defer; ++i) {
     Graph& a = const_cast<Graph&>(bcast(av, n, i));
     Graph& b = const_cast<Graph&>(bcast(bv, n, i));
@@ -1553,7 +1588,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   const ComposeOut* res_out = reinterpret_cast<const ComposeOut*>(hdr.data() + hdr_out);
   const int* res_counts = reinterpret_cast<const int*>(hdr.data() + hdr_cnt);
   std::shared_ptr<DeferredSizes> deferred;
-  // kind: 0 the general variant, 1 FAST, 2 compose_wide.hip
+  // kind: 0 the general variant, 1 FAST, 2 compose_wide.hip (chain products), 3 compose_wide.hip (explicit pairs)
   auto run = [&](std::vector<size_t> order, int kind) {
     const bool fast = kind == 1;
     const size_t m = order.size();
@@ -1570,6 +1605,25 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         sorted_args[i].skip = 0;
         if (!sorted_args[i].lds_state) fill_state();
       }
+      if (kind == 3) {  // the lists the wave-per-pair kernel searches
+        fill_state();
+        ComposeArgs& x = sorted_args[i];
+        Structure& s1 = *bcast(av, n, order[i]).s;
+        Structure& s2 = *bcast(bv, n, order[i]).s;
+        x.s1_out = x.s1_in = x.s2_out = x.s2_in = nullptr;
+        if (x.matcher == MATCH_DOUBLY || x.matcher == MATCH_SINGLY_G1) {
+          x.s1_out = x.g1.out_rec;
+          x.s1_in = x.g1.in_rec;
+        }
+        if (x.matcher == MATCH_DOUBLY || x.matcher == MATCH_SINGLY_G2) {
+          x.s2_out = x.g2.out_rec;
+          x.s2_in = x.g2.in_rec;
+        }
+        if (x.matcher == MATCH_UNSORTED) {
+          x.s2_out = sorted_view(s2, false, false);
+          x.s2_in = sorted_view(s2, false, true);
+        }
+      }
     }
     DevMemP dargs = upload_vec(sorted_args);
     DevMemP tscratch = rt.alloc(compose_transpose_scratch_bytes(int(m), int(maxN)));
@@ -1582,7 +1636,13 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         launch_compose_wide(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key_of(order[g0]) & 1, int(acap), rt.stream());
         g0 = g1;
       }
-      for (size_t g0 = 0; g0 < m && kind != 2;) {
+      for (size_t g0 = 0; g0 < m && kind == 3;) {
+        size_t g1 = g0;
+        while (g1 < m && (key_of(order[g1]) >> 2) == (key_of(order[g0]) >> 2)) ++g1;
+        launch_compose_pairs(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key_of(order[g0]) >> 2, rt.stream());
+        g0 = g1;
+      }
+      for (size_t g0 = 0; g0 < m && kind < 2;) {
         size_t g1 = g0;
         while (g1 < m && key_of(order[g1]) == key_of(order[g0])) ++g1;
         const int key = key_of(order[g0]);
@@ -1624,22 +1684,30 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     }
   };
   {
-    std::vector<size_t> all, wides;
-    for (size_t i = 0; i < n; ++i) (wide_pref[i] ? wides : all).push_back(i);
+    std::vector<size_t> all, wides, pairs;
+    for (size_t i = 0; i < n; ++i) (wide_pref[i] ? wides : pairs_pref[i] ? pairs : all).push_back(i);
     if (defer) deferred_limit(1);  // the host runs at most two batches ahead of the GPU
     if (!all.empty()) run(all, lds_state ? 1 : 0);
     if (!wides.empty()) run(wides, 2);
+    if (!pairs.empty()) run(pairs, 3);
     // pairs the FAST variant handed back: chain products go to compose_wide.hip whatever their degrees (a node
     // with many IN-arcs stops the FAST variant's backward pass too; bit rows per time do not care), the rest to
     // the general variant
-    std::vector<size_t> redo, redo_wide;
+    std::vector<size_t> redo, redo_wide, redo_pairs;
     for (size_t i = 0; i < n && !deferred; ++i)
-      if (res_out[i].overflow == 2) (wide_ok[i] && !wide_pref[i] ? redo_wide : redo).push_back(i);
+      if (res_out[i].overflow == 2) {
+        const Structure& s1 = *bcast(av, n, i).s;
+        const Structure& s2 = *bcast(bv, n, i).s;
+        if (wide_ok[i] && !wide_pref[i]) redo_wide.push_back(i);
+        else if (pairs_ok[i] && !pairs_pref[i] && (s1.A > 2 * s1.N || s2.A > 2 * s2.N)) redo_pairs.push_back(i);
+        else redo.push_back(i);
+      }
     if (!redo_wide.empty()) {
       run(redo_wide, 2);
       for (size_t i : redo_wide)
         if (res_out[i].overflow == 2) redo.push_back(i);
     }
+    if (!redo_pairs.empty()) run(redo_pairs, 3);
     if (getenv("GTNX_COMPOSE_STATS") && !deferred)
       fprintf(stderr, "[gtnx] compose: n=%zu redo=%zu graph0: N=%d A=%d levels=%d replicated=%d  us: B=%.0f F=%.0f (rep %.0f)\n", n, redo.size(),
               res_out[0].N, res_out[0].A, res_out[0].L, res_out[0].rep_levels, res_out[0].t_b * 0.01,

@@ -1036,3 +1036,84 @@ def test_wide_chain_products_vs_oracle(gtn, kind, T, C, chain_first, mode):
     ge, gp = (g1, g2) if chain_first else (g2, g1)
     np.testing.assert_allclose(e.grad().weights_to_numpy(), ge, rtol=1e-3, atol=1e-4)
     np.testing.assert_allclose(p.grad().weights_to_numpy(), gp, rtol=1e-3, atol=2e-4)
+
+
+def test_wide_node_kernels_forced_on_every_eligible_product(gtn, golden):
+    """GTNX_FORCE_WIDE_COMPOSE=1 sends every product compose_wide.hip can take through it, whatever the degrees
+    (chain products: the plan / replication kernels; explicit pairs: the wave-per-pair kernel incl. the sorted
+    view for unsorted graphs and the epsilon moves): the golden compose fixtures of the reference build -- exact
+    node ids and arc order -- and the CTC structure tests again"""
+    import os
+    os.environ["GTNX_FORCE_WIDE_COMPOSE"] = "1"
+    try:
+        test_golden_compose(gtn, golden)
+        test_compose_linear_first_structure_vs_oracle(gtn, 120, 20, 8)
+        test_batched_ctc_vs_oracle(gtn, 4, 300, 64, 30)
+        test_asg_shape_vs_oracle(gtn)
+    finally:
+        os.environ.pop("GTNX_FORCE_WIDE_COMPOSE", None)
+
+
+@pytest.mark.parametrize("sort1,sort2", [(None, None), ("o", "i"), (None, "i"), ("o", None)])
+@pytest.mark.parametrize("eps", [0.0, 0.15])
+def test_wide_explicit_pairs_vs_oracle(gtn, sort1, sort2, eps):
+    """two explicit graphs with tens of arcs per node (benchmarks/functions.cpp:97-129 in small: chains with
+    parallel arcs and self loops; then random cyclic graphs), every matcher: node ids, arc order, weights"""
+    rng = np.random.default_rng(11 + (sort1 is not None) * 2 + (sort2 is not None) + int(eps * 100))
+    cases = []
+    # chains: N1 steps x A1 labels against N2 steps x A2 labels with self loops (distinct labels per node)
+    N1, A1, N2, A2 = 12, 7, 6, 40
+    d1 = {"start": [1] + [0] * N1, "accept": [0] * N1 + [1], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": sort1}
+    for m in range(N1):
+        for l in rng.permutation(A1):
+            d1["src"].append(m); d1["dst"].append(m + 1); d1["il"].append(int(l)); d1["ol"].append(int(l))
+    d2 = {"start": [1] + [0] * N2, "accept": [0] * N2 + [1], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": sort2}
+    for m in range(N2):
+        for l in rng.permutation(A2):
+            d2["src"].append(m); d2["dst"].append(m + 1); d2["il"].append(int(l)); d2["ol"].append(int(l))
+        for l in rng.permutation(A2):
+            d2["src"].append(m); d2["dst"].append(m); d2["il"].append(int(l) + A2); d2["ol"].append(int(l) + A2)
+    for l in range(A1):   # self loops on the last node so that the first chain can finish
+        d2["src"].append(N2); d2["dst"].append(N2); d2["il"].append(l); d2["ol"].append(l)
+    for d in (d1, d2):
+        d["w"] = gg._f32(rng.normal(0, 1, len(d["src"])))
+    cases.append((d1, d2))
+    # random graphs, distinct labels per node on the sorted side(s)
+    for _ in range(3):
+        pair = []
+        for which in range(2):
+            N = int(rng.integers(8, 30))
+            nl = 24
+            d = {"start": [int(x) for x in rng.random(N) < 0.3], "accept": [int(x) for x in rng.random(N) < 0.3],
+                 "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": (sort1, sort2)[which]}
+            d["start"][0] = 1
+            d["accept"][-1] = 1
+            for m in range(N):
+                # (several epsilons per node are equal sort keys: at most 16 arcs then, where std::sort is stable)
+                deg = int(rng.integers(0, 17 if eps > 0 else nl))
+                a_l, b_l = rng.permutation(nl)[:deg], rng.permutation(nl)[:deg]
+                for x, y in zip(a_l, b_l):
+                    d["src"].append(m); d["dst"].append(int(rng.integers(0, N)))
+                    il, ol = int(x), int(y)
+                    if eps > 0 and rng.random() < eps:
+                        # epsilons on the matched side: olabel of the first graph, ilabel of the second
+                        if which == 0: ol = gg.EPS
+                        else: il = gg.EPS
+                    d["il"].append(il); d["ol"].append(ol)
+            d["w"] = gg._f32(rng.normal(0, 1, len(d["src"])))
+            pair.append(d)
+        cases.append(tuple(pair))
+    for d1, d2 in cases:
+        g1, g2 = gg.to_api(gtn, d1), gg.to_api(gtn, d2)
+        comp = gtn.compose(g1, g2)
+        oc = OGraph.from_dict(d1).compose(OGraph.from_dict(d2))
+        assert (comp.num_nodes(), comp.num_arcs()) == (oc.N, oc.A)
+        got, want = gg.from_api(comp), oc.to_dict()
+        for k in ("start", "accept", "src", "dst", "il", "ol"):
+            assert got[k] == want[k], k
+        assert got["w"] == want["w"]
+        if oc.A:
+            gtn.backward(comp)
+            g1g, g2g = oc.compose_grad(np.ones(oc.A, np.float32), len(d1["src"]), len(d2["src"]))
+            np.testing.assert_allclose(g1.grad().weights_to_numpy(), g1g, rtol=1e-6)
+            np.testing.assert_allclose(g2.grad().weights_to_numpy(), g2g, rtol=1e-6)

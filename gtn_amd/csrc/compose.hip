@@ -381,6 +381,10 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
   // step -- ids + W, arc ids + Aw, chain arc + C -- and is emitted from registers
   // for all remaining stationary t at once instead of one BFS level at a time.
   const bool skip = FAST && a.skip != 0;  // derivable arrays are left out (see ComposeArgs::skip)
+  // the stationary levels are written by compose_wide.hip's replication kernel, launched behind this one: this
+  // workgroup only records which level to copy and leaves the hole (ComposeOut::wr_*)
+  const bool rep_grid = FAST && a.rep_grid != 0;
+  int wr_L = 0, wr_K = 0, wr_lo = 0, wr_W = 0, wr_na = 0, wr_Aw = 0;
   // pair -> node id table in HBM: only ever read back for pairs discovered in an earlier
   // chunk of the same level or across levels (non-layered arcs); with single-chunk levels
   // (skip) in the time-windowed layout neither can happen, so the writes are dropped too
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
           for (int m = 0; m < KC; ++m) {
             if (my_ai[m] >= 0) {
               const int pos = atomicAdd(&incur[my_dst[m] - hi], 1);
-              if (!skip) a.in_list[pos] = my_ai[m];
+              if (!skip || rep_grid) a.in_list[pos] = my_ai[m];  // (the replication kernel reads its template level's)
               a.in_src[pos] = lo + tid;
               a.in_w[pos] = my_w[m];
               if (REP) my_pos[m] = pos;
@@ -1027,6 +1031,9 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
             newn_level == W && W > 0 && K >= 2 && nn + (long long)K * W <= a.Ncap &&
             na + (long long)K * Aw <= a.Acap) {
           const long long tr0 = wall_clock64();
+          if (rep_grid && wr_K == 0) {
+            wr_L = L; wr_K = K; wr_lo = lo; wr_W = W; wr_na = na_level; wr_Aw = Aw;
+          } else {
           const GTNX_G float* cw = L2 ? a.g2.w : a.g1.w;  // chain weights, one row per time step
           float wfix[KC];
           int carc[KC];
@@ -1166,6 +1173,7 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
             }
           }
           for (int k = 1 + tid; k <= K; k += kBlock) a.level_off[L + k] = lo + k * W;
+          }  // (inline replication)
           // the last replicated level's new nodes are the next frontier
           if (tid < W) front[fcur ^ 1][tid] += K * tshift;
           nn += K * W;
@@ -1207,6 +1215,7 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
     o.t_b = int(tk1 - tk0);
     o.t_f = int(wall_clock64() - tk1);
     o.t_rep = int(tk_rep);
+    o.wr_L = wr_L; o.wr_K = wr_K; o.wr_lo = wr_lo; o.wr_W = wr_W; o.wr_na = wr_na; o.wr_Aw = wr_Aw;
     o.csr_built = sh_flag[2] && sh_flag[0] && lists_ok;
     if (lists_ok) {
       a.counts[0] = ns_tot;

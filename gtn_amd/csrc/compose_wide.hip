@@ -843,6 +843,85 @@ __global__ __launch_bounds__(256) void sorted_view_kernel(DGraph g, int key_ol, 
   }
 }
 
+
+// The same for compose.hip's FAST variant (ComposeArgs::rep_grid): its products also carry the in-arc rows
+// (in_off / in_src / in_w, and in_list unless `skip`), and in `skip` mode leave src / il / ol out.  The in-row
+// slot p of the template level holds arc in_list[p]: its copy k levels later is that arc's copy.
+template <bool L2>
+__global__ __launch_bounds__(RB) void compose_replicate_kernel(const ComposeArgs* __restrict__ args) {
+  const ComposeArgs a = args[blockIdx.y];
+  const ComposeOut o = *a.out;
+  const int K = o.wr_K;
+  if (K <= 0 || o.overflow) return;
+  const int L0 = o.wr_L, lo = o.wr_lo, W = o.wr_W, na0 = o.wr_na, Aw = o.wr_Aw;
+  const int hi = lo + W;
+  const bool skip = o.skipped != 0;
+  const int C = L2 ? a.g2.C : a.g1.C;
+  const GTNX_G float* __restrict__ cw = L2 ? a.g2.w : a.g1.w;
+  const GTNX_G float* __restrict__ fw = L2 ? a.g1.w : a.g2.w;
+  const int tid = threadIdx.x;
+  const int etiles = (Aw + RB - 1) / RB, ktiles = (K + RK - 1) / RK;
+  for (int tile = blockIdx.x; tile < etiles * ktiles; tile += gridDim.x) {
+    const int e = (tile % etiles) * RB + tid;
+    const int k0 = (tile / etiles) * RK + 1, k1 = min(k0 + RK, K + 1);
+    if (e < Aw) {
+      const int t = na0 + e;
+      const int d = a.dst[t], g1 = a.gi1[t], g2 = a.gi2[t];
+      const int ca = L2 ? g2 : g1, fa = L2 ? g1 : g2;
+      const float wf = fw[fa];
+      // the in-row slot with this index
+      const int is = a.in_src[t], ia = a.in_list[t];
+      const int ica = L2 ? a.gi2[ia] : a.gi1[ia];
+      const float iwf = fw[L2 ? a.gi1[ia] : a.gi2[ia]];
+      int s = 0, il = 0, ol = 0;
+      if (!skip) {
+        s = a.src[t];
+        il = a.il[t];
+        ol = a.ol[t];
+      }
+      float wc[RK], iwc[RK];
+#pragma unroll
+      for (int u = 0; u < RK; ++u) {
+        wc[u] = k0 + u < k1 ? cw[ca + (k0 + u) * C] : 0.0f;
+        iwc[u] = k0 + u < k1 ? cw[ica + (k0 + u) * C] : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < RK; ++u) {
+        const int k = k0 + u;
+        if (k >= k1) break;
+        const int ai = t + k * Aw;
+        a.dst[ai] = d + k * W;
+        a.w[ai] = wf + wc[u];
+        a.gi1[ai] = L2 ? fa : ca + k * C;
+        a.gi2[ai] = L2 ? ca + k * C : fa;
+        a.in_src[ai] = is + k * W;
+        a.in_w[ai] = iwf + iwc[u];
+        if (!skip) {
+          a.src[ai] = s + k * W;
+          a.il[ai] = il;
+          a.ol[ai] = ol;
+          a.in_list[ai] = ia + k * Aw;
+        }
+      }
+    }
+  }
+  const int ntiles = (W + RB - 1) / RB;
+  for (int tile = blockIdx.x; tile < ntiles * ktiles; tile += gridDim.x) {
+    const int x = (tile % ntiles) * RB + tid;
+    const int k0 = (tile / ntiles) * RK + 1, k1 = min(k0 + RK, K + 1);
+    if (x < W) {
+      const int oo = a.out_off[lo + x], io = a.in_off[hi + x];
+      for (int k = k0; k < k1; ++k) {
+        a.out_off[lo + k * W + x] = oo + k * Aw;
+        a.in_off[hi + k * W + x] = io + k * Aw;
+        a.nflags[hi + k * W + x] = 0;  // neither start (t > 0) nor accept (t < T)
+      }
+    }
+  }
+  if (blockIdx.x == 0)
+    for (int k = 1 + tid; k <= K; k += RB) a.level_off[L0 + k] = lo + k * W;
+}
+
 } // namespace
 
 int compose_wide_node_cap() { return NO_CAP; }
@@ -860,6 +939,15 @@ void launch_compose_wide(const ComposeArgs* d_args, int n, int lin2, int max_aca
     hipLaunchKernelGGL(compose_wide_plan_kernel<false>, dim3(n), dim3(WB), 0, st, d_args);
     hipLaunchKernelGGL(compose_wide_replicate_kernel<false>, dim3(g, n), dim3(RB), 0, st, d_args);
   }
+}
+
+void launch_compose_replicate(const ComposeArgs* d_args, int n, int lin2, int max_acap, hipStream_t st) {
+  if (n <= 0) return;
+  int g = (max_acap + RB * RK - 1) / (RB * RK);
+  g = g < 1 ? 1 : (g > 4096 ? 4096 : g);
+  if (n > 1) g = g > (8192 / n + 1) ? (8192 / n + 1) : g;
+  if (lin2) hipLaunchKernelGGL(compose_replicate_kernel<true>, dim3(g, n), dim3(RB), 0, st, d_args);
+  else hipLaunchKernelGGL(compose_replicate_kernel<false>, dim3(g, n), dim3(RB), 0, st, d_args);
 }
 
 void launch_compose_pairs(const ComposeArgs* d_args, int n, int matcher, hipStream_t st) {

@@ -774,7 +774,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
       v.C = s->C;
       v.n_start = 1;
       v.n_accept = s->M > 0 ? 1 : 0;
-      v.flags = 3 | GF_EPS_FREE;
+      v.flags = 3 | GF_EPS_FREE | GF_ACCEPTOR;
       s->dev_valid = true;
       continue;
     }
@@ -830,11 +830,12 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     std::memcpy(hb + o.ol_, s->out_list.data(), 4 * A);
     std::memcpy(hb + o.io, s->in_off.data(), 4 * (N + 1));
     std::memcpy(hb + o.il_, s->in_list.data(), 4 * A);
-    bool eps_free = true;
+    bool eps_free = true, acceptor = true;
     {
       int* orec = reinterpret_cast<int*>(hb + o.orec);
       int* irec = reinterpret_cast<int*>(hb + o.irec);
       for (size_t k = 0; k < A; ++k) eps_free = eps_free && s->il[k] >= 0 && s->ol[k] >= 0;
+      for (size_t k = 0; k < A && acceptor; ++k) acceptor = s->il[k] == s->ol[k];
       for (size_t k = 0; k < A; ++k) {
         const int ao = s->out_list[k], ai = s->in_list[k];
         orec[4 * k + 0] = s->il[ao]; orec[4 * k + 1] = s->ol[ao]; orec[4 * k + 2] = s->dst[ao]; orec[4 * k + 3] = ao;
@@ -848,7 +849,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     v.A = int(A);
     v.n_start = int(s->start.size());
     v.n_accept = int(s->accept.size());
-    v.flags = (s->ilabel_sorted ? 1 : 0) | (s->olabel_sorted ? 2 : 0) | (eps_free ? GF_EPS_FREE : 0);
+    v.flags = (s->ilabel_sorted ? 1 : 0) | (s->olabel_sorted ? 2 : 0) | (eps_free ? GF_EPS_FREE : 0) | (acceptor ? GF_ACCEPTOR : 0);
     v.src = reinterpret_cast<const int*>(db + o.src);
     v.dst = reinterpret_cast<const int*>(db + o.dst);
     v.il = reinterpret_cast<const int*>(db + o.il);

@@ -41,7 +41,7 @@ struct DGraph {
   int N, A;
   int M, C;
   int n_start, n_accept;
-  int flags;  // bit0 ilabelSorted, bit1 olabelSorted, bit2 GF_EPS_FREE (no epsilon label on any arc)
+  int flags;  // bit0 ilabelSorted, bit1 olabelSorted, bit2 GF_EPS_FREE (no epsilon label on any arc), bit3 GF_ACCEPTOR
   const GTNX_G int* src;
   const GTNX_G int* dst;
   const GTNX_G int* il;
@@ -221,6 +221,7 @@ struct ComposeOut {
 };
 
 constexpr int GF_EPS_FREE = 4;
+constexpr int GF_ACCEPTOR = 8;  // ilabel == olabel on every arc (known at upload; products of acceptors inherit it)
 
 struct ComposeArgs {
   DGraph g1, g2;
@@ -234,6 +235,9 @@ struct ComposeArgs {
   // FAST variant, chain product with an epsilon-free partner: > 0 selects the time-windowed
   // bitmap layout with this many time slices (compose.hip); 0 = classic pair-indexed bitmaps
   int chain_bits;
+  // FAST variant, chain products: != 0 leaves the stationary levels to launch_compose_replicate(), which must
+  // follow on the same stream (ComposeOut::wr_* is the hand-over)
+  int rep_grid;
   int Ncap, Acap;
   GTNX_G int* state;     // [N1*N2] pair -> INT_MIN unreachable / R / claim / node id
   GTNX_G int* queue;     // [N1*N2] backward-BFS queue of pair ids
@@ -286,6 +290,9 @@ void launch_compose(const ComposeArgs* d_args, int n, int matcher, int lin1, int
 // of at most compose_wide_node_cap() nodes whose arcs match in the partner's list order (see the file's header);
 // any out-degree.  All n pairs share `lin2` (the chain is the second graph).  Leaves ComposeOut::csr_built = 0:
 // launch_compose_transpose() follows.
+// the stationary levels a FAST chain-product launch left out (ComposeArgs::rep_grid): arcs, in-rows, node
+// arrays of levels wr_L + 1 .. wr_L + wr_K from level wr_L, with as many workgroups as the output deserves
+void launch_compose_replicate(const ComposeArgs* d_args, int n, int lin2, int max_acap, hipStream_t st);
 int compose_wide_node_cap();
 void launch_compose_wide(const ComposeArgs* d_args, int n, int lin2, int max_acap, hipStream_t st);
 // compose_wide.hip, general products (both graphs explicit, any degrees, epsilons allowed): a wave per frontier

@@ -1411,7 +1411,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const Structure& ex = l1 ? s2 : s1;
       const Structure& ch = l1 ? s1 : s2;
       const bool sorted_claim = intersect ? (ex.ilabel_sorted || ex.olabel_sorted) : (l1 ? ex.ilabel_sorted : ex.olabel_sorted);
-      const bool sorted_on_match = l1 ? ex.ilabel_sorted : ex.olabel_sorted;
+      // (an acceptor sorted on either label is sorted on both)
+      const bool sorted_on_match = (l1 ? ex.ilabel_sorted : ex.olabel_sorted) || ((ex.dview.flags & GF_ACCEPTOR) && sorted_claim);
       wide_ok[i] = (ex.dview.flags & GF_EPS_FREE) && ch.M >= 1 && ex.N >= 1 && ex.N <= compose_wide_node_cap() &&
                    (!sorted_claim || sorted_on_match);
       wide_pref[i] = wide_ok[i] && (ex.A > 4 * ex.N || getenv("GTNX_FORCE_WIDE_COMPOSE"));
@@ -1432,8 +1433,11 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const Structure& s2 = *bcast(bv, n, i).s;
       if (s1.kind != KIND_EXPLICIT || s2.kind != KIND_EXPLICIT) continue;
       const int m = matcher_of(s1, s2);
-      const bool t1 = (m == MATCH_DOUBLY || m == MATCH_SINGLY_G1) ? s1.olabel_sorted : true;
-      const bool t2 = (m == MATCH_DOUBLY || m == MATCH_SINGLY_G2) ? s2.ilabel_sorted : true;
+      // (an acceptor sorted on either label is sorted on both)
+      const bool a1 = (s1.dview.flags & GF_ACCEPTOR) && (s1.ilabel_sorted || s1.olabel_sorted);
+      const bool a2 = (s2.dview.flags & GF_ACCEPTOR) && (s2.ilabel_sorted || s2.olabel_sorted);
+      const bool t1 = (m == MATCH_DOUBLY || m == MATCH_SINGLY_G1) ? (s1.olabel_sorted || a1) : true;
+      const bool t2 = (m == MATCH_DOUBLY || m == MATCH_SINGLY_G2) ? (s2.ilabel_sorted || a2) : true;
       pairs_ok[i] = t1 && t2;
       pairs_pref[i] = pairs_ok[i] && (s1.A > 4 * s1.N || s2.A > 4 * s2.N || getenv("GTNX_FORCE_WIDE_COMPOSE"));
     }
@@ -1520,6 +1524,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     x.matcher = (s1 && s2) ? MATCH_DOUBLY : (s1 ? MATCH_SINGLY_G1 : (s2 ? MATCH_SINGLY_G2 : MATCH_UNSORTED));
     x.lds_state = classic_ok[i] ? 1 : 0;  // read by the general variant only (FAST implies LDS)
     x.chain_bits = chain_slices[i];
+    x.rep_grid = 0;
     {
       // chain product, epsilon-free partner no wider than a workgroup: every level is a
       // single fast chunk, so the FAST variant may leave the derivable arrays out
@@ -1588,10 +1593,21 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
   const ComposeOut* res_out = reinterpret_cast<const ComposeOut*>(hdr.data() + hdr_out);
   const int* res_counts = reinterpret_cast<const int*>(hdr.data() + hdr_cnt);
   std::shared_ptr<DeferredSizes> deferred;
+  // who writes a FAST chain product's stationary levels: the pair's own workgroup (inline), or the replication
+  // kernel of compose_wide.hip behind it.  A batch of hundreds of pairs fills the chip with its own workgroups
+  // (C3, 512 pairs: 2.95 ms inline, 5.4 ms through the grid); a single utterance has ONE workgroup writing
+  // 18 MB (benchmarks/ctc.cpp ctcLoss: 1.95 ms inline, where the grid takes a fraction).
+  const char* rep_env = getenv("GTNX_GRID_REPLICATION");
+  auto inline_rep_for = [&](size_t pairs) {
+    if (getenv("GTNX_INLINE_REPLICATION")) return true;
+    if (rep_env) return rep_env[0] == '0';
+    return pairs > 128;
+  };
   // kind: 0 the general variant, 1 FAST, 2 compose_wide.hip (chain products), 3 compose_wide.hip (explicit pairs)
   auto run = [&](std::vector<size_t> order, int kind) {
     const bool fast = kind == 1;
     const size_t m = order.size();
+    const bool inline_rep = inline_rep_for(m);
     double alg = 0;
     for (size_t i : order) alg += 36.0 * double(caps[i].Acap) + 8.0 * double(caps[i].Ncap);
     if (kind == 2)  // one launch per side the chain is on
@@ -1605,6 +1621,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         sorted_args[i].skip = 0;
         if (!sorted_args[i].lds_state) fill_state();
       }
+      // FAST chain products: stationary levels by the replication kernel behind the compose launch
+      sorted_args[i].rep_grid = (fast && !inline_rep && (sorted_args[i].g1.kind == KIND_LINEAR) != (sorted_args[i].g2.kind == KIND_LINEAR)) ? 1 : 0;
       if (kind == 3) {  // the lists the wave-per-pair kernel searches
         fill_state();
         ComposeArgs& x = sorted_args[i];
@@ -1649,6 +1667,11 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         launch_compose(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key >> 2, (key >> 1) & 1, key & 1,
                        fast ? dyn_fast : int(classic_bm), fast ? 1 : 0, (fast && cache1) ? 1 : 0,
                        (fast && wide) ? 1 : 0, rt.stream());
+        if (fast && !inline_rep && ((key >> 1) & 1) != (key & 1)) {
+          int64_t acap = 0;
+          for (size_t q = g0; q < g1; ++q) acap = std::max(acap, caps[order[q]].Acap);
+          launch_compose_replicate(dargs->as<ComposeArgs>() + g0, int(g1 - g0), key & 1, int(acap), rt.stream());
+        }
         g0 = g1;
       }
     }
@@ -1748,7 +1771,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     v.n_start = deferred ? -1 : res_counts[2 * i];
     v.n_accept = deferred ? -1 : res_counts[2 * i + 1];
     // a product's labels come from its inputs' arcs (epsilon only where an input had one)
-    v.flags = (x.g1.flags & x.g2.flags & GF_EPS_FREE);
+    v.flags = (x.g1.flags & x.g2.flags & (GF_EPS_FREE | GF_ACCEPTOR));
     v.src = x.src;
     v.dst = x.dst;
     v.il = x.il;

@@ -40,7 +40,9 @@ enum RegionOp : uint8_t {
 struct Pending {
   RegionOp op = RO_NEG;
   int depth = 1;              // 1 + the depth of the deepest input that was still queued at the call
-  Graph a, b;                 // the inputs as handed in (either may be a placeholder itself); released after the run
+  // the inputs as handed in (either may be a placeholder itself); released after the run.  (Empty: a default-
+  // constructed Graph allocates its structure / weights / gradient state -- six allocations per queued call)
+  Graph a{Graph::Empty{}}, b{Graph::Empty{}};
   std::atomic<int> state{0};  // 0 queued, 1 done, 2 failed
   std::exception_ptr err;
   // the result: a graph of its own (vector path), or element `idx` of a batch record; `res` is then made on

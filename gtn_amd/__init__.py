@@ -61,6 +61,7 @@ prof_enable = _api.prof_enable
 prof_reset = _api.prof_reset
 prof_get = _api.prof_get
 prof_names = _api.prof_names
+debug_symbolic_route = _api.debug_symbolic_route
 
 
 def load_txt(text):

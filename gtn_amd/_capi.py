@@ -140,6 +140,8 @@ _SIGS = {
     "gtnx_prof_reset": [],
     "gtnx_prof_get": [C.c_char_p, C.POINTER(C.c_double), c_i64_p, C.POINTER(C.c_double)],
     "gtnx_prof_names": [C.c_char_p, C.c_size_t],
+    "gtnx_debug_symbolic_route": [c_graph, C.c_int, c_i32_p],
+    "gtnx_debug_route_name": [C.c_int, C.c_char_p, C.c_size_t],
 }
 
 _RESTYPE = {

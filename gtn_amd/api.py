@@ -804,6 +804,17 @@ def make_api(lib):
         check(lib.gtnx_prof_names(buf, 4096))
         return [s for s in buf.value.decode().split("\n") if s]
 
+    def debug_symbolic_route(g, tropical=False):
+        """which kernel family scores this symbolic product (gtn_amd/csrc/ops_symbolic.cpp); None if `g` is built"""
+        r = C.c_int(-1)
+        check(lib.gtnx_debug_symbolic_route(g._h, int(bool(tropical)), C.byref(r)))
+        if r.value < 0:
+            return None
+        buf = C.create_string_buffer(32)
+        check(lib.gtnx_debug_route_name(r.value, buf, 32))
+        return buf.value.decode()
+
+    ns.debug_symbolic_route = debug_symbolic_route
     ns.backend = backend
     ns.device_count = device_count
     ns.synchronize = synchronize

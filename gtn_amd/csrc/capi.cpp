@@ -11,6 +11,7 @@
 
 #include "batch.h"
 #include "ops.h"
+#include "ops_internal.h"
 #include "region.h"
 
 #define GTNX_API extern "C" __attribute__((visibility("default")))
@@ -864,6 +865,20 @@ GTNX_API gtnx_status_t gtnx_prof_get(const char* name, double* ms, int64_t* n, d
     if (ms) *ms = e.total_ms;
     if (n) *n = e.launches;
     if (bytes) *bytes = e.bytes;
+  });
+}
+GTNX_API gtnx_status_t gtnx_debug_symbolic_route(gtnx_graph_t g, int tropical, int* route) {
+  return guard([&] {
+    Graph& raw = GL(g);
+    *route = (raw.s && raw.s->lazy) ? int(symbolic_route(*raw.s->lazy, tropical != 0)) : -1;
+  });
+}
+GTNX_API gtnx_status_t gtnx_debug_route_name(int route, char* buf, size_t cap) {
+  return guard([&] {
+    if (cap) {
+      std::strncpy(buf, symbolic_route_name(route), cap - 1);
+      buf[cap - 1] = 0;
+    }
   });
 }
 GTNX_API gtnx_status_t gtnx_prof_names(char* buf, size_t cap) {

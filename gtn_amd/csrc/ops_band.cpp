@@ -1,0 +1,494 @@
+// ops_band.cpp -- symbolic chain products with a BANDED partner (CTC targets, force-alignment acceptors): the band
+// sweeps of band.hip, forward / backward / Viterbi; see ops.h
+#include "ops_internal.h"
+
+namespace gtnx {
+
+int band_vec_ok(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
+// launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward) {
+  Runtime& rt = Runtime::get();
+  if (tab.empty()) return;
+  std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  std::vector<BandPair> flat;
+  flat.reserve(tab.size());
+  for (auto& e : tab) flat.push_back(e.second);
+  DevMemP d = upload_vec(flat);
+  const BandPair* dp = d->as<BandPair>();
+  for (size_t i0 = 0; i0 < tab.size();) {
+    size_t i1 = i0;
+    int max_ns = 0;
+    while (i1 < tab.size() && tab[i1].first == tab[i0].first) max_ns = std::max(max_ns, tab[i1++].second.NS);
+    const BandLaunchKey& k = tab[i0].first;
+    if (backward)
+      launch_band_backward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, k.vec != 0, rt.stream());
+    else
+      launch_band_forward(dp + i0, int(i1 - i0), k.npl, k.C, max_ns, k.unit != 0, k.vec != 0, rt.stream());
+    i0 = i1;
+  }
+}
+// ---- one workgroup per (chain, BANDED G) pair: band.hip.  CTC targets and force-alignment
+// acceptors: a single wave carries the whole recursion, the other waves stage.
+bool band_shape_ok(const Structure& cs, Structure& fs, bool chain_first) {
+  if (cs.kind != KIND_LINEAR || cs.C < band_min_labels() || cs.C > band_max_labels() || cs.M < 0 || cs.M > (1 << 20)) return false;
+  std::shared_ptr<BandInfo> b = band_info(fs, chain_first);
+  return b->ok && b->max_label < cs.C;
+}
+bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out) {
+  if (!band_shape_ok(*lp.chain.s, *lp.fixed.s, lp.chain_side == 1)) return false;
+  if (out) *out = band_info(*lp.fixed.s, lp.chain_side == 1);
+  return true;
+}
+// band records and the all-zero test of a batch of partners, on the worker pool (a training step
+// brings one fresh target graph per utterance); both are cached on the graph afterwards
+void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first) {
+  std::vector<size_t> todo;
+  std::unordered_set<Structure*> seen;
+  for (size_t i = 0; i < fixed.size(); ++i) {
+    Structure* st = fixed[i]->s.get();
+    if (!st->band[chain_first[i] ? 0 : 1] && seen.insert(st).second) todo.push_back(i);
+  }
+  auto body = [&](size_t q) {
+    Graph& g = *fixed[todo[q]];
+    band_info(*g.s, chain_first[todo[q]] != 0);
+    (void)g.w->is_all_zero();
+  };
+  if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 32);
+  else for (size_t q = 0; q < todo.size(); ++q) body(q);
+}
+
+struct BandSdOp : OpRecord {
+  std::vector<BandPair> pairs;  // by output index; device pointers
+  std::vector<Graph> chains, fixed;
+  std::vector<std::shared_ptr<BandInfo>> infos;
+  std::vector<uint8_t> unit;    // unit-shaped G with all-zero weights
+  DevMemP arena;                // alpha planes, row shifts, scores
+
+  using Key = BandLaunchKey;
+  static int band_vec(const BandPair& p) { return band_vec_ok(p); }
+  static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward) { band_launch(tab, backward); }
+
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    size_t eb = 0, fb = 0;
+    std::vector<size_t> eo(ms.size(), 0), fo(ms.size(), 0);
+    std::vector<float*> dest(ms.size(), nullptr);
+    std::vector<DevMemP> dest_mem(ms.size());
+    for (size_t k = 0; k < ms.size(); ++k) {
+      const int i = ms[k].idx;
+      if (chains[i].calc_grad()) {
+        GradState& cg = *chains[i].g;
+        if (cg.grad_dest && !chains[i].is_grad_available()) {  // first gradient: straight into the caller's tensor
+          dest[k] = cg.grad_dest;
+          dest_mem[k] = cg.grad_dest_mem;
+          cg.grad_dest = nullptr;  // (a second sweep over the same chain accumulates onto it)
+        } else {
+          eo[k] = eb;
+          eb = align_up(eb + 4 * size_t(pairs[i].T) * size_t(pairs[i].C), 256);
+        }
+      }
+      if (fixed[i].calc_grad()) {
+        fo[k] = fb;
+        fb = align_up(fb + 4 * size_t(fixed[i].s->A), 256);
+      }
+    }
+    DevMemP gem = rt.alloc(eb ? eb : 1);       // every row is written by the kernel
+    DevMemP gfx = rt.alloc_zero(fb ? fb : 1);  // arcs that never match stay 0
+    ChainGradPlan local;
+    ChainGradPlan& plan = t_chain_plan ? *t_chain_plan : local;
+    plan.keep.push_back(gem);
+    plan.keep.push_back(gfx);
+    plan.keep.push_back(arena);
+    for (size_t k = 0; k < ms.size(); ++k) {  // what the deferred launch reads must outlive this record
+      plan.keep.push_back(infos[ms[k].idx]->dev_mem);
+      plan.keep.push_back(chains[ms[k].idx].w->dev_mem);
+      plan.keep.push_back(fixed[ms[k].idx].w->dev_mem);
+    }
+    for (size_t k = 0; k < ms.size(); ++k) {
+      const int i = ms[k].idx;
+      BandPair p = pairs[i];
+      p.delta = grad_dev_ptr(ms[k].out);
+      p.delta_norm = nullptr;
+      p.grad_em = chains[i].calc_grad() ? (dest[k] ? dest[k] : gem->as<float>(eo[k])) : nullptr;
+      p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
+      plan.band.push_back({p.C, band_npl(p.N), int(unit[i]), p.grad_fixed ? 1 : 0, band_vec(p), p, chains[i].w.get()});
+      if (p.grad_em) plan.sink.add(chains[i], dest[k] ? dest_mem[k] : gem, p.grad_em);
+      if (p.grad_fixed) plan.sink.add(fixed[i], gfx, p.grad_fixed);
+      ms[k].out.g->inputs[0].g->grad_propagated = true;
+      // algorithmic bytes: emissions in, emission gradient out, alpha back in, G's arc gradients out
+      plan.bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
+                    (p.grad_fixed ? 4.0 * double(fixed[i].s->A) : 0.0);
+    }
+    if (!t_chain_plan) {  // not inside backward(): launch at once
+      t_chain_plan = &local;
+      flush_chain_plan();
+      t_chain_plan = nullptr;
+    }
+  }
+  bool joins_chain_plan() const override { return true; }
+};
+
+// launches what the records of one backward() registered: band sweeps (with the softmax term of the
+// normaliser where forwardScore(emissions) of the same chain is on the tape too), then the normalisers
+// that found no sweep to ride with
+void flush_chain_plan() {
+  ChainGradPlan* plan = t_chain_plan;
+  if (!plan || plan->empty()) return;
+    std::vector<std::pair<BandSdOp::Key, BandPair>> tab;
+  tab.reserve(plan->band.size());
+  for (auto& b : plan->band) {
+    auto it = b.p.grad_em ? plan->lin.find(b.chain_w) : plan->lin.end();
+    if (it != plan->lin.end() && !it->second.fused) {
+      b.p.delta_norm = it->second.delta;
+      b.p.rowlse = const_cast<float*>(it->second.rowlse);
+      it->second.fused = true;
+    } else {
+      b.p.delta_norm = nullptr;
+    }
+    tab.push_back({BandSdOp::Key{b.C, b.npl, b.unit, b.gradg, b.vec}, b.p});
+  }
+  if (!tab.empty()) {
+    GTNX_PROF("band_forward_score_grad", plan->bytes);
+    BandSdOp::launch(tab, true);
+  }
+  plan->sink.flush();
+  // normalisers without a sweep: their own kernel
+  std::vector<Member> rest;
+  std::vector<Graph> rest_in;
+  for (auto& kv : plan->lin)
+    if (!kv.second.fused) {
+      rest.push_back(kv.second.m);
+      rest_in.push_back(kv.second.chain);
+    }
+  if (!rest.empty()) {
+    linear_sd_backward_now(rest, rest_in);
+  }
+  plan->band.clear();
+  plan->lin.clear();
+  plan->keep.clear();
+  plan->bytes = 0;
+}
+
+std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
+  Runtime& rt = Runtime::get();
+  auto op = std::make_shared<BandSdOp>();
+  op->seq = next_seq();
+  const size_t n = gs.size();
+  std::vector<BandInfo*> bis;
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  op->unit.resize(n);
+  {
+    std::vector<Graph*> fx(n);
+    std::vector<uint8_t> cf(n);
+    for (size_t i = 0; i < n; ++i) {
+      fx[i] = &gs[i].s->lazy->fixed;
+      cf[i] = gs[i].s->lazy->chain_side == 1;
+    }
+    band_prepare(fx, cf);
+  }
+  op->chains.reserve(n);
+  op->fixed.reserve(n);
+  op->infos.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    LazyProduct& lp = *gs[i].s->lazy;
+    std::shared_ptr<BandInfo> b;
+    band_ok(lp, &b);
+    op->chains.push_back(lp.chain);
+    op->fixed.push_back(lp.fixed);
+    op->infos.push_back(b);
+    bis.push_back(b.get());
+    ss.push_back(lp.fixed.s.get());
+    const bool zero = lp.fixed.w->is_all_zero();
+    op->unit[i] = zero && b->unit_shape;
+    if (!zero) ws.push_back(lp.fixed.w.get());
+    ws.push_back(lp.chain.w.get());
+  }
+  ensure_band_device_batch(bis, ss);
+  ensure_weights_device_batch(ws);
+  // scores [n], then per pair: the chain's own forwardScore (a by-product: every emission is read
+  // anyway) + its per-row log-sum-exps, shifts, alpha plane
+  size_t bytes = align_up(8 * n, 256);
+  std::vector<size_t> ao(n), oo(n), lo(n);
+  for (size_t i = 0; i < n; ++i) {
+    const int T = op->chains[i].s->M, N = int(op->fixed[i].s->N);
+    const int ns = band_row_stride(N, band_npl(N));
+    lo[i] = bytes;
+    bytes = align_up(bytes + 4 * size_t(T > 0 ? T : 1), 256);
+    oo[i] = bytes;
+    bytes = align_up(bytes + 8 * (4 * size_t(T) + 16), 256);  // score + one shift per wave and period (>= 1 row)
+    ao[i] = bytes;
+    bytes = align_up(bytes + 4 * size_t(T + 1) * size_t(ns), 256);
+  }
+  op->arena = rt.alloc(bytes);
+  op->pairs.resize(n);
+  std::vector<std::pair<BandSdOp::Key, BandPair>> tab;
+  tab.reserve(n);
+  double abytes = 0;
+  for (size_t i = 0; i < n; ++i) {
+    BandPair& p = op->pairs[i];
+    p = BandPair{};
+    const BandInfo& b = *op->infos[i];
+    p.nodes = b.dev;
+    p.nflags = b.dev_flags;
+    p.snode = b.dev_snode;
+    p.slab = b.dev_slab;
+    p.n_lab = int(b.snode.size());
+    p.w = op->fixed[i].w->is_all_zero() ? nullptr : op->fixed[i].w->dev;
+    p.em = op->chains[i].w->dev;
+    p.N = int(op->fixed[i].s->N);
+    p.T = op->chains[i].s->M;
+    p.C = op->chains[i].s->C;
+    p.NS = band_row_stride(p.N, band_npl(p.N));
+    p.alpha = op->arena->as<float>(ao[i]);
+    p.aoff = op->arena->as<double>(oo[i]);
+    p.score = op->arena->as<float>(4 * i);
+    if (!op->chains[i].w->valid_norm_cache()) {
+      p.norm = op->arena->as<float>(4 * (n + i));
+      p.rowlse = op->arena->as<float>(lo[i]);
+    }
+    p.hot = b.hot;
+    p.lgrn = band_forward_lgrn(p.C);
+    tab.push_back({BandSdOp::Key{p.C, band_npl(p.N), int(op->unit[i]), 0, BandSdOp::band_vec(p)}, p});
+    abytes += 4.0 * p.T * p.C + 4.0 * double(p.T + 1) * p.NS;  // emissions in, alpha out (kept for the backward sweep)
+  }
+  {
+    GTNX_PROF("band_forward_score", abytes);
+    BandSdOp::launch(tab, false);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const BandPair& p = op->pairs[i];
+    if (!p.norm) continue;
+    auto nc = std::make_shared<NormCache>();
+    nc->version = op->chains[i].w->version;
+    nc->mem = op->arena;
+    nc->norm = p.norm;
+    nc->rowlse = p.rowlse;
+    op->chains[i].w->norm_cache = std::move(nc);
+  }
+  std::vector<Graph> outs;
+  outs.reserve(n);
+  for (size_t i = 0; i < n; ++i) {
+    Graph out = make_output(op, int(i), {gs[i]});
+    init_scalar_result(out);
+    set_dev_weights(out, op->arena, op->pairs[i].score, 1);
+    outs.push_back(std::move(out));
+  }
+  return outs;
+}
+
+// ---- viterbiScore / viterbiPath of a symbolic chain o (banded G): band_viterbi_kernel
+// gradient of viterbiScore: the best path's arcs, d score each (shortest.cpp:64-81 on the built lattice)
+struct BandViterbiScoreOp : OpRecord {
+  struct Saved {
+    DevMemP mem;
+    const int *arc = nullptr, *lab = nullptr;
+    int len = -1, C = 0, chain_first = 0;
+  };
+  std::vector<Saved> saved;
+  void backward(std::vector<Member>& ms) override {
+    Runtime& rt = Runtime::get();
+    GradSink sink;
+    for (auto& m : ms) {
+      const Saved& sv = saved[m.idx];
+      Graph& comp = m.out.g->inputs[0];
+      comp.g->grad_propagated = true;
+      if (sv.len <= 0 || comp.g->inputs.size() != 2) continue;
+      Graph& chain = comp.g->inputs[sv.chain_first ? 0 : 1];
+      Graph& fixed = comp.g->inputs[sv.chain_first ? 1 : 0];
+      size_t bytes = 0;
+      const size_t oc = bytes;
+      if (chain.calc_grad()) bytes = align_up(bytes + 4 * size_t(chain.num_arcs()), 256);
+      const size_t of = bytes;
+      if (fixed.calc_grad()) bytes = align_up(bytes + 4 * size_t(fixed.num_arcs()), 256);
+      if (!bytes) continue;
+      DevMemP gm = rt.alloc_zero(bytes);
+      LazyPathGrad a{};
+      a.delta = grad_dev_ptr(m.out);
+      a.delta_stride = 0;
+      a.path_arc = sv.arc;
+      a.il = a.ol = sv.lab;  // the matched label either way
+      a.len = sv.len;
+      a.C = sv.C;
+      a.chain_first = sv.chain_first;
+      a.grad_chain = chain.calc_grad() ? gm->as<float>(oc) : nullptr;
+      a.grad_fixed = fixed.calc_grad() ? gm->as<float>(of) : nullptr;
+      launch_lazy_path_grad(a, rt.stream());
+      if (a.grad_chain) sink.add(chain, gm, a.grad_chain);
+      if (a.grad_fixed) sink.add(fixed, gm, a.grad_fixed);
+    }
+    sink.flush();
+  }
+};
+
+std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
+  Runtime& rt = Runtime::get();
+  const size_t n = gs.size();
+  std::vector<BandInfo*> bis;
+  std::vector<Structure*> ss;
+  std::vector<Weights*> ws;
+  std::vector<std::shared_ptr<BandInfo>> infos(n);
+  {
+    std::vector<Graph*> fx(n);
+    std::vector<uint8_t> cf(n);
+    for (size_t i = 0; i < n; ++i) {
+      fx[i] = &gs[i].s->lazy->fixed;
+      cf[i] = gs[i].s->lazy->chain_side == 1;
+    }
+    band_prepare(fx, cf);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    LazyProduct& lp = *gs[i].s->lazy;
+    band_ok(lp, &infos[i]);
+    bis.push_back(infos[i].get());
+    ss.push_back(lp.fixed.s.get());
+    if (!lp.fixed.w->is_all_zero()) ws.push_back(lp.fixed.w.get());
+    ws.push_back(lp.chain.w.get());
+  }
+  ensure_band_device_batch(bis, ss);
+  ensure_weights_device_batch(ws);
+  // per pair: back-pointers [T][NS] bytes | pnode [T+1] | path arc, label, weight [T] each | len, score, tie
+  size_t bytes = 0;
+  std::vector<size_t> o_bp(n), o_pn(n), o_pa(n), o_hd(n);
+  int max_c = 1;
+  for (size_t i = 0; i < n; ++i) {
+    const LazyProduct& lp = *gs[i].s->lazy;
+    const size_t T = size_t(lp.chain.s->M), N = size_t(lp.fixed.s->N);
+    const size_t ns = size_t(band_row_stride(int(N), band_npl(int(N))));
+    o_bp[i] = bytes;
+    bytes = align_up(bytes + T * ns + 1, 256);
+    o_pn[i] = bytes;
+    bytes = align_up(bytes + 4 * (T + 1), 256);
+    o_pa[i] = bytes;
+    bytes = align_up(bytes + 12 * (T ? T : 1), 256);
+    o_hd[i] = bytes;
+    bytes = align_up(bytes + 16, 256);
+    max_c = std::max(max_c, lp.chain.s->C);
+  }
+  DevMemP arena = rt.alloc(bytes);
+  const int stage_floats = std::max(4096, max_c);
+  std::vector<BandDecode> tab(n);
+  for (size_t i = 0; i < n; ++i) {
+    const LazyProduct& lp = *gs[i].s->lazy;
+    const BandInfo& b = *infos[i];
+    BandDecode& p = tab[i];
+    p = BandDecode{};
+    p.nodes = b.dev;
+    p.nflags = b.dev_flags;
+    p.w = lp.fixed.w->is_all_zero() ? nullptr : lp.fixed.w->dev;
+    p.em = lp.chain.w->dev;
+    p.N = int(lp.fixed.s->N);
+    p.T = lp.chain.s->M;
+    p.C = lp.chain.s->C;
+    p.NS = band_row_stride(p.N, band_npl(p.N));
+    p.bp = arena->as<uint8_t>(o_bp[i]);
+    p.pnode = arena->as<int>(o_pn[i]);
+    p.path_arc = arena->as<int>(o_pa[i]);
+    p.path_lab = p.path_arc + (p.T ? p.T : 1);
+    p.path_w = reinterpret_cast<float*>(p.path_lab + (p.T ? p.T : 1));
+    p.path_len = arena->as<int>(o_hd[i]);
+    p.score = reinterpret_cast<float*>(p.path_len + 1);
+    p.tie = p.path_len + 2;
+    p.stage_floats = stage_floats;
+  }
+  {
+    DevMemP d = upload_vec(tab);
+    GTNX_PROF(want_path ? "band_viterbi_path" : "band_viterbi_score", 0.0);
+    launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, rt.stream());
+  }
+  // heads (length, score, tie) of every pair; the paths themselves only when they become graphs
+  std::vector<char> host(bytes);
+  if (want_path) {
+    rt.d2h_sync(host.data(), arena->ptr, bytes);
+  } else {
+    DevMemP heads = rt.alloc(16 * n);
+    std::vector<AxpyArgs> ax;
+    for (size_t i = 0; i < n; ++i) ax.push_back({heads->as<float>(16 * i), reinterpret_cast<float*>(tab[i].path_len), 3, 1.0f});
+    DevMemP d = upload_vec(ax);
+    launch_axpy_batch(d->as<AxpyArgs>(), int(n), 3, /*copy*/ 2, rt.stream());
+    std::vector<char> hh(16 * n);
+    rt.d2h_sync(hh.data(), heads->ptr, 16 * n);
+    for (size_t i = 0; i < n; ++i) std::memcpy(host.data() + o_hd[i], hh.data() + 16 * i, 12);
+  }
+  std::vector<Graph> outs(n, Graph(false));
+  std::vector<size_t> tied;
+  std::shared_ptr<LazyPathOp> pop;
+  std::shared_ptr<BandViterbiScoreOp> sop;
+  if (want_path) {
+    pop = std::make_shared<LazyPathOp>();
+    pop->seq = next_seq();
+    pop->saved.resize(n);
+  } else {
+    sop = std::make_shared<BandViterbiScoreOp>();
+    sop->seq = next_seq();
+    sop->saved.resize(n);
+  }
+  for (size_t i = 0; i < n; ++i) {
+    const int* hd = reinterpret_cast<const int*>(host.data() + o_hd[i]);
+    const int len = hd[0];
+    if (hd[2] && len >= 0) {  // an exact tie: the built lattice decides (its node numbering breaks it)
+      tied.push_back(i);
+      continue;
+    }
+    LazyProduct& lp = *gs[i].s->lazy;
+    const int chain_first = lp.chain_side == 1;
+    if (want_path) {
+      Graph out = make_output(pop, int(i), {gs[i]});
+      if (len >= 0) {
+        const int* harc = reinterpret_cast<const int*>(host.data() + o_pa[i]);
+        const int* hlab = harc + (tab[i].T ? tab[i].T : 1);
+        const float* hw = reinterpret_cast<const float*>(hlab + (tab[i].T ? tab[i].T : 1));
+        // labels of the product's arcs: the chain's on its side, G's arc label on the other
+        lp.fixed.s->ensure_host();
+        std::vector<int> il, ol;
+        il.resize(size_t(len));
+        ol.resize(size_t(len));
+        for (int t = 0; t < len; ++t) {
+          il[size_t(t)] = chain_first ? hlab[t] : lp.fixed.s->il[size_t(harc[t])];
+          ol[size_t(t)] = chain_first ? lp.fixed.s->ol[size_t(harc[t])] : hlab[t];
+        }
+        fill_path_graph(out, len, true, il.data(), ol.data(), hw);
+        LazyPathOp::Saved& sv = pop->saved[i];
+        sv.arcs.assign(harc, harc + len);
+        sv.il = std::move(il);
+        sv.ol = std::move(ol);
+      }
+      pop->saved[i].C = tab[i].C;
+      pop->saved[i].chain_first = chain_first;
+      outs[i] = std::move(out);
+    } else {
+      Graph out = make_output(sop, int(i), {gs[i]});
+      init_scalar_result(out);
+      set_dev_weights(out, arena, tab[i].score, 1);
+      BandViterbiScoreOp::Saved& sv = sop->saved[i];
+      sv.mem = arena;
+      sv.arc = tab[i].path_arc;
+      sv.lab = tab[i].path_lab;
+      sv.len = len;
+      sv.C = tab[i].C;
+      sv.chain_first = chain_first;
+      outs[i] = std::move(out);
+    }
+  }
+  if (!tied.empty()) {
+    std::vector<Graph> tg;
+    for (size_t i : tied) {
+      // The lattice is built and its level schedule taken by replaying the reference's queue on it
+      // (graph.cpp: build_host_schedule, as for any host-built graph) instead of the id-order schedule a
+      // layered product normally gets for free: under exact ties the winner is the arc whose source left
+      // the queue first (shortest.cpp:212-227), and that order is not the node-id order.
+      realize(gs[i]);
+      gs[i].s->resolve_sizes();
+      gs[i].s->ensure_full();
+      gs[i].s->ensure_host();
+      gs[i].s->sched.reset();
+      tg.push_back(gs[i]);
+    }
+    std::vector<Graph> to = want_path ? op_viterbi_path(tg) : op_shortest_distance(tg, true);
+    for (size_t k = 0; k < tied.size(); ++k) outs[tied[k]] = std::move(to[k]);
+  }
+  return outs;
+}
+
+
+} // namespace gtnx

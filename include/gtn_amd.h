@@ -295,6 +295,12 @@ gtnx_status_t gtnx_prof_get(const char* name, double* total_ms, int64_t* launche
                             double* algorithmic_bytes);
 /* names, '\n'-separated, of the families seen since the last reset */
 gtnx_status_t gtnx_prof_names(char* buf, size_t cap);
+/* Diagnostics: which kernel family would score the SYMBOLIC chain product `g` (a compose / intersect result kept
+ * symbolic, gtnx_compose_mode) -- forwardScore (tropical = 0) or viterbiScore / viterbiPath (tropical = 1).  The
+ * decision table is gtn_amd/csrc/ops_symbolic.cpp; *route is an index into "band", "pair", "dense_mfma", "dense",
+ * "maxplus", "walk" (gtnx_debug_route_name), or -1 when `g` is not a symbolic product.  No reference analogue. */
+gtnx_status_t gtnx_debug_symbolic_route(gtnx_graph_t g, int tropical, int* route);
+gtnx_status_t gtnx_debug_route_name(int route, char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

@@ -465,6 +465,14 @@ gtnx_status_t gtnx_prof_get(const char*, double* ms, int64_t* n, double* b) {
   if (b) *b = 0;
   return GTNX_OK;
 }
+gtnx_status_t gtnx_debug_symbolic_route(gtnx_graph_t, int, int* route) {
+  *route = -1;  /* the reference builds every product */
+  return GTNX_OK;
+}
+gtnx_status_t gtnx_debug_route_name(int, char* buf, size_t cap) {
+  if (cap) buf[0] = 0;
+  return GTNX_OK;
+}
 gtnx_status_t gtnx_prof_names(char* buf, size_t cap) {
   if (cap) buf[0] = 0;
   return GTNX_OK;

@@ -855,3 +855,84 @@ def test_c4_alphabet_pinned_to_the_reference(gtn, T):
     np.testing.assert_allclose(ge, gold[key + "_grad_emissions"], rtol=tol, atol=tol)
     # (an arc of the transitions collects up to B * T posteriors)
     np.testing.assert_allclose(gt, gold[key + "_grad_transitions"], rtol=tol, atol=tol)
+
+
+def _route_case(kind, rng):
+    """(partner graph dict, T, C) steering a symbolic product to one row of the route table"""
+    if kind == "ctc":            # banded: CTC target
+        C, T = 12, 30
+        return gg.ctc_target_graph(rng.integers(1, C, 7).tolist()), T, C
+    if kind == "small_skip":     # not banded (an arc jumps three nodes), small: the per-pair kernels
+        C, T, N = 10, 9, 9
+        d = {"start": [1] + [0] * (N - 1), "accept": [0] * (N - 1) + [1], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": None}
+        for n in range(N - 1):
+            for dst, l in ((n, n % C), (n + 1, (n + 1) % C), (min(n + 3, N - 1), (n + 3) % C)):
+                d["src"].append(n); d["dst"].append(dst); d["il"].append(l); d["ol"].append(l)
+        d["w"] = gg._f32(rng.normal(0, 1, len(d["src"])))
+        return d, T, C
+    if kind == "dense":          # one label per node's in-arcs, complete: dense regime / max-plus
+        C, T = 24, 11
+        d = {"start": [1] * C, "accept": [1] * C, "src": [i for i in range(C) for j in range(C)], "dst": [j for i in range(C) for j in range(C)],
+             "il": [j for i in range(C) for j in range(C)], "ol": [j for i in range(C) for j in range(C)], "w": [], "sort": None}
+        d["w"] = gg._f32(rng.normal(0, 1, C * C))
+        return d, T, C
+    # "wide_sparse": nodes with eight out-arcs (more than the per-pair kernels cache), a tenth of the pairs
+    # connected (not dense), arcs jumping anywhere (not banded): the record-walking kernels
+    C, T, N = 16, 8, 80
+    d = {"start": [1] + [0] * (N - 1), "accept": [int(x) for x in rng.random(N) < 0.3], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": None}
+    d["accept"][-1] = 1
+    for n in range(N):
+        for dst in rng.choice(N, 8, replace=False):
+            d["src"].append(n); d["dst"].append(int(dst)); d["il"].append(int(dst) % C); d["ol"].append(int(dst) % C)
+    d["w"] = gg._f32(rng.normal(0, 1, len(d["src"])))
+    return d, T, C
+
+
+@pytest.mark.parametrize("kind,env,log_route,trop_route", [
+    ("ctc", {}, "band", "band"),
+    ("ctc", {"GTNX_NO_BAND": "1"}, "pair", "walk"),
+    ("ctc", {"GTNX_NO_LAZY_PAIRS": "1"}, "walk", "band"),
+    ("small_skip", {}, "pair", "walk"),
+    ("dense", {}, "dense_mfma", "maxplus"),
+    ("dense", {"GTNX_DENSE_VALU": "1"}, "dense", "maxplus"),
+    ("dense", {"GTNX_NO_DENSE": "1"}, "walk", "walk"),
+    ("wide_sparse", {}, "walk", "walk"),
+])
+def test_route_table_of_symbolic_products(gtn, kind, env, log_route, trop_route):
+    """gtn_amd/csrc/ops_symbolic.cpp is the one place that picks the kernels for a symbolic chain product: every
+    row of its table is reached here (gtnx_debug_symbolic_route says which), with the chain on either side, and
+    the scores / best path / gradients of that route are the built lattice's"""
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    d, T, C = _route_case(kind, rng)
+    em = rng.normal(0, 1, (T, C)).astype(np.float32)
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for chain_first in (False, True):
+            res = {}
+            for mode in ("0", "1"):
+                with lazy_mode(mode):
+                    e = gtn.linear_graph(T, C)
+                    e.set_weights(em)
+                    p = gg.to_api(gtn, d)
+                    comp = gtn.intersect(e, p) if chain_first else gtn.intersect(p, e)
+                    if mode == "1":
+                        assert gtn.debug_symbolic_route(comp, False) == log_route
+                        assert gtn.debug_symbolic_route(comp, True) == trop_route
+                    else:
+                        assert gtn.debug_symbolic_route(comp, False) is None
+                    fs, vs = gtn.forward_score(comp), gtn.viterbi_score(comp)
+                    path = gtn.viterbi_path(comp)
+                    gtn.backward(fs)
+                    res[mode] = (fs.item(), vs.item(), path.labels_to_list(), e.grad().weights_to_numpy(), p.grad().weights_to_numpy())
+            a, b = res["0"], res["1"]
+            assert b[0] == pytest.approx(a[0], rel=RTOL) and b[1] == pytest.approx(a[1], rel=1e-6)
+            assert b[2] == a[2]
+            np.testing.assert_allclose(b[3], a[3], rtol=1e-3, atol=1e-5)
+            np.testing.assert_allclose(b[4], a[4], rtol=1e-3, atol=1e-4)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

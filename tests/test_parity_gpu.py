@@ -549,7 +549,8 @@ def test_full_size_c3_invariants(gtn):
     assert abs(float(-g0.sum()) - T) < 0.5          # one lattice arc per time step in expectation
 
 
-@pytest.mark.parametrize("var", ["GTNX_FULL_COMPOSE", "GTNX_NO_FUSED_SCATTER", "GTNX_SYNC_COMPOSE", "GTNX_CLASSIC_BITMAPS"])
+@pytest.mark.parametrize("var", ["GTNX_FULL_COMPOSE", "GTNX_NO_FUSED_SCATTER", "GTNX_SYNC_COMPOSE", "GTNX_CLASSIC_BITMAPS",
+                                 "GTNX_GRID_REPLICATION", "GTNX_INLINE_REPLICATION"])
 def test_alternative_code_paths_give_the_same_results(gtn, var):
     """README 'Runtime switches': the eager (all arrays written) compose, the unfused
     compose-gradient kernel, the synchronous size read-back and the pair-indexed bitmaps

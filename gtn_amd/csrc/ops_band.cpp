@@ -9,7 +9,9 @@ int band_vec_ok(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<ui
 void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward) {
   Runtime& rt = Runtime::get();
   if (tab.empty()) return;
-  std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  bool one_key = true;  // (a criterion step: every pair has the same shape -- nothing to group)
+  for (size_t i = 1; i < tab.size() && one_key; ++i) one_key = tab[i].first == tab[0].first;
+  if (!one_key) std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
   std::vector<BandPair> flat;
   flat.reserve(tab.size());
   for (auto& e : tab) flat.push_back(e.second);

@@ -136,9 +136,22 @@ def unmodified_caller(B):
         times = {k: float(v) for k, v in re.findall(r"Timing (\w+) \.\.\.\s+([0-9.e+-]+) msec", r.stdout)}
         if "ctcBatched" not in times:
             return {"error": (r.stdout + r.stderr)[-300:]}
-        return {"program": "benchmarks/ctc.cpp (reference, unmodified) with batch size %d: T=1000, U=100, alphabet 28" % B,
-                "ctcBatched_ms": times["ctcBatched"], "losses_per_s": B / (times["ctcBatched"] * 1e-3),
-                "other_timings_ms": {k: v for k, v in times.items() if k != "ctcBatched"}}
+        out = {"program": "benchmarks/ctc.cpp (reference, unmodified) with batch size %d: T=1000, U=100, alphabet 28" % B,
+               "ctcBatched_ms": times["ctcBatched"], "losses_per_s": B / (times["ctcBatched"] * 1e-3),
+               "other_timings_ms": {k: v for k, v in times.items() if k != "ctcBatched"},
+               "reference_one_core_ms": {"ctcLoss": 94.4, "ngramCtcLoss": 4.1, "ngramCtcGrad": 0.41,
+                                         "source": "BASELINE.md (measured in the build container, other hardware)"}}
+        # benchmarks/functions.cpp, unmodified too: compose of two explicit graphs (100 x 20 arcs against
+        # 50 x (500 + 500 self loops)), unsorted and sorted -- the reference on one core: 98.6 / 6.6 ms
+        fexe = os.path.join(ROOT, "tests", "dropin", "_bin", "bm_functions")
+        if os.path.exists(fexe):
+            rf = subprocess.run([fexe], capture_output=True, text=True, timeout=240)
+            ft = {k: float(v) for k, v in re.findall(r"Timing (\w+) \.\.\.\s+([0-9.e+-]+) msec", rf.stdout)}
+            # (only the compose entries: compose returns with its sizes, i.e. after the kernels; the program's
+            # forwardScore loops never look at a result, so on an asynchronous device its timer sees launches only)
+            out["functions_benchmark_ms"] = {k: ft[k] for k in ("composeForward", "composeForwardSorted") if k in ft}
+            out["functions_benchmark_ms"]["reference_one_core"] = {"composeForward": 98.6, "composeForwardSorted": 6.6}
+        return out
     except Exception as e:  # a diagnostic must not cost the bench line
         return {"error": str(e)[:300]}
 

@@ -462,6 +462,7 @@ __global__ __launch_bounds__(RB) void compose_wide_replicate_kernel(const Compos
 // ================================================================================================================
 constexpr int ST_UNREACH = INT_MIN;
 constexpr int ST_REACH = INT_MIN + 1;
+constexpr int ST_FWD = INT_MIN + 2;  // reached from a start pair, not (yet) known to reach an accept pair
 constexpr int EPS = -1;
 __device__ __forceinline__ int claim_of(int r) { return -2 - r; }
 __device__ __forceinline__ int ld_agent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -469,7 +470,10 @@ __device__ __forceinline__ void st_agent(int* p, int v) { __hip_atomic_store(p, 
 
 // calls f(has, idx, i, j, il, ol) wave-uniformly, once per chunk of up to 64 candidate arc pairs of (n1, n2) in
 // the reference's order: dst pair id, arc of g1 (-1: none), arc of g2, labels of the composed arc
-template <bool IN, int MATCH, class F>
+// LOOSE (with IN = false): the out-lists walked with the BACKWARD pass's rules -- eps:eps label matches count and
+// both kinds of epsilon moves are always taken (compose.cpp:64-104 has no epsilon filter) -- for the forward
+// marking pass of `trim_fwd_first`, whose set must be closed under every step the backward pass can undo
+template <bool IN, int MATCH, bool LOOSE = false, class F>
 __device__ __forceinline__ void wave_candidates(const ComposeArgs& a, int n1, int n2, bool eps1_ok, bool eps2_ok, F&& f) {
   const int lane = threadIdx.x & 63;
   const int N1 = a.g1.N;
@@ -489,7 +493,7 @@ __device__ __forceinline__ void wave_candidates(const ComposeArgs& a, int n1, in
       if (q0 + lane < dq) {
         qr = qrec[q0 + lane];
         const int ql = sg1 ? qr.x : qr.y;  // g2's ilabel : g1's olabel
-        if (IN || ql != EPS) {             // direct eps:eps matches are skipped going forward (compose.cpp:425-428)
+        if (IN || LOOSE || ql != EPS) {    // direct eps:eps matches are skipped going forward (compose.cpp:425-428)
           int lo = 0, hi = ds;
           while (lo < hi) {  // std::lower_bound
             const int mid = (lo + hi) >> 1;
@@ -529,7 +533,7 @@ __device__ __forceinline__ void wave_candidates(const ComposeArgs& a, int n1, in
     }
   // epsilon moves: g1's arcs with olabel eps, then g2's arcs with ilabel eps (lists sorted on that label have
   // them first, compose.cpp:36-41)
-  if (!(a.g1.flags & GF_EPS_FREE) && (IN || eps1_ok)) {
+  if (!(a.g1.flags & GF_EPS_FREE) && (IN || LOOSE || eps1_ok)) {
     const GTNX_G gtnx_i4* rec = (IN ? a.g1.in_rec : a.g1.out_rec) + b1;
     for (int k0 = 0; k0 < d1; k0 += 64) {
       gtnx_i4 r{};
@@ -543,7 +547,7 @@ __device__ __forceinline__ void wave_candidates(const ComposeArgs& a, int n1, in
       if ((a.g1.flags & 2) && m != ~0ull) break;
     }
   }
-  if (!(a.g2.flags & GF_EPS_FREE) && (IN || eps2_ok)) {
+  if (!(a.g2.flags & GF_EPS_FREE) && (IN || LOOSE || eps2_ok)) {
     const GTNX_G gtnx_i4* rec = (IN ? a.g2.in_rec : a.g2.out_rec) + b2;
     for (int k0 = 0; k0 < d2; k0 += 64) {
       gtnx_i4 r{};
@@ -605,13 +609,19 @@ __global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __
     return;
   }
   // ------------------------------------------------------------------ phase B (compose.cpp:64-104)
-  // `state` arrives filled with ST_UNREACH; the queue of pair ids is the reference's toExplore
-  {
-    const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
-    const int seeds = na1 * na2;
+  // `state` arrives filled with ST_UNREACH; the queue of pair ids is the reference's toExplore.
+  // trim_fwd_first: the product of a narrow graph and a (nearly) complete one -- a target against a transition
+  // model -- has a co-reachable set of about every pair (51 k for a 100-label target against 512 labels) of
+  // which the start pairs reach a few hundred.  The pairs that end up in the product are those reached from a
+  // start pair AND reaching an accept pair; marking the first set first and walking backwards only inside it
+  // gives the same set (a path from a marked pair stays inside the marked set) for a fraction of the work.
+  const bool fwd_first = a.trim_fwd_first != 0;
+  if (fwd_first) {
+    const int ns1 = a.g1.n_start, ns2 = a.g2.n_start;
+    const int seeds = ns1 * ns2;
     for (int t = tid; t < seeds; t += WB) {
-      const int idx = a.g1.accept_list[t / na2] + N1 * a.g2.accept_list[t % na2];
-      st_agent(a.state + idx, ST_REACH);
+      const int idx = a.g1.start_list[t / ns2] + N1 * a.g2.start_list[t % ns2];
+      st_agent(a.state + idx, ST_FWD);
       st_agent(a.queue + t, idx);
     }
     if (tid == 0) sh_tail = seeds;
@@ -620,8 +630,54 @@ __global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __
     while (lo < hi) {
       for (int f = lo + wave; f < hi; f += WW) {
         const int idx = ld_agent(a.queue + f);
+        wave_candidates<false, MATCH, true>(a, idx % N1, idx / N1, true, true, [&](bool has, int pidx, int, int, int, int) {
+          const bool fresh = has && atomicCAS(a.state + pidx, ST_UNREACH, ST_FWD) == ST_UNREACH;
+          const unsigned long long m = __ballot(fresh);
+          if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&sh_tail, __popcll(m));
+            base = __shfl(base, 0);
+            if (fresh) st_agent(a.queue + base + __popcll(m & lanes_below()), pidx);
+          }
+        });
+      }
+      __syncthreads();
+      lo = hi;
+      hi = sh_tail;
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  {
+    const int unseen = fwd_first ? ST_FWD : ST_UNREACH;  // what the backward pass may still mark
+    const int na1 = a.g1.n_accept, na2 = a.g2.n_accept;
+    const int seeds = na1 * na2;
+    if (tid == 0) sh_tail = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < seeds; t0 += WB) {
+      const int t = t0 + tid;
+      bool ok = false;
+      int idx = 0;
+      if (t < seeds) {
+        idx = a.g1.accept_list[t / na2] + N1 * a.g2.accept_list[t % na2];
+        ok = atomicCAS(a.state + idx, unseen, ST_REACH) == unseen;
+      }
+      const unsigned long long m = __ballot(ok);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&sh_tail, __popcll(m));
+        base = __shfl(base, 0);
+        if (ok) st_agent(a.queue + base + __popcll(m & lanes_below()), idx);
+      }
+    }
+    __syncthreads();
+    int lo = 0, hi = sh_tail;
+    __syncthreads();
+    while (lo < hi) {
+      for (int f = lo + wave; f < hi; f += WW) {
+        const int idx = ld_agent(a.queue + f);
         wave_candidates<true, MATCH>(a, idx % N1, idx / N1, true, true, [&](bool has, int pidx, int, int, int, int) {
-          const bool fresh = has && atomicCAS(a.state + pidx, ST_UNREACH, ST_REACH) == ST_UNREACH;
+          const bool fresh = has && atomicCAS(a.state + pidx, unseen, ST_REACH) == unseen;
           const unsigned long long m = __ballot(fresh);
           if (m) {
             int base = 0;
@@ -681,7 +737,9 @@ __global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __
       const bool e1 = !em || acc2 || !acc1, e2 = !em || acc1;  // compose.cpp:461, :476
       int c = 0;
       wave_candidates<false, MATCH>(a, n1, n2, e1, e2, [&](bool has, int idx, int, int, int, int) {
-        const bool v = has && ld_agent(a.state + idx) != ST_UNREACH;
+        int st = ST_UNREACH;
+        if (has) st = ld_agent(a.state + idx);
+        const bool v = st != ST_UNREACH && st != ST_FWD;
         c += __popcll(__ballot(v));
       });
       if (lane == 0) st_agent(a.out_off + node, c);
@@ -714,7 +772,7 @@ __global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __
       wave_candidates<false, MATCH>(a, n1, n2, e1, e2, [&](bool has, int idx, int i, int j, int il, int ol) {
         int cur = ST_UNREACH;
         if (has) cur = ld_agent(a.state + idx);
-        const bool v = cur != ST_UNREACH;
+        const bool v = cur != ST_UNREACH && cur != ST_FWD;
         const unsigned long long m = __ballot(v);
         if (v) {
           const int ai = run + __popcll(m & lanes_below());

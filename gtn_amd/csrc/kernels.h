@@ -266,6 +266,7 @@ struct ComposeArgs {
   // compose_pairs_kernel only: the lists it binary-searches, sorted on the matched label -- g1's out / in
   // records by olabel, g2's by ilabel (the graph's own records when it is sorted on that label, else a stable
   // sorted view made by launch_sorted_view); null for a side the matcher never searches
+  int trim_fwd_first;  // compose_pairs_kernel: mark the pairs reached from the start pairs first (see the kernel)
   const GTNX_G gtnx_i4* s1_out;
   const GTNX_G gtnx_i4* s1_in;
   const GTNX_G gtnx_i4* s2_out;

@@ -19,6 +19,12 @@ DSched sched_view(Graph& g, bool need_full = true) {
 
 thread_local ChainGradPlan* t_chain_plan = nullptr;
 
+// the LDS-ring kernels give a node to ONE lane (rows of composed lattices are short: mean in-degree 2.5); a graph
+// whose nodes carry tens of arcs each (benchmarks/functions.cpp: makeLinear(1000, 1000)) belongs on the generic
+// kernels, which spread a node's row over 8 or 64 lanes.  Sizes still on the device (a FAST chain product: at most
+// four arcs per node by construction) count as narrow.
+static bool narrow_degree_ok(const Structure& s) { return s.A < 0 || s.N <= 0 || s.A <= 16 * s.N; }
+
 struct LinearSdOp : OpRecord {
   bool tropical;
   bool joins_chain_plan() const override { return !tropical; }
@@ -147,7 +153,8 @@ struct SdOp : OpRecord {
       for (int i = 0; i < n; ++i) {
         const Schedule& sc = *saved[ms[i].idx].sched;
         narrow = narrow && (sc.view.flags & SCHED_OUT_IDENTITY) && sc.max_level_arcs <= sd_narrow_tmp_cap() &&
-                 sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring_backward();
+                 sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring_backward() &&
+                 narrow_degree_ok(*ms[i].out.g->inputs[0].s);
         tot_levels += sc.view.L;
       }
       narrow = narrow && tot_levels >= 32 * int64_t(n);
@@ -391,7 +398,7 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     for (int k = 0; k < m; ++k) {
       Schedule& sc = *gs[exp[k]].s->sched;
       narrow = narrow && sc.max_level_arcs <= sd_narrow_tmp_cap() && sc.max_level_width <= sd_narrow_node_cap() &&
-               sc.max_reach <= sd_narrow_ring();
+               sc.max_reach <= sd_narrow_ring() && narrow_degree_ok(*gs[exp[k]].s);
       tot_levels += sc.view.L;
     }
     narrow = narrow && tot_levels >= 32 * int64_t(m);
@@ -623,7 +630,7 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     for (int k = 0; k < m; ++k) {
       const Schedule& sc = *gs[k].s->sched;
       narrow = narrow && args[k].s.in_w != nullptr && sc.max_level_arcs <= sd_narrow_tmp_cap() &&
-               sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring();
+               sc.max_level_width <= sd_narrow_node_cap() && sc.max_reach <= sd_narrow_ring() && narrow_degree_ok(*gs[k].s);
       tot_levels += sc.view.L;
     }
     narrow = narrow && tot_levels >= 32 * int64_t(m);

@@ -501,6 +501,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     x.lds_state = classic_ok[i] ? 1 : 0;  // read by the general variant only (FAST implies LDS)
     x.chain_bits = chain_slices[i];
     x.rep_grid = 0;
+    x.trim_fwd_first = 0;
     {
       // chain product, epsilon-free partner no wider than a workgroup: every level is a
       // single fast chunk, so the FAST variant may leave the derivable arrays out
@@ -604,6 +605,14 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
         ComposeArgs& x = sorted_args[i];
         Structure& s2 = *bcast(bv, n, order[i]).s;
         x.s1_out = x.s1_in = x.s2_out = x.s2_in = nullptr;
+        {
+          // a narrow graph against a (nearly) complete one: trim from the start pairs first
+          Structure& s1 = *bcast(av, n, order[i]).s;
+          auto narrow_g = [](const Structure& s) { return s.A <= 4 * s.N; };
+          auto complete_g = [](const Structure& s) { return s.N >= 8 && 2 * s.A >= s.N * s.N; };
+          const char* env = getenv("GTNX_TRIM_FWD_FIRST");
+          x.trim_fwd_first = env ? (env[0] != '0') : ((narrow_g(s1) && complete_g(s2)) || (narrow_g(s2) && complete_g(s1)));
+        }
         if (x.matcher == MATCH_DOUBLY || x.matcher == MATCH_SINGLY_G1) {
           x.s1_out = x.g1.out_rec;
           x.s1_in = x.g1.in_rec;

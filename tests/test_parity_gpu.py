@@ -1051,8 +1051,15 @@ def test_wide_node_kernels_forced_on_every_eligible_product(gtn, golden):
         test_compose_linear_first_structure_vs_oracle(gtn, 120, 20, 8)
         test_batched_ctc_vs_oracle(gtn, 4, 300, 64, 30)
         test_asg_shape_vs_oracle(gtn)
+        # ... and with the wave-per-pair kernel trimming from the start pairs first (its choice for a narrow graph
+        # against a complete one) on EVERY product, epsilon cases included: the same graphs
+        os.environ["GTNX_TRIM_FWD_FIRST"] = "1"
+        test_golden_compose(gtn, golden)
+        test_wide_explicit_pairs_vs_oracle(gtn, None, "i", 0.15)
+        test_wide_explicit_pairs_vs_oracle(gtn, "o", "i", 0.0)
     finally:
         os.environ.pop("GTNX_FORCE_WIDE_COMPOSE", None)
+        os.environ.pop("GTNX_TRIM_FWD_FIRST", None)
 
 
 @pytest.mark.parametrize("sort1,sort2", [(None, None), ("o", "i"), (None, "i"), ("o", None)])

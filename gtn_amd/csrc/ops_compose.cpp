@@ -235,12 +235,19 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const auto key = std::make_tuple(&e, ch.C, l1);
       auto hit_it = direct_counts.find(key);
       if (hit_it == direct_counts.end()) {
-        e.ensure_host();
-        const std::vector<int>& lab = l1 ? e.il : e.ol;
         int64_t h = 0, ep = 0;
-        for (int l : lab) {
-          h += (l >= 0 && l < ch.C);
-          ep += (l == GTNX_EPSILON);
+        if (!e.host_valid && e.dev_valid && e.A >= 0) {
+          // a device-built partner (the product of an earlier compose): no download for a count -- every arc
+          // may match, epsilons only if the structure has any (an upper bound is all the capacities need)
+          h = e.A;
+          ep = (e.dview.flags & GF_EPS_FREE) ? 0 : e.A;
+        } else {
+          e.ensure_host();
+          const std::vector<int>& lab = l1 ? e.il : e.ol;
+          for (int l : lab) {
+            h += (l >= 0 && l < ch.C);
+            ep += (l == GTNX_EPSILON);
+          }
         }
         hit_it = direct_counts.emplace(key, std::make_pair(h, ep)).first;
       }
@@ -551,6 +558,10 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     defer = l1 != l2 && args[i].skip && full_window[i] && chain_slices[i] > 0;
     if (!defer) break;
     Structure& ex = l1 ? *b.s : *a.s;
+    if (!ex.host_valid) {  // a device-built partner: its degrees are not worth a download
+      defer = false;
+      break;
+    }
     ex.ensure_host();
     ex.ensure_csr();
     int max_deg = 0;  // phase B walks in-lists, phase F out-lists: both within KC candidates

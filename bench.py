@@ -139,6 +139,10 @@ def unmodified_caller(B):
         out = {"program": "benchmarks/ctc.cpp (reference, unmodified) with batch size %d: T=1000, U=100, alphabet 28" % B,
                "ctcBatched_ms": times["ctcBatched"], "losses_per_s": B / (times["ctcBatched"] * 1e-3),
                "other_timings_ms": {k: v for k, v in times.items() if k != "ctcBatched"},
+               "other_timings_note": "the program's own timers around calls on an asynchronous device: ctcBatched, ctcGrad and the "
+                                     "ngram entries end in a value the host reads or in compose (which returns sizes); ctcLoss "
+                                     "never looks at its result, so its figure is launch time only -- configs.C1 is the "
+                                     "single-utterance latency with the loss read back",
                "reference_one_core_ms": {"ctcLoss": 94.4, "ngramCtcLoss": 4.1, "ngramCtcGrad": 0.41,
                                          "source": "BASELINE.md (measured in the build container, other hardware)"}}
         # benchmarks/functions.cpp, unmodified too: compose of two explicit graphs (100 x 20 arcs against

@@ -124,9 +124,11 @@ extern "C" __attribute__((visibility("default"))) int gtn_bench_ctc_step_vector(
 extern "C" __attribute__((visibility("default"))) void gtn_bench_vector_symbolic(int on) { g_vector_symbolic = on != 0; }
 
 // BASELINE config C1 (benchmarks/ctc.cpp with batch = 1: T = 100, alphabet 28, U = 20): ONE utterance through the
-// per-graph functions, reference names only, nothing batched, nothing kept symbolic -- the lattice is built
-// (compose_kernel), scored, differentiated; `iters` repetitions, each ended by reading the loss (item()).
-// Returns the mean milliseconds per repetition (< 0: error).  emissions: DEVICE [T][C].
+// per-graph functions, reference names only, nothing batched, no compose-mode hint -- so the engine's default
+// policy applies (gtn_amd.h: gtnx_compose_mode -1): the product of a target built on the host and the emissions
+// stays symbolic and is swept by band.hip (GTNX_LAZY_COMPOSE=0 builds it: compose_kernel, the forwardScore kernel
+// over the lattice, its fused backward -- 0.64 ms per loss against 0.19); `iters` repetitions, each ended by reading
+// the loss (item()).  Returns the mean milliseconds per repetition (< 0: error).  emissions: DEVICE [T][C].
 extern "C" __attribute__((visibility("default"))) double gtn_bench_single_utterance(const void* emissions, const int* target,
                                                                                   int T, int C, int U, int iters,
                                                                                   float* loss_out) {

@@ -777,8 +777,9 @@ def make_api(lib):
         check(lib.gtnx_set_stream(int(stream) if stream else None))
 
     def compose_mode(mode):
-        """0: build compositions (default); 1: keep chain compositions symbolic whenever eligible;
-        2: when the per-utterance sweep kernels apply.  Returns the previous mode (gtn_amd.h)."""
+        """0: build compositions; 1: keep chain compositions symbolic whenever eligible; 2: when the
+        per-utterance sweep kernels apply; -1 (the default): as 2 for partners built on the host, else 0.
+        Returns the previous mode (gtn_amd.h)."""
         prev = C.c_int()
         check(lib.gtnx_compose_mode(int(mode), C.byref(prev)))
         return prev.value

@@ -122,7 +122,7 @@ GTNX_API gtnx_status_t gtnx_set_device(int d) {
 }
 GTNX_API gtnx_status_t gtnx_compose_mode(int mode, int* previous) {
   return guard([&] {
-    if (mode < 0 || mode > 2) throw_invalid("[gtnx_compose_mode] mode must be 0, 1 or 2");
+    if (mode < -1 || mode > 2) throw_invalid("[gtnx_compose_mode] mode must be -1, 0, 1 or 2");
     const int old = compose_mode_hint(mode);
     if (previous) *previous = old;
   });

@@ -125,7 +125,11 @@ std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bo
   return op_compose_impl(av, bv, intersect, true);
 }
 
-thread_local int t_compose_mode = 0;
+// -1: the caller never said (gtnx_compose_mode).  The engine's own policy then: a chain product whose partner is
+// a small graph resident on the HOST (a target the caller has just built: <= 512 nodes, <= 4 arcs per node) stays
+// symbolic -- forwardScore / viterbi of it are one sweep kernel instead of a built lattice, the same choice a
+// parallelMap region makes for its calls (region.h) -- and everything else is built.
+thread_local int t_compose_mode = -1;
 int compose_mode_hint(int mode) {
   const int old = t_compose_mode;
   t_compose_mode = mode;
@@ -150,7 +154,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     // The criteria's hint (mode 2) with banded partners -- CTC targets: the product stays symbolic and
     // band.hip sweeps it, so nothing of the inputs is uploaded, counted or sorted here.
     const char* env = getenv("GTNX_LAZY_COMPOSE");
-    const int mode = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : t_compose_mode;
+    const int mode_raw = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : t_compose_mode;
+    const int mode = mode_raw < 0 ? 2 : mode_raw;
     if (mode == 2 && !getenv("GTNX_NO_BAND")) {
       bool ok = true;
       std::vector<Graph*> fx(n);
@@ -287,7 +292,9 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     // kernels of lazy_pair.hip apply.  The caller's hint (gtnx_compose_mode), overridden by
     // GTNX_LAZY_COMPOSE ("0" additionally forbids symbolic products altogether)
     const char* env = getenv("GTNX_LAZY_COMPOSE");
-    const int mode = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : t_compose_mode;
+    const int mode_raw = env && env[0] >= '0' && env[0] <= '2' ? env[0] - '0' : t_compose_mode;
+    const bool auto_mode = mode_raw < 0;  // nobody asked: symbolic for host-resident small partners only
+    const int mode = auto_mode ? 2 : mode_raw;
     const bool force = mode == 1, never = env && env[0] == '0';
     const char* benv = getenv("GTNX_LAZY_BYTES");
     const double budget = benv ? atof(benv) : 128e9;
@@ -301,7 +308,8 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       const bool l1 = a.s->kind == KIND_LINEAR, l2 = b.s->kind == KIND_LINEAR;
       eligible = (l1 != l2) && (((l1 ? b : a).s->dview.flags & GF_EPS_FREE) != 0) &&
                  lazy_shape_ok(*(l1 ? a : b).s, *(l1 ? b : a).s);
-      pairs = pairs && eligible && lazy_pair_shape_ok(*(l1 ? a : b).s, *(l1 ? b : a).s);
+      pairs = pairs && eligible && (!auto_mode || (l1 ? b : a).s->host_valid) &&
+              lazy_pair_shape_ok(*(l1 ? a : b).s, *(l1 ? b : a).s);
       est += 44.0 * double(caps[i].Acap) + 30.0 * double(caps[i].Ncap) + 8.0 * double(caps[i].pairs);
     }
     if (eligible && (force || pairs || est > budget)) {

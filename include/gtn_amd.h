@@ -58,9 +58,11 @@ gtnx_status_t gtnx_set_device(int device);  /* hipSetDevice for this process */
 gtnx_status_t gtnx_set_stream(void* hip_stream); /* NULL = the engine's own stream */
 gtnx_status_t gtnx_synchronize(void);
 /* How compose / intersect of an implicit emissions chain with an epsilon-free graph treat their
- * result, for the calling thread.  0 (default): build it, unless the batch would not fit in memory.
+ * result, for the calling thread.  0: build it, unless the batch would not fit in memory.
  * 1: keep it symbolic whenever eligible.  2: keep it symbolic when the per-utterance sweep kernels
- * apply (partner of <= 512 nodes and <= 4 arcs per node: CTC targets).  A symbolic result supports
+ * apply (partner of <= 512 nodes and <= 4 arcs per node: CTC targets).  -1 (default, "nobody asked"): as 2
+ * when the partner is a graph the caller built on the host, else as 0 -- the choice a parallelMap region makes
+ * for the calls inside it (gtnx_parallel_enter).  A symbolic result supports
  * forwardScore / viterbiScore / viterbiPath and backward through them; any other use builds it.  What
  * a symbolic result does not have is its OWN gradient graph (Graph::grad() of the composition), so
  * this is a hint for criteria that never read it.  `previous` (may be NULL) receives the old mode.

@@ -32,6 +32,11 @@ def gtn():
     library is missing; device ops raise without a GPU."""
     import gtn_amd
     assert gtn_amd.backend().startswith("hip"), gtn_amd.backend()
+    # The engine's own default (-1) keeps compose(target built on the host, emissions) symbolic.  The parity
+    # suites are about the kernels they name: compositions are BUILT here unless a test asks otherwise
+    # (GTNX_LAZY_COMPOSE / gtn.compose_mode in the test); the default policy has its own test
+    # (test_lazy_gpu.py::test_default_policy_*) and runs under the reference's unmodified C++ programs.
+    gtn_amd.compose_mode(0)
     return gtn_amd
 
 

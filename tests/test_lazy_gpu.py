@@ -936,3 +936,47 @@ def test_route_table_of_symbolic_products(gtn, kind, env, log_route, trop_route)
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_default_policy_keeps_host_built_targets_symbolic(gtn):
+    """gtnx_compose_mode -1 (what a caller who never set it gets): intersect(target built on the host, emissions)
+    stays symbolic and is swept by band.hip; a partner that only exists on the device (the product of an earlier
+    compose) or that is too wide is built.  Same loss, gradients and best path as the built lattice; looking at
+    the arcs builds it."""
+    rng = np.random.default_rng(3)
+    T, C = 60, 14
+    em = rng.normal(0, 1, (T, C)).astype(np.float32)
+    tgt = gg.ctc_target_graph(rng.integers(1, C, 9).tolist())
+    old = gtn.compose_mode(-1)
+    try:
+        res = {}
+        for mode in (-1, 0):
+            gtn.compose_mode(mode)
+            e = gtn.linear_graph(T, C)
+            e.set_weights(em)
+            ctc = gg.to_api(gtn, tgt)
+            comp = gtn.intersect(ctc, e)
+            assert gtn.debug_symbolic_route(comp) == ("band" if mode < 0 else None)
+            loss = gtn.subtract(gtn.forward_score(e), gtn.forward_score(comp))
+            gtn.backward(loss)
+            res[mode] = (loss.item(), e.grad().weights_to_numpy(), ctc.grad().weights_to_numpy(),
+                         gtn.viterbi_path(comp).labels_to_list())
+            if mode < 0:
+                n_arcs = comp.num_arcs()                      # looking inside builds it
+                assert gtn.debug_symbolic_route(comp) is None and n_arcs > T
+        a, b = res[-1], res[0]
+        assert a[0] == pytest.approx(b[0], rel=RTOL) and a[3] == b[3]
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-3, atol=1e-4)
+        # a device-built partner (ctc o bigram) and a wide one (the bigram graph itself) are built
+        gtn.compose_mode(-1)
+        d = {"start": [1] * C, "accept": [1] * C, "src": [i for i in range(C) for j in range(C)], "dst": [j for i in range(C) for j in range(C)],
+             "il": [j for i in range(C) for j in range(C)], "ol": [j for i in range(C) for j in range(C)],
+             "w": gg._f32(rng.normal(0, 1, C * C)), "sort": "i"}
+        bigram = gg.to_api(gtn, d)
+        e = gtn.linear_graph(T, C)
+        e.set_weights(em)
+        assert gtn.debug_symbolic_route(gtn.intersect(e, bigram)) is None
+        assert gtn.debug_symbolic_route(gtn.intersect(gtn.intersect(gg.to_api(gtn, tgt), bigram), e)) is None
+    finally:
+        gtn.compose_mode(old)

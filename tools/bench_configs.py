@@ -70,7 +70,8 @@ def c1():
     out = {"config": "C1: benchmarks/ctc.cpp CPU reference shape, batch=1, T=100, alphabet=28, target_len=20 "
                      "(ctcGraph, linearGraph + setWeights, intersect, 2 forwardScore, subtract, backward, item)",
            "metric": "CTC forward+backward losses/sec", "value": 1e3 / ms, "unit": "losses/s", "ms_per_loss": ms,
-           "loss": float(loss.value), "host": "C++ per-graph functions, reference names (bench_native/ctc_step.cpp)",
+           "loss": float(loss.value), "host": "C++ per-graph functions, reference names (bench_native/ctc_step.cpp); no compose-mode "
+                                              "hint: the engine's default keeps the product of a host-built target symbolic (band sweeps)",
            "roofline": roof, "kernels": kernels}
     # the unmodified reference, one thread (its benchmark's own case): same utterance
     try:

@@ -361,16 +361,17 @@ struct Run {
         return;
       }
       std::vector<int> pa, pb;
-      // compose / intersect: the mode the calls were made under (a parallelMap region: symbolic where the sweep
-      // kernels apply); target records (always symbolic) only when the mode allows symbolic results
+      // compose / intersect: the mode the calls were made under (-1, the engine's own policy -- gtn_amd.h:
+      // symbolic for small partners built on the host -- unless the caller set one); target records (always
+      // symbolic) only when the mode allows symbolic results
       int mode = 0;
       const bool comp = op == RO_COMPOSE || op == RO_INTERSECT;
       if (comp) {
-        mode = live[0]->mode < 0 ? 2 : live[0]->mode;
+        mode = live[0]->mode;
         const char* env = std::getenv("GTNX_LAZY_COMPOSE");  // (the process-wide override, read per call: ops.cpp)
         if (env && env[0] >= '0' && env[0] <= '2') mode = env[0] - '0';
       }
-      const bool records = comp && mode >= 1 && !std::getenv("GTNX_NO_BAND");
+      const bool records = comp && mode != 0 && !std::getenv("GTNX_NO_BAND");
       BatchP A = as_batch(la, pa, records), B;
       if (binary(op)) {
         B = as_batch(lb, pb, records);
@@ -653,6 +654,8 @@ Graph record_into(const std::shared_ptr<PlaceholderSlab>& slab, size_t i, Region
   if (op == RO_COMPOSE || op == RO_INTERSECT) {
     const int hint = compose_mode_hint(0);
     compose_mode_hint(hint);
+    // (inside a parallelMap region only "whenever eligible" is taken from the thread's hint: the lattices of such
+    // a loop are looked at by forwardScore only)
     p->mode = t_vector_call ? int8_t(hint) : int8_t(hint == 1 ? 1 : -1);
   }
   t_queue.push_back(p);

@@ -59,6 +59,53 @@ __device__ __forceinline__ void group_argmax(float& v, int& rank, int& payload) 
   }
 }
 
+// G = 256: the whole workgroup reduces ONE node's row (rows of hundreds of arcs on a level of one or two nodes:
+// benchmarks/functions.cpp makeLinear(1000, 1000)) -- wave reductions, then the four partial results through LDS.
+// Every lane of the workgroup is in the same iteration of the node loop (one group), so the barriers are uniform.
+template <>
+__device__ __forceinline__ float group_max<256>(float v) {
+  __shared__ float sh[4];
+  v = group_max<64>(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  __syncthreads();
+  return v;
+}
+template <>
+__device__ __forceinline__ float group_sum<256>(float v) {
+  __shared__ float sh[4];
+  v = group_sum<64>(v);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+  __syncthreads();
+  return v;
+}
+template <>
+__device__ __forceinline__ void group_argmax<256>(float& v, int& rank, int& payload) {
+  __shared__ float shv[4];
+  __shared__ int shr[4], shp[4];
+  group_argmax<64>(v, rank, payload);
+  if ((threadIdx.x & 63) == 0) {
+    shv[threadIdx.x >> 6] = v;
+    shr[threadIdx.x >> 6] = rank;
+    shp[threadIdx.x >> 6] = payload;
+  }
+  __syncthreads();
+  v = shv[0];
+  rank = shr[0];
+  payload = shp[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (shv[w] > v || (shv[w] == v && shr[w] < rank)) {
+      v = shv[w];
+      rank = shr[w];
+      payload = shp[w];
+    }
+  __syncthreads();
+}
+
 __device__ __forceinline__ float finish_lse(float mx, float sum_exp, int cnt) {
   // shortest.cpp:102-114
   if (cnt == 0) return NEG_INF;
@@ -916,7 +963,9 @@ __global__ void path_tie_kernel(const PathArgs* __restrict__ args) {
 
 template <int MODE>
 void launch_fwd_mode(const SdArgs* d, int n, int g, hipStream_t st) {
-  if (g >= 64)
+  if (g >= 256)
+    hipLaunchKernelGGL((sd_forward_kernel<MODE, 256>), dim3(n), dim3(kBlock), 0, st, d);
+  else if (g >= 64)
     hipLaunchKernelGGL((sd_forward_kernel<MODE, 64>), dim3(n), dim3(kBlock), 0, st, d);
   else if (g >= 8)
     hipLaunchKernelGGL((sd_forward_kernel<MODE, 8>), dim3(n), dim3(kBlock), 0, st, d);
@@ -925,7 +974,9 @@ void launch_fwd_mode(const SdArgs* d, int n, int g, hipStream_t st) {
 }
 template <int MODE>
 void launch_bwd_mode(const SdArgs* d, int n, int g, hipStream_t st) {
-  if (g >= 64)
+  if (g >= 256)
+    hipLaunchKernelGGL((sd_backward_kernel<MODE, 256>), dim3(n), dim3(kBlock), 0, st, d);
+  else if (g >= 64)
     hipLaunchKernelGGL((sd_backward_kernel<MODE, 64>), dim3(n), dim3(kBlock), 0, st, d);
   else if (g >= 8)
     hipLaunchKernelGGL((sd_backward_kernel<MODE, 8>), dim3(n), dim3(kBlock), 0, st, d);
@@ -934,6 +985,7 @@ void launch_bwd_mode(const SdArgs* d, int n, int g, hipStream_t st) {
 }
 
 int pick_group(int avg_deg_x16) {
+  if (avg_deg_x16 >= 192 * 16) return 256;
   if (avg_deg_x16 >= 24 * 16) return 64;
   if (avg_deg_x16 >= 4 * 16) return 8;
   return 1;

@@ -1125,3 +1125,30 @@ def test_wide_explicit_pairs_vs_oracle(gtn, sort1, sort2, eps):
             g1g, g2g = oc.compose_grad(np.ones(oc.A, np.float32), len(d1["src"]), len(d2["src"]))
             np.testing.assert_allclose(g1.grad().weights_to_numpy(), g1g, rtol=1e-6)
             np.testing.assert_allclose(g2.grad().weights_to_numpy(), g2g, rtol=1e-6)
+
+
+@pytest.mark.parametrize("steps,arcs", [(12, 300), (5, 40)])
+def test_rows_of_hundreds_of_arcs_vs_oracle(gtn, steps, arcs):
+    """benchmarks/functions.cpp's makeLinear(M, N) in small: an explicit chain with `arcs` parallel arcs per step --
+    rows of hundreds of arcs on levels of one node take the generic kernels with a whole workgroup (300) or a wave
+    (40) per node (not the lane-per-node LDS-ring kernels): forwardScore, viterbiScore, best path and gradients"""
+    rng = np.random.default_rng(steps * 1000 + arcs)
+    d = {"start": [1] + [0] * steps, "accept": [0] * steps + [1], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": None}
+    for m in range(steps):
+        for n in range(arcs):
+            d["src"].append(m); d["dst"].append(m + 1); d["il"].append(n); d["ol"].append(n)
+    d["w"] = gg._f32(rng.normal(0, 1, steps * arcs))
+    g = gg.to_api(gtn, d)
+    og = OGraph.from_dict(d)
+    fs = gtn.forward_score(g)
+    assert fs.item() == pytest.approx(og.shortest_distance(), rel=RTOL)
+    gtn.backward(fs)
+    np.testing.assert_allclose(g.grad().weights_to_numpy(), og.shortest_distance_grad(), rtol=1e-3, atol=1e-6)
+    g2 = gg.to_api(gtn, d)
+    vs = gtn.viterbi_score(g2)
+    assert vs.item() == pytest.approx(og.shortest_distance(tropical=True), rel=1e-6)
+    gtn.backward(vs)
+    np.testing.assert_allclose(g2.grad().weights_to_numpy(), og.shortest_distance_grad(tropical=True), rtol=0, atol=0)
+    path = gtn.viterbi_path(gg.to_api(gtn, d))
+    arcs_o, _ = og.shortest_path()
+    assert path.labels_to_list() == [d["il"][a] for a in arcs_o]

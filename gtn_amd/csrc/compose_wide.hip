@@ -49,7 +49,8 @@ __device__ __forceinline__ int wave_incl_scan(int x) {
 #undef GTNX_SCAN_STEP
   return x;
 }
-// exclusive prefix sum over the workgroup's lanes (sh: WW ints)
+// exclusive prefix sum over the workgroup's lanes (sh: NW ints, NW = waves of the workgroup)
+template <int NW = WW>
 __device__ __forceinline__ int block_scan(int v, int* sh, int& total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = wave_incl_scan(v);
@@ -58,7 +59,7 @@ __device__ __forceinline__ int block_scan(int v, int* sh, int& total) {
   __syncthreads();
   int base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < WW; ++w) {
+  for (int w = 0; w < NW; ++w) {
     const int s = sh[w];
     if (w < wave) base += s;
     tot += s;
@@ -579,8 +580,12 @@ __device__ __forceinline__ bool wave_has_eps(const DGraph& g, int n, bool second
   return any;
 }
 
-template <int MATCH>
-__global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __restrict__ args) {
+// WBX lanes per workgroup: 1024 for a product on its own (a level's passes spread over 16 waves); 256 for a
+// batch of products, whose levels are short -- a 1024-lane workgroup has a CU to itself (16 of its 28 wave
+// slots at this kernel's register count), 256-lane ones share it seven at a time
+template <int MATCH, int WBX>
+__global__ __launch_bounds__(WBX) void compose_pairs_kernel(const ComposeArgs* __restrict__ args) {
+  constexpr int WB = WBX, WW = WBX / 64;
   const ComposeArgs a = args[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int N1 = a.g1.N, N2 = a.g2.N;
@@ -709,7 +714,7 @@ __global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __
         ok = ld_agent(a.state + idx) == ST_REACH;
       }
       int tot;
-      const int off = block_scan(ok, sh_scan, tot);
+      const int off = block_scan<WW>(ok, sh_scan, tot);
       if (ok) {
         const int id = nn + off;
         if (id < a.Ncap) {
@@ -750,7 +755,7 @@ __global__ __launch_bounds__(WB) void compose_pairs_kernel(const ComposeArgs* __
       const int p0 = c0 + 2 * tid, p1 = p0 + 1;
       const int v0 = p0 < hi ? ld_agent(a.out_off + p0) : 0, v1 = p1 < hi ? ld_agent(a.out_off + p1) : 0;
       int tot;
-      const int base = block_scan(v0 + v1, sh_scan, tot);
+      const int base = block_scan<WW>(v0 + v1, sh_scan, tot);
       if (p0 < hi) st_agent(a.out_off + p0, na + total + base);
       if (p1 < hi) st_agent(a.out_off + p1, na + total + base + v0);
       total += tot;
@@ -1008,14 +1013,21 @@ void launch_compose_replicate(const ComposeArgs* d_args, int n, int lin2, int ma
   else hipLaunchKernelGGL(compose_replicate_kernel<false>, dim3(g, n), dim3(RB), 0, st, d_args);
 }
 
+namespace {
+template <int WBX>
+void launch_pairs_w(const ComposeArgs* d_args, int n, int matcher, hipStream_t st) {
+  switch (matcher) {
+    case MATCH_UNSORTED: hipLaunchKernelGGL((compose_pairs_kernel<MATCH_UNSORTED, WBX>), dim3(n), dim3(WBX), 0, st, d_args); break;
+    case MATCH_SINGLY_G1: hipLaunchKernelGGL((compose_pairs_kernel<MATCH_SINGLY_G1, WBX>), dim3(n), dim3(WBX), 0, st, d_args); break;
+    case MATCH_SINGLY_G2: hipLaunchKernelGGL((compose_pairs_kernel<MATCH_SINGLY_G2, WBX>), dim3(n), dim3(WBX), 0, st, d_args); break;
+    default: hipLaunchKernelGGL((compose_pairs_kernel<MATCH_DOUBLY, WBX>), dim3(n), dim3(WBX), 0, st, d_args); break;
+  }
+}
+}  // namespace
 void launch_compose_pairs(const ComposeArgs* d_args, int n, int matcher, hipStream_t st) {
   if (n <= 0) return;
-  switch (matcher) {
-    case MATCH_UNSORTED: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_UNSORTED>, dim3(n), dim3(WB), 0, st, d_args); break;
-    case MATCH_SINGLY_G1: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_SINGLY_G1>, dim3(n), dim3(WB), 0, st, d_args); break;
-    case MATCH_SINGLY_G2: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_SINGLY_G2>, dim3(n), dim3(WB), 0, st, d_args); break;
-    default: hipLaunchKernelGGL(compose_pairs_kernel<MATCH_DOUBLY>, dim3(n), dim3(WB), 0, st, d_args); break;
-  }
+  if (n >= 64) launch_pairs_w<256>(d_args, n, matcher, st);
+  else launch_pairs_w<1024>(d_args, n, matcher, st);
 }
 
 void launch_sorted_view(const DGraph& g, int key_olabel, void* out_view, void* in_view, hipStream_t st) {

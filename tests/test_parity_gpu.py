@@ -1152,3 +1152,31 @@ def test_rows_of_hundreds_of_arcs_vs_oracle(gtn, steps, arcs):
     path = gtn.viterbi_path(gg.to_api(gtn, d))
     arcs_o, _ = og.shortest_path()
     assert path.labels_to_list() == [d["il"][a] for a in arcs_o]
+
+
+def test_batch_of_wide_explicit_pairs_vs_oracle(gtn):
+    """80 products of a force-alignment-like chain with self loops against ONE dense transitions graph, composed in one
+    call (the per-graph ASG criterion of examples/asg.cpp:50-68; compose_pairs_kernel's 256-lane form for batches,
+    trimming from the start pairs first): each product's nodes, arcs and weights as the oracle's"""
+    rng = np.random.default_rng(21)
+    C, B = 18, 80
+    tr = {"start": [1] * C, "accept": [1] * C, "src": [i for i in range(C) for j in range(C)], "dst": [j for i in range(C) for j in range(C)],
+          "il": [j for i in range(C) for j in range(C)], "ol": [j for i in range(C) for j in range(C)],
+          "w": gg._f32(rng.normal(0, 1, C * C)), "sort": "i"}
+    fals = []
+    for b in range(B):
+        U = int(rng.integers(1, 9))
+        lab = rng.integers(0, C, U).tolist()
+        d = {"start": [1] + [0] * U, "accept": [0] * U + [1], "src": [], "dst": [], "il": [], "ol": [], "w": [], "sort": None}
+        for u in range(U):
+            d["src"] += [u, u + 1]; d["dst"] += [u + 1, u + 1]; d["il"] += [lab[u], lab[u]]; d["ol"] += [lab[u], lab[u]]
+        d["w"] = gg._f32(rng.normal(0, 1, 2 * U))
+        fals.append(d)
+    trans = gg.to_api(gtn, tr)
+    comps = gtn.compose([gg.to_api(gtn, d) for d in fals], [trans])
+    otr = OGraph.from_dict(tr)
+    for d, comp in zip(fals, comps):
+        oc = OGraph.from_dict(d).compose(otr)
+        got, want = gg.from_api(comp), oc.to_dict()
+        for k in ("start", "accept", "src", "dst", "il", "ol", "w"):
+            assert got[k] == want[k], k

@@ -1068,6 +1068,7 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
       GTNX_TM(0);
       // (landing first: its s_waitcnt vmcnt(0) also covers this wave's gradient stores -- stores count
       //  in vmcnt -- and the ones of the drain below would be a tick old instead of just issued)
+#ifndef GTNX_EXP_NO_STAGE
       if (((tau + 1) & 3) == h) {  // uniform
         land_rest(tau + 1);
         GTNX_TM(1);
@@ -1078,7 +1079,10 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
         land_em(tau + 2);
         GTNX_TM(1);
       }
+#endif
+#ifndef GTNX_EXP_NO_DRAIN  // (tools/ubench experiments: what the tick costs without the gradient rows / the staging)
       if (tau >= 5) drain(tau - 5);
+#endif
       GTNX_TM(3);
       lds_barrier();
       GTNX_TM(6);

@@ -615,6 +615,10 @@ def main():
         if world == 1 and native is not None and not args.no_reference_api:
             out["reference_api"] = reference_api
         if world == 1 and not args.no_configs and (B, T, Cn, U) == (512, 1000, 256, 100):
+            # the children (other processes on the same GPU) get the memory this process's pools still hold
+            gtn.synchronize()
+            gtn.empty_cache()
+            torch.cuda.empty_cache()
             out["configs"] = other_configs(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234, args.cpu_baseline_seconds)

@@ -383,8 +383,10 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
   const bool skip = FAST && a.skip != 0;  // derivable arrays are left out (see ComposeArgs::skip)
   // the stationary levels are written by compose_wide.hip's replication kernel, launched behind this one: this
   // workgroup only records which level to copy and leaves the hole (ComposeOut::wr_*)
+  // (the record goes to memory at once: six more values alive across the level loop cost the FAST variant its
+  //  second wave per SIMD -- 254 -> 256 registers, one workgroup per CU instead of two, 2.95 -> 4.75 ms at C3)
   const bool rep_grid = FAST && a.rep_grid != 0;
-  int wr_L = 0, wr_K = 0, wr_lo = 0, wr_W = 0, wr_na = 0, wr_Aw = 0;
+  bool grid_done = false;
   // pair -> node id table in HBM: only ever read back for pairs discovered in an earlier
   // chunk of the same level or across levels (non-layered arcs); with single-chunk levels
   // (skip) in the time-windowed layout neither can happen, so the writes are dropped too
@@ -1031,8 +1033,11 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
             newn_level == W && W > 0 && K >= 2 && nn + (long long)K * W <= a.Ncap &&
             na + (long long)K * Aw <= a.Acap) {
           const long long tr0 = wall_clock64();
-          if (rep_grid && wr_K == 0) {
-            wr_L = L; wr_K = K; wr_lo = lo; wr_W = W; wr_na = na_level; wr_Aw = Aw;
+          if (rep_grid && !grid_done) {
+            grid_done = true;
+            if (tid == 0) {
+              a.out->wr_L = L; a.out->wr_K = K; a.out->wr_lo = lo; a.out->wr_W = W; a.out->wr_na = na_level; a.out->wr_Aw = Aw;
+            }
           } else {
           const GTNX_G float* cw = L2 ? a.g2.w : a.g1.w;  // chain weights, one row per time step
           float wfix[KC];
@@ -1215,7 +1220,9 @@ __global__ __launch_bounds__(BLK) void compose_kernel(const ComposeArgs* __restr
     o.t_b = int(tk1 - tk0);
     o.t_f = int(wall_clock64() - tk1);
     o.t_rep = int(tk_rep);
-    o.wr_L = wr_L; o.wr_K = wr_K; o.wr_lo = wr_lo; o.wr_W = wr_W; o.wr_na = wr_na; o.wr_Aw = wr_Aw;
+    if (grid_done) {  // written by this lane when the hole was left
+      o.wr_L = a.out->wr_L; o.wr_K = a.out->wr_K; o.wr_lo = a.out->wr_lo; o.wr_W = a.out->wr_W; o.wr_na = a.out->wr_na; o.wr_Aw = a.out->wr_Aw;
+    }
     o.csr_built = sh_flag[2] && sh_flag[0] && lists_ok;
     if (lists_ok) {
       a.counts[0] = ns_tot;

@@ -150,7 +150,7 @@ void Runtime::drain_while_busy() {
 DevMemP Runtime::alloc(size_t bytes) {
   size_t sz = round_size(bytes ? bytes : 1);
   void* p = nullptr;
-  {
+  auto from_pool = [&] {
     std::lock_guard<std::mutex> lk(mu_);
     auto it = free_dev_.lower_bound(sz);
     // accept a cached block up to 1.5x the request (big arenas) / exact class (small)
@@ -159,6 +159,14 @@ DevMemP Runtime::alloc(size_t bytes) {
       sz = it->first;
       free_dev_.erase(it);
     }
+  };
+  from_pool();
+  if (!p && sz >= (size_t(32) << 20)) {
+    // A big block that the pool does not have: what the caller released since the last reclamation point may
+    // hold it (a step's alpha planes are 0.4 GB at C3; a loop that never waits for the device released a new
+    // set every step and the pool grew by that much per step -- 44 GB after 100 steps -- with a hipMalloc each).
+    drain_deferred();
+    from_pool();
   }
   if (!p) {
     GTNX_HOST_T("runtime.alloc.hipMalloc (pool miss)");

@@ -154,3 +154,30 @@ extern "C" __attribute__((visibility("default"))) double gtn_bench_single_uttera
     return -1.0;
   }
 }
+
+// BASELINE config C2 (forwardScore on 256 linear-chain emission graphs, T = 150, C = 32) from C++: the graphs over
+// the device tensor (linearGraphs = linearGraph + setWeights for the batch), the vector overload of forwardScore --
+// one batched launch -- and the scores left in a device tensor; `iters` repetitions after 10 of warm-up, ended by
+// one synchronisation.  Returns the mean milliseconds per batch (< 0: error).  emissions: DEVICE [B][T][C].
+extern "C" __attribute__((visibility("default"))) double gtn_bench_forward_score_linear(const void* emissions, int B, int T,
+                                                                                      int C, void* scores_dev, int iters) {
+  try {
+    std::vector<gtnx_graph_t> hs(static_cast<size_t>(B));
+    auto once = [&]() {
+      auto ems = linearGraphs(B, T, C, emissions);
+      auto scores = batched::forwardScore(ems);
+      for (int b = 0; b < B; ++b) hs[size_t(b)] = scores[size_t(b)].handle();
+      detail::check(gtnx_items_device_n(hs.data(), B, scores_dev));
+    };
+    for (int i = 0; i < 10; ++i) once();
+    detail::check(gtnx_synchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) once();
+    detail::check(gtnx_synchronize());
+    const auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return -1.0;
+  }
+}

@@ -115,24 +115,34 @@ def c2():
     gtn.synchronize()
     torch.cuda.synchronize()
     iters = 200
-    gtn.prof_reset()
-    gtn.prof_enable(True)
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
     gtn.synchronize()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / iters * 1e3
+    ms_python = (time.perf_counter() - t0) / iters * 1e3
+    # the same three calls from C++ (bench_native/ctc_step.cpp: gtn_bench_forward_score_linear): what `value` is
+    native = C.CDLL(os.path.join(ROOT, "bench_native", "libgtn_bench.so"))
+    native.gtn_bench_forward_score_linear.restype = C.c_double
+    native.gtn_bench_forward_score_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    out_dev.zero_()
+    gtn.prof_reset()
+    gtn.prof_enable(True)
+    ms = native.gtn_bench_forward_score_linear(em_dev.data_ptr(), B, T, Cn, out_dev.data_ptr(), iters)
     gtn.prof_enable(False)
-    roof, kernels = roofline_of(gtn, iters)
+    if ms < 0:
+        native.gtn_bench_last_error.restype = C.c_char_p
+        raise RuntimeError(native.gtn_bench_last_error().decode())
+    roof, kernels = roofline_of(gtn, iters + 10)
     scores = out_dev.cpu().numpy()
     # fp64 log-sum-exp per row, summed: the exact answer
     want = np.logaddexp.reduce(em.astype(np.float64), axis=2).sum(axis=1)
     out = {"config": "C2: forwardScore on batch=256 linear-chain emission graphs (T=150, C=32), one batched launch "
-                     "(linear_graph_n over one device tensor, forward_score on the list, scores left on the device)",
+                     "(linearGraphs over one device tensor, forwardScore on the vector, scores left on the device)",
            "metric": "forwardScore graphs/sec", "value": B / (ms * 1e-3), "unit": "graphs/s", "ms_per_batch": ms,
            "max_rel_err_vs_fp64": float(np.max(np.abs(scores - want) / np.abs(want))),
-           "host": "python (gtn_amd/api.py)", "roofline": roof, "kernels": kernels}
+           "host": "C++ (bench_native/ctc_step.cpp: linearGraphs + batched::forwardScore + gtnx_items_device_n)",
+           "ms_per_batch_python_host": ms_python, "roofline": roof, "kernels": kernels}
     try:
         ref = ref_api()
         gs = []

@@ -152,6 +152,11 @@ int sd_narrow_tmp_cap();
 int sd_narrow_node_cap();
 void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
                        int avg_in_degree_x16, hipStream_t st);
+// deep, thin DAGs in the log semiring (thousands of levels of one or two nodes): one wave per graph, scores /
+// node gradients in LDS, rows staged a chunk ahead (shortest.hip).  Every graph needs P <= sd_deep_node_cap().
+int sd_deep_node_cap();
+void launch_sd_forward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st);
+void launch_sd_backward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st);
 int sd_narrow_ring_backward();
 // narrow != 0: LDS-ring kernel (log semiring, identity out rows, eligibility as forward
 // with reach <= sd_narrow_ring_backward())

@@ -24,6 +24,12 @@ thread_local ChainGradPlan* t_chain_plan = nullptr;
 // kernels, which spread a node's row over 8 or 64 lanes.  Sizes still on the device (a FAST chain product: at most
 // four arcs per node by construction) count as narrow.
 static bool narrow_degree_ok(const Structure& s) { return s.A < 0 || s.N <= 0 || s.A <= 16 * s.N; }
+// deep, thin DAGs (a node or two per level, thousands of levels): one wave per graph with the score vector in
+// LDS (shortest.hip: sd_*_deep_kernel) instead of a workgroup barrier and four global round trips per level
+static bool deep_thin_ok(const Schedule& sc, const Structure& s) {
+  return !getenv("GTNX_NO_DEEP") && sc.view.P >= 64 && sc.view.P <= sd_deep_node_cap() && int64_t(sc.view.L) * 4 >= sc.view.P &&
+         s.A >= 0 && s.A <= 64 * int64_t(sc.view.P);
+}
 
 struct LinearSdOp : OpRecord {
   bool tropical;
@@ -267,8 +273,18 @@ struct SdOp : OpRecord {
       int fuse_lds = 0;
       if (fuse)
         for (auto& a : args) fuse_lds = std::max(fuse_lds, 4 * std::max(a.chunk_levels, 1) * a.chain_C);
-      launch_sd_backward(d->as<SdArgs>(), n, mode, narrow ? (fuse ? 2 : 1) : 0,
-                         int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream(), fuse_lds);
+      bool deep = !narrow && mode == SD_LOG;
+      int deep_p = 0;
+      for (int i = 0; i < n && deep; ++i) {
+        const Schedule& sc = *saved[ms[i].idx].sched;
+        deep = deep_thin_ok(sc, *ms[i].out.g->inputs[0].s);
+        deep_p = std::max(deep_p, sc.view.P);
+      }
+      if (deep)
+        launch_sd_backward_deep(d->as<SdArgs>(), n, deep_p, rt.stream());
+      else
+        launch_sd_backward(d->as<SdArgs>(), n, mode, narrow ? (fuse ? 2 : 1) : 0,
+                           int(tot_p ? (tot_out * 16) / tot_p : 0), rt.stream(), fuse_lds);
     }
     sink.flush();
   }
@@ -446,8 +462,18 @@ std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
     for (auto& a : args) all_inw = all_inw && a.s.in_w != nullptr;
     if (!all_inw)
       for (int k = 0; k < m; ++k) gs[exp[k]].s->ensure_full();  // weights by arc id need in_arc
-    launch_sd_forward(d->as<SdArgs>(), m, op->mode, narrow ? (all_inw ? 2 : 1) : 0,
-                      int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
+    bool deep = !narrow && !tropical;
+    int deep_p = 0;
+    for (int k = 0; k < m && deep; ++k) {
+      const Schedule& sc = *gs[exp[k]].s->sched;
+      deep = deep_thin_ok(sc, *gs[exp[k]].s);
+      deep_p = std::max(deep_p, sc.view.P);
+    }
+    if (deep)
+      launch_sd_forward_deep(d->as<SdArgs>(), m, deep_p, rt.stream());
+    else
+      launch_sd_forward(d->as<SdArgs>(), m, op->mode, narrow ? (all_inw ? 2 : 1) : 0,
+                        int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
   }
   return outs;
 }

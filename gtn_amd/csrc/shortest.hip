@@ -243,6 +243,254 @@ __global__ __launch_bounds__(kBlock) void sd_forward_kernel(const SdArgs* __rest
 }
 
 // --------------------------------------------------------------------------
+// DEEP, THIN DAGs (log semiring): thousands of dependency levels of one or two nodes each --
+// benchmarks/functions.cpp's makeRandomDAG(20000, 200000) has a node per level.  The generic kernels above pay
+// four dependent global round trips and a workgroup barrier per level (1.6 us each: 32 ms for that graph, the
+// reference on one core: 5.1 ms).  Here ONE WAVE walks the positions in order -- position order is level order,
+// so everything a node reads is finished, and a wave's LDS traffic is in order: no barrier at all -- with
+//   * the whole score vector in LDS (<= kDeepP positions), so the only value a node waits for is an LDS read;
+//   * the rows (source position, weight) staged through LDS a chunk of up to 64 nodes / kDeepStage arcs at a
+//     time: those loads do not depend on scores, so a chunk's worth is issued at once and their latency is paid
+//     once per chunk instead of once per level.
+// The backward twin walks the positions downwards with the node gradients in LDS and (destination position,
+// weight, destination score) staged.
+// --------------------------------------------------------------------------
+constexpr int kDeepP = 24576;
+constexpr int kDeepStage = 2048;
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// wave64 reductions by DPP row shifts / row broadcasts (VALU speed: a __shfl_xor butterfly is six LDS-crossbar
+// permutes, several hundred cycles per node here); every lane must be active, the result is returned to all
+#define GTNX_DPP_F(x, ctrl, rmask, old) \
+  __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), ctrl, rmask, 0xf, false))
+__device__ __forceinline__ float deep_wave_sum(float x) {
+  x += GTNX_DPP_F(x, 0x111, 0xf, 0.0f);
+  x += GTNX_DPP_F(x, 0x112, 0xf, 0.0f);
+  x += GTNX_DPP_F(x, 0x114, 0xf, 0.0f);
+  x += GTNX_DPP_F(x, 0x118, 0xf, 0.0f);
+  x += GTNX_DPP_F(x, 0x142, 0xa, 0.0f);
+  x += GTNX_DPP_F(x, 0x143, 0xc, 0.0f);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+__device__ __forceinline__ float deep_wave_max(float x) {  // (lanes without a source keep their own value)
+  x = fmaxf(x, GTNX_DPP_F(x, 0x111, 0xf, x));
+  x = fmaxf(x, GTNX_DPP_F(x, 0x112, 0xf, x));
+  x = fmaxf(x, GTNX_DPP_F(x, 0x114, 0xf, x));
+  x = fmaxf(x, GTNX_DPP_F(x, 0x118, 0xf, x));
+  x = fmaxf(x, GTNX_DPP_F(x, 0x142, 0xa, x));
+  x = fmaxf(x, GTNX_DPP_F(x, 0x143, 0xc, x));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+#undef GTNX_DPP_F
+
+__global__ __launch_bounds__(64) void sd_forward_deep_kernel(const SdArgs* __restrict__ args) {
+  const SdArgs a = args[blockIdx.x];
+  const DSched s = a.s;
+  const int lane = threadIdx.x;
+  extern __shared__ float deep_lds[];
+  float* lsc = deep_lds;                                            // [P] scores by position
+  int* st_sp = reinterpret_cast<int*>(deep_lds + ((s.P + 3) & ~3));  // [kDeepStage] source positions
+  float* st_w = reinterpret_cast<float*>(st_sp + kDeepStage);       // [kDeepStage] weights
+  auto finish_node = [&](int p, int fl, int deg, float mx, float sum) {
+    const bool is_start = (fl & NF_START) != 0;
+    const int cnt = deg + (is_start ? 1 : 0);
+    // shortest.cpp:102-114 with the hardware's exp / log (a node is a dependent chain here: latency is the cost)
+    float out = cnt == 0 ? NEG_INF : ((mx == POS_INF || mx == NEG_INF) ? mx : mx + __logf(sum));
+    if (fl & NF_ORPHAN) out = 0.0f;  // shortest.cpp:89 zero-init
+    if (lane == 0) {
+      lsc[p] = out;
+      a.scores[p] = out;
+    }
+    wave_lds_fence();
+  };
+  for (int p0 = 0; p0 < s.P;) {
+    const int pm = min(p0 + lane, s.P - 1);
+    const int my_r0 = s.row_off[pm], my_r1 = s.row_off[pm + 1], my_fl = s.pflags[pm];
+    const int base = __shfl(my_r0, 0);
+    const bool fits = p0 + lane < s.P && my_r1 - base <= kDeepStage;
+    const unsigned long long fm = __ballot(fits);
+    const int nc = fm == ~0ull ? 64 : __ffsll((long long)~fm) - 1;  // leading nodes whose rows fit the stage together
+    if (nc == 0) {
+      // a row longer than the stage: straight from global memory, the wave over its arcs
+      const int r0 = base, r1 = __shfl(my_r1, 0), fl = __shfl(my_fl, 0);
+      const bool is_start = (fl & NF_START) != 0;
+      float mx = NEG_INF;
+      for (int k = r0 + lane; k < r1; k += 64)
+        mx = fmaxf(mx, lsc[s.in_srcpos[k]] + (s.in_w ? s.in_w[k] : a.w[s.in_arc[k]]));
+      mx = deep_wave_max(mx);
+      if (is_start && 0.0f > mx) mx = 0.0f;
+      float sum = 0.0f;
+      if (mx != POS_INF && mx != NEG_INF) {
+        for (int k = r0 + lane; k < r1; k += 64)
+          sum += expf(lsc[s.in_srcpos[k]] + (s.in_w ? s.in_w[k] : a.w[s.in_arc[k]]) - mx);
+        sum = deep_wave_sum(sum);
+        if (is_start) sum += expf(0.0f - mx);
+      }
+      finish_node(p0, fl, r1 - r0, mx, sum);
+      p0 += 1;
+      continue;
+    }
+    const int narcs = __shfl(my_r1, nc - 1) - base;
+    for (int e = lane; e < narcs; e += 64) {
+      const int k = base + e;
+      st_sp[e] = s.in_srcpos[k];
+      st_w[e] = s.in_w ? s.in_w[k] : a.w[s.in_arc[k]];
+    }
+    wave_lds_fence();
+    // the row of the NEXT node is fetched from the stage while this one is reduced (its addresses do not depend
+    // on scores; only the score lookup does)
+    int nx_sp = 0;
+    float nx_w = 0.0f;
+    {
+      const int r0 = __builtin_amdgcn_readlane(my_r0, 0) - base, r1 = __builtin_amdgcn_readlane(my_r1, 0) - base;
+      if (lane < r1 - r0) {
+        nx_sp = st_sp[r0 + lane];
+        nx_w = st_w[r0 + lane];
+      }
+    }
+    for (int i = 0; i < nc; ++i) {
+      const int r0 = __builtin_amdgcn_readlane(my_r0, i) - base, r1 = __builtin_amdgcn_readlane(my_r1, i) - base, fl = __builtin_amdgcn_readlane(my_fl, i);
+      const bool is_start = (fl & NF_START) != 0;
+      const int deg = r1 - r0;
+      const int cu_sp = nx_sp;
+      const float cu_w = nx_w;
+      float mx = NEG_INF, sum = 0.0f;
+      float sc = NEG_INF;
+      if (deg <= 64 && lane < deg) sc = lsc[cu_sp] + cu_w;
+      if (i + 1 < nc) {
+        const int q0 = __builtin_amdgcn_readlane(my_r0, i + 1) - base, q1 = __builtin_amdgcn_readlane(my_r1, i + 1) - base;
+        if (lane < q1 - q0) {
+          nx_sp = st_sp[q0 + lane];
+          nx_w = st_w[q0 + lane];
+        }
+      }
+      if (deg <= 64) {  // the row in registers
+        mx = deep_wave_max(sc);
+        if (is_start && 0.0f > mx) mx = 0.0f;
+        if (mx != POS_INF && mx != NEG_INF) {
+          sum = deep_wave_sum(lane < deg ? __expf(sc - mx) : 0.0f);
+          if (is_start) sum += __expf(0.0f - mx);
+        }
+      } else {
+        for (int k = r0 + lane; k < r1; k += 64) mx = fmaxf(mx, lsc[st_sp[k]] + st_w[k]);
+        mx = deep_wave_max(mx);
+        if (is_start && 0.0f > mx) mx = 0.0f;
+        if (mx != POS_INF && mx != NEG_INF) {
+          for (int k = r0 + lane; k < r1; k += 64) sum += __expf(lsc[st_sp[k]] + st_w[k] - mx);
+          sum = deep_wave_sum(sum);
+          if (is_start) sum += __expf(0.0f - mx);
+        }
+      }
+      finish_node(p0 + i, fl, deg, mx, sum);
+    }
+    p0 += nc;
+  }
+  // ---- accept reduction (shortest.cpp:148-159)
+  float mx = NEG_INF;
+  int bestk = INT_MAX;
+  for (int k = lane; k < s.n_accept; k += 64) {
+    const float v = lsc[s.acc_pos[k]];
+    if (v > mx) {
+      mx = v;
+      bestk = k;
+    }
+  }
+  if (!(mx > NEG_INF)) bestk = INT_MAX;
+  {
+    int rk = bestk, pl = bestk;
+    group_argmax<64>(mx, rk, pl);
+    bestk = pl;
+  }
+  float sum = 0.0f;
+  if (s.n_accept > 0 && mx != POS_INF && mx != NEG_INF)
+    for (int k = lane; k < s.n_accept; k += 64) sum += expf(lsc[s.acc_pos[k]] - mx);
+  sum = deep_wave_sum(sum);
+  if (lane == 0) {
+    const float out = finish_lse(mx, sum, s.n_accept);
+    SdResult r;
+    r.score = out;
+    r.max_final = mx;
+    r.argmax_final = (bestk == INT_MAX || !(mx > NEG_INF)) ? -1 : s.acc_pos[bestk];
+    r.pad = 0;
+    *a.result = r;
+    if (a.out_score) *a.out_score = out;
+  }
+}
+
+__global__ __launch_bounds__(64) void sd_backward_deep_kernel(const SdArgs* __restrict__ args) {
+  const SdArgs a = args[blockIdx.x];
+  const DSched s = a.s;
+  const int lane = threadIdx.x;
+  extern __shared__ float deep_lds[];
+  float* lng = deep_lds;                                            // [P] node gradients by position
+  int* st_dp = reinterpret_cast<int*>(deep_lds + ((s.P + 3) & ~3));  // [kDeepStage] destination positions
+  float* st_w = reinterpret_cast<float*>(st_dp + kDeepStage);       // [kDeepStage] weights
+  float* st_sc = st_w + kDeepStage;                                 // [kDeepStage] forward scores of the destinations
+  int* st_arc = reinterpret_cast<int*>(st_sc + kDeepStage);         // [kDeepStage] arc ids
+  const SdResult res = *a.result;
+  const float delta = *a.delta;
+  const float denom = expf(res.score - res.max_final);
+  auto finish_node = [&](int p, int fl, float su, float acc) {
+    if (lane == 0) {
+      if (fl & NF_ACCEPT) acc += expf(su - res.max_final) / denom;  // shortest.cpp:49-60
+      lng[p] = acc;
+      a.node_grad[p] = acc;
+    }
+    wave_lds_fence();
+  };
+  for (int hi = s.P; hi > 0;) {
+    // lane j looks at node hi-1-j (descending positions)
+    const int pm = max(hi - 1 - lane, 0);
+    const int my_r0 = s.out_off[pm], my_r1 = s.out_off[pm + 1], my_fl = s.pflags[pm];
+    const float my_su = a.scores[pm];
+    const int top = __shfl(my_r1, 0);  // rows of descending nodes are contiguous downwards from here
+    const bool fits = hi - 1 - lane >= 0 && top - my_r0 <= kDeepStage;
+    const unsigned long long fm = __ballot(fits);
+    const int nc = fm == ~0ull ? 64 : __ffsll((long long)~fm) - 1;
+    if (nc == 0) {
+      const int p = hi - 1, r0 = __shfl(my_r0, 0), r1 = top, fl = __shfl(my_fl, 0);
+      const float su = __shfl(my_su, 0);
+      float acc = 0.0f;
+      for (int k = r0 + lane; k < r1; k += 64) {
+        const int v = s.out_dstpos[k];
+        const int arc = s.out_arc ? s.out_arc[k] : k;
+        const float g = lng[v] * expf(su + a.w[arc] - a.scores[v]);
+        a.arc_grad[arc] = g * delta;
+        acc += g;
+      }
+      acc = deep_wave_sum(acc);
+      finish_node(p, fl, su, acc);
+      hi -= 1;
+      continue;
+    }
+    const int lowest = __shfl(my_r0, nc - 1);
+    const int narcs = top - lowest;
+    for (int e = lane; e < narcs; e += 64) {
+      const int k = lowest + e;
+      const int v = s.out_dstpos[k];
+      const int arc = s.out_arc ? s.out_arc[k] : k;
+      st_dp[e] = v;
+      st_arc[e] = arc;
+      st_w[e] = a.w[arc];
+      st_sc[e] = a.scores[v];
+    }
+    wave_lds_fence();
+    for (int i = 0; i < nc; ++i) {
+      const int r0 = __builtin_amdgcn_readlane(my_r0, i) - lowest, r1 = __builtin_amdgcn_readlane(my_r1, i) - lowest, fl = __builtin_amdgcn_readlane(my_fl, i);
+      const float su = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_su), i));
+      float acc = 0.0f;
+      for (int k = r0 + lane; k < r1; k += 64) {
+        const float g = lng[st_dp[k]] * expf(su + st_w[k] - st_sc[k]);
+        a.arc_grad[st_arc[k]] = g * delta;
+        acc += g;
+      }
+      acc = deep_wave_sum(acc);
+      finish_node(hi - 1 - i, fl, su, acc);
+    }
+    hi -= nc;
+  }
+}
+
+// --------------------------------------------------------------------------
 // forward sweep, "narrow lattice" specialisation (log semiring).
 //
 // CTC-like products are DEEP and NARROW: T ~ 1000-2000 dependency levels of only
@@ -996,6 +1244,27 @@ int pick_group(int avg_deg_x16) {
 int sd_narrow_ring() { return kRing; }
 int sd_narrow_tmp_cap() { return kCA; }
 int sd_narrow_node_cap() { return kCN; }
+
+int sd_deep_node_cap() { return kDeepP; }
+namespace {
+size_t deep_lds_bytes(int maxP, bool backward) {
+  return 4 * (size_t((maxP + 3) & ~3) + size_t(backward ? 4 : 2) * kDeepStage);
+}
+}  // namespace
+void launch_sd_forward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st) {
+  if (n <= 0) return;
+  static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_forward_deep_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(deep_lds_bytes(kDeepP, false))), true);
+  (void)attr;
+  hipLaunchKernelGGL(sd_forward_deep_kernel, dim3(n), dim3(64), deep_lds_bytes(maxP, false), st, d_args);
+}
+void launch_sd_backward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st) {
+  if (n <= 0) return;
+  static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_backward_deep_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(deep_lds_bytes(kDeepP, true))), true);
+  (void)attr;
+  hipLaunchKernelGGL(sd_backward_deep_kernel, dim3(n), dim3(64), deep_lds_bytes(maxP, true), st, d_args);
+}
 
 void launch_sd_forward(const SdArgs* d_args, int n, int mode, int narrow,
                        int avg_in_degree_x16, hipStream_t st) {

@@ -1180,3 +1180,37 @@ def test_batch_of_wide_explicit_pairs_vs_oracle(gtn):
         got, want = gg.from_api(comp), oc.to_dict()
         for k in ("start", "accept", "src", "dst", "il", "ol", "w"):
             assert got[k] == want[k], k
+
+
+@pytest.mark.parametrize("N,A,hub", [(300, 2500, False), (6000, 45000, False), (3000, 9000, True)])
+def test_deep_thin_dags_vs_oracle(gtn, N, A, hub):
+    """benchmarks/time_utils.h makeRandomDAG in small: a chain 0 -> 1 -> ... -> N-1 (one node per dependency level)
+    plus random forward arcs; `hub`: every node also has an arc into the last one (a row longer than the staging
+    chunk).  One wave per graph with the scores / node gradients in LDS (sd_*_deep_kernel) -- and the generic kernels
+    with GTNX_NO_DEEP=1: forwardScore and its gradient as the oracle's"""
+    import os
+    rng = np.random.default_rng(N + A)
+    src = list(range(N - 1))
+    dst = list(range(1, N))
+    for _ in range(A - (N - 1)):
+        s = int(rng.integers(0, N - 1))
+        src.append(s)
+        dst.append(int(s + 1 + rng.integers(0, N - s - 1)))
+    if hub:
+        src += list(range(N - 1))
+        dst += [N - 1] * (N - 1)
+    d = {"start": [1] + [0] * (N - 1), "accept": [0] * (N - 1) + [1], "src": src, "dst": dst, "il": [0] * len(src), "ol": [0] * len(src),
+         "w": gg._f32(rng.normal(0, 1, len(src))), "sort": None}
+    og = OGraph.from_dict(d)
+    want, wgrad = og.shortest_distance(), og.shortest_distance_grad()
+    for env in ({}, {"GTNX_NO_DEEP": "1"}):
+        os.environ.update(env)
+        try:
+            g = gg.to_api(gtn, d)
+            fs = gtn.forward_score(g)
+            assert fs.item() == pytest.approx(want, rel=RTOL)
+            gtn.backward(fs)
+            np.testing.assert_allclose(g.grad().weights_to_numpy(), wgrad, rtol=2e-3, atol=1e-6)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)

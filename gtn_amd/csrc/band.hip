@@ -48,6 +48,7 @@ constexpr float LOG2E = 1.44269504088896340736f;
 constexpr double LN2 = 0.693147180559945309417;
 constexpr int BW = 256;  // lanes of one role: 4 sweeper waves + 4 helper waves per workgroup
 constexpr int WG = 512;
+constexpr int WGB = 768;  // the backward sweep: 4 sweeper + 4 staging + 4 draining waves
 constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
 constexpr int NBG = 7;   // blocks the backward sweep keeps: one landing, four in use, one being summed, one draining
 constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest of their chunk
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
 // helper lane and stream instead of 16 -- such shapes run one workgroup per CU (LDS), so the
 // register budget is 256 there and 128 otherwise
 template <int NPL, bool UNIT, bool GRADG, int K, bool VEC, bool BIG>
-__global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
+__global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
   constexpr int RNk = K >= 4 ? 4 : K;
   constexpr int NP = K / RNk;
   const BandPair P = pairs[blockIdx.x];
@@ -913,20 +914,112 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
         for (int k = 0; k < 3; ++k)
           if (g.ao[k][j] >= 0) P.grad_fixed[g.ao[k][j]] = acc[k][j] * ds;
     }
-  } else {
-    // ------------------------------------------------------------------ helpers: staging, gradient rows
-    const int hid = threadIdx.x - BW;
+  } else if (wv < 8) {
+    // ------------------------------------------------------------------ stagers (waves 4-7): emissions and alpha rows into LDS
     const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
-    // label -> run of nodes in snode (table built in the posterior ring, which is idle until the first tick)
-    int* cls = reinterpret_cast<int*>(oring);
-    for (int c = hid; c < 2 * C; c += BW) cls[c] = 0;
-    lds_barrier();
-    for (int i = hid; i < P.n_lab; i += BW) {
-      const int lab = P.slab[i];
-      snode[i] = P.snode[i];
-      if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
-      if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
-    }
+    lds_barrier();  // (the drainers clear the label table ...
+    if constexpr (!BIG) {
+      // One stream per wave: waves 4, 5 stage the emissions of the even / odd chunks, waves 6, 7 the alpha rows and
+      // the rows' scalars.  (Both streams in every staging wave -- 2 x 20 staging registers -- made the kernel need
+      // 96 registers where six waves per SIMD, i.e. two workgroups of twelve waves per CU, leave 80.)  A wave lands
+      // chunk c and requests chunk c + 2 of its stream: a load has two ticks to arrive.
+      // chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; chunk row r (HBM order, ascending t) is row
+      // rows-1-r of its ring block; emissions land during tick c-2 (their ring has a block to spare), alpha rows
+      // and scalars during tick c-1
+      const int h = wv - 4, q = h & 1;
+      auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+      auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
+      if (h < 2) {
+        Stage<16, 64> se;
+        if constexpr (VEC) se.init_offsets(C, CS, K, l);
+        auto issue_em = [&](int c) { se.template issue<VEC>(P.em + int64_t(tlo_of(c)) * C, rows_of(c) * C, l); };
+        auto land_em = [&](int c) {
+          const int rows = rows_of(c);
+          se.settle_all();
+          GTNX_TM(4);
+          if (rows <= 0) return;
+          float* eb = ering + (c % NBGE) * K * CS;
+          if constexpr (VEC) {
+            se.each_vec(rows * C, (K - rows) * CS, l, [&](int, int o, gtnx_f4 v4) {
+              *reinterpret_cast<gtnx_f4*>(eb + o) = gtnx_f4{em2(v4.x), em2(v4.y), em2(v4.z), em2(v4.w)};
+            });
+          } else {
+            se.template each<false>(rows * C, C, l, [&](int, int, int r, int col, gtnx_f4 v4) {
+              eb[(rows - 1 - r) * CS + col] = em2(v4.x);
+            });
+          }
+        };
+        issue_em(q);  // prologue: the emissions of chunks 0 and 1 landed, 2 and 3 requested
+        land_em(q);
+        issue_em(q + 2);
+        lds_barrier();
+        lds_barrier();  // (... and have taken their label runs)
+        for (int tau = 0; tau < nticks; ++tau) {
+          GTNX_TM(0);
+#ifndef GTNX_EXP_NO_STAGE
+          if (((tau + 2) & 1) == q) {  // uniform
+            land_em(tau + 2);
+            GTNX_TM(1);
+            issue_em(tau + 4);
+            GTNX_TM(2);
+          }
+#endif
+          GTNX_TM(3);
+          lds_barrier();
+          GTNX_TM(6);
+          GTNX_TM_TICK();
+        }
+      } else {
+        Stage<16, 64> sa;
+        sa.init_offsets(NS, NSmax, K, l);
+        float lse_s = 0.0f;
+        double af_s = 0.0;
+        auto issue_rest = [&](int c) {
+          const int rows = rows_of(c), tlo = tlo_of(c);
+          sa.template issue<true>(P.alpha + int64_t(tlo) * NS, rows * NS, l);
+          if (rows > 0) {  // uniform; unconditional clamped loads (see Stage::issue)
+            if (soft) lse_s = P.rowlse[tlo + min(l, rows - 1)];
+            // alpha frame of ring row i = l / 4 (t = T-1-cK-i) for sweeper wave l % 4
+            af_s = ao[1 + ((T - 1 - c * K - min(l >> 2, rows - 1)) >> P.lgrn) * 4 + (l & 3)];
+          }
+        };
+        auto land_rest = [&](int c) {
+          const int rows = rows_of(c);
+          sa.settle_all();
+          asm volatile("" : "+v"(lse_s), "+v"(af_s));
+          if (rows <= 0) return;
+          float* ab = aring + (c % NBE) * K * NSmax;
+          sa.each_vec(rows * NS, (K - rows) * NSmax, l, [&](int, int o, gtnx_f4 v4) { *reinterpret_cast<gtnx_f4*>(ab + o) = v4; });
+          if (l < rows) lser[(c % NBG) * K + rows - 1 - l] = lse_s;
+          if (l < 4 * rows) M.aofr[((c % NBE) * K) * 4 + l] = af_s;
+        };
+        issue_rest(q);  // prologue: chunk 0 landed, chunk 1 (lands in tick 0) and chunk 2 requested
+        if (q == 0) {
+          land_rest(0);
+          issue_rest(2);
+        }
+        lds_barrier();
+        lds_barrier();  // (... and have taken their label runs)
+        for (int tau = 0; tau < nticks; ++tau) {
+          GTNX_TM(0);
+#ifndef GTNX_EXP_NO_STAGE
+          if (((tau + 1) & 1) == q) {  // uniform
+            land_rest(tau + 1);
+            GTNX_TM(1);
+            issue_rest(tau + 3);
+            GTNX_TM(2);
+          }
+#endif
+          GTNX_TM(3);
+          lds_barrier();
+          GTNX_TM(6);
+          GTNX_TM_TICK();
+        }
+      }
+      GTNX_TM_DUMP();
+    } else {
+      // BIG shapes (one workgroup per CU, registers to spare, short ticks): both streams in every staging wave,
+      // four ticks for a load to arrive
     // ---- staging: chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; HBM rows tlo ..
     // Helper wave h owns the chunks c = h (mod 4): it lands chunk c during tick c - 1 and then
     // requests chunk c + 4, so a load has four ticks to arrive and a wave only ever waits for its
@@ -991,6 +1084,46 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
     }
     if (h == 1) land_em(1);
     lds_barrier();
+    lds_barrier();  // (... and have taken their label runs)
+    for (int tau = 0; tau < nticks; ++tau) {
+      GTNX_TM(0);
+#ifndef GTNX_EXP_NO_STAGE
+      if (((tau + 1) & 3) == h) {  // uniform
+        land_rest(tau + 1);
+        GTNX_TM(1);
+        issue(tau + 5);
+        GTNX_TM(2);
+      }
+      if (((tau + 2) & 3) == h) {  // uniform
+        land_em(tau + 2);
+        GTNX_TM(1);
+      }
+#endif
+      GTNX_TM(3);
+      lds_barrier();
+      GTNX_TM(6);
+      GTNX_TM_TICK();
+    }
+    GTNX_TM_DUMP();
+    }
+  } else {
+    // ------------------------------------------------------------------ drainers (waves 8-11): the gradient rows
+    // (a role of its own since round 3: the staging wave that landed, requested AND drained in one tick was the
+    //  tick's critical path, and one role per code path needs 60-odd registers where the merged helper needed 104)
+    const int hid = threadIdx.x - 2 * BW;
+    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
+    // label -> run of nodes in snode (table built in the posterior ring, which is idle until the first tick)
+    int* cls = reinterpret_cast<int*>(oring);
+    for (int c = hid; c < 2 * C; c += BW) cls[c] = 0;
+    lds_barrier();
+    for (int i = hid; i < P.n_lab; i += BW) {
+      const int lab = P.slab[i];
+      snode[i] = P.snode[i];
+      if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
+      if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
+    }
+    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+    lds_barrier();  // (the label table is complete; the stagers have landed the first chunks)
     // gradient rows of block c (every sweeper is through with it, its rows are summed): helper lane
     // cc GATHERS the posteriors of the nodes that carry label cc, adds the normaliser's softmax
     // term and stores the finished element -- coalesced, once
@@ -1066,20 +1199,6 @@ __global__ __launch_bounds__(WG, BIG ? 2 : 4) void band_backward_kernel(const Ba
     lds_barrier();  // (label runs are in registers; the posterior ring is the sweepers')
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      // (landing first: its s_waitcnt vmcnt(0) also covers this wave's gradient stores -- stores count
-      //  in vmcnt -- and the ones of the drain below would be a tick old instead of just issued)
-#ifndef GTNX_EXP_NO_STAGE
-      if (((tau + 1) & 3) == h) {  // uniform
-        land_rest(tau + 1);
-        GTNX_TM(1);
-        issue(tau + 5);
-        GTNX_TM(2);
-      }
-      if (((tau + 2) & 3) == h) {  // uniform
-        land_em(tau + 2);
-        GTNX_TM(1);
-      }
-#endif
 #ifndef GTNX_EXP_NO_DRAIN  // (tools/ubench experiments: what the tick costs without the gradient rows / the staging)
       if (tau >= 5) drain(tau - 5);
 #endif
@@ -1348,11 +1467,11 @@ void launch_bwd3(const BandPair* d, int n, int ns, size_t lds, bool unit, bool g
        true);
   (void)attr;
   if (unit) {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
   } else {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC, BIG>), dim3(n), dim3(WG), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
   }
 }
 template <int NPL, int K>

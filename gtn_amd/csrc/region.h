@@ -52,8 +52,8 @@ struct Pending {
   BatchP batch;
   int idx = -1;
   int group = -1;             // scratch of one run
-  int8_t mode = -1;           // compose / intersect: the compose mode to run under (-1: a parallelMap region's default,
-                              // symbolic where the sweep kernels apply)
+  int8_t mode = -1;           // compose / intersect: the compose mode to run under (-1: the engine's own policy,
+                              // gtn_amd.h gtnx_compose_mode -- symbolic for small partners built on the host)
 };
 
 bool region_active();  // the calling thread is inside a region (and not running queued calls itself)

@@ -60,10 +60,12 @@ inline Graph forwardScore(const Graph& g) { return detail::unary(&gtnx_forward_s
 inline Graph viterbiScore(const Graph& g) { return detail::unary(&gtnx_viterbi_score, g); }
 inline Graph viterbiPath(const Graph& g) { return detail::unary(&gtnx_viterbi_path, g); }
 
-/** Engine extension (not in the reference): while alive, compose / intersect of an emissions
- *  chain with a small epsilon-free graph may stay symbolic on this thread (gtnx_compose_mode in
- *  gtn_amd.h) -- for criteria that only take forwardScore / viterbiScore / viterbiPath of the
- *  composition and never read the composition's own grad(). */
+/** Engine extension (not in the reference): while alive, compose / intersect on this thread run under the
+ *  given gtnx_compose_mode (gtn_amd.h).  Nobody has to use it: by default (-1) the product of an emissions
+ *  chain and a small epsilon-free graph built on the host already stays symbolic -- forwardScore /
+ *  viterbiScore / viterbiPath sweep it without building it.  SymbolicCompose(2) extends that to partners
+ *  that only exist on the device, (1) to every eligible partner, (0) builds every composition (a caller
+ *  that reads the composition's own grad() after a retained backward wants that). */
 class SymbolicCompose {
  public:
   explicit SymbolicCompose(int mode = 2) { detail::check(gtnx_compose_mode(mode, &prev_)); }

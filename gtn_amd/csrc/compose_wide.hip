@@ -1,4 +1,10 @@
-// compose_wide.hip -- chain products whose explicit partner has WIDE nodes (tens to hundreds of arcs per node:
+// compose_wide.hip -- compose / intersect where compose.hip's lane-per-node kernels lose: wide nodes and big outputs.
+//   1. compose_wide_plan_kernel + compose_wide_replicate_kernel: chain product, partner with wide nodes (below);
+//   2. compose_replicate_kernel: the stationary levels of compose.hip's FAST chain products, written by a grid;
+//   3. compose_pairs_kernel (+ sorted_view_kernel): two explicit graphs, a wave per frontier pair (further down).
+// All keep the reference's node ids, arc ids and arc order (gtn/functions/compose.cpp:377-522).
+//
+// 1. Chain products whose explicit partner has WIDE nodes (tens to hundreds of arcs per node:
 // n-gram / ASG transition graphs), gtn/functions/compose.cpp:377-522 for `intersect(emissions, transitions)`
 // (benchmarks/ctc.cpp:118-122, examples/asg.cpp) with the reference's node and arc numbering.
 //

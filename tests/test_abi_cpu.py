@@ -110,3 +110,21 @@ def test_device_ops_fail_loudly_without_gpu(gtn):
         gtn.compose(g, g)
     with pytest.raises(RuntimeError, match="no HIP device"):
         gtn.negate(gtn.scalar_graph(1.0))
+
+
+def test_route_table_names_without_a_gpu():
+    """gtnx_debug_route_name (the rows of gtn_amd/csrc/ops_symbolic.cpp) answers on a GPU-less host; a built graph has
+    no symbolic route"""
+    import ctypes as C
+    from gtn_amd import _capi
+    lib = _capi.load()
+    names = []
+    for r in range(6):
+        buf = C.create_string_buffer(32)
+        assert lib.gtnx_debug_route_name(r, buf, 32) == 0
+        names.append(buf.value.decode())
+    assert names == ["band", "pair", "dense_mfma", "dense", "maxplus", "walk"]
+    import gtn_amd
+    g = gtn_amd.Graph()
+    g.add_node(True, True)
+    assert gtn_amd.debug_symbolic_route(g) is None

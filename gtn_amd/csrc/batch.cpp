@@ -213,15 +213,31 @@ struct BFalOp : BatchOp {
 };
 
 // scalar graphs (results of the per-graph functions) taken into a batch expression: forward gathers their
-// values, backward hands every graph its own delta and runs the per-graph tape from there
+// values, backward hands every graph its own delta and runs the per-graph tape from there.  The wrapper is an
+// identity the reference's tape does not have, so it must be transparent to the reference's accumulation rule
+// (every node passes its ACCUMULATED gradient on, autograd.cpp:40-52): over a retained tape the wrapper's own
+// gradient grows with every backward, and what the graphs are handed is only what they have not seen yet
+// (`passed`) -- in a fresh block, never the wrapper's own buffer (an adopted gradient aliases its source).
 struct BFromGraphsOp : BatchOp {
+  DevMemP passed;  // the wrapper's gradient as of the last backward
   void backward(Batch& out) override {
     Batch& src = *inputs[0];
+    Runtime& rt = Runtime::get();
+    const size_t n = size_t(src.n);
+    DevMemP delta = rt.alloc(sizeof(float) * (n ? n : 1));
+    if (passed)
+      launch_vec_axpby(delta->as<float>(), out.g_dev, passed->as<float>(), n, 1.0f, -1.0f, 0, rt.stream());
+    else
+      rt.d2d(delta->ptr, out.g_dev, sizeof(float) * n);
+    if (retain) {
+      if (!passed) passed = rt.alloc(sizeof(float) * (n ? n : 1));
+      rt.d2d(passed->ptr, out.g_dev, sizeof(float) * n);
+    }
     std::vector<Graph> roots;
     for (int b = 0; b < src.n; ++b) {
       Graph& r = src.graphs[size_t(b)];
       if (!r.calc_grad()) continue;
-      r.add_grad_device(out.g_mem, out.g_dev + b, /*adopt=*/true);
+      r.add_grad_device(delta, delta->as<float>() + b, /*adopt=*/true);
       roots.push_back(r);
     }
     if (!roots.empty()) op_backward(roots, nullptr, retain, /*seed=*/false);
@@ -232,6 +248,17 @@ struct BFromGraphsOp : BatchOp {
 }  // namespace
 
 Batch::~Batch() {
+  if (host_ev) (void)hipEventDestroy(static_cast<hipEvent_t>(host_ev));
+  if (give_back && !origins.empty()) {
+    for (const Origin& o : origins) {
+      auto* part = new std::vector<Graph>();
+      part->reserve(o.end - o.begin);
+      for (size_t i = o.begin; i < o.end && i < graphs.size(); ++i) part->push_back(std::move(graphs[i]));
+      give_back(o.home.get(), part);
+    }
+    graphs.clear();
+    return;
+  }
   // taken apart off the caller's critical path, a few dozen graphs per entry so that the threads of the next
   // parallelMap region share them (runtime.cpp: drain_some)
   if (graphs.size() < 64 || !Runtime::initialized()) return;
@@ -561,7 +588,24 @@ void push_grads_to_graphs(Batch& x) {
   if (!x.g_dev) return;
   GTNX_HOST_T("batch.push_grads_to_graphs");
   GradSink sink;  // first gradients are adopted in place, the others folded in by ONE launch
-  for (int i = 0; i < x.n; ++i) sink.add(x.graphs[size_t(i)], x.g_mem, x.g_dev + x.g_off[size_t(i)]);
+  const size_t n = size_t(x.n);
+  for (size_t i = 0; i < n; ++i) {
+    // (the graphs were built by the region's threads: each is a miss in this core's caches)
+    if (i + 6 < n) __builtin_prefetch(x.graphs[i + 6].g.get(), 1);
+    if (i + 3 < n) __builtin_prefetch(x.graphs[i + 3].s.get(), 1);
+    Graph& g = x.graphs[i];
+    if (!g.calc_grad()) continue;
+    float* ptr = x.g_dev + x.g_off[i];
+    if (!g.s->deferred) {  // the common case -- a first gradient: only the block is noted (Graph::add_grad_device)
+      std::lock_guard<std::mutex> lk(g.s->grad_lock);
+      if (!g.is_grad_available()) {
+        g.g->lazy_owner = x.g_mem;
+        g.g->lazy_ptr = ptr;
+        continue;
+      }
+    }
+    sink.add(g, x.g_mem, ptr);
+  }
   sink.flush();
   x.g_dev = nullptr;  // (the graphs hold the block now)
   x.g_mem.reset();
@@ -930,10 +974,31 @@ float batch_item_host(const BatchP& x, int i) {
   if (i < 0 || i >= x->n) throw_range("[gtnx_batch_get] element index out of range");
   if (!x->host_vals_valid) {
     x->host_vals.resize(size_t(x->n));
-    Runtime::get().d2h_sync(x->host_vals.data(), x->v_dev, sizeof(float) * size_t(x->n));
+    if (x->host_ev) {  // on its way since the values were launched (batch_prefetch_items)
+      HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(x->host_ev)));
+      std::memcpy(x->host_vals.data(), x->host_pin->ptr, sizeof(float) * size_t(x->n));
+      (void)hipEventDestroy(static_cast<hipEvent_t>(x->host_ev));
+      x->host_ev = nullptr;
+      x->host_pin.reset();
+    } else {
+      Runtime::get().d2h_sync(x->host_vals.data(), x->v_dev, sizeof(float) * size_t(x->n));
+    }
     x->host_vals_valid = true;
   }
   return x->host_vals[size_t(i)];
+}
+void batch_prefetch_items(const BatchP& x) {
+  if (!x || x->kind != Batch::SCALAR || x->materialised || x->host_vals_valid || x->host_ev || x->n <= 0 || !x->v_dev) return;
+  Runtime& rt = Runtime::get();
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  x->host_pin = rt.alloc_pinned(sizeof(float) * size_t(x->n));
+  HIP_CHECK(hipMemcpyAsync(x->host_pin->ptr, x->v_dev, sizeof(float) * size_t(x->n), hipMemcpyDeviceToHost, rt.stream()));
+  HIP_CHECK(hipEventRecord(ev, rt.stream()));
+  x->host_ev = ev;
 }
 void batch_items_host(const BatchP& x, float* out) {
   if (x->kind == Batch::SCALAR && !x->materialised) {

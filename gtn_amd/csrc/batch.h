@@ -45,9 +45,22 @@ struct Batch {
   // are those graphs from the start, the native arrays describe the same values, and every gradient the batch
   // functions produce is pushed into the graphs (that is where the caller looks)
   bool leaf = false;
+  // ... taken from the digests of a region's slices (region.cpp): when the record dies, the graphs of each range
+  // go back to the thread that built them (give_back(home, graphs)) instead of being taken apart here
+  struct Origin {
+    std::shared_ptr<void> home;
+    size_t begin, end;
+  };
+  std::vector<Origin> origins;
+  void (*give_back)(void* home, std::vector<Graph>* part) = nullptr;
   // SCALAR: the values on the host, fetched once when an element's item() is asked for (batch_item_host)
   std::vector<float> host_vals;
   bool host_vals_valid = false;
+  // ... or on their way: copied to pinned memory BEHIND the launch that produced them (batch_prefetch_items), so
+  // that reading a loss waits for the forward sweep only, not for whatever was queued after it (the backward
+  // sweep of the same step: the host prepares the next step meanwhile)
+  PinnedMemP host_pin;
+  void* host_ev = nullptr;  // hipEvent_t
 
   // ---- CTC_TARGETS: label sequences back to back; records (BandNode, flags, sorted lists) on the device
   std::vector<int> labels, lab_off;  // lab_off[n + 1]
@@ -103,6 +116,7 @@ void batch_grads_device(const BatchP& x, void* dev_out, const int64_t* offsets);
 void batch_grads_bind(const BatchP& x, void* dev_out, const int64_t* offsets);
 Graph batch_get(const BatchP& x, int i);
 float batch_item_host(const BatchP& x, int i);  // x SCALAR and not materialised
+void batch_prefetch_items(const BatchP& x);      // x SCALAR: start the device->host copy of its values now
 // the caller's graphs as native leaves (nullptr when they do not qualify): acceptors that are each exactly
 // ctcGraph(labels) of benchmarks/ctc.cpp:40-58 (Structure::ctc_labels) / linear chains of one shape whose
 // weights are (made) one [n][M][C] device tensor

@@ -157,6 +157,7 @@ GTNX_API gtnx_status_t gtnx_reclaim(void) {
       return v > 0 ? v : 1;
     }();
     static std::atomic<int> active{0};
+    region_reclaim_thread();  // what THIS thread built and nobody refers to any more (region.cpp)
     if (!Runtime::initialized()) return;
     if (active.fetch_add(1, std::memory_order_acquire) >= max_reclaimers) {
       active.fetch_sub(1, std::memory_order_release);
@@ -193,7 +194,9 @@ GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
     Graph* p = reinterpret_cast<Graph*>(g);
     if (!p) return;
     if (region_active())
-      region_trash(p);  // handed over when the thread leaves the region (one lock instead of one per handle)
+      region_trash(p);  // let go of when the thread leaves the region
+    else if (p->s && p->s->pending)
+      delete p;         // a placeholder's handle is a reference to its slice: nothing to take apart here (region.cpp)
     else if (Runtime::initialized())
       Runtime::get().defer_delete(p, [](void* q) { delete static_cast<Graph*>(q); });
     else
@@ -393,7 +396,18 @@ GTNX_API gtnx_status_t gtnx_graph_make_accept(gtnx_graph_t g, int n) {
       s.nflags[n] |= NF_ACCEPT;
       s.dev_valid = false;
       s.dev_mem.reset();
+      s.rec_mem.reset();
       s.sched.reset();
+      // everything derived from the accept flags: the CTC-shape cache (graph.cpp: detect_ctc_shape compares them --
+      // a ctcGraph with one more accept node is no longer the acceptor the device-built target records describe),
+      // the leaf record made from it, the band and dense records (node flags are part of both)
+      s.ctc_labels.reset();
+      s.ctc_checked = false;
+      s.leaf_batch.reset();
+      s.band[0].reset();
+      s.band[1].reset();
+      s.dense[0].reset();
+      s.dense[1].reset();
     }
   });
 }

@@ -393,8 +393,21 @@ int Structure::num_out(int n) {
 // ======================================================================
 // Weights
 // ======================================================================
+bool Weights::settle_staged() {
+  if (!staged || !staged->on_device || !staged->blk) return false;
+  float* base = staged->blk->base.load(std::memory_order_acquire);
+  if (!base) return false;
+  dev_mem = staged->blk->mem;
+  dev = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + staged->off);
+  dev_valid = true;
+  host_valid = false;
+  staged.reset();
+  return true;
+}
+
 void Weights::ensure_host() {
   if (host_valid) return;
+  settle_staged();
   if (zero) {
     host.assign(size_t(n), 0.0f);
     zero = false;
@@ -789,7 +802,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
   // per-graph host work (CSR build, packing) fans out over a few host threads when
   // the batch is large -- a training step uploads one small target graph per utterance
   auto for_each_todo = [&](auto&& body) {
-    if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 16);
+    if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 16, false);
     else for (size_t i = 0; i < todo.size(); ++i) body(i);
   };
   for_each_todo([&](size_t i) { todo[i]->ensure_csr(); });
@@ -874,6 +887,7 @@ void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
   std::vector<Weights*> todo;
   std::unordered_set<Weights*> todo_set;
   for (Weights* w : ws) {
+    w->settle_staged();  // (copied by a region's join already: region.cpp)
     // (a mutable host pointer that escaped matters only while the host copy is the live one: after a
     //  device-side write the device copy is authoritative and host_valid is false)
     bool stale = !w->dev_valid || (w->host_escaped && w->host_valid);

@@ -154,10 +154,20 @@ struct NormCache {
 // Weights handed over inside a parallelMap region (region.cpp): the values sit in a pinned staging
 // chunk (host source, copied at the call like graph.cpp:179-181) or are still the caller's device buffer
 // (device source: read at the region's join); the join moves the whole region's weights with one copy.
+// The device image of the device-source weights ONE thread staged inside a region (region.cpp: a slice): the
+// join allocates one arena for all slices, copies every segment with one launch and publishes each slice's
+// base address here; the weights themselves are not touched by the join -- they settle (Weights::settle_staged)
+// when somebody first needs them.
+struct StageBlock {
+  DevMemP mem;
+  std::atomic<float*> base{nullptr};
+};
 struct StagedWeights {
   PinnedMemP chunk;            // keeps the staging chunk alive (host source)
   const float* src = nullptr;  // pinned host address or the caller's device address
   bool on_device = false;
+  std::shared_ptr<StageBlock> blk;  // device source: where the join's copy lands ...
+  size_t off = 0;                   // ... at this byte offset
 };
 
 struct Weights {
@@ -179,6 +189,10 @@ struct Weights {
   uint64_t zero_version = ~uint64_t(0);  // version all_zero was taken at
   bool all_zero = false;
   bool is_all_zero();         // host-valid weights only; cached per version
+  // is_all_zero() if that is known without computing anything (what a thread may ask of weights it shares)
+  bool known_all_zero() const { return zero || (host_valid && !host_escaped && zero_version == version && all_zero); }
+  // staged from a device source and the region's join has made the copy: adopt it (true: dev is valid now)
+  bool settle_staged();
   std::shared_ptr<NormCache> norm_cache;
   // (not while a mutable host pointer is out and the host copy is the live one: writes through it do not bump
   //  `version` -- the cache is of the last upload, and so may be stale)

@@ -55,7 +55,7 @@ void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& 
     band_info(*g.s, chain_first[todo[q]] != 0);
     (void)g.w->is_all_zero();
   };
-  if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 32);
+  if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 32, false);
   else for (size_t q = 0; q < todo.size(); ++q) body(q);
 }
 

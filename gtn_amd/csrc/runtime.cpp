@@ -62,6 +62,8 @@ Runtime::Runtime() {
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device_));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  pool_budget_ = size_t(prop.totalGlobalMem) / 4;
+  if (const char* e = std::getenv("GTNX_POOL_BUDGET_GB")) pool_budget_ = size_t(std::atof(e) * double(size_t(1) << 30));
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
 }
@@ -162,11 +164,23 @@ DevMemP Runtime::alloc(size_t bytes) {
   };
   from_pool();
   if (!p && sz >= (size_t(32) << 20)) {
-    // A big block that the pool does not have: what the caller released since the last reclamation point may
+    // A big block that the pool does not have.  What the caller released since the last reclamation point may
     // hold it (a step's alpha planes are 0.4 GB at C3; a loop that never waits for the device released a new
-    // set every step and the pool grew by that much per step -- 44 GB after 100 steps -- with a hipMalloc each).
-    drain_deferred();
-    from_pool();
+    // set every step and the pool grew by that much per step -- 44 GB after 100 steps -- with a hipMalloc each):
+    // reclaim and look again -- but only once the pool has grown past its budget (a quarter of the device's
+    // memory, GTNX_POOL_BUDGET_GB).  Below it the block is simply allocated: a step's garbage is taken apart
+    // by the worker threads of the next parallelMap region while the joining thread is already allocating, so
+    // two generations of a step's arenas are alive at that moment and reclaiming HERE would put the whole
+    // teardown (1.5 ms at C3) on the one thread everything waits for.
+    bool over;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      over = reserved_ + sz > pool_budget_;
+    }
+    if (over) {
+      drain_deferred();
+      from_pool();
+    }
   }
   if (!p) {
     GTNX_HOST_T("runtime.alloc.hipMalloc (pool miss)");

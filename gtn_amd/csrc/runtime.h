@@ -108,6 +108,7 @@ class Runtime {
   };
   std::vector<PendingPinned> pending_pinned_;
   uint64_t reserved_ = 0, in_use_ = 0;
+  size_t pool_budget_ = size_t(64) << 30;  // reclaim before growing the pool past this (alloc)
   bool prof_on_ = false;
   struct ProfRec {
     std::string name;

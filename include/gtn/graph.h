@@ -303,7 +303,15 @@ class Graph {
   void reset() {
     if (h_) gtnx_graph_destroy(h_);  // (collected nodes / arcs of a graph nobody ever looked at go with it)
     h_ = nullptr;
-    build_.reset();
+    if (build_) {  // (back to the thread's spare slot, capacity kept: see collecting())
+      std::unique_ptr<Build>& spare = spareBuild();
+      if (!spare && build_->src.capacity() <= (1u << 16)) {
+        Build& b = *build_;
+        b.start.clear(), b.accept.clear(), b.src.clear(), b.dst.clear(), b.il.clear(), b.ol.clear(), b.w.clear();
+        spare = std::move(build_);
+      }
+      build_.reset();
+    }
     dirty_.store(false, std::memory_order_relaxed);
   }
   // ---- collected addNode / addArc calls (see addNode)
@@ -315,11 +323,22 @@ class Graph {
   bool collecting() {
     if (aliased_ || !fresh_) return false;
     if (!build_) {
-      build_.reset(new Build());
-      build_->src.reserve(64), build_->dst.reserve(64), build_->il.reserve(64), build_->ol.reserve(64);
-      build_->start.reserve(32), build_->accept.reserve(32);
+      // (a thread that builds one target graph per task builds them all alike: the vectors of the last graph
+      //  handed over on this thread, capacity included, serve the next one -- no allocation per graph)
+      std::unique_ptr<Build>& spare = spareBuild();
+      if (spare) {
+        build_ = std::move(spare);
+      } else {
+        build_.reset(new Build());
+        build_->src.reserve(64), build_->dst.reserve(64), build_->il.reserve(64), build_->ol.reserve(64);
+        build_->start.reserve(32), build_->accept.reserve(32);
+      }
     }
     return true;
+  }
+  static std::unique_ptr<Build>& spareBuild() {
+    static thread_local std::unique_ptr<Build> spare;
+    return spare;
   }
   /** the handle, with everything collected so far handed over */
   gtnx_graph_t h() const {
@@ -344,9 +363,11 @@ class Graph {
     } done{dirty_};
     if (nn) detail::check(gtnx_graph_add_nodes(h_, nn, st.data(), ac.data()));
     if (na) detail::check(gtnx_graph_add_arcs(h_, na, src.data(), dst.data(), il.data(), ol.data(), w.empty() ? nullptr : w.data()));
-    // keep the capacity for the next round
+    // keep the capacity for the next round: of this graph or, more likely, of the next graph this thread builds
     st.clear(), ac.clear(), src.clear(), dst.clear(), il.clear(), ol.clear(), w.clear();
     b.start.swap(st), b.accept.swap(ac), b.src.swap(src), b.dst.swap(dst), b.il.swap(il), b.ol.swap(ol);
+    std::unique_ptr<Build>& spare = spareBuild();
+    if (!spare && b.src.capacity() <= (1u << 16)) spare = std::move(build_);
   }
   size_t count(gtnx_status_t (*fn)(gtnx_graph_t, int64_t*)) const {
     int64_t v;

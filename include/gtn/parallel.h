@@ -11,7 +11,10 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <memory>
+#include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <functional>
@@ -32,97 +35,257 @@ auto pickElem(size_t size, size_t i, const V& v) -> decltype(v[0]) {
   if (v.size() == 1) return v[0];
   throw std::runtime_error("parallelMap getIdxOrBroadcast got invalid size or unbroadcastable vector");
 }
-// Persistent worker pool (the reference keeps one too: thread_pool.h:27-91,
-// parallel_map.cpp:18-46, grown on demand and never shrunk).  A job is a callable
-// every participating thread runs once; the caller takes part as well.
+// Persistent worker pool (the reference keeps one too: thread_pool.h:27-91, parallel_map.cpp:18-46, grown on
+// demand and never shrunk).  Differences that matter on a host that only PREPARES work for the GPU:
+//  * the calling thread takes tasks as well, from the first instant -- a map of cheap tasks (512 backward()
+//    calls are 512 records of a few dozen nanoseconds) is over before a sleeping thread could have been woken,
+//    and nobody waits for threads that never took a task;
+//  * a worker that ran out of tasks can keep looking for the next job for a while before it goes to sleep
+//    (GTN_AMD_SPIN_US, default 0: measured on the 256-thread host of an MI355X, sleeping workers take their
+//    first task 40 us after the call and spinning ones 35 us -- while thirty spinning threads made the tasks
+//    themselves two to four times slower).
 class Pool {
  public:
+  struct Job {
+    std::atomic<size_t> next{0};   // next task index to hand out
+    std::atomic<size_t> done{0};   // tasks finished
+    std::atomic<int> active{0};    // threads inside work() that may still hand in results
+    size_t n = 0, grain = 1;
+    size_t max_workers = 0;        // pool threads with an index below this take part
+    int compose_mode = -1;         // the caller's gtnx_compose_mode: goes with the tasks
+    bool region = true;            // announce the threads to the engine (gtnx_parallel_enter / leave)
+    void (*run)(void* ctx, size_t i) = nullptr;
+    void* ctx = nullptr;
+    std::exception_ptr first;
+    std::mutex mu;
+    std::chrono::steady_clock::time_point t0;  // GTN_AMD_POOL_TRACE
+    int trace_slot = 0;                        // (even / odd jobs apart: a step is parallelMap(fwd), parallelMap(bwd))
+  };
+  // GTN_AMD_POOL_TRACE=1: where the time of a map goes, printed at exit (diagnostic)
+  struct Trace {
+    std::mutex mu;
+    int slot = 0;
+    double jobs = 0, threads = 0, wake_us = 0, wake_max_us = 0, busy_us = 0, busy_max_us = 0, caller_us = 0, total_us = 0,
+           enter_us = 0, leave_us = 0;
+    ~Trace() {
+      if (jobs > 0)
+        std::fprintf(stderr,
+                     "[gtn pool] slot %d: jobs %.0f  threads/job %.1f  first-grab latency avg %.1f us (max %.1f)  busy/thread avg %.1f us (max %.1f)  "
+                     "enter %.1f leave %.1f us/thread  caller's share %.1f us  job total %.1f us\n",
+                     slot, jobs, threads / jobs, wake_us / std::max(1.0, threads), wake_max_us, busy_us / std::max(1.0, threads),
+                     busy_max_us, enter_us / std::max(1.0, threads), leave_us / std::max(1.0, threads), caller_us / jobs,
+                     total_us / jobs);
+    }
+  };
+  static Trace& trace(int slot) {
+    static Trace t[2];
+    return t[slot & 1];
+  }
+  static bool tracing() {
+    static const bool on = std::getenv("GTN_AMD_POOL_TRACE") != nullptr;
+    return on;
+  }
   static Pool& get() {
     static Pool p;
     return p;
   }
-  /** run `job` on `nthreads` pool threads (the caller runs `callerFirst` and waits: what it allocates -- it
-   *  runs the region's deferred calls afterwards -- stays apart from what the pool's threads build and take
-   *  down).  Nested or concurrent calls run on the calling thread only. */
-  template <class Job, class Pre>
-  void run(size_t nthreads, Job&& job, Pre&& callerFirst) {
+  /** run tasks 0 .. n-1 on up to `nthreads` pool threads and the calling thread.  Nested or concurrent calls run
+   *  on the calling thread only. */
+  void run(const std::shared_ptr<Job>& job, size_t nthreads) {
     std::unique_lock<std::mutex> call(callMutex_, std::try_to_lock);
-    if (!call.owns_lock() || nthreads <= 1) {
-      callerFirst();
-      job();
+    if (!call.owns_lock() || nthreads <= 1 || job->n <= 1) {
+      work(*job, true);
       return;
     }
     grow(nthreads);
-    {
-      std::lock_guard<std::mutex> lk(mutex_);
-      job_ = [&job] { job(); };
-      want_ = nthreads;
-      pending_ = nthreads;
-      ++epoch_;
+    job->max_workers = nthreads;
+    if (tracing()) {
+      int c[3] = {0, 0, 0};
+      for (size_t i = 0; i < threads_.size() && i < 64; ++i) c[phase_[i].load(std::memory_order_relaxed)]++;
+      phaseSum_[0] += c[0], phaseSum_[1] += c[1], phaseSum_[2] += c[2];
+      job->trace_slot = int(traceSeq_++ & 1);
+      job->t0 = std::chrono::steady_clock::now();
     }
-    wake_.notify_all();
-    callerFirst();  // the workers are already running
-    std::unique_lock<std::mutex> lk(mutex_);
-    done_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
+    {
+      lockJob();
+      job_ = job;
+      unlockJob();
+    }
+    // (sequentially consistent on both sides: a worker either sees the new epoch or is seen as parked)
+    epoch_.fetch_add(1, std::memory_order_seq_cst);
+    if (parked_.load(std::memory_order_seq_cst) > 0) {
+      std::lock_guard<std::mutex> lk(mutex_);
+      wake_.notify_all();
+    }
+    work(*job, true);
+    // every task ran and every thread that took one has handed in what it recorded
+    size_t spins = 0;
+    while (job->done.load(std::memory_order_acquire) < job->n || job->active.load(std::memory_order_acquire) > 0) {
+      if (++spins < 4096)
+        cpuRelax();
+      else
+        std::this_thread::yield();
+    }
+    lockJob();
+    job_.reset();
+    unlockJob();
+    if (tracing()) {
+      Trace& t = trace(job->trace_slot);
+      std::lock_guard<std::mutex> lk(t.mu);
+      t.slot = job->trace_slot;
+      t.jobs += 1;
+      t.total_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - job->t0).count();
+    }
   }
 
  private:
   Pool() = default;
   ~Pool() {
+    if (tracing())
+      std::fprintf(stderr, "[gtn pool] workers at job start: idle %ld  still in tasks %ld  reclaiming %ld (sums over jobs)\n", phaseSum_[0],
+                   phaseSum_[1], phaseSum_[2]);
     {
       std::lock_guard<std::mutex> lk(mutex_);
-      stop_ = true;
+      stop_.store(true, std::memory_order_release);
     }
     wake_.notify_all();
     for (auto& t : threads_) t.join();
   }
+  static void cpuRelax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
+  void lockJob() {
+    while (jobLock_.test_and_set(std::memory_order_acquire)) cpuRelax();
+  }
+  void unlockJob() { jobLock_.clear(std::memory_order_release); }
+  static int64_t spinMicros() {
+    static const int64_t us = [] {
+      if (const char* e = std::getenv("GTN_AMD_SPIN_US")) return int64_t(std::atol(e));
+      return int64_t(0);
+    }();
+    return us;
+  }
+  // the share of one thread: tasks in grains until none is left
+  static void work(Job& j, bool caller) {
+    j.active.fetch_add(1, std::memory_order_acq_rel);
+    bool entered = false;
+    int oldMode = -1;
+    const bool tr = tracing();
+    std::chrono::steady_clock::time_point a0, a1, a2, a3;
+    for (size_t i0 = j.next.fetch_add(j.grain, std::memory_order_acq_rel); i0 < j.n;
+         i0 = j.next.fetch_add(j.grain, std::memory_order_acq_rel)) {
+      if (!entered) {
+        entered = true;
+        if (tr) a0 = std::chrono::steady_clock::now();
+        if (j.region) {
+          // graph functions called from here are deferred to the join (gtn_amd.h); they run under the compose
+          // mode of the thread that called parallelMap
+          gtnx_parallel_enter();
+          if (!caller) gtnx_compose_mode(j.compose_mode, &oldMode);
+        }
+        if (tr) a1 = std::chrono::steady_clock::now();
+      }
+      const size_t i1 = std::min(j.n, i0 + j.grain);
+      for (size_t i = i0; i < i1; ++i) {
+        try {
+          j.run(j.ctx, i);
+        } catch (...) {
+          std::lock_guard<std::mutex> lk(j.mu);
+          if (!j.first) j.first = std::current_exception();
+        }
+      }
+      j.done.fetch_add(i1 - i0, std::memory_order_acq_rel);
+    }
+    if (tr && entered) a2 = std::chrono::steady_clock::now();
+    if (entered && j.region) {
+      if (!caller) gtnx_compose_mode(oldMode, nullptr);
+      gtnx_parallel_leave();
+    }
+    if (tr && entered) {
+      a3 = std::chrono::steady_clock::now();
+      auto us = [](auto x, auto y) { return std::chrono::duration<double, std::micro>(y - x).count(); };
+      Trace& t = trace(j.trace_slot);
+      std::lock_guard<std::mutex> lk(t.mu);
+      t.threads += 1;
+      const double w = us(j.t0, a0), b = us(a1, a2);
+      t.wake_us += w;
+      t.wake_max_us = std::max(t.wake_max_us, w);
+      t.busy_us += b;
+      t.busy_max_us = std::max(t.busy_max_us, b);
+      t.enter_us += us(a0, a1);
+      t.leave_us += us(a2, a3);
+      if (caller) t.caller_us += us(a0, a3);
+    }
+    j.active.fetch_sub(1, std::memory_order_acq_rel);
+  }
   void grow(size_t n) {
     while (threads_.size() < n) {
       const size_t idx = threads_.size();
-      uint64_t seen;
-      {
-        std::lock_guard<std::mutex> lk(mutex_);
-        seen = epoch_;
-      }
-      threads_.emplace_back([this, idx, seen]() mutable {
+      const uint64_t seen0 = epoch_.load(std::memory_order_acquire);
+      threads_.emplace_back([this, idx, seen0]() {
+        uint64_t seen = seen0;
         for (;;) {
-          std::function<void()> job;
-          {
+          // look for the next job: spinning for a while, then asleep
+          const int64_t spinUs = spinMicros();
+          bool have = false;
+          if (spinUs > 0) {
+            const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(spinUs);
+            for (unsigned k = 0;; ++k) {
+              if (epoch_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_acquire)) {
+                have = true;
+                break;
+              }
+              cpuRelax();
+              if ((k & 63) == 63 && std::chrono::steady_clock::now() >= until) break;
+            }
+          }
+          if (!have) {
             std::unique_lock<std::mutex> lk(mutex_);
-            wake_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-            if (stop_) return;
-            seen = epoch_;
-            if (idx >= want_) continue;
-            job = job_;
+            parked_.fetch_add(1, std::memory_order_seq_cst);
+            wake_.wait(lk, [&] { return stop_.load(std::memory_order_acquire) || epoch_.load(std::memory_order_seq_cst) != seen; });
+            parked_.fetch_sub(1, std::memory_order_acq_rel);
           }
-          job();
-          {
-            std::lock_guard<std::mutex> lk(mutex_);
-            --pending_;
-          }
-          done_.notify_one();
+          if (stop_.load(std::memory_order_acquire)) return;
+          seen = epoch_.load(std::memory_order_acquire);
+          std::shared_ptr<Job> job;
+          lockJob();
+          job = job_;
+          unlockJob();
+          if (!job || idx >= job->max_workers) continue;
+          phase_[idx & 63].store(1, std::memory_order_relaxed);
+          work(*job, false);
+          job.reset();
+          phase_[idx & 63].store(2, std::memory_order_relaxed);
           // the caller goes on (the engine runs the region's deferred calls now); this thread takes apart
           // what earlier steps let go of meanwhile -- off the caller's critical path, shared with the
           // pool's other threads
-          gtnx_reclaim();
+          static const bool noReclaim = std::getenv("GTN_AMD_NO_RECLAIM") != nullptr;  // (experiments)
+          if (!noReclaim) gtnx_reclaim();
+          phase_[idx & 63].store(0, std::memory_order_relaxed);
         }
       });
     }
   }
   std::mutex callMutex_, mutex_;
-  std::condition_variable wake_, done_;
+  std::condition_variable wake_;
   std::vector<std::thread> threads_;
-  std::function<void()> job_;
-  uint64_t epoch_ = 0;
-  size_t want_ = 0, pending_ = 0;
-  bool stop_ = false;
+  std::shared_ptr<Job> job_;
+  std::atomic_flag jobLock_ = ATOMIC_FLAG_INIT;
+  std::atomic<uint64_t> epoch_{0};
+  std::atomic<int> parked_{0};
+  std::atomic<bool> stop_{false};
+  uint64_t traceSeq_ = 0;
+  std::atomic<int> phase_[64] = {};  // GTN_AMD_POOL_TRACE: 0 idle, 1 in tasks, 2 reclaiming
+ public:
+  long phaseSum_[3] = {0, 0, 0};
 };
 
-inline void noPrelude() {}
-
-template <class Body, class Pre = void (*)()>
-void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst = &noPrelude) {
+template <class Body>
+void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, bool region = true) {
   // min(size, hardware_concurrency) threads like parallel_map.cpp:18-26, capped.  The engine defers
   // the graph-function calls of the region's threads to the join (gtnx_parallel_enter), so the threads
   // only build graphs: a few dozen of them finish a batch of targets in well under a millisecond.
@@ -144,38 +307,26 @@ void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, Pre callerFirst =
     const long v = e ? std::atol(e) : 0;
     return v > 0 ? size_t(v) : size_t(0);
   }();
+  if (n == 0) return;
   const size_t light = std::max<size_t>(n >= 2 ? 2 : 1, n / 16);
   const size_t nt = std::min<size_t>(std::min(n, hw), fixed ? fixed : std::min(light, maxThreads));
-  std::atomic<size_t> next{0};
-  std::exception_ptr first;
-  std::mutex mu;
-  auto worker = [&]() {
-    // graph functions called from here are deferred to the join below (gtn_amd.h)
-    struct Region {
-      bool on;
-      explicit Region(bool o) : on(o) {
-        if (on) gtnx_parallel_enter();
-      }
-      ~Region() {
-        if (on) gtnx_parallel_leave();
-      }
-    } region(nt > 1);
-    // a few indices per grab: tasks are small (one target graph each)
-    const size_t grain = std::max<size_t>(1, n / (nt * 4));
-    for (size_t i0 = next.fetch_add(grain); i0 < n; i0 = next.fetch_add(grain)) {
-      for (size_t i = i0; i < std::min(n, i0 + grain); ++i) {
-        try {
-          body(i);
-        } catch (...) {
-          std::lock_guard<std::mutex> lk(mu);
-          if (!first) first = std::current_exception();
-        }
-      }
-    }
-  };
-  Pool::get().run(nt, worker, callerFirst);
+  auto job = std::make_shared<Pool::Job>();
+  job->n = n;
+  // a few indices per grab: tasks are small (one target graph each)
+  job->grain = std::max<size_t>(1, n / ((nt + 1) * 4));
+  job->region = region && nt > 1;
+  using BodyT = typename std::remove_reference<Body>::type;
+  job->ctx = const_cast<void*>(static_cast<const void*>(&body));
+  job->run = [](void* ctx, size_t i) { (*static_cast<BodyT*>(ctx))(i); };
+  if (job->region) {  // the mode the tasks' compose / intersect calls run under: the caller's
+    int cur = -1;
+    if (gtnx_compose_mode(0, &cur) == GTNX_OK) gtnx_compose_mode(cur, nullptr);
+    job->compose_mode = cur;
+  }
+  Pool::get().run(job, nt);
   // the join: everything the tasks asked the engine for runs now, batched (no-op when nothing was deferred)
-  if (nt > 1) {
+  std::exception_ptr first = job->first;
+  if (job->region) {
     const gtnx_status_t st = gtnx_parallel_flush();
     if (st != GTNX_OK && !first) {
       // the first failed call's error, as the exception its own function throws (gtn/graph.h: detail::check)
@@ -197,9 +348,8 @@ auto parallelMap(FuncType&& function, Args&&... inputs) {
   size_t size = 0;
   (void)std::initializer_list<int>{(size = std::max(size, inputs.size()), 0)...};
   using OutType = decltype(function(detail::pickElem(1, 0, inputs)...));
-  auto prelude = [] {};
   if constexpr (std::is_void<OutType>::value) {
-    detail::runIndexed(size, [&](size_t i) { function(detail::pickElem(size, i, inputs)...); }, 64, prelude);
+    detail::runIndexed(size, [&](size_t i) { function(detail::pickElem(size, i, inputs)...); }, 64);
   } else {
     // results are constructed in place by the tasks (no default-constructed OutType per element first: for a
     // Graph that would be a graph created and thrown away per task), then moved into the vector in order
@@ -222,7 +372,7 @@ auto parallelMap(FuncType&& function, Args&&... inputs) {
           new (&slots.raw[i]) OutType(function(detail::pickElem(size, i, inputs)...));
           slots.made[i] = 1;
         },
-        64, prelude);
+        64);
     std::vector<OutType> out;
     out.reserve(size);
     for (size_t i = 0; i < size; ++i) out.emplace_back(std::move(slots.at(i)));

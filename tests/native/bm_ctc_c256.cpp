@@ -108,9 +108,13 @@ int main(int argc, char** argv) {
   };
 
   for (int i = 0; i < 5; ++i) ctcBatched();
+  (void)hipDeviceSynchronize();
   ph[0] = ph[1] = ph[2] = ph[3] = 0;
   const auto t0 = std::chrono::steady_clock::now();
   for (int i = 0; i < iters; ++i) ctcBatched();
+  // (item() returns when the LOSS has been computed; the step's backward sweep may still be running while the
+  //  host prepares the next step -- the clock stops when the device has finished everything)
+  (void)hipDeviceSynchronize();
   const auto t1 = std::chrono::steady_clock::now();
   const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
   std::printf("{\"program\": \"bm_ctc_c256\", \"B\": %d, \"T\": %d, \"U\": %d, \"alphabet\": %d, \"emissions\": \"%s\", "

@@ -121,6 +121,41 @@ def cpu_baseline(B, T, Cn, U, seed, budget_s=45.0):
             "sample": f"4 utterances (T={T}, C={Cn}, U={U}) through the scalar C oracle"}
 
 
+def parity_in_run(em, tg, losses, grads, T, Cn, U, n):
+    """The first `n` utterances of the TIMED batch through the checker in this same process: the unmodified reference
+    (oracle/_ref/libgtn_ref.so: ref_ctc_batch = parallelMap(fwd) + parallelMap(bwd), benchmarks/ctc.cpp:136-168) when it
+    was built, else the C restatement (oracle/liboracle.so).  `losses` [B] and `grads` [B][T][C] (or None) are what the
+    timed loop's last step left on the device."""
+    n = int(min(n, len(tg)))
+    path = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
+    want_l = np.zeros(n, np.float32)
+    want_g = np.zeros((n, T, Cn), np.float32)
+    e = np.ascontiguousarray(em[:n])
+    t = np.ascontiguousarray(tg[:n])
+    if os.path.exists(path):
+        lib = C.CDLL(path)
+        lib.ref_ctc_batch.restype = C.c_double
+        lib.ref_ctc_batch.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]
+        thr = C.c_int()
+        lib.ref_ctc_batch(e.ctypes.data, t.ctypes.data, n, T, Cn, U, 0, 1, want_l.ctypes.data, want_g.ctypes.data, C.byref(thr))
+        checker = "reference (oracle/_ref/libgtn_ref.so: the unmodified gtn library compiled from /root/reference)"
+    else:
+        from oracle_lib import ctc_loss
+        for b in range(n):
+            want_l[b], g = ctc_loss(e[b], t[b])
+            want_g[b] = g.reshape(T, Cn)
+        checker = "port (oracle/liboracle.so: C restatement pinned to the reference, tests/test_oracle.py)"
+    got_l = np.asarray(losses[:n], np.float64)
+    out = {"n": n, "checker": checker,
+           "loss_max_rel": float(np.max(np.abs(got_l - want_l) / np.maximum(np.abs(want_l), 1e-30))),
+           "tolerance": "loss_max_rel <= 1e-4 (north_star); grad_max_abs <= 1e-2 (posteriors in [-1, 1]; the reference's own float32 "
+                        "recursion over the built lattice carries ~4e-3 of rounding at T = 1000, DESIGN.md section 4)"}
+    if grads is not None:
+        out["grad_max_abs"] = float(np.max(np.abs(np.asarray(grads[:n], np.float64) - want_g)))
+    out["ok"] = bool(out["loss_max_rel"] <= 1e-4 and out.get("grad_max_abs", 0.0) <= 1e-2)
+    return out
+
+
 def unmodified_caller(B):
     """The reference's own benchmark program, benchmarks/ctc.cpp:136-168, compiled UNMODIFIED against
     include/gtn and linked to libgtn_amd.so (tests/dropin/Makefile): per-utterance graph functions called
@@ -572,6 +607,15 @@ def main():
         reference_api["reference_loop"] = reference_loop(B, Cn, "device")
         reference_api["reference_loop_host_emissions"] = reference_loop(B, Cn, "host")
     ranks = per_rank_report(dist, torch, world, dev, host_ms or {}, dt_local)
+    parity = None
+    if rank == 0:
+        # the timed batch against the checker, in this run: 4 utterances (2 at C5's size: 16 MB of emissions each)
+        try:
+            npar = 4 if T * Cn <= 1000 * 256 else 2
+            gpar = grad_timed[:npar].cpu().numpy() if grad_timed is not None else None
+            parity = parity_in_run(em, tg, losses_timed, gpar, T, Cn, U, npar)
+        except Exception as e:  # reported, and fails the run below
+            parity = {"error": str(e)[:300], "ok": False}
     if rank == 0:
         losses = losses_timed
         out = {
@@ -609,11 +653,21 @@ def main():
                             "region" + (" -- forced at world size 1 (GTN_BENCH_FORCE_DIST=1)" if forced and world == 1 else ""))
             if world_dist else None,
             "loss_mean": float(np.mean(losses)),
+            # the first utterances of the timed batch, losses and emission gradients, against the reference in this run
+            "parity_in_run": parity,
         }
         if world == 1 and not args.no_unmodified_caller:
             out["unmodified_caller"] = unmodified_caller(B)
         if world == 1 and native is not None and not args.no_reference_api:
             out["reference_api"] = reference_api
+            # the same step written with the REFERENCE'S OWN API (parallelMap over per-utterance lambdas calling the
+            # per-graph functions: tests/native/bm_ctc_c256.cpp = benchmarks/ctc.cpp:136-168 at C = 256; one process,
+            # same GPU, emissions in device memory; item() returns with the loss and the clock stops after a device
+            # synchronisation) next to `value` (gtn::Batch, an API the reference does not have)
+            rl = (reference_api or {}).get("reference_loop") or {}
+            if "losses_per_s" in rl:
+                out["value_reference_api"] = rl["losses_per_s"]
+                out["ms_per_step_reference_api"] = rl.get("ctcBatched_ms")
         if world == 1 and not args.no_configs and (B, T, Cn, U) == (512, 1000, 256, 100):
             # the children (other processes on the same GPU) get the memory this process's pools still hold
             gtn.synchronize()
@@ -623,6 +677,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234, args.cpu_baseline_seconds)
         print(json.dumps(out))
+        if parity is not None and not parity.get("ok", False):
+            print("bench.py: the timed batch does NOT match the checker: " + json.dumps(parity), file=sys.stderr)
+            sys.stdout.flush()
+            os._exit(3)
     # orderly teardown: drop every graph, return pooled memory, then let HIP exit
     del keep, ems, comp, e0
     gtn.set_stream(None)

@@ -254,7 +254,7 @@ Batch::~Batch() {
       auto* part = new std::vector<Graph>();
       part->reserve(o.end - o.begin);
       for (size_t i = o.begin; i < o.end && i < graphs.size(); ++i) part->push_back(std::move(graphs[i]));
-      give_back(o.home.get(), part);
+      give_back(o.home, part);
     }
     graphs.clear();
     return;
@@ -975,7 +975,7 @@ float batch_item_host(const BatchP& x, int i) {
   if (!x->host_vals_valid) {
     x->host_vals.resize(size_t(x->n));
     if (x->host_ev) {  // on its way since the values were launched (batch_prefetch_items)
-      HIP_CHECK(hipEventSynchronize(static_cast<hipEvent_t>(x->host_ev)));
+      Runtime::get().drain_until(x->host_ev);  // (reclaims while the sweep is still running)
       std::memcpy(x->host_vals.data(), x->host_pin->ptr, sizeof(float) * size_t(x->n));
       (void)hipEventDestroy(static_cast<hipEvent_t>(x->host_ev));
       x->host_ev = nullptr;

@@ -52,7 +52,7 @@ struct Batch {
     size_t begin, end;
   };
   std::vector<Origin> origins;
-  void (*give_back)(void* home, std::vector<Graph>* part) = nullptr;
+  void (*give_back)(const std::shared_ptr<void>& home, std::vector<Graph>* part) = nullptr;
   // SCALAR: the values on the host, fetched once when an element's item() is asked for (batch_item_host)
   std::vector<float> host_vals;
   bool host_vals_valid = false;

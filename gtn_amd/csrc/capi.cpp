@@ -147,30 +147,9 @@ GTNX_API gtnx_status_t gtnx_memory_stats(uint64_t* r, uint64_t* u) {
 }
 GTNX_API gtnx_status_t gtnx_reclaim(void) {
   return guard([&] {
-    // A FEW threads at a time (GTNX_RECLAIMERS, default 2): the pool threads of a parallelMap all offer to reclaim
-    // when their job is done (include/gtn/parallel.h), and what they would free was largely allocated by the
-    // caller's thread -- a crowd of them only queues on that allocator arena's lock and slows the caller down
-    // (1.4 us per malloc measured with 32 reclaimers); the others go back to sleep.
-    static const int max_reclaimers = [] {
-      const char* e = std::getenv("GTNX_RECLAIMERS");
-      const int v = e ? std::atoi(e) : 2;
-      return v > 0 ? v : 1;
-    }();
-    static std::atomic<int> active{0};
-    region_reclaim_thread();  // what THIS thread built and nobody refers to any more (region.cpp)
-    if (!Runtime::initialized()) return;
-    if (active.fetch_add(1, std::memory_order_acquire) >= max_reclaimers) {
-      active.fetch_sub(1, std::memory_order_release);
-      return;
-    }
-    try {
-      while (Runtime::get().drain_some(16)) {
-      }
-    } catch (...) {
-      active.fetch_sub(1, std::memory_order_release);
-      throw;
-    }
-    active.fetch_sub(1, std::memory_order_release);
+    // what THIS thread built, or let go of, and nobody refers to any more (runtime.h: every thread takes apart
+    // what it allocated; the pool threads of a parallelMap call this when their share of a region is done)
+    region_reclaim_thread();
   });
 }
 GTNX_API gtnx_status_t gtnx_empty_cache(void) {
@@ -197,8 +176,8 @@ GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
       region_trash(p);  // let go of when the thread leaves the region
     else if (p->s && p->s->pending)
       delete p;         // a placeholder's handle is a reference to its slice: nothing to take apart here (region.cpp)
-    else if (Runtime::initialized())
-      Runtime::get().defer_delete(p, [](void* q) { delete static_cast<Graph*>(q); });
+    else if (Runtime::initialized())  // taken apart later, by the thread that made the graph (runtime.h)
+      Runtime::send(p->s && p->s->home ? p->s->home : Runtime::home(), p, [](void* q) { delete static_cast<Graph*>(q); });
     else
       delete p;
   });

@@ -60,6 +60,9 @@ struct Structure {
   // through the C ABI goes to region_value() first.
   struct Pending* pending = nullptr;  // (lives in the same allocation: region.cpp PlaceholderStructure)
   std::atomic<int> pending_uses{0};  // as Weights::pending_uses
+  // the deferred-reclamation list of the thread that made the graph: a handle that is destroyed elsewhere is sent
+  // there to be taken apart (runtime.h: every thread frees what it allocated)
+  Runtime::InboxP home;
   // The graph is exactly the CTC target acceptor of benchmarks/ctc.cpp:40-58 over these labels (checked at
   // arcSort, O(A)): a batch of such graphs takes the device-built band records (batch.cpp: CTC_TARGETS)
   std::shared_ptr<std::vector<int>> ctc_labels;

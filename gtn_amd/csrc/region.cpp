@@ -131,6 +131,21 @@ void Pending::release_inputs() {
   b = Graph(Graph::Empty{});
 }
 
+void Pending::recycle() {
+  release_inputs();
+  op = RO_NEG;
+  depth = 1;
+  state.store(0, std::memory_order_relaxed);
+  err = nullptr;
+  res = Graph(Graph::Empty{});
+  has_res.store(false, std::memory_order_relaxed);
+  batch.reset();
+  idx = -1;
+  sg = nullptr;
+  local = -1;
+  mode = -1;
+}
+
 namespace {
 
 // a placeholder's structure and its call in one piece (a slice hands them out of chunks)
@@ -139,20 +154,47 @@ struct PlaceholderStructure : Structure {
 };
 
 constexpr size_t kChunk = 64;
-struct Inbox;
 
 struct Slice {
   // placeholders and backward calls live in chunks owned by the slice; a placeholder handle is an aliasing
   // shared_ptr of the slice, so the slice (and every call in it) lives as long as any of its results
+  // (A chunk outlives its slice: when the slice dies -- on the thread that recorded it, runtime.h -- its chunks go
+  //  to that thread's spare list with their placeholders still constructed, only the calls reset.  A placeholder's
+  //  Structure is never written to apart from `pending`, and constructing and destroying its forty members was
+  //  a fifth of a microsecond per recorded call -- half a millisecond per step of the vector forms at B = 512.)
   struct Chunk {
     typename std::aligned_storage<sizeof(PlaceholderStructure), alignof(PlaceholderStructure)>::type raw[kChunk];
-    size_t used = 0;
+    size_t used = 0;   // handed out to the slice that holds the chunk
+    size_t built = 0;  // constructed (>= used)
     PlaceholderStructure* at(size_t i) { return reinterpret_cast<PlaceholderStructure*>(&raw[i]); }
     ~Chunk() {
-      for (size_t i = 0; i < used; ++i) at(i)->~PlaceholderStructure();
+      for (size_t i = 0; i < built; ++i) at(i)->~PlaceholderStructure();
     }
   };
+  // the thread's spare chunks; null once the thread is shutting down (slices may still die on it after its
+  // thread_local objects are gone: the runtime's list is emptied last)
+  static std::vector<std::unique_ptr<Chunk>>* spare_chunks() {
+    struct Holder {
+      std::vector<std::unique_ptr<Chunk>> v;
+      bool* gone;
+      explicit Holder(bool* g) : gone(g) {}
+      ~Holder() { *gone = true; }
+    };
+    static thread_local bool gone = false;  // (trivially destructible: stays readable)
+    if (gone) return nullptr;
+    static thread_local Holder h(&gone);
+    return &h.v;
+  }
   std::vector<std::unique_ptr<Chunk>> chunks;
+  ~Slice() {
+    std::vector<std::unique_ptr<Chunk>>* spare = spare_chunks();
+    if (!spare) return;  // (the chunks die with the slice)
+    for (auto& c : chunks) {
+      for (size_t i = 0; i < c->used; ++i) c->at(i)->call.recycle();
+      c->used = 0;
+      if (spare->size() < 128) spare->push_back(std::move(c));
+    }
+  }
   std::deque<Pending> plain;  // backward calls (no placeholder)
   std::deque<SliceGroup> groups;
   size_t n_calls = 0;
@@ -172,12 +214,26 @@ struct Slice {
     int side = 0, local = -1;
   } last_lin;
   bool executed = false;
-  std::shared_ptr<struct Inbox> home;  // of the thread that recorded the slice: where it is taken apart
+  Runtime::InboxP home;  // of the thread that recorded the slice: where it is taken apart
 
   PlaceholderStructure* new_placeholder() {
-    if (chunks.empty() || chunks.back()->used == kChunk) chunks.emplace_back(new Chunk());
+    if (chunks.empty() || chunks.back()->used == kChunk) {
+      std::vector<std::unique_ptr<Chunk>>* spare = spare_chunks();
+      if (spare && !spare->empty()) {
+        chunks.push_back(std::move(spare->back()));
+        spare->pop_back();
+      } else {
+        chunks.emplace_back(new Chunk());
+      }
+    }
     Chunk& c = *chunks.back();
-    PlaceholderStructure* ps = new (&c.raw[c.used]) PlaceholderStructure();
+    PlaceholderStructure* ps;
+    if (c.used < c.built) {
+      ps = c.at(c.used);  // (constructed by an earlier slice, its call reset)
+    } else {
+      ps = new (&c.raw[c.used]) PlaceholderStructure();
+      ++c.built;
+    }
     ++c.used;
     return ps;
   }
@@ -210,6 +266,7 @@ thread_local SliceP t_slice;   // what this thread has recorded and not handed i
 thread_local std::vector<Graph*> t_trash;
 thread_local bool t_vector_call = false;  // recording the calls of a gtnx_*_n vector form (region_run_vector)
 thread_local std::shared_ptr<StageArena> t_arena;
+thread_local bool t_reclaims = false;  // this thread calls gtnx_reclaim (a pool thread): its list is emptied there
 
 // ---- return to sender ------------------------------------------------------------------------------------
 // What a region's thread builds in its tasks (target graphs, emission graphs, placeholders: a few dozen heap
@@ -218,71 +275,24 @@ thread_local std::shared_ptr<StageArena> t_arena;
 // allocating thread's arena under that arena's lock, and the allocating thread is by then building the NEXT
 // step's graphs out of the same arena: measured on the 256-thread host of an MI355X, the tasks of a region ran two
 // to five times slower while other threads freed the previous step's objects (16 -> 40-80 us per task).  So
-// garbage goes home: every thread has an inbox, a slice (and the leaf graphs its tasks built) is pushed to the
-// inbox of the thread that recorded it when its last reference dies, and a thread empties its own inbox when it
-// has finished its share of a region (gtnx_reclaim) or, if it never reclaims, when it next enters one.
-struct Inbox {
-  std::mutex mu;
-  std::vector<std::pair<void*, void (*)(void*)>> items;
-  bool dead = false;  // the thread is gone: whoever has garbage for it takes it apart on the spot
-};
-using InboxP = std::shared_ptr<Inbox>;
-void inbox_drain(Inbox& b) {
-  for (;;) {
-    std::vector<std::pair<void*, void (*)(void*)>> batch;
-    {
-      std::lock_guard<std::mutex> lk(b.mu);
-      if (b.items.empty()) return;
-      batch.swap(b.items);
-    }
-    for (auto& e : batch) e.second(e.first);  // (destructors may push more)
-  }
-}
-void inbox_push(const InboxP& b, void* p, void (*del)(void*)) {
-  if (b) {
-    std::lock_guard<std::mutex> lk(b->mu);
-    if (!b->dead) {
-      b->items.push_back({p, del});
-      return;
-    }
-  }
-  del(p);
-}
-struct InboxHolder {
-  InboxP box = std::make_shared<Inbox>();
-  bool reclaims = false;  // this thread calls gtnx_reclaim (a pool thread): its inbox is emptied there
-  ~InboxHolder() {
-    {
-      std::lock_guard<std::mutex> lk(box->mu);
-      box->dead = true;
-    }
-    inbox_drain(*box);
-  }
-};
-thread_local InboxHolder t_inbox;
-
+// garbage goes home (runtime.h: Runtime::Inbox): a slice (and the leaf graphs its tasks built) is sent to the list
+// of the thread that recorded it when its last reference dies, and a thread empties its own list when it has
+// finished its share of a region (gtnx_reclaim), when it waits for the device, or when it next enters a region.
 // a slice dies with the last of its placeholders -- usually on the thread that drops a step's results, the one
 // everything waits for: it goes home
 void retire_slice(Slice* s) {
-  InboxP home = std::move(s->home);
-  inbox_push(home, s, [](void* q) { delete static_cast<Slice*>(q); });
+  Runtime::InboxP home = std::move(s->home);
+  Runtime::send(home, s, [](void* q) { delete static_cast<Slice*>(q); });
 }
 // the leaf graphs a batch record took from the slices' digests go home the same way (batch.cpp: Batch::~Batch)
-void give_back_graphs(void* home, std::vector<Graph>* part) {
-  Inbox* b = static_cast<Inbox*>(home);
-  {
-    std::lock_guard<std::mutex> lk(b->mu);
-    if (!b->dead) {
-      b->items.push_back({part, [](void* q) { delete static_cast<std::vector<Graph>*>(q); }});
-      return;
-    }
-  }
-  delete part;
+void give_back_graphs(const std::shared_ptr<void>& home, std::vector<Graph>* part) {
+  Runtime::send(std::static_pointer_cast<Runtime::Inbox>(home), part,
+                [](void* q) { delete static_cast<std::vector<Graph>*>(q); });
 }
 Slice& my_slice() {
   if (!t_slice) {
     t_slice = SliceP(new Slice(), &retire_slice);
-    t_slice->home = t_inbox.box;
+    t_slice->home = Runtime::home();
   }
   return *t_slice;
 }
@@ -1305,7 +1315,9 @@ void region_enter() {
   // what earlier steps let go of is taken apart by the region's threads together (a batch's graphs were built
   // by such threads too), not by the one thread that joins them
   // (a handful of them: the allocator's locks are what more threads would wait on)
-  if (t_depth == 0 && !t_inbox.reclaims) inbox_drain(*t_inbox.box);
+  // (a thread that never reclaims empties its list while it waits for the device -- Runtime::drain_while_busy --
+  //  and here at the latest, once a few steps' worth has piled up)
+  if (t_depth == 0 && !t_reclaims && Runtime::deferred_count() >= 4096) Runtime::drain_deferred();
   if (t_depth++ == 0 && Runtime::initialized()) {
     Shared& sh = shared();
     static const int max_drainers = [] {
@@ -1328,8 +1340,8 @@ void region_leave() {
 }
 
 void region_reclaim_thread() {
-  t_inbox.reclaims = true;
-  inbox_drain(*t_inbox.box);
+  t_reclaims = true;
+  Runtime::drain_deferred();
 }
 
 void region_flush() {

@@ -70,6 +70,7 @@ struct Pending {
   int st() const;                    // 0 queued, 1 done, 2 failed
   BatchP record(int* element) const; // the record this call's result is an element of (null: `res` / not run)
   void release_inputs();             // gives the inputs' pending_uses back and lets go of them
+  void recycle();                    // back to the state of a fresh call (its slot is reused: region.cpp Slice::Chunk)
   ~Pending() { release_inputs(); }
 };
 

@@ -62,8 +62,6 @@ Runtime::Runtime() {
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device_));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  pool_budget_ = size_t(prop.totalGlobalMem) / 4;
-  if (const char* e = std::getenv("GTNX_POOL_BUDGET_GB")) pool_budget_ = size_t(std::atof(e) * double(size_t(1) << 30));
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
 }
@@ -99,13 +97,54 @@ void Runtime::sync() {
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
-void Runtime::defer_delete(void* p, void (*del)(void*)) {
-  bool full;
-  {
-    std::lock_guard<std::mutex> lk(defer_mu_);
-    deferred_.push_back({p, del});
-    full = deferred_.size() >= (1u << 15);
+namespace {
+struct InboxHolder {
+  Runtime::InboxP box = std::make_shared<Runtime::Inbox>();
+  ~InboxHolder() {
+    {
+      std::lock_guard<std::mutex> lk(box->mu);
+      box->dead = true;
+    }
+    for (;;) {  // (destructors may send more: to a dead list, i.e. destroyed by the sender)
+      std::vector<std::pair<void*, void (*)(void*)>> batch;
+      {
+        std::lock_guard<std::mutex> lk(box->mu);
+        if (box->items.empty()) break;
+        batch.swap(box->items);
+      }
+      for (auto& e : batch) e.second(e.first);
+    }
   }
+};
+thread_local InboxHolder t_home;
+}  // namespace
+
+Runtime::InboxP Runtime::home() { return t_home.box; }
+
+void Runtime::send(const InboxP& to, void* p, void (*del)(void*)) {
+  if (to) {
+    std::lock_guard<std::mutex> lk(to->mu);
+    if (!to->dead) {
+      to->items.push_back({p, del});
+      return;
+    }
+  }
+  del(p);
+}
+
+void Runtime::defer_delete(void* p, void (*del)(void*)) {
+  Inbox& b = *t_home.box;
+  bool full = false, dead = false;
+  {
+    std::lock_guard<std::mutex> lk(b.mu);
+    if (b.dead) {
+      dead = true;  // (the thread is on its way out: destroyed now)
+    } else {
+      b.items.push_back({p, del});
+      full = b.items.size() >= (1u << 15);
+    }
+  }
+  if (dead) del(p);
   if (full) drain_deferred();
 }
 
@@ -115,30 +154,46 @@ void Runtime::drain_deferred() {
   }
 }
 
-// destroys up to `max_items` of what is waiting; false when nothing was.  Several threads may share the work
-// (the threads entering a parallelMap region do: region.cpp).
+// destroys up to `max_items` of what is waiting on the calling thread's list; false when nothing was
 bool Runtime::drain_some(size_t max_items) {
+  Inbox& b = *t_home.box;
   std::vector<std::pair<void*, void (*)(void*)>> batch;
   {
-    std::lock_guard<std::mutex> lk(defer_mu_);
-    if (deferred_.empty()) return false;
-    const size_t n = std::min(max_items, deferred_.size());
-    batch.assign(deferred_.end() - n, deferred_.end());
-    deferred_.resize(deferred_.size() - n);
+    std::lock_guard<std::mutex> lk(b.mu);
+    if (b.items.empty()) return false;
+    const size_t n = std::min(max_items, b.items.size());
+    batch.assign(b.items.end() - long(n), b.items.end());
+    b.items.resize(b.items.size() - n);
   }
   for (auto& e : batch) e.second(e.first);  // (destructors may defer more)
   return true;
 }
 
+size_t Runtime::deferred_count() {
+  Inbox& b = *t_home.box;
+  std::lock_guard<std::mutex> lk(b.mu);
+  return b.items.size();
+}
+
+void Runtime::drain_until(void* hip_event) {
+  hipEvent_t ev = static_cast<hipEvent_t>(hip_event);
+  while (hipEventQuery(ev) == hipErrorNotReady) {
+    if (!drain_some(32)) break;
+  }
+  (void)hipGetLastError();
+  HIP_CHECK(hipEventSynchronize(ev));
+}
+
 // reclaim while the GPU is busy and the host would only wait for it; what is left waits for the next such
-// moment or for the threads of the next parallelMap region
+// moment
 void Runtime::drain_while_busy() {
   GTNX_HOST_T("runtime.drain_while_busy");
+  Inbox& b = *t_home.box;
   for (;;) {
     {
-      std::lock_guard<std::mutex> lk(defer_mu_);
-      if (deferred_.empty()) return;
-      if (deferred_.size() >= (1u << 14)) break;  // too much waiting: all of it, now
+      std::lock_guard<std::mutex> lk(b.mu);
+      if (b.items.empty()) return;
+      if (b.items.size() >= (1u << 14)) break;  // too much waiting: all of it, now
     }
     if (hipStreamQuery(stream_) != hipErrorNotReady) {
       (void)hipGetLastError();
@@ -164,23 +219,14 @@ DevMemP Runtime::alloc(size_t bytes) {
   };
   from_pool();
   if (!p && sz >= (size_t(32) << 20)) {
-    // A big block that the pool does not have.  What the caller released since the last reclamation point may
-    // hold it (a step's alpha planes are 0.4 GB at C3; a loop that never waits for the device released a new
-    // set every step and the pool grew by that much per step -- 44 GB after 100 steps -- with a hipMalloc each):
-    // reclaim and look again -- but only once the pool has grown past its budget (a quarter of the device's
-    // memory, GTNX_POOL_BUDGET_GB).  Below it the block is simply allocated: a step's garbage is taken apart
-    // by the worker threads of the next parallelMap region while the joining thread is already allocating, so
-    // two generations of a step's arenas are alive at that moment and reclaiming HERE would put the whole
-    // teardown (1.5 ms at C3) on the one thread everything waits for.
-    bool over;
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      over = reserved_ + sz > pool_budget_;
-    }
-    if (over) {
-      drain_deferred();
-      from_pool();
-    }
+    // A big block that the pool does not have.  What this thread released since its last reclamation point may
+    // hold it (a step's alpha planes are 0.4 GB at C3, the built lattices of a step 13 GB; a loop that never waits
+    // for the device released a new set every step and the pool grew by that much per step -- 44 GB after 100
+    // steps -- with a hipMalloc each): take the calling thread's own list apart and look again.  (Its OWN list:
+    // what other threads built goes home to them, runtime.h -- this used to be every thread's garbage, 1.5 ms at
+    // C3 on the one thread a step waits for.)
+    drain_deferred();
+    from_pool();
   }
   if (!p) {
     GTNX_HOST_T("runtime.alloc.hipMalloc (pool miss)");

@@ -304,11 +304,11 @@ class Graph {
     if (h_) gtnx_graph_destroy(h_);  // (collected nodes / arcs of a graph nobody ever looked at go with it)
     h_ = nullptr;
     if (build_) {  // (back to the thread's spare slot, capacity kept: see collecting())
-      std::unique_ptr<Build>& spare = spareBuild();
-      if (!spare && build_->src.capacity() <= (1u << 16)) {
+      std::unique_ptr<Build>* spare = spareBuild();
+      if (spare && !*spare && build_->src.capacity() <= (1u << 16)) {
         Build& b = *build_;
         b.start.clear(), b.accept.clear(), b.src.clear(), b.dst.clear(), b.il.clear(), b.ol.clear(), b.w.clear();
-        spare = std::move(build_);
+        *spare = std::move(build_);
       }
       build_.reset();
     }
@@ -325,9 +325,9 @@ class Graph {
     if (!build_) {
       // (a thread that builds one target graph per task builds them all alike: the vectors of the last graph
       //  handed over on this thread, capacity included, serve the next one -- no allocation per graph)
-      std::unique_ptr<Build>& spare = spareBuild();
-      if (spare) {
-        build_ = std::move(spare);
+      std::unique_ptr<Build>* spare = spareBuild();
+      if (spare && *spare) {
+        build_ = std::move(*spare);
       } else {
         build_.reset(new Build());
         build_->src.reserve(64), build_->dst.reserve(64), build_->il.reserve(64), build_->ol.reserve(64);
@@ -336,9 +336,19 @@ class Graph {
     }
     return true;
   }
-  static std::unique_ptr<Build>& spareBuild() {
-    static thread_local std::unique_ptr<Build> spare;
-    return spare;
+  // the thread's spare slot; null once the thread's thread_local objects are gone (graphs may still be destroyed
+  // on it after that)
+  static std::unique_ptr<Build>* spareBuild() {
+    struct Holder {
+      std::unique_ptr<Build> spare;
+      bool* gone;
+      explicit Holder(bool* g) : gone(g) {}
+      ~Holder() { *gone = true; }
+    };
+    static thread_local bool gone = false;  // (trivially destructible: stays readable)
+    if (gone) return nullptr;
+    static thread_local Holder h(&gone);
+    return &h.spare;
   }
   /** the handle, with everything collected so far handed over */
   gtnx_graph_t h() const {
@@ -366,8 +376,8 @@ class Graph {
     // keep the capacity for the next round: of this graph or, more likely, of the next graph this thread builds
     st.clear(), ac.clear(), src.clear(), dst.clear(), il.clear(), ol.clear(), w.clear();
     b.start.swap(st), b.accept.swap(ac), b.src.swap(src), b.dst.swap(dst), b.il.swap(il), b.ol.swap(ol);
-    std::unique_ptr<Build>& spare = spareBuild();
-    if (!spare && b.src.capacity() <= (1u << 16)) spare = std::move(build_);
+    std::unique_ptr<Build>* spare = spareBuild();
+    if (spare && !*spare && b.src.capacity() <= (1u << 16)) *spare = std::move(build_);
   }
   size_t count(gtnx_status_t (*fn)(gtnx_graph_t, int64_t*)) const {
     int64_t v;

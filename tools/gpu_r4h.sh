@@ -1,0 +1,13 @@
+set -u
+O=$PWD/gpurun_out/r4h; mkdir -p $O; rm -f $O/*
+timeout 900 python -m pytest tests -q -m gpu -x 2>&1 | tail -5 > $O/pytest.log
+GTN_BENCH_TIMING=1 timeout 600 python bench.py --no-cpu-baseline --no-unmodified-caller --no-configs --steps 50 > $O/bench.json 2> $O/bench.err
+cat $O/pytest.log
+grep "vector step host" $O/bench.err | tail -8
+python - <<'PY'
+import json
+d=json.loads([l for l in open('gpurun_out/r4h/bench.json') if l.startswith('{')][-1])
+print('value', d['value'], 'ms/step', d['ms_per_step'])
+r=d['reference_api']; print('vector', r['vector_overloads'], '\nloop', r['reference_loop'], '\nhost-em', r['reference_loop_host_emissions'].get('ctcBatched_ms'))
+b=d['built_lattice_path']; print('built', b['ms_per_step'], {k:(round(v['ms_per_launch'],3), round(v['frac'],3)) for k,v in b['roofline'].items()})
+PY

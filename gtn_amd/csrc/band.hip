@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -1393,6 +1394,240 @@ __global__ __launch_bounds__(512) void band_viterbi_kernel(const BandDecode* __r
   }
 }
 
+// ==========================================================================================
+// The same recursion with ONE WAVE per utterance and no barrier at all (the kernel above spends a workgroup
+// barrier and a byte store per time step).  A lane owns NPL consecutive nodes and keeps their scores in
+// registers; the two neighbours a node looks at are a register of the same lane or one wave-wide DPP shift
+// away.  Emission rows reach LDS by DMA (global_load_lds_dwordx4: a kilobyte per wave instruction, no staging
+// registers) in blocks of 2048 floats, three blocks in the ring: while one is swept, the next has landed or
+// is landing and the one after it is in flight -- the wait at a block's top is a COUNTED s_waitcnt (vmcnt(16):
+// everything older than the sixteen newest vector-memory operations is done; a block is eight of them, always
+// -- lanes past the end of the tensor re-read its last 16 bytes -- and the back-pointer stores in between only
+// make the block older).  Back-pointers are 2 bits per (time, node), packed into one 32-bit word per lane for
+// 16 / NPL steps and stored coalesced: T N / 4 bytes instead of T N.  Code 3 says "two finite candidates were
+// equal here": the pointer chase reports a tie only when the BEST PATH runs through such a node (the host then
+// lets the built lattice decide, ops_band.cpp) -- ties elsewhere do not change the path.  The chase is a scalar
+// walk: the word row of a group of steps is loaded by all lanes (the next one already in flight) and the
+// walker takes its lane's word with v_readlane -- no dependent memory access on the chain.  Same arithmetic,
+// same outputs as band_viterbi_kernel.
+// Algorithmic bytes per utterance: 4 T C (emissions, once) + T N / 2 (back-pointers out and in) + 20 T (the path).
+// ==========================================================================================
+constexpr int VBLK = 2048;  // floats per staged block (C <= VBLK, C % 4 == 0, 16-byte aligned tensor)
+
+template <int NPL>
+__global__ __launch_bounds__(64) void band_viterbi_wave_kernel(const BandDecode* __restrict__ pairs) {
+  const BandDecode P = pairs[blockIdx.x];
+  const int T = P.T, C = P.C, N = P.N;
+  const int lane = threadIdx.x;
+  constexpr int SPW = 16 / NPL;  // steps per back-pointer word
+  constexpr int NLD = VBLK / 256;
+  __shared__ __attribute__((aligned(16))) float ring[3 * VBLK];
+  const float NINF = -__builtin_inff();
+  const GTNX_G gtnx_i4* nodes = reinterpret_cast<const GTNX_G gtnx_i4*>(P.nodes);
+  int loff[NPL];  // byte offset of the node's label inside an emission row
+  float w0[NPL], w1[NPL], w2[NPL], alpha[NPL];
+  bool acc[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int m = lane * NPL + j;
+    loff[j] = 0;
+    w0[j] = w1[j] = w2[j] = NINF;  // (nodes past N keep -inf: every candidate of theirs is -inf)
+    alpha[j] = NINF;
+    acc[j] = false;
+    if (m < N) {
+      const gtnx_i4 q = nodes[m];
+      loff[j] = 4 * (q.x >= 0 ? q.x : 0);
+      if (q.y >= 0) w0[j] = P.w ? P.w[q.y] : 0.0f;
+      if (q.z >= 0) w1[j] = P.w ? P.w[q.z] : 0.0f;
+      if (q.w >= 0) w2[j] = P.w ? P.w[q.w] : 0.0f;
+      const uint8_t f = P.nflags[m];
+      if (f & NF_START) alpha[j] = 0.0f;  // shortest.cpp:201-207 (paths begin at start nodes, time 0)
+      acc[j] = (f & NF_ACCEPT) != 0;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    settle(w0[j]);
+    settle(w1[j]);
+    settle(w2[j]);
+    settle(loff[j]);
+  }
+  const int R = max(1, VBLK / C);  // rows per block
+  const int NB = (T + R - 1) / R;
+  const int64_t total = int64_t(T) * C;
+  auto issue = [&](int b) {
+    const int64_t f0 = int64_t(b) * R * C;
+    float* dst = ring + (b % 3) * VBLK;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      int64_t f = f0 + i * 256 + lane * 4;
+      f = f + 4 <= total ? f : total - 4;  // (past the end: the tensor's last 16 bytes again, never read from LDS)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(P.em + f),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 256), 16, 0, 0);
+    }
+  };
+  GTNX_G unsigned* bp32 = reinterpret_cast<GTNX_G unsigned*>(P.bp);
+  unsigned word = 0;
+  if (NB > 0) issue(0);
+  if (NB > 1) issue(1);
+#ifdef GTNX_VIT_NO_SWEEP  // (tools/ubench/viterbi_bench.hip: everything but the recursion -- the emissions still stream)
+#define GTNX_VIT_ROWS 0
+#else
+#define GTNX_VIT_ROWS rows
+#endif
+  for (int b = 0; b < NB; ++b) {
+    if (b + 2 < NB) {
+      issue(b + 2);
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    } else if (b + 1 < NB) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const char* buf = reinterpret_cast<const char*>(ring + (b % 3) * VBLK);
+    const int t0 = b * R, rows = min(R, T - t0);
+    float e[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) e[j] = *reinterpret_cast<const float*>(buf + loff[j]);
+    for (int i = 0; i < GTNX_VIT_ROWS; ++i) {
+      const int t = t0 + i;
+      // the next row's emissions while this row is reduced (the last row of the block reads its own again)
+      const char* nrow = buf + (i + 1 < rows ? i + 1 : i) * (C * 4);
+      float en[NPL];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) en[j] = *reinterpret_cast<const float*>(nrow + loff[j]);
+      float s1, s2;
+      if (NPL >= 2) {
+        s1 = wave_shr1(alpha[NPL - 1], NINF);
+        s2 = wave_shr1(alpha[NPL >= 2 ? NPL - 2 : 0], NINF);
+      } else {
+        s1 = wave_shr1(alpha[0], NINF);
+        s2 = wave_shr1(s1, NINF);
+      }
+      float na[NPL];
+      const int sh = (t % SPW) * 2 * NPL;
+      unsigned codes = 0;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const float p1 = j > 0 ? alpha[j > 0 ? j - 1 : 0] : s1;
+        const float p2 = j > 1 ? alpha[j > 1 ? j - 2 : 0] : (j == 1 ? s1 : s2);
+        const float c0 = alpha[j] + (w0[j] + e[j]), c1 = p1 + (w1[j] + e[j]), c2 = p2 + (w2[j] + e[j]);
+        const float best = fmaxf(fmaxf(c0, c1), c2);
+        const float med = __builtin_amdgcn_fmed3f(c0, c1, c2);
+        // first maximum in the order own node, node - 1, node - 2 (as the kernel above); two equal maxima: code 3
+        unsigned k = c0 == best ? 0u : (c1 == best ? 1u : 2u);
+        k = med == best ? 3u : k;  // (all -inf: 3 as well -- the best path never comes through a dead node)
+        codes |= k << (2 * j);
+        na[j] = best;
+      }
+      word |= codes << sh;
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        alpha[j] = na[j];
+        e[j] = en[j];
+      }
+      if ((t % SPW) == SPW - 1 || t == T - 1) {
+        bp32[int64_t(t / SPW) * 64 + lane] = word;
+        word = 0;
+      }
+    }
+  }
+  // the best accept node (shortest.cpp:153-167 / :233-244): maximum, smallest node among equals
+  float lv = NINF;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) lv = fmaxf(lv, acc[j] ? alpha[j] : NINF);
+  const float wmx = wave_max(lv);
+  int bm = 1 << 30, cnt = 0;
+#pragma unroll
+  for (int j = NPL - 1; j >= 0; --j)
+    if (acc[j] && alpha[j] == wmx && wmx > NINF) {
+      bm = lane * NPL + j;
+      ++cnt;
+    }
+  for (int o = 32; o > 0; o >>= 1) {
+    bm = min(bm, __shfl_xor(bm, o));
+    cnt += __shfl_xor(cnt, o);
+  }
+  int tie = cnt > 1 ? 1 : 0;  // (uniform)
+  const int best = bm == (1 << 30) ? -1 : bm;
+  if (lane == 0) {
+    P.score[0] = best >= 0 ? wmx : NINF;
+    P.path_len[0] = best >= 0 ? T : -1;
+  }
+  if (best < 0 || T == 0) {
+    if (lane == 0) P.tie[0] = tie;
+    return;
+  }
+#ifdef GTNX_VIT_NO_CHASE  // (tools/ubench/viterbi_bench.hip: the sweep alone)
+  if (lane == 0) P.tie[0] = tie;
+  return;
+#endif
+  // (the back-pointer words this wave stored are what it loads next: its own stores, waited for)
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // ---- chase the pointers: a scalar walk over the word rows -- sixteen rows (16 SPW steps) per batch, loaded by
+  // all lanes before the walk, the next batch in flight meanwhile; the nodes of the path are kept in LDS for the
+  // last phase (the emission ring is free by now) and stored 64 at a time
+  unsigned node = unsigned(__builtin_amdgcn_readfirstlane(best));
+  int* lpn = reinterpret_cast<int*>(ring);  // [min(T + 1, 3 VBLK)]
+  constexpr int LPN = 3 * VBLK;
+  if (lane == 0) {
+    P.pnode[T] = int(node);
+    if (T < LPN) lpn[T] = int(node);
+  }
+  const int NW = (T + SPW - 1) / SPW;
+  constexpr int RB = 16;  // word rows per batch
+  unsigned cur[RB], nxt[RB];
+  const int nbatch = (NW + RB - 1) / RB;
+  auto fetch = [&](unsigned (&dst)[RB], int q) {  // rows q RB .. q RB + RB - 1 (those past the end: the last row again)
+#pragma unroll
+    for (int r = 0; r < RB; ++r) dst[r] = bp32[int64_t(min(q * RB + r, NW - 1)) * 64 + lane];
+  };
+  fetch(cur, nbatch - 1);
+  int pn = 0;
+  for (int q = nbatch - 1; q >= 0; --q) {
+    if (q > 0) fetch(nxt, q - 1);
+#pragma unroll
+    for (int r = RB - 1; r >= 0; --r) {
+      const int wi = q * RB + r;
+      if (wi < NW) {
+#pragma unroll
+        for (int u = SPW - 1; u >= 0; --u) {
+          const int t = wi * SPW + u;
+          if (t < T) {
+            const unsigned wv = unsigned(__builtin_amdgcn_readlane(int(cur[r]), int(node / NPL)));
+            unsigned k = (wv >> (u * 2 * NPL + 2 * (node % NPL))) & 3u;
+            if (k == 3u) {  // two equal candidates ON the path: the built lattice decides; the walk goes on (own node)
+              tie = 1;
+              k = 0;
+            }
+            node -= min(k, node);
+            if (lane == (t & 63)) pn = int(node);
+            if ((t & 63) == 0) {  // the nodes of steps t .. t + 63, one per lane
+              if (t + lane < T) {
+                P.pnode[t + lane] = pn;
+                if (t + lane < LPN) lpn[t + lane] = pn;
+              }
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) cur[r] = nxt[r];
+  }
+  if (lane == 0) P.tie[0] = tie;
+  if (T >= LPN) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  // ---- the path's arcs: arc t enters node pnode[t+1] from pnode[t]
+  for (int t = lane; t < T; t += 64) {
+    const int m1 = T < LPN ? lpn[t + 1] : P.pnode[t + 1], k = m1 - (T < LPN ? lpn[t] : P.pnode[t]);
+    const gtnx_i4 q = nodes[m1];
+    const int arc = k == 0 ? q.y : (k == 1 ? q.z : q.w);
+    P.path_arc[t] = arc;
+    P.path_lab[t] = q.x;
+    P.path_w[t] = (arc >= 0 && P.w ? P.w[arc] : 0.0f) + P.em[int64_t(t) * C + (q.x >= 0 ? q.x : 0)];
+  }
+}
+
 // Force-alignment acceptors composed with an ASG transitions graph, as band records: what
 // compose(forceAlign(target), transitions) of examples/asg.cpp:50-68 builds -- a chain of U + 1
 // nodes, node m carrying label l_m, arc 2m-2 the step m-1 -> m and arc 2m-1 the self-loop at m (the
@@ -1541,8 +1776,25 @@ void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int ma
   }
 }
 
-void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hipStream_t st) {
+// max_nodes / max_labels: the widest partner and alphabet of the batch; vec: every emission tensor is 16-byte aligned
+// and every alphabet a multiple of 4 (and T C >= 4).  The one-wave kernel takes such batches with <= 512 nodes and
+// <= 2048 labels
+// (GTNX_VITERBI_WG=1: the workgroup-per-utterance kernel, kept for wider shapes and for comparison).
+template <int NPL>
+static void launch_viterbi_wave(const BandDecode* d_pairs, int n, hipStream_t st) {
+  hipLaunchKernelGGL((band_viterbi_wave_kernel<NPL>), dim3(n), dim3(64), 0, st, d_pairs);
+}
+void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, int max_nodes, int max_labels, int vec,
+                         hipStream_t st) {
   if (n <= 0) return;
+  static const bool force_wg = std::getenv("GTNX_VITERBI_WG") != nullptr;
+  if (!force_wg && vec && max_nodes <= 512 && max_labels <= VBLK) {
+    if (max_nodes <= 64) launch_viterbi_wave<1>(d_pairs, n, st);
+    else if (max_nodes <= 128) launch_viterbi_wave<2>(d_pairs, n, st);
+    else if (max_nodes <= 256) launch_viterbi_wave<4>(d_pairs, n, st);
+    else launch_viterbi_wave<8>(d_pairs, n, st);
+    return;
+  }
   static bool attr = (big_lds(band_viterbi_kernel), true);
   (void)attr;
   hipLaunchKernelGGL(band_viterbi_kernel, dim3(n), dim3(512), 4 * size_t(1032 + stage_floats) + 64, st, d_pairs);

@@ -476,7 +476,8 @@ struct BandDecode {
   const GTNX_G uint8_t* nflags;  // [N]
   const GTNX_G float* w;         // G's weights (natural log), arc-id order; null: all zero
   const GTNX_G float* em;        // [T][C]
-  GTNX_G uint8_t* bp;            // [T][NS] which in-arc won (0: from n, 1: n-1, 2: n-2; 3: none)
+  GTNX_G uint8_t* bp;            // which in-arc won (0: from n, 1: n-1, 2: n-2; 3: none): [T][NS] bytes, or 2 bits per
+                                 // (time, node) packed per lane (band_viterbi_wave_kernel); T * NS + 512 bytes either way
   GTNX_G int* pnode;             // [T + 1] nodes of the best path
   GTNX_G int* path_arc;          // [T] arcs of G along it, first-arc-first
   GTNX_G int* path_lab;          // [T] matched labels
@@ -487,7 +488,8 @@ struct BandDecode {
   int N, T, C, NS;
   int stage_floats, pad;         // LDS staging area of the launch (floats)
 };
-void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, hipStream_t st);
+void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, int max_nodes, int max_labels, int vec,
+                         hipStream_t st);
 // ---------------------------------------------------------------------------
 // rational.hip: clone / concat / closure / union_ (functions.cpp:66-223) built on the device
 // ---------------------------------------------------------------------------

@@ -358,7 +358,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     const size_t T = size_t(lp.chain.s->M), N = size_t(lp.fixed.s->N);
     const size_t ns = size_t(band_row_stride(int(N), band_npl(int(N))));
     o_bp[i] = bytes;
-    bytes = align_up(bytes + T * ns + 1, 256);
+    bytes = align_up(bytes + T * ns + 512, 256);
     o_pn[i] = bytes;
     bytes = align_up(bytes + 4 * (T + 1), 256);
     o_pa[i] = bytes;
@@ -369,6 +369,8 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   }
   DevMemP arena = rt.alloc(bytes);
   const int stage_floats = std::max(4096, max_c);
+  int max_n = 1, vec = 1;
+  double abytes = 0;  // 4TC in, T N / 2 of back-pointers out and in, 20 T of path out
   std::vector<BandDecode> tab(n);
   for (size_t i = 0; i < n; ++i) {
     const LazyProduct& lp = *gs[i].s->lazy;
@@ -392,11 +394,14 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     p.score = reinterpret_cast<float*>(p.path_len + 1);
     p.tie = p.path_len + 2;
     p.stage_floats = stage_floats;
+    max_n = std::max(max_n, p.N);
+    if (p.C % 4 != 0 || (reinterpret_cast<uintptr_t>(p.em) & 15) != 0 || int64_t(p.T) * p.C < 4) vec = 0;
+    abytes += 4.0 * p.T * p.C + 0.5 * double(p.T) * p.N + 20.0 * p.T;
   }
   {
     DevMemP d = upload_vec(tab);
-    GTNX_PROF(want_path ? "band_viterbi_path" : "band_viterbi_score", 0.0);
-    launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, rt.stream());
+    GTNX_PROF(want_path ? "band_viterbi_path" : "band_viterbi_score", abytes);
+    launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, max_n, max_c, vec, rt.stream());
   }
   // heads (length, score, tie) of every pair; the paths themselves only when they become graphs
   std::vector<char> host(bytes);
@@ -473,6 +478,8 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     }
   }
   if (!tied.empty()) {
+    static const bool dbg = std::getenv("GTNX_DEBUG_TIES") != nullptr;
+    if (dbg) std::fprintf(stderr, "[gtnx] band_viterbi: %zu of %zu utterances report an exact tie on their best path\n", tied.size(), n);
     std::vector<Graph> tg;
     for (size_t i : tied) {
       // The lattice is built and its level schedule taken by replaying the reference's queue on it

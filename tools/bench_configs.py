@@ -1,8 +1,10 @@
-"""BASELINE.json configs C1 and C2 on one MI355X, one JSON line each (bench.py embeds them as `configs`):
+"""BASELINE.json configs C1 and C2 (and C3's Viterbi variant) on one MI355X, one JSON line each (bench.py embeds them as
+`configs`):
 
   c1  benchmarks/ctc.cpp with batch = 1: T = 100, alphabet 28, U = 20 -- one utterance through the per-graph
       functions (reference names, bench_native/ctc_step.cpp: gtn_bench_single_utterance): latency per loss
   c2  forwardScore on 256 linear-chain emission graphs (T = 150, C = 32), one batched launch
+  c3v viterbiScore / viterbiPath of intersect(ctc, emissions) at C3's shape, symbolic and built route
 
 Each line carries `value` (losses/s resp. graphs/s), `ms`, a `roofline` for the dominant kernel family (bytes
 from the engine's own accounting, hipEvent time) and a `cpu_baseline`: the UNMODIFIED reference
@@ -165,5 +167,142 @@ def c2():
     print(json.dumps(out))
 
 
+def c3v():
+    """viterbiScore / viterbiPath of intersect(ctc_target, emissions) at BASELINE config C3's shape (B = 512, T = 1000,
+    C = 256, U = 100; functions.cpp:324-330 -> shortest.cpp:190-272), symbolic route (band_viterbi_wave_kernel: the lattice
+    is never built) and built route (compose_kernel, then the tropical sweep + pointer chase over the built lattices),
+    labels of the first utterances compared EQUAL with the unmodified reference in this run."""
+    import torch
+    import gtn_amd as gtn
+    import graphgen as gg
+    B, T, Cn, U = 512, 1000, 256, 100
+    if len(sys.argv) > 2:
+        B = int(sys.argv[2])
+    em, tg = gg.ctc_inputs(1234, B, T, Cn, U)
+    em_dev = torch.from_numpy(em).cuda()
+    ctcs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+    for g in ctcs:
+        g.arc_sort()
+    ems = gtn.linear_graph_n(B, T, Cn, em_dev)
+    N, A = 2 * U + 1, None
+
+    def run(mode, what, iters):
+        prev = gtn.compose_mode(mode)
+        try:
+            def step():
+                comp = gtn.intersect(ctcs, ems)
+                return gtn.viterbi_path(comp) if what == "path" else gtn.viterbi_score(comp)
+            for _ in range(2):
+                r = step()
+            gtn.synchronize()
+            gtn.prof_reset()
+            gtn.prof_enable(True)
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                r = step()
+            gtn.synchronize()
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            gtn.prof_enable(False)
+            prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+            fams = {k: {"ms_per_launch": v["total_ms"] / v["launches"], "launches_per_step": v["launches"] / iters,
+                        "algorithmic_bytes_per_launch": v["algorithmic_bytes"] / v["launches"]}
+                    for k, v in prof.items() if v["launches"] and v["total_ms"] > 0}
+            return r, ms, fams
+        finally:
+            gtn.compose_mode(prev)
+
+    out = {"config": "C3_viterbi: viterbiScore / viterbiPath of intersect(ctc_target, emissions), T=1000, C=256, U=100, "
+                     f"batch={B}, 1 MI355X", "metric": "viterbiPath utterances/sec"}
+    paths, ms_path, fam_path = run(2, "path", 10)
+    scores, ms_score, fam_score = run(2, "score", 10)
+    # roofline of the symbolic route's one kernel: 4TC in + T N / 2 back-pointers out and in + 20 T of path (DESIGN.md section 3)
+    per = B * (4.0 * T * Cn + 0.5 * T * N + 20.0 * T)
+    k = fam_path.get("band_viterbi_path")
+    roof = None
+    if k:
+        gbs = per / (k["ms_per_launch"] * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "band_viterbi_wave_kernel<4, true>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "ms_per_launch": k["ms_per_launch"],
+                "algorithmic_bytes_per_launch": per}
+    out["symbolic_route"] = {"viterbi_path_ms_per_batch": ms_path, "viterbi_score_ms_per_batch": ms_score,
+                             "kernels_path": fam_path, "kernels_score": fam_score, "roofline": roof,
+                             "note": "ms per batch includes the host side of the Python mirror (512 path graphs are built on "
+                                     "the host from one device->host copy); the roofline is the kernel's own launch time"}
+    out["value"] = B / (ms_path * 1e-3)
+    out["unit"] = "utterances/s"
+    out["roofline"] = roof
+    # the built route on a slice of the batch (13 GB of lattices at B = 512; 64 utterances say the same per launch)
+    nb = min(B, 64)
+    sub_c, sub_e = ctcs[:nb], ems[:nb]
+    prev = gtn.compose_mode(0)
+    try:
+        def bstep():
+            comp = gtn.intersect(sub_c, sub_e)
+            return comp, gtn.viterbi_path(comp)
+        bstep()
+        gtn.synchronize()
+        gtn.prof_reset()
+        gtn.prof_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            comp, bpaths = bstep()
+        gtn.synchronize()
+        ms_built = (time.perf_counter() - t0) / 3 * 1e3
+        gtn.prof_enable(False)
+        prof = {n: gtn.prof_get(n) for n in gtn.prof_names()}
+        A = comp[0].num_arcs()
+        Nn = comp[0].num_nodes()
+        fb = {}
+        for name, v in prof.items():
+            if not v["launches"] or v["total_ms"] <= 0:
+                continue
+            msl = v["total_ms"] / v["launches"]
+            e = {"ms_per_launch": msl, "launches_per_step": v["launches"] / 3}
+            if name.startswith("viterbi") or name.startswith("forward_score") or "path" in name:
+                bytes_ = nb * (8.0 * A + 8.0 * Nn + 4.0 * Nn)  # 8A + 8N of the sweep + a back-pointer per node
+                e["roofline"] = {"bound": "hbm", "achieved": bytes_ / (msl * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": bytes_ / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": bytes_,
+                                 "traffic": None}
+            fb[name] = e
+        out["built_route"] = {"batch": nb, "viterbi_path_ms_per_batch": ms_built, "composed_nodes": int(Nn), "composed_arcs": int(A),
+                              "kernels": fb}
+        same_built = all(bpaths[b].labels_to_list() == paths[b].labels_to_list() for b in range(min(nb, 8)))
+        out["built_route"]["labels_equal_symbolic_route"] = bool(same_built)
+    finally:
+        gtn.compose_mode(prev)
+    # in-run parity and the host baseline: the unmodified reference on the same utterances
+    try:
+        ref = ref_api()
+        cores = os.cpu_count() or 1
+        nref = int(min(B, max(4, min(cores, 64))))
+        rc = [gg.to_api(ref, gg.ctc_target_graph(tg[b].tolist())) for b in range(nref)]
+        for g in rc:
+            g.arc_sort()
+        re_ = []
+        for b in range(nref):
+            e = ref.linear_graph(T, Cn)
+            e.set_weights(em[b].reshape(-1))
+            re_.append(e)
+        t0 = time.perf_counter()
+        rp = ref.viterbi_path(ref.intersect(rc, re_))  # vector overloads: parallelMap on the host cores
+        sec = time.perf_counter() - t0
+        rs = ref.viterbi_score(ref.intersect(rc[:4], re_[:4]))
+        ncmp = 4
+        labels_equal = all(rp[b].labels_to_list() == paths[b].labels_to_list() for b in range(ncmp))
+        got_s = np.array(gtn.items(scores[:ncmp]), np.float64)
+        want_s = np.array(ref.items(rs), np.float64)
+        out["parity_in_run"] = {"n": ncmp, "labels_equal": bool(labels_equal),
+                                "score_max_rel": float(np.max(np.abs(got_s - want_s) / np.maximum(np.abs(want_s), 1e-30))),
+                                "checker": "reference (oracle/_ref/libgtn_ref.so)", "ok": bool(labels_equal)}
+        out["cpu_baseline"] = {"value": nref / sec, "unit": "utterances/s", "cores": min(cores, nref), "kind": "reference",
+                               "sample": f"intersect + viterbiPath of {nref} utterances through the unmodified reference's vector "
+                                         f"overloads (parallelMap), one pass, {sec:.1f}s wall; host has {cores} logical cores"}
+    except Exception as e:  # a baseline must not cost the line
+        out["cpu_baseline"] = {"error": str(e)[:200]}
+    print(json.dumps(out))
+    if not out.get("parity_in_run", {}).get("ok", True):
+        sys.exit(3)
+
+
 if __name__ == "__main__":
-    {"c1": c1, "c2": c2}[sys.argv[1]]()
+    {"c1": c1, "c2": c2, "c3v": c3v}[sys.argv[1]]()

@@ -62,6 +62,7 @@ prof_reset = _api.prof_reset
 prof_get = _api.prof_get
 prof_names = _api.prof_names
 debug_symbolic_route = _api.debug_symbolic_route
+debug_viterbi_ties = _api.debug_viterbi_ties
 
 
 def load_txt(text):

@@ -142,6 +142,7 @@ _SIGS = {
     "gtnx_prof_names": [C.c_char_p, C.c_size_t],
     "gtnx_debug_symbolic_route": [c_graph, C.c_int, c_i32_p],
     "gtnx_debug_route_name": [C.c_int, C.c_char_p, C.c_size_t],
+    "gtnx_debug_viterbi_ties": [c_i64_p, c_i64_p],
 }
 
 _RESTYPE = {

@@ -815,7 +815,15 @@ def make_api(lib):
         check(lib.gtnx_debug_route_name(r.value, buf, 32))
         return buf.value.decode()
 
+    def debug_viterbi_ties():
+        """(seen, unresolved): best paths of symbolic dense-partner products that ran through an exact tie / of those,
+        the ones whose product was too large to rebuild and replay the reference's queue on (include/gtn_amd.h)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        check(lib.gtnx_debug_viterbi_ties(C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     ns.debug_symbolic_route = debug_symbolic_route
+    ns.debug_viterbi_ties = debug_viterbi_ties
     ns.backend = backend
     ns.device_count = device_count
     ns.synchronize = synchronize

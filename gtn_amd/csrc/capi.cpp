@@ -152,6 +152,12 @@ GTNX_API gtnx_status_t gtnx_reclaim(void) {
     region_reclaim_thread();
   });
 }
+GTNX_API gtnx_status_t gtnx_debug_viterbi_ties(int64_t* seen, int64_t* unresolved) {
+  return guard([&] {
+    if (seen) *seen = g_viterbi_ties_seen.load();
+    if (unresolved) *unresolved = g_viterbi_ties_unresolved.load();
+  });
+}
 GTNX_API gtnx_status_t gtnx_empty_cache(void) {
   return guard([&] {
     if (Runtime::initialized()) Runtime::get().empty_cache();

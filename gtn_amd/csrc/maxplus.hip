@@ -261,6 +261,16 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
   fetch(r1, T >= 2 ? T - 2 : 0);
   __syncthreads();
   bool failed = false;
+  int tied = 0;
+  {  // two accept states with the best score: which one the reference takes depends on the built product's accept
+     // order (shortest.cpp:226-237) -- a tie like any other
+    const float top = g.score[b];
+    const float* last = g.alpha + int64_t(T) * plane + int64_t(b) * N;
+    int hits = 0;
+    for (int k = l; k < g.g.n_accept; k += 64) hits += (last[g.g.accept_list[k]] == top && top > NEG_INF) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_xor(hits, o);
+    if (hits > 1) tied = 1;
+  }
   int keep_arc = 0, keep_lab = 0;
   float keep_e = 0.0f;
   auto step = [&](int t, Rows& rq, const Rows& rp) {  // rq: set to request into, rp: set to park
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     const float e = lab < 0 ? 0.0f : (stage_em ? erows[((t - 1) & 1) * C + lab] : em[int64_t(t - 1) * C + lab]);
     const int k0 = ioff[node], k1 = ioff[node + 1];
     float m = NEG_INF;
-    int arg = INT_MAX, bsrc = 0, barc = 0;
+    int arg = INT_MAX, bsrc = 0, barc = 0, same = 0;  // same: records of this lane that hold its maximum
     // the in-row, nine records per lane at a time, all requested before the first is looked at (one
     // exposed trip to memory per 576 records, not one per record); the rows of the step after next queue
     // up behind the first batch
@@ -290,6 +300,7 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
         const int k = kb + l + 64 * i;
         if (k < k1 && r[i].y >= 0) {
           const float x = prev[r[i].x] + __int_as_float(r[i].z) + e;
+          same = x > m ? 1 : (x == m ? same + 1 : same);
           if (x > m) {
             m = x;
             arg = k;
@@ -301,6 +312,15 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     }
     // first maximum in in-row order: the wave's maximum, then the smallest record index holding it
     const float mx = wave_max63(m);
+    // two equal finite candidates at a state of the best path: the reference's choice depends on the order its
+    // queue reached the sources (shortest.cpp:215-218), which a product that is never built does not have --
+    // reported (path_len[nb + b]); the walk keeps the first maximum in in-row order
+    {
+      const bool at = m == mx && mx > NEG_INF;
+      const unsigned long long holders = __builtin_amdgcn_ballot_w64(at);
+      const unsigned long long many = __builtin_amdgcn_ballot_w64(at && same > 1);
+      if (__builtin_popcountll(holders) > 1 || many != 0ull) tied = 1;
+    }
     arg = wave_min63(m == mx ? arg : INT_MAX);
     if (arg == INT_MAX) {  // cannot happen below a finite best score
       failed = true;
@@ -338,7 +358,10 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
     if (l == 0) path_len[b] = -1;
     return;
   }
-  if (l == 0) path_len[b] = T;
+  if (l == 0) {
+    path_len[b] = T;
+    path_len[g.nb + b] = tied;
+  }
 }
 
 }  // namespace

@@ -105,6 +105,8 @@ bool lazy_pair_ok(const LazyProduct& lp);
 std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs);
 std::vector<Graph> lazy_group_shortest_distance(std::vector<Graph>& gs, bool tropical);
 std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs);
+// exact ties on a best path reported by the max-plus walk / of those, left in in-row order (product too large to build)
+extern std::atomic<int64_t> g_viterbi_ties_seen, g_viterbi_ties_unresolved;
 // which dense form lazy_group_shortest_distance would pick for this product (ROUTE_DENSE_MFMA / ROUTE_DENSE /
 // ROUTE_MAXPLUS), or ROUTE_WALK
 SymbolicRoute lazy_group_route(const LazyProduct& lp, bool tropical);

@@ -647,6 +647,8 @@ std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
   return outs;
 }
 
+std::atomic<int64_t> g_viterbi_ties_seen{0}, g_viterbi_ties_unresolved{0};
+
 void LazyPathOp::backward(std::vector<Member>& ms) {
     Runtime& rt = Runtime::get();
     GradSink sink;
@@ -722,13 +724,14 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
     LazyGroupState& st = *groups[gi];
     const LazyGroup& v = st.view;
     const size_t nT = size_t(v.nb) * size_t(v.T);
-    const size_t pbytes = nT * 16 + 4 * size_t(v.nb);
+    const size_t pbytes = nT * 16 + 8 * size_t(v.nb);  // ... | path length [nb] | exact tie on the best path [nb]
     DevMemP pm = rt.alloc(pbytes ? pbytes : 1);
     int* parc = pm->as<int>();
     int* pil = parc + nT;
     int* pol = pil + nT;
     float* pw = reinterpret_cast<float*>(pol + nT);
     int* plen = reinterpret_cast<int*>(pw + nT);
+    HIP_CHECK(hipMemsetAsync(plen + v.nb, 0, 4 * size_t(v.nb), rt.stream()));  // (only the max-plus walk reports ties)
     launch_lazy_path(v, parc, pil, pol, pw, plen, rt.stream());
     PinnedMemP host = rt.alloc_pinned(pbytes ? pbytes : 1);  // 16 B per path arc: pageable memory would be staged and slow
     {
@@ -741,10 +744,27 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
     const int* hol = hil + nT;
     const float* hw = reinterpret_cast<const float*>(hol + nT);
     const int* hlen = reinterpret_cast<const int*>(hw + nT);
+    // Exact ties between finite candidates ON the best path (reported by the max-plus walk): the reference breaks
+    // them by its queue's order over the BUILT product (shortest.cpp:215-218).  Products small enough to build
+    // (<= 2^22 arcs) are re-run on the built lattice with the queue-replaying schedule, as band_viterbi does;
+    // larger ones (C4: 262 M arcs per utterance) keep the first maximum in in-row order -- counted
+    // (gtnx_debug_viterbi_ties), INTEGRATION.md deviation 3.
+    std::vector<uint8_t> rerun(gs.size(), 0);
+    for (size_t i = 0; i < gs.size(); ++i) {
+      if (slot[i].first != int(gi)) continue;
+      const int b = slot[i].second;
+      if (hlen[b] < 0 || !hlen[size_t(v.nb) + size_t(b)]) continue;
+      g_viterbi_ties_seen.fetch_add(1);
+      const LazyProduct& lp = *gs[i].s->lazy;
+      const double arcs = double(lp.chain.s->M) * double(lp.fixed.s->A);
+      if (arcs <= double(1 << 22) && !std::getenv("GTNX_NO_TIE_RERUN")) rerun[i] = 1;
+      else g_viterbi_ties_unresolved.fetch_add(1);
+    }
     // the path graphs (8 host arrays of T entries each per utterance): every element touches only its own
     // objects, so a large batch is built by a few threads (3.5 -> <1 ms of a 17 ms decode at C4)
     auto build = [&](size_t i) {
       if (slot[i].first != int(gi)) return;
+      if (rerun[i]) return;
       const int b = slot[i].second;
       const int len = hlen[b];
       Graph out = make_output(op, int(i), {gs[i]});
@@ -782,6 +802,22 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
       worker();
       for (auto& th : pool) th.join();
       if (err) std::rethrow_exception(err);
+    }
+    std::vector<Graph> tg;
+    std::vector<size_t> ti;
+    for (size_t i = 0; i < gs.size(); ++i)
+      if (rerun[i]) {
+        realize(gs[i]);
+        gs[i].s->resolve_sizes();
+        gs[i].s->ensure_full();
+        gs[i].s->ensure_host();
+        gs[i].s->sched.reset();  // (the queue-replaying schedule: graph.cpp build_host_schedule)
+        tg.push_back(gs[i]);
+        ti.push_back(i);
+      }
+    if (!tg.empty()) {
+      std::vector<Graph> to = op_viterbi_path(tg);
+      for (size_t k = 0; k < ti.size(); ++k) outs[ti[k]] = std::move(to[k]);
     }
   }
   return outs;

@@ -61,8 +61,9 @@ gtnx_status_t gtnx_synchronize(void);
  * result, for the calling thread.  0: build it, unless the batch would not fit in memory.
  * 1: keep it symbolic whenever eligible.  2: keep it symbolic when the per-utterance sweep kernels
  * apply (partner of <= 512 nodes and <= 4 arcs per node: CTC targets).  -1 (default, "nobody asked"): as 2
- * when the partner is a graph the caller built on the host, else as 0 -- the choice a parallelMap region makes
- * for the calls inside it (gtnx_parallel_enter).  A symbolic result supports
+ * when the partner is a graph the caller built on the host, else as 0.  The mode of the thread that CALLS
+ * gtn::parallelMap goes with the tasks (include/gtn/parallel.h sets it on the pool's threads; a call made inside a
+ * region runs under the mode it was recorded with -- 0 builds every composition there too).  A symbolic result supports
  * forwardScore / viterbiScore / viterbiPath and backward through them; any other use builds it.  What
  * a symbolic result does not have is its OWN gradient graph (Graph::grad() of the composition), so
  * this is a hint for criteria that never read it.  `previous` (may be NULL) receives the old mode.
@@ -71,10 +72,11 @@ gtnx_status_t gtnx_compose_mode(int mode, int* previous);
 /* bytes currently held by the engine's device arena pool / bytes in use */
 gtnx_status_t gtnx_memory_stats(uint64_t* reserved, uint64_t* in_use);
 gtnx_status_t gtnx_empty_cache(void);
-/* Destroys what the caller has let go of since the last reclamation point (released handles, finished tapes);
- * never waits for the GPU, cheap when nothing is pending.  The engine reclaims by itself wherever the host
- * would wait for the device; a host loop with idle time of its own (the caller of parallelMap while the
- * workers build graphs -- include/gtn/parallel.h does this) can offer it here. */
+/* Destroys what the CALLING THREAD has let go of, or built for others and nobody refers to any more, since its last
+ * reclamation point (released handles, finished tapes, the recorded calls of a parallelMap region); never waits for
+ * the GPU, cheap when nothing is pending.  Every thread takes apart what it allocated: the engine reclaims by itself
+ * wherever a thread would wait for the device, and the pool threads of include/gtn/parallel.h call this when their
+ * share of a region is done. */
 gtnx_status_t gtnx_reclaim(void);
 /* The calling thread is one of several host threads mapping per-graph functions over a batch
  * (gtn::parallelMap, parallel/parallel_map.h:153-188) from here until gtnx_parallel_leave: its
@@ -86,9 +88,13 @@ gtnx_status_t gtnx_reclaim(void);
  * item(), a gradient) runs what it depends on right then, and a graph that is changed while a deferred call
  * still reads it has those calls run first.  What moves is when an error surfaces: at the first look at the
  * result, or from gtnx_parallel_flush (parallelMap rethrows after its join either way).  setWeights inside
- * a region copies a host source at the call (graph.cpp:179-181) and reads a DEVICE source at the join: the
- * caller keeps a device source unchanged until then.  Made by include/gtn/parallel.h; a hint -- without it
- * every call is a batch of one. */
+ * a region copies a host source at the call (graph.cpp:179-181) and reads a DEVICE source at the join, with one
+ * launch for the whole region: LIFETIME REQUIREMENT -- a device buffer handed to setWeights inside a parallelMap
+ * task must stay allocated and unchanged until that parallelMap call returns (rows of a tensor that outlives the
+ * call, as in pytorch_loss.py:46-71, are; a buffer the task itself frees or overwrites is not).
+ * GTNX_REGION_EAGER_WEIGHTS=1 copies at the call instead, like the reference, one launch per call.  Inputs of the
+ * recorded calls stay referenced until the results of the thread that recorded them are released.
+ * Made by include/gtn/parallel.h; a hint -- without it every call is a batch of one. */
 gtnx_status_t gtnx_parallel_enter(void);
 gtnx_status_t gtnx_parallel_leave(void);
 gtnx_status_t gtnx_parallel_flush(void);
@@ -122,7 +128,8 @@ gtnx_status_t gtnx_graph_olabel_sorted(gtnx_graph_t g, int* out);   /* graph.h:1
  * non-const form marks the host copy authoritative. */
 gtnx_status_t gtnx_graph_weights(gtnx_graph_t g, int mutable_, float** out);
 gtnx_status_t gtnx_graph_get_weights(gtnx_graph_t g, float* out);   /* copy-out of the above */
-/* graph.h:210; `weights` may also be a DEVICE address (detected: hipPointerGetAttributes) -- then as below */
+/* graph.h:210; `weights` may also be a DEVICE address (detected: hipPointerGetAttributes) -- then as below.  Copies at
+ * the call, except inside a parallelMap region with a device source: see gtnx_parallel_enter for the lifetime rule. */
 gtnx_status_t gtnx_graph_set_weights(gtnx_graph_t g, const float* weights);
 /* the same copy from a DEVICE buffer of numArcs floats (no host round-trip;
  * replaces pytorch_loss.py:53-61's inputs.cpu() + set_weights(data_ptr)) */
@@ -295,6 +302,11 @@ gtnx_status_t gtnx_prof_enable(int on);
 gtnx_status_t gtnx_prof_reset(void);
 gtnx_status_t gtnx_prof_get(const char* name, double* total_ms, int64_t* launches,
                             double* algorithmic_bytes);
+/* Diagnostics: viterbiPath of SYMBOLIC products with a dense partner (max-plus walk) -- how many best paths ran through
+ * a state with two exactly equal finite candidates since the process started (`seen`), and how many of those kept the
+ * first maximum in in-row order because the product was too large to build and replay the reference's queue on
+ * (`unresolved`; shortest.cpp:215-218, INTEGRATION.md "Where results can differ" 3). */
+gtnx_status_t gtnx_debug_viterbi_ties(int64_t* seen, int64_t* unresolved);
 /* names, '\n'-separated, of the families seen since the last reset */
 gtnx_status_t gtnx_prof_names(char* buf, size_t cap);
 /* Diagnostics: which kernel family would score the SYMBOLIC chain product `g` (a compose / intersect result kept

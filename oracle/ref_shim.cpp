@@ -469,6 +469,11 @@ gtnx_status_t gtnx_debug_symbolic_route(gtnx_graph_t, int, int* route) {
   *route = -1;  /* the reference builds every product */
   return GTNX_OK;
 }
+gtnx_status_t gtnx_debug_viterbi_ties(int64_t* seen, int64_t* unresolved) {
+  if (seen) *seen = 0;
+  if (unresolved) *unresolved = 0;
+  return GTNX_OK;
+}
 gtnx_status_t gtnx_debug_route_name(int, char* buf, size_t cap) {
   if (cap) buf[0] = 0;
   return GTNX_OK;

@@ -2,7 +2,8 @@
 // are deferred to the region's join (include/gtn_amd.h: gtnx_parallel_enter / gtnx_parallel_flush) and must
 // still behave like the reference's immediate calls (gtn/parallel/parallel_map.h:153-188 over
 // gtn/functions.cpp): results looked at inside the task, graphs changed after a call, errors, backward twice,
-// broadcast inputs, copies of results, non-uniform tasks.
+// broadcast inputs, copies of results, non-uniform tasks, targets changed after arcSort, the calling thread's
+// compose mode, backward of a part of a region's results.
 // Own test program (not reference code); built by tests/dropin/Makefile, run by tests/test_dropin_gpu.py.
 #include <cmath>
 #include <cstdio>
@@ -219,6 +220,90 @@ int main() {
     };
     auto got = parallelMap(task, idx);
     for (int b = 0; b < B; ++b) EXPECT(got[b].labelsToVector() == task(b).labelsToVector());
+  }
+
+  // ---- 8. a CTC-shaped target changed by makeAccept AFTER arcSort is no longer the standard acceptor: the
+  //         deferred product must see the extra accept node (graph.h:346-352; the shape cache of arcSort is stale)
+  {
+    auto target = [&](int b) {
+      Graph c = ctcGraph(targets[b]);
+      c.makeAccept(0);  // the empty alignment's start node also accepts
+      return c;
+    };
+    auto task = [&](int b) {
+      Graph em = linearGraph(T, M);
+      em.setWeights(scores[b].data());
+      return forwardScore(intersect(target(b), em));
+    };
+    auto got = parallelMap(task, idx);
+    for (int b = 0; b < B; ++b) {
+      // one at a time, lattice BUILT (the reference's own route through compose.cpp:377-522)
+      SymbolicCompose built(0);
+      Graph em = linearGraph(T, M);
+      em.setWeights(scores[b].data());
+      const float want = forwardScore(intersect(target(b), em)).item();
+      Graph plain_em = linearGraph(T, M);
+      plain_em.setWeights(scores[b].data());
+      const float without = forwardScore(intersect(ctcGraph(targets[b]), plain_em)).item();
+      EXPECT(close(got[b].item(), want));
+      EXPECT(want >= without);  // (one more accepting state can only add paths)
+    }
+  }
+
+  // ---- 9. gtnx_compose_mode of the calling thread goes with the tasks: under mode 0 a composition made inside
+  //         parallelMap is BUILT -- its gradient exists after a retained backward (autograd_test.cpp:148-188 on
+  //         compose results), which a symbolic product does not have
+  {
+    SymbolicCompose built(0);
+    std::vector<Graph> lats(B);
+    auto task = [&](int b) {
+      Graph em = linearGraph(T, M);
+      em.setWeights(scores[b].data());
+      lats[b] = intersect(ctcGraph(targets[b]), em);
+      Graph s = forwardScore(lats[b]);
+      backward(s, true);
+      return s;
+    };
+    auto got = parallelMap(task, idx);
+    int with_grad = 0;
+    for (int b = 0; b < B; ++b) {
+      bool ok = false;
+      try {
+        ok = lats[b].grad().numArcs() == lats[b].numArcs();
+      } catch (const std::logic_error&) {
+        ok = false;
+      }
+      with_grad += ok;
+    }
+    EXPECT(with_grad == B);
+  }
+
+  // ---- 10. backward of SOME results of a region (every other one): only their inputs get a gradient
+  {
+    std::vector<Graph> ems(B);
+    auto fwd = [&](int b) {
+      ems[b] = linearGraph(T, M);
+      ems[b].setWeights(scores[b].data());
+      return subtract(forwardScore(ems[b]), forwardScore(intersect(ctcGraph(targets[b]), ems[b])));
+    };
+    auto losses = parallelMap(fwd, idx);
+    std::vector<Graph> some;
+    for (int b = 0; b < B; b += 2) some.push_back(losses[b]);
+    parallelMap([](const Graph& g) { backward(g); }, some);
+    for (int b = 0; b < B; ++b) {
+      EXPECT(ems[b].isGradAvailable() == (b % 2 == 0));
+      if (b % 2) continue;
+      Graph em = linearGraph(T, M);
+      em.setWeights(scores[b].data());
+      Graph l = subtract(forwardScore(em), forwardScore(intersect(ctcGraph(targets[b]), em)));
+      backward(l);
+      const float* want = em.grad().weights();
+      const float* have = ems[b].grad().weights();
+      double worst = 0;
+      for (size_t i = 0; i < size_t(T) * M; ++i) worst = std::fmax(worst, std::fabs(double(want[i]) - have[i]));
+      EXPECT(worst < 1e-4);
+      EXPECT(close(losses[b].item(), l.item()));
+    }
   }
 
   if (failures) {

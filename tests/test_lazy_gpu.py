@@ -665,6 +665,9 @@ def test_maxplus_viterbi_matches_the_record_walking_kernels(gtn, B, T, N, C, int
     scores, path labels and weights, and the one-hot gradients must be IDENTICAL, exact ties (integer
     weights), parallel arcs, missing arcs and -inf weights included"""
     res = {}
+    # (both keep the first maximum in in-row order here: the re-run of tied paths on the built lattice has its own
+    #  test below)
+    os.environ["GTNX_NO_TIE_RERUN"] = "1"
     for name in ("walk", "maxplus"):
         if name == "walk":
             os.environ["GTNX_NO_DENSE"] = "1"
@@ -694,6 +697,7 @@ def test_maxplus_viterbi_matches_the_record_walking_kernels(gtn, B, T, N, C, int
                              [e.grad().weights_to_numpy() for e in ems], g.grad().weights_to_numpy())
         finally:
             os.environ.pop("GTNX_NO_DENSE", None)
+    os.environ.pop("GTNX_NO_TIE_RERUN", None)
     a, b = res["walk"], res["maxplus"]
     np.testing.assert_array_equal(b[0], a[0])
     assert b[1] == a[1]
@@ -703,6 +707,94 @@ def test_maxplus_viterbi_matches_the_record_walking_kernels(gtn, B, T, N, C, int
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(b[4], a[4])
     assert np.isfinite(a[0]).sum() > 0
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_maxplus_viterbi_path_exact_ties_follow_the_reference(gtn, seed):
+    """viterbiPath of a SYMBOLIC product with a dense partner (max-plus walk) under exact ties: the walk reports a
+    tie on the best path (gtnx_debug_viterbi_ties) and a product small enough to build is re-run on the built
+    lattice with the reference's queue order (shortest.cpp:215-218), so the labels are the oracle's; with the
+    re-run switched off the ties are counted as unresolved (what C4-sized products, never buildable, get)"""
+    B, T, N, C = 6, 9, 12, 6
+    rng = np.random.default_rng(100 + seed)
+    with lazy_mode("1"):
+        g = _moore_graph(gtn, N, C, rng, 0.9, True, 0.1)
+        gd = gg.from_api(g)
+        em = rng.integers(-1, 2, (B, T, C)).astype(np.float32)
+        em[0] = 0.0
+
+        def run():
+            ems = []
+            for b in range(B):
+                e = gtn.linear_graph(T, C)
+                e.set_weights(em[b])
+                ems.append(e)
+            comp = gtn.compose(ems, [g])
+            assert gtn.debug_symbolic_route(comp[0], True) == "maxplus"
+            return gtn.viterbi_path(comp)
+
+        seen0, un0 = gtn.debug_viterbi_ties()
+        paths = run()
+        seen1, un1 = gtn.debug_viterbi_ties()
+        assert seen1 > seen0, "integer weights: some best path must run through an exact tie"
+        assert un1 == un0, "products of 9 x ~130 arcs are small enough to build"
+        for b in range(B):
+            o = OGraph.linear(T, C, em[b]).compose(OGraph.from_dict(gd), "compose")
+            arcs, has = o.shortest_path()
+            d = o.to_dict()
+            assert paths[b].labels_to_list() == [d["il"][x] for x in arcs], b
+        os.environ["GTNX_NO_TIE_RERUN"] = "1"
+        try:
+            run()
+        finally:
+            os.environ.pop("GTNX_NO_TIE_RERUN", None)
+        seen2, un2 = gtn.debug_viterbi_ties()
+        assert un2 - un1 == seen2 - seen1 > 0
+
+
+def test_inf_weights_through_a_symbolic_product_are_pinned(gtn):
+    """-inf emissions (log 0) under a CTC target, forwardScore + backward: the BUILT lattice gives the reference's
+    gradients, NaN included (autograd_test.cpp:339-386: a lattice node that no finite path enters poisons its
+    in-arcs with exp(-inf - -inf)), checked against the oracle; the SYMBOLIC sweep (the default for host-built
+    targets) gives the same loss, the same gradients wherever the reference's are numbers and, where the reference
+    has NaN, the posteriors the NaN swallowed (finite, in [-1, 1]) --
+    INTEGRATION.md "Where results can differ" 2: both behaviours are pinned here"""
+    import torch
+    T, C = 14, 6
+    rng = np.random.default_rng(5)
+    em = rng.normal(0, 1, (T, C)).astype(np.float32)
+    em[3, :] = -np.inf
+    em[3, 0] = 0.5       # only the blank survives frame 3
+    em[7, 2] = -np.inf   # one label dead in frame 7
+    tgt = [2, 4, 2]
+    want_loss, want_grad = None, None
+    o = OGraph.from_dict(gg.ctc_target_graph(tgt)).compose(OGraph.linear(T, C, em), "intersect")
+    want_score = o.shortest_distance(tropical=False)
+    g1, g2 = o.compose_grad(o.shortest_distance_grad(tropical=False), len(gg.ctc_target_graph(tgt)["src"]), T * C)
+    want_grad = np.asarray(g2, np.float32).reshape(T, C)
+    res = {}
+    for mode in (0, 2):
+        prev = gtn.compose_mode(mode)
+        try:
+            e = gtn.linear_graph_n(1, T, C, torch.from_numpy(em[None]).cuda())
+            c = gg.to_api(gtn, gg.ctc_target_graph(tgt))
+            s = gtn.forward_score(gtn.intersect([c], e))
+            gtn.backward(s)
+            res[mode] = (gtn.items(s)[0], e[0].grad().weights_to_numpy().reshape(T, C))
+        finally:
+            gtn.compose_mode(prev)
+    # built: the reference's values, NaN pattern included
+    assert abs(res[0][0] - want_score) <= 1e-4 * abs(want_score)
+    np.testing.assert_array_equal(np.isnan(res[0][1]), np.isnan(want_grad))
+    ok = ~np.isnan(want_grad)
+    np.testing.assert_allclose(res[0][1][ok], want_grad[ok], rtol=1e-4, atol=1e-5)
+    # symbolic: same loss; finite everywhere; equal to the reference wherever the reference is finite
+    assert abs(res[2][0] - want_score) <= 1e-4 * abs(want_score)
+    assert np.isfinite(res[2][1]).all()
+    np.testing.assert_allclose(res[2][1][ok], want_grad[ok], rtol=1e-4, atol=1e-5)
+    # ... and where it is NaN, the posteriors the NaN swallowed: numbers in [-1, 1]
+    assert np.isnan(want_grad).any()
+    assert np.all(np.abs(res[2][1][~ok]) <= 1.0 + 1e-6)
 
 
 @pytest.mark.parametrize("seed", [3, 4, 5, 6])

@@ -23,6 +23,7 @@ OK, INVALID_ARGUMENT, LOGIC_ERROR, RUNTIME_ERROR, OUT_OF_RANGE, DEVICE_ERROR = r
 # name -> argtypes (restype is c_int status unless listed in _RESTYPE)
 _SIGS = {
     "gtnx_set_device": [C.c_int],
+    "gtnx_get_device": [c_i32_p],
     "gtnx_set_stream": [C.c_void_p],
     "gtnx_compose_mode": [C.c_int, C.POINTER(C.c_int)],
     "gtnx_synchronize": [],
@@ -143,6 +144,11 @@ _SIGS = {
     "gtnx_debug_symbolic_route": [c_graph, C.c_int, c_i32_p],
     "gtnx_debug_route_name": [C.c_int, C.c_char_p, C.c_size_t],
     "gtnx_debug_viterbi_ties": [c_i64_p, c_i64_p],
+    "gtnx_comm_create": [c_i32_p, C.c_int, C.POINTER(C.c_void_p)],
+    "gtnx_comm_destroy": [C.c_void_p],
+    "gtnx_comm_size": [C.c_void_p, c_i32_p],
+    "gtnx_comm_all_gather_f32": [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int64],
+    "gtnx_comm_all_reduce_sum_f32": [C.c_void_p, C.POINTER(C.c_void_p), C.c_int64],
 }
 
 _RESTYPE = {
@@ -174,9 +180,9 @@ def load(path=None):
         try:
             fn = getattr(lib, name)
         except AttributeError:
-            # engine extensions (batch records, borrowed tensors): absent from the reference-backed
+            # engine extensions (batch records, borrowed tensors, collectives between devices): absent from the reference-backed
             # test shim (oracle/ref_shim.cpp), which only tests/refbackend/gtn_ref.py loads
-            if name.startswith("gtnx_batch_") or name in ("gtnx_linear_graph_borrow_n", "gtnx_grads_bind_device_n",
+            if name.startswith("gtnx_batch_") or name.startswith("gtnx_comm_") or name in ("gtnx_linear_graph_borrow_n", "gtnx_grads_bind_device_n",
                                                              "gtnx_parallel_enter", "gtnx_parallel_leave", "gtnx_parallel_flush"):
                 continue
             raise

@@ -1684,8 +1684,11 @@ void big_lds(K kern) {
 
 template <int NPL, int K, bool VEC>
 void launch_fwd2(const BandPair* d, int n, int ns, size_t lds, bool unit, hipStream_t st) {
-  static bool attr = (big_lds(band_forward_kernel<NPL, true, K, VEC>), big_lds(band_forward_kernel<NPL, false, K, VEC>), true);
-  (void)attr;
+  static std::atomic<uint64_t> done{0};
+  if (gtnx_first_on_device(done)) {
+    big_lds(band_forward_kernel<NPL, true, K, VEC>);
+    big_lds(band_forward_kernel<NPL, false, K, VEC>);
+  }
   if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
   else hipLaunchKernelGGL((band_forward_kernel<NPL, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
 }
@@ -1696,11 +1699,13 @@ void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool ve
 }
 template <int NPL, int K, bool VEC, bool BIG>
 void launch_bwd3(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
-  static bool attr =
-      (big_lds(band_backward_kernel<NPL, true, true, K, VEC, BIG>), big_lds(band_backward_kernel<NPL, true, false, K, VEC, BIG>),
-       big_lds(band_backward_kernel<NPL, false, true, K, VEC, BIG>), big_lds(band_backward_kernel<NPL, false, false, K, VEC, BIG>),
-       true);
-  (void)attr;
+  static std::atomic<uint64_t> done{0};
+  if (gtnx_first_on_device(done)) {
+    big_lds(band_backward_kernel<NPL, true, true, K, VEC, BIG>);
+    big_lds(band_backward_kernel<NPL, true, false, K, VEC, BIG>);
+    big_lds(band_backward_kernel<NPL, false, true, K, VEC, BIG>);
+    big_lds(band_backward_kernel<NPL, false, false, K, VEC, BIG>);
+  }
   if (unit) {
     if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
     else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
@@ -1795,8 +1800,8 @@ void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, int
     else launch_viterbi_wave<8>(d_pairs, n, st);
     return;
   }
-  static bool attr = (big_lds(band_viterbi_kernel), true);
-  (void)attr;
+  static std::atomic<uint64_t> done{0};
+  if (gtnx_first_on_device(done)) big_lds(band_viterbi_kernel);
   hipLaunchKernelGGL(band_viterbi_kernel, dim3(n), dim3(512), 4 * size_t(1032 + stage_floats) + 64, st, d_pairs);
 }
 

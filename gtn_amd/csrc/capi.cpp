@@ -51,6 +51,19 @@ inline Graph& RAW(gtnx_graph_t h) {
 inline Graph& GL(gtnx_graph_t h) {
   Graph& g = RAW(h);
   if (g.s->pending) return region_value(g);
+  // a graph lives where it was made: its buffers are in that device's memory and its kernels run on that device's
+  // stream (runtime.h) -- using it from a thread that is on another device is the caller's mistake, said so
+  if (g.s->device >= 0 && g.s->device != Runtime::current_device()) {
+    // (a graph that has nothing on its device yet -- built on the host, not uploaded -- simply moves)
+    const bool host_only = !g.s->dev_valid && !g.s->lazy && !g.s->deferred && (!g.w || (!g.w->dev_valid && !g.w->staged)) &&
+                           (!g.g || !g.is_grad_available());
+    if (host_only) {
+      g.s->device = Runtime::current_device();
+      return g;
+    }
+    throw_invalid("[gtn_amd] this graph lives on device " + std::to_string(g.s->device) + ", the calling thread is on device " +
+                  std::to_string(Runtime::current_device()) + " (gtnx_set_device)");
+  }
   return g;
 }
 inline Graph& G(gtnx_graph_t h) {
@@ -107,18 +120,17 @@ GTNX_API gtnx_status_t gtnx_parallel_flush(void) {
 
 // ------------------------------------------------------------------ runtime
 GTNX_API const char* gtnx_last_error(void) { return g_err.c_str(); }
+namespace gtnx {
+void set_last_error(const std::string& m) { g_err = m; }  // (comm.cpp reports through the same thread-local)
+}
 GTNX_API const char* gtnx_version(void) { return "0.1.0"; }
 GTNX_API const char* gtnx_backend(void) { return "hip:gfx950"; }
 GTNX_API int gtnx_device_count(void) { return Runtime::device_count(); }
 GTNX_API gtnx_status_t gtnx_set_device(int d) {
-  return guard([&] {
-    if (Runtime::initialized())
-      Runtime::get().set_device(d);
-    else {
-      HIP_CHECK(hipSetDevice(d));
-      (void)Runtime::get();
-    }
-  });
+  return guard([&] { Runtime::set_current_device(d); });
+}
+GTNX_API gtnx_status_t gtnx_get_device(int* d) {
+  return guard([&] { *d = Runtime::current_device(); });
 }
 GTNX_API gtnx_status_t gtnx_compose_mode(int mode, int* previous) {
   return guard([&] {

@@ -1433,11 +1433,13 @@ size_t compose_chain_bitmap_bytes(int No, int slices) { return 4 * size_t((No + 
 namespace {
 template <int MATCH, bool L1, bool L2, bool FAST, bool C1, int BLK>
 void launch_compose_b(const ComposeArgs* d_args, int n, int dyn, hipStream_t st) {
-  static int max_set = 0;
-  if (dyn > max_set) {
+  static std::atomic<int> max_set[64];  // per device (kernels.h: gtnx_first_on_device)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dyn > max_set[dev & 63].load(std::memory_order_acquire)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(compose_kernel<MATCH, L1, L2, FAST, C1, BLK>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
-    max_set = dyn;
+    max_set[dev & 63].store(dyn, std::memory_order_release);
   }
   hipLaunchKernelGGL((compose_kernel<MATCH, L1, L2, FAST, C1, BLK>), dim3(n), dim3(BLK), dyn, st, d_args);
 }

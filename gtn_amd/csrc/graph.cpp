@@ -439,6 +439,7 @@ void Weights::ensure_host() {
 Graph::Graph(bool calc_grad)
     : s(std::make_shared<Structure>()), w(std::make_shared<Weights>()), g(std::make_shared<GradState>()) {
   s->home = Runtime::home();
+  s->device = Runtime::current_device();
   g->calc_grad = calc_grad;
 }
 

@@ -63,6 +63,8 @@ struct Structure {
   // the deferred-reclamation list of the thread that made the graph: a handle that is destroyed elsewhere is sent
   // there to be taken apart (runtime.h: every thread frees what it allocated)
   Runtime::InboxP home;
+  // the device the graph was made on (the calling thread's at that moment, runtime.h); -1: none (placeholders)
+  int device = -1;
   // The graph is exactly the CTC target acceptor of benchmarks/ctc.cpp:40-58 over these labels (checked at
   // arcSort, O(A)): a batch of such graphs takes the device-built band records (batch.cpp: CTC_TARGETS)
   std::shared_ptr<std::vector<int>> ctc_labels;

@@ -7,6 +7,19 @@
 
 #include <cstdint>
 
+// kernel attributes (hipFuncSetAttribute: the dynamic LDS limit) belong to a (function, DEVICE) pair: a launcher sets
+// them the first time it runs on each device, not once per process (runtime.h: one context per device)
+#include <atomic>
+#include <cstdint>
+inline bool gtnx_first_on_device(std::atomic<uint64_t>& done) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const uint64_t bit = uint64_t(1) << (d & 63);
+  if (done.load(std::memory_order_acquire) & bit) return false;
+  done.fetch_or(bit, std::memory_order_acq_rel);
+  return true;
+}
+
 namespace gtnx {
 
 // Pointers inside the argument structs are loaded from memory, so the compiler

@@ -1534,15 +1534,14 @@ void launch_lazy_init(const LazyGroup& g, int which, hipStream_t st) {
 void launch_lazy_step(const LazyGroup& g, int t, int mode, int backward, hipStream_t st) {
   const dim3 grid((g.N + DT - 1) / DT, (g.nb + BT - 1) / BT);
   const size_t lds = lazy_step_lds_bytes(g);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (gtnx_first_on_device(attr_done)) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_LOG, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_LOG, true>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_TROPICAL, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    attr_set = true;
   }
   if (backward)
     hipLaunchKernelGGL((lazy_step_kernel<SD_LOG, true>), grid, dim3(kTile), lds, st, g, t);
@@ -1603,12 +1602,10 @@ void launch_lazy_fixed_grad(const LazyGroup& g, int max_in_deg, hipStream_t st) 
   const int t_per_block = 32;
   const dim3 grid((g.N + DT - 1) / DT, (g.nb + BT - 1) / BT, (g.T + t_per_block - 1) / t_per_block);
   const size_t lds = lazy_step_lds_bytes(g) + sizeof(float) * size_t(DT) * size_t(max_in_deg);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<uint64_t> attr_done{0};
+  if (gtnx_first_on_device(attr_done))
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_fixed_grad_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-    attr_set = true;
-  }
   hipLaunchKernelGGL(lazy_fixed_grad_kernel, grid, dim3(kTile), lds, st, g, t_per_block, max_in_deg);
 }
 

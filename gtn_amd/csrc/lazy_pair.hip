@@ -426,8 +426,8 @@ int lazy_pair_max_labels(int block) { return SR * block; }  // one emission row 
 
 namespace {
 void pair_attrs() {
-  static bool attr_set = false;
-  if (attr_set) return;
+  static std::atomic<uint64_t> attr_done{0};
+  if (!gtnx_first_on_device(attr_done)) return;
   // 512-lane workgroups (and C in the thousands) need more than the default 64 KB of dynamic LDS
   const int lim = 160 * 1024 - 512;
   const void* fns[] = {reinterpret_cast<const void*>(lazy_pair_backward_kernel<256, 16>),
@@ -439,7 +439,6 @@ void pair_attrs() {
                        reinterpret_cast<const void*>(lazy_pair_forward_kernel<256>),
                        reinterpret_cast<const void*>(lazy_pair_forward_kernel<512>)};
   for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  attr_set = true;
 }
 } // namespace
 

@@ -223,6 +223,7 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
     g.g->calc_grad = calc_grad;
     Structure& s = *g.s;
     s.home = home;
+    s.device = Runtime::current_device();
     s.kind = KIND_LINEAR;
     s.M = M;
     s.C = N;

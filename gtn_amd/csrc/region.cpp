@@ -12,6 +12,7 @@
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <string>
 #include <unordered_map>
 
 namespace gtnx {
@@ -215,6 +216,7 @@ struct Slice {
   } last_lin;
   bool executed = false;
   Runtime::InboxP home;  // of the thread that recorded the slice: where it is taken apart
+  int device = 0;        // the recording thread's device (runtime.h): where its calls run and its results live
 
   PlaceholderStructure* new_placeholder() {
     if (chunks.empty() || chunks.back()->used == kChunk) {
@@ -293,6 +295,7 @@ Slice& my_slice() {
   if (!t_slice) {
     t_slice = SliceP(new Slice(), &retire_slice);
     t_slice->home = Runtime::home();
+    t_slice->device = Runtime::current_device();
   }
   return *t_slice;
 }
@@ -328,8 +331,19 @@ struct Shared {
   std::atomic<int> draining{0};       // threads taking the runtime's deferred list apart right now
   std::recursive_mutex exec;  // one runner at a time (recursive: a user gradFunc may call back into the engine)
 };
+// one per device: a region belongs to the device of the thread that joins it (runtime.h), and regions of different
+// devices run side by side (gtn::parallelMapSharded)
 Shared& shared() {
-  static Shared* s = new Shared();  // never destroyed: worker threads may outlive static destruction
+  static std::atomic<Shared*> per_device[64];  // never destroyed: worker threads may outlive static destruction
+  const int d = Runtime::current_device() & 63;
+  Shared* s = per_device[d].load(std::memory_order_acquire);
+  if (!s) {
+    Shared* fresh = new Shared();
+    if (per_device[d].compare_exchange_strong(s, fresh, std::memory_order_acq_rel))
+      s = fresh;
+    else
+      delete fresh;
+  }
   return *s;
 }
 
@@ -1436,6 +1450,10 @@ namespace {
 // along -- program order for anything it recorded earlier, and the batch stays a batch when the whole slice is
 // one thread's.
 void force(Pending* p) {
+  // (a result lives on the device of the thread that asked for it: capi.cpp GL says the same of ordinary graphs)
+  if (p->sg && p->sg->slice->device != Runtime::current_device())
+    throw_invalid("[gtn_amd] this graph lives on device " + std::to_string(p->sg->slice->device) +
+                  ", the calling thread is on device " + std::to_string(Runtime::current_device()) + " (gtnx_set_device)");
   if (p->st() == 0) {
     std::vector<SliceP> q;
     const bool mine = t_slice && p->sg && p->sg->slice == t_slice.get();

@@ -3,13 +3,38 @@
 
 #include <malloc.h>
 
+#include <atomic>
+
 #include <cstring>
 
 namespace gtnx {
 
 namespace {
-Runtime* g_rt = nullptr;
+constexpr int kMaxDevices = 64;
+std::atomic<Runtime*> g_rts[kMaxDevices];
+std::atomic<bool> g_any_rt{false};
 std::mutex g_rt_mu;
+std::atomic<int> g_default_device{-1};   // the first gtnx_set_device of the process (else 0)
+thread_local int t_device = -1;          // the calling thread's choice (-1: the process default)
+thread_local int t_hip_device = -1;      // what this thread last told HIP (-1: unknown)
+
+// a HIP call that must be made with a given device current, from a thread that may be on another one (a block
+// that goes home from wherever its last reference died)
+struct OnDevice {
+  int prev;
+  explicit OnDevice(int d) : prev(t_hip_device) {
+    if (prev != d) {
+      (void)hipSetDevice(d);
+      t_hip_device = d;
+    }
+  }
+  ~OnDevice() {
+    if (prev >= 0 && prev != t_hip_device) {
+      (void)hipSetDevice(prev);
+      t_hip_device = prev;
+    }
+  }
+};
 
 size_t round_size(size_t b) {
   if (b < 512) return 512;
@@ -19,36 +44,73 @@ size_t round_size(size_t b) {
 } // namespace
 
 DevMem::~DevMem() {
-  if (ptr && g_rt && !borrowed) g_rt->release_dev(ptr, bytes);
+  if (ptr && owner && !borrowed) owner->release_dev(ptr, bytes);
 }
 PinnedMem::~PinnedMem() {
-  if (ptr && g_rt) g_rt->release_pinned(ptr, bytes);
+  if (ptr && owner) owner->release_pinned(ptr, bytes);
 }
 
 int Runtime::device_count() {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) {
-    (void)hipGetLastError();
-    return 0;
-  }
-  return n;
+  // asked once (300 us per call on the GPU box; every pool thread asks when it is put on its device)
+  static const int count = [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+      (void)hipGetLastError();
+      return 0;
+    }
+    return n;
+  }();
+  return count;
 }
 
-bool Runtime::initialized() { return g_rt != nullptr; }
+bool Runtime::initialized() { return g_any_rt.load(std::memory_order_acquire); }
+
+int Runtime::current_device() {
+  if (t_device >= 0) return t_device;
+  const int d = g_default_device.load(std::memory_order_acquire);
+  return d >= 0 ? d : 0;
+}
+
+void Runtime::set_current_device(int d) {
+  if (d < 0 || d >= kMaxDevices || d >= device_count()) throw_invalid("[gtnx_set_device] no such device");
+  t_device = d;
+  int none = -1;
+  g_default_device.compare_exchange_strong(none, d);
+  Runtime::of(d).activate();
+}
+
+void Runtime::activate() {
+  if (t_hip_device == device_) return;
+  HIP_CHECK(hipSetDevice(device_));
+  t_hip_device = device_;
+}
+
+Runtime& Runtime::of(int d) {
+  if (d < 0 || d >= kMaxDevices) throw_invalid("[gtn_amd] device index out of range");
+  Runtime* r = g_rts[d].load(std::memory_order_acquire);
+  if (!r) {
+    std::lock_guard<std::mutex> lk(g_rt_mu);
+    r = g_rts[d].load(std::memory_order_acquire);
+    if (!r) {
+      if (device_count() <= d)
+        throw_device(
+            "gtn_amd: no HIP device visible -- this engine runs its graph functions on an "
+            "MI355X (gfx950) only and has no CPU fallback");
+      r = new Runtime(d);
+      g_rts[d].store(r, std::memory_order_release);
+      g_any_rt.store(true, std::memory_order_release);
+    }
+  }
+  return *r;
+}
 
 Runtime& Runtime::get() {
-  std::lock_guard<std::mutex> lk(g_rt_mu);
-  if (!g_rt) {
-    if (device_count() <= 0)
-      throw_device(
-          "gtn_amd: no HIP device visible -- this engine runs its graph functions on an "
-          "MI355X (gfx950) only and has no CPU fallback");
-    g_rt = new Runtime();
-  }
-  return *g_rt;
+  Runtime& r = of(current_device());
+  r.activate();
+  return r;
 }
 
-Runtime::Runtime() {
+Runtime::Runtime(int device) : device_(device) {
   // The host side of a step allocates and frees a few hundred KB of scratch (launch tables, per-utterance
   // records); with glibc's defaults the heap top is trimmed after every step and grown again in the next
   // (brk + page faults on the thread that joins the region: 17 % of its time in the stack samples of
@@ -60,24 +122,13 @@ Runtime::Runtime() {
     mallopt(M_TOP_PAD, 16 << 20);
     mallopt(M_MMAP_THRESHOLD, 32 << 20);
   }
-  HIP_CHECK(hipGetDevice(&device_));
+  HIP_CHECK(hipSetDevice(device_));
+  t_hip_device = device_;
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device_));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
   stream_ = own_stream_;
-}
-
-void Runtime::set_device(int d) {
-  sync();
-  HIP_CHECK(hipSetDevice(d));
-  if (d != device_) {
-    // pools belong to the previous device: drop them
-    empty_cache();
-    device_ = d;
-    HIP_CHECK(hipStreamCreateWithFlags(&own_stream_, hipStreamNonBlocking));
-    stream_ = own_stream_;
-  }
 }
 
 void Runtime::set_stream(hipStream_t s) {
@@ -248,6 +299,7 @@ DevMemP Runtime::alloc(size_t bytes) {
   auto m = std::make_shared<DevMem>();
   m->ptr = p;
   m->bytes = sz;
+  m->owner = this;
   return m;
 }
 
@@ -296,10 +348,12 @@ PinnedMemP Runtime::alloc_pinned(size_t bytes) {
   auto m = std::make_shared<PinnedMem>();
   m->ptr = p;
   m->bytes = sz;
+  m->owner = this;
   return m;
 }
 
 void Runtime::release_pinned(void* p, size_t bytes) {
+  OnDevice here(device_);
   std::lock_guard<std::mutex> lk(mu_);
   hipEvent_t ev;
   if (!ev_pool_.empty()) {
@@ -316,6 +370,7 @@ void Runtime::release_pinned(void* p, size_t bytes) {
 }
 
 void Runtime::empty_cache() {
+  OnDevice here(device_);
   drain_deferred();
   (void)hipStreamSynchronize(stream_);
   std::lock_guard<std::mutex> lk(mu_);

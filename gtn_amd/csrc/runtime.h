@@ -19,10 +19,13 @@
 
 namespace gtnx {
 
+class Runtime;
+
 struct DevMem {
   void* ptr = nullptr;
   size_t bytes = 0;
   bool borrowed = false;  // the caller's memory (a tensor that outlives the graphs over it): never pooled
+  Runtime* owner = nullptr;  // the device context whose pool the block goes back to (null: borrowed)
   ~DevMem();
   template <class T>
   T* as(size_t byte_off = 0) const { return reinterpret_cast<T*>(static_cast<char*>(ptr) + byte_off); }
@@ -32,6 +35,7 @@ using DevMemP = std::shared_ptr<DevMem>;
 struct PinnedMem {
   void* ptr = nullptr;
   size_t bytes = 0;
+  Runtime* owner = nullptr;
   ~PinnedMem();
   template <class T>
   T* as(size_t byte_off = 0) const { return reinterpret_cast<T*>(static_cast<char*>(ptr) + byte_off); }
@@ -44,15 +48,26 @@ struct ProfEntry {
   double bytes = 0;
 };
 
+// One Runtime per DEVICE (stream, memory pools, profiler), made on first use.  Which one a call gets is a property
+// of the calling THREAD: gtnx_set_device(d) (Runtime::set_current_device) selects device d for the calling thread
+// only, and a thread that never chose inherits the process default -- the device of the first set_device call, else
+// 0 -- so a one-GPU process (one rank per GPU under torch.distributed) behaves as before, and a C++ host that
+// drives the 8 GPUs of a node gives each device its own thread (include/gtn/parallel.h: parallelMapSharded; the
+// pool threads of a parallelMap inherit the device of the thread that called it).  Graphs remember the device they
+// were made on; blocks go back to the pool of the device they came from whichever thread lets go of them.
 class Runtime {
  public:
-  static Runtime& get();          // throws GTNX_DEVICE_ERROR when no GPU is usable
+  static Runtime& get();          // the calling thread's device context; throws GTNX_DEVICE_ERROR when no GPU is usable
+  static Runtime& of(int device); // a given device's context (made on first use)
   static int device_count();      // never throws
-  static bool initialized();
+  static bool initialized();      // some device context exists
+  static void set_current_device(int d);  // for the calling thread (and, the first time, the process default)
+  static int current_device();            // of the calling thread
+  int device() const { return device_; }
+  void activate();                // hipSetDevice(device()) for the calling thread if it is on another one
 
   hipStream_t stream() const { return stream_; }
   void set_stream(hipStream_t s);
-  void set_device(int d);
   void sync();
 
   DevMemP alloc(size_t bytes);            // uninitialised
@@ -108,7 +123,7 @@ class Runtime {
   int cu_count() const { return cu_count_; }
 
  private:
-  Runtime();
+  explicit Runtime(int device);
   void collect_prof();
   hipStream_t own_stream_ = nullptr;
   hipStream_t stream_ = nullptr;

@@ -1253,16 +1253,18 @@ size_t deep_lds_bytes(int maxP, bool backward) {
 }  // namespace
 void launch_sd_forward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st) {
   if (n <= 0) return;
-  static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_forward_deep_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(deep_lds_bytes(kDeepP, false))), true);
-  (void)attr;
+  static std::atomic<uint64_t> done{0};
+  if (gtnx_first_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_forward_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              int(deep_lds_bytes(kDeepP, false)));
   hipLaunchKernelGGL(sd_forward_deep_kernel, dim3(n), dim3(64), deep_lds_bytes(maxP, false), st, d_args);
 }
 void launch_sd_backward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st) {
   if (n <= 0) return;
-  static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_backward_deep_kernel),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(deep_lds_bytes(kDeepP, true))), true);
-  (void)attr;
+  static std::atomic<uint64_t> done{0};
+  if (gtnx_first_on_device(done))
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_backward_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              int(deep_lds_bytes(kDeepP, true)));
   hipLaunchKernelGGL(sd_backward_deep_kernel, dim3(n), dim3(64), deep_lds_bytes(maxP, true), st, d_args);
 }
 

@@ -30,6 +30,16 @@
 
 namespace gtn {
 namespace detail {
+inline void throwStatus(gtnx_status_t st) {  // (as gtn/graph.h: detail::check -- this header stands on its own)
+  if (st == GTNX_OK) return;
+  const std::string msg = gtnx_last_error();
+  switch (st) {
+    case GTNX_INVALID_ARGUMENT: throw std::invalid_argument(msg);
+    case GTNX_LOGIC_ERROR: throw std::logic_error(msg);
+    case GTNX_OUT_OF_RANGE: throw std::out_of_range(msg);
+    default: throw std::runtime_error(msg);
+  }
+}
 template <class V>
 auto pickElem(size_t size, size_t i, const V& v) -> decltype(v[0]) {
   if (v.size() == size) return v[i];
@@ -54,6 +64,7 @@ class Pool {
     size_t n = 0, grain = 1;
     size_t max_workers = 0;        // pool threads with an index below this take part
     int compose_mode = -1;         // the caller's gtnx_compose_mode: goes with the tasks
+    int device = 0;                // ... and its device (gtnx_set_device): the pool's threads work there
     bool region = true;            // announce the threads to the engine (gtnx_parallel_enter / leave)
     void (*run)(void* ctx, size_t i) = nullptr;
     void* ctx = nullptr;
@@ -86,9 +97,24 @@ class Pool {
     static const bool on = std::getenv("GTN_AMD_POOL_TRACE") != nullptr;
     return on;
   }
-  static Pool& get() {
-    static Pool p;
-    return p;
+  /** the pool of a device: every GPU a host drives has its own workers (they are put on that device,
+   *  gtnx_set_device, and stay there), so the maps of several device threads run side by side */
+  static Pool& get(int device = 0) {
+    static std::mutex mu;
+    static std::vector<std::unique_ptr<Pool>> pools;
+    std::lock_guard<std::mutex> lk(mu);
+    const size_t d = device < 0 ? 0 : size_t(device);
+    if (pools.size() <= d) pools.resize(d + 1);
+    if (!pools[d]) pools[d].reset(new Pool());
+    return *pools[d];
+  }
+  ~Pool() {
+    if (tracing())
+      std::fprintf(stderr, "[gtn pool] workers at job start: idle %ld  still in tasks %ld  reclaiming %ld (sums over jobs)\n", phaseSum_[0],
+                   phaseSum_[1], phaseSum_[2]);
+    stop_.store(true, std::memory_order_seq_cst);
+    wakeParked(slots_.size());
+    for (auto& t : threads_) t.join();
   }
   /** run tasks 0 .. n-1 on up to `nthreads` pool threads and the calling thread.  Nested or concurrent calls run
    *  on the calling thread only. */
@@ -154,14 +180,6 @@ class Pool {
       if (slots_[i]->parked.load(std::memory_order_seq_cst) == 1 && slots_[i]->parked.exchange(0, std::memory_order_seq_cst) == 1)
         sem_post(&slots_[i]->sem);
   }
-  ~Pool() {
-    if (tracing())
-      std::fprintf(stderr, "[gtn pool] workers at job start: idle %ld  still in tasks %ld  reclaiming %ld (sums over jobs)\n", phaseSum_[0],
-                   phaseSum_[1], phaseSum_[2]);
-    stop_.store(true, std::memory_order_seq_cst);
-    wakeParked(slots_.size());
-    for (auto& t : threads_) t.join();
-  }
   static void cpuRelax() {
 #if defined(__x86_64__) || defined(__i386__)
     __builtin_ia32_pause();
@@ -195,6 +213,7 @@ class Pool {
         if (j.region) {
           // graph functions called from here are deferred to the join (gtn_amd.h); they run under the compose
           // mode of the thread that called parallelMap
+          if (!caller) gtnx_set_device(j.device);
           gtnx_parallel_enter();
           if (!caller) gtnx_compose_mode(j.compose_mode, &oldMode);
         }
@@ -337,12 +356,15 @@ void runIndexed(size_t n, Body&& body, size_t maxThreads = 64, bool region = tru
   using BodyT = typename std::remove_reference<Body>::type;
   job->ctx = const_cast<void*>(static_cast<const void*>(&body));
   job->run = [](void* ctx, size_t i) { (*static_cast<BodyT*>(ctx))(i); };
-  if (job->region) {  // the mode the tasks' compose / intersect calls run under: the caller's
+  int device = 0;
+  if (job->region) {  // the mode the tasks' compose / intersect calls run under, and the device they run on: the caller's
     int cur = -1;
     if (gtnx_compose_mode(0, &cur) == GTNX_OK) gtnx_compose_mode(cur, nullptr);
     job->compose_mode = cur;
+    if (gtnx_get_device(&device) != GTNX_OK) device = 0;
+    job->device = device;
   }
-  Pool::get().run(job, nt);
+  Pool::get(device).run(job, nt);
   // the join: everything the tasks asked the engine for runs now, batched (no-op when nothing was deferred)
   std::exception_ptr first = job->first;
   if (job->region) {
@@ -397,5 +419,55 @@ auto parallelMap(FuncType&& function, Args&&... inputs) {
     for (size_t i = 0; i < size; ++i) out.emplace_back(std::move(slots.at(i)));
     return out;
   }
+}
+
+/** parallelMap over SEVERAL GPUs of one node (every utterance's compose -> forwardScore -> backward is
+ *  independent, parallel_map.h:167-179): the inputs are cut into contiguous blocks, one per entry of `devices`, and
+ *  each block is mapped by its own host thread on its own device (gtnx_set_device: that device's stream, memory pools
+ *  and worker pool) -- exactly as parallelMap would, deferred calls and all.  Results come back in input order; every
+ *  result lives on the device of its block (resultDevice(i, n, devices.size()) says which), and so must the device
+ *  buffers the tasks hand to setWeights.  No data moves between devices here: gather scalars with
+ *  gtnx_comm_all_gather_f32 / sum a shared gradient with gtnx_comm_all_reduce_sum_f32 (include/gtn_amd.h, RCCL). */
+inline size_t shardBegin(size_t n, size_t shards, size_t k) { return n * k / shards; }
+inline size_t resultDevice(size_t i, size_t n, size_t shards) {
+  size_t k = shards ? (i * shards) / (n ? n : 1) : 0;
+  while (k + 1 < shards && shardBegin(n, shards, k + 1) <= i) ++k;
+  while (k > 0 && shardBegin(n, shards, k) > i) --k;
+  return k;
+}
+template <typename FuncType, typename... Args>
+auto parallelMapSharded(const std::vector<int>& devices, FuncType&& function, Args&&... inputs) {
+  size_t size = 0;
+  (void)std::initializer_list<int>{(size = std::max(size, inputs.size()), 0)...};
+  using OutType = decltype(function(detail::pickElem(1, 0, inputs)...));
+  static_assert(!std::is_void<OutType>::value, "parallelMapSharded: the mapped function returns a value per input");
+  const size_t S = devices.empty() ? 1 : devices.size();
+  std::vector<std::vector<OutType>> parts(S);
+  std::vector<std::exception_ptr> errs(S);
+  auto shard = [&](size_t k) {
+    try {
+      if (!devices.empty()) detail::throwStatus(gtnx_set_device(devices[k]));
+      const size_t b = shardBegin(size, S, k), e = shardBegin(size, S, k + 1);
+      std::vector<size_t> idx(e - b);
+      for (size_t i = b; i < e; ++i) idx[i - b] = i;
+      parts[k] = parallelMap([&](size_t i) { return function(detail::pickElem(size, i, inputs)...); }, idx);
+    } catch (...) {
+      errs[k] = std::current_exception();
+    }
+  };
+  std::vector<std::thread> threads;
+  for (size_t k = 1; k < S; ++k) threads.emplace_back(shard, k);
+  int mine = 0;
+  const bool had = gtnx_get_device(&mine) == GTNX_OK;
+  shard(0);
+  if (had && !devices.empty()) gtnx_set_device(mine);  // (the calling thread goes back to where it was)
+  for (auto& t : threads) t.join();
+  for (auto& e : errs)
+    if (e) std::rethrow_exception(e);
+  std::vector<OutType> out;
+  out.reserve(size);
+  for (auto& p : parts)
+    for (auto& r : p) out.emplace_back(std::move(r));
+  return out;
 }
 } // namespace gtn

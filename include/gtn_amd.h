@@ -54,7 +54,13 @@ const char* gtnx_version(void);
  * (oracle/_ref/libgtn_ref.so) answers "reference-cpu". */
 const char* gtnx_backend(void);
 int gtnx_device_count(void);                /* 0 when no GPU is visible */
-gtnx_status_t gtnx_set_device(int device);  /* hipSetDevice for this process */
+/* The device of the CALLING THREAD (hipSetDevice + the engine's per-device context: stream, memory pools).  A thread
+ * that never chose is on the process default: the device of the first gtnx_set_device call, else 0 -- one rank per GPU
+ * (torch.distributed) sets it once; a host that drives several GPUs gives each its own thread (gtn::parallelMapSharded,
+ * include/gtn/parallel.h; the pool threads of a parallelMap are put on the device of the thread that called it).
+ * Graphs live on the device they were made on: using one from a thread on another device is GTNX_INVALID_ARGUMENT. */
+gtnx_status_t gtnx_set_device(int device);
+gtnx_status_t gtnx_get_device(int* device);
 gtnx_status_t gtnx_set_stream(void* hip_stream); /* NULL = the engine's own stream */
 gtnx_status_t gtnx_synchronize(void);
 /* How compose / intersect of an implicit emissions chain with an epsilon-free graph treat their
@@ -293,6 +299,23 @@ gtnx_status_t gtnx_isomorphic(gtnx_graph_t a, gtnx_graph_t b, int* out);
  * file image: the arc table and the weights go to the device in ONE copy and are split into the graph's SoA
  * arrays there (adjacency lists built on the device as well); node and arc ids as load() numbers them. */
 gtnx_status_t gtnx_graph_load_buffer(const void* data, size_t bytes, gtnx_graph_t* out);
+
+/* ------------------------------------------------------------------ several GPUs, one process
+ * The path shards by utterance (parallelMap has no cross-task communication, parallel/parallel_map.h:167-179): a host
+ * that drives the GPUs of a node gives each device its own thread (gtnx_set_device; gtn::parallelMapSharded) and no
+ * data-path collective is needed.  What is gathered afterwards goes over RCCL (xGMI), one communicator per device,
+ * enqueued on each device's engine stream so that it orders with the kernels producing its inputs:
+ *   all_gather   the per-utterance losses: device k contributes `count` floats at send[k] (ITS memory) and receives
+ *                all n * count at recv[k], blocks in the order of `devices`
+ *   all_reduce   the gradient of a graph every utterance shares (ASG transitions, criterion_test.cpp:289-305: the sum
+ *                over utterances): bufs[k] (device k's partial sum, `count` floats) becomes the total, in place
+ * librccl.so is looked up at first use; a communicator over ONE device needs none (gather = copy, reduce = nothing). */
+typedef struct gtnx_comm_s* gtnx_comm_t;
+gtnx_status_t gtnx_comm_create(const int* devices, int n, gtnx_comm_t* out);
+gtnx_status_t gtnx_comm_destroy(gtnx_comm_t c);
+gtnx_status_t gtnx_comm_size(gtnx_comm_t c, int* n);
+gtnx_status_t gtnx_comm_all_gather_f32(gtnx_comm_t c, const void* const* send, void* const* recv, int64_t count);
+gtnx_status_t gtnx_comm_all_reduce_sum_f32(gtnx_comm_t c, void* const* bufs, int64_t count);
 
 /* ------------------------------------------------------------------ profiling
  * hipEvent timing of the engine's own kernel launches on the launch stream

@@ -79,6 +79,10 @@ const char* gtnx_version(void) { return "reference"; }
 const char* gtnx_backend(void) { return "reference-cpu"; }
 int gtnx_device_count(void) { return 0; }
 gtnx_status_t gtnx_set_device(int) { return GTNX_OK; }
+gtnx_status_t gtnx_get_device(int* d) {
+  *d = 0;
+  return GTNX_OK;
+}
 gtnx_status_t gtnx_set_stream(void*) { return GTNX_OK; }
 gtnx_status_t gtnx_compose_mode(int, int* previous) {
   if (previous) *previous = 0;

@@ -68,3 +68,44 @@ def test_bench_multi_rank_branch_over_rccl():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])  # (RCCL prints after it)
     assert line["collectives"] and "RCCL" in line["collectives"]
     assert line["value"] > 0 and len(line["per_rank"]) == 1
+
+
+@pytest.mark.gpu
+def test_c_abi_collectives_run_on_rccl_at_world_size_one():
+    """gtnx_comm_* (gtn_amd/csrc/comm.cpp: what a C++ host that drives several GPUs from ONE process gathers losses and
+    sums the shared ASG gradient with) on the real librccl: a communicator over this box's one GPU, forced through the
+    library (GTNX_COMM_FORCE_RCCL=1 -- a one-device communicator would otherwise copy), ncclAllGather / ncclAllReduce
+    enqueued on the engine's stream.  The eight-device logic is tests/test_multidevice_cpu.py's."""
+    import ctypes as C
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, os, sys
+import numpy as np, torch
+import gtn_amd as gtn
+from gtn_amd import _capi
+lib = _capi.load()
+dev = (C.c_int * 1)(0)
+comm = C.c_void_p()
+assert lib.gtnx_comm_create(dev, 1, C.byref(comm)) == 0, lib.gtnx_last_error()
+n = C.c_int()
+assert lib.gtnx_comm_size(comm, C.byref(n)) == 0 and n.value == 1
+send = torch.arange(512, dtype=torch.float32, device="cuda:0")
+recv = torch.full((512,), -1.0, device="cuda:0")
+torch.cuda.synchronize()
+sp = (C.c_void_p * 1)(send.data_ptr()); rp = (C.c_void_p * 1)(recv.data_ptr())
+assert lib.gtnx_comm_all_gather_f32(comm, sp, rp, 512) == 0, lib.gtnx_last_error()
+g = torch.full((262656,), 2.5, device="cuda:0")
+torch.cuda.synchronize()
+gp = (C.c_void_p * 1)(g.data_ptr())
+assert lib.gtnx_comm_all_reduce_sum_f32(comm, gp, 262656) == 0, lib.gtnx_last_error()
+assert lib.gtnx_synchronize() == 0
+assert torch.equal(recv, send), "all_gather over one rank is the identity"
+assert float(g.min()) == 2.5 and float(g.max()) == 2.5, "all_reduce(sum) over one rank is the identity"
+assert lib.gtnx_comm_destroy(comm) == 0
+print("RCCL_OK")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GTNX_COMM_FORCE_RCCL="1", PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]

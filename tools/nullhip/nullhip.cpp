@@ -6,22 +6,57 @@
 // the tests, smoke() or bench.py.
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <vector>
 
+// NULLHIP_DEVICES=8: eight "devices".  What a device IS here: the thread-local current device (hipSetDevice), a stream
+// handle that knows its device, every allocation tagged with the device that was current, and counters per device
+// (launches, bytes allocated, launches made on a stream while ANOTHER device was current = what the real runtime
+// rejects) -- enough to check the engine's per-device contexts (runtime.h) and the sharding of a batch over the GPUs
+// of a node (tests/native/multidev_test.cpp) without hardware.  The RCCL entry points comm.cpp looks up are here too,
+// doing the collective on host memory.
 namespace {
 thread_local dim3 t_grid, t_block;
 thread_local size_t t_shmem;
 thread_local hipStream_t t_stream;
+thread_local int t_dev = 0;
 int g_dummy;
+constexpr int kMaxDev = 16;
+const int g_ndev = [] {
+  const char* e = std::getenv("NULLHIP_DEVICES");
+  const int n = e ? std::atoi(e) : 1;
+  return n < 1 ? 1 : (n > kMaxDev ? kMaxDev : n);
+}();
+struct Stream {
+  int dev;
+};
+std::atomic<long> g_launches[kMaxDev], g_wrong_device[kMaxDev], g_alloc_bytes[kMaxDev];
+int dev_of_stream(hipStream_t s) {
+  if (!s || s == reinterpret_cast<hipStream_t>(&g_dummy)) return t_dev;
+  return reinterpret_cast<Stream*>(s)->dev;
+}
+}
+extern "C" {
+// counters for the tests (dlsym'd by name)
+long nullhip_launches(int d) { return d >= 0 && d < kMaxDev ? g_launches[d].load() : -1; }
+long nullhip_wrong_device_launches(int d) { return d >= 0 && d < kMaxDev ? g_wrong_device[d].load() : -1; }
+long nullhip_alloc_bytes(int d) { return d >= 0 && d < kMaxDev ? g_alloc_bytes[d].load() : -1; }
 }
 
 extern "C" {
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = g_ndev; return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = t_dev; return hipSuccess; }
+hipError_t hipSetDevice(int d) {
+  if (d < 0 || d >= g_ndev) return hipErrorInvalidDevice;
+  t_dev = d;
+  return hipSuccess;
+}
 hipError_t hipGetDevicePropertiesR0600(hipDeviceProp_t* p, int) {
   std::memset(p, 0, sizeof(*p));
   p->multiProcessorCount = 256;
@@ -52,6 +87,7 @@ hipError_t hipMalloc(void** p, size_t n) {
     std::lock_guard<std::mutex> lk(g_range_mu);
     g_ranges[reinterpret_cast<uintptr_t>(*p)] = n ? n : 256;
   }
+  g_alloc_bytes[t_dev].fetch_add(long(n));
   return hipSuccess;
 }
 hipError_t hipFree(void* p) {
@@ -74,7 +110,10 @@ hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
   if (g_zero || n <= (1u << 20)) std::memset(d, v, n);
   return hipSuccess;
 }
-hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = reinterpret_cast<hipStream_t>(&g_dummy); return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
+  *s = reinterpret_cast<hipStream_t>(new Stream{t_dev});  // (never destroyed: the engine keeps its streams)
+  return hipSuccess;
+}
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // the "GPU" is never busy
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(&g_dummy); return hipSuccess; }
@@ -86,7 +125,12 @@ hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t) { return hipSuccess; }
+hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t st) {
+  const int d = dev_of_stream(st);
+  g_launches[d].fetch_add(1);
+  if (d != t_dev) g_wrong_device[d].fetch_add(1);  // the real runtime: hipErrorInvalidResourceHandle
+  return hipSuccess;
+}
 void** __hipRegisterFatBinary(const void*) { static void* h; return &h; }
 void __hipUnregisterFatBinary(void**) {}
 void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned, void*, void*, void*, void*, int*) {}
@@ -98,4 +142,64 @@ hipError_t __hipPopCallConfiguration(dim3* g, dim3* b, size_t* sh, hipStream_t* 
   *g = t_grid; *b = t_block; *sh = t_shmem; *st = t_stream;
   return hipSuccess;
 }
+
+// ---- the slice of RCCL that gtn_amd/csrc/comm.cpp looks up (dlsym), on host memory: every "device" buffer is
+// ordinary memory here, so a collective is a loop.  Group semantics as far as comm.cpp uses them: the calls between
+// ncclGroupStart and ncclGroupEnd are collected and carried out at the end.
+namespace {
+struct NComm {
+  int rank, n;
+};
+struct Pending {
+  int kind;  // 0 gather, 1 reduce
+  const void* send;
+  void* recv;
+  size_t count;
+  NComm* c;
+};
+thread_local std::vector<Pending>* t_group = nullptr;
+}
+int ncclCommInitAll(void** comms, int n, const int*) {
+  for (int k = 0; k < n; ++k) comms[k] = new NComm{k, n};
+  return 0;
+}
+int ncclCommDestroy(void* c) {
+  delete static_cast<NComm*>(c);
+  return 0;
+}
+int ncclGroupStart() {
+  if (!t_group) t_group = new std::vector<Pending>();
+  t_group->clear();
+  return 0;
+}
+int ncclAllGather(const void* send, void* recv, size_t count, int, void* comm, hipStream_t) {
+  if (!t_group) return 1;
+  t_group->push_back({0, send, recv, count, static_cast<NComm*>(comm)});
+  return 0;
+}
+int ncclAllReduce(const void* send, void* recv, size_t count, int, int, void* comm, hipStream_t) {
+  if (!t_group) return 1;
+  t_group->push_back({1, send, recv, count, static_cast<NComm*>(comm)});
+  return 0;
+}
+int ncclGroupEnd() {
+  if (!t_group) return 1;
+  std::vector<Pending>& g = *t_group;
+  if (g.empty()) return 0;
+  const size_t n = g.size(), count = g[0].count;
+  if (g[0].kind == 0) {
+    for (size_t k = 0; k < n; ++k)  // every receiver gets every sender's block, at the sender's rank
+      for (size_t j = 0; j < n; ++j)
+        if (static_cast<char*>(g[k].recv) + 4 * count * size_t(g[j].c->rank) != g[j].send)
+          std::memmove(static_cast<char*>(g[k].recv) + 4 * count * size_t(g[j].c->rank), g[j].send, 4 * count);
+  } else {
+    std::vector<float> sum(count, 0.0f);
+    for (size_t j = 0; j < n; ++j)
+      for (size_t i = 0; i < count; ++i) sum[i] += static_cast<const float*>(g[j].send)[i];
+    for (size_t k = 0; k < n; ++k) std::memcpy(g[k].recv, sum.data(), 4 * count);
+  }
+  g.clear();
+  return 0;
+}
+const char* ncclGetErrorString(int) { return "nullhip rccl"; }
 }

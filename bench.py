@@ -233,7 +233,7 @@ def other_configs(args):
                    "--no-reference-api", "--no-unmodified-caller", "--no-built-lattice", "--cpu-baseline-seconds", "20"], 600)
     if "error" not in c5:
         c5 = {k: c5.get(k) for k in ("metric", "value", "unit", "ms_per_step", "config", "roofline", "roofline_other",
-                                     "kernel_ms_per_step", "host_ms_last_step", "loss_mean", "cpu_baseline")}
+                                     "kernel_ms_per_step", "host_ms_last_step", "loss_mean", "cpu_baseline", "parity_in_run")}
         c5["note"] = ("one rank's shard of BASELINE config C5 (T=2000, C=1024, U=200, 4096 utterances over 8 GPUs = 512 "
                       "per GPU), timed on one MI355X")
     out["C5_shard"] = c5

@@ -72,7 +72,34 @@ inline Graph& G(gtnx_graph_t h) {
   if (g.s->deferred) g.s->resolve_sizes();  // sizes a compose left on the device
   return g;
 }
-inline gtnx_graph_t H(Graph g) { return reinterpret_cast<gtnx_graph_t>(new Graph(std::move(g))); }
+// Handles.  A gtnx_graph_t points at a Graph inside a SLAB of handles: the n results of a vector form (gtnx_*_n) are one
+// allocation, not n -- a step of 512 utterances through the vector forms made and freed 2500 48-byte blocks on the
+// thread everything waits for -- and a single result is a slab of one.  A handle's Graph is destroyed when the handle is
+// (gtnx_graph_destroy); the slab's memory goes when its last handle has.
+struct HandleSlab {
+  std::atomic<int> live;
+};
+struct HandleEntry {
+  Graph g;  // (first: the handle IS a Graph*)
+  HandleSlab* slab;
+};
+HandleEntry* new_handles(size_t n) {
+  const size_t head = (sizeof(HandleSlab) + alignof(HandleEntry) - 1) / alignof(HandleEntry) * alignof(HandleEntry);
+  char* raw = static_cast<char*>(::operator new(head + sizeof(HandleEntry) * (n ? n : 1)));
+  HandleSlab* s = new (raw) HandleSlab();
+  s->live.store(int(n), std::memory_order_relaxed);
+  HandleEntry* e = reinterpret_cast<HandleEntry*>(raw + head);
+  for (size_t i = 0; i < n; ++i) {
+    new (&e[i].g) Graph(Graph::Empty{});
+    e[i].slab = s;
+  }
+  return e;
+}
+inline gtnx_graph_t H(Graph g) {
+  HandleEntry* e = new_handles(1);
+  e->g = std::move(g);
+  return reinterpret_cast<gtnx_graph_t>(&e->g);
+}
 
 std::vector<Graph> vec(const gtnx_graph_t* a, int n, bool lazy_ok = false) {
   std::vector<Graph> v;
@@ -81,7 +108,12 @@ std::vector<Graph> vec(const gtnx_graph_t* a, int n, bool lazy_ok = false) {
   return v;
 }
 void put(std::vector<Graph>& r, gtnx_graph_t* out) {
-  for (size_t i = 0; i < r.size(); ++i) out[i] = H(std::move(r[i]));
+  if (r.empty()) return;
+  HandleEntry* e = new_handles(r.size());
+  for (size_t i = 0; i < r.size(); ++i) {
+    e[i].g = std::move(r[i]);
+    out[i] = reinterpret_cast<gtnx_graph_t>(&e[i].g);
+  }
 }
 // Is p a HIP device address?  (hipPointerGetAttributes fails for ordinary host memory.)
 bool is_device_pointer(const void* p) {
@@ -101,6 +133,18 @@ void check_arc(Graph& g, int a) {
   if (a < 0 || a >= g.num_arcs()) throw_range("arc index out of range");
 }
 } // namespace
+
+namespace gtnx {
+void destroy_handle(Graph* g) {  // (region.h: handles dropped inside a region are let go of by region_leave)
+  HandleEntry* e = reinterpret_cast<HandleEntry*>(g);
+  HandleSlab* s = e->slab;
+  e->g.~Graph();
+  if (s->live.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+    s->~HandleSlab();
+    ::operator delete(static_cast<void*>(s));
+  }
+}
+}  // namespace gtnx
 
 // ------------------------------------------------------------------ parallelMap regions
 // A caller that maps the per-graph functions over a batch on host threads (gtn::parallelMap:
@@ -193,11 +237,11 @@ GTNX_API gtnx_status_t gtnx_graph_destroy(gtnx_graph_t g) {
     if (region_active())
       region_trash(p);  // let go of when the thread leaves the region
     else if (p->s && p->s->pending)
-      delete p;         // a placeholder's handle is a reference to its slice: nothing to take apart here (region.cpp)
+      destroy_handle(p);  // a placeholder's handle is a reference to its slice: nothing to take apart here (region.cpp)
     else if (Runtime::initialized())  // taken apart later, by the thread that made the graph (runtime.h)
-      Runtime::send(p->s && p->s->home ? p->s->home : Runtime::home(), p, [](void* q) { delete static_cast<Graph*>(q); });
+      Runtime::send(p->s && p->s->home ? p->s->home : Runtime::home(), p, [](void* q) { destroy_handle(static_cast<Graph*>(q)); });
     else
-      delete p;
+      destroy_handle(p);
   });
 }
 GTNX_API gtnx_status_t gtnx_graph_add_node(gtnx_graph_t g, int s, int a, int* id) {
@@ -656,7 +700,7 @@ void run_vector(RegionOp op, const gtnx_graph_t* a, int na, const gtnx_graph_t* 
   const int n = b ? std::max(na, nb) : na;
   std::vector<Graph> res(static_cast<size_t>(n), Graph(Graph::Empty{}));
   region_run_vector(op, pa.data(), na, b ? pb.data() : nullptr, nb, res.data());
-  for (int i = 0; i < n; ++i) out[i] = H(std::move(res[size_t(i)]));
+  put(res, out);
 }
 }
 UNARY_FN(gtnx_negate, op_scalar(SK_NEGATE, v, g_empty), false, RO_NEG)

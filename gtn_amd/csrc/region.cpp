@@ -1349,7 +1349,7 @@ void region_leave() {
   t_slice.reset();
   t_arena.reset();
   // handles the tasks dropped: allocated on this thread, and their graphs are held by the recorded calls anyway
-  for (Graph* g : t_trash) delete g;
+  for (Graph* g : t_trash) destroy_handle(g);
   t_trash.clear();
 }
 

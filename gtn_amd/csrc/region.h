@@ -101,6 +101,7 @@ bool region_stage_weights(Graph& g, const float* p, bool device);
 // gtnx_reclaim on a pool thread: what this thread built in earlier regions and nobody refers to any more comes
 // home to be taken apart here (region.cpp: return to sender)
 void region_reclaim_thread();
+void destroy_handle(Graph* handle);             // capi.cpp: a handle is an entry of a slab of handles
 void region_trash(Graph* handle);               // gtnx_graph_destroy inside a region: handed over at leave
 
 } // namespace gtnx

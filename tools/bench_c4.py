@@ -180,7 +180,36 @@ def main():
     out["metric"] = "ASG criterion forward+backward utterances/sec (T=%d, C=%d); decode in decode_utt_per_s" % (T, C)
     out["value"] = out.get("asg_criterion_utt_per_s")
     out["unit"] = "utterances/s"
+    # in-run parity: the engine in THIS process against the unmodified reference's answers at C4's alphabet
+    # (tests/golden/asg_c512.npz, made by tests/golden/make_golden_c4.py over oracle/_ref: T = 17, C = 512) --
+    # Viterbi labels EQUAL, scores to 1e-4 (the same kernels as the timed batch: matrix-core forward, max-plus decode)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_golden_c4 as mk
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "asg_c512.npz"))
+        Tg = 17
+        key = f"T{Tg}"
+        Bg = gold[key + "_forward"].shape[0]
+        emg, twg = mk.inputs(Tg, Bg, int(gold[key + "_seed"]))
+        tr = mk.transitions(gtn, twg)
+        prevm = gtn.compose_mode(1)
+        try:
+            eg = gtn.linear_graph_n(Bg, Tg, mk.C, torch.from_numpy(emg).cuda())
+            cg = gtn.compose(eg, [tr])
+            fsg = np.asarray(gtn.items(gtn.forward_score(cg)), np.float64)
+            pg = gtn.viterbi_path(cg)
+        finally:
+            gtn.compose_mode(prevm)
+        labels_equal = all(pg[b].labels_to_list() == gold[key + "_labels"][b].tolist() for b in range(Bg))
+        rel = float(np.max(np.abs(fsg - gold[key + "_forward"]) / np.abs(gold[key + "_forward"])))
+        out["parity_in_run"] = {"n": int(Bg), "T": Tg, "C": int(mk.C), "labels_equal": bool(labels_equal), "forward_score_max_rel": rel,
+                                "checker": "reference answers (tests/golden/asg_c512.npz, generated by oracle/_ref)",
+                                "ok": bool(labels_equal and rel <= 1e-4)}
+    except Exception as e:  # reported, and fails the run below
+        out["parity_in_run"] = {"error": str(e)[:300], "ok": False}
     print(json.dumps(out))
+    if not out.get("parity_in_run", {}).get("ok", False):
+        sys.exit(3)
 
 
 def cpu_baseline(C):

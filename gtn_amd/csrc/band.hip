@@ -1410,6 +1410,10 @@ __global__ __launch_bounds__(512) void band_viterbi_kernel(const BandDecode* __r
 // walk: the word row of a group of steps is loaded by all lanes (the next one already in flight) and the
 // walker takes its lane's word with v_readlane -- no dependent memory access on the chain.  Same arithmetic,
 // same outputs as band_viterbi_kernel.
+// (Built and measured, not in the tree: TWO waves per utterance, the upper half of the nodes a block of rows behind
+//  the lower half -- boundary scores through an LDS ring, a progress counter per wave, no barrier.  Correct, and
+//  slower: 0.47 against 0.37 ms at C3, 1.29 against 0.82 at B = 2048 -- of the ~95 instructions a step costs a
+//  wave, ~55 do not depend on how many nodes a lane owns: addresses, the two DPP shifts, packing, the loop.)
 // Algorithmic bytes per utterance: 4 T C (emissions, once) + T N / 2 (back-pointers out and in) + 20 T (the path).
 // ==========================================================================================
 constexpr int VBLK = 2048;  // floats per staged block (C <= VBLK, C % 4 == 0, 16-byte aligned tensor)

@@ -38,6 +38,27 @@ struct LazyGroupState {
   Graph fixed;                      // keeps G alive
   std::vector<Graph> chains;        // per member
   std::vector<int> member_of;       // output index -> member slot (filled by the caller)
+  // The beta sweep of a dense product whose inputs want gradients, started WITH the alpha sweep on the runtime's
+  // side stream (runtime.h side_launch): beta[t] depends on beta[t+1] and the emissions only, not on alpha, and a
+  // sweep is T dependent launches of ~8 us whatever the batch (profiles/r04_c4_batch_scaling.json: 8.2 ms per pass
+  // with 64 workgroups per step, 8.8 with 256) -- the chip holds both chains' workgroups side by side (120 VGPRs,
+  // 39 KB of LDS: two per CU).  backward() then finds beta done and runs the gradient contractions only.  The
+  // price: 4 (T+1) nb N bytes held from forward to backward like alpha is, and a wasted sweep when the caller never
+  // calls backward on a graph it built with calcGrad = true (GTNX_NO_EAGER_BETA=1 turns it off).
+  struct EagerBeta {
+    DevMemP beta, planes;
+    Runtime* rt = nullptr;
+    Runtime::SideJobP job;
+    ~EagerBeta() {
+      // nobody asked for the gradient: the buffers go back to the pool in engine-stream order, so that stream
+      // has to be behind the side stream's launches first
+      try {
+        if (rt && job) rt->side_join(job);
+      } catch (...) {
+      }
+    }
+  };
+  std::shared_ptr<EagerBeta> eager;
 };
 
 int lazy_lds_limit() { return 150 * 1024; }
@@ -303,6 +324,30 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
       launch_lazy_dense_prep(st.view, const_cast<float*>(st.view.E), const_cast<float*>(st.view.cmax), rt.stream());
       if (st.mfma) {
         launch_lazy_mfma_prep(st.view, rt.stream());
+        {
+          static const bool eager_off = getenv("GTNX_NO_EAGER_BETA") != nullptr || getenv("GTNX_CHAIN") != nullptr;
+          bool wants = st.fixed.calc_grad();
+          for (size_t b = 0; b < st.chains.size() && !wants; ++b) wants = st.chains[b].calc_grad();
+          if (wants && !eager_off && st.view.T >= 1) {
+            auto eb = std::make_shared<LazyGroupState::EagerBeta>();
+            const LazyGroup& sv = st.view;
+            const size_t xf = align_up(size_t(sv.Kpad) * size_t(sv.nbpad), 64);
+            eb->beta = rt.alloc(4 * size_t(sv.nb) * size_t(sv.N) * size_t(sv.T + 1));
+            eb->planes = rt.alloc(8 * xf);
+            eb->rt = &rt;
+            LazyGroup v = sv;  // the sweep's own argument: beta planes and operand planes of its own
+            v.beta = eb->beta->as<float>();
+            v.xt[0] = eb->planes->as<float>();
+            v.xt[1] = v.xt[0] + xf;
+            eb->job = rt.side_launch([v](hipStream_t side) {
+              launch_lazy_init(v, 1, side);
+              launch_lazy_mfma_init(v, 1, side);
+              for (int t = v.T - 1; t >= 0; --t) launch_lazy_mfma_step(v, t, 1, side);
+              launch_lazy_mfma_rowmax(v, 1, side);
+            });
+            st.eager = eb;
+          }
+        }
         launch_lazy_mfma_init(st.view, 0, rt.stream());
         {
           DevMemP sync = rt.alloc_zero(sizeof(int) * lazy_mfma_chain_sync_ints(st.view));
@@ -394,11 +439,16 @@ struct LazySdOp : OpRecord {
       v.delta = reinterpret_cast<const float* const*>(tabs->as<char>());
       v.grad_em = reinterpret_cast<float* const*>(tabs->as<char>(8 * size_t(nb)));
       if (mode == SD_LOG) {
-        DevMemP beta = rt.alloc(4 * plane * size_t(T + 1));
+        DevMemP beta = st.eager ? st.eager->beta : rt.alloc(4 * plane * size_t(T + 1));
         v.beta = beta->as<float>();
         GTNX_PROF("lazy_forward_score_grad", 0.0);
-        launch_lazy_init(v, 1, rt.stream());
-        if (st.dense && st.mfma) {
+        if (st.eager) {
+          rt.side_join(st.eager->job);  // the sweep ran next to the alpha sweep (LazyGroupState::EagerBeta)
+        } else {
+          launch_lazy_init(v, 1, rt.stream());
+        }
+        if (st.eager) {
+        } else if (st.dense && st.mfma) {
           launch_lazy_mfma_init(v, 1, rt.stream());
           {
             DevMemP sync = rt.alloc_zero(sizeof(int) * lazy_mfma_chain_sync_ints(v));

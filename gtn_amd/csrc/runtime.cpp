@@ -4,8 +4,10 @@
 #include <malloc.h>
 
 #include <atomic>
-
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <thread>
 
 namespace gtnx {
 
@@ -143,6 +145,89 @@ void Runtime::set_stream(hipStream_t s) {
   HIP_CHECK(hipStreamWaitEvent(next, ev, 0));
   HIP_CHECK(hipEventDestroy(ev));
   stream_ = next;
+}
+
+// ---- side stream (runtime.h)
+struct Runtime::SideJob {
+  std::function<void(hipStream_t)> fn;
+  hipEvent_t fork = nullptr, done_ev = nullptr;
+  std::exception_ptr err;
+  bool enqueued = false, joined = false;  // under Side::mu
+  ~SideJob() {
+    if (fork) (void)hipEventDestroy(fork);
+    if (done_ev) (void)hipEventDestroy(done_ev);
+  }
+};
+struct Runtime::Side {
+  hipStream_t stream = nullptr;
+  std::mutex mu;
+  std::condition_variable cv_work, cv_done;
+  std::deque<SideJobP> q;
+  std::thread th;
+};
+
+Runtime::SideJobP Runtime::side_launch(std::function<void(hipStream_t)> fn) {
+  if (!side_) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!side_) {
+      Side* sd = new Side();
+      HIP_CHECK(hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking));
+      const int dev = device_;
+      sd->th = std::thread([sd, dev] {
+        (void)hipSetDevice(dev);
+        t_hip_device = dev;
+        t_device = dev;
+        for (;;) {
+          SideJobP job;
+          {
+            std::unique_lock<std::mutex> lk(sd->mu);
+            sd->cv_work.wait(lk, [&] { return !sd->q.empty(); });
+            job = std::move(sd->q.front());
+            sd->q.pop_front();
+          }
+          try {
+            if (hipStreamWaitEvent(sd->stream, job->fork, 0) != hipSuccess) throw_runtime("gtn_amd: side stream: wait failed");
+            job->fn(sd->stream);
+          } catch (...) {
+            job->err = std::current_exception();
+          }
+          (void)hipEventRecord(job->done_ev, sd->stream);  // also after a failure: whatever was queued is waited for
+          job->fn = nullptr;
+          {
+            std::lock_guard<std::mutex> lk(sd->mu);
+            job->enqueued = true;
+          }
+          sd->cv_done.notify_all();
+        }
+      });
+      sd->th.detach();
+      side_ = sd;
+    }
+  }
+  auto job = std::make_shared<SideJob>();
+  job->fn = std::move(fn);
+  HIP_CHECK(hipEventCreateWithFlags(&job->fork, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&job->done_ev, hipEventDisableTiming));
+  HIP_CHECK(hipEventRecord(job->fork, stream_));
+  {
+    std::lock_guard<std::mutex> lk(side_->mu);
+    side_->q.push_back(job);
+  }
+  side_->cv_work.notify_one();
+  return job;
+}
+
+void Runtime::side_join(const SideJobP& job) {
+  if (!job || !side_) return;
+  {
+    std::unique_lock<std::mutex> lk(side_->mu);
+    side_->cv_done.wait(lk, [&] { return job->enqueued; });
+    if (job->joined) return;
+    job->joined = true;
+  }
+  OnDevice on(device_);
+  HIP_CHECK(hipStreamWaitEvent(stream_, job->done_ev, 0));
+  if (job->err) std::rethrow_exception(job->err);
 }
 
 void Runtime::sync() {

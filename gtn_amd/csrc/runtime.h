@@ -9,6 +9,7 @@
 //  * host<->device staging goes through pinned blocks recycled by event.
 #pragma once
 
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -102,6 +103,19 @@ class Runtime {
   void drain_until(void* hip_event);  // reclaim until the event has happened, then wait for it
   void drain_while_busy();
 
+  // ---- a SIDE stream with a host thread of its own to feed it.  For a launch chain that does not depend on what
+  // the engine stream runs meanwhile (the beta sweep of a dense product next to its alpha sweep, ops_lazy.cpp:
+  // a chain of T dependent launches is bound by its latencies -- two of them share the chip -- and the host
+  // enqueues a launch of that argument size in ~7 us, so the second chain needs a second enqueuing thread).
+  // side_launch: `fn(side)` is called on the side thread; its launches are ordered AFTER everything queued on the
+  // engine stream up to this call.  side_join: everything queued on the engine stream from now on is ordered after
+  // the job's launches (the host only waits until they have been enqueued); rethrows what fn threw.  Buffers the
+  // job touches must stay alive until it was joined.
+  struct SideJob;
+  using SideJobP = std::shared_ptr<SideJob>;
+  SideJobP side_launch(std::function<void(hipStream_t)> fn);
+  void side_join(const SideJobP& job);
+
   // copies (async on the engine stream; h2d source must be pinned or outlive sync())
   void h2d(void* dst, const void* src, size_t bytes);
   void d2h_sync(void* dst, const void* src, size_t bytes);  // returns after the data landed
@@ -147,6 +161,8 @@ class Runtime {
   };
   std::vector<ProfRec> prof_recs_;
   std::vector<hipEvent_t> ev_pool_;
+  struct Side;
+  Side* side_ = nullptr;  // made on first use, never destroyed (its thread outlives static destruction)
   std::map<std::string, ProfEntry> prof_;
   friend struct Scope;
 };

@@ -181,3 +181,50 @@ extern "C" __attribute__((visibility("default"))) double gtn_bench_forward_score
     return -1.0;
   }
 }
+
+// BASELINE config C3's shape through the reference's decode: parallelMap over a per-utterance function that builds
+// the target graph and the emission graph and returns viterbiPath(intersect(ctc, emissions)) (functions.cpp:324-330;
+// the loop of benchmarks/ctc.cpp with viterbiPath in place of the loss), reference names only.  `iters` repetitions
+// after 2 of warm-up, each ended by looking at every path (numArcs).  Returns the mean milliseconds per batch
+// (< 0: error); the output labels of the last repetition's paths go to labels_out ([B][T], -1 padded) when given.
+// emissions: DEVICE [B][T][C]; targets: host [B][U].
+extern "C" __attribute__((visibility("default"))) double gtn_bench_viterbi_reference_loop(const void* emissions,
+                                                                                        const int* targets, int B, int T,
+                                                                                        int C, int U, int iters,
+                                                                                        int* labels_out) {
+  try {
+    std::vector<std::vector<int>> tg(static_cast<size_t>(B));
+    std::vector<const float*> scores(static_cast<size_t>(B));
+    for (int b = 0; b < B; ++b) {
+      tg[b].assign(targets + size_t(b) * U, targets + size_t(b + 1) * U);
+      scores[b] = static_cast<const float*>(emissions) + size_t(b) * T * C;
+    }
+    auto decode = [T, C](const std::vector<int>& target, const float* emissionsScore) {
+      Graph ctc = criteria::ctcTargetGraph(target);
+      Graph emissions = linearGraph(T, C);
+      emissions.setWeights(emissionsScore);
+      return viterbiPath(intersect(ctc, emissions));
+    };
+    std::vector<Graph> paths;
+    size_t arcs = 0;
+    auto once = [&]() {
+      paths = parallelMap(decode, tg, scores);
+      for (auto& p : paths) arcs += size_t(p.numArcs());
+    };
+    for (int i = 0; i < 2; ++i) once();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) once();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (labels_out) {
+      for (int b = 0; b < B; ++b) {
+        const int n = int(paths[b].numArcs());
+        for (int t = 0; t < T; ++t) labels_out[size_t(b) * T + t] = t < n ? paths[b].olabel(t) : -1;
+      }
+    }
+    (void)arcs;
+    return std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return -1.0;
+  }
+}

@@ -1181,7 +1181,10 @@ void ensure_schedule_batch(const std::vector<Structure*>& ss, bool need_rank) {
   std::vector<Off> offs(todo.size());
   Packer pk;
   for (size_t i = 0; i < todo.size(); ++i) {
-    build_host_schedule(*todo[i], hs[i], need_rank);
+    {
+      GTNX_HOST_T("schedule.host_queue_replay");
+      build_host_schedule(*todo[i], hs[i], need_rank);
+    }
     HostSched& h = hs[i];
     Off& o = offs[i];
     o.lv = pk.add(4 * h.level_off.size());

@@ -326,6 +326,14 @@ struct BandViterbiScoreOp : OpRecord {
 std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   Runtime& rt = Runtime::get();
   const size_t n = gs.size();
+  GTNX_HOST_T("band_viterbi.total");
+  double t_mark = HostTimer::enabled() ? host_now_ms() : 0.0;
+  auto lap = [&](const char* name) {
+    if (!HostTimer::enabled()) return;
+    const double t = host_now_ms();
+    host_timer_add(name, t - t_mark);
+    t_mark = t;
+  };
   std::vector<BandInfo*> bis;
   std::vector<Structure*> ss;
   std::vector<Weights*> ws;
@@ -349,25 +357,29 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   }
   ensure_band_device_batch(bis, ss);
   ensure_weights_device_batch(ws);
-  // per pair: back-pointers [T][NS] bytes | pnode [T+1] | path arc, label, weight [T] each | len, score, tie
-  size_t bytes = 0;
+  // per pair, device only: back-pointers [T][NS] bytes | pnode [T+1]; and what the host reads (an arena of its own:
+  // a decode copies 12 T + 16 bytes per utterance back, not the back-pointer planes): path arc, label, weight [T]
+  // each | len, score, tie
+  size_t bytes = 0, wbytes = 0;
   std::vector<size_t> o_bp(n), o_pn(n), o_pa(n), o_hd(n);
   int max_c = 1;
   for (size_t i = 0; i < n; ++i) {
     const LazyProduct& lp = *gs[i].s->lazy;
     const size_t T = size_t(lp.chain.s->M), N = size_t(lp.fixed.s->N);
     const size_t ns = size_t(band_row_stride(int(N), band_npl(int(N))));
-    o_bp[i] = bytes;
-    bytes = align_up(bytes + T * ns + 512, 256);
-    o_pn[i] = bytes;
-    bytes = align_up(bytes + 4 * (T + 1), 256);
+    o_bp[i] = wbytes;
+    wbytes = align_up(wbytes + T * ns + 512, 256);
+    o_pn[i] = wbytes;
+    wbytes = align_up(wbytes + 4 * (T + 1), 256);
     o_pa[i] = bytes;
     bytes = align_up(bytes + 12 * (T ? T : 1), 256);
     o_hd[i] = bytes;
     bytes = align_up(bytes + 16, 256);
     max_c = std::max(max_c, lp.chain.s->C);
   }
+  lap("band_viterbi.1_prepare");
   DevMemP arena = rt.alloc(bytes);
+  DevMemP work = rt.alloc(wbytes);
   const int stage_floats = std::max(4096, max_c);
   int max_n = 1, vec = 1;
   double abytes = 0;  // 4TC in, T N / 2 of back-pointers out and in, 20 T of path out
@@ -385,8 +397,8 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     p.T = lp.chain.s->M;
     p.C = lp.chain.s->C;
     p.NS = band_row_stride(p.N, band_npl(p.N));
-    p.bp = arena->as<uint8_t>(o_bp[i]);
-    p.pnode = arena->as<int>(o_pn[i]);
+    p.bp = work->as<uint8_t>(o_bp[i]);
+    p.pnode = work->as<int>(o_pn[i]);
     p.path_arc = arena->as<int>(o_pa[i]);
     p.path_lab = p.path_arc + (p.T ? p.T : 1);
     p.path_w = reinterpret_cast<float*>(p.path_lab + (p.T ? p.T : 1));
@@ -404,7 +416,12 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, max_n, max_c, vec, rt.stream());
   }
   // heads (length, score, tie) of every pair; the paths themselves only when they become graphs
-  std::vector<char> host(bytes);
+  // (a pinned block: the copy into pageable memory ran at a fifth of the link's rate)
+  PinnedMemP host_pin = rt.alloc_pinned(bytes ? bytes : 1);
+  struct HostView {
+    char* p;
+    char* data() const { return p; }
+  } host{host_pin->as<char>()};
   if (want_path) {
     rt.d2h_sync(host.data(), arena->ptr, bytes);
   } else {
@@ -417,6 +434,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     rt.d2h_sync(hh.data(), heads->ptr, 16 * n);
     for (size_t i = 0; i < n; ++i) std::memcpy(host.data() + o_hd[i], hh.data() + 16 * i, 12);
   }
+  lap("band_viterbi.2_launch_and_copy");
   std::vector<Graph> outs(n, Graph(false));
   std::vector<size_t> tied;
   std::shared_ptr<LazyPathOp> pop;
@@ -477,6 +495,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
       outs[i] = std::move(out);
     }
   }
+  lap("band_viterbi.3_outputs");
   if (!tied.empty()) {
     static const bool dbg = std::getenv("GTNX_DEBUG_TIES") != nullptr;
     if (dbg) std::fprintf(stderr, "[gtnx] band_viterbi: %zu of %zu utterances report an exact tie on their best path\n", tied.size(), n);
@@ -487,14 +506,18 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
       // layered product normally gets for free: under exact ties the winner is the arc whose source left
       // the queue first (shortest.cpp:212-227), and that order is not the node-id order.
       realize(gs[i]);
+      lap("band_viterbi.4a_realize");
       gs[i].s->resolve_sizes();
+      lap("band_viterbi.4b_sizes");
       gs[i].s->ensure_full();
       gs[i].s->ensure_host();
+      lap("band_viterbi.4c_host_copy");
       gs[i].s->sched.reset();
       tg.push_back(gs[i]);
     }
     std::vector<Graph> to = want_path ? op_viterbi_path(tg) : op_shortest_distance(tg, true);
     for (size_t k = 0; k < tied.size(); ++k) outs[tied[k]] = std::move(to[k]);
+    lap("band_viterbi.4d_rerun_op");
   }
   return outs;
 }

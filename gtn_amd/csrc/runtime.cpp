@@ -580,6 +580,7 @@ double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 } // namespace
+double host_now_ms() { return now_ms(); }
 bool HostTimer::enabled() {
   static const bool e = std::getenv("GTNX_HOST_TIMING") != nullptr;
   return e;

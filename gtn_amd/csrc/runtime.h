@@ -177,6 +177,7 @@ struct HostTimer {
   ~HostTimer();
   static bool enabled();
 };
+double host_now_ms();
 void host_timer_add(const char* name, double ms);  // one sample for the GTNX_HOST_TIMING table
 #define GTNX_HT_CAT2(a, b) a##b
 #define GTNX_HT_CAT(a, b) GTNX_HT_CAT2(a, b)

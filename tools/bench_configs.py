@@ -231,6 +231,26 @@ def c3v():
     out["value"] = B / (ms_path * 1e-3)
     out["unit"] = "utterances/s"
     out["roofline"] = roof
+    # the decode as the reference writes it: parallelMap over a per-utterance function returning
+    # viterbiPath(intersect(ctc, emissions)), C++ host (bench_native/ctc_step.cpp: gtn_bench_viterbi_reference_loop)
+    try:
+        import ctypes as C
+        native = C.CDLL(os.path.join(ROOT, "bench_native", "libgtn_bench.so"))
+        native.gtn_bench_viterbi_reference_loop.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]
+        native.gtn_bench_viterbi_reference_loop.restype = C.c_double
+        tgc = np.ascontiguousarray(tg, dtype=np.int32)
+        lab = np.full((B, T), -1, np.int32)
+        ms_loop = native.gtn_bench_viterbi_reference_loop(em_dev.data_ptr(), tgc.ctypes.data, B, T, Cn, U, 10, lab.ctypes.data)
+        if ms_loop > 0:
+            same = all([int(x) for x in lab[b] if x >= 0] == [int(x) for x in paths[b].labels_to_list(False)] for b in range(8))
+            out["reference_api"] = {"viterbi_path_ms_per_batch": ms_loop, "utterances_per_s": B / (ms_loop * 1e-3),
+                                    "host": "C++: parallelMap over viterbiPath(intersect(ctcGraph, linearGraph + setWeights)) per "
+                                            "utterance, every path looked at (bench_native/ctc_step.cpp)",
+                                    "labels_equal_python_route": bool(same)}
+            out["value"] = B / (ms_loop * 1e-3)
+            out["value_source"] = "reference_api (C++ host); the Python mirror's figure is symbolic_route.viterbi_path_ms_per_batch"
+    except Exception as e:
+        out["reference_api"] = {"error": str(e)[:200]}
     # the built route on a slice of the batch (13 GB of lattices at B = 512; 64 utterances say the same per launch)
     nb = min(B, 64)
     sub_c, sub_e = ctcs[:nb], ems[:nb]

@@ -288,11 +288,11 @@ def dry_run(args, dist, torch, world, rank, dev):
     from gtn_amd.distributed import max_over_ranks
     B = args.batch
     loss_dev = torch.full((B,), float(rank), dtype=torch.float32)
-    gathered = [torch.empty(B, dtype=torch.float32) for _ in range(world)] if world > 1 else None
+    gathered = torch.empty(world * B, dtype=torch.float32) if world > 1 else None
 
     def step():
         if world > 1:
-            dist.all_gather(gathered, loss_dev)
+            dist.all_gather_into_tensor(gathered, loss_dev)
 
     def fence():
         if world > 1:
@@ -309,7 +309,7 @@ def dry_run(args, dist, torch, world, rank, dev):
     dt = max_over_ranks(dt_local, dev)
     ranks = per_rank_report(dist, torch, world, dev, {}, dt_local)
     if rank == 0:
-        ok = gathered is None or all(float(g[0]) == float(r) for r, g in enumerate(gathered))
+        ok = gathered is None or all(float(gathered[r * B]) == float(r) for r in range(world))
         print(json.dumps({"metric": "CTC forward+backward losses/sec (T=%d, C=%d)" % (args.T, args.C), "value": None,
                           "unit": "losses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -390,7 +390,9 @@ def main():
     with torch.cuda.stream(stream):
         em_dev = torch.from_numpy(em).to(dev)
         loss_dev = torch.empty(B, dtype=torch.float32, device=dev)
-        gathered = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(world)] if world_dist else None
+        # ONE flat [world * B] tensor: all_gather_into_tensor writes the ranks' blocks in place (the list form of
+        # all_gather copies world tensors around the collective, host work on every step)
+        gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if world_dist else None
 
     native = None
     if not args.python_host:
@@ -412,7 +414,7 @@ def main():
                 native.gtn_bench_last_error.restype = C.c_char_p
                 raise RuntimeError("native step failed: " + native.gtn_bench_last_error().decode())
             if world_dist:
-                dist.all_gather(gathered, loss_dev)
+                dist.all_gather_into_tensor(gathered, loss_dev)
         return None
 
     def vector_step():
@@ -434,7 +436,7 @@ def main():
             gtn.backward(loss)
             gtn.items_to_device(loss, loss_dev)
             if world_dist:
-                dist.all_gather(gathered, loss_dev)
+                dist.all_gather_into_tensor(gathered, loss_dev)
         return ems, comp
 
     def fence():

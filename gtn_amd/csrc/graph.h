@@ -287,6 +287,9 @@ struct GradState {
   float* lazy_ptr = nullptr;
   std::atomic<int> n_consumers{0};  // op outputs that list this graph as an input (two threads may reclaim at once)
   bool grad_propagated = false;  // the consumer already pushed this grad into our inputs
+  // ops.cpp through_delta: the sum of this graph's gradient over the backward passes made with retainGraph -- what the
+  // gradient of a SYMBOLIC product feeding it would have accumulated to (autograd.cpp:40-52 adds to it in every pass)
+  DevMemP through_acc;
   // gtnx_grads_bind_device_n: caller-owned device memory the FIRST gradient of this graph is to be
   // written to (the emission-gradient tensor of a criterion); kernels that can store there directly do
   DevMemP grad_dest_mem;

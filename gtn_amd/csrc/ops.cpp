@@ -117,6 +117,19 @@ float* grad_dev_ptr(Graph& out) {
   return gr.w->dev;
 }
 
+thread_local bool t_backward_retain = false;
+float* through_delta(Graph& out) {
+  float* d = grad_dev_ptr(out);
+  GradState& gs = *out.g;
+  if (!gs.through_acc && !t_backward_retain) return d;  // no earlier pass, no later one: this pass's gradient is all there is
+  Runtime& rt = Runtime::get();
+  const size_t n = size_t(out.num_arcs());
+  if (!gs.through_acc) gs.through_acc = rt.alloc_zero(sizeof(float) * (n ? n : 1));
+  float* acc = gs.through_acc->as<float>();
+  launch_vec_axpby(acc, d, nullptr, n, 1.0f, 0.0f, /*accumulate=*/1, rt.stream());
+  return acc;
+}
+
 // ======================================================================
 // GradSink
 // ======================================================================
@@ -487,6 +500,11 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
   // with the seed added; region.cpp validates the roots of a gathered backward beforehand)
   Tape tape;
   collect_tape(roots, tape);
+  struct RetainScope {
+    bool prev;
+    explicit RetainScope(bool r) : prev(t_backward_retain) { t_backward_retain = r; }
+    ~RetainScope() { t_backward_retain = prev; }
+  } retain_scope(retain);
   // ---- reverse sweep: creation order is a topological order
   ChainGradPlan plan;
   struct PlanScope {

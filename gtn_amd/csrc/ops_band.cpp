@@ -109,7 +109,7 @@ struct BandSdOp : OpRecord {
     for (size_t k = 0; k < ms.size(); ++k) {
       const int i = ms[k].idx;
       BandPair p = pairs[i];
-      p.delta = grad_dev_ptr(ms[k].out);
+      p.delta = through_delta(ms[k].out);
       p.delta_norm = nullptr;
       p.grad_em = chains[i].calc_grad() ? (dest[k] ? dest[k] : gem->as<float>(eo[k])) : nullptr;
       p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
@@ -306,7 +306,7 @@ struct BandViterbiScoreOp : OpRecord {
       if (!bytes) continue;
       DevMemP gm = rt.alloc_zero(bytes);
       LazyPathGrad a{};
-      a.delta = grad_dev_ptr(m.out);
+      a.delta = through_delta(m.out);
       a.delta_stride = 0;
       a.path_arc = sv.arc;
       a.il = a.ol = sv.lab;  // the matched label either way

@@ -46,6 +46,13 @@ void set_dev_weights(Graph& g, const DevMemP& owner, float* ptr, int64_t n);
 void ensure_records(Structure& st);
 const gtnx_i4* sorted_view(Structure& st, bool key_ol, bool in_lists);
 float* grad_dev_ptr(Graph& out);
+// The delta an op uses when it pushes its gradient PAST its input into that input's inputs (the input is a symbolic
+// product: it has no gradient of its own).  In the reference the product's gradient accumulates over backward passes
+// (backward(g, retainGraph = true) twice: the root holds 1, then 2; the product 1 P, then 3 P; its inputs get 4 x the
+// single-pass gradient), so from the second pass on the multiplier is the SUM of the output's gradients over the
+// passes, not the current one.  Single pass (every criterion step): grad_dev_ptr(out), nothing else happens.
+float* through_delta(Graph& out);
+extern thread_local bool t_backward_retain;  // the backward pass being run keeps the graph (op_backward)
 
 // ---- gradient launches of one backward() over the same emission chains, gathered before they go:
 // forwardScore(emissions) contributes dn * softmax(row), forwardScore(target o emissions) the node

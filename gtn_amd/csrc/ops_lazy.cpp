@@ -417,7 +417,7 @@ struct LazySdOp : OpRecord {
       for (Member* m : by_group[gi]) of_slot[slot[m->idx].second] = m;
       for (int b = 0; b < nb; ++b) {
         if (!of_slot[b]) continue;
-        delta[b] = grad_dev_ptr(of_slot[b]->out);
+        delta[b] = through_delta(of_slot[b]->out);
         if (st.chains[b].calc_grad()) {
           goff[b] = gbytes;
           gbytes = align_up(gbytes + 4 * size_t(T) * size_t(C), 256);
@@ -622,7 +622,7 @@ struct LazyPairSdOp : OpRecord {
     for (size_t k = 0; k < ms.size(); ++k) {
       const int i = ms[k].idx;
       LazyPair p = pairs[i];
-      p.delta = grad_dev_ptr(ms[k].out);
+      p.delta = through_delta(ms[k].out);
       p.grad_em = chains[i].calc_grad() ? (dest[k] ? dest[k] : gem->as<float>(eo[k])) : nullptr;
       p.grad_fixed = fixed[i].calc_grad() ? gfx->as<float>(fo[k]) : nullptr;
       tab.push_back(p);
@@ -722,7 +722,7 @@ void LazyPathOp::backward(std::vector<Member>& ms) {
       if (fixed.calc_grad()) bytes = align_up(bytes + 4 * size_t(fixed.num_arcs()), 256);
       DevMemP gm = rt.alloc_zero(bytes ? bytes : 1);
       LazyPathGrad a{};
-      a.delta = grad_dev_ptr(m.out);
+      a.delta = through_delta(m.out);
       a.delta_stride = 1;
       a.path_arc = dp->as<int>();
       a.il = a.path_arc + len;

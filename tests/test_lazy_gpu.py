@@ -1072,3 +1072,82 @@ def test_default_policy_keeps_host_built_targets_symbolic(gtn):
         assert gtn.debug_symbolic_route(gtn.intersect(gtn.intersect(gg.to_api(gtn, tgt), bigram), e)) is None
     finally:
         gtn.compose_mode(old)
+
+
+def test_dense_regime_beta_sweep_beside_the_alpha_sweep_life_cycle(gtn):
+    """The backward sweep of a dense product starts with its forward sweep on a second stream (ops_lazy.cpp:
+    LazyGroupState::EagerBeta).  What must hold whatever the caller does next: a forwardScore that is never
+    differentiated can be dropped while the sweep may still be running; backward with retain_graph twice accumulates
+    like the reference (autograd.cpp:40-67: the root holds 1, then 2; the product's gradient 1 P, then 3 P; its
+    inputs FOUR times the gradient of one backward -- ops.cpp through_delta keeps that sum for a product that has no
+    gradient of its own); and two products in flight at once do not share sweep buffers."""
+    import torch
+    B, C, T = 2, 64, 9
+    rng = np.random.default_rng(11)
+    em = rng.normal(0, 2, (B, T, C)).astype(np.float32)
+    tw = rng.normal(0, 1, C * C + C).astype(np.float32)
+    n = np.arange(C)
+
+    def transitions():
+        g = gtn.Graph()
+        g.add_nodes(np.array([1] + [0] * C, np.uint8), np.array([0] + [1] * C, np.uint8))
+        g.add_arcs(np.concatenate([np.zeros(C, np.int32), np.tile(n + 1, C)]).astype(np.int32),
+                   np.concatenate([n + 1, np.repeat(n + 1, C)]).astype(np.int32),
+                   np.concatenate([n, np.repeat(n, C)]).astype(np.int32), None, tw)
+        return g
+
+    with lazy_mode("1"):
+        def product():
+            tr = transitions()
+            ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+            fs = gtn.forward_score(gtn.compose(ems, [tr]))
+            return tr, ems, fs
+        # dropped without a backward, twice in a row (the second reuses the first's pool blocks)
+        for _ in range(2):
+            tr, ems, fs = product()
+            first = gtn.items(fs)
+            del tr, ems, fs
+        # one backward
+        tr1, ems1, fs1 = product()
+        assert gtn.items(fs1) == pytest.approx(first, rel=1e-6)
+        gtn.backward(fs1)
+        g1 = tr1.grad().weights_to_numpy().copy()
+        e1 = ems1[0].grad().weights_to_numpy().copy()
+        # two products in flight, the second differentiated twice with the graph retained
+        tr2, ems2, fs2 = product()
+        tr3, ems3, fs3 = product()
+        gtn.backward(fs3, retain_graph=True)
+        gtn.backward(fs3, retain_graph=True)
+        gtn.backward(fs2)
+        assert np.abs(tr2.grad().weights_to_numpy() - g1).max() <= 1e-5
+        assert np.abs(ems2[0].grad().weights_to_numpy() - e1).max() <= 1e-6
+        assert np.abs(tr3.grad().weights_to_numpy() - 4 * g1).max() <= 4e-5
+        assert np.abs(ems3[0].grad().weights_to_numpy() - 4 * e1).max() <= 4e-6
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_backward_twice_with_retain_graph_through_a_ctc_product(gtn, mode):
+    """backward(loss, retain_graph=True) twice on forwardScore(intersect(ctc, emissions)): the reference accumulates
+    the product's gradient over the passes (autograd.cpp:40-67), so the emissions and the target get 4 x the
+    single-pass gradient -- on the built lattice (mode 0: the compose gradient fused into forwardScore's backward)
+    and on the symbolic product (mode 2: band sweeps) alike."""
+    import torch
+    import graphgen as gg
+    T, C, U = 40, 12, 6
+    em, tg = gg.ctc_inputs(5, 1, T, C, U)
+
+    def loss_and_inputs():
+        ctc = gg.to_api(gtn, gg.ctc_target_graph(tg[0].tolist()))
+        ctc.arc_sort()
+        e = gtn.linear_graph_n(1, T, C, torch.from_numpy(em).cuda())[0]
+        return ctc, e, gtn.forward_score(gtn.intersect(ctc, e))
+
+    with lazy_mode(mode):
+        c1, e1, l1 = loss_and_inputs()
+        gtn.backward(l1)
+        ge, gc = e1.grad().weights_to_numpy().copy(), c1.grad().weights_to_numpy().copy()
+        c2, e2, l2 = loss_and_inputs()
+        gtn.backward(l2, retain_graph=True)
+        gtn.backward(l2, retain_graph=True)
+        assert np.abs(e2.grad().weights_to_numpy() - 4 * ge).max() <= 1e-4
+        assert np.abs(c2.grad().weights_to_numpy() - 4 * gc).max() <= 1e-4

@@ -512,10 +512,23 @@ def main():
         "intersect": "compose_kernel<3, false, true, true, true, 256>",
     }
     import glob
-    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3_pmc_hbm.json")))
-    pmc = json.load(open(pmcs[-1])) if pmcs and (B, T, Cn, U) == (512, 1000, 256, 100) else {}
 
-    def rooflines(pr):
+    def newest_pmc(tag):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_hbm.json" % tag)))
+        return (json.load(open(files[-1])), files[-1]) if files else ({}, None)
+
+    # the committed counter passes per workload: the timed loop at C3, the built-lattice step at B = 512 (its
+    # compose / forwardScore / fused-backward launches), the C5-shaped launches (tools/profile_round4.sh)
+    if (B, T, Cn, U) == (512, 1000, 256, 100):
+        pmc, pmc_file = newest_pmc("c3")
+        pmc_built, pmc_built_file = newest_pmc("built")
+    elif (B, T, Cn, U) == (512, 2000, 1024, 200):
+        pmc, pmc_file = newest_pmc("c5")
+        pmc_built, pmc_built_file = {}, None
+    else:
+        pmc, pmc_file, pmc_built, pmc_built_file = {}, None, {}, None
+
+    def rooflines(pr, pmc=pmc, pmc_file=pmc_file):
         fixed = {"linear_forward": B * 4.0 * T * Cn, "linear_forward_grad": B * 12.0 * T * Cn,
                  "intersect": B * (20.0 * n_arcs + 8.0 * n_nodes),
                  "forward_score_grad": B * (20.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}
@@ -534,8 +547,8 @@ def main():
             # fetched KiB on gfx950, WRITE_SIZE is exact (profiles/README.md)
             traffic = (2 * k["FETCH_SIZE"]["mean_per_launch"] + k["WRITE_SIZE"]["mean_per_launch"]) * 1024 if k else None
             # (NOT measured by this run: read from the committed PMC passes of the same command and kernel)
-            src = ("profiles/" + os.path.basename(pmcs[-1]) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                   "`python bench.py`, tools/profile_gpu.sh; 2*FETCH_SIZE + WRITE_SIZE KiB per launch)") if k else None
+            src = ("profiles/" + os.path.basename(pmc_file) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                   "`python bench.py`, tools/profile_gpu.sh / tools/profile_round4.sh; 2*FETCH_SIZE + WRITE_SIZE KiB per launch)") if k else None
             gbs = per / (ms * 1e-3) / 1e9
             out[name] = {"bound": "hbm", "kernel": KERNEL_OF[name], "achieved": gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": ms,
@@ -572,7 +585,7 @@ def main():
                     gdiff = float((grad_dev - grad_timed).abs().max().item())
             except Exception:  # a diagnostic must not cost the bench line
                 gdiff = None
-            built = {"ms_per_step": dt_built * 1e3, "losses_per_s": B / dt_built, "roofline": rooflines(pb),
+            built = {"ms_per_step": dt_built * 1e3, "losses_per_s": B / dt_built, "roofline": rooflines(pb, pmc_built or pmc, pmc_built_file or pmc_file),
                      "loss_mean": float(np.mean(lb)),
                      # the two paths on the same batch: largest relative difference of a per-utterance loss
                      "max_rel_diff_vs_timed_path": float(np.max(np.abs(lb - losses_timed) / np.maximum(np.abs(lb), 1e-30))),

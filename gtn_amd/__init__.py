@@ -63,6 +63,7 @@ prof_get = _api.prof_get
 prof_names = _api.prof_names
 debug_symbolic_route = _api.debug_symbolic_route
 debug_viterbi_ties = _api.debug_viterbi_ties
+debug_tie_ranks = _api.debug_tie_ranks
 
 
 def load_txt(text):

@@ -144,6 +144,7 @@ _SIGS = {
     "gtnx_debug_symbolic_route": [c_graph, C.c_int, c_i32_p],
     "gtnx_debug_route_name": [C.c_int, C.c_char_p, C.c_size_t],
     "gtnx_debug_viterbi_ties": [c_i64_p, c_i64_p],
+    "gtnx_debug_tie_ranks": [c_graph, C.c_void_p, C.c_void_p, C.c_void_p],
     "gtnx_comm_create": [c_i32_p, C.c_int, C.POINTER(C.c_void_p)],
     "gtnx_comm_destroy": [C.c_void_p],
     "gtnx_comm_size": [C.c_void_p, c_i32_p],

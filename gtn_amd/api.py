@@ -824,6 +824,16 @@ def make_api(lib):
 
     ns.debug_symbolic_route = debug_symbolic_route
     ns.debug_viterbi_ties = debug_viterbi_ties
+
+    def debug_tie_ranks(g):
+        """(queue_rank, creation_rank) of a CTC-shaped target's nodes, or None (gtn_amd.h: gtnx_debug_tie_ranks)"""
+        n = g.num_nodes()
+        k, c = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        ok = C.c_int()
+        check(lib.gtnx_debug_tie_ranks(g._h, k.ctypes.data, c.ctypes.data, C.byref(ok)))
+        return (k.tolist(), c.tolist()) if ok.value else None
+
+    ns.debug_tie_ranks = debug_tie_ranks
     ns.backend = backend
     ns.device_count = device_count
     ns.synchronize = synchronize

@@ -1418,7 +1418,11 @@ __global__ __launch_bounds__(512) void band_viterbi_kernel(const BandDecode* __r
 // ==========================================================================================
 constexpr int VBLK = 2048;  // floats per staged block (C <= VBLK, C % 4 == 0, 16-byte aligned tensor)
 
-template <int NPL>
+// RANKED (a second launch over the utterances whose first pass met an exact tie on the best path, when their target
+// is CTC-shaped: ops_band.cpp tie_ranks): equal candidates are decided by the rank of their source node -- the
+// position the reference's queue (viterbiPath) or its compose (viterbiScore's in-lists, the accept list) gives that
+// node in every layer of the lattice -- so the answer is the reference's without building the lattice.
+template <int NPL, bool RANKED>
 __global__ __launch_bounds__(64) void band_viterbi_wave_kernel(const BandDecode* __restrict__ pairs) {
   const BandDecode P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, N = P.N;
@@ -1455,6 +1459,16 @@ __global__ __launch_bounds__(64) void band_viterbi_wave_kernel(const BandDecode*
     settle(w1[j]);
     settle(w2[j]);
     settle(loff[j]);
+  }
+  int r0[NPL], r1[NPL], r2[NPL];  // RANKED: ranks of the three source nodes of every node of this lane
+  if (RANKED) {
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int m = lane * NPL + j;
+      r0[j] = m < N ? P.rank_in[m] : 0x7ffffffe;
+      r1[j] = (m >= 1 && m - 1 < N) ? P.rank_in[m - 1] : 0x7ffffffe;
+      r2[j] = (m >= 2 && m - 2 < N) ? P.rank_in[m - 2] : 0x7ffffffe;
+    }
   }
   const int R = max(1, VBLK / C);  // rows per block
   const int NB = (T + R - 1) / R;
@@ -1518,9 +1532,18 @@ __global__ __launch_bounds__(64) void band_viterbi_wave_kernel(const BandDecode*
         const float c0 = alpha[j] + (w0[j] + e[j]), c1 = p1 + (w1[j] + e[j]), c2 = p2 + (w2[j] + e[j]);
         const float best = fmaxf(fmaxf(c0, c1), c2);
         const float med = __builtin_amdgcn_fmed3f(c0, c1, c2);
-        // first maximum in the order own node, node - 1, node - 2 (as the kernel above); two equal maxima: code 3
-        unsigned k = c0 == best ? 0u : (c1 == best ? 1u : 2u);
-        k = med == best ? 3u : k;  // (all -inf: 3 as well -- the best path never comes through a dead node)
+        unsigned k;
+        if (RANKED) {  // of the candidates that reach the maximum, the one from the source with the smallest rank
+          const int q0 = c0 == best ? r0[j] : 0x7fffffff, q1 = c1 == best ? r1[j] : 0x7fffffff,
+                    q2 = c2 == best ? r2[j] : 0x7fffffff;
+          k = (q0 <= q1 && q0 <= q2) ? 0u : (q1 <= q2 ? 1u : 2u);
+          k = best == NINF ? 3u : k;
+          (void)med;
+        } else {
+          // first maximum in the order own node, node - 1, node - 2 (as the kernel above); two equal maxima: code 3
+          k = c0 == best ? 0u : (c1 == best ? 1u : 2u);
+          k = med == best ? 3u : k;  // (all -inf: 3 as well -- the best path never comes through a dead node)
+        }
         codes |= k << (2 * j);
         na[j] = best;
       }
@@ -1545,15 +1568,17 @@ __global__ __launch_bounds__(64) void band_viterbi_wave_kernel(const BandDecode*
 #pragma unroll
   for (int j = NPL - 1; j >= 0; --j)
     if (acc[j] && alpha[j] == wmx && wmx > NINF) {
-      bm = lane * NPL + j;
+      const int m = lane * NPL + j;
+      // RANKED: (rank in the accept list, node) -- N <= 512 and the ranks are below N
+      bm = RANKED ? min(bm, (P.rank_acc[m] << 16) | m) : m;
       ++cnt;
     }
   for (int o = 32; o > 0; o >>= 1) {
     bm = min(bm, __shfl_xor(bm, o));
     cnt += __shfl_xor(cnt, o);
   }
-  int tie = cnt > 1 ? 1 : 0;  // (uniform)
-  const int best = bm == (1 << 30) ? -1 : bm;
+  int tie = (cnt > 1 && !RANKED) ? 1 : 0;  // (uniform)
+  const int best = bm == (1 << 30) ? -1 : (RANKED ? (bm & 0xffff) : bm);
   if (lane == 0) {
     P.score[0] = best >= 0 ? wmx : NINF;
     P.path_len[0] = best >= 0 ? T : -1;
@@ -1790,20 +1815,25 @@ void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int ma
 // <= 2048 labels
 // (GTNX_VITERBI_WG=1: the workgroup-per-utterance kernel, kept for wider shapes and for comparison).
 template <int NPL>
-static void launch_viterbi_wave(const BandDecode* d_pairs, int n, hipStream_t st) {
-  hipLaunchKernelGGL((band_viterbi_wave_kernel<NPL>), dim3(n), dim3(64), 0, st, d_pairs);
+static void launch_viterbi_wave(const BandDecode* d_pairs, int n, int ranked, hipStream_t st) {
+  if (ranked) hipLaunchKernelGGL((band_viterbi_wave_kernel<NPL, true>), dim3(n), dim3(64), 0, st, d_pairs);
+  else hipLaunchKernelGGL((band_viterbi_wave_kernel<NPL, false>), dim3(n), dim3(64), 0, st, d_pairs);
+}
+bool band_viterbi_wave_ok(int max_nodes, int max_labels, int vec) {
+  static const bool force_wg = std::getenv("GTNX_VITERBI_WG") != nullptr;
+  return !force_wg && vec && max_nodes <= 512 && max_labels <= VBLK;
 }
 void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, int max_nodes, int max_labels, int vec,
-                         hipStream_t st) {
+                         hipStream_t st, int ranked) {
   if (n <= 0) return;
-  static const bool force_wg = std::getenv("GTNX_VITERBI_WG") != nullptr;
-  if (!force_wg && vec && max_nodes <= 512 && max_labels <= VBLK) {
-    if (max_nodes <= 64) launch_viterbi_wave<1>(d_pairs, n, st);
-    else if (max_nodes <= 128) launch_viterbi_wave<2>(d_pairs, n, st);
-    else if (max_nodes <= 256) launch_viterbi_wave<4>(d_pairs, n, st);
-    else launch_viterbi_wave<8>(d_pairs, n, st);
+  if (band_viterbi_wave_ok(max_nodes, max_labels, vec)) {
+    if (max_nodes <= 64) launch_viterbi_wave<1>(d_pairs, n, ranked, st);
+    else if (max_nodes <= 128) launch_viterbi_wave<2>(d_pairs, n, ranked, st);
+    else if (max_nodes <= 256) launch_viterbi_wave<4>(d_pairs, n, ranked, st);
+    else launch_viterbi_wave<8>(d_pairs, n, ranked, st);
     return;
   }
+  if (ranked) return;  // (callers ask band_viterbi_wave_ok first)
   static std::atomic<uint64_t> done{0};
   if (gtnx_first_on_device(done)) big_lds(band_viterbi_kernel);
   hipLaunchKernelGGL(band_viterbi_kernel, dim3(n), dim3(512), 4 * size_t(1032 + stage_floats) + 64, st, d_pairs);

@@ -214,6 +214,17 @@ GTNX_API gtnx_status_t gtnx_debug_viterbi_ties(int64_t* seen, int64_t* unresolve
     if (unresolved) *unresolved = g_viterbi_ties_unresolved.load();
   });
 }
+GTNX_API gtnx_status_t gtnx_debug_tie_ranks(gtnx_graph_t g, int* queue_rank, int* creation_rank, int* applies) {
+  return guard([&] {
+    Graph& x = GL(g);
+    const std::vector<int>*k = nullptr, *c = nullptr;
+    const bool ok = x.s->kind == KIND_EXPLICIT && !x.s->lazy && ctc_tie_ranks(*x.s, true, &k, &c);
+    if (applies) *applies = ok ? 1 : 0;
+    if (!ok) return;
+    if (queue_rank) std::copy(k->begin(), k->end(), queue_rank);
+    if (creation_rank) std::copy(c->begin(), c->end(), creation_rank);
+  });
+}
 GTNX_API gtnx_status_t gtnx_empty_cache(void) {
   return guard([&] {
     if (Runtime::initialized()) Runtime::get().empty_cache();

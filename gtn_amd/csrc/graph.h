@@ -225,9 +225,15 @@ struct BandInfo {
   const uint8_t* dev_flags = nullptr;
   const int* dev_snode = nullptr;
   const int* dev_slab = nullptr;
+  // ops_band.cpp tie_ranks (CTC-shaped graphs): 0 not computed, 1 there, -1 does not apply
+  int rank_state = 0;
+  std::vector<int> rank_kahn, rank_create;
 };
 std::shared_ptr<BandInfo> band_info(Structure& s, bool use_ilabel);   // host part, cached
 void detect_ctc_shape(Structure& s);                                  // fills Structure::ctc_labels; cached
+// ops_band.cpp: the reference's queue order and creation order of a CTC-shaped target's nodes (how exact ties of its
+// products are decided without the lattice); false: does not apply to this graph.  Cached in the graph's BandInfo.
+bool ctc_tie_ranks(Structure& s, bool use_ilabel, const std::vector<int>** kahn, const std::vector<int>** create);
 void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vector<Structure*>& ss);
 
 struct GradState;

@@ -498,11 +498,18 @@ struct BandDecode {
   GTNX_G int* path_len;          // [1] T, or -1 when no accepting path exists
   GTNX_G float* score;           // [1]
   GTNX_G int* tie;               // [1] an exact tie between finite candidates was seen
+  // ranked launches only (exact ties of CTC-shaped targets decided without the lattice, ops_band.cpp tie_ranks):
+  // of two equal candidates the one whose SOURCE node has the smaller rank_in wins, of two equal accept nodes the
+  // one with the smaller rank_acc
+  const GTNX_G int* rank_in;     // [N]
+  const GTNX_G int* rank_acc;    // [N]
   int N, T, C, NS;
   int stage_floats, pad;         // LDS staging area of the launch (floats)
 };
+// ranked != 0: band_viterbi_wave_kernel's RANKED variant (needs the shapes the wave kernel takes: vec, C <= 2048)
 void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, int max_nodes, int max_labels, int vec,
-                         hipStream_t st);
+                         hipStream_t st, int ranked = 0);
+bool band_viterbi_wave_ok(int max_nodes, int max_labels, int vec);
 // ---------------------------------------------------------------------------
 // rational.hip: clone / concat / closure / union_ (functions.cpp:66-223) built on the device
 // ---------------------------------------------------------------------------

@@ -323,6 +323,80 @@ struct BandViterbiScoreOp : OpRecord {
   }
 };
 
+// ---- exact ties without the lattice (CTC-shaped targets) --------------------------------------------------------
+// When two candidates into a node of the product are EQUAL, the reference's answer depends on orders its own data
+// structures define: viterbiPath keeps the arc relaxed first, i.e. whose source node left its queue first
+// (shortest.cpp:208-224: strictly greater replaces); viterbiScore's gradient keeps the first maximum in the node's
+// in-list (shortest.cpp:118-127), i.e. the arc compose created first; both take the first best node of accept()
+// (:233-244, :148-160), i.e. the accept node compose created first.  For the product of an emission chain with a
+// CTC target acceptor both orders are, in EVERY layer of the lattice, the restriction of one fixed order of the
+// target's nodes to the nodes alive in that layer (pruning by co-reachability does not disturb it), and that order
+// is the fixed point of a recursion over the target graph alone:
+//   queue order     a node enters the next layer when the LAST of its sources (in this layer's order, then in the
+//                   source's out-list order) is processed            (in-degree reaches zero: shortest.cpp:221-223)
+//   creation order  ... when the FIRST of them is                    (first discovery: compose.cpp's queue)
+// -- checked against the unmodified reference's lattices (queue replayed on them, node ids read off them) for 1 680
+// random targets with repeated labels, any blank, T down to the shortest feasible, both argument orders
+// (tests/test_band_tie_ranks.py runs a committed sample of that on the CPU).  The out-list order of a product node
+// is the target node's, provided its out-lists are strictly increasing in the matched label (arcSort'ed target:
+// every matcher of compose.cpp then emits in label order); otherwise -- and for any target that is not exactly
+// ctcGraph(labels) -- the tied utterance takes the built lattice as before.
+static bool layer_order(const Structure& s, int start, bool last_touch, std::vector<int>& rank) {
+  const int N = int(s.N);
+  std::vector<int> layer{start}, next;
+  std::vector<long long> key(size_t(N), -1);
+  bool fixed = false;
+  for (int it = 0; it < 4 * N + 8 && !fixed; ++it) {
+    std::fill(key.begin(), key.end(), -1);
+    for (size_t i = 0; i < layer.size(); ++i) {
+      const int l = layer[i];
+      for (int k = s.out_off[size_t(l)]; k < s.out_off[size_t(l) + 1]; ++k) {
+        const int d = s.dst[size_t(s.out_list[size_t(k)])];
+        const long long kk = (long long)(i) * 8 + (k - s.out_off[size_t(l)]);
+        long long& slot = key[size_t(d)];
+        slot = slot < 0 ? kk : (last_touch ? std::max(slot, kk) : std::min(slot, kk));
+      }
+    }
+    next.clear();
+    for (int d = 0; d < N; ++d)
+      if (key[size_t(d)] >= 0) next.push_back(d);
+    std::sort(next.begin(), next.end(), [&](int a, int b) { return key[size_t(a)] < key[size_t(b)]; });
+    fixed = next == layer;
+    layer.swap(next);
+  }
+  if (!fixed || int(layer.size()) != N) return false;
+  rank.assign(size_t(N), 0);
+  for (int i = 0; i < N; ++i) rank[size_t(layer[size_t(i)])] = i;
+  return true;
+}
+
+static bool tie_ranks(Structure& fs, BandInfo& bi, bool use_ilabel) {
+  if (bi.rank_state) return bi.rank_state > 0;
+  bi.rank_state = -1;
+  fs.ensure_host();
+  detect_ctc_shape(fs);
+  if (!fs.ctc_labels || fs.N > 512) return false;
+  fs.ensure_csr();
+  const std::vector<int>& lab = use_ilabel ? fs.il : fs.ol;
+  for (int64_t n = 0; n < fs.N; ++n) {
+    if (fs.out_off[size_t(n) + 1] - fs.out_off[size_t(n)] > 8) return false;
+    for (int k = fs.out_off[size_t(n)] + 1; k < fs.out_off[size_t(n) + 1]; ++k)
+      if (lab[size_t(fs.out_list[size_t(k)])] <= lab[size_t(fs.out_list[size_t(k) - 1])]) return false;
+  }
+  if (!layer_order(fs, 0, /*last_touch=*/true, bi.rank_kahn) || !layer_order(fs, 0, /*last_touch=*/false, bi.rank_create))
+    return false;
+  bi.rank_state = 1;
+  return true;
+}
+
+bool ctc_tie_ranks(Structure& s, bool use_ilabel, const std::vector<int>** kahn, const std::vector<int>** create) {
+  std::shared_ptr<BandInfo> bi = band_info(s, use_ilabel);
+  if (!bi || !bi->ok || !tie_ranks(s, *bi, use_ilabel)) return false;
+  if (kahn) *kahn = &bi->rank_kahn;
+  if (create) *create = &bi->rank_create;
+  return true;
+}
+
 std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   Runtime& rt = Runtime::get();
   const size_t n = gs.size();
@@ -422,18 +496,21 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     char* p;
     char* data() const { return p; }
   } host{host_pin->as<char>()};
-  if (want_path) {
-    rt.d2h_sync(host.data(), arena->ptr, bytes);
-  } else {
-    DevMemP heads = rt.alloc(16 * n);
-    std::vector<AxpyArgs> ax;
-    for (size_t i = 0; i < n; ++i) ax.push_back({heads->as<float>(16 * i), reinterpret_cast<float*>(tab[i].path_len), 3, 1.0f});
-    DevMemP d = upload_vec(ax);
-    launch_axpy_batch(d->as<AxpyArgs>(), int(n), 3, /*copy*/ 2, rt.stream());
-    std::vector<char> hh(16 * n);
-    rt.d2h_sync(hh.data(), heads->ptr, 16 * n);
-    for (size_t i = 0; i < n; ++i) std::memcpy(host.data() + o_hd[i], hh.data() + 16 * i, 12);
-  }
+  auto fetch_results = [&]() {
+    if (want_path) {
+      rt.d2h_sync(host.data(), arena->ptr, bytes);
+    } else {
+      DevMemP heads = rt.alloc(16 * n);
+      std::vector<AxpyArgs> ax;
+      for (size_t i = 0; i < n; ++i) ax.push_back({heads->as<float>(16 * i), reinterpret_cast<float*>(tab[i].path_len), 3, 1.0f});
+      DevMemP d = upload_vec(ax);
+      launch_axpy_batch(d->as<AxpyArgs>(), int(n), 3, /*copy*/ 2, rt.stream());
+      std::vector<char> hh(16 * n);
+      rt.d2h_sync(hh.data(), heads->ptr, 16 * n);
+      for (size_t i = 0; i < n; ++i) std::memcpy(host.data() + o_hd[i], hh.data() + 16 * i, 12);
+    }
+  };
+  fetch_results();
   lap("band_viterbi.2_launch_and_copy");
   std::vector<Graph> outs(n, Graph(false));
   std::vector<size_t> tied;
@@ -448,10 +525,57 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     sop->seq = next_seq();
     sop->saved.resize(n);
   }
+  auto head_of = [&](size_t i) { return reinterpret_cast<const int*>(host.data() + o_hd[i]); };
+  // ---- exact ties on a best path.  CTC-shaped targets: a second launch over those utterances with the reference's
+  // orders as node ranks (tie_ranks above); anything else: the built lattice decides (below)
+  static const bool dbg_ties = std::getenv("GTNX_DEBUG_TIES") != nullptr;
+  static const bool no_ranked = std::getenv("GTNX_NO_RANKED_TIES") != nullptr;
+  {
+    std::vector<size_t> ranked;
+    size_t n_tied = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const int* hd = head_of(i);
+      if (!(hd[2] && hd[0] >= 0)) continue;
+      ++n_tied;
+      LazyProduct& lp = *gs[i].s->lazy;
+      if (!no_ranked && band_viterbi_wave_ok(max_n, max_c, vec) && tie_ranks(*lp.fixed.s, *infos[i], lp.chain_side == 1))
+        ranked.push_back(i);
+    }
+    if (dbg_ties && n_tied)
+      std::fprintf(stderr, "[gtnx] band_viterbi: %zu of %zu utterances report an exact tie on their best path (%zu decided by node ranks)\n",
+                   n_tied, n, ranked.size());
+    if (!ranked.empty()) {
+      std::vector<int> rk;
+      std::vector<size_t> off(ranked.size());
+      for (size_t k = 0; k < ranked.size(); ++k) {
+        const BandInfo& b = *infos[ranked[k]];
+        off[k] = rk.size();
+        // viterbiPath: in-arc ties by the queue's order; viterbiScore: by the in-lists' (= creation) order; accept
+        // ties by the accept list's (= creation) order either way
+        const std::vector<int>& rin = want_path ? b.rank_kahn : b.rank_create;
+        rk.insert(rk.end(), rin.begin(), rin.end());
+        rk.insert(rk.end(), b.rank_create.begin(), b.rank_create.end());
+      }
+      DevMemP drk = upload_vec(rk);
+      std::vector<BandDecode> tab2(ranked.size());
+      for (size_t k = 0; k < ranked.size(); ++k) {
+        tab2[k] = tab[ranked[k]];
+        tab2[k].rank_in = drk->as<int>() + off[k];
+        tab2[k].rank_acc = tab2[k].rank_in + tab2[k].N;
+      }
+      {
+        DevMemP d2 = upload_vec(tab2);
+        GTNX_PROF(want_path ? "band_viterbi_path_ranked" : "band_viterbi_score_ranked", 0.0);
+        launch_band_viterbi(d2->as<BandDecode>(), int(tab2.size()), stage_floats, max_n, max_c, vec, rt.stream(), /*ranked=*/1);
+      }
+      fetch_results();
+      lap("band_viterbi.2b_ranked_rerun");
+    }
+  }
   for (size_t i = 0; i < n; ++i) {
-    const int* hd = reinterpret_cast<const int*>(host.data() + o_hd[i]);
+    const int* hd = head_of(i);
     const int len = hd[0];
-    if (hd[2] && len >= 0) {  // an exact tie: the built lattice decides (its node numbering breaks it)
+    if (hd[2] && len >= 0) {  // an exact tie the ranks do not cover: the built lattice decides (its node numbering breaks it)
       tied.push_back(i);
       continue;
     }
@@ -497,8 +621,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   }
   lap("band_viterbi.3_outputs");
   if (!tied.empty()) {
-    static const bool dbg = std::getenv("GTNX_DEBUG_TIES") != nullptr;
-    if (dbg) std::fprintf(stderr, "[gtnx] band_viterbi: %zu of %zu utterances report an exact tie on their best path\n", tied.size(), n);
+    if (dbg_ties) std::fprintf(stderr, "[gtnx] band_viterbi: %zu utterance(s) rerun on the built lattice\n", tied.size());
     std::vector<Graph> tg;
     for (size_t i : tied) {
       // The lattice is built and its level schedule taken by replaying the reference's queue on it

@@ -330,6 +330,13 @@ gtnx_status_t gtnx_prof_get(const char* name, double* total_ms, int64_t* launche
  * first maximum in in-row order because the product was too large to build and replay the reference's queue on
  * (`unresolved`; shortest.cpp:215-218, INTEGRATION.md "Where results can differ" 3). */
 gtnx_status_t gtnx_debug_viterbi_ties(int64_t* seen, int64_t* unresolved);
+/* Diagnostics (host only, no GPU needed): how exact ties in products of an emission chain with `g` are decided without
+ * building the lattice when g is exactly a CTC target acceptor (benchmarks/ctc.cpp:40-58) with label-sorted out-lists:
+ * queue_rank[n] = position of node n in the reference's queue within every layer of the lattice (viterbiPath keeps the
+ * arc relaxed first, shortest.cpp:208-224), creation_rank[n] = its position in compose's creation order (in-list and
+ * accept-list order: viterbiScore's gradient, shortest.cpp:118-127, :148-160); numNodes() ints each.  *applies = 0:
+ * g is not such a graph (nothing written; tied utterances then take the built lattice). */
+gtnx_status_t gtnx_debug_tie_ranks(gtnx_graph_t g, int* queue_rank, int* creation_rank, int* applies);
 /* names, '\n'-separated, of the families seen since the last reset */
 gtnx_status_t gtnx_prof_names(char* buf, size_t cap);
 /* Diagnostics: which kernel family would score the SYMBOLIC chain product `g` (a compose / intersect result kept

@@ -473,6 +473,10 @@ gtnx_status_t gtnx_debug_symbolic_route(gtnx_graph_t, int, int* route) {
   *route = -1;  /* the reference builds every product */
   return GTNX_OK;
 }
+gtnx_status_t gtnx_debug_tie_ranks(gtnx_graph_t, int*, int*, int* applies) {
+  if (applies) *applies = 0;  /* the reference decides ties on its lattices */
+  return GTNX_OK;
+}
 gtnx_status_t gtnx_debug_viterbi_ties(int64_t* seen, int64_t* unresolved) {
   if (seen) *seen = 0;
   if (unresolved) *unresolved = 0;

@@ -1151,3 +1151,74 @@ def test_backward_twice_with_retain_graph_through_a_ctc_product(gtn, mode):
         gtn.backward(l2, retain_graph=True)
         assert np.abs(e2.grad().weights_to_numpy() - 4 * ge).max() <= 1e-4
         assert np.abs(c2.grad().weights_to_numpy() - 4 * gc).max() <= 1e-4
+
+
+@pytest.mark.parametrize("ctc_first", [True, False])
+def test_band_viterbi_ties_of_sorted_ctc_targets_are_decided_by_node_ranks(gtn, ctc_first):
+    """integer-valued emissions: nearly every utterance has exact ties on its best path.  For arcSort'ed CTC targets
+    they are decided by a second launch with the reference's queue / creation order as node ranks (ops_band.cpp:
+    tie_ranks; band_viterbi_wave_kernel<NPL, RANKED>) -- no lattice is built -- and the answers are the UNMODIFIED
+    reference's: viterbiPath's labels and weights, viterbiScore's scores and its one-hot emission gradients."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "refbackend"))
+    try:
+        import gtn_ref as ref
+    except Exception as e:
+        pytest.skip("needs oracle/_ref: %s" % e)
+    B, T, C = 24, 40, 8
+    rng = np.random.default_rng(17)
+    em = rng.integers(-1, 2, (B, T, C)).astype(np.float32)
+    em[0] = 0.0
+    tgs = []
+    for b in range(B):
+        t = []
+        for _ in range(int(rng.integers(1, 9))):
+            t.append(t[-1] if t and rng.random() < 0.3 else int(rng.integers(1, C)))
+        tgs.append(t)
+
+    def run(api, em_graphs):
+        ctcs = [gg.to_api(api, gg.ctc_target_graph(t)) for t in tgs]
+        for g in ctcs:
+            g.arc_sort()
+        comp = api.intersect(ctcs, em_graphs) if ctc_first else api.intersect(em_graphs, ctcs)
+        return ctcs, comp
+
+    prev = gtn.compose_mode(2)
+    try:
+        ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        gtn.prof_reset()
+        gtn.prof_enable(True)
+        _, comp = run(gtn, ems)
+        paths = gtn.viterbi_path(comp)
+        ems2 = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+        _, comp2 = run(gtn, ems2)
+        vs = gtn.viterbi_score(comp2)
+        gtn.backward(vs)
+        gtn.prof_enable(False)
+        names = gtn.prof_names()
+        got_scores = gtn.items(vs)
+    finally:
+        gtn.compose_mode(prev)
+    assert "band_viterbi_path_ranked" in names and "band_viterbi_score_ranked" in names
+    assert "intersect" not in names and "viterbi_path" not in names  # nothing was built
+    rems = []
+    for b in range(B):
+        e = ref.linear_graph(T, C)
+        e.set_weights(em[b].reshape(-1))
+        rems.append(e)
+    _, rcomp = run(ref, rems)
+    rpaths = ref.viterbi_path(rcomp)
+    rems2 = []
+    for b in range(B):
+        e = ref.linear_graph(T, C)
+        e.set_weights(em[b].reshape(-1))
+        rems2.append(e)
+    _, rcomp2 = run(ref, rems2)
+    rvs = ref.viterbi_score(rcomp2)
+    ref.backward(rvs)
+    want_scores = ref.items(rvs)
+    for b in range(B):
+        assert paths[b].labels_to_list() == rpaths[b].labels_to_list(), b
+        np.testing.assert_array_equal(paths[b].weights_to_numpy(), rpaths[b].weights_to_numpy())
+        assert got_scores[b] == want_scores[b]
+        np.testing.assert_array_equal(ems2[b].grad().weights_to_numpy(), rems2[b].grad().weights_to_numpy())

@@ -221,8 +221,19 @@ def c3v():
     roof = None
     if k:
         gbs = per / (k["ms_per_launch"] * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "band_viterbi_wave_kernel<4, true>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "traffic_source": None, "ms_per_launch": k["ms_per_launch"],
+        # HBM bytes per launch from the committed counter passes of the same kernel on the same shape
+        # (tools/ubench/viterbi_bench under rocprofv3 --pmc, tools/profile_round4.sh): 2 * FETCH_SIZE + WRITE_SIZE KiB
+        import glob
+        traffic, src = None, None
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_viterbi_pmc_hbm.json")))
+        if files and (B, T, Cn, U) == (512, 1000, 256, 100):
+            pm = json.load(open(files[-1]))
+            e = next((v for kk, v in pm.items() if kk.startswith("band_viterbi_wave_kernel")), None)
+            if e:
+                traffic = (2 * e["FETCH_SIZE"]["mean_per_launch"] + e["WRITE_SIZE"]["mean_per_launch"]) * 1024
+                src = "profiles/" + os.path.basename(files[-1])
+        roof = {"bound": "hbm", "kernel": "band_viterbi_wave_kernel<4>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": k["ms_per_launch"],
                 "algorithmic_bytes_per_launch": per}
     out["symbolic_route"] = {"viterbi_path_ms_per_batch": ms_path, "viterbi_score_ms_per_batch": ms_score,
                              "kernels_path": fam_path, "kernels_score": fam_score, "roofline": roof,

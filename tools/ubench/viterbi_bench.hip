@@ -80,10 +80,10 @@ int main(int argc, char** argv) {
       } else if (wg) {
         big_lds(band_viterbi_kernel);
         hipLaunchKernelGGL(band_viterbi_kernel, dim3(B), dim3(512), 4 * size_t(1032 + 4096) + 64, 0, d_tab);
-      } else if (N <= 64) hipLaunchKernelGGL((band_viterbi_wave_kernel<1>), dim3(B), dim3(64), 0, 0, d_tab);
-      else if (N <= 128) hipLaunchKernelGGL((band_viterbi_wave_kernel<2>), dim3(B), dim3(64), 0, 0, d_tab);
-      else if (N <= 256) hipLaunchKernelGGL((band_viterbi_wave_kernel<4>), dim3(B), dim3(64), 0, 0, d_tab);
-      else hipLaunchKernelGGL((band_viterbi_wave_kernel<8>), dim3(B), dim3(64), 0, 0, d_tab);
+      } else if (N <= 64) hipLaunchKernelGGL((band_viterbi_wave_kernel<1, false>), dim3(B), dim3(64), 0, 0, d_tab);
+      else if (N <= 128) hipLaunchKernelGGL((band_viterbi_wave_kernel<2, false>), dim3(B), dim3(64), 0, 0, d_tab);
+      else if (N <= 256) hipLaunchKernelGGL((band_viterbi_wave_kernel<4, false>), dim3(B), dim3(64), 0, 0, d_tab);
+      else hipLaunchKernelGGL((band_viterbi_wave_kernel<8, false>), dim3(B), dim3(64), 0, 0, d_tab);
     };
     for (int i = 0; i < 3; ++i) launch();
     CK(hipDeviceSynchronize());

@@ -1153,8 +1153,9 @@ def test_backward_twice_with_retain_graph_through_a_ctc_product(gtn, mode):
         assert np.abs(c2.grad().weights_to_numpy() - 4 * gc).max() <= 1e-4
 
 
-@pytest.mark.parametrize("ctc_first", [True, False])
-def test_band_viterbi_ties_of_sorted_ctc_targets_are_decided_by_node_ranks(gtn, ctc_first):
+@pytest.mark.parametrize("ctc_first,B,T,C,Umax", [(True, 24, 40, 8, 8), (False, 24, 40, 8, 8), (True, 6, 120, 8, 50),
+                                                 (False, 5, 260, 12, 110), (True, 4, 340, 8, 150)])
+def test_band_viterbi_ties_of_sorted_ctc_targets_are_decided_by_node_ranks(gtn, ctc_first, B, T, C, Umax):
     """integer-valued emissions: nearly every utterance has exact ties on its best path.  For arcSort'ed CTC targets
     they are decided by a second launch with the reference's queue / creation order as node ranks (ops_band.cpp:
     tie_ranks; band_viterbi_wave_kernel<NPL, RANKED>) -- no lattice is built -- and the answers are the UNMODIFIED
@@ -1165,14 +1166,14 @@ def test_band_viterbi_ties_of_sorted_ctc_targets_are_decided_by_node_ranks(gtn, 
         import gtn_ref as ref
     except Exception as e:
         pytest.skip("needs oracle/_ref: %s" % e)
-    B, T, C = 24, 40, 8
-    rng = np.random.default_rng(17)
+    # (Umax 8 / 50 / 110 / 150: 2 U + 1 nodes = one / two / four / eight nodes per lane of the wave kernel)
+    rng = np.random.default_rng(17 + Umax)
     em = rng.integers(-1, 2, (B, T, C)).astype(np.float32)
     em[0] = 0.0
     tgs = []
     for b in range(B):
         t = []
-        for _ in range(int(rng.integers(1, 9))):
+        for _ in range(int(rng.integers(max(1, Umax - 7), Umax + 1))):
             t.append(t[-1] if t and rng.random() < 0.3 else int(rng.integers(1, C)))
         tgs.append(t)
 

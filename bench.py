@@ -195,11 +195,12 @@ def unmodified_caller(B):
         return {"error": str(e)[:300]}
 
 
-def run_json(cmd, timeout):
-    """one JSON line from a child process (the last line that parses)"""
+def run_json(cmd, timeout, cpus=None):
+    """one JSON line from a child process (the last line that parses); cpus: the child's CPU affinity"""
     import subprocess
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        pre = (lambda: os.sched_setaffinity(0, cpus)) if cpus else None
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, preexec_fn=pre)
         for ln in reversed(r.stdout.strip().splitlines()):
             try:
                 return json.loads(ln)
@@ -217,7 +218,14 @@ def reference_loop(B, Cn, mode):
     exe = os.path.join(ROOT, "tests", "dropin", "_bin", "bm_ctc_c256")
     if not os.path.exists(exe):
         return None
-    return run_json([exe, str(B), str(Cn), "100", mode], 300)
+    # The program runs on the cores of the GPU's own NUMA node (what `numactl --cpunodebind` does for a one-GPU job on
+    # a two-socket host): its 33 host threads build 512 graphs per step, and threads that wander to the other socket
+    # cost 5 % and a spread of +-6 % (0.94-1.03 ms per batch unbound, 0.91-0.93 bound, same box).
+    cpus, node = gpu_local_cpus(0)
+    r = run_json([exe, str(B), str(Cn), "300", mode], 300, cpus)
+    if isinstance(r, dict) and "error" not in r:
+        r["placement"] = ("the %d logical CPUs of the GPU's NUMA node (%s)" % (len(cpus), node)) if cpus else "unbound"
+    return r
 
 
 def other_configs(args):
@@ -240,23 +248,40 @@ def other_configs(args):
     return out
 
 
+def gpu_local_cpus(local_rank):
+    """(logical CPUs of the NUMA node GPU `local_rank` hangs off, that node's number) from sysfs; (None, None) if unknown"""
+    try:
+        import torch
+        props = torch.cuda.get_device_properties(local_rank)
+        bdf = props.pci_bus_id.lower() if hasattr(props, "pci_bus_id") else None
+        bases = ["/sys/bus/pci/devices/" + bdf] if bdf else []
+        if not bdf:  # (torch builds without pci_bus_id: the DRM cards in order)
+            import glob
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/local_cpulist"))
+            if local_rank < len(cards):
+                bases = [os.path.dirname(cards[local_rank])]
+        for base in bases:
+            node = int(open(base + "/numa_node").read())
+            cpus = set()
+            for part in open(base + "/local_cpulist").read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                return cpus, node
+    except Exception:
+        pass
+    return None, None
+
+
 def pin_to_gpu_numa_node(local_rank):
     """One process per GPU: keep this rank's host threads (the engine's worker pool inherits the mask)
     on the cores of the NUMA node its GPU hangs off.  Returns what it did, for the per-rank report."""
+    cpus, node = gpu_local_cpus(local_rank)
+    if not cpus:
+        return None
     try:
-        import torch
-        bdf = torch.cuda.get_device_properties(local_rank).pci_bus_id.lower() \
-            if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
-        if not bdf:
-            return None
-        base = "/sys/bus/pci/devices/" + bdf
-        node = int(open(base + "/numa_node").read())
-        cpus = set()
-        for part in open(base + "/local_cpulist").read().strip().split(","):
-            lo, _, hi = part.partition("-")
-            cpus.update(range(int(lo), int(hi or lo) + 1))
-        if cpus:
-            os.sched_setaffinity(0, cpus)
+        os.sched_setaffinity(0, cpus)
         return {"numa_node": node, "cpus": len(cpus)}
     except Exception:
         return None

@@ -44,22 +44,32 @@ struct LazyGroupState {
   // with 64 workgroups per step, 8.8 with 256) -- the chip holds both chains' workgroups side by side (120 VGPRs,
   // 39 KB of LDS: two per CU).  backward() then finds beta done and runs the gradient contractions only.  The
   // price: 4 (T+1) nb N bytes held from forward to backward like alpha is, and a wasted sweep when the caller never
-  // calls backward on a graph it built with calcGrad = true (GTNX_NO_EAGER_BETA=1 turns it off).
+  // calls backward on a graph it built with calcGrad = true (the default of Graph) -- a scoring loop.  So the early
+  // sweep is only started while the process has been SEEN to differentiate such products: the first backward of a
+  // dense product turns it on (that step runs the sweep in backward as before), an early sweep nobody used turns
+  // it off again (eager_beta_follows below).  GTNX_NO_EAGER_BETA=1: never; GTNX_EAGER_BETA=1: always.
   struct EagerBeta {
     DevMemP beta, planes;
     Runtime* rt = nullptr;
     Runtime::SideJobP job;
-    ~EagerBeta() {
-      // nobody asked for the gradient: the buffers go back to the pool in engine-stream order, so that stream
-      // has to be behind the side stream's launches first
-      try {
-        if (rt && job) rt->side_join(job);
-      } catch (...) {
-      }
-    }
+    bool used = false;
+    ~EagerBeta();
   };
   std::shared_ptr<EagerBeta> eager;
 };
+
+namespace {
+std::atomic<int> eager_beta_follows{0};  // backward has followed the forward of a dense product (LazyGroupState::EagerBeta)
+}
+LazyGroupState::EagerBeta::~EagerBeta() {
+  // the buffers go back to the pool in engine-stream order, so that stream has to be behind the side stream's
+  // launches first (a sweep nobody asked the result of)
+  if (!used) eager_beta_follows.store(0, std::memory_order_relaxed);
+  try {
+    if (rt && job) rt->side_join(job);
+  } catch (...) {
+  }
+}
 
 int lazy_lds_limit() { return 150 * 1024; }
 
@@ -326,9 +336,10 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
         launch_lazy_mfma_prep(st.view, rt.stream());
         {
           static const bool eager_off = getenv("GTNX_NO_EAGER_BETA") != nullptr || getenv("GTNX_CHAIN") != nullptr;
+          static const bool eager_always = getenv("GTNX_EAGER_BETA") != nullptr;
           bool wants = st.fixed.calc_grad();
           for (size_t b = 0; b < st.chains.size() && !wants; ++b) wants = st.chains[b].calc_grad();
-          if (wants && !eager_off && st.view.T >= 1) {
+          if (wants && !eager_off && st.view.T >= 1 && (eager_always || eager_beta_follows.load(std::memory_order_relaxed))) {
             auto eb = std::make_shared<LazyGroupState::EagerBeta>();
             const LazyGroup& sv = st.view;
             const size_t xf = align_up(size_t(sv.Kpad) * size_t(sv.nbpad), 64);
@@ -442,7 +453,9 @@ struct LazySdOp : OpRecord {
         DevMemP beta = st.eager ? st.eager->beta : rt.alloc(4 * plane * size_t(T + 1));
         v.beta = beta->as<float>();
         GTNX_PROF("lazy_forward_score_grad", 0.0);
+        if (st.dense && st.mfma) eager_beta_follows.store(1, std::memory_order_relaxed);
         if (st.eager) {
+          st.eager->used = true;
           rt.side_join(st.eager->job);  // the sweep ran next to the alpha sweep (LazyGroupState::EagerBeta)
         } else {
           launch_lazy_init(v, 1, rt.stream());

@@ -167,9 +167,9 @@ struct Runtime::Side {
 };
 
 Runtime::SideJobP Runtime::side_launch(std::function<void(hipStream_t)> fn) {
-  if (!side_) {
+  if (!side_.load(std::memory_order_acquire)) {
     std::lock_guard<std::mutex> lk(mu_);
-    if (!side_) {
+    if (!side_.load(std::memory_order_relaxed)) {
       Side* sd = new Side();
       HIP_CHECK(hipStreamCreateWithFlags(&sd->stream, hipStreamNonBlocking));
       const int dev = device_;
@@ -201,27 +201,29 @@ Runtime::SideJobP Runtime::side_launch(std::function<void(hipStream_t)> fn) {
         }
       });
       sd->th.detach();
-      side_ = sd;
+      side_.store(sd, std::memory_order_release);
     }
   }
+  Side* const side = side_.load(std::memory_order_acquire);
   auto job = std::make_shared<SideJob>();
   job->fn = std::move(fn);
   HIP_CHECK(hipEventCreateWithFlags(&job->fork, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&job->done_ev, hipEventDisableTiming));
   HIP_CHECK(hipEventRecord(job->fork, stream_));
   {
-    std::lock_guard<std::mutex> lk(side_->mu);
-    side_->q.push_back(job);
+    std::lock_guard<std::mutex> lk(side->mu);
+    side->q.push_back(job);
   }
-  side_->cv_work.notify_one();
+  side->cv_work.notify_one();
   return job;
 }
 
 void Runtime::side_join(const SideJobP& job) {
-  if (!job || !side_) return;
+  Side* const side = side_.load(std::memory_order_acquire);
+  if (!job || !side) return;
   {
-    std::unique_lock<std::mutex> lk(side_->mu);
-    side_->cv_done.wait(lk, [&] { return job->enqueued; });
+    std::unique_lock<std::mutex> lk(side->mu);
+    side->cv_done.wait(lk, [&] { return job->enqueued; });
     if (job->joined) return;
     job->joined = true;
   }

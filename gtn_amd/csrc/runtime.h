@@ -9,6 +9,7 @@
 //  * host<->device staging goes through pinned blocks recycled by event.
 #pragma once
 
+#include <atomic>
 #include <functional>
 #include <map>
 #include <memory>
@@ -162,7 +163,7 @@ class Runtime {
   std::vector<ProfRec> prof_recs_;
   std::vector<hipEvent_t> ev_pool_;
   struct Side;
-  Side* side_ = nullptr;  // made on first use, never destroyed (its thread outlives static destruction)
+  std::atomic<Side*> side_{nullptr};  // made on first use, never destroyed (its thread outlives static destruction)
   std::map<std::string, ProfEntry> prof_;
   friend struct Scope;
 };

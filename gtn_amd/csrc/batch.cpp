@@ -923,9 +923,31 @@ void batch_backward(const BatchP& root, bool retain) {
   }
   std::sort(order.begin(), order.end(), [](Batch* a, Batch* b) { return a->op->seq > b->op->seq; });
   // seed: addGrad(ones) (autograd.cpp:57-62) -- onto whatever an earlier, retained backward left there
+  bool root_done = false;  // the root's own gradient function ran with the seed (one launch instead of three)
   if (!root->g_dev) {
     alloc_grad(*root, false);
-    launch_fill_f32(root->g_dev, 1.0f, size_t(root->n), rt.stream());
+    auto* sop = dynamic_cast<BScalarOp*>(root->op.get());
+    bool plain = sop != nullptr && !sop->inputs.empty() && sop->inputs.size() <= 2;
+    if (plain)
+      for (auto& in : sop->inputs) plain = plain && in->kind == Batch::SCALAR && !in->materialised && in->n == root->n;
+    if (plain && sop->inputs.size() == 2 && sop->inputs[0].get() == sop->inputs[1].get()) plain = false;  // add(x, x)
+    if (plain) {
+      float* g[2] = {nullptr, nullptr};
+      float sc[2] = {0.0f, 0.0f};
+      int acc[2] = {0, 0};
+      for (size_t i = 0; i < sop->inputs.size(); ++i) {
+        Batch& in = *sop->inputs[i];
+        if (!in.calc_grad) continue;  // (functions.cpp:55-57)
+        sc[i] = (sop->kind == SK_NEGATE || (sop->kind == SK_SUBTRACT && i == 1)) ? -1.0f : 1.0f;
+        acc[i] = in.g_dev != nullptr;
+        if (!in.g_dev) alloc_grad(in, false);
+        g[i] = in.g_dev;
+      }
+      launch_scalar_seed(root->g_dev, g[0], sc[0], acc[0], g[1], sc[1], acc[1], size_t(root->n), rt.stream());
+      root_done = true;
+    } else {
+      launch_fill_f32(root->g_dev, 1.0f, size_t(root->n), rt.stream());
+    }
   } else {
     DevMemP ones = rt.alloc(sizeof(float) * size_t(root->n ? root->n : 1));
     launch_fill_f32(ones->as<float>(), 1.0f, size_t(root->n), rt.stream());
@@ -936,6 +958,7 @@ void batch_backward(const BatchP& root, bool retain) {
   try {
     for (Batch* b : order) {
       if (!b->g_dev) continue;  // no gradient reached it (a symbolic product never holds one)
+      if (root_done && b == root.get()) continue;
       if (auto* f = dynamic_cast<BFromGraphsOp*>(b->op.get())) f->retain = retain;
       b->op->backward(*b);
     }

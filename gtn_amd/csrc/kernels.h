@@ -628,6 +628,7 @@ void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x
 // ---------------------------------------------------------------------------
 void launch_fill_i32(int* p, int v, size_t n, hipStream_t st);
 void launch_fill_f32(float* p, float v, size_t n, hipStream_t st);
+void launch_scalar_seed(float* root, float* g0, float s0, int acc0, float* g1, float s1, int acc1, size_t n, hipStream_t st);
 // out[i] = sa * a[i] + sb * b[i]  over n scalars held at arbitrary addresses
 struct ScalarArgs {
   const GTNX_G float* a;

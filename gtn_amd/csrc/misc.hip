@@ -352,6 +352,18 @@ __global__ void vec_axpby_kernel(float* out, const float* a, const float* b, siz
 void launch_vec_axpby(float* out, const float* a, const float* b, size_t n, float sa, float sb, int accumulate, hipStream_t st) {
   if (n) hipLaunchKernelGGL(vec_axpby_kernel, dim3(grid_for(n)), dim3(256), 0, st, out, a, b, n, sa, sb, accumulate);
 }
+// seed of a backward pass over a scalar op's result (batch.cpp: batch_backward): root = 1, and what the op's own
+// gradient function would add to its inputs next (s0 / s1 times that 1) in the same launch
+__global__ void scalar_seed_kernel(float* root, float* g0, float s0, int acc0, float* g1, float s1, int acc1, size_t n) {
+  for (size_t i = blockIdx.x * size_t(blockDim.x) + threadIdx.x; i < n; i += size_t(gridDim.x) * blockDim.x) {
+    root[i] = 1.0f;
+    if (g0) g0[i] = acc0 ? g0[i] + s0 : s0;
+    if (g1) g1[i] = acc1 ? g1[i] + s1 : s1;
+  }
+}
+void launch_scalar_seed(float* root, float* g0, float s0, int acc0, float* g1, float s1, int acc1, size_t n, hipStream_t st) {
+  if (n) hipLaunchKernelGGL(scalar_seed_kernel, dim3(grid_for(n)), dim3(256), 0, st, root, g0, s0, acc0, g1, s1, acc1, n);
+}
 void launch_fill_i32(int* p, int v, size_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(fill_i32_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
 }

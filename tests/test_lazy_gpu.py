@@ -1204,8 +1204,9 @@ def test_band_viterbi_ties_of_sorted_ctc_targets_are_decided_by_node_ranks(gtn, 
         got_scores = gtn.items(vs)
     finally:
         gtn.compose_mode(prev)
-    assert "band_viterbi_path_ranked" in names and "band_viterbi_score_ranked" in names
-    assert "intersect" not in names and "viterbi_path" not in names  # nothing was built
+    if not (os.environ.get("GTNX_NO_RANKED_TIES") or os.environ.get("GTNX_VITERBI_WG")):  # (those take the built lattice)
+        assert "band_viterbi_path_ranked" in names and "band_viterbi_score_ranked" in names
+        assert "intersect" not in names and "viterbi_path" not in names  # nothing was built
     rems = []
     for b in range(B):
         e = ref.linear_graph(T, C)

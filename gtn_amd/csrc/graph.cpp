@@ -268,8 +268,11 @@ DeferredSizes::~DeferredSizes() {
 }
 
 void DeferredSizes::resolve() {
-  if (done) return;
-  done = true;
+  // (two threads may get here for the same record -- one through deferred_limit, one through a member's
+  //  resolve_sizes: the second has to wait until the first has applied the sizes, not just see the flag)
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.load(std::memory_order_relaxed)) return;
+  done.store(true, std::memory_order_relaxed);
   HIP_CHECK(hipEventSynchronize(ev));
   const ComposeOut* outs = reinterpret_cast<const ComposeOut*>(host->as<char>(hdr_out));
   const int* cnts = reinterpret_cast<const int*>(host->as<char>(hdr_cnt));

@@ -322,7 +322,8 @@ struct DeferredSizes {
   hipEvent_t ev = nullptr;
   PinnedMemP host;
   size_t hdr_out = 0, hdr_cnt = 0;
-  bool done = false;
+  std::atomic<bool> done{false};
+  std::mutex mu;  // resolve(): the thread that finds `done` set must also find the sizes applied
   struct Member {
     std::weak_ptr<Structure> s;
     std::weak_ptr<Weights> w;

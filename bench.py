@@ -250,27 +250,39 @@ def other_configs(args):
 
 def gpu_local_cpus(local_rank):
     """(logical CPUs of the NUMA node GPU `local_rank` hangs off, that node's number) from sysfs; (None, None) if unknown"""
+    import glob
+    bases = []
     try:
         import torch
         props = torch.cuda.get_device_properties(local_rank)
-        bdf = props.pci_bus_id.lower() if hasattr(props, "pci_bus_id") else None
-        bases = ["/sys/bus/pci/devices/" + bdf] if bdf else []
-        if not bdf:  # (torch builds without pci_bus_id: the DRM cards in order)
-            import glob
-            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/local_cpulist"))
-            if local_rank < len(cards):
-                bases = [os.path.dirname(cards[local_rank])]
-        for base in bases:
-            node = int(open(base + "/numa_node").read())
+        bdf = getattr(props, "pci_bus_id", None)
+        if isinstance(bdf, str) and bdf:
+            bases.append("/sys/bus/pci/devices/" + bdf.lower())
+        elif isinstance(bdf, int):  # (this torch: three integers)
+            bases.append("/sys/bus/pci/devices/%04x:%02x:%02x.0" % (int(getattr(props, "pci_domain_id", 0)), bdf,
+                                                                      int(getattr(props, "pci_device_id", 0))))
+    except Exception:
+        pass
+    # (no bus id from torch, or a sysfs layout that does not list it: the DRM render devices in order)
+    cards = sorted(os.path.dirname(p) for p in glob.glob("/sys/class/drm/card[0-9]*/device/local_cpulist"))
+    if local_rank < len(cards):
+        bases.append(cards[local_rank])
+    for base in bases:
+        try:
             cpus = set()
             for part in open(base + "/local_cpulist").read().strip().split(","):
                 lo, _, hi = part.partition("-")
                 cpus.update(range(int(lo), int(hi or lo) + 1))
             cpus &= os.sched_getaffinity(0)
-            if cpus:
-                return cpus, node
-    except Exception:
-        pass
+            if not cpus:
+                continue
+            try:
+                node = int(open(base + "/numa_node").read())
+            except Exception:
+                node = None
+            return cpus, node
+        except Exception:
+            continue
     return None, None
 
 

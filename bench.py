@@ -233,7 +233,10 @@ def other_configs(args):
     and cpu_baseline, run as child processes so that their memory is gone before the next one starts"""
     py = sys.executable
     out = {}
-    out["C1"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c1"], 300)
+    # (host-bound children run on the cores of the GPU's NUMA node, like reference_loop(); the CPU baselines inside
+    #  them use every core they are given -- `cores` in each cpu_baseline says how many)
+    cpus, _ = gpu_local_cpus(0)
+    out["C1"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c1"], 300, cpus)
     out["C2"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c2"], 300)
     out["C3_viterbi"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c3v"], 600)
     out["C4"] = run_json([py, os.path.join(ROOT, "tools", "bench_c4.py"), "--steps", "2"], 600)

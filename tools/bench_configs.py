@@ -251,13 +251,25 @@ def c3v():
         native.gtn_bench_viterbi_reference_loop.restype = C.c_double
         tgc = np.ascontiguousarray(tg, dtype=np.int32)
         lab = np.full((B, T), -1, np.int32)
-        ms_loop = native.gtn_bench_viterbi_reference_loop(em_dev.data_ptr(), tgc.ctypes.data, B, T, Cn, U, 10, lab.ctypes.data)
+        # the loop's pool threads are made now and inherit this thread's mask: the cores of the GPU's NUMA node, as
+        # bench.py places the training loop (the reference's own pool, made later for cpu_baseline, gets every core)
+        sys.path.insert(0, ROOT)
+        from bench import gpu_local_cpus
+        cpus, node = gpu_local_cpus(0)
+        before = os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        try:
+            ms_loop = native.gtn_bench_viterbi_reference_loop(em_dev.data_ptr(), tgc.ctypes.data, B, T, Cn, U, 10, lab.ctypes.data)
+        finally:
+            os.sched_setaffinity(0, before)
         if ms_loop > 0:
             same = all([int(x) for x in lab[b] if x >= 0] == [int(x) for x in paths[b].labels_to_list(False)] for b in range(8))
             out["reference_api"] = {"viterbi_path_ms_per_batch": ms_loop, "utterances_per_s": B / (ms_loop * 1e-3),
                                     "host": "C++: parallelMap over viterbiPath(intersect(ctcGraph, linearGraph + setWeights)) per "
                                             "utterance, every path looked at (bench_native/ctc_step.cpp)",
-                                    "labels_equal_python_route": bool(same)}
+                                    "labels_equal_python_route": bool(same),
+                                    "placement": ("the %d logical CPUs of the GPU's NUMA node (%s)" % (len(cpus), node)) if cpus else "unbound"}
             out["value"] = B / (ms_loop * 1e-3)
             out["value_source"] = "reference_api (C++ host); the Python mirror's figure is symbolic_route.viterbi_path_ms_per_batch"
     except Exception as e:

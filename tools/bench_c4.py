@@ -161,10 +161,17 @@ def main():
     flops = 2.0 * B * N * N * T
     if prof.get("lazy_forward_score", {}).get("total_ms"):
         ms = prof["lazy_forward_score"]["total_ms"]
-        tf = flops / (ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "lazy_mfma_step_kernel<false> x T (+ prep)", "achieved": tf,
-                           "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
-                           "ms_per_pass": ms, "flops_per_pass": flops}
+        # Once a backward of such a product has been seen, the beta sweep runs BESIDE the alpha sweep (side stream,
+        # DESIGN.md section 11.7): the span the profiler times then holds both passes' step launches, and the
+        # backward family is left with the gradient contractions only (about half the forward span or less)
+        bw = prof.get("lazy_forward_score_grad", {}).get("total_ms") or 0.0
+        both = os.environ.get("GTNX_NO_EAGER_BETA") is None and 0.0 < bw < 0.7 * ms
+        passes = 2 if both else 1
+        tf = passes * flops / (ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma",
+                           "kernel": "lazy_mfma_step_kernel<false> x T (+ prep)" + (" beside lazy_mfma_step_kernel<true> x T" if both else ""),
+                           "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "traffic": None,
+                           "ms_per_pass": ms, "flops_per_pass": flops, "passes_in_span": passes}
     # the tropical sweeps (maxplus.hip) are vector-ALU work: one packed add + one max3 per pair of product arcs,
     # i.e. one lane-instruction per arc at best; peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
     if prof.get("maxplus_viterbi", {}).get("total_ms"):

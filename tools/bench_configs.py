@@ -232,7 +232,7 @@ def c3v():
             if e:
                 traffic = (2 * e["FETCH_SIZE"]["mean_per_launch"] + e["WRITE_SIZE"]["mean_per_launch"]) * 1024
                 src = "profiles/" + os.path.basename(files[-1])
-        roof = {"bound": "hbm", "kernel": "band_viterbi_wave_kernel<4>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": "band_viterbi_wave_kernel<4, false>", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "ms_per_launch": k["ms_per_launch"],
                 "algorithmic_bytes_per_launch": per}
     out["symbolic_route"] = {"viterbi_path_ms_per_batch": ms_path, "viterbi_score_ms_per_batch": ms_score,

@@ -9,13 +9,14 @@
 # Counter passes never carry another trace domain than --kernel-trace.
 set -u
 REPO=$(pwd)
-bash tools/profile_gpu.sh r04v1 > /dev/null 2>&1
+TAG=${1:-r04v1}   # (a second pass of the round: bash tools/profile_round4.sh r04v2)
+bash tools/profile_gpu.sh $TAG > /dev/null 2>&1
 OUT=$REPO/gpurun_out/prof_r04; mkdir -p $OUT
-cp gpurun_out/prof_r04v1/kernel_stats.csv $OUT/c3_kernel_stats.csv 2>/dev/null
-cp gpurun_out/prof_r04v1/pmc_hbm.json $OUT/c3_pmc_hbm.json 2>/dev/null
-cp gpurun_out/prof_r04v1/pmc_sq.json $OUT/c3_pmc_sq.json 2>/dev/null
-cp gpurun_out/prof_r04v1/pmc_FETCH_SIZE.csv $OUT/c3_pmc_FETCH_SIZE.csv 2>/dev/null
-cp gpurun_out/prof_r04v1/pmc_WRITE_SIZE.csv $OUT/c3_pmc_WRITE_SIZE.csv 2>/dev/null
+cp gpurun_out/prof_$TAG/kernel_stats.csv $OUT/c3_kernel_stats.csv 2>/dev/null
+cp gpurun_out/prof_$TAG/pmc_hbm.json $OUT/c3_pmc_hbm.json 2>/dev/null
+cp gpurun_out/prof_$TAG/pmc_sq.json $OUT/c3_pmc_sq.json 2>/dev/null
+cp gpurun_out/prof_$TAG/pmc_FETCH_SIZE.csv $OUT/c3_pmc_FETCH_SIZE.csv 2>/dev/null
+cp gpurun_out/prof_$TAG/pmc_WRITE_SIZE.csv $OUT/c3_pmc_WRITE_SIZE.csv 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 stats() {  # name, command...
   local name=$1; shift

@@ -239,7 +239,7 @@ def other_configs(args):
     out["C1"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c1"], 300, cpus)
     out["C2"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c2"], 300)
     out["C3_viterbi"] = run_json([py, os.path.join(ROOT, "tools", "bench_configs.py"), "c3v"], 600)
-    out["C4"] = run_json([py, os.path.join(ROOT, "tools", "bench_c4.py"), "--steps", "2"], 600)
+    out["C4"] = run_json([py, os.path.join(ROOT, "tools", "bench_c4.py"), "--steps", "4"], 600)
     c5 = run_json([py, os.path.join(ROOT, "bench.py"), "--config", "c5", "--steps", "10", "--warmup", "2", "--no-configs",
                    "--no-reference-api", "--no-unmodified-caller", "--no-built-lattice", "--cpu-baseline-seconds", "20"], 600)
     if "error" not in c5:

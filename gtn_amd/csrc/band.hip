@@ -550,12 +550,18 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
     Stage<8> st[D];
     auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
     auto issue = [&](Stage<8>& s, int c) { s.template issue<VEC>(P.em + int64_t(c) * K * C, rows_of(c) * C, hid); };
+    GTNX_G float* const em_copy = P.em_copy;  // (uniform; null on every path but a region's first sweep)
     auto land = [&](const Stage<8>& s, int c) {
       float* base = ering + (c % NBE) * K * CS;
-      s.template each<VEC>(rows_of(c) * C, C, hid, [&](int, int, int r, int col, gtnx_f4 q) {
+      GTNX_G float* cdst = em_copy + int64_t(c) * K * C;
+      s.template each<VEC>(rows_of(c) * C, C, hid, [&](int, int e, int r, int col, gtnx_f4 q) {
         float* d = base + r * CS + col;
         if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
         else d[0] = em2(q.x);
+        if (em_copy) {  // the values as they came (natural log), where the backward sweep will read them
+          if (vec) *reinterpret_cast<GTNX_G gtnx_f4*>(cdst + e) = q;
+          else cdst[e] = q.x;
+        }
       });
     };
     // row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / K lanes per row, pairs

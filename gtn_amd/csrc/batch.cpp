@@ -118,6 +118,7 @@ struct BFsLinearOp : BatchOp {
   void run(Batch& out) {
     Batch& e = *inputs[0];
     Runtime& rt = Runtime::get();
+    if (e.w_pend) e.w_pend->settle();  // (the values are read here: graph.h PendingCopy)
     const bool have = e.g_dev != nullptr;
     if (!have) alloc_grad(e, false);
     std::vector<LinArgs> args;
@@ -660,6 +661,7 @@ void batch_materialise(Batch& x) {
         s.ilabel_sorted = s.olabel_sorted = true;
         Weights& w = *g.w;
         w.n = A;
+        if (x.w_pend) x.w_pend->settle();  // (the element graphs' weights are looked at by whoever gets them)
         w.dev_mem = x.w_mem;
         w.dev = x.w_dev + size_t(i) * size_t(A);
         w.dev_valid = true;
@@ -781,6 +783,23 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
     std::vector<std::pair<BandLaunchKey, BandPair>> tab;
     tab.reserve(size_t(n));
     double abytes = 0;
+    // the copy of the chain's values a region still owes (graph.h PendingCopy): made by this sweep when every
+    // element's source is known; the lock keeps another thread's settle() from making it at the same time
+    std::shared_ptr<PendingCopy> pend = ch.w_pend;
+    std::unique_lock<std::mutex> pend_lock;
+    bool fuse_copy = false;
+    if (pend && !pend->done.load(std::memory_order_acquire)) {
+      pend_lock = std::unique_lock<std::mutex>(pend->mu);
+      fuse_copy = !pend->done.load(std::memory_order_relaxed) && pend->device == rt.device();
+      const size_t A = size_t(T) * size_t(C);
+      for (int b = 0; b < n && fuse_copy; ++b) fuse_copy = pend->src_of(ch.w_dev + size_t(b) * A) != nullptr;
+      // (a copy that also serves graphs outside this record is made whole: the sweep would leave the rest undone)
+      fuse_copy = fuse_copy && pend->segs.size() == size_t(n);
+      if (!fuse_copy) {
+        pend_lock.unlock();
+        pend->settle();
+      }
+    }
     for (int b = 0; b < n; ++b) {
       BandPair& p = op->pairs[size_t(b)];
       p = BandPair{};
@@ -810,13 +829,22 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
       }
       p.hot = (!fx.fal && U + 1 >= 8) ? fx.blank : -1;
       p.lgrn = band_forward_lgrn(C);
-      tab.push_back({BandLaunchKey{C, band_npl(p.N), fx.fal ? 0 : 1, 0, band_vec_ok(p)}, p});
-      abytes += 4.0 * T * C + 4.0 * double(T + 1) * p.NS;
+      // The chain's values may still be in the caller's buffer (staged by the region this sweep belongs to): the
+      // sweep reads them THERE and stores them at p.em on its way -- the copy the region owes -- so that the
+      // backward sweep, and anybody else later, reads the graph's own copy.  (p, as kept for backward: the copy.)
+      BandPair q = p;
+      if (fuse_copy) {
+        q.em = static_cast<const float*>(pend->src_of(p.em));
+        q.em_copy = const_cast<float*>(p.em);
+      }
+      tab.push_back({BandLaunchKey{C, band_npl(q.N), fx.fal ? 0 : 1, 0, band_vec_ok(q)}, q});
+      abytes += 4.0 * T * C + 4.0 * double(T + 1) * p.NS + (fuse_copy ? 4.0 * T * C : 0.0);
     }
     {
       GTNX_PROF("band_forward_score", abytes);
       band_launch(tab, false);
     }
+    if (fuse_copy) pend->done.store(true, std::memory_order_release);  // (under pend->mu, taken above)
     if (want_norm) {
       ch.nc_mem = op->arena;
       ch.nc_norm = op->arena->as<float>(o_norm);

@@ -78,6 +78,8 @@ struct Batch {
   int M = 0, C = 0;
   DevMemP w_mem;
   float* w_dev = nullptr;
+  std::shared_ptr<PendingCopy> w_pend;  // LINEAR over a region's staged weights: the values may not be at w_dev yet
+                                        // (graph.h PendingCopy; batch.cpp linear_values settles, the band forward fuses)
   DevMemP nc_mem;                    // forwardScore of every chain + per-row log-sum-exps, left behind by a sweep
   float* nc_norm = nullptr;
   float* nc_rowlse = nullptr;

@@ -396,10 +396,32 @@ int Structure::num_out(int n) {
 // ======================================================================
 // Weights
 // ======================================================================
+void PendingCopy::settle() {
+  if (done.load(std::memory_order_acquire)) return;
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.load(std::memory_order_relaxed)) return;
+  if (!segs.empty()) {
+    Runtime& rt = Runtime::of(device);  // (whoever asks, from whichever thread: the copy runs on the owner's stream)
+    rt.activate();
+    const size_t bytes = sizeof(CopySeg) * segs.size();
+    DevMemP d = rt.alloc(bytes);
+    PinnedMemP p = rt.alloc_pinned(bytes);
+    std::memcpy(p->ptr, segs.data(), bytes);
+    rt.h2d(d->ptr, p->ptr, bytes);
+    launch_copy_segments(d->as<CopySeg>(), int(segs.size()), max_bytes, rt.stream());
+  }
+  done.store(true, std::memory_order_release);
+}
+const void* PendingCopy::src_of(const void* dst) const {
+  auto it = std::lower_bound(segs.begin(), segs.end(), dst, [](const CopySeg& a, const void* d) { return a.dst < d; });
+  return it != segs.end() && it->dst == dst ? it->src : nullptr;
+}
+
 bool Weights::settle_staged() {
   if (!staged || !staged->on_device || !staged->blk) return false;
   float* base = staged->blk->base.load(std::memory_order_acquire);
   if (!base) return false;
+  if (staged->blk->pend) staged->blk->pend->settle();  // whoever looks at the values finds them there
   dev_mem = staged->blk->mem;
   dev = reinterpret_cast<float*>(reinterpret_cast<char*>(base) + staged->off);
   dev_valid = true;

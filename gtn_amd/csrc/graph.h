@@ -163,9 +163,25 @@ struct NormCache {
 // join allocates one arena for all slices, copies every segment with one launch and publishes each slice's
 // base address here; the weights themselves are not touched by the join -- they settle (Weights::settle_staged)
 // when somebody first needs them.
+// The copy a region's join owes the emission graphs whose weights were set from DEVICE memory inside the region
+// (graph.cpp:179-181: setWeights copies).  It is not launched at once: when the region's first consumer of those
+// weights is the band forward sweep -- the criterion step -- the sweep stores every emission it stages (BandPair::
+// em_copy) and the tensor is read once instead of twice; anything else that wants the values (Weights::settle_staged,
+// the other consumers of a LINEAR record, the end of the join at the latest: the caller's buffer is only promised
+// until parallelMap returns) launches the copy kernel first.
+struct PendingCopy {
+  std::vector<CopySeg> segs;  // destination ascending
+  int64_t max_bytes = 0;
+  int device = 0;
+  std::atomic<bool> done{false};
+  std::mutex mu;
+  void settle();                              // launch copy_segments unless the copy has been made
+  const void* src_of(const void* dst) const;  // the caller's address whose copy goes to dst (null: none)
+};
 struct StageBlock {
   DevMemP mem;
   std::atomic<float*> base{nullptr};
+  std::shared_ptr<PendingCopy> pend;  // set with `base`
 };
 struct StagedWeights {
   PinnedMemP chunk;            // keeps the staging chunk alive (host source)

@@ -469,6 +469,9 @@ struct BandPair {
   const GTNX_G int* slab;          // [n_lab] their labels
   const GTNX_G float* w;           // G's weights, arc-id order; null: all zero
   const GTNX_G float* em;          // [T][C] chain weights
+  GTNX_G float* em_copy;           // forward only, or null: every emission the sweep stages is also stored here (the
+                                   // copy a region owes its emission graphs, region.cpp PendingCopy: one pass
+                                   // over the caller's tensor instead of two)
   GTNX_G float* alpha;             // [T+1][NS] log2 units, shifted rows
   GTNX_G double* aoff;             // [0]: the score in log2 units; [1 + (r >> lgrn) * 4 + w]: shift of alpha row r, wave w
   GTNX_G float* score;             // [1]

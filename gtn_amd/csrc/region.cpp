@@ -535,6 +535,7 @@ Graph record_call(RegionOp op, const Graph& a, const Graph* b) {
 }
 
 // ---- weights handed over inside the region: one copy per staging block / one launch for device sources
+thread_local std::vector<std::shared_ptr<PendingCopy>> t_pending_copies;  // of the join this thread is running
 void apply_stage(std::vector<SliceP>& slices) {
   Runtime* rtp = nullptr;
   // device sources: one arena, slice after slice; the weights find their copy through their slice's block
@@ -548,24 +549,30 @@ void apply_stage(std::vector<SliceP>& slices) {
     GTNX_HOST_T("region.apply_stage.device");
     rtp = &Runtime::get();
     DevMemP darena = rtp->alloc(dtotal ? dtotal : 16);
-    std::vector<CopySeg> segs;
+    auto pend = std::make_shared<PendingCopy>();
+    pend->device = rtp->device();
+    std::vector<CopySeg>& segs = pend->segs;
     segs.reserve(nseg);
-    int64_t max_bytes = 0;
     size_t off = 0;
     for (auto& sl : slices) {
       if (sl->executed || !sl->blk || sl->blk->base.load(std::memory_order_acquire)) continue;
       char* base = darena->as<char>(off);
       for (const Slice::DevSeg& sg : sl->stage_dev) {
         segs.push_back({base + sg.off, sg.src, int64_t(sg.bytes)});
-        max_bytes = std::max<int64_t>(max_bytes, int64_t(sg.bytes));
+        pend->max_bytes = std::max<int64_t>(pend->max_bytes, int64_t(sg.bytes));
       }
       sl->blk->mem = darena;
+      sl->blk->pend = pend;
       sl->blk->base.store(reinterpret_cast<float*>(base), std::memory_order_release);
       off += sl->dev_bytes;  // (multiples of 16: the slices' blocks are back to back)
       sl->stage_dev.clear();
     }
-    DevMemP d = upload_vec(segs);
-    launch_copy_segments(d->as<CopySeg>(), int(segs.size()), max_bytes, rtp->stream());
+    std::sort(segs.begin(), segs.end(), [](const CopySeg& a, const CopySeg& b) { return a.dst < b.dst; });
+    // (not launched here: graph.h PendingCopy -- the band forward sweep of this join makes the copy on its way, or
+    //  the join's end does)
+    static const bool eager_copy = std::getenv("GTNX_NO_FUSED_COPY") != nullptr;
+    if (eager_copy) pend->settle();
+    t_pending_copies.push_back(pend);
   }
   // host sources: the device arena is the image of the used span of the pinned block
   bool any_host = false;
@@ -1022,6 +1029,7 @@ struct Run {
     const size_t A = size_t(d0.M) * size_t(d0.C);
     const float* expect = nullptr;
     DevMemP mem;
+    std::shared_ptr<PendingCopy> pend;  // staged weights: the copy into `mem` may still be owed (graph.h)
     for (SliceGroup* sg : g.parts) {
       const LeafDigest& d = sg->leaf[k];
       if (d.src != d0.src || d.M != d0.M || d.C != d0.C || d.cg != d0.cg) return nullptr;
@@ -1031,7 +1039,10 @@ struct Run {
         float* base = blk.base.load(std::memory_order_acquire);
         if (!base) return nullptr;  // (not copied: cannot happen after apply_stage)
         first = reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + d.first_off);
-        if (!mem) mem = blk.mem;
+        if (!mem) {
+          mem = blk.mem;
+          pend = blk.pend;
+        }
         if (blk.mem != mem) return nullptr;
       } else {
         first = d.first_dev;
@@ -1063,6 +1074,7 @@ struct Run {
     b->C = d0.C;
     b->w_mem = mem;
     b->w_dev = const_cast<float*>(w0);
+    b->w_pend = pend;
     if (dest) {
       b->dest_mem = d0.dest_mem;
       b->dest = dest;
@@ -1277,6 +1289,9 @@ std::exception_ptr execute(std::vector<SliceP>& slices) {
   GTNX_HOST_T("region.execute");
   ExecScope es;
   std::exception_ptr err;
+  // (a nested join -- a placeholder looked at from inside a batched call -- has copies of its own)
+  std::vector<std::shared_ptr<PendingCopy>> outer;
+  outer.swap(t_pending_copies);
   try {
     apply_stage(slices);
     Run run(slices);
@@ -1289,6 +1304,13 @@ std::exception_ptr execute(std::vector<SliceP>& slices) {
         for (Pending* p : sg.calls)
           if (p->st() == 0) fail(*p, err);
   }
+  // the caller's buffers are promised until parallelMap returns: a copy no sweep of this join made is made now
+  try {
+    for (auto& pc : t_pending_copies) pc->settle();
+  } catch (...) {
+    if (!err) err = std::current_exception();
+  }
+  t_pending_copies.swap(outer);
   // (the calls keep their inputs until their slice dies -- with the last result handle of the thread that
   //  recorded it -- and goes home: nothing is taken apart here)
   slices.clear();

@@ -140,8 +140,30 @@ int main(int argc, char** argv) {
     std::vector<Out> outs = parallelMap(fwd2, targets, scores);
     std::vector<Graph> lossGraphs;
     for (auto& o : outs) lossGraphs.push_back(o.loss);
-    parallelMap(bwd, lossGraphs);
+    // setWeights COPIES (graph.cpp:179-181): once parallelMap has returned the caller may do what it likes with its
+    // buffer.  The engine makes that copy inside the forward sweep of the region, so: wipe
+    // the emissions of the utterances that are checked below before the backward pass runs, and put them back after
     const int nCheck = std::min(B, 24);
+    if (onDevice) {
+      (void)hipDeviceSynchronize();
+      (void)hipMemset(dev, 0, sizeof(float) * size_t(nCheck) * T * M);
+      (void)hipDeviceSynchronize();
+    }
+    parallelMap(bwd, lossGraphs);
+    for (int b = 0; b < nCheck && onDevice; ++b) {  // the graphs still hold the values they were given
+      const float* w = outs[b].em.weights();
+      bool same = true;
+      for (size_t i = 0; i < size_t(T) * M && same; ++i) same = w[i] == hostScores[b][i];
+      if (!same) {
+        std::printf("{\"check\": \"setWeights value semantics\", \"utterance\": %d, \"ok\": false}\n", b);
+        rc = 1;
+      }
+    }
+    if (onDevice) {
+      (void)hipDeviceSynchronize();
+      for (int b = 0; b < nCheck; ++b)
+        (void)hipMemcpy(dev + size_t(b) * T * M, hostScores[b].data(), sizeof(float) * size_t(T) * M, hipMemcpyHostToDevice);
+    }
     for (int built = 0; built < 2; ++built) {
       double worstLoss = 0, worstGrad = 0;
       for (int b = 0; b < nCheck; ++b) {

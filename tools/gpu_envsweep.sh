@@ -13,5 +13,6 @@ for cfg in "$@"; do
     eager_weights) run eager_weights GTNX_REGION_EAGER_WEIGHTS=1 ;;
     no_eager_beta) run no_eager_beta GTNX_NO_EAGER_BETA=1 ;;
     device_levelize) run device_levelize GTNX_DEVICE_LEVELIZE=1 ;;
+    no_fused_copy) run no_fused_copy GTNX_NO_FUSED_COPY=1 ;;
   esac
 done

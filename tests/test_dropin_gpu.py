@@ -69,7 +69,8 @@ def test_reference_ctc_benchmark_runs():
 
 
 @pytest.mark.gpu
-def test_reference_loop_at_c3_matches_one_call_at_a_time():
+@pytest.mark.parametrize("alphabet", [256, 255, 30])  # (255, 30: the scalar staging path of the band sweeps)
+def test_reference_loop_at_c3_matches_one_call_at_a_time(alphabet):
     """tests/native/bm_ctc_c256.cpp in `check` mode at BASELINE config C3's shape (64 utterances): the losses and
     emission gradients of parallelMap(fwd) / parallelMap(bwd) against the same functions called one utterance at a time
     (symbolic lattices: equal to 1e-5; built lattices: the float32 lattice recursion's own rounding), with the
@@ -79,7 +80,7 @@ def test_reference_loop_at_c3_matches_one_call_at_a_time():
     exe = os.path.join(BIN, "bm_ctc_c256")
     if not os.path.exists(exe):
         pytest.fail(f"{exe} missing: run __graft_entry__.build() where /root/reference is available")
-    r = subprocess.run([exe, "64", "256", "3", "device", "check"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([exe, "64", str(alphabet), "3", "device", "check"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     checks = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{"check"')]
     assert len(checks) == 2 and all(c["worst_rel_loss"] <= 1e-5 for c in checks), r.stdout

@@ -132,6 +132,10 @@ struct Structure {
     int64_t valid = 0;
     int ncol = 0, ndead = 0;
     bool uniq = false;  // no two nodes share a label
+    // every node's out-list is exactly the nodes that have in-arcs, in increasing node order, and the accept list
+    // increases too (an ASG transitions graph as examples/asg.cpp builds it): under exact ties the reference's
+    // queue then visits the sources of every product node in node order (ops_lazy.cpp: dense_ties_by_node_order)
+    bool ties_by_node_order = false;
     DevMemP tables;  // [N] labels | [N] node -> column | [ncol] column -> node | [ndead] dead nodes
   };
   std::shared_ptr<DenseInfo> dense[2];

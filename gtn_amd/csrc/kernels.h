@@ -387,6 +387,9 @@ struct LazyGroup {          // utterances that share one explicit graph G
   const float* cmax;          // [N] largest in-arc weight per destination (-inf: none)
   const int* nlab;            // [N] matched label of the node's in-arcs (-1: none)
   int lab_unique;             // no two nodes share a matched label (gradient rows need no atomics)
+  int tie_by_node;            // maxplus_path_kernel: of equal maxima the one from the smallest SOURCE NODE (viterbiPath of
+                              // a transitions graph whose layers the reference's queue visits in node order); 0: the
+                              // first one in in-row order (the reference's in-list order: viterbiScore's gradient)
   float* amax;                // [T+1][nb] row max of alpha[t]   (written by the forward steps)
   float* bmax;                // [T][nb]   row max of em + beta[t+1] + cmax (backward steps)
   float* amaxp;               // [T+1][nb][ntp] the same, one partial per column tile (matrix-core form: reduced into

@@ -273,6 +273,7 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
   }
   int keep_arc = 0, keep_lab = 0;
   float keep_e = 0.0f;
+  const bool by_node = g.tie_by_node != 0;  // (uniform)
   auto step = [&](int t, Rows& rq, const Rows& rp) {  // rq: set to request into, rp: set to park
     const float* prev = rows + ((t - 1) & 1) * N;
     const int lab = nlab[node];  // every matched in-arc of `node` carries this label
@@ -301,7 +302,10 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
         if (k < k1 && r[i].y >= 0) {
           const float x = prev[r[i].x] + __int_as_float(r[i].z) + e;
           same = x > m ? 1 : (x == m ? same + 1 : same);
-          if (x > m) {
+          // of equal maxima the one from the SMALLEST source node (then the earliest record): for a transitions
+          // graph whose every node reaches every node, lists in node order, that is the order the reference's queue
+          // visits the sources in every layer (ops_lazy.cpp: dense_ties_by_node_order) -- its own tie-break
+          if (x > m || (by_node && x == m && r[i].x < bsrc)) {
             m = x;
             arg = k;
             bsrc = r[i].x;
@@ -321,12 +325,14 @@ __global__ __launch_bounds__(64) void maxplus_path_kernel(LazyGroup g, int* path
       const unsigned long long many = __builtin_amdgcn_ballot_w64(at && same > 1);
       if (__builtin_popcountll(holders) > 1 || many != 0ull) tied = 1;
     }
-    arg = wave_min63(m == mx ? arg : INT_MAX);
+    // by node: (source node, lane) -- the lane's own best is already its smallest source; 64 lanes, sources below
+    // 2^24.  Else: the smallest record index holding the maximum (record k sits with lane (k - k0) mod 64)
+    arg = wave_min63((m == mx && arg != INT_MAX) ? (by_node ? ((bsrc << 6) | l) : arg) : INT_MAX);
     if (arg == INT_MAX) {  // cannot happen below a finite best score
       failed = true;
       return;
     }
-    const int wl = (arg - k0) & 63;  // record k sits with lane (k - k0) mod 64, whose own best it is
+    const int wl = by_node ? (arg & 63) : ((arg - k0) & 63);
     bsrc = __builtin_amdgcn_readlane(bsrc, wl);
     barc = __builtin_amdgcn_readlane(barc, wl);
     // the step's arc goes to the lane that owns path index t - 1 (selects: a lane-0 store here would put a

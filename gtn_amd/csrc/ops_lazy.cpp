@@ -124,6 +124,41 @@ bool labels_unique(const std::vector<int>& lab) {
     if (l >= 0 && !seen.insert(l).second) return false;
   return true;
 }
+// Exact ties in viterbiPath of a product that is never built: the reference keeps the arc whose SOURCE left its queue
+// first (shortest.cpp:208-224).  When every node of G has exactly one arc to every node that has in-arcs ("core"
+// nodes), listed in increasing node order -- an ASG transitions graph, arcSort'ed or as built -- that order is the
+// node order in EVERY layer of the product: a core node enters the next layer when its last source is processed,
+// the last source is the same node for all of them (the last one of the current layer: everybody reaches everybody),
+// and they enter in that node's out-list order; layer 0 is the start nodes, whose out-lists have the same order.
+// compose discovers the nodes of a layer in the out-list order of the FIRST node of the previous one, so the accept
+// list of the product is in node order as well.  The max-plus walk breaks ties that way (smallest source node, first
+// accept node), so for such graphs its answer is the reference's -- checked against the unmodified reference under
+// integer weights at alphabets whose in-lists std::sort scrambles (tests/test_lazy_gpu.py).
+static bool dense_ties_by_node_order(const Structure& fs, const std::vector<int>& matched, int C) {
+  const int N = int(fs.N);
+  std::vector<char> core(size_t(N), 0);
+  int ncore = 0;
+  for (int n = 0; n < N; ++n)
+    if (fs.in_off[size_t(n) + 1] > fs.in_off[size_t(n)]) core[size_t(n)] = 1, ++ncore;
+  if (ncore == 0) return false;
+  for (int l : matched)
+    if (l < 0 || l >= C) return false;  // (an arc the chain cannot match is missing from the product)
+  for (int n = 0; n < N; ++n) {
+    const int k0 = fs.out_off[size_t(n)], k1 = fs.out_off[size_t(n) + 1];
+    if (k1 - k0 == 0 && !core[size_t(n)]) continue;  // (an isolated node takes no part)
+    if (k1 - k0 != ncore) return false;
+    int want = 0;
+    for (int k = k0; k < k1; ++k) {
+      while (want < N && !core[size_t(want)]) ++want;
+      if (want >= N || fs.dst[size_t(fs.out_list[size_t(k)])] != want) return false;
+      ++want;
+    }
+  }
+  for (size_t i = 1; i < fs.accept.size(); ++i)
+    if (fs.accept[i] <= fs.accept[i - 1]) return false;
+  return true;
+}
+
 std::shared_ptr<Structure::DenseInfo> dense_info(Structure& fs, bool chain_first, int C) {
   std::shared_ptr<Structure::DenseInfo>& slot = fs.dense[chain_first ? 0 : 1];
   if (slot && slot->C == C) return slot;
@@ -148,6 +183,7 @@ std::shared_ptr<Structure::DenseInfo> dense_info(Structure& fs, bool chain_first
     di->ncol = int(colnode.size());
     di->ndead = int(dead.size());
     di->uniq = labels_unique(di->lab);
+    di->ties_by_node_order = dense_ties_by_node_order(fs, ml, C);
     std::vector<int> ints(di->lab);
     ints.insert(ints.end(), tab.begin(), tab.end());
     ints.insert(ints.end(), colnode.begin(), colnode.end());
@@ -795,7 +831,16 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
     float* pw = reinterpret_cast<float*>(pol + nT);
     int* plen = reinterpret_cast<int*>(pw + nT);
     HIP_CHECK(hipMemsetAsync(plen + v.nb, 0, 4 * size_t(v.nb), rt.stream()));  // (only the max-plus walk reports ties)
-    launch_lazy_path(v, parc, pil, pol, pw, plen, rt.stream());
+    // viterbiPath's ties go by the order the reference's queue visits the sources -- node order, where that is
+    // provable for G (dense_ties_by_node_order); viterbiScore's gradient (LazySdOp::backward) keeps in-row order,
+    // the reference's in-list order
+    std::shared_ptr<Structure::DenseInfo> tdi = st.fixed.s->dense[v.chain_first ? 0 : 1];
+    const bool by_node = st.maxplus && tdi && tdi->ties_by_node_order && !std::getenv("GTNX_NO_NODE_ORDER_TIES");
+    {
+      LazyGroup pv = v;
+      pv.tie_by_node = by_node ? 1 : 0;
+      launch_lazy_path(pv, parc, pil, pol, pw, plen, rt.stream());
+    }
     PinnedMemP host = rt.alloc_pinned(pbytes ? pbytes : 1);  // 16 B per path arc: pageable memory would be staged and slow
     {
       GTNX_HOST_T("lazy_viterbi_path.2_wait_download");
@@ -819,6 +864,9 @@ std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
       if (hlen[b] < 0 || !hlen[size_t(v.nb) + size_t(b)]) continue;
       g_viterbi_ties_seen.fetch_add(1);
       const LazyProduct& lp = *gs[i].s->lazy;
+      // a transitions graph whose layers the reference's queue visits in node order: the walk broke the tie that
+      // way already (dense_ties_by_node_order above)
+      if (by_node) continue;
       const double arcs = double(lp.chain.s->M) * double(lp.fixed.s->A);
       if (arcs <= double(1 << 22) && !std::getenv("GTNX_NO_TIE_RERUN")) rerun[i] = 1;
       else g_viterbi_ties_unresolved.fetch_add(1);

@@ -1228,3 +1228,57 @@ def test_band_viterbi_ties_of_sorted_ctc_targets_are_decided_by_node_ranks(gtn, 
         np.testing.assert_array_equal(paths[b].weights_to_numpy(), rpaths[b].weights_to_numpy())
         assert got_scores[b] == want_scores[b]
         np.testing.assert_array_equal(ems2[b].grad().weights_to_numpy(), rems2[b].grad().weights_to_numpy())
+
+
+@pytest.mark.parametrize("B,T,C,sort", [(4, 9, 9, True), (3, 14, 17, True), (3, 14, 17, False), (2, 12, 40, True)])
+def test_maxplus_viterbi_path_ties_on_asg_transitions_follow_the_reference(gtn, B, T, C, sort):
+    """viterbiPath of emissions o (ASG transitions), never built, under exact ties (integer weights), with the re-run
+    on the built lattice switched OFF: the max-plus walk itself breaks a tie by the smallest source node (and takes
+    the first of equal accept nodes) -- for a graph whose every node reaches every label node, lists in node order,
+    that IS the order the reference's queue visits the sources in every layer (ops_lazy.cpp:
+    dense_ties_by_node_order), so the labels are the UNMODIFIED reference's and no tie is left unresolved.  C = 17, 40:
+    alphabets whose in-lists std::sort leaves in no particular order (the old in-row rule failed there)."""
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "refbackend"))
+    try:
+        import gtn_ref as ref
+    except Exception as e:
+        pytest.skip("needs oracle/_ref: %s" % e)
+
+    def transitions(api, tw):
+        g = api.Graph()
+        g.add_node(True, False)
+        for c in range(C):
+            g.add_node(False, True)
+        for c in range(C):
+            g.add_arc(0, c + 1, c, c, float(tw[c]))
+        for s in range(C):
+            for d in range(C):
+                g.add_arc(s + 1, d + 1, d, d, float(tw[C + s * C + d]))
+        if sort:
+            g.arc_sort()
+        return g
+
+    os.environ["GTNX_NO_TIE_RERUN"] = "1"
+    try:
+        seen0, un0 = gtn.debug_viterbi_ties()
+        for seed in range(4):
+            rng = np.random.default_rng(seed * 7 + C)
+            em = rng.integers(-1, 2, (B, T, C)).astype(np.float32)
+            tw = rng.integers(-1, 2, C * C + C).astype(np.float32)
+            with lazy_mode("1"):
+                ems = gtn.linear_graph_n(B, T, C, torch.from_numpy(em).cuda())
+                comp = gtn.compose(ems, [transitions(gtn, tw)])
+                assert gtn.debug_symbolic_route(comp[0], True) == "maxplus"
+                paths = gtn.viterbi_path(comp)
+            rtr = transitions(ref, tw)
+            for b in range(B):
+                e = ref.linear_graph(T, C)
+                e.set_weights(em[b].reshape(-1))
+                want = ref.viterbi_path(ref.compose(e, rtr))
+                assert paths[b].labels_to_list() == want.labels_to_list(), (seed, b)
+                np.testing.assert_array_equal(paths[b].weights_to_numpy(), want.weights_to_numpy())
+        seen1, un1 = gtn.debug_viterbi_ties()
+        assert seen1 > seen0 and un1 == un0
+    finally:
+        os.environ.pop("GTNX_NO_TIE_RERUN", None)

@@ -612,11 +612,14 @@ def main():
             fence()
             gtn.prof_reset()
             gtn.prof_enable(True)
-            t1 = time.perf_counter()
-            for _ in range(5):
-                vector_step()
-            fence()
-            dt_built = (time.perf_counter() - t1) / 5
+            dt_built = None
+            for _ in range(3):  # (the best of three timed loops of five steps; the profiler sees all fifteen)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    vector_step()
+                fence()
+                d = (time.perf_counter() - t1) / 5
+                dt_built = d if dt_built is None else min(dt_built, d)
             gtn.prof_enable(False)
             pb = {n: gtn.prof_get(n) for n in gtn.prof_names()}
             lb = loss_dev.cpu().numpy()
@@ -648,11 +651,14 @@ def main():
                 vstep()
             fence()
             nv = max(5, min(args.steps, 30))
-            t1 = time.perf_counter()
-            for _ in range(nv):
-                vstep()
-            fence()
-            dv = (time.perf_counter() - t1) / nv
+            dv = None
+            for _ in range(3):  # (a side figure: the best of three timed loops -- one host hiccup is not the path's speed)
+                t1 = time.perf_counter()
+                for _ in range(nv):
+                    vstep()
+                fence()
+                d = (time.perf_counter() - t1) / nv
+                dv = d if dv is None else min(dv, d)
             lv = loss_dev.cpu().numpy()
             reference_api["vector_overloads"] = {
                 "losses_per_s": B / dv, "ms_per_batch": dv * 1e3,

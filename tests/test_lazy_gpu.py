@@ -1239,6 +1239,8 @@ def test_maxplus_viterbi_path_ties_on_asg_transitions_follow_the_reference(gtn, 
     dense_ties_by_node_order), so the labels are the UNMODIFIED reference's and no tie is left unresolved.  C = 17, 40:
     alphabets whose in-lists std::sort leaves in no particular order (the old in-row rule failed there)."""
     import torch
+    if os.environ.get("GTNX_NO_NODE_ORDER_TIES"):
+        pytest.skip("the switch brings the in-row rule back, which is what this test shows to be wrong here")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "refbackend"))
     try:
         import gtn_ref as ref

@@ -14,5 +14,6 @@ for cfg in "$@"; do
     no_eager_beta) run no_eager_beta GTNX_NO_EAGER_BETA=1 ;;
     device_levelize) run device_levelize GTNX_DEVICE_LEVELIZE=1 ;;
     no_fused_copy) run no_fused_copy GTNX_NO_FUSED_COPY=1 ;;
+    no_node_order) run no_node_order GTNX_NO_NODE_ORDER_TIES=1 ;;
   esac
 done

@@ -145,14 +145,41 @@ def parity_in_run(em, tg, losses, grads, T, Cn, U, n):
             want_l[b], g = ctc_loss(e[b], t[b])
             want_g[b] = g.reshape(T, Cn)
         checker = "port (oracle/liboracle.so: C restatement pinned to the reference, tests/test_oracle.py)"
+    # third corner: the same loss and gradient in float64 (tests/ctc_fp64.py: the alpha-beta recursion of
+    # shortest.cpp:86-170 / :33-62 over the product of compose.cpp:377-522 in numpy float64).  The float32 reference
+    # keeps unnormalised scores of magnitude ~8.5 T, so ITS gradients carry ~8 eps |z| of rounding (1.4e-3 at
+    # T = 1000); the gate is therefore the north star's 1e-4 against exact arithmetic, and "no further from exact
+    # arithmetic than the reference itself is" per utterance -- both distances measured here, not assumed.
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from ctc_fp64 import ctc_loss_fp64
     got_l = np.asarray(losses[:n], np.float64)
+    l64 = np.zeros(n)
+    d_gpu = np.zeros(n)
+    d_ref = np.zeros(n)
+    d_gpu_ref = np.zeros(n)
+    closer = 0.0
+    for b in range(n):
+        l64[b], g64, _ = ctc_loss_fp64(e[b], t[b])
+        d_ref[b] = np.abs(want_g[b] - g64).max()
+        if grads is not None:
+            gb = np.asarray(grads[b], np.float64)
+            d_gpu[b] = np.abs(gb - g64).max()
+            d_gpu_ref[b] = np.abs(gb - want_g[b]).max()
+            closer += float(np.mean(np.abs(gb - g64) <= np.abs(want_g[b] - g64)))
     out = {"n": n, "checker": checker,
            "loss_max_rel": float(np.max(np.abs(got_l - want_l) / np.maximum(np.abs(want_l), 1e-30))),
-           "tolerance": "loss_max_rel <= 1e-4 (north_star); grad_max_abs <= 1e-2 (posteriors in [-1, 1]; the reference's own float32 "
-                        "recursion over the built lattice carries ~4e-3 of rounding at T = 1000, DESIGN.md section 4)"}
+           "loss_max_rel_vs_fp64": float(np.max(np.abs(got_l - l64) / np.maximum(np.abs(l64), 1e-30))),
+           "reference_loss_max_rel_vs_fp64": float(np.max(np.abs(want_l - l64) / np.maximum(np.abs(l64), 1e-30))),
+           "tolerance": "losses: <= 1e-4 relative against the reference AND against float64 (north_star).  emission gradients "
+                        "(posteriors in [-1, 1]): max |gpu - float64| <= 1e-4 AND <= max |reference - float64| per utterance "
+                        "(tests/ctc_fp64.py; the reference's own float32 recursion is the larger error, reported beside it)"}
     if grads is not None:
-        out["grad_max_abs"] = float(np.max(np.abs(np.asarray(grads[:n], np.float64) - want_g)))
-    out["ok"] = bool(out["loss_max_rel"] <= 1e-4 and out.get("grad_max_abs", 0.0) <= 1e-2)
+        out["grad_max_abs_vs_fp64"] = float(d_gpu.max())
+        out["reference_grad_max_abs_vs_fp64"] = float(d_ref.max())
+        out["grad_max_abs_vs_reference"] = float(d_gpu_ref.max())
+        out["grad_elements_no_further_from_fp64_than_reference"] = closer / n
+    out["ok"] = bool(out["loss_max_rel"] <= 1e-4 and out["loss_max_rel_vs_fp64"] <= 1e-4
+                     and (grads is None or (d_gpu.max() <= 1e-4 and bool(np.all(d_gpu <= d_ref + 1e-6)))))
     return out
 
 
@@ -698,6 +725,11 @@ def main():
                                    f"fwd+bwd, T={T}, C={Cn}, U={U}, batch={B} per GPU",
                        "global_batch": world * B, "composed_nodes": n_nodes, "composed_arcs": n_arcs,
                        "parallelism": f"dp{world} (utterance sharding, all_gather of losses)",
+                       # (in `config` so that the driver's parsed record keeps them:) ranks in the RCCL process group
+                       # of THIS run (0: no process group), and the same step through the reference's own API
+                       # (parallelMap over per-utterance lambdas, tests/native/bm_ctc_c256.cpp) beside `value`
+                       "rccl_ranks": world if world_dist else 0,
+                       "value_reference_api": ((reference_api or {}).get("reference_loop") or {}).get("losses_per_s"),
                        "host": "python (gtn_amd/api.py)" if native is None else "C++ (include/gtn/, bench_native/ctc_step.cpp)"},
             "roofline": roof,
             # every other kernel family of the timed loop against the same 8 TB/s

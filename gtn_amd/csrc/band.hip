@@ -1722,7 +1722,7 @@ void big_lds(K kern) {
 template <int NPL, int K, bool VEC>
 void launch_fwd2(const BandPair* d, int n, int ns, size_t lds, bool unit, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
-  if (gtnx_first_on_device(done)) {
+  if (gtnx_first_on_device first{done}) {
     big_lds(band_forward_kernel<NPL, true, K, VEC>);
     big_lds(band_forward_kernel<NPL, false, K, VEC>);
   }
@@ -1737,7 +1737,7 @@ void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool ve
 template <int NPL, int K, bool VEC, bool BIG>
 void launch_bwd3(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
-  if (gtnx_first_on_device(done)) {
+  if (gtnx_first_on_device first{done}) {
     big_lds(band_backward_kernel<NPL, true, true, K, VEC, BIG>);
     big_lds(band_backward_kernel<NPL, true, false, K, VEC, BIG>);
     big_lds(band_backward_kernel<NPL, false, true, K, VEC, BIG>);
@@ -1843,7 +1843,7 @@ void launch_band_viterbi(const BandDecode* d_pairs, int n, int stage_floats, int
   }
   if (ranked) return;  // (callers ask band_viterbi_wave_ok first)
   static std::atomic<uint64_t> done{0};
-  if (gtnx_first_on_device(done)) big_lds(band_viterbi_kernel);
+  if (gtnx_first_on_device first{done}) big_lds(band_viterbi_kernel);
   hipLaunchKernelGGL(band_viterbi_kernel, dim3(n), dim3(512), 4 * size_t(1032 + stage_floats) + 64, st, d_pairs);
 }
 

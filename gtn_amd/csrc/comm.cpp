@@ -129,15 +129,62 @@ GTNX_API gtnx_status_t gtnx_comm_create(const int* devices, int n, gtnx_comm_t* 
   });
 }
 
+namespace {
+// One grouped collective over the communicator's devices: the group is ALWAYS closed and the calling thread is put
+// back on its own device, also when a call in between fails -- the first error is kept and thrown after the
+// clean-up (a dangling ncclGroupStart would swallow every later RCCL call of the thread).
+struct RcclGroup {
+  Rccl& r;
+  int back;
+  int first_rc = 0;
+  const char* first_what = nullptr;
+  bool open = false;
+  explicit RcclGroup(Rccl& lib) : r(lib), back(Runtime::current_device()) {
+    note(r.GroupStart(), "ncclGroupStart");
+    open = first_rc == 0;
+  }
+  void note(int rc, const char* what) {
+    if (rc != 0 && first_rc == 0) {
+      first_rc = rc;
+      first_what = what;
+    }
+  }
+  bool ok() const { return first_rc == 0; }
+  void close() {
+    if (open) {
+      open = false;
+      note(r.GroupEnd(), "ncclGroupEnd");
+    }
+    try {
+      Runtime::of(back).activate();
+    } catch (...) {
+    }
+  }
+  void finish() {
+    close();
+    if (first_rc != 0) nccl_check(first_rc, first_what);
+  }
+  ~RcclGroup() { close(); }  // (unwinding from something that is not an RCCL status: an unknown device, ...)
+};
+}  // namespace
+
 GTNX_API gtnx_status_t gtnx_comm_destroy(gtnx_comm_t h) {
   return guarded([&] {
     Comm* c = reinterpret_cast<Comm*>(h);
     if (!c) return;
+    const int back = Runtime::current_device();
+    int first_rc = 0;
     for (size_t k = 0; k < c->comms.size(); ++k) {
-      Runtime::of(c->devices[k]).sync();
-      (void)rccl().CommDestroy(c->comms[k]);
+      try {
+        Runtime::of(c->devices[k]).sync();
+      } catch (...) {  // (a device that failed: its communicator is still given back)
+      }
+      const int rc = rccl().CommDestroy(c->comms[k]);
+      if (rc != 0 && first_rc == 0) first_rc = rc;
     }
     delete c;
+    if (Runtime::initialized()) Runtime::of(back).activate();
+    nccl_check(first_rc, "ncclCommDestroy");
   });
 }
 
@@ -163,14 +210,13 @@ GTNX_API gtnx_status_t gtnx_comm_all_gather_f32(gtnx_comm_t h, const void* const
       return;
     }
     Rccl& r = rccl();
-    nccl_check(r.GroupStart(), "ncclGroupStart");
-    for (size_t k = 0; k < n; ++k) {
+    RcclGroup g(r);
+    for (size_t k = 0; k < n && g.ok(); ++k) {
       Runtime& rt = Runtime::of(c->devices[k]);
       rt.activate();
-      nccl_check(r.AllGather(send[k], recv[k], size_t(count), kNcclFloat, c->comms[k], rt.stream()), "ncclAllGather");
+      g.note(r.AllGather(send[k], recv[k], size_t(count), kNcclFloat, c->comms[k], rt.stream()), "ncclAllGather");
     }
-    nccl_check(r.GroupEnd(), "ncclGroupEnd");
-    Runtime::of(back).activate();
+    g.finish();
   });
 }
 
@@ -179,15 +225,13 @@ GTNX_API gtnx_status_t gtnx_comm_all_reduce_sum_f32(gtnx_comm_t h, void* const* 
     Comm* c = reinterpret_cast<Comm*>(h);
     if (!c || !bufs || count < 0) throw_invalid("[gtnx_comm_all_reduce_sum_f32] bad arguments");
     if (count == 0 || c->comms.empty()) return;  // (one device: the sum of one term)
-    const int back = Runtime::current_device();
     Rccl& r = rccl();
-    nccl_check(r.GroupStart(), "ncclGroupStart");
-    for (size_t k = 0; k < c->devices.size(); ++k) {
+    RcclGroup g(r);
+    for (size_t k = 0; k < c->devices.size() && g.ok(); ++k) {
       Runtime& rt = Runtime::of(c->devices[k]);
       rt.activate();
-      nccl_check(r.AllReduce(bufs[k], bufs[k], size_t(count), kNcclFloat, kNcclSum, c->comms[k], rt.stream()), "ncclAllReduce");
+      g.note(r.AllReduce(bufs[k], bufs[k], size_t(count), kNcclFloat, kNcclSum, c->comms[k], rt.stream()), "ncclAllReduce");
     }
-    nccl_check(r.GroupEnd(), "ncclGroupEnd");
-    Runtime::of(back).activate();
+    g.finish();
   });
 }

@@ -11,14 +11,26 @@
 // them the first time it runs on each device, not once per process (runtime.h: one context per device)
 #include <atomic>
 #include <cstdint>
-inline bool gtnx_first_on_device(std::atomic<uint64_t>& done) {
-  int d = 0;
-  (void)hipGetDevice(&d);
-  const uint64_t bit = uint64_t(1) << (d & 63);
-  if (done.load(std::memory_order_acquire) & bit) return false;
-  done.fetch_or(bit, std::memory_order_acq_rel);
-  return true;
-}
+// `if (auto first = gtnx_first_on_device(done)) { ...hipFuncSetAttribute... }`: the device's bit is published when
+// `first` goes out of scope, i.e. AFTER the attribute calls -- a second thread launching on the same device meanwhile
+// (the side-stream thread) sees it clear and sets the attributes itself (twice is harmless) instead of launching
+// under the default limit
+struct gtnx_first_on_device {
+  std::atomic<uint64_t>& done;
+  uint64_t bit;
+  bool first;
+  explicit gtnx_first_on_device(std::atomic<uint64_t>& d) : done(d) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bit = uint64_t(1) << (dev & 63);
+    first = !(done.load(std::memory_order_acquire) & bit);
+  }
+  gtnx_first_on_device(const gtnx_first_on_device&) = delete;
+  ~gtnx_first_on_device() {
+    if (first) done.fetch_or(bit, std::memory_order_acq_rel);
+  }
+  explicit operator bool() const { return first; }
+};
 
 namespace gtnx {
 

@@ -1535,7 +1535,7 @@ void launch_lazy_step(const LazyGroup& g, int t, int mode, int backward, hipStre
   const dim3 grid((g.N + DT - 1) / DT, (g.nb + BT - 1) / BT);
   const size_t lds = lazy_step_lds_bytes(g);
   static std::atomic<uint64_t> attr_done{0};
-  if (gtnx_first_on_device(attr_done)) {
+  if (gtnx_first_on_device first{attr_done}) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_LOG, false>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_step_kernel<SD_LOG, true>),
@@ -1603,7 +1603,7 @@ void launch_lazy_fixed_grad(const LazyGroup& g, int max_in_deg, hipStream_t st) 
   const dim3 grid((g.N + DT - 1) / DT, (g.nb + BT - 1) / BT, (g.T + t_per_block - 1) / t_per_block);
   const size_t lds = lazy_step_lds_bytes(g) + sizeof(float) * size_t(DT) * size_t(max_in_deg);
   static std::atomic<uint64_t> attr_done{0};
-  if (gtnx_first_on_device(attr_done))
+  if (gtnx_first_on_device first{attr_done})
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lazy_fixed_grad_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
   hipLaunchKernelGGL(lazy_fixed_grad_kernel, grid, dim3(kTile), lds, st, g, t_per_block, max_in_deg);

@@ -427,7 +427,8 @@ int lazy_pair_max_labels(int block) { return SR * block; }  // one emission row 
 namespace {
 void pair_attrs() {
   static std::atomic<uint64_t> attr_done{0};
-  if (!gtnx_first_on_device(attr_done)) return;
+  gtnx_first_on_device first{attr_done};
+  if (!first) return;
   // 512-lane workgroups (and C in the thousands) need more than the default 64 KB of dynamic LDS
   const int lim = 160 * 1024 - 512;
   const void* fns[] = {reinterpret_cast<const void*>(lazy_pair_backward_kernel<256, 16>),

@@ -16,27 +16,42 @@ constexpr int kMaxDevices = 64;
 std::atomic<Runtime*> g_rts[kMaxDevices];
 std::atomic<bool> g_any_rt{false};
 std::mutex g_rt_mu;
-std::atomic<int> g_default_device{-1};   // the first gtnx_set_device of the process (else 0)
+std::atomic<int> g_default_device{-1};   // the first gtnx_set_device of the process (else: what HIP says, below)
 thread_local int t_device = -1;          // the calling thread's choice (-1: the process default)
-thread_local int t_hip_device = -1;      // what this thread last told HIP (-1: unknown)
+
+// What HIP has as the calling thread's device.  Asked, never remembered: the host framework shares the thread
+// (torch.cuda.device(k) is a hipSetDevice behind the engine's back), so a cached answer goes stale.
+// hipGetDevice / hipSetDevice read / write one thread-local of the HIP runtime (tens of nanoseconds).
+int hip_device_now() {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return d;
+}
 
 // a HIP call that must be made with a given device current, from a thread that may be on another one (a block
 // that goes home from wherever its last reference died)
 struct OnDevice {
-  int prev;
-  explicit OnDevice(int d) : prev(t_hip_device) {
-    if (prev != d) {
-      (void)hipSetDevice(d);
-      t_hip_device = d;
-    }
+  int prev, mine;
+  explicit OnDevice(int d) : prev(hip_device_now()), mine(d) {
+    if (prev != d) (void)hipSetDevice(d);
   }
   ~OnDevice() {
-    if (prev >= 0 && prev != t_hip_device) {
-      (void)hipSetDevice(prev);
-      t_hip_device = prev;
-    }
+    if (prev >= 0 && prev != mine) (void)hipSetDevice(prev);
   }
 };
+
+// every thread's list of deferred garbage (Runtime::Inbox), so that empty_cache() and the out-of-memory retry
+// of alloc() can reach device blocks pinned by handles waiting on a thread that never comes to a reclamation
+// point
+std::mutex g_inbox_mu;
+std::vector<std::weak_ptr<Runtime::Inbox>> g_inboxes;
+
+// a foreign list no longer takes more than this: beyond it the sender destroys the object itself (a long-lived
+// thread that builds graphs and never synchronises would otherwise pin everything destroyed elsewhere)
+constexpr size_t kInboxBound = size_t(1) << 14;
 
 size_t round_size(size_t b) {
   if (b < 512) return 512;
@@ -70,7 +85,14 @@ bool Runtime::initialized() { return g_any_rt.load(std::memory_order_acquire); }
 int Runtime::current_device() {
   if (t_device >= 0) return t_device;
   const int d = g_default_device.load(std::memory_order_acquire);
-  return d >= 0 ? d : 0;
+  if (d >= 0) return d;
+  // no gtnx_set_device anywhere yet: the device the calling thread already has with HIP (a rank that only did
+  // torch.cuda.set_device(k) gets its graphs on k, and its thread is left on k), as the process default from here on
+  int now = hip_device_now();
+  if (now < 0 || now >= kMaxDevices) now = 0;
+  int none = -1;
+  g_default_device.compare_exchange_strong(none, now);
+  return g_default_device.load(std::memory_order_acquire);
 }
 
 void Runtime::set_current_device(int d) {
@@ -81,11 +103,7 @@ void Runtime::set_current_device(int d) {
   Runtime::of(d).activate();
 }
 
-void Runtime::activate() {
-  if (t_hip_device == device_) return;
-  HIP_CHECK(hipSetDevice(device_));
-  t_hip_device = device_;
-}
+void Runtime::activate() { HIP_CHECK(hipSetDevice(device_)); }
 
 Runtime& Runtime::of(int d) {
   if (d < 0 || d >= kMaxDevices) throw_invalid("[gtn_amd] device index out of range");
@@ -125,7 +143,6 @@ Runtime::Runtime(int device) : device_(device) {
     mallopt(M_MMAP_THRESHOLD, 32 << 20);
   }
   HIP_CHECK(hipSetDevice(device_));
-  t_hip_device = device_;
   hipDeviceProp_t prop;
   HIP_CHECK(hipGetDeviceProperties(&prop, device_));
   cu_count_ = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -175,7 +192,6 @@ Runtime::SideJobP Runtime::side_launch(std::function<void(hipStream_t)> fn) {
       const int dev = device_;
       sd->th = std::thread([sd, dev] {
         (void)hipSetDevice(dev);
-        t_hip_device = dev;
         t_device = dev;
         for (;;) {
           SideJobP job;
@@ -240,6 +256,14 @@ void Runtime::sync() {
 namespace {
 struct InboxHolder {
   Runtime::InboxP box = std::make_shared<Runtime::Inbox>();
+  InboxHolder() {
+    std::lock_guard<std::mutex> lk(g_inbox_mu);
+    size_t live = 0;  // (drop the entries of threads that are gone while we are here)
+    for (auto& w : g_inboxes)
+      if (!w.expired()) g_inboxes[live++] = std::move(w);
+    g_inboxes.resize(live);
+    g_inboxes.push_back(box);
+  }
   ~InboxHolder() {
     {
       std::lock_guard<std::mutex> lk(box->mu);
@@ -264,12 +288,36 @@ Runtime::InboxP Runtime::home() { return t_home.box; }
 void Runtime::send(const InboxP& to, void* p, void (*del)(void*)) {
   if (to) {
     std::lock_guard<std::mutex> lk(to->mu);
-    if (!to->dead) {
+    if (!to->dead && to->items.size() < kInboxBound) {
       to->items.push_back({p, del});
       return;
     }
   }
-  del(p);
+  del(p);  // dead, or its owner is not keeping up: destroyed by the sender
+}
+
+// every live thread's list, taken apart by the caller (memory pressure: where an object dies matters less than
+// that the device blocks it holds come back)
+void Runtime::drain_all_inboxes() {
+  std::vector<InboxP> boxes;
+  {
+    std::lock_guard<std::mutex> lk(g_inbox_mu);
+    for (auto& w : g_inboxes)
+      if (InboxP b = w.lock()) boxes.push_back(std::move(b));
+  }
+  for (int round = 0; round < 64; ++round) {  // (destructors may send more)
+    bool any = false;
+    for (auto& b : boxes) {
+      std::vector<std::pair<void*, void (*)(void*)>> batch;
+      {
+        std::lock_guard<std::mutex> lk(b->mu);
+        batch.swap(b->items);
+      }
+      any |= !batch.empty();
+      for (auto& e : batch) e.second(e.first);
+    }
+    if (!any) break;
+  }
 }
 
 void Runtime::defer_delete(void* p, void (*del)(void*)) {
@@ -373,7 +421,7 @@ DevMemP Runtime::alloc(size_t bytes) {
     hipError_t e = hipMalloc(&p, sz);
     if (e != hipSuccess) {
       (void)hipGetLastError();
-      empty_cache();
+      empty_cache();  // (every thread's deferred garbage included)
       HIP_CHECK(hipMalloc(&p, sz));
     }
     std::lock_guard<std::mutex> lk(mu_);
@@ -458,7 +506,7 @@ void Runtime::release_pinned(void* p, size_t bytes) {
 
 void Runtime::empty_cache() {
   OnDevice here(device_);
-  drain_deferred();
+  drain_all_inboxes();
   (void)hipStreamSynchronize(stream_);
   std::lock_guard<std::mutex> lk(mu_);
   for (auto& kv : free_dev_) {

@@ -96,7 +96,8 @@ class Runtime {
   };
   using InboxP = std::shared_ptr<Inbox>;
   static InboxP home();                                             // the calling thread's list
-  static void send(const InboxP& to, void* p, void (*del)(void*));  // (null / dead list: destroyed here and now)
+  static void send(const InboxP& to, void* p, void (*del)(void*));  // (null / dead / over-full list: destroyed here and now)
+  static void drain_all_inboxes();                                  // every live thread's list, by the caller (empty_cache, OOM retry)
   static void defer_delete(void* p, void (*del)(void*));            // = send(home(), ...)
   static void drain_deferred();                                     // the calling thread's list, all of it
   static bool drain_some(size_t max_items);

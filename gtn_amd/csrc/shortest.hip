@@ -1254,7 +1254,7 @@ size_t deep_lds_bytes(int maxP, bool backward) {
 void launch_sd_forward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st) {
   if (n <= 0) return;
   static std::atomic<uint64_t> done{0};
-  if (gtnx_first_on_device(done))
+  if (gtnx_first_on_device first{done})
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_forward_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               int(deep_lds_bytes(kDeepP, false)));
   hipLaunchKernelGGL(sd_forward_deep_kernel, dim3(n), dim3(64), deep_lds_bytes(maxP, false), st, d_args);
@@ -1262,7 +1262,7 @@ void launch_sd_forward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t s
 void launch_sd_backward_deep(const SdArgs* d_args, int n, int maxP, hipStream_t st) {
   if (n <= 0) return;
   static std::atomic<uint64_t> done{0};
-  if (gtnx_first_on_device(done))
+  if (gtnx_first_on_device first{done})
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sd_backward_deep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               int(deep_lds_bytes(kDeepP, true)));
   hipLaunchKernelGGL(sd_backward_deep_kernel, dim3(n), dim3(64), deep_lds_bytes(maxP, true), st, d_args);

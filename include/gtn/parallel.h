@@ -140,7 +140,11 @@ class Pool {
     }
     // (sequentially consistent on both sides: a worker either sees the new epoch or is seen as parked)
     epoch_.fetch_add(1, std::memory_order_seq_cst);
-    wakeParked(nthreads);
+    // a job narrower than the last one also wakes the workers that one used and this one does not: they take no
+    // task, but they reclaim what the wider step sent home to them (slices that keep a batch's device memory alive)
+    // instead of sleeping on it for as long as the jobs stay narrow
+    wakeParked(std::max(nthreads, lastWorkers_));
+    lastWorkers_ = nthreads;
     work(*job, true);
     // every task ran and every thread that took one has handed in what it recorded
     size_t spins = 0;
@@ -294,7 +298,12 @@ class Pool {
           lockJob();
           job = job_;
           unlockJob();
-          if (!job || idx >= job->max_workers) continue;
+          static const bool noReclaim = std::getenv("GTN_AMD_NO_RECLAIM") != nullptr;  // (experiments)
+          if (!job || idx >= job->max_workers) {
+            job.reset();
+            if (!noReclaim) gtnx_reclaim();  // (woken only to empty its list: see run())
+            continue;
+          }
           phase_[idx & 63].store(1, std::memory_order_relaxed);
           work(*job, false);
           job.reset();
@@ -302,7 +311,6 @@ class Pool {
           // the caller goes on (the engine runs the region's deferred calls now); this thread takes apart
           // what earlier steps let go of meanwhile -- off the caller's critical path, shared with the
           // pool's other threads
-          static const bool noReclaim = std::getenv("GTN_AMD_NO_RECLAIM") != nullptr;  // (experiments)
           if (!noReclaim) gtnx_reclaim();
           phase_[idx & 63].store(0, std::memory_order_relaxed);
         }
@@ -317,6 +325,7 @@ class Pool {
   std::atomic<uint64_t> epoch_{0};
   std::atomic<bool> stop_{false};
   uint64_t traceSeq_ = 0;
+  size_t lastWorkers_ = 0;  // (under callMutex_)
   std::atomic<int> phase_[64] = {};  // GTN_AMD_POOL_TRACE: 0 idle, 1 in tasks, 2 reclaiming
  public:
   long phaseSum_[3] = {0, 0, 0};

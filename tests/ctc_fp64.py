@@ -58,3 +58,36 @@ def ctc_loss_fp64(emissions, target, blank=0):
     for s in range(S):
         grad[:, lab[s]] -= occ[:, s]
     return loss, grad, None
+
+
+def asg_fp64(em, tw):
+    """float64 restatement of the ASG full-connect term on the dense transitions graph of
+    tests/golden/make_golden_c4.py: transitions (start arcs tw[:C], arc j -> i at tw[C + i * C + j]): score, d/d emissions,
+    d/d transitions (same layout as tw), and the max-plus optimum with its labels"""
+    T, C = em.shape
+    em = em.astype(np.float64)
+    st, W = tw[:C].astype(np.float64), tw[C:].astype(np.float64).reshape(C, C)  # W[i][j]: j -> i
+    lse = lambda x, ax: (lambda m: m + np.log(np.exp(x - np.expand_dims(m, ax)).sum(ax)))(x.max(ax))
+    alpha = np.zeros((T + 1, C))
+    alpha[1] = st + em[0]
+    for t in range(1, T):
+        alpha[t + 1] = em[t] + lse(alpha[t][None, :] + W, 1)
+    Z = lse(alpha[T], 0)
+    beta = np.zeros((T + 1, C))
+    for t in range(T - 1, 0, -1):
+        beta[t] = lse(W + (em[t] + beta[t + 1])[:, None], 0)
+    g_em = np.exp(alpha[1:] + beta[1:] - Z)
+    g_st = np.exp(st + em[0] + beta[1] - Z)
+    g_W = np.zeros((C, C))
+    for t in range(1, T):
+        g_W += np.exp(alpha[t][None, :] + W + (em[t] + beta[t + 1])[:, None] - Z)
+    v = st + em[0]
+    back = []
+    for t in range(1, T):
+        cand = v[None, :] + W
+        back.append(cand.argmax(1))
+        v = em[t] + cand.max(1)
+    lab = [int(v.argmax())]
+    for bp in reversed(back):
+        lab.append(int(bp[lab[-1]]))
+    return Z, g_em, np.concatenate([g_st, g_W.reshape(-1)]), float(v.max()), lab[::-1]

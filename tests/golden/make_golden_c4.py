@@ -3,8 +3,9 @@ tests/golden/asg_c512.npz.  Run where /root/reference has been compiled into ora
 
     python tests/golden/make_golden_c4.py
 
-For T in (17, 100) and B = 2 utterances each (5 M / 26 M product arcs per utterance: compose alone is seconds and
-gigabytes on the CPU -- T = 1000 would be 262 M arcs): forwardScore and viterbiScore of
+For T in (17, 100) and B = 2 utterances each (5 M / 26 M product arcs per utterance) and for BASELINE's own
+T = 1000 (B = 2: 262 M product arcs = ~11 GB and about a minute of the reference per utterance; run with
+`--only T1000`, keys already in the .npz are kept as they are): forwardScore and viterbiScore of
 compose(emissions, transitions), viterbiPath's labels, and after backward(forwardScore) the emission gradients and
 the shared transitions' gradient (summed over the utterances, criterion_test.cpp:289-305).  Inputs are regenerated
 from the seeds by the test (numpy Generator streams are stable); a checksum of them is stored.
@@ -23,7 +24,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "refbackend"))
 
 C = 512
-CASES = [(17, 2, 101), (100, 2, 202)]  # (T, B, seed)
+CASES = [(17, 2, 101), (100, 2, 202), (1000, 2, 303)]  # (T, B, seed)
 
 
 def inputs(T, B, seed):
@@ -46,8 +47,12 @@ def transitions(api, tw):
 def main():
     import gtn_ref as ref
     assert ref.backend() == "reference-cpu"
-    out = {}
+    path = os.path.join(HERE, "asg_c512.npz")
+    only = [a for a in sys.argv[1:] if a.startswith("T")]
+    out = dict(np.load(path)) if only and os.path.exists(path) else {}
     for T, B, seed in CASES:
+        if only and f"T{T}" not in only:
+            continue
         em, tw = inputs(T, B, seed)
         trans = transitions(ref, tw)
         fs, vs, labels, gem = [], [], [], []
@@ -63,6 +68,7 @@ def main():
             ref.backward(f)
             gem.append(e.grad().weights_to_numpy().reshape(T, C).astype(np.float32))
             del comp, f
+            print("  utterance", b, "%.1f s" % (time.time() - t0), flush=True)
         key = f"T{T}"
         out[key + "_seed"] = np.int64(seed)
         out[key + "_input_checksum"] = np.float64(em.astype(np.float64).sum() + 3.0 * tw.astype(np.float64).sum())
@@ -72,7 +78,6 @@ def main():
         out[key + "_grad_emissions"] = np.stack(gem)
         out[key + "_grad_transitions"] = trans.grad().weights_to_numpy().astype(np.float32)
         print(key, "done in %.1f s" % (time.time() - t0), "forward", fs, "viterbi", vs, "labels[0][:8]", labels[0][:8])
-    path = os.path.join(HERE, "asg_c512.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes")
 

@@ -482,8 +482,6 @@ def test_c3_full_size_timed_path_vs_fp64_and_reference(gtn):
             assert got[b] == pytest.approx(l32, rel=1e-4)
             err_ref = np.abs(g32 - g64).max()
             worst_ref = max(worst_ref, err_ref)
-            # |gpu - reference| is bounded by the two errors against exact arithmetic
-            assert np.abs(ge[b] - g32).max() <= err_gpu + err_ref + 1e-7
             assert err_gpu <= err_ref + 1e-6, "the sweep kernels are no less accurate than the float32 reference"
             # gradient of the target graph's arcs (benchmarks/ctc.cpp builds it with calcGrad = true)
             tgt = gg.ctc_target_graph(list(tg[b]))
@@ -827,37 +825,7 @@ def test_built_lattice_viterbi_path_exact_ties_follow_the_reference(gtn, seed, c
         assert float(paths[b].weights_to_numpy().sum()) == np.float32(score)
 
 
-def _asg_fp64(em, tw):
-    """float64 restatement of the ASG full-connect term on the dense transitions graph of
-    test_parity_gpu.asg_transitions (start arcs tw[:C], arc j -> i at tw[C + i * C + j]): score, d/d emissions,
-    d/d transitions (same layout as tw), and the max-plus optimum with its labels"""
-    T, C = em.shape
-    em = em.astype(np.float64)
-    st, W = tw[:C].astype(np.float64), tw[C:].astype(np.float64).reshape(C, C)  # W[i][j]: j -> i
-    lse = lambda x, ax: (lambda m: m + np.log(np.exp(x - np.expand_dims(m, ax)).sum(ax)))(x.max(ax))
-    alpha = np.zeros((T + 1, C))
-    alpha[1] = st + em[0]
-    for t in range(1, T):
-        alpha[t + 1] = em[t] + lse(alpha[t][None, :] + W, 1)
-    Z = lse(alpha[T], 0)
-    beta = np.zeros((T + 1, C))
-    for t in range(T - 1, 0, -1):
-        beta[t] = lse(W + (em[t] + beta[t + 1])[:, None], 0)
-    g_em = np.exp(alpha[1:] + beta[1:] - Z)
-    g_st = np.exp(st + em[0] + beta[1] - Z)
-    g_W = np.zeros((C, C))
-    for t in range(1, T):
-        g_W += np.exp(alpha[t][None, :] + W + (em[t] + beta[t + 1])[:, None] - Z)
-    v = st + em[0]
-    back = []
-    for t in range(1, T):
-        cand = v[None, :] + W
-        back.append(cand.argmax(1))
-        v = em[t] + cand.max(1)
-    lab = [int(v.argmax())]
-    for bp in reversed(back):
-        lab.append(int(bp[lab[-1]]))
-    return Z, g_em, np.concatenate([g_st, g_W.reshape(-1)]), float(v.max()), lab[::-1]
+from ctc_fp64 import asg_fp64 as _asg_fp64  # noqa: E402  (float64 full-connect ASG term: tests/ctc_fp64.py)
 
 
 @pytest.mark.parametrize("T", [1, 17])
@@ -909,14 +877,18 @@ def test_dense_regime_at_the_real_alphabet_vs_fp64(gtn, T):
     assert np.abs(gt - want_gt).max() <= 1e-4
 
 
-@pytest.mark.parametrize("T", [17, 100])
+@pytest.mark.parametrize("T", [17, 100, 1000])
 def test_c4_alphabet_pinned_to_the_reference(gtn, T):
-    """BASELINE config C4's alphabet (ASG, dense transitions, C = 512) against the UNMODIFIED reference compiled
-    here: tests/golden/asg_c512.npz (tests/golden/make_golden_c4.py over oracle/_ref; 5 M / 26 M product arcs per
-    utterance).  forwardScore / viterbiScore within the north-star's 1e-4 relative, viterbiPath's labels EQUAL,
-    emission gradients and the shared transitions' gradient (summed over the utterances) within the reference's
-    own float32 rounding, max(1e-4, 8 eps |score|) -- every product kept symbolic (matrix-core and max-plus
-    kernels).  Mirrors examples/asg.cpp:59-68 and test/criterion_test.cpp:308-345."""
+    """BASELINE config C4 (ASG, dense transitions, C = 512) against the UNMODIFIED reference compiled here:
+    tests/golden/asg_c512.npz (tests/golden/make_golden_c4.py over oracle/_ref; 5 M / 26 M / 262 M product arcs per
+    utterance -- T = 1000 is BASELINE's own size: 11 GB and two minutes of the reference per utterance).
+    forwardScore / viterbiScore within the north-star's 1e-4 relative, viterbiPath's labels EQUAL, emission gradients
+    and the shared transitions' gradient (summed over the utterances) within the reference's own float32 rounding,
+    max(1e-4, 8 eps |score|) -- every product kept symbolic (matrix-core and max-plus kernels).  At T = 1000 that
+    rounding is 8e-3, so there the gradients are ALSO held to the north star's 1e-4 against float64 arithmetic
+    (tests/ctc_fp64.py: asg_fp64), and to being no further from it than the reference's own are (measured: the
+    reference's emission gradients are 1.0e-3 from float64 at this size, its transitions' gradient 5.4e-4).
+    Mirrors examples/asg.cpp:59-68 and test/criterion_test.cpp:308-345."""
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_golden_c4 as mk
@@ -947,6 +919,21 @@ def test_c4_alphabet_pinned_to_the_reference(gtn, T):
     np.testing.assert_allclose(ge, gold[key + "_grad_emissions"], rtol=tol, atol=tol)
     # (an arc of the transitions collects up to B * T posteriors)
     np.testing.assert_allclose(gt, gold[key + "_grad_transitions"], rtol=tol, atol=tol)
+    if T >= 1000:
+        want_gt = np.zeros(C * C + C)
+        for b in range(B):
+            Z, g_em, g_tw, vbest, lab = _asg_fp64(em[b], tw)
+            want_gt += g_tw
+            assert f[b] == pytest.approx(Z, rel=1e-4) and v[b] == pytest.approx(vbest, rel=1e-4)
+            err_gpu = np.abs(ge[b] - g_em).max()
+            err_ref = np.abs(gold[key + "_grad_emissions"][b] - g_em).max()
+            print(f"C4 full size, utterance {b}: max |emission grad - fp64| engine {err_gpu:.2e}, float32 reference {err_ref:.2e}")
+            assert err_gpu <= 1e-4, (b, err_gpu)
+            assert err_gpu <= err_ref + 1e-6
+        err_gpu = np.abs(gt - want_gt).max()
+        err_ref = np.abs(gold[key + "_grad_transitions"] - want_gt).max()
+        print(f"C4 full size: max |transitions grad - fp64| engine {err_gpu:.2e}, float32 reference {err_ref:.2e}")
+        assert err_gpu <= 1e-4 and err_gpu <= err_ref + 1e-6
 
 
 def _route_case(kind, rng):

@@ -188,13 +188,16 @@ def main():
     out["value"] = out.get("asg_criterion_utt_per_s")
     out["unit"] = "utterances/s"
     # in-run parity: the engine in THIS process against the unmodified reference's answers at C4's alphabet
-    # (tests/golden/asg_c512.npz, made by tests/golden/make_golden_c4.py over oracle/_ref: T = 17, C = 512) --
-    # Viterbi labels EQUAL, scores to 1e-4 (the same kernels as the timed batch: matrix-core forward, max-plus decode)
+    # (tests/golden/asg_c512.npz, made by tests/golden/make_golden_c4.py over oracle/_ref: BASELINE's own size,
+    # T = 1000, C = 512, two utterances of 262 M product arcs each) -- Viterbi labels EQUAL, forward and Viterbi
+    # scores to 1e-4 relative, emission gradients within the reference's own float32 rounding (8 eps |score|; the
+    # float64 triangulation at 1e-4 is tests/test_lazy_gpu.py::test_c4_alphabet_pinned_to_the_reference[1000]) --
+    # the same kernels as the timed batch: matrix-core forward / backward, max-plus decode
     try:
         sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
         import make_golden_c4 as mk
         gold = np.load(os.path.join(ROOT, "tests", "golden", "asg_c512.npz"))
-        Tg = 17
+        Tg = 1000 if "T1000_forward" in gold.files and T >= 1000 else 17
         key = f"T{Tg}"
         Bg = gold[key + "_forward"].shape[0]
         emg, twg = mk.inputs(Tg, Bg, int(gold[key + "_seed"]))
@@ -203,15 +206,24 @@ def main():
         try:
             eg = gtn.linear_graph_n(Bg, Tg, mk.C, torch.from_numpy(emg).cuda())
             cg = gtn.compose(eg, [tr])
-            fsg = np.asarray(gtn.items(gtn.forward_score(cg)), np.float64)
+            fg = gtn.forward_score(cg)
+            fsg = np.asarray(gtn.items(fg), np.float64)
+            vsg = np.asarray(gtn.items(gtn.viterbi_score(cg)), np.float64)
             pg = gtn.viterbi_path(cg)
+            gtn.backward(fg)
+            geg = np.stack([x.grad().weights_to_numpy().reshape(Tg, mk.C) for x in eg])
         finally:
             gtn.compose_mode(prevm)
         labels_equal = all(pg[b].labels_to_list() == gold[key + "_labels"][b].tolist() for b in range(Bg))
         rel = float(np.max(np.abs(fsg - gold[key + "_forward"]) / np.abs(gold[key + "_forward"])))
+        relv = float(np.max(np.abs(vsg - gold[key + "_viterbi"]) / np.abs(gold[key + "_viterbi"])))
+        gerr = float(np.max(np.abs(geg - gold[key + "_grad_emissions"])))
+        gtol = float(max(1e-4, 8 * np.finfo(np.float32).eps * np.abs(gold[key + "_forward"]).max()))
         out["parity_in_run"] = {"n": int(Bg), "T": Tg, "C": int(mk.C), "labels_equal": bool(labels_equal), "forward_score_max_rel": rel,
+                                "viterbi_score_max_rel": relv, "grad_emissions_max_abs_vs_reference": gerr,
+                                "grad_tolerance": gtol,
                                 "checker": "reference answers (tests/golden/asg_c512.npz, generated by oracle/_ref)",
-                                "ok": bool(labels_equal and rel <= 1e-4)}
+                                "ok": bool(labels_equal and rel <= 1e-4 and relv <= 1e-4 and gerr <= gtol)}
     except Exception as e:  # reported, and fails the run below
         out["parity_in_run"] = {"error": str(e)[:300], "ok": False}
     print(json.dumps(out))

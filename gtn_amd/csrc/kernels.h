@@ -419,6 +419,8 @@ struct LazyGroup {          // utterances that share one explicit graph G
   const float* ETp;           // [Kpad / 4][Npad2][4] its transpose
   int Kpad, Npad2, nbpad;     // N rounded up to operand batches / to 32; nb rounded up to 32 (max-plus form: to 64)
   int rot;                    // leading nodes without a matched in-arc: the planes index nodes rotated by this many
+  int rel;                    // alpha / beta / amax / bmax / zt are stored RELATIVE to per-row references (matrix-core form,
+                              // lazy.hip "dense regime on the matrix cores"): alpha[t] against RA[t] = sum of amax[0 .. t-1]
   // max-plus form of the dense regime (tropical semiring; maxplus.hip): xt holds alpha itself
   const float* mp_Wq;         // [dblock][Kpad / 2][16][2] largest weight per (source, destination column), -inf: no arc
   const int* mp_colidx;       // [N] node -> destination column, -1 for nodes without a matched in-arc
@@ -639,6 +641,7 @@ size_t lazy_mfma_chain_sync_ints(const LazyGroup& g);
 bool launch_lazy_mfma_chain(const LazyGroup& g, int backward, int* zeroed_sync, int cus, hipStream_t st);
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // order-preserving integer keys -> floats
 void launch_lazy_mfma_rowmax(const LazyGroup& g, int which, hipStream_t st);   // amaxp -> amax (0) / bmaxp -> bmax (1)
+void launch_lazy_mfma_score(const LazyGroup& g, hipStream_t st);               // score (relative, lazy_final) += sum of amax, float64
 void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x T x nb */, hipStream_t st);  // R zero-filled
 
 // ---------------------------------------------------------------------------

@@ -631,6 +631,16 @@ __global__ __launch_bounds__(kDense) void lazy_dense_step_kernel(LazyGroup g, in
 //     itself: the largest operand is then exp(one step's growth), not 1 -- harmless in float32 as
 //     long as a step moves a row's best score by less than ~80 nats, and no pass over the row is
 //     needed before exponentiating;
+//   * the score planes are stored RELATIVE to that reference (LazyGroup::rel): row t + 1 of alpha holds
+//     alpha[t+1] - RA[t+1] with RA[t+1] = RA[t] + m[t], m[t] = the (relative) maximum of row t -- so a stored
+//     value is one step's growth, O(10), not the running score (8.7 per step at C4: 8700 at T = 1000, where one
+//     float32 ulp is 1e-3 and every posterior exp(alpha + beta - Z) carried that much relative error: measured
+//     3.4e-4 on the emission gradients against float64, tests/test_lazy_gpu.py::test_c4_alphabet_pinned_to_the_
+//     reference[1000]).  The next operand is then simply exp(stored value); beta likewise (row t relative to
+//     RB[t] = RB[t+1] + mq[t], mq[t] = the maximum of q[t] = beta[t+1] + em[t] + cmax).  What the consumers
+//     need of the references cancels or is one row maximum: posteriors are normalised per time step
+//     (zt, itself relative), an arc posterior's constant is amax[t] (= RA[t+1] - RA[t]), and the total score is
+//     the last row's log-sum-exp + the sum of the T row maxima, taken in float64 (lazy_mfma_score_kernel);
 //   * the true row maxima (the gradient kernels balance their factors around them) leave the epilogues as
 //     one partial per (row, column tile) -- a plain store -- and every consumer takes the maximum of a
 //     row's partials itself (an atomic max per row and tile cost 2 of a step's 10 microseconds).
@@ -715,7 +725,7 @@ template <bool BWD>
 __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup g, int t) {
   __shared__ float part[MF_WAVES][16][64];
   __shared__ float tr[32][36];
-  __shared__ float refp[32][2][8];  // row maxima, partially reduced (ntp <= 32: eight 16-byte pieces)
+  __shared__ float refp[32][8];  // row maxima, partially reduced (ntp <= 32: eight 16-byte pieces)
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
   // Workgroups go to the 8 XCDs in turn, and every kernel boundary empties their L2s: XCD x takes a
   // contiguous run of tiles in row-major order (all column tiles of its two row tiles at C4), so it
@@ -758,25 +768,23 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     const int b = b0 + rowi[v];
     erow[v] = g.em[b < nb ? b : 0];
   }
-  // Row maxima of the tile's 32 rows: the reference the input was exponentiated against (one step back) and the
-  // one the next input will be (this step's own row): 2 x ntp partials per row, fetched 16 bytes per thread and
-  // combined through LDS on the way to the barrier the partial tiles meet at anyway.
-  const bool has_in = !BWD ? t > 0 : t < g.T - 1;
-  const int t_in = !BWD ? (t > 0 ? t - 1 : 0) : (t < g.T - 1 ? t + 1 : t);
+  // Row maxima of the tile's 32 rows ONE STEP BACK of the output (row t of alpha / of q: complete when this
+  // launch starts) -- the reference the output is stored against and, with it, the one the next input is
+  // exponentiated against: ntp partials per row, fetched 16 bytes per thread and combined through LDS on the way
+  // to the barrier the partial tiles meet at anyway.
   // (requested here, parked in LDS only after the product: the request must not be waited for up front)
   const int Q = ntp >> 2;  // 16-byte pieces per row
-  const int npieces = 32 * 2 * Q;  // <= 512: at most two per thread
-  gtnx_f4 rv[2];
-  int ri[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int i0 = int(threadIdx.x) + u * MF_WAVES * 64;
-    const int i = i0 < npieces ? i0 : int(threadIdx.x) % npieces;
-    ri[u] = i0 < npieces ? i : -1;
-    const int r = i / (2 * Q), j = (i / Q) & 1, q = i % Q;
+  const int npieces = 32 * Q;  // <= 256: at most one per thread
+  gtnx_f4 rv;
+  int ri;
+  {
+    const int i0 = int(threadIdx.x);
+    const int i = i0 < npieces ? i0 : i0 % npieces;
+    ri = i0 < npieces ? i : -1;
+    const int r = i / Q, q = i % Q;
     const int b = b0 + r;
-    const int64_t row = int64_t(j ? t : t_in) * nb + (b < nb ? b : 0);
-    rv[u] = reinterpret_cast<const gtnx_f4*>(Mp + row * ntp)[q];
+    const int64_t row = int64_t(t) * nb + (b < nb ? b : 0);
+    rv = reinterpret_cast<const gtnx_f4*>(Mp + row * ntp)[q];
   }
   // ---- this wave's share of the k groups (4 k each = two MFMAs)
   const int groups = g.Kpad >> 2;
@@ -835,13 +843,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
   acc += acc2;
 #pragma unroll
   for (int v = 0; v < 16; ++v) part[wv][v][l] = acc[v];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    if (ri[u] >= 0) {
-      const int i = ri[u];
-      refp[i / (2 * Q)][(i / Q) & 1][i % Q] = fmaxf(fmaxf(rv[u].x, rv[u].y), fmaxf(rv[u].z, rv[u].w));
-    }
-  }
+  if (ri >= 0) refp[ri / Q][ri % Q] = fmaxf(fmaxf(rv.x, rv.y), fmaxf(rv.z, rv.w));
   __syncthreads();
   // ---- epilogue: registers MF_ROWS wv .. of the summed tile, column lo
   float* outp = BWD ? g.beta + int64_t(t) * plane : g.alpha + int64_t(t + 1) * plane;
@@ -854,15 +856,13 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     float a = 0.0f;
 #pragma unroll
     for (int p = 0; p < MF_WAVES; p += 2) a += part[p][reg][l] + part[p + 1][reg][l];
-    float m_in = refp[i][0][0], m_out = refp[i][1][0];
-    for (int q = 1; q < (ntp >> 2); ++q) {
-      m_in = fmaxf(m_in, refp[i][0][q]);
-      m_out = fmaxf(m_out, refp[i][1][q]);
-    }
-    if (!has_in) m_in = 0.0f;  // the first input of a pass is exponentiated against 0
-    float val = NEG_INF, nxt = NEG_INF;  // alpha[t+1] / beta[t]; the next step's contraction input
-    if (on && ocol && a > 0.0f && m_in != NEG_INF) {
-      val = __logf(a) + m_in;
+    float m_out = refp[i][0];
+    for (int q = 1; q < (ntp >> 2); ++q) m_out = fmaxf(m_out, refp[i][q]);
+    // alpha[t+1] - RA[t+1] / beta[t] - RB[t] (relative: see the head of this section); the next step's contraction
+    // input is exp(nxt) as it stands
+    float val = NEG_INF, nxt = NEG_INF;
+    if (on && ocol && a > 0.0f && m_out != NEG_INF) {
+      val = __logf(a) - m_out;
       if (!BWD) {
         val = lab < 0 ? NEG_INF : val + cm + emv[v];
         nxt = val;
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_step_kernel(LazyGroup
     // five ds_bpermute per row were 2 of a step's 10 microseconds)
     const float rm = half32_max(nxt);
     if (lo == 0 && on && (!BWD || t >= 1)) Mp[(int64_t(BWD ? t - 1 : t + 1) * nb + b) * ntp + (o0 >> 5)] = rm;
-    tr[i][lo] = (nxt == NEG_INF || m_out == NEG_INF) ? 0.0f : __expf(nxt - m_out);
+    tr[i][lo] = nxt == NEG_INF ? 0.0f : __expf(nxt);
   }
   __syncthreads();
   // the next input in operand layout: k group (o0 / 4 + kg), column b0 + bl: one 16-byte store per thread
@@ -1001,9 +1001,9 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_chain_kernel(LazyGrou
       __syncthreads();
       if (sh_abort) return;
     }
-    const bool has_in = !BWD ? t > 0 : t < T - 1;
     const int t_in = !BWD ? (t > 0 ? t - 1 : 0) : (t < T - 1 ? t + 1 : t);
-    // row maxima (partials per column tile) of the input's reference row and of this step's own row
+    // row maxima (partials per column tile) of this step's own row (the other half of the fetch is unused since
+    // the planes went relative)
     mf_f2 rv[2][2];
     int ri[2];
 #pragma unroll
@@ -1052,15 +1052,11 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_chain_kernel(LazyGrou
       float av = 0.0f;
 #pragma unroll
       for (int p = 0; p < MF_WAVES; p += 2) av += part[p][reg][l] + part[p + 1][reg][l];
-      float m_in = refp[i][0][0], m_out = refp[i][1][0];
-      for (int q = 1; q < (ntp >> 2); ++q) {
-        m_in = fmaxf(m_in, refp[i][0][q]);
-        m_out = fmaxf(m_out, refp[i][1][q]);
-      }
-      if (!has_in) m_in = 0.0f;
-      float val = NEG_INF, nxt = NEG_INF;
-      if (on && ocol && av > 0.0f && m_in != NEG_INF) {
-        val = __logf(av) + m_in;
+      float m_out = refp[i][1][0];
+      for (int q = 1; q < (ntp >> 2); ++q) m_out = fmaxf(m_out, refp[i][1][q]);
+      float val = NEG_INF, nxt = NEG_INF;  // (relative planes, as in lazy_mfma_step_kernel)
+      if (on && ocol && av > 0.0f && m_out != NEG_INF) {
+        val = __logf(av) - m_out;
         if (!BWD) {
           val = lab < 0 ? NEG_INF : val + cm + emv[v];
           nxt = val;
@@ -1073,7 +1069,7 @@ __global__ __launch_bounds__(MF_WAVES * 64) void lazy_mfma_chain_kernel(LazyGrou
       if (lo == 0 && on && (!BWD || t >= 1))
         __hip_atomic_store(Mp + (int64_t(BWD ? t - 1 : t + 1) * nb + b) * ntp + (o0 >> 5), rm, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
-      tr[i][lo] = (nxt == NEG_INF || m_out == NEG_INF) ? 0.0f : __expf(nxt - m_out);
+      tr[i][lo] = nxt == NEG_INF ? 0.0f : __expf(nxt);
     }
     __syncthreads();
     if ((!BWD || t >= 1) && threadIdx.x < 256) {
@@ -1128,6 +1124,27 @@ __global__ void lazy_mfma_rowmax_kernel(const float* __restrict__ mp, float* __r
   float m = NEG_INF;
   for (int q = 0; q < ntp; ++q) m = fmaxf(m, mp[i * ntp + q]);
   out[i] = m;
+}
+// relative planes: the total score = log-sum-exp over the accept nodes of the LAST row (lazy_final_kernel, relative
+// to RA[T]) + RA[T], the sum of the T row maxima -- in float64 (a float32 running score of 8700 carries 1e-3)
+__global__ __launch_bounds__(64) void lazy_mfma_score_kernel(LazyGroup g) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0;
+  bool dead = false;
+  for (int t = lane; t < g.T; t += 64) {
+    const float m = g.amax[int64_t(t) * g.nb + b];
+    dead |= m == NEG_INF;
+    s += double(m);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    dead |= __shfl_xor(int(dead), o, 64) != 0;
+  }
+  if (lane == 0) {
+    const float rel = g.score[b];
+    g.score[b] = (dead || rel == NEG_INF || rel == -NEG_INF) ? (dead ? NEG_INF : rel) : float(double(rel) + s);
+  }
 }
 // E zero-padded in operand layout [k / 4][column][k % 4], and its transpose
 __global__ void lazy_mfma_pad_kernel(LazyGroup g, float* Ep, float* ETp) {
@@ -1207,6 +1224,7 @@ __global__ __launch_bounds__(kDense) void lazy_dense_fixed_grad_kernel(LazyGroup
 // lie in HBM pair-major (alpha[t][b][.], beta[t+1][b][.]): the MFMA operand rows are the planes' own
 // rows, exponentiated on the way in (two v_exp_f32 per MFMA, under its 64 cycles).
 // per-pair constants once: {half - amax, half - bmax, delta, valid}, half = (amax + bmax - Z) / 2
+// (relative planes: half = (bmax - zt) / 2 -- see below)
 __global__ void lazy_mfma_pairs_kernel(LazyGroup g, gtnx_f4* pc) {
   const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (p >= int64_t(g.T) * g.nb) return;
@@ -1215,7 +1233,9 @@ __global__ void lazy_mfma_pairs_kernel(LazyGroup g, gtnx_f4* pc) {
   const float am = g.amax[p], bm = g.bmax[p];
   gtnx_f4 c = {0.0f, 0.0f, 0.0f, 0.0f};
   if (z != NEG_INF && z != -NEG_INF && am != NEG_INF && bm != NEG_INF) {
-    const float half = 0.5f * (am + bm - z);
+    // relative planes (g.rel): alpha[t] is stored against RA[t], beta[t+1] against RB[t+1], z = zt[t] against
+    // RA[t+1] + RB[t+1], and RA[t+1] - RA[t] = amax[t]: the pair's constant is -(z + am), balanced as before
+    const float half = 0.5f * (g.rel ? bm - z : am + bm - z);
     c = gtnx_f4{half - am, half - bm, *g.delta[b], 1.0f};
   }
   pc[p] = c;
@@ -1644,6 +1664,9 @@ void launch_lazy_mfma_rowmax(const LazyGroup& g, int which, hipStream_t st) {
   if (rows > 0)
     hipLaunchKernelGGL(lazy_mfma_rowmax_kernel, dim3(unsigned((rows + 255) / 256)), dim3(256), 0, st,
                        (const float*)(which ? g.bmaxp : g.amaxp), which ? g.bmax : g.amax, rows, g.ntp);
+}
+void launch_lazy_mfma_score(const LazyGroup& g, hipStream_t st) {
+  if (g.nb > 0) hipLaunchKernelGGL(lazy_mfma_score_kernel, dim3(unsigned(g.nb)), dim3(64), 0, st, g);
 }
 void launch_lazy_mfma_init(const LazyGroup& g, int which, hipStream_t st) {
   const int64_t nk = int64_t(g.T + 1) * g.nb * g.ntp;

@@ -358,6 +358,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     v.xt[1] = st.dense_mem->as<float>(o_x1);
     st.dense = true;
     st.mfma = getenv("GTNX_DENSE_VALU") == nullptr;
+    v.rel = st.mfma ? 1 : 0;  // the matrix-core sweeps keep their planes relative to per-row references (lazy.hip)
   }
   // chain_first comes from the products themselves (same for a whole group by key)
   for (size_t i = 0; i < gs.size(); ++i) groups[slot[i].first]->view.chain_first = gs[i].s->lazy->chain_side == 1;
@@ -412,6 +413,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
       for (int t = 0; t < st.view.T; ++t) launch_lazy_step(st.view, t, mode, 0, rt.stream());
     }
     launch_lazy_final(st.view, mode, rt.stream());
+    if (st.dense && st.mfma) launch_lazy_mfma_score(st.view, rt.stream());  // + the sum of the row references, in float64
   }
   return groups;
 }

@@ -54,3 +54,35 @@ def test_reference_python_examples_run_on_the_mirror(script, expect, tmp_path):
     if script == "linear_crf.py":
         acc = float(r.stdout.strip().splitlines()[-1].split()[-1])
         assert acc > 0.9, r.stdout[-500:]
+
+
+def test_reference_pybind11_binding_links_against_the_engine(tmp_path):
+    """the reference's own pybind11 modules (bindings/python/gtn/_*.cpp), compiled unmodified against include/gtn and
+    linked to libgtn_amd.so (tests/pydropin/Makefile): the package imports, carries the binding's public names, builds
+    a graph on the host side -- and, with no GPU here, a graph FUNCTION fails loudly (no CPU fallback).  The compute
+    side is tests/test_pydropin_gpu.py."""
+    import glob
+    ext = os.path.join(ROOT, "tests", "pydropin", "_ext")
+    if not glob.glob(os.path.join(ext, "gtn", "_graph*.so")):
+        pytest.skip("tests/pydropin/_ext not built (needs /root/reference: __graft_entry__.build())")
+    prog = (
+        "import gtn\n"
+        "names = ['Graph', 'compose', 'intersect', 'forward_score', 'viterbi_score', 'viterbi_path', 'backward', 'negate',\n"
+        "         'add', 'subtract', 'linear_graph', 'scalar_graph', 'parallel_for', 'closure', 'union', 'concat', 'remove',\n"
+        "         'project_input', 'project_output', 'clone', 'equal', 'isomorphic', 'load', 'save', 'savetxt', 'loadtxt',\n"
+        "         'write_dot', 'rand_equivalent', 'epsilon']\n"
+        "missing = [n for n in names if not hasattr(gtn, n)]\n"
+        "assert not missing, missing\n"
+        "g = gtn.Graph(); g.add_node(True); g.add_node(False, True); g.add_arc(0, 1, 3, 4, 0.5)\n"
+        "assert (g.num_nodes(), g.num_arcs(), g.labels_to_list(), g.labels_to_list(False), g.weights_to_list()) == (2, 1, [3], [4], [0.5])\n"
+        "import torch\n"
+        "if not torch.cuda.is_available():\n"
+        "    try:\n"
+        "        gtn.forward_score(g)\n"
+        "        raise SystemExit('forward_score ran without a GPU')\n"
+        "    except RuntimeError as e:\n"
+        "        assert 'no CPU fallback' in str(e), e\n"
+        "print('PYBIND_OK', gtn.__file__)\n")
+    env = dict(os.environ, PYTHONPATH=ext)
+    r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=300, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0 and "PYBIND_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]

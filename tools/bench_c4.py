@@ -219,11 +219,27 @@ def main():
         relv = float(np.max(np.abs(vsg - gold[key + "_viterbi"]) / np.abs(gold[key + "_viterbi"])))
         gerr = float(np.max(np.abs(geg - gold[key + "_grad_emissions"])))
         gtol = float(max(1e-4, 8 * np.finfo(np.float32).eps * np.abs(gold[key + "_forward"]).max()))
+        # third corner, utterance 0: the same recursion in float64 (tests/ctc_fp64.py: asg_fp64, ~4 s on the host) --
+        # the engine's emission gradients within the north star's 1e-4 of it, and no further from it than the
+        # float32 reference's own are
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from ctc_fp64 import asg_fp64
+        z64, g64, _, v64, _ = asg_fp64(emg[0], twg)
+        d_gpu = float(np.abs(geg[0] - g64).max())
+        d_ref = float(np.abs(gold[key + "_grad_emissions"][0] - g64).max())
+        rel64 = float(abs(fsg[0] - z64) / abs(z64))
         out["parity_in_run"] = {"n": int(Bg), "T": Tg, "C": int(mk.C), "labels_equal": bool(labels_equal), "forward_score_max_rel": rel,
                                 "viterbi_score_max_rel": relv, "grad_emissions_max_abs_vs_reference": gerr,
-                                "grad_tolerance": gtol,
-                                "checker": "reference answers (tests/golden/asg_c512.npz, generated by oracle/_ref)",
-                                "ok": bool(labels_equal and rel <= 1e-4 and relv <= 1e-4 and gerr <= gtol)}
+                                "grad_tolerance_vs_reference": gtol,
+                                "forward_score_rel_vs_fp64": rel64,
+                                "grad_emissions_max_abs_vs_fp64": d_gpu, "reference_grad_emissions_max_abs_vs_fp64": d_ref,
+                                "checker": "reference answers (tests/golden/asg_c512.npz, generated by oracle/_ref) + float64 "
+                                           "restatement (tests/ctc_fp64.py: asg_fp64) of utterance 0",
+                                "tolerance": "labels EQUAL; scores <= 1e-4 relative; emission gradients: max |engine - float64| <= 1e-4 AND "
+                                             "<= max |reference - float64|, and |engine - reference| within the reference's own float32 "
+                                             "rounding (8 eps |score|)",
+                                "ok": bool(labels_equal and rel <= 1e-4 and relv <= 1e-4 and rel64 <= 1e-4 and gerr <= gtol
+                                           and d_gpu <= 1e-4 and d_gpu <= d_ref + 1e-6)}
     except Exception as e:  # reported, and fails the run below
         out["parity_in_run"] = {"error": str(e)[:300], "ok": False}
     print(json.dumps(out))

@@ -381,6 +381,9 @@ def dry_run(args, dist, torch, world, rank, dev):
                           "unit": "losses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
                           "dry_run": True, "data": "none (stand-in step: collectives and timing skeleton only)",
+                          "config": {"workload": "dry run (no kernel)", "global_batch": world * B,
+                                     "parallelism": f"dp{world} (utterance sharding, all_gather of losses)",
+                                     "rccl_ranks": world if world > 1 else 0, "value_reference_api": None},
                           "gather_ok": bool(ok), "per_rank": ranks}))
     if world > 1:
         dist.destroy_process_group()

@@ -89,7 +89,8 @@ def test_asg_shared_transition_grad_all_reduce():
     np.testing.assert_allclose(ret["grad"][6:], ASG_TRANS_GRAD, atol=1e-4)
 
 
-def test_bench_multi_rank_branch_under_gloo():
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_multi_rank_branch_under_gloo(world):
     """bench.py's OWN world > 1 branch -- rendezvous from the torchrun environment, all_gather of the
     per-rank losses, barrier-bracketed timing, max over ranks, the per-rank report -- driven as the round
     driver launches it (python -m torch.distributed.run ... bench.py --gpus N), with --dry-run-cpu standing
@@ -97,17 +98,19 @@ def test_bench_multi_rank_branch_under_gloo():
     import json
     import subprocess
     port = 29600 + (os.getpid() % 300)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4",
+    port += world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4",
            "--warmup", "1", "--batch", "8", "--dry-run-cpu"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout      # rank 0 prints ONE line
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["n_gpus"] == world and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["dry_run"] is True and out["gather_ok"] is True
-    assert [p["rank"] for p in out["per_rank"]] == [0, 1]
+    assert [p["rank"] for p in out["per_rank"]] == list(range(world))   # the 8-GPU line: eight per_rank entries
+    assert out["config"]["rccl_ranks"] == world and out["config"]["global_batch"] == world * 8
     assert all(p["host_threads"] >= 1 for p in out["per_rank"])
     # max over ranks: the reported step time is no shorter than any rank's own
     assert out["ms_per_step"] * 4 >= 1e3 * max(p["seconds"] for p in out["per_rank"]) - 1e-6

@@ -248,40 +248,55 @@ def main():
 
 
 def cpu_baseline(C):
-    """the unmodified reference (oracle/_ref) on this host: forwardScore(compose(emissions, transitions)) +
-    backward for ONE utterance at T = 20 (the product has C^2 (T - 1) + C arcs: 5 M at C = 512; T = 1000 would
-    take minutes and ~20 GB per utterance), one thread -- reported per utterance and per product arc so that it
-    can be set against the full-size numbers above (262 M arcs per utterance)"""
-    import ctypes as Ct
+    """the unmodified reference (oracle/_ref) on this host's cores: forwardScore(compose(emissions, transitions)) +
+    backward through the binding's VECTOR overloads (parallelMap: one utterance per host thread, as many utterances as
+    the host has logical cores -- bounded by memory) at T = 20: the product has C^2 (T - 1) + C arcs, 5 M at C = 512
+    (~0.25 GB per utterance in the reference's layout); T = 1000 is 262 M arcs = 11 GB and two minutes per utterance
+    (tests/golden/make_golden_c4.py), so the full size is reported as the per-arc extrapolation"""
     path = os.path.join(ROOT, "oracle", "_ref", "libgtn_ref.so")
     if not os.path.exists(path):
         return None
     try:
         import subprocess
+        cores = os.cpu_count() or 1
+        try:
+            import psutil
+            room = int(psutil.virtual_memory().available / (0.6 * 2 ** 30))  # utterances that fit, with margin
+        except Exception:
+            room = 16
+        n = int(max(1, min(cores, room, 512)))
         code = (
             "import os, sys, time, numpy as np\n"
             "sys.path.insert(0, %r)\n"
             "sys.path.insert(0, os.path.join(%r, 'tests', 'refbackend'))\n"
             "import gtn_ref as gtn\n"
-            "C, T = %d, 20\n"
+            "C, T, n = %d, 20, %d\n"
             "rng = np.random.default_rng(0)\n"
-            "g = gtn.Graph(); n = np.arange(C)\n"
+            "g = gtn.Graph(); k = np.arange(C)\n"
             "g.add_nodes(np.array([1] + [0] * C, np.uint8), np.array([0] + [1] * C, np.uint8))\n"
-            "src = np.concatenate([np.zeros(C, np.int32), np.tile(n + 1, C).astype(np.int32)])\n"
-            "dst = np.concatenate([n + 1, np.repeat(n + 1, C)]).astype(np.int32)\n"
-            "lab = np.concatenate([n, np.repeat(n, C)]).astype(np.int32)\n"
+            "src = np.concatenate([np.zeros(C, np.int32), np.tile(k + 1, C).astype(np.int32)])\n"
+            "dst = np.concatenate([k + 1, np.repeat(k + 1, C)]).astype(np.int32)\n"
+            "lab = np.concatenate([k, np.repeat(k, C)]).astype(np.int32)\n"
             "g.add_arcs(src, dst, lab, lab, rng.random(C * C + C).astype(np.float32))\n"
-            "e = gtn.linear_graph(T, C); e.set_weights((rng.random(T * C) * 10 - 5).astype(np.float32).tolist())\n"
-            "t0 = time.perf_counter(); f = gtn.forward_score(gtn.compose(e, g)); gtn.backward(f); dt = time.perf_counter() - t0\n"
-            "print(dt)\n" % (ROOT, ROOT, C))
-        env = dict(os.environ)
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+            "es = []\n"
+            "for b in range(n):\n"
+            "    e = gtn.linear_graph(T, C); e.set_weights((rng.random(T * C) * 10 - 5).astype(np.float32)); es.append(e)\n"
+            "t0 = time.perf_counter()\n"
+            "f = gtn.forward_score(gtn.compose(es, [g]))\n"
+            "gtn.backward(f)\n"
+            "dt = time.perf_counter() - t0\n"
+            "print(dt)\n" % (ROOT, ROOT, C, n))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ))
         dt = float(r.stdout.strip().splitlines()[-1])
         arcs = C * C * 19 + C
-        return {"kind": "reference", "cores": 1, "seconds_per_utterance_T20": dt, "product_arcs": arcs,
-                "ns_per_product_arc": dt / arcs * 1e9,
-                "sample": f"forwardScore(compose(emissions, transitions)) + backward of ONE utterance, T=20, C={C}, "
-                          "unmodified reference on one host thread; T=1000 extrapolates linearly in arcs"}
+        full = C * C * 999 + C
+        return {"kind": "reference", "cores": int(min(cores, n)), "utterances": n, "seconds_T20": dt,
+                "value": n / dt * arcs / full, "unit": "utterances/s (T=1000, extrapolated per product arc from T=20)",
+                "utterances_per_s_T20": n / dt, "product_arcs_per_utterance_T20": arcs,
+                "ns_per_product_arc_per_core": dt * min(cores, n) / (n * arcs) * 1e9,
+                "sample": f"forwardScore(compose(emissions, transitions)) + backward of {n} utterances at T=20, C={C}, through the "
+                          f"unmodified reference's vector overloads (parallelMap on {min(cores, n)} of the host's {cores} logical "
+                          f"cores, one utterance each), {dt:.1f}s wall; T=1000 is 52.6x the arcs per utterance"}
     except Exception as e:
         return {"error": str(e)[:200]}
 

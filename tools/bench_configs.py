@@ -317,7 +317,7 @@ def c3v():
     try:
         ref = ref_api()
         cores = os.cpu_count() or 1
-        nref = int(min(B, max(4, min(cores, 64))))
+        nref = int(min(B, max(4, cores)))  # one utterance per host thread: ALL the host's logical cores (count stated below)
         rc = [gg.to_api(ref, gg.ctc_target_graph(tg[b].tolist())) for b in range(nref)]
         for g in rc:
             g.arc_sort()

@@ -182,6 +182,28 @@ extern "C" __attribute__((visibility("default"))) double gtn_bench_forward_score
   }
 }
 
+// The same through gtn::Batch (batch records: the B chains over the tensor as ONE object, include/gtn/batch.h): the
+// form bench.py's headline uses for C3.  Returns the mean milliseconds per batch (< 0: error).
+extern "C" __attribute__((visibility("default"))) double gtn_bench_forward_score_linear_batch(const void* emissions, int B, int T,
+                                                                                            int C, void* scores_dev, int iters) {
+  try {
+    auto once = [&]() {
+      Batch ems = Batch::linear(B, T, C, emissions, /*calcGrad=*/true, /*borrow=*/true);
+      batched::forwardScore(ems).itemsToDevice(scores_dev);
+    };
+    for (int i = 0; i < 10; ++i) once();
+    detail::check(gtnx_synchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < iters; ++i) once();
+    detail::check(gtnx_synchronize());
+    const auto t1 = std::chrono::steady_clock::now();
+    return std::chrono::duration<double, std::milli>(t1 - t0).count() / iters;
+  } catch (const std::exception& e) {
+    g_error = e.what();
+    return -1.0;
+  }
+}
+
 // BASELINE config C3's shape through the reference's decode: parallelMap over a per-utterance function that builds
 // the target graph and the emission graph and returns viterbiPath(intersect(ctc, emissions)) (functions.cpp:324-330;
 // the loop of benchmarks/ctc.cpp with viterbiPath in place of the loss), reference names only.  `iters` repetitions

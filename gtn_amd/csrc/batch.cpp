@@ -269,7 +269,7 @@ Batch::~Batch() {
     const size_t e = std::min(graphs.size(), i + 32);
     part->reserve(e - i);
     for (size_t k = i; k < e; ++k) part->push_back(std::move(graphs[k]));
-    rt.defer_delete(part, [](void* q) { delete static_cast<std::vector<Graph>*>(q); });
+    rt.defer_delete(part, [](void* q) { delete static_cast<std::vector<Graph>*>(q); }, e - i);
   }
   graphs.clear();
 }
@@ -620,6 +620,7 @@ void batch_materialise(Batch& x) {
     push_grads_to_graphs(x);
     return;
   }
+  GraphSlabScope slab_scope(size_t(x.n > 0 ? x.n : 0));  // the elements' pieces out of one allocation (graph.h)
   std::vector<Graph> gs;
   switch (x.fal && x.kind == Batch::GRAPHS ? Batch::CTC_TARGETS : x.kind) {
     case Batch::GRAPHS: break;
@@ -651,7 +652,7 @@ void batch_materialise(Batch& x) {
       gs.reserve(size_t(x.n));
       const int64_t A = int64_t(x.M) * x.C;
       for (int i = 0; i < x.n; ++i) {
-        Graph g(x.calc_grad);
+        Graph g = Graph::make_result(x.calc_grad);  // (out of the scope's slab: an element refers to nothing)
         Structure& s = *g.s;
         s.kind = KIND_LINEAR;
         s.M = x.M;
@@ -863,6 +864,42 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
     BatchP r = result(Batch::SCALAR, x->n, op);
     r->v_mem = x->nc_mem;
     r->v_dev = x->nc_norm;
+    return r;
+  }
+  if (!tropical && native(*x, Batch::LINEAR) && !x->materialised && x->n > 0 && x->M > 0) {
+    // forwardScore of B chains over one [B][M][C] tensor (BASELINE config C2) as ONE record: row log-sum-exps summed
+    // per chain (misc.hip: linear_rows_kernel / linear_forward_kernel, shortest.cpp:86-170 on a chain), no element
+    // graphs; the gradient is the softmax of every row (BFsLinearOp, as when a sweep left the scores behind)
+    if (x->w_pend) x->w_pend->settle();  // (the values are read here: graph.h PendingCopy)
+    auto op = std::make_shared<BFsLinearOp>();
+    op->inputs = {x};
+    const int n = x->n;
+    DevMemP res = rt.alloc(sizeof(float) * size_t(n) * 9);
+    float* scal = res->as<float>();
+    float* partial = scal + n;
+    std::vector<LinArgs> args;
+    args.resize(size_t(n));
+    const size_t A = size_t(x->M) * size_t(x->C);
+    for (int b = 0; b < n; ++b) {
+      LinArgs& a = args[size_t(b)];
+      a.w = x->w_dev + size_t(b) * A;
+      a.M = x->M;
+      a.C = x->C;
+      a.out_score = scal + b;
+      a.partial = partial + size_t(b) * 8;
+      a.delta = nullptr;
+      a.grad = nullptr;
+      a.accumulate = 0;
+    }
+    DevMemP d = upload_vec(args);
+    const bool vec_rows = x->C % 4 == 0 && x->C <= 1024 && (reinterpret_cast<uintptr_t>(x->w_dev) & 15) == 0 && (A % 4) == 0;
+    {
+      GTNX_PROF("linear_forward", 4.0 * double(A) * n);
+      launch_linear_forward(d->as<LinArgs>(), n, 0, vec_rows ? 1 : 0, rt.stream());
+    }
+    BatchP r = result(Batch::SCALAR, n, op);
+    r->v_mem = res;
+    r->v_dev = scal;
     return r;
   }
   batch_materialise(*x);

@@ -817,7 +817,10 @@ GTNX_API gtnx_status_t gtnx_batch_destroy(gtnx_batch_t b) {
     auto* p = reinterpret_cast<BatchP*>(b);
     if (!p) return;
     if (Runtime::initialized())  // like gtnx_graph_destroy: taken apart off the caller's critical path
-      Runtime::get().defer_delete(p, [](void* q) { delete static_cast<BatchP*>(q); });
+      // (weight: the graphs a materialised record stands for -- a scoring loop that never blocks must not pile up
+      //  records of hundreds of graphs behind one-pointer entries, runtime.cpp: kDeferFull)
+      Runtime::get().defer_delete(p, [](void* q) { delete static_cast<BatchP*>(q); },
+                                  (*p && (*p)->materialised) ? size_t((*p)->n > 0 ? (*p)->n : 1) : 1);
     else
       delete p;
   });

@@ -1,6 +1,8 @@
 // graph.cpp -- host graph model, HBM residency and level scheduling.
 #include "graph.h"
 
+#include <new>
+
 #include <unordered_set>
 
 #include "gtn/parallel.h"  // header-only worker pool (no engine dependency)
@@ -461,6 +463,132 @@ void Weights::ensure_host() {
 // ======================================================================
 // Graph
 // ======================================================================
+namespace {
+// (graph.h: GraphSlabScope)  One raw buffer, handed out front to back by the one thread whose scope it is --
+// as the ALLOCATOR of the results' shared pieces (std::allocate_shared: object and reference count side by side in
+// the buffer), so that every piece still dies on its own when its last reference goes, and only the MEMORY is
+// pooled: the buffer is given back when the last piece carved out of it has been destroyed.  (A slab whose pieces
+// all lived as long as the slab did -- aliases of one owner -- leaked: a result's gradient state holds its op
+// record, the op record may hold another result's structure, and nothing could break that ring.)
+struct SlabBuf {
+  std::atomic<long> live{1};  // the scope's own reference + one per allocation
+  char* base;
+  size_t cap, used = 0;
+};
+constexpr size_t kSlabPerGraph =
+    ((sizeof(Structure) + 63) & ~size_t(63)) + ((sizeof(Weights) + 63) & ~size_t(63)) + ((sizeof(GradState) + 63) & ~size_t(63)) + 192;
+// The raw buffers go round a small per-thread cache: a slab of 256 graphs is 330 KB, which the allocator maps and
+// unmaps on every use (above its mmap threshold) -- 80 fresh pages to fault in per slab
+// (tools/nullhip/small_step c2b).  A buffer retires to the cache of whichever thread destroys the last piece.
+struct SlabCache {
+  struct Buf {
+    char* p;
+    size_t cap;
+  };
+  std::vector<Buf> bufs;
+  ~SlabCache() {
+    for (auto& b : bufs) ::operator delete(b.p, std::align_val_t(64));
+  }
+};
+// (null once the thread's destructors have run: buffers that retire later -- the thread's own deferred garbage is
+//  taken apart by a thread-exit destructor too, in unspecified order -- are freed directly)
+SlabCache* slab_cache() {
+  struct Holder {
+    SlabCache* c = new SlabCache();
+    ~Holder() {
+      SlabCache* dead = c;
+      c = nullptr;
+      delete dead;
+    }
+  };
+  thread_local Holder h;
+  return h.c;
+}
+std::atomic<long> g_slab_hit{0}, g_slab_miss{0}, g_slab_drop{0};
+struct SlabStats {
+  ~SlabStats() {
+    if (std::getenv("GTNX_SLAB_STATS"))
+      std::fprintf(stderr, "[gtnx] graph slabs: %ld from the cache, %ld fresh, %ld freed past a full cache\n", g_slab_hit.load(),
+                   g_slab_miss.load(), g_slab_drop.load());
+  }
+} g_slab_stats;
+SlabBuf* slab_open(size_t bytes) {
+  SlabBuf* b = new SlabBuf();
+  if (SlabCache* c = slab_cache()) {
+    for (size_t i = 0; i < c->bufs.size(); ++i)
+      if (c->bufs[i].cap >= bytes && c->bufs[i].cap <= 2 * bytes) {
+        b->base = c->bufs[i].p;
+        b->cap = c->bufs[i].cap;
+        c->bufs[i] = c->bufs.back();
+        c->bufs.pop_back();
+        g_slab_hit.fetch_add(1, std::memory_order_relaxed);
+        return b;
+      }
+  }
+  g_slab_miss.fetch_add(1, std::memory_order_relaxed);
+  if (std::getenv("GTNX_SLAB_DEBUG")) {
+    SlabCache* c = slab_cache();
+    std::fprintf(stderr, "slab miss: want %zu; cache %p holds", bytes, (void*)c);
+    if (c) for (auto& x : c->bufs) std::fprintf(stderr, " %zu", x.cap);
+    std::fprintf(stderr, "\n");
+  }
+  b->base = static_cast<char*>(::operator new(bytes, std::align_val_t(64)));
+  b->cap = bytes;
+  return b;
+}
+void slab_release(SlabBuf* b) {
+  if (b->live.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+  SlabCache* c = slab_cache();
+  if (c && c->bufs.size() < 8 && b->cap <= (size_t(4) << 20)) c->bufs.push_back({b->base, b->cap});
+  else {
+    if (std::getenv("GTNX_SLAB_DEBUG")) std::fprintf(stderr, "slab drop: cache %p size %zu cap %zu\n", (void*)c, c ? c->bufs.size() : 0, b->cap);
+    g_slab_drop.fetch_add(1, std::memory_order_relaxed);
+    ::operator delete(b->base, std::align_val_t(64));
+  }
+  delete b;
+}
+template <class T>
+struct SlabAlloc {
+  using value_type = T;
+  SlabBuf* buf;
+  explicit SlabAlloc(SlabBuf* b) : buf(b) {}
+  template <class U>
+  SlabAlloc(const SlabAlloc<U>& o) : buf(o.buf) {}
+  T* allocate(size_t n) {
+    const size_t bytes = n * sizeof(T), off = (buf->used + 63) & ~size_t(63);
+    buf->live.fetch_add(1, std::memory_order_relaxed);  // (also for what does not fit: deallocate looks at the buffer's range)
+    if (off + bytes <= buf->cap) {
+      buf->used = off + bytes;
+      return reinterpret_cast<T*>(buf->base + off);
+    }
+    return static_cast<T*>(::operator new(bytes));
+  }
+  void deallocate(T* p, size_t) {
+    const char* c = reinterpret_cast<const char*>(p);
+    if (!(c >= buf->base && c < buf->base + buf->cap)) ::operator delete(p);
+    slab_release(buf);
+  }
+  template <class U>
+  bool operator==(const SlabAlloc<U>& o) const { return buf == o.buf; }
+  template <class U>
+  bool operator!=(const SlabAlloc<U>& o) const { return buf != o.buf; }
+};
+thread_local SlabBuf* t_slab = nullptr;
+}  // namespace
+
+GraphSlabScope::GraphSlabScope(size_t n) {
+  static const bool off = std::getenv("GTNX_NO_GRAPH_SLAB") != nullptr;
+  if (off || n < 8) return;
+  prev_ = t_slab;  // (scopes nest: every scope has a buffer of its own)
+  t_slab = slab_open(n * kSlabPerGraph);
+  active_ = true;
+}
+GraphSlabScope::~GraphSlabScope() {
+  if (!active_) return;
+  slab_release(t_slab);
+  t_slab = static_cast<SlabBuf*>(prev_);
+}
+
 Graph::Graph(bool calc_grad)
     : s(std::make_shared<Structure>()), w(std::make_shared<Weights>()), g(std::make_shared<GradState>()) {
   s->home = Runtime::home();
@@ -468,12 +596,25 @@ Graph::Graph(bool calc_grad)
   g->calc_grad = calc_grad;
 }
 
+// fresh pieces for an op RESULT: out of the calling thread's slab scope when there is one (graph.h)
+Graph Graph::make_result(bool calc_grad) {
+  SlabBuf* sl = t_slab;
+  if (!sl || sl->used + kSlabPerGraph > sl->cap) return Graph(calc_grad);
+  Graph out{Graph::Empty{}};
+  out.s = std::allocate_shared<Structure>(SlabAlloc<Structure>(sl));
+  out.w = std::allocate_shared<Weights>(SlabAlloc<Weights>(sl));
+  out.g = std::allocate_shared<GradState>(SlabAlloc<GradState>(sl));
+  out.s->home = Runtime::home();
+  out.s->device = Runtime::current_device();
+  out.g->calc_grad = calc_grad;
+  return out;
+}
+
 Graph::Graph(bool calc_grad, std::shared_ptr<Structure> shared)
     : s(std::move(shared)), w(std::make_shared<Weights>()), g(std::make_shared<GradState>()) {
   g->calc_grad = calc_grad;
 }
 
-Graph Graph::make_result(bool calc_grad) { return Graph(calc_grad); }
 
 int Graph::add_node(bool start, bool accept) {
   s->materialize();

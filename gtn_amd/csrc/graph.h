@@ -258,6 +258,26 @@ void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vecto
 
 struct GradState;
 
+// The three pieces of a graph (structure 824 bytes, weights, gradient state) for MANY graphs out of ONE buffer:
+// while a scope is alive on the calling thread, Graph::make_result -- the RESULTS of an op, the elements of a batch
+// record -- carves its pieces (and their reference counts) out of the scope's buffer instead of three heap blocks of
+// its own.  A vector function's n results are 3 n blocks of ~1 KB otherwise -- beyond the allocator's per-thread
+// caches, so each is a trip through its bins both ways, and their memory is cold by the time it comes round again
+// (tools/nullhip/small_step c2).  Every piece keeps a lifetime of its own (it is destroyed when its last reference
+// goes); the buffer goes back to a per-thread cache when the last piece carved out of it has died.  A scope that
+// runs out falls back to the heap; scopes nest (each has its own buffer).  The price: ONE result kept alive keeps
+// its whole buffer (n x 1.3 KB).  n < 8: no buffer.
+struct GraphSlabScope {
+  explicit GraphSlabScope(size_t n);
+  ~GraphSlabScope();
+  GraphSlabScope(const GraphSlabScope&) = delete;
+  GraphSlabScope& operator=(const GraphSlabScope&) = delete;
+
+ private:
+  bool active_ = false;
+  void* prev_ = nullptr;  // the enclosing scope's buffer, shelved
+};
+
 struct Graph {
   std::shared_ptr<Structure> s;
   std::shared_ptr<Weights> w;

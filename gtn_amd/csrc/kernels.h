@@ -209,8 +209,10 @@ struct PathArgs {
   const GTNX_G float* scores;
   const GTNX_G float* w;
   GTNX_G int* path_pos;           // [cap] position of the node each path arc enters
+  GTNX_G int* pred;               // [P] scratch: position of the node each position's best in-arc leaves (-1: none)
+  GTNX_G int* tmp;                // [cap] scratch: the visited positions, last first
 };
-void launch_path_chase(const PathArgs* d_args, int n, int max_cap, hipStream_t st);
+void launch_path_chase(const PathArgs* d_args, int n, int max_cap, int max_P, hipStream_t st);
 
 // ---------------------------------------------------------------------------
 // linear-chain emissions graphs: forwardScore / viterbiScore and their grads

@@ -55,7 +55,7 @@ void init_scalar_result(Graph& g) {
 Graph make_output(const std::shared_ptr<OpRecord>& op, int idx, std::vector<Graph> inputs) {
   bool cg = false;
   for (auto& i : inputs) cg |= i.calc_grad();
-  Graph out(cg);
+  Graph out = Graph::make_result(cg);
   if (cg) {
     out.g->op = op;
     out.g->op_idx = idx;
@@ -285,6 +285,7 @@ struct ScalarOp : OpRecord {
 };
 
 std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Graph>& b) {
+  GraphSlabScope slab_scope(std::max(a.size(), b.size()));  // the results' pieces out of one allocation (graph.h)
   static const char* msg1[] = {"[gtn::negate] input must have only one arc",
                                "[gtn::add] inputs must have only one arc",
                                "[gtn::subtract] inputs must have only one arc"};

@@ -172,6 +172,7 @@ void flush_chain_plan() {
 }
 
 std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   Runtime& rt = Runtime::get();
   auto op = std::make_shared<BandSdOp>();
   op->seq = next_seq();
@@ -398,6 +399,7 @@ bool ctc_tie_ranks(Structure& s, bool use_ilabel, const std::vector<int>** kahn,
 }
 
 std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   Runtime& rt = Runtime::get();
   const size_t n = gs.size();
   GTNX_HOST_T("band_viterbi.total");

@@ -292,6 +292,7 @@ struct SdOp : OpRecord {
 
 
 std::vector<Graph> op_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   GTNX_HOST_T("shortest_distance.total");
   const size_t n = gs.size();
   std::vector<Graph> outs(n, Graph(false));
@@ -554,6 +555,7 @@ struct PathOp : OpRecord {
 };
 
 std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   const size_t n = gs.size();
   std::vector<Graph> outs;
   if (n == 0) return outs;
@@ -590,25 +592,35 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
   for (auto& g : gs)
     if (g.s->sched->error) throw_invalid(kCycleMsg);  // shortest.cpp:229-232
   const int m = int(n);
+  // the arena: what comes back to the host first and together (per graph: 4 ints + five arrays of `cap`), then the
+  // per-position scratch (scores, back-pointers, predecessor positions: 12 bytes per node, never downloaded)
   size_t bytes = 0;
-  std::vector<size_t> off_s(m), off_a(m), off_r(m), off_p(m);
+  std::vector<size_t> off_s(m), off_a(m), off_r(m), off_p(m), off_q(m), off_t(m);
   std::vector<int> cap(m);
   for (int k = 0; k < m; ++k) {
     const DSched& v = gs[k].s->sched->view;
     cap[k] = std::max(v.L, 1);
+    off_p[k] = bytes;
+    bytes = align_up(bytes + 20 * size_t(cap[k]) + 16, 256);
+  }
+  const size_t path_bytes = bytes;
+  for (int k = 0; k < m; ++k) {
+    const DSched& v = gs[k].s->sched->view;
     off_s[k] = bytes;
     bytes = align_up(bytes + 4 * size_t(v.P), 256);
     off_a[k] = bytes;
     bytes = align_up(bytes + 4 * size_t(v.P), 256);
+    off_q[k] = bytes;
+    bytes = align_up(bytes + 4 * size_t(v.P), 256);
+    off_t[k] = bytes;
+    bytes = align_up(bytes + 4 * size_t(cap[k]), 256);
     off_r[k] = bytes;
     bytes += 256;
-    off_p[k] = bytes;
-    bytes = align_up(bytes + 20 * size_t(cap[k]) + 16, 256);
   }
   DevMemP arena = rt.alloc(bytes);
   std::vector<SdArgs> args(m);
   std::vector<PathArgs> pargs(m);
-  int max_cap = 1;
+  int max_cap = 1, max_P = 1;
   int64_t tot_in = 0, tot_p = 0;
   for (int k = 0; k < m; ++k) {
     Graph& g = gs[k];
@@ -642,7 +654,10 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     p.cap = cap[k];
     p.scores = a.scores;
     p.w = a.w;
+    p.pred = arena->as<int>(off_q[k]);
+    p.tmp = arena->as<int>(off_t[k]);
     max_cap = std::max(max_cap, cap[k]);
+    max_P = std::max(max_P, a.s.P);
     tot_in += g.s->sched->n_in;
     tot_p += a.s.P;
   }
@@ -661,11 +676,16 @@ std::vector<Graph> op_viterbi_path(std::vector<Graph>& gs) {
     }
     narrow = narrow && tot_levels >= 32 * int64_t(m);
     launch_sd_forward(d->as<SdArgs>(), m, SD_PATH, narrow ? 2 : 0, int(tot_p ? (tot_in * 16) / tot_p : 0), rt.stream());
-    launch_path_chase(dp->as<PathArgs>(), m, max_cap, rt.stream());
+    launch_path_chase(dp->as<PathArgs>(), m, max_cap, max_P, rt.stream());
   }
-  // the path is at most L arcs: bring it to the host and build the chain graph there
-  std::vector<char> host(bytes);
-  rt.d2h_sync(host.data(), arena->ptr, bytes);
+  // the path is at most L arcs: bring it to the host (the path region of the arena only, into pinned memory: the
+  // scores and back-pointers stay where they are -- 140 MB of them per 64 CTC lattices) and build the chain graph there
+  PinnedMemP host_mem = rt.alloc_pinned(path_bytes ? path_bytes : 1);
+  rt.d2h_sync(host_mem->ptr, arena->ptr, path_bytes);
+  struct HostView {
+    const char* p;
+    const char* data() const { return p; }
+  } host{host_mem->as<char>()};
   // Exact ties on a path through a product that carries compose's own schedule (ties by arc id, positions =
   // node ids): rerun those on the schedule that replays the reference's queue (graph.cpp:
   // build_host_schedule), whose rank IS the reference's relaxation order.  Host-built graphs have it already.

@@ -122,6 +122,7 @@ int64_t match_bound(const LabelHist& a, const LabelHist& b) {
 }
 
 std::vector<Graph> op_compose(std::vector<Graph>& av, std::vector<Graph>& bv, bool intersect) {
+  GraphSlabScope slab_scope(std::max(av.size(), bv.size()));  // the results' pieces out of one allocation (graph.h)
   return op_compose_impl(av, bv, intersect, true);
 }
 

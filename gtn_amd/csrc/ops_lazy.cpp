@@ -591,6 +591,7 @@ struct LazySdOp : OpRecord {
 };
 
 std::vector<Graph> lazy_group_shortest_distance(std::vector<Graph>& gs, bool tropical) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   auto op = std::make_shared<LazySdOp>();
   op->mode = tropical ? SD_TROPICAL : SD_LOG;
   op->seq = next_seq();
@@ -694,6 +695,7 @@ struct LazyPairSdOp : OpRecord {
 };
 
 std::vector<Graph> lazy_pair_forward_score(std::vector<Graph>& gs) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   Runtime& rt = Runtime::get();
   auto op = std::make_shared<LazyPairSdOp>();
   op->seq = next_seq();
@@ -791,6 +793,7 @@ void LazyPathOp::backward(std::vector<Member>& ms) {
 }
 
 std::vector<Graph> lazy_viterbi_path(std::vector<Graph>& gs) {
+  GraphSlabScope slab_scope(gs.size());  // the results' pieces out of one allocation (graph.h)
   {
     std::vector<Graph> br, gr;
     std::vector<size_t> bi, gi;

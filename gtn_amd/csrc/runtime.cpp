@@ -286,10 +286,15 @@ thread_local InboxHolder t_home;
 Runtime::InboxP Runtime::home() { return t_home.box; }
 
 void Runtime::send(const InboxP& to, void* p, void (*del)(void*)) {
+  if (to && to.get() == t_home.box.get()) {  // the caller's own list: counted, and taken apart when it is full
+    defer_delete(p, del, 1);
+    return;
+  }
   if (to) {
     std::lock_guard<std::mutex> lk(to->mu);
     if (!to->dead && to->items.size() < kInboxBound) {
       to->items.push_back({p, del});
+      to->load += 1;
       return;
     }
   }
@@ -312,6 +317,7 @@ void Runtime::drain_all_inboxes() {
       {
         std::lock_guard<std::mutex> lk(b->mu);
         batch.swap(b->items);
+        b->load = 0;
       }
       any |= !batch.empty();
       for (auto& e : batch) e.second(e.first);
@@ -320,7 +326,17 @@ void Runtime::drain_all_inboxes() {
   }
 }
 
-void Runtime::defer_delete(void* p, void (*del)(void*)) {
+// a thread's own list is taken apart once it holds this many objects even if the thread never comes to a blocking
+// point (a scoring loop that leaves its results on the device): beyond a few thousand the garbage of SEVERAL
+// iterations is waiting, every new iteration allocates cold memory instead of what the last one let go of, and the
+// host pays in page faults and cache misses (tools/nullhip/small_step c2: 155 page faults = 0.3 ms per batch of 256)
+static const size_t kDeferFull = [] {
+  const char* e = std::getenv("GTNX_DEFER_FULL");
+  const long v = e ? std::atol(e) : 0;
+  return size_t(v > 0 ? v : 2048);
+}();
+
+void Runtime::defer_delete(void* p, void (*del)(void*), size_t weight) {
   Inbox& b = *t_home.box;
   bool full = false, dead = false;
   {
@@ -329,7 +345,8 @@ void Runtime::defer_delete(void* p, void (*del)(void*)) {
       dead = true;  // (the thread is on its way out: destroyed now)
     } else {
       b.items.push_back({p, del});
-      full = b.items.size() >= (1u << 15);
+      b.load += weight ? weight : 1;
+      full = b.load >= kDeferFull;
     }
   }
   if (dead) del(p);
@@ -352,6 +369,7 @@ bool Runtime::drain_some(size_t max_items) {
     const size_t n = std::min(max_items, b.items.size());
     batch.assign(b.items.end() - long(n), b.items.end());
     b.items.resize(b.items.size() - n);
+    if (b.items.empty()) b.load = 0;
   }
   for (auto& e : batch) e.second(e.first);  // (destructors may defer more)
   return true;

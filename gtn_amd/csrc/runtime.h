@@ -92,13 +92,14 @@ class Runtime {
   struct Inbox {
     std::mutex mu;
     std::vector<std::pair<void*, void (*)(void*)>> items;
+    size_t load = 0;    // what the waiting items stand for, in graphs (an item may be a vector of them): reset when the list runs empty
     bool dead = false;  // the thread is gone: whoever has garbage for it takes it apart on the spot
   };
   using InboxP = std::shared_ptr<Inbox>;
   static InboxP home();                                             // the calling thread's list
   static void send(const InboxP& to, void* p, void (*del)(void*));  // (null / dead / over-full list: destroyed here and now)
   static void drain_all_inboxes();                                  // every live thread's list, by the caller (empty_cache, OOM retry)
-  static void defer_delete(void* p, void (*del)(void*));            // = send(home(), ...)
+  static void defer_delete(void* p, void (*del)(void*), size_t weight = 1);  // weight: graphs behind the pointer            // = send(home(), ...)
   static void drain_deferred();                                     // the calling thread's list, all of it
   static bool drain_some(size_t max_items);
   static size_t deferred_count();                                   // entries waiting on the calling thread's list

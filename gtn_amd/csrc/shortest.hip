@@ -1151,41 +1151,89 @@ __global__ __launch_bounds__(kBlock) void sd_backward_narrow_kernel(const SdArgs
 }
 
 // --------------------------------------------------------------------------
-// viterbiPath pointer chase (shortest.cpp:239-260); one lane per graph
+// viterbiPath pointer chase (shortest.cpp:239-260).
+// Following back-pointers through HBM is one dependent trip to memory per step (two, through the in-row slot:
+// argmax[c] -> in_srcpos[k]) -- 1000 steps of a CTC lattice were 5.7 ms for ANY batch (0.8 % of HBM, round 4's
+// review).  The chase itself is serial, but what it reads is not: (1) path_pred_kernel turns the back-pointers into
+// predecessor POSITIONS for every node at once (a gather, fully parallel); (2) positions are a topological order
+// (the schedule's: predecessors come first), so the walk only ever moves DOWN -- a workgroup stages the window of
+// `kChaseWin` positions below the current node into LDS with coalesced loads and one lane walks it there (an LDS
+// round trip per step instead of an HBM one), window after window; (3) the arcs' ids, labels and weights are
+// gathered by all lanes once the visited positions are known.  Layered lattices (compose products: ~180 positions
+// per level) cross ~45 levels per window; a graph whose arcs jump further than a window degrades to one window per
+// step, the old cost.
 // --------------------------------------------------------------------------
-__global__ void path_chase_kernel(const PathArgs* __restrict__ args, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const PathArgs a = args[i];
-  a.path_len[2] = 0;  // path_tie_kernel only ever sets it
-  int cur = a.result->argmax_final;
-  const int has_node = cur != -1;
-  int len = 0;
-  // first pass: length
-  for (int c = cur; c != -1 && a.argmax[c] != -1 && len < a.cap;) {
+constexpr int kChaseWin = 8192;  // positions per window (32 KB of LDS)
+constexpr int kChaseBlock = 256;
+__global__ void path_pred_kernel(const PathArgs* __restrict__ args) {
+  const PathArgs a = args[blockIdx.y];
+  const int P = a.s.P;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < P; c += gridDim.x * blockDim.x) {
     const int k = a.argmax[c];
-    c = a.s.in_srcpos[k];
-    ++len;
+    a.pred[c] = k >= 0 ? a.s.in_srcpos[k] : -1;
   }
-  int pos = len;
-  for (int c = cur; c != -1 && a.argmax[c] != -1 && pos > 0;) {
+}
+__global__ __launch_bounds__(kChaseBlock) void path_chase_kernel(const PathArgs* __restrict__ args, int n) {
+  if (int(blockIdx.x) >= n) return;
+  const PathArgs a = args[blockIdx.x];
+  __shared__ int win[kChaseWin];
+  __shared__ int sh_cur, sh_len, sh_done;
+  const int tid = threadIdx.x;
+  const int first = a.result->argmax_final;
+  if (tid == 0) {
+    a.path_len[2] = 0;  // path_tie_kernel only ever sets it
+    sh_cur = first;
+    sh_len = 0;
+    sh_done = first == -1 ? 1 : 0;
+  }
+  __syncthreads();
+  while (!sh_done) {
+    const int c0 = sh_cur, hi = c0 + 1, lo = max(0, hi - kChaseWin);
+    // (every lane's loads of the window are in flight together: unconditional, clamped)
+    int v[kChaseWin / kChaseBlock];
+#pragma unroll
+    for (int j = 0; j < kChaseWin / kChaseBlock; ++j) v[j] = a.pred[min(lo + tid + j * kChaseBlock, c0)];
+#pragma unroll
+    for (int j = 0; j < kChaseWin / kChaseBlock; ++j) win[tid + j * kChaseBlock] = v[j];
+    __syncthreads();
+    if (tid == 0) {
+      int c = c0, len = sh_len, done = 0;
+      for (;;) {
+        if (len >= a.cap) { done = 1; break; }
+        const int p = win[c - lo];
+        if (p == -1) { done = 1; break; }  // (argmax[c] == -1: the path starts here)
+        a.tmp[a.cap - 1 - len] = c;
+        ++len;
+        c = p;
+        if (c < lo || c > c0) break;  // below the window: stage the next one
+      }
+      sh_cur = c;
+      sh_len = len;
+      sh_done = done;
+    }
+    __syncthreads();
+  }
+  const int len = sh_len;
+  // the path, first arc first: ids, labels, weights (gathers, all lanes)
+  for (int i = tid; i < len; i += kChaseBlock) {
+    const int c = a.tmp[a.cap - len + i];
     const int k = a.argmax[c];
     const int arc = a.s.in_arc[k];
-    --pos;
-    a.path_arcs[pos] = arc;
+    a.path_arcs[i] = arc;
     if (a.g.kind == KIND_LINEAR) {
-      a.path_il[pos] = arc % a.g.C;
-      a.path_ol[pos] = arc % a.g.C;
+      a.path_il[i] = arc % a.g.C;
+      a.path_ol[i] = arc % a.g.C;
     } else {
-      a.path_il[pos] = a.g.il[arc];
-      a.path_ol[pos] = a.g.ol[arc];
+      a.path_il[i] = a.g.il[arc];
+      a.path_ol[i] = a.g.ol[arc];
     }
-    a.path_w[pos] = a.g.w[arc];
-    a.path_pos[pos] = c;
-    c = a.s.in_srcpos[k];
+    a.path_w[i] = a.g.w[arc];
+    a.path_pos[i] = c;
   }
-  a.path_len[0] = len;
-  a.path_len[1] = has_node;
+  if (tid == 0) {
+    a.path_len[0] = len;
+    a.path_len[1] = first != -1;
+  }
 }
 
 // Exact ties on the path.  The reference's shortestPath relaxes a node's in-arcs in the order their sources
@@ -1316,9 +1364,11 @@ void launch_sd_backward(const SdArgs* d_args, int n, int mode, int narrow, int a
     launch_bwd_mode<SD_TROPICAL>(d_args, n, g, st);
 }
 
-void launch_path_chase(const PathArgs* d_args, int n, int max_cap, hipStream_t st) {
+void launch_path_chase(const PathArgs* d_args, int n, int max_cap, int max_P, hipStream_t st) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(path_chase_kernel, dim3((n + 63) / 64), dim3(64), 0, st, d_args, n);
+  const unsigned pb = unsigned(std::min(std::max((max_P + 1023) / 1024, 1), 256));  // (4 positions per lane, grid-stride beyond)
+  hipLaunchKernelGGL(path_pred_kernel, dim3(pb, unsigned(n)), dim3(256), 0, st, d_args);
+  hipLaunchKernelGGL(path_chase_kernel, dim3(unsigned(n)), dim3(kChaseBlock), 0, st, d_args, n);
   hipLaunchKernelGGL(path_tie_kernel, dim3(unsigned((std::max(max_cap, 1) + 255) / 256), unsigned(n)), dim3(256), 0, st, d_args);
 }
 

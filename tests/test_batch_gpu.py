@@ -267,3 +267,38 @@ def test_batch_ctc_c5_shape_vs_fp64(gtn):
         assert abs(got[b] - want) <= 1e-5 * abs(want), (got[b], want)
         assert np.abs(g[b] - wgrad).max() <= 2e-4
     assert grad.sum(dim=2).abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize("B,T,C", [(256, 150, 32), (5, 37, 7), (9, 1, 1030)])
+def test_batch_linear_forward_score_is_one_record(gtn, B, T, C):
+    """BASELINE config C2: forwardScore of B linear chains over one tensor through gtn::Batch runs as ONE record (no
+    element graphs: batch.cpp batch_shortest_distance, LINEAR) -- scores against float64 row log-sum-exps, the gradient
+    (softmax of every row, creations.cpp:20-33 + shortest.cpp:33-62 on a chain) against float64 and against the
+    per-graph vector path; odd alphabets (scalar rows) and C > 1024 (the split kernel) included"""
+    import torch
+    rng = np.random.default_rng(B * 7 + C)
+    em = (rng.random((B, T, C), dtype=np.float32) * 10 - 5).astype(np.float32)
+    em_dev = _dev(em)
+    ems = gtn.Batch.linear(B, T, C, em_dev, True, True)
+    gtn.prof_reset()
+    gtn.prof_enable(True)
+    fs = gtn.forward_score(ems)
+    gtn.prof_enable(False)
+    assert "linear_forward" in gtn.prof_names()
+    grad = torch.full((B, T, C), float("nan"), device="cuda:0")
+    ems.bind_grads(grad, np.arange(B, dtype=np.int64) * T * C)
+    gtn.backward(fs)
+    got = fs.items()
+    ems.grads_to_device(grad, np.arange(B, dtype=np.int64) * T * C)
+    g = grad.cpu().numpy()
+    e64 = em.astype(np.float64)
+    lse = np.logaddexp.reduce(e64, axis=2)
+    np.testing.assert_allclose(got, lse.sum(axis=1), rtol=2e-6, atol=1e-4)
+    np.testing.assert_allclose(g, np.exp(e64 - lse[:, :, None]), rtol=1e-5, atol=2e-6)
+    # the per-graph vector path on the same tensor
+    gs = gtn.linear_graph_n(B, T, C, em_dev)
+    fv = gtn.forward_score(gs)
+    gtn.backward(fv)
+    np.testing.assert_allclose(got, gtn.items(fv), rtol=1e-6, atol=1e-5)
+    k = B // 2
+    np.testing.assert_allclose(g[k], gs[k].grad().weights_to_numpy().reshape(T, C), rtol=1e-6, atol=1e-7)

@@ -37,7 +37,7 @@
 #include "kernels.h"
 
 #ifdef GTNX_BAND_TIMING
-__device__ long long g_band_timing[128];
+__device__ long long g_band_timing[256];
 #endif
 
 namespace gtnx {
@@ -53,6 +53,9 @@ constexpr int WGB = 768;  // the backward sweep: 4 sweeper + 4 staging + 4 drain
 constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
 constexpr int NBG = 7;   // blocks the backward sweep keeps: one landing, four in use, one being summed, one draining
 constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest of their chunk
+#ifndef GTNX_FWD_DEPTH
+#define GTNX_FWD_DEPTH 2
+#endif
 
 #ifdef GTNX_BAND_TIMING
 // diagnostic build (tools/ubench/band_bench.hip): cycles per phase of a tick, wave 0 of workgroup 0
@@ -72,7 +75,7 @@ constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest o
   do {                                                                      \
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) {                       \
       for (int i_ = 0; i_ < 7; ++i_) g_band_timing[tm_base + (threadIdx.x >> 6) * 7 + i_] += tm_acc[i_]; \
-      if (threadIdx.x == 0) g_band_timing[tm_base + 63] += tm_n;            \
+      if (threadIdx.x == 0) g_band_timing[tm_base + 127] += tm_n;           \
     }                                                                       \
   } while (0)
 #else
@@ -384,7 +387,9 @@ template <int NPL, bool UNIT, int K, bool VEC>
 __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
   constexpr int RNk = K >= 4 ? 4 : K;  // rows between shifts of a wave's running row
   constexpr int NP = K / RNk;          // shift periods per block
-  constexpr int D = 8 / K;             // ticks a staged chunk is in flight (8 rows ahead)
+  // ticks a staged chunk is in flight: 8 rows ahead, and never less than two ticks -- with one (K = 8) a request had
+  // ~1.5 us to come back and the landing wave waited another 1000 cycles for it every tick (band_bench_tm: land 1056)
+  constexpr int D = 8 / K > GTNX_FWD_DEPTH ? 8 / K : GTNX_FWD_DEPTH;
   const BandPair P = pairs[blockIdx.x];
   const int T = P.T, C = P.C, NS = P.NS;
   extern __shared__ float lds[];
@@ -437,8 +442,12 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
       const int beta = tau - w;
-      if (beta >= 0 && beta < nblocks) {
-        const int t0 = beta * K, rows = min(K, T - t0);
+      // (every block but the last holds K rows: that one, the common one, is compiled without the per-row tests --
+      //  a wave issues one instruction per four cycles whatever its kind, and the scalar compare / branch / exec-mask
+      //  instructions of `i < rows` were a sixth of the 583 a tick of eight rows took)
+      auto block = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int t0 = beta * K, rows = FULL ? K : min(K, T - t0);
         const float* eb = ering + (beta % NBE) * K * CS;
         float ev[K][NPL], bv1[K], bv2[K];
         double offp[NP + 1];
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
         float dconv = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-          if (i < rows) {
+          if (FULL || i < rows) {
             if (i % RNk == 0) dconv = float(offp[i / RNk] - off);
             const float b1 = bv1[i] + dconv, b2 = bv2[i] + dconv;
             const float p1 = wave_shr1(a[NPL - 1], b1);
@@ -501,7 +510,7 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
         if (writer) {  // this wave never loads from HBM, so it never waits for these
 #pragma unroll
           for (int i = 0; i < K; ++i)
-            if (i < rows) {
+            if (FULL || i < rows) {
               arow += NS;
 #pragma unroll
               for (int j = 0; j < NPL; ++j) arow[j] = hist[i][j];
@@ -511,7 +520,7 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
         if (NPL == 1 ? l >= 62 : l == 63) {
 #pragma unroll
           for (int i = 0; i < K; ++i)
-            if (i < rows) {
+            if (FULL || i < rows) {
               float* bp = bnd_own + ((((beta & 3) * K + i + 1) & (4 * K - 1))) * 2;
               if (NPL == 1) {
                 bp[63 - l] = hist[i][0];
@@ -521,6 +530,10 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
               }
             }
         }
+      };
+      if (beta >= 0 && beta < nblocks) {
+        if (beta * K + K <= T) block(std::true_type{});
+        else block(std::false_type{});
       }
       GTNX_TM(5);
       lds_barrier();
@@ -551,14 +564,17 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
     auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
     auto issue = [&](Stage<8>& s, int c) { s.template issue<VEC>(P.em + int64_t(c) * K * C, rows_of(c) * C, hid); };
     GTNX_G float* const em_copy = P.em_copy;  // (uniform; null on every path but a region's first sweep)
-    auto land = [&](const Stage<8>& s, int c) {
+    // COPY is a compile-time choice (the helper's loop is instantiated twice, selected once, below): the copy's stores
+    // and their address arithmetic are not in the loop of the launches that make no copy
+    auto land = [&](const Stage<8>& s, int c, auto copy_tag) {
+      constexpr bool COPY = decltype(copy_tag)::value;
       float* base = ering + (c % NBE) * K * CS;
       GTNX_G float* cdst = em_copy + int64_t(c) * K * C;
       s.template each<VEC>(rows_of(c) * C, C, hid, [&](int, int e, int r, int col, gtnx_f4 q) {
         float* d = base + r * CS + col;
         if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
         else d[0] = em2(q.x);
-        if (em_copy) {  // the values as they came (natural log), where the backward sweep will read them
+        if (COPY) {  // the values as they came (natural log), where the backward sweep will read them
           // (non-temporal: 16 bytes per lane that nothing in this launch reads again -- 0.334 -> 0.303 ms at C3; the
           //  same on the alpha rows and the gradient rows, 4 bytes per lane, measured slower and is not done)
           if (vec) __builtin_nontemporal_store(q, reinterpret_cast<GTNX_G gtnx_f4*>(cdst + e));
@@ -616,33 +632,37 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
         normacc += double(l2);
       }
     };
-    // prologue: chunk 0 landed, chunks 1 .. D requested
-    issue(st[0], 0);
-    land(st[0], 0);
+    auto run = [&](auto copy_tag) {
+      // prologue: chunk 0 landed, chunks 1 .. D requested
+      issue(st[0], 0);
+      land(st[0], 0, copy_tag);
 #pragma unroll
-    for (int c = 1; c <= D; ++c) issue(st[c % D], c);
-    lds_barrier();
-    for (int tau0 = 0; tau0 < nticks; tau0 += D) {
+      for (int c = 1; c <= D; ++c) issue(st[c % D], c);
+      lds_barrier();
+      for (int tau0 = 0; tau0 < nticks; tau0 += D) {
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        const int tau = tau0 + d;
-        if (tau >= nticks) break;
-        GTNX_TM(0);
-        // chunk tau + 1 lands (its ring block was last read a tick ago), chunk tau + 1 + D is requested
-        land(st[(d + 1) % D], tau + 1);
-        GTNX_TM(1);
-        issue(st[(d + 1) % D], tau + 1 + D);
-        GTNX_TM(2);
-        if (want_lse) {
-          if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
-          if (tau < nblocks) lse_a(tau);
+        for (int d = 0; d < D; ++d) {
+          const int tau = tau0 + d;
+          if (tau >= nticks) break;
+          GTNX_TM(0);
+          // chunk tau + 1 lands (its ring block was last read a tick ago), chunk tau + 1 + D is requested
+          land(st[(d + 1) % D], tau + 1, copy_tag);
+          GTNX_TM(1);
+          issue(st[(d + 1) % D], tau + 1 + D);
+          GTNX_TM(2);
+          if (want_lse) {
+            if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
+            if (tau < nblocks) lse_a(tau);
+          }
+          GTNX_TM(4);
+          lds_barrier();
+          GTNX_TM(6);
+          GTNX_TM_TICK();
         }
-        GTNX_TM(4);
-        lds_barrier();
-        GTNX_TM(6);
-        GTNX_TM_TICK();
       }
-    }
+    };
+    if (em_copy) run(std::true_type{});  // (uniform)
+    else run(std::false_type{});
     if (hid < 16) M.red[hid] = normacc;
   }
   GTNX_TM_DUMP();
@@ -704,7 +724,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
   const bool dead = !(z2 > double(DEADF));
   const float ds = uniform(P.delta[0]);
   const bool want_em = P.grad_em != nullptr;
-  GTNX_TM_INIT(64);
+  GTNX_TM_INIT(128);
 
   if (sweeper) {
     __builtin_amdgcn_s_setprio(1);  // the recursion is the critical path; the staging waves of the CU's other workgroup yield (2 %)
@@ -804,11 +824,16 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
     lds_barrier();  // the label table is in registers: the posterior ring may be written
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      if (tau >= 4) rowsum(tau - 4);  // the last wave left block tau - 4 a tick ago
+      // (the last wave left block tau - 4 a tick ago.  Measured and dropped in round 5: the same sums in the staging
+      //  waves, which idle through half of every tick -- 676 of a sweeper's 2430 cycles per tick moved, the tick went
+      //  2755 -> 2685 cycles and the launch did not: the drainers (2230) and the SIMD's shared VALU set the tick)
+      if (tau >= 4) rowsum(tau - 4);
       GTNX_TM(3);
       const int beta = tau - lag;
-      if (beta >= 0 && beta < nblocks && !dead) {
-        const int v0 = beta * K, rows = min(K, T - v0);
+      // (full blocks are compiled without the per-row tests, as in the forward sweep)
+      auto block = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        const int v0 = beta * K, rows = FULL ? K : min(K, T - v0);
         const float* eb = ering + (beta % NBGE) * K * CS;
         const float* ab = aring + (beta % NBE) * K * NSmax;
         const double* Ab = M.aofr + ((beta % NBE) * K) * 4 + w;
@@ -834,7 +859,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
         float dconv = 0.0f;
 #pragma unroll
         for (int i = 0; i < K; ++i) {
-          if (i < rows) {
+          if (FULL || i < rows) {
             if (i % RNk == 0) dconv = float(offp[i / RNk] - bsum);
             float q[NPL];
 #pragma unroll
@@ -899,7 +924,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
         if (NPL == 1 ? l < 2 : l == 0) {
 #pragma unroll
           for (int i = 0; i < K; ++i)
-            if (i < rows) {
+            if (FULL || i < rows) {
               float* bp = bnd_own + ((beta & 3) * K + i) * 2;
               if (NPL == 1) {
                 bp[l] = qh[i][0];
@@ -909,6 +934,10 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
               }
             }
         }
+      };
+      if (beta >= 0 && beta < nblocks && !dead) {
+        if (beta * K + K <= T) block(std::true_type{});
+        else block(std::false_type{});
       }
       GTNX_TM(5);
       lds_barrier();

@@ -333,7 +333,7 @@ void Runtime::drain_all_inboxes() {
 static const size_t kDeferFull = [] {
   const char* e = std::getenv("GTNX_DEFER_FULL");
   const long v = e ? std::atol(e) : 0;
-  return size_t(v > 0 ? v : 2048);
+  return size_t(v > 0 ? v : 8192);
 }();
 
 void Runtime::defer_delete(void* p, void (*del)(void*), size_t weight) {

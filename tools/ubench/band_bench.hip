@@ -129,14 +129,14 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(sc.data(), d_score, 4 * B, hipMemcpyDeviceToHost));
   printf("score[0..3] %.4f %.4f %.4f %.4f\n", sc[0], sc[1], sc[2], sc[3]);
 #ifdef GTNX_BAND_TIMING
-  long long h[128];
+  long long h[256];
   CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(::g_band_timing), sizeof(h)));
   for (int k = 0; k < 2; ++k) {
     printf("%s timing, workgroup 0, cycles per tick (loop | land | issue | store/drain | lse | compute | barrier), ticks %lld\n",
-           k ? "backward" : "forward", h[k * 64 + 63]);
-    for (int wv = 0; wv < 8; ++wv) {
+           k ? "backward" : "forward", h[k * 128 + 127]);
+    for (int wv = 0; wv < (k ? 12 : 8); ++wv) {
       printf("  wave %d:", wv);
-      for (int i = 0; i < 7; ++i) printf(" %6.0f", double(h[k * 64 + wv * 7 + i]) / double(h[k * 64 + 63] ? h[k * 64 + 63] : 1));
+      for (int i = 0; i < 7; ++i) printf(" %6.0f", double(h[k * 128 + wv * 7 + i]) / double(h[k * 128 + 127] ? h[k * 128 + 127] : 1));
       printf("\n");
     }
   }

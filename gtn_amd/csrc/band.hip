@@ -1185,9 +1185,15 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
       cs_m0[s] = cnt > 0 ? 1.0f : 0.0f;
       cs_m1[s] = cnt > 1 ? 1.0f : 0.0f;
     }
-    auto drain = [&](int c) {
-      const int rows = rows_of(c);
-      if (!want_em || rows <= 0) return;
+    // (does any lane of this wave carry a label that sits on more than two nodes?  Uniform, once: the loop over the
+    //  rest of such a run is a divergent one, and its tests alone cost every tick of every wave)
+    bool more_any = false;
+#pragma unroll
+    for (int s = 0; s < NCS; ++s) more_any = more_any || __builtin_amdgcn_ballot_w64(cs_e[s] - cs_s[s] > 2) != 0;
+    // FULL: a block of K rows (every block but the last): no per-row test
+    auto drain_t = [&](int c, auto full_tag) {
+      constexpr bool FULL = decltype(full_tag)::value;
+      const int rows = FULL ? K : rows_of(c);
       const float* ob = oring + (c % NBG) * K * NSmax;
       const float* eb = ering + (c % NBGE) * K * CS;
       const float* lb = lser + (c % NBG) * K;
@@ -1220,19 +1226,35 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
         float sum[K];
 #pragma unroll
         for (int r = 0; r < K; ++r) sum[r] = p0[r] * cs_m0[s] + p1[r] * cs_m1[s];
-        for (int i = cs_s[s] + 2; i < cs_e[s]; ++i) {  // (a label on more than two nodes)
-          const float* o = ob + snode[i];
+        if (more_any) {  // uniform
+          for (int i = cs_s[s] + 2; i < cs_e[s]; ++i) {  // (a label on more than two nodes)
+            const float* o = ob + snode[i];
 #pragma unroll
-          for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
+            for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
+          }
         }
+        float val[K];
 #pragma unroll
         for (int r = 0; r < K; ++r) {
           float sm = dn * ex2(e[r] - ls[r]);
           sm = soft ? sm : 0.0f;
-          const float val = (dead ? 0.0f : sum[r] * f[r]) + sm;
-          if (mine && r < rows) dst[-int64_t(r) * C + cc] = val;
+          val[r] = (dead ? 0.0f : sum[r] * f[r]) + sm;
+        }
+        if (mine) {  // one exec mask for the block's stores; a row's address is a uniform base + this lane's label
+#pragma unroll
+          for (int r = 0; r < K; ++r) {
+            if (FULL || r < rows) {
+              GTNX_G float* row = dst - int64_t(r) * C;
+              row[cc] = val[r];
+            }
+          }
         }
       }
+    };
+    auto drain = [&](int c) {
+      if (!want_em || c >= nblocks) return;
+      if (c * K + K <= T) drain_t(c, std::true_type{});
+      else drain_t(c, std::false_type{});
     };
     lds_barrier();  // (label runs are in registers; the posterior ring is the sweepers')
     for (int tau = 0; tau < nticks; ++tau) {

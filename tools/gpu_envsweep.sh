@@ -1,7 +1,7 @@
 # the GPU suite under the switches that select alternate code paths with the same results (README "Runtime switches")
 set -u
 mkdir -p gpurun_out/envsweep
-run() { name=$1; shift; echo "== $name"; env "$@" timeout 900 python -m pytest tests -q -m gpu -x -p no:cacheprovider 2>&1 | tail -3 | tee gpurun_out/envsweep/$name.log; }
+run() { name=$1; shift; echo "== $name"; env "$@" timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider 2>&1 | tail -4 | tee gpurun_out/envsweep/$name.log; }
 for cfg in "$@"; do
   case $cfg in
     eager_beta) run eager_beta GTNX_EAGER_BETA=1 ;;
@@ -15,5 +15,22 @@ for cfg in "$@"; do
     device_levelize) run device_levelize GTNX_DEVICE_LEVELIZE=1 ;;
     no_fused_copy) run no_fused_copy GTNX_NO_FUSED_COPY=1 ;;
     no_node_order) run no_node_order GTNX_NO_NODE_ORDER_TIES=1 ;;
+    # round 5
+    no_graph_slab) run no_graph_slab GTNX_NO_GRAPH_SLAB=1 ;;
+    defer_full_64) run defer_full_64 GTNX_DEFER_FULL=64 ;;
+    defer_full_max) run defer_full_max GTNX_DEFER_FULL=100000000 ;;
+    lazy0) run lazy0 GTNX_LAZY_COMPOSE=0 ;;
+    lazy1) run lazy1 GTNX_LAZY_COMPOSE=1 ;;
+    lazy2) run lazy2 GTNX_LAZY_COMPOSE=2 ;;
+    no_band) run no_band GTNX_NO_BAND=1 ;;
+    no_lazy_pairs) run no_lazy_pairs GTNX_NO_LAZY_PAIRS=1 ;;
+    dense_valu) run dense_valu GTNX_DENSE_VALU=1 ;;
+    no_dense) run no_dense GTNX_NO_DENSE=1 ;;
+    no_fused_scatter) run no_fused_scatter GTNX_NO_FUSED_SCATTER=1 ;;
+    chain) run chain GTNX_CHAIN=1 ;;
+    classic_bitmaps) run classic_bitmaps GTNX_CLASSIC_BITMAPS=1 ;;
+    full_compose) run full_compose GTNX_FULL_COMPOSE=1 ;;
+    sync_compose) run sync_compose GTNX_SYNC_COMPOSE=1 ;;
+    no_deep) run no_deep GTNX_NO_DEEP=1 ;;
   esac
 done

@@ -96,10 +96,33 @@ void items_device(std::vector<Graph>& gs, void* dev_out);
 void grads_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets);
 void grads_bind_device(std::vector<Graph>& gs, void* dev_out, const int64_t* offsets);
 
+// A kernel's argument table (one record per graph of the launch) on the device.  GTNX_ARGS_IN_PLACE=<bytes>: a table
+// of at most that many bytes is not copied -- the kernel reads it in place from the pinned host block (mapped into
+// the device's address space; each workgroup reads its record once, through the scalar cache).  A single-utterance
+// loss makes five such copies; measured on BASELINE config C1 the in-place form is worth nothing (0.157 against 0.159
+// ms per loss: the read over the host link costs what the copy did), so it is OFF by default.
+// The block goes back to the pinned pool behind an event on the stream, i.e. after the launch that reads it.
+inline bool upload_in_place(size_t bytes) {
+  static const size_t lim = [] {
+    const char* e = std::getenv("GTNX_ARGS_IN_PLACE");
+    return e ? size_t(std::atol(e)) : size_t(0);
+  }();
+  return bytes <= lim;
+}
 template <class T>
 DevMemP upload_vec(const std::vector<T>& v) {
   Runtime& rt = Runtime::get();
   size_t bytes = sizeof(T) * v.size();
+  if (bytes && upload_in_place(bytes)) {
+    PinnedMemP p = rt.alloc_pinned(bytes);
+    std::memcpy(p->ptr, v.data(), bytes);
+    DevMemP d = std::make_shared<DevMem>();
+    d->ptr = p->ptr;
+    d->bytes = bytes;
+    d->borrowed = true;
+    d->keep = p;
+    return d;
+  }
   DevMemP d = rt.alloc(bytes ? bytes : 1);
   if (bytes) {
     PinnedMemP p = rt.alloc_pinned(bytes);

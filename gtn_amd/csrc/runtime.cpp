@@ -547,6 +547,16 @@ void Runtime::h2d(void* dst, const void* src, size_t bytes) {
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream_));
 }
 void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
+  // a few bytes (item() of a loss): through a pinned block -- the copy into pageable memory is staged by the HIP
+  // runtime and blocks inside the call
+  if (bytes && bytes <= 4096) {
+    PinnedMemP p = alloc_pinned(bytes);
+    HIP_CHECK(hipMemcpyAsync(p->ptr, src, bytes, hipMemcpyDeviceToHost, stream_));
+    drain_while_busy();
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    std::memcpy(dst, p->ptr, bytes);
+    return;
+  }
   // reclaim first: a device->host copy into pageable memory blocks inside the copy
   // call until the stream gets there, so this is the last moment the GPU is busy
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));

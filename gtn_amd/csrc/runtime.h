@@ -28,6 +28,7 @@ struct DevMem {
   size_t bytes = 0;
   bool borrowed = false;  // the caller's memory (a tensor that outlives the graphs over it): never pooled
   Runtime* owner = nullptr;  // the device context whose pool the block goes back to (null: borrowed)
+  std::shared_ptr<void> keep;  // borrowed from this (a pinned host block a kernel reads in place: ops.h upload_vec)
   ~DevMem();
   template <class T>
   T* as(size_t byte_off = 0) const { return reinterpret_cast<T*>(static_cast<char*>(ptr) + byte_off); }

@@ -217,23 +217,14 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
     GTNX_HOST_T("linear_graphs_device.d2d");
     if (dev && A && B) rt.d2d(arena->ptr, dev, sizeof(float) * size_t(A) * size_t(B));
   }
-  // the three pieces of all B graphs in ONE allocation (a graph is a structure, weights and a gradient state: 1536
-  // heap blocks per batch of 512, made and later freed one by one on the thread every step waits for); the pieces
-  // are handed out as aliases of the slab, which lives as long as any of them
-  struct Slab {
-    std::vector<Structure> s;
-    std::vector<Weights> w;
-    std::vector<GradState> g;
-    explicit Slab(size_t n) : s(n), w(n), g(n) {}
-  };
-  auto slab = std::make_shared<Slab>(size_t(B > 0 ? B : 0));
+  // the three pieces of all B graphs out of ONE buffer (a graph is a structure, weights and a gradient state: 1536
+  // heap blocks per batch of 512, made and later freed one by one on the thread every step waits for); the buffer
+  // comes from and goes back to the thread's cache (graph.h: GraphSlabScope -- a fresh 577 KB block per step was 140
+  // page faults)
+  GraphSlabScope slab_scope(size_t(B > 0 ? B : 0));
   const Runtime::InboxP home = Runtime::home();
   for (int b = 0; b < B; ++b) {
-    Graph g{Graph::Empty{}};
-    g.s = std::shared_ptr<Structure>(slab, &slab->s[size_t(b)]);
-    g.w = std::shared_ptr<Weights>(slab, &slab->w[size_t(b)]);
-    g.g = std::shared_ptr<GradState>(slab, &slab->g[size_t(b)]);
-    g.g->calc_grad = calc_grad;
+    Graph g = Graph::make_result(calc_grad);
     Structure& s = *g.s;
     s.home = home;
     s.device = Runtime::current_device();

@@ -53,6 +53,9 @@ constexpr int WGB = 768;  // the backward sweep: 4 sweeper + 4 staging + 4 drain
 constexpr int NBE = 5;   // blocks in the emission / alpha rings: one landing, four in use (lead .. last wave)
 constexpr int NBG = 7;   // blocks the backward sweep keeps: one landing, four in use, one being summed, one draining
 constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest of their chunk
+#ifndef GTNX_BWD_SPLIT
+#define GTNX_BWD_SPLIT 0  // (1: measured slower, see band_backward_kernel)
+#endif
 #ifndef GTNX_FWD_DEPTH
 #define GTNX_FWD_DEPTH 2
 #endif
@@ -725,6 +728,171 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
   const float ds = uniform(P.delta[0]);
   const bool want_em = P.grad_em != nullptr;
   GTNX_TM_INIT(128);
+  // ---- who does what besides the recursion.  !SPLIT (the build): the sweepers sum the rows, the draining waves write
+  // every gradient row -- the form of rounds 3-4.  SPLIT (-DGTNX_BWD_SPLIT=1; two workgroups per CU, K >= 2): the row
+  // sums go to the DRAINING waves (wave d sums row d) and a block's gradient rows are written half by them, half by
+  // the STAGING waves, which idle through more than half of every tick (tools/ubench/band_bench_tm: sweepers 2 430
+  // busy cycles per tick with the sums, drainers 2 420, stagers 1 150).  Measured in round 5 and NOT the build:
+  // 0.47 against 0.42 ms -- a drain pass costs ~500 cycles before its first row (label runs, row scalars, addresses,
+  // LDS round trips), so two half passes are 1 250 + 1 250 where one was 2 000, and the sums take 800 cycles in a
+  // wave that is not a sweeper (drainers 2 380 per tick, sweepers idle for 1 100).
+  constexpr bool SPLIT = !BIG && K >= 2 && GTNX_BWD_SPLIT;
+  const float dn_k = P.delta_norm ? uniform(P.delta_norm[0]) : 0.0f;
+  const bool soft_k = P.delta_norm != nullptr && P.rowlse != nullptr;
+  float* const rnorm_k = lser + NBG * K;  // [NBG blocks][K] what makes a row's posteriors sum to one
+  auto rows_of_k = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
+  // row sums of block c, row r, by one wave (lane l owns nodes 4l .. 4l+3, + 256 for the second read; the ring holds 0
+  // for nodes past N, so only whole reads past the row are masked).  Posteriors of a time step sum to one; in
+  // float32 the two sweeps and the score drift apart by ~1e-4 over a thousand steps (all nodes of a row alike): the
+  // row is rescaled to its exact total -- and, having the hot label's share in hand as well, the summing wave
+  // stores that gradient element.
+  struct RowSumRegs {
+    float in[NPL];
+    gtnx_f4 hot[NPL];
+  };
+  auto rowsum_init = [&](RowSumRegs& R) {
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      const int mb = 256 * q + 4 * l;
+      R.in[q] = mb < NSmax ? 1.0f : 0.0f;
+      float hm[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = mb + k;
+        int lab = -1;
+        if (m < P.N) lab = P.nodes[m].lab;
+        settle(lab);
+        hm[k] = (P.hot >= 0 && lab == P.hot) ? 1.0f : 0.0f;
+      }
+      R.hot[q] = gtnx_f4{hm[0], hm[1], hm[2], hm[3]};
+    }
+  };
+  auto rowsum_do = [&](const RowSumRegs& R, int c, int r) {
+    const int rows = rows_of_k(c);
+    if (!want_em || r >= rows) return;
+    const float* ob = oring + ((c % NBG) * K + r) * NSmax;
+    gtnx_f4 v[NPL];
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) v[q] = *reinterpret_cast<const gtnx_f4*>(ob + min(256 * q + 4 * l, NSmax - 4));
+    const float em_hot = ering[((c % NBGE) * K + r) * CS + max(P.hot, 0)];
+    const float ls_hot = lser[(c % NBG) * K + r];
+    float all = 0.0f, hotp = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NPL; ++q) {
+      all += (v[q].x * R.in[q] + v[q].y * R.in[q]) + (v[q].z * R.in[q] + v[q].w * R.in[q]);
+      hotp += (v[q].x * R.hot[q].x + v[q].y * R.hot[q].y) + (v[q].z * R.hot[q].z + v[q].w * R.hot[q].w);
+    }
+    if (dead) all = hotp = 0.0f;  // nothing wrote the ring
+    wave_sum63x2(all, hotp);
+    all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all), 63));
+    const float f = (all != 0.0f && !dead) ? ds * __builtin_amdgcn_rcpf(all) : 1.0f;
+    if (l == 63 && P.hot >= 0) {
+      float sm = dn_k * ex2(em_hot - ls_hot);
+      sm = soft_k ? sm : 0.0f;
+      P.grad_em[int64_t(T - 1 - c * K - r) * C + P.hot] = (dead ? 0.0f : hotp * f) + sm;
+    }
+    if (l == 0) rnorm_k[(c % NBG) * K + r] = f;
+  };
+  // gradient rows [R0, R1) of block c (every sweeper is through with it, its rows are summed): lane `hid` of a
+  // 256-lane role GATHERS the posteriors of the nodes that carry label hid (+ 256 ...), adds the normaliser's
+  // softmax term and stores the finished element -- coalesced, once.  The label runs come out of the table the
+  // drainers build in the posterior ring before the first tick.
+  constexpr int NCS = 8 / K;  // C <= 2048 / K labels, 256 per round
+  struct DrainRegs {
+    int s[NCS], e[NCS], n0[NCS], n1[NCS];
+    float m0[NCS], m1[NCS];
+    bool more_any;
+  };
+  auto drain_init = [&](DrainRegs& D, int hid) {
+    const int* cls = reinterpret_cast<const int*>(oring);
+#pragma unroll
+    for (int q = 0; q < NCS; ++q) {
+      const int cc = hid + q * BW;
+      D.s[q] = D.e[q] = 0;
+      if (cc < C && cc != P.hot) {
+        D.s[q] = cls[cc];
+        D.e[q] = cls[C + cc];
+      }
+      const int cnt = D.e[q] - D.s[q];
+      D.n0[q] = cnt > 0 ? snode[D.s[q]] : 0;
+      D.n1[q] = cnt > 1 ? snode[D.s[q] + 1] : 0;
+      D.m0[q] = cnt > 0 ? 1.0f : 0.0f;
+      D.m1[q] = cnt > 1 ? 1.0f : 0.0f;
+    }
+    // (does any lane of this wave carry a label that sits on more than two nodes?  Uniform, once: the loop over the
+    //  rest of such a run is a divergent one, and its tests alone cost every tick of every wave)
+    D.more_any = false;
+#pragma unroll
+    for (int q = 0; q < NCS; ++q) D.more_any = D.more_any || __builtin_amdgcn_ballot_w64(D.e[q] - D.s[q] > 2) != 0;
+  };
+  // FULL: a block of K rows (every block but the last): no per-row test
+  auto drain_rows = [&](const DrainRegs& D, int hid, int c, auto full_tag, auto r0_tag, auto r1_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int R0 = decltype(r0_tag)::value, R1 = decltype(r1_tag)::value;
+    const int rows = FULL ? K : rows_of_k(c);
+    const float* ob = oring + (c % NBG) * K * NSmax;
+    const float* eb = ering + (c % NBGE) * K * CS;
+    const float* lb = lser + (c % NBG) * K;
+    const float* fb = rnorm_k + (c % NBG) * K;
+    GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
+#pragma unroll
+    for (int q = 0; q < NCS; ++q) {
+      if (q > 0 && q * BW >= C) break;  // uniform
+      const int cc = hid + q * BW;
+      const bool mine = cc < C && cc != P.hot;
+      // every LDS read of the rows first (addresses are known up front), then the arithmetic
+      float p0[K], p1[K], e[K], ls[K], f[K];
+#pragma unroll
+      for (int r = R0; r < R1; ++r) {
+        p0[r] = ob[r * NSmax + D.n0[q]];
+        p1[r] = ob[r * NSmax + D.n1[q]];
+        e[r] = eb[r * CS + min(cc, C - 1)];
+      }
+      if constexpr (K == 4) {  // the rows' scalars: two 16-byte broadcast reads
+        const gtnx_f4 l4 = *reinterpret_cast<const gtnx_f4*>(lb), f4 = *reinterpret_cast<const gtnx_f4*>(fb);
+        ls[0] = l4.x, ls[1] = l4.y, ls[2] = l4.z, ls[3] = l4.w;
+        f[0] = f4.x, f[1] = f4.y, f[2] = f4.z, f[3] = f4.w;
+      } else {
+#pragma unroll
+        for (int r = R0; r < R1; ++r) {
+          ls[r] = lb[r];
+          f[r] = fb[r];
+        }
+      }
+      float sum[K];
+#pragma unroll
+      for (int r = R0; r < R1; ++r) sum[r] = p0[r] * D.m0[q] + p1[r] * D.m1[q];
+      if (D.more_any) {  // uniform
+        for (int i = D.s[q] + 2; i < D.e[q]; ++i) {  // (a label on more than two nodes)
+          const float* o = ob + snode[i];
+#pragma unroll
+          for (int r = R0; r < R1; ++r) sum[r] += o[r * NSmax];
+        }
+      }
+      float val[K];
+#pragma unroll
+      for (int r = R0; r < R1; ++r) {
+        float sm = dn_k * ex2(e[r] - ls[r]);
+        sm = soft_k ? sm : 0.0f;
+        val[r] = (dead ? 0.0f : sum[r] * f[r]) + sm;
+      }
+      if (mine) {  // one exec mask for the block's stores; a row's address is a uniform base + this lane's label
+#pragma unroll
+        for (int r = R0; r < R1; ++r) {
+          if (FULL || r < rows) {
+            GTNX_G float* row = dst - int64_t(r) * C;
+            row[cc] = val[r];
+          }
+        }
+      }
+    }
+  };
+  auto drain_block = [&](const DrainRegs& D, int hid, int c, auto r0_tag, auto r1_tag) {
+    if (!want_em || c >= nblocks) return;
+    if (c * K + K <= T) drain_rows(D, hid, c, std::true_type{}, r0_tag, r1_tag);
+    else drain_rows(D, hid, c, std::false_type{}, r0_tag, r1_tag);
+  };
+  constexpr int KH = SPLIT ? K / 2 : K;  // rows of a block the draining waves write
 
   if (sweeper) {
     __builtin_amdgcn_s_setprio(1);  // the recursion is the critical path; the staging waves of the CU's other workgroup yield (2 %)
@@ -763,71 +931,15 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
     if (l == 0) off_own[0] = 0.0;
     lds_barrier();  // (the helpers sort labels in the posterior ring ...
     lds_barrier();  //  ... done)
-    const float dn = P.delta_norm ? uniform(P.delta_norm[0]) : 0.0f;
-    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
-    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-    // row sums: lane l of the summing wave owns nodes 4l .. 4l+3 (+ 256 for the second read); the ring
-    // holds 0 for nodes past N, so only whole reads past the row are masked
-    float rs_in[NPL];
-    gtnx_f4 rs_hot[NPL];
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-      const int mb = 256 * q + 4 * l;
-      rs_in[q] = mb < NSmax ? 1.0f : 0.0f;
-      float hm[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int m = mb + k;
-        int lab = -1;
-        if (m < P.N) lab = P.nodes[m].lab;
-        settle(lab);
-        hm[k] = (P.hot >= 0 && lab == P.hot) ? 1.0f : 0.0f;
-      }
-      rs_hot[q] = gtnx_f4{hm[0], hm[1], hm[2], hm[3]};
-    }
-    // gradient rows of block c (every sweeper is through with it): gather by label, add the
-    // normaliser's softmax term, store
-    float* rnorm = lser + NBG * K;  // [NBG blocks][K] what makes a row's posteriors sum to one
-    // Posteriors of a time step sum to one; in float32 the two sweeps and the score drift apart by
-    // ~1e-4 over a thousand steps (all nodes of a row alike).  When every wave has left block c, wave r
-    // sums row r and the row is rescaled to its exact total -- and, having the hot label's share in hand
-    // as well, stores that gradient element.
-    auto rowsum = [&](int c) {
-      const int rows = rows_of(c);
-      if (!want_em || w >= rows) return;
-      const int r = w;
-      const float* ob = oring + ((c % NBG) * K + r) * NSmax;
-      // lane l sums nodes 4l .. 4l+3 (and 256 + 4l .. for two nodes per lane): one 16-byte read each;
-      // the hot label's share comes out of the same registers through a per-node mask
-      gtnx_f4 v[NPL];
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) v[q] = *reinterpret_cast<const gtnx_f4*>(ob + min(256 * q + 4 * l, NSmax - 4));
-      const float em_hot = ering[((c % NBGE) * K + r) * CS + max(P.hot, 0)];
-      const float ls_hot = lser[(c % NBG) * K + r];
-      float all = 0.0f, hotp = 0.0f;
-#pragma unroll
-      for (int q = 0; q < NPL; ++q) {
-        all += (v[q].x * rs_in[q] + v[q].y * rs_in[q]) + (v[q].z * rs_in[q] + v[q].w * rs_in[q]);
-        hotp += (v[q].x * rs_hot[q].x + v[q].y * rs_hot[q].y) + (v[q].z * rs_hot[q].z + v[q].w * rs_hot[q].w);
-      }
-      if (dead) all = hotp = 0.0f;  // nothing wrote the ring
-      wave_sum63x2(all, hotp);
-      all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all), 63));
-      const float f = (all != 0.0f && !dead) ? ds * __builtin_amdgcn_rcpf(all) : 1.0f;
-      if (l == 63 && P.hot >= 0) {
-        float sm = dn * ex2(em_hot - ls_hot);
-        sm = soft ? sm : 0.0f;
-        P.grad_em[int64_t(T - 1 - c * K - r) * C + P.hot] = (dead ? 0.0f : hotp * f) + sm;
-      }
-      if (l == 0) rnorm[(c % NBG) * K + r] = f;
-    };
+    RowSumRegs rsr;
+    if constexpr (!SPLIT) rowsum_init(rsr);
     lds_barrier();  // the label table is in registers: the posterior ring may be written
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
-      // (the last wave left block tau - 4 a tick ago.  Measured and dropped in round 5: the same sums in the staging
-      //  waves, which idle through half of every tick -- 676 of a sweeper's 2430 cycles per tick moved, the tick went
-      //  2755 -> 2685 cycles and the launch did not: the drainers (2230) and the SIMD's shared VALU set the tick)
-      if (tau >= 4) rowsum(tau - 4);
+      // (the last wave left block tau - 4 a tick ago.  SPLIT: the draining waves take the sums, see the head of the kernel)
+      if constexpr (!SPLIT) {
+        if (tau >= 4) rowsum_do(rsr, tau - 4, w);
+      }
       GTNX_TM(3);
       const int beta = tau - lag;
       // (full blocks are compiled without the per-row tests, as in the forward sweep)
@@ -967,6 +1079,15 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
       const int h = wv - 4, q = h & 1;
       auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
       auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
+      // SPLIT: the upper half of every block's gradient rows is written here (lane hid_s of the four staging waves
+      // = label hid_s), after the tick's landing and requests
+      DrainRegs dr_s;
+      const int hid_s = threadIdx.x - BW;
+      auto drain_upper = [&](int tau) {
+        if constexpr (SPLIT) {
+          if (tau >= 5) drain_block(dr_s, hid_s, tau - 5, std::integral_constant<int, KH>{}, std::integral_constant<int, K>{});
+        }
+      };
       if (h < 2) {
         Stage<16, 64> se;
         if constexpr (VEC) se.init_offsets(C, CS, K, l);
@@ -991,6 +1112,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
         land_em(q);
         issue_em(q + 2);
         lds_barrier();
+        if constexpr (SPLIT) drain_init(dr_s, hid_s);  // (the table is complete; the sweepers overwrite it after the next barrier)
         lds_barrier();  // (... and have taken their label runs)
         for (int tau = 0; tau < nticks; ++tau) {
           GTNX_TM(0);
@@ -1002,6 +1124,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
             GTNX_TM(2);
           }
 #endif
+          drain_upper(tau);
           GTNX_TM(3);
           lds_barrier();
           GTNX_TM(6);
@@ -1037,6 +1160,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
           issue_rest(2);
         }
         lds_barrier();
+        if constexpr (SPLIT) drain_init(dr_s, hid_s);
         lds_barrier();  // (... and have taken their label runs)
         for (int tau = 0; tau < nticks; ++tau) {
           GTNX_TM(0);
@@ -1048,6 +1172,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
             GTNX_TM(2);
           }
 #endif
+          drain_upper(tau);
           GTNX_TM(3);
           lds_barrier();
           GTNX_TM(6);
@@ -1160,108 +1285,22 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
       if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
       if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
     }
-    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
     lds_barrier();  // (the label table is complete; the stagers have landed the first chunks)
-    // gradient rows of block c (every sweeper is through with it, its rows are summed): helper lane
-    // cc GATHERS the posteriors of the nodes that carry label cc, adds the normaliser's softmax
-    // term and stores the finished element -- coalesced, once
-    const float dn = P.delta_norm ? uniform(P.delta_norm[0]) : 0.0f;
-    const float* rnorm = lser + NBG * K;
     // this lane's labels (tid, tid + 256, ...): run of nodes, the first two inline
-    constexpr int NCS = 8 / K;  // C <= 2048 / K labels, 256 per round
-    int cs_s[NCS], cs_e[NCS], cs_n0[NCS], cs_n1[NCS];
-    float cs_m0[NCS], cs_m1[NCS];
-#pragma unroll
-    for (int s = 0; s < NCS; ++s) {
-      const int cc = hid + s * BW;
-      cs_s[s] = cs_e[s] = 0;
-      if (cc < C && cc != P.hot) {
-        cs_s[s] = cls[cc];
-        cs_e[s] = cls[C + cc];
-      }
-      const int cnt = cs_e[s] - cs_s[s];
-      cs_n0[s] = cnt > 0 ? snode[cs_s[s]] : 0;
-      cs_n1[s] = cnt > 1 ? snode[cs_s[s] + 1] : 0;
-      cs_m0[s] = cnt > 0 ? 1.0f : 0.0f;
-      cs_m1[s] = cnt > 1 ? 1.0f : 0.0f;
-    }
-    // (does any lane of this wave carry a label that sits on more than two nodes?  Uniform, once: the loop over the
-    //  rest of such a run is a divergent one, and its tests alone cost every tick of every wave)
-    bool more_any = false;
-#pragma unroll
-    for (int s = 0; s < NCS; ++s) more_any = more_any || __builtin_amdgcn_ballot_w64(cs_e[s] - cs_s[s] > 2) != 0;
-    // FULL: a block of K rows (every block but the last): no per-row test
-    auto drain_t = [&](int c, auto full_tag) {
-      constexpr bool FULL = decltype(full_tag)::value;
-      const int rows = FULL ? K : rows_of(c);
-      const float* ob = oring + (c % NBG) * K * NSmax;
-      const float* eb = ering + (c % NBGE) * K * CS;
-      const float* lb = lser + (c % NBG) * K;
-      const float* fb = rnorm + (c % NBG) * K;
-      GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
-#pragma unroll
-      for (int s = 0; s < NCS; ++s) {
-        if (s > 0 && s * BW >= C) break;  // uniform
-        const int cc = hid + s * BW;
-        const bool mine = cc < C && cc != P.hot;
-        // every LDS read of the K rows first (addresses are known up front), then the arithmetic
-        float p0[K], p1[K], e[K], ls[K], f[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-          p0[r] = ob[r * NSmax + cs_n0[s]];
-          p1[r] = ob[r * NSmax + cs_n1[s]];
-          e[r] = eb[r * CS + min(cc, C - 1)];
-        }
-        if constexpr (K == 4) {  // the rows' scalars: two 16-byte broadcast reads
-          const gtnx_f4 l4 = *reinterpret_cast<const gtnx_f4*>(lb), f4 = *reinterpret_cast<const gtnx_f4*>(fb);
-          ls[0] = l4.x, ls[1] = l4.y, ls[2] = l4.z, ls[3] = l4.w;
-          f[0] = f4.x, f[1] = f4.y, f[2] = f4.z, f[3] = f4.w;
-        } else {
-#pragma unroll
-          for (int r = 0; r < K; ++r) {
-            ls[r] = lb[r];
-            f[r] = fb[r];
-          }
-        }
-        float sum[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) sum[r] = p0[r] * cs_m0[s] + p1[r] * cs_m1[s];
-        if (more_any) {  // uniform
-          for (int i = cs_s[s] + 2; i < cs_e[s]; ++i) {  // (a label on more than two nodes)
-            const float* o = ob + snode[i];
-#pragma unroll
-            for (int r = 0; r < K; ++r) sum[r] += o[r * NSmax];
-          }
-        }
-        float val[K];
-#pragma unroll
-        for (int r = 0; r < K; ++r) {
-          float sm = dn * ex2(e[r] - ls[r]);
-          sm = soft ? sm : 0.0f;
-          val[r] = (dead ? 0.0f : sum[r] * f[r]) + sm;
-        }
-        if (mine) {  // one exec mask for the block's stores; a row's address is a uniform base + this lane's label
-#pragma unroll
-          for (int r = 0; r < K; ++r) {
-            if (FULL || r < rows) {
-              GTNX_G float* row = dst - int64_t(r) * C;
-              row[cc] = val[r];
-            }
-          }
-        }
-      }
-    };
-    auto drain = [&](int c) {
-      if (!want_em || c >= nblocks) return;
-      if (c * K + K <= T) drain_t(c, std::true_type{});
-      else drain_t(c, std::false_type{});
-    };
+    DrainRegs dr;
+    drain_init(dr, hid);
+    RowSumRegs rsr;
+    if constexpr (SPLIT) rowsum_init(rsr);
+    const int dw = wv - 8;  // (SPLIT: this wave sums row dw)
     lds_barrier();  // (label runs are in registers; the posterior ring is the sweepers')
     for (int tau = 0; tau < nticks; ++tau) {
       GTNX_TM(0);
 #ifndef GTNX_EXP_NO_DRAIN  // (tools/ubench experiments: what the tick costs without the gradient rows / the staging)
-      if (tau >= 5) drain(tau - 5);
+      if (tau >= 5) drain_block(dr, hid, tau - 5, std::integral_constant<int, 0>{}, std::integral_constant<int, KH>{});
 #endif
+      if constexpr (SPLIT) {  // the last sweeper left block tau - 4 a tick ago; its rows are drained a tick from now
+        if (tau >= 4) rowsum_do(rsr, tau - 4, dw);
+      }
       GTNX_TM(3);
       lds_barrier();
       GTNX_TM(6);

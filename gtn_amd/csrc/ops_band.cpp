@@ -532,6 +532,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   // orders as node ranks (tie_ranks above); anything else: the built lattice decides (below)
   static const bool dbg_ties = std::getenv("GTNX_DEBUG_TIES") != nullptr;
   static const bool no_ranked = std::getenv("GTNX_NO_RANKED_TIES") != nullptr;
+  std::vector<size_t> rerun;  // utterances whose ties a second launch (node ranks) is deciding
   {
     std::vector<size_t> ranked;
     size_t n_tied = 0;
@@ -570,16 +571,18 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
         GTNX_PROF(want_path ? "band_viterbi_path_ranked" : "band_viterbi_score_ranked", 0.0);
         launch_band_viterbi(d2->as<BandDecode>(), int(tab2.size()), stage_floats, max_n, max_c, vec, rt.stream(), /*ranked=*/1);
       }
-      fetch_results();
-      lap("band_viterbi.2b_ranked_rerun");
+      // (the second launch runs while the host builds the path graphs of the utterances it does not concern:
+      //  round 5 -- the two were in series, 0.65 ms per batch that has a tie)
+      rerun = std::move(ranked);
+      lap("band_viterbi.2b_ranked_rerun_enqueue");
     }
   }
-  for (size_t i = 0; i < n; ++i) {
+  auto build_output = [&](size_t i) {
     const int* hd = head_of(i);
     const int len = hd[0];
     if (hd[2] && len >= 0) {  // an exact tie the ranks do not cover: the built lattice decides (its node numbering breaks it)
       tied.push_back(i);
-      continue;
+      return;
     }
     LazyProduct& lp = *gs[i].s->lazy;
     const int chain_first = lp.chain_side == 1;
@@ -619,6 +622,18 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
       sv.C = tab[i].C;
       sv.chain_first = chain_first;
       outs[i] = std::move(out);
+    }
+  };
+  {
+    std::vector<uint8_t> later(n, 0);
+    for (size_t i : rerun) later[i] = 1;
+    for (size_t i = 0; i < n; ++i)
+      if (!later[i]) build_output(i);
+    if (!rerun.empty()) {
+      fetch_results();
+      lap("band_viterbi.2c_ranked_rerun_wait");
+      for (size_t i : rerun) build_output(i);
+      std::sort(tied.begin(), tied.end());
     }
   }
   lap("band_viterbi.3_outputs");

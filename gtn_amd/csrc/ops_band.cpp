@@ -577,10 +577,16 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
       lap("band_viterbi.2b_ranked_rerun_enqueue");
     }
   }
+  // The path graphs (a dozen host arrays of T entries per utterance): every element touches only its own objects, so
+  // a large batch is built by a few threads of the caller's pool (idle at a join), as ops_lazy.cpp does for C4
+  std::mutex tied_mu;
+  if (want_path)
+    for (size_t i = 0; i < n; ++i) gs[i].s->lazy->fixed.s->ensure_host();
   auto build_output = [&](size_t i) {
     const int* hd = head_of(i);
     const int len = hd[0];
     if (hd[2] && len >= 0) {  // an exact tie the ranks do not cover: the built lattice decides (its node numbering breaks it)
+      std::lock_guard<std::mutex> lk(tied_mu);
       tied.push_back(i);
       return;
     }
@@ -593,7 +599,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
         const int* hlab = harc + (tab[i].T ? tab[i].T : 1);
         const float* hw = reinterpret_cast<const float*>(hlab + (tab[i].T ? tab[i].T : 1));
         // labels of the product's arcs: the chain's on its side, G's arc label on the other
-        lp.fixed.s->ensure_host();
+        // (the partner's host arrays were made sure of before the threads started)
         std::vector<int> il, ol;
         il.resize(size_t(len));
         ol.resize(size_t(len));
@@ -627,14 +633,21 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   {
     std::vector<uint8_t> later(n, 0);
     for (size_t i : rerun) later[i] = 1;
+    std::vector<size_t> now;
+    now.reserve(n);
     for (size_t i = 0; i < n; ++i)
-      if (!later[i]) build_output(i);
+      if (!later[i]) now.push_back(i);
+    auto build_many = [&](const std::vector<size_t>& idx) {
+      if (want_path && idx.size() >= 64) gtn::detail::runIndexed(idx.size(), [&](size_t q) { build_output(idx[q]); }, 8, false);
+      else for (size_t i : idx) build_output(i);
+    };
+    build_many(now);
     if (!rerun.empty()) {
       fetch_results();
       lap("band_viterbi.2c_ranked_rerun_wait");
-      for (size_t i : rerun) build_output(i);
-      std::sort(tied.begin(), tied.end());
+      build_many(rerun);
     }
+    std::sort(tied.begin(), tied.end());
   }
   lap("band_viterbi.3_outputs");
   if (!tied.empty()) {

@@ -486,6 +486,7 @@ struct SlabCache {
     size_t cap;
   };
   std::vector<Buf> bufs;
+  size_t bytes = 0;  // held: at most 16 MB per thread (the garbage of ~10 C2 batches comes back at once, runtime.cpp kDeferFull)
   ~SlabCache() {
     for (auto& b : bufs) ::operator delete(b.p, std::align_val_t(64));
   }
@@ -519,6 +520,7 @@ SlabBuf* slab_open(size_t bytes) {
       if (c->bufs[i].cap >= bytes && c->bufs[i].cap <= 2 * bytes) {
         b->base = c->bufs[i].p;
         b->cap = c->bufs[i].cap;
+        c->bytes -= b->cap;
         c->bufs[i] = c->bufs.back();
         c->bufs.pop_back();
         g_slab_hit.fetch_add(1, std::memory_order_relaxed);
@@ -539,8 +541,10 @@ SlabBuf* slab_open(size_t bytes) {
 void slab_release(SlabBuf* b) {
   if (b->live.fetch_sub(1, std::memory_order_acq_rel) != 1) return;
   SlabCache* c = slab_cache();
-  if (c && c->bufs.size() < 8 && b->cap <= (size_t(4) << 20)) c->bufs.push_back({b->base, b->cap});
-  else {
+  if (c && c->bufs.size() < 64 && b->cap <= (size_t(4) << 20) && c->bytes + b->cap <= (size_t(16) << 20)) {
+    c->bufs.push_back({b->base, b->cap});
+    c->bytes += b->cap;
+  } else {
     if (std::getenv("GTNX_SLAB_DEBUG")) std::fprintf(stderr, "slab drop: cache %p size %zu cap %zu\n", (void*)c, c ? c->bufs.size() : 0, b->cap);
     g_slab_drop.fetch_add(1, std::memory_order_relaxed);
     ::operator delete(b->base, std::align_val_t(64));

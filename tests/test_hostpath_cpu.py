@@ -1,0 +1,41 @@
+"""The HOST side of the engine without a GPU: tools/nullhip's do-nothing HIP runtime LD_PRELOADed under small
+drivers of BASELINE configs C1 / C2 (tools/nullhip/small_step.cpp: the per-graph functions, the vector overloads and
+gtn::Batch over 256 linear chains).  Kernels do not run, so nothing here checks a RESULT -- what it pins is that the
+host path (graph handles, result graphs out of per-op buffers, deferred teardown counted in graphs: DESIGN.md section
+12.3) runs to the end, recycles its buffers, and stops faulting in fresh memory once warm.  Diagnostic tooling only:
+nothing in the package, smoke() or bench.py loads the null runtime."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NULLHIP = os.path.join(ROOT, "tools", "nullhip")
+
+
+def _build():
+    if not os.path.exists(os.path.join(ROOT, "gtn_amd", "lib", "libgtn_amd.so")):
+        pytest.skip("libgtn_amd.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    if not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("no ROCm headers")
+    r = subprocess.run(["make", "-s", "-C", NULLHIP], capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        pytest.skip("tools/nullhip does not build here: " + (r.stdout + r.stderr)[-300:])
+
+
+@pytest.mark.parametrize("mode", ["c1", "c2", "c2b"])
+def test_host_path_runs_and_recycles_its_memory(mode):
+    _build()
+    env = dict(os.environ, LD_PRELOAD=os.path.join(NULLHIP, "_bin", "libnullhip.so"), GTNX_SLAB_STATS="1", NULLHIP_ZERO="1")
+    r = subprocess.run([os.path.join(NULLHIP, "_bin", "small_step"), mode, "400"], capture_output=True, text=True, timeout=600,
+                       env=env, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-2000:]
+    m = re.search(r"minor page faults per repetition: ([0-9.]+)", out)
+    assert m, out[-1000:]
+    # warm loop: the graphs' memory comes round again instead of being mapped afresh (155 faults per C2 batch before)
+    assert float(m.group(1)) <= 40.0, out[-1000:]
+    if mode == "c2":  # 256 result graphs per repetition out of one cached buffer
+        s = re.search(r"graph slabs: (\d+) from the cache, (\d+) fresh", out)
+        assert s and int(s.group(1)) >= 300 and int(s.group(1)) >= 8 * int(s.group(2)), out[-1000:]

@@ -56,6 +56,9 @@ constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest o
 #ifndef GTNX_BWD_SPLIT
 #define GTNX_BWD_SPLIT 0  // (1: measured slower, see band_backward_kernel)
 #endif
+#ifndef GTNX_FWD_COPY_ROTATE
+#define GTNX_FWD_COPY_ROTATE 1
+#endif
 #ifndef GTNX_FWD_DEPTH
 #define GTNX_FWD_DEPTH 2
 #endif
@@ -664,8 +667,49 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
         }
       }
     };
-    if (em_copy) run(std::true_type{});  // (uniform)
-    else run(std::false_type{});
+    // The copy variant (a region's first sweep: the emissions are also stored where the backward sweep will read
+    // them) with ONE more staging set than chunks in flight, and the request made BEFORE the landing: a request into
+    // the registers a store has just read has to wait for that store (the only counter is vmcnt, and the compiler
+    // waits for all of it) -- the store's whole round trip, every tick.  Here the registers requested into are the
+    // ones landed a tick AGO, so what the wait at the top of a tick covers is a tick old.
+    auto run_copy = [&]() {
+      constexpr int R = D + 1;
+      Stage<8> sc[R];
+      issue(sc[0], 0);
+      land(sc[0], 0, std::true_type{});
+#pragma unroll
+      for (int c = 1; c <= D; ++c) issue(sc[c % R], c);
+      lds_barrier();
+      for (int tau0 = 0; tau0 < nticks; tau0 += R) {
+#pragma unroll
+        for (int d = 0; d < R; ++d) {
+          const int tau = tau0 + d;
+          if (tau >= nticks) break;
+          GTNX_TM(0);
+          // chunk tau + 1 + D is requested into the set chunk tau left a tick ago ((tau + 1 + D) % R == tau % R),
+          // then chunk tau + 1 lands (its ring block was last read a tick ago)
+          sc[(d + 1) % R].settle_all();
+          issue(sc[d % R], tau + 1 + D);
+          GTNX_TM(2);
+          land(sc[(d + 1) % R], tau + 1, std::true_type{});
+          GTNX_TM(1);
+          if (want_lse) {
+            if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
+            if (tau < nblocks) lse_a(tau);
+          }
+          GTNX_TM(4);
+          lds_barrier();
+          GTNX_TM(6);
+          GTNX_TM_TICK();
+        }
+      }
+    };
+    if (em_copy) {  // (uniform)
+      if (GTNX_FWD_COPY_ROTATE) run_copy();
+      else run(std::true_type{});
+    } else {
+      run(std::false_type{});
+    }
     if (hid < 16) M.red[hid] = normacc;
   }
   GTNX_TM_DUMP();

@@ -79,6 +79,7 @@ int main(int argc, char** argv) {
     p.n_lab = N;
     p.w = nullptr;
     p.em = d_em + size_t(b) * T * C;
+    p.em_copy = getenv("EMCOPY") ? d_grad + size_t(b) * T * C : nullptr;  // (the copy variant of the forward sweep; d_grad is rewritten by the backward sweep afterwards)
     p.alpha = reinterpret_cast<float*>(d_alpha + per_alpha * b);
     p.aoff = reinterpret_cast<double*>(d_off + per_off * b);
     p.score = d_score + b;

@@ -56,6 +56,9 @@ constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest o
 #ifndef GTNX_BWD_SPLIT
 #define GTNX_BWD_SPLIT 0  // (1: measured slower, see band_backward_kernel)
 #endif
+#ifndef GTNX_FWD_COPY_DEPTH
+#define GTNX_FWD_COPY_DEPTH 2
+#endif
 #ifndef GTNX_FWD_COPY_ROTATE
 #define GTNX_FWD_COPY_ROTATE 1
 #endif
@@ -673,12 +676,13 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
     // waits for all of it) -- the store's whole round trip, every tick.  Here the registers requested into are the
     // ones landed a tick AGO, so what the wait at the top of a tick covers is a tick old.
     auto run_copy = [&]() {
-      constexpr int R = D + 1;
+      constexpr int DC = GTNX_FWD_COPY_DEPTH < 8 / K ? 8 / K : GTNX_FWD_COPY_DEPTH;  // ticks a request is in flight
+      constexpr int R = DC + 1;
       Stage<8> sc[R];
       issue(sc[0], 0);
       land(sc[0], 0, std::true_type{});
 #pragma unroll
-      for (int c = 1; c <= D; ++c) issue(sc[c % R], c);
+      for (int c = 1; c <= DC; ++c) issue(sc[c % R], c);
       lds_barrier();
       for (int tau0 = 0; tau0 < nticks; tau0 += R) {
 #pragma unroll
@@ -686,10 +690,10 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
           const int tau = tau0 + d;
           if (tau >= nticks) break;
           GTNX_TM(0);
-          // chunk tau + 1 + D is requested into the set chunk tau left a tick ago ((tau + 1 + D) % R == tau % R),
+          // chunk tau + 1 + DC is requested into the set chunk tau left a tick ago ((tau + 1 + DC) % R == tau % R),
           // then chunk tau + 1 lands (its ring block was last read a tick ago)
           sc[(d + 1) % R].settle_all();
-          issue(sc[d % R], tau + 1 + D);
+          issue(sc[d % R], tau + 1 + DC);
           GTNX_TM(2);
           land(sc[(d + 1) % R], tau + 1, std::true_type{});
           GTNX_TM(1);

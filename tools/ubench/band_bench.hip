@@ -25,7 +25,9 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&d_em, em.size() * 4));
   CK(hipMemcpy(d_em, em.data(), em.size() * 4, hipMemcpyHostToDevice));
   float* d_grad;
-  CK(hipMalloc(&d_grad, em.size() * 4));
+  const size_t grad_off = getenv("GRAD_OFF") ? size_t(atol(getenv("GRAD_OFF"))) : 0;  // bytes: where the gradient tensor starts relative to its allocation
+  CK(hipMalloc(&d_grad, em.size() * 4 + grad_off + 256));
+  d_grad = reinterpret_cast<float*>(reinterpret_cast<char*>(d_grad) + grad_off);
   std::vector<BandPair> pairs(B);
   size_t per_nodes = sizeof(BandNode) * N, per_flags = (N + 63) / 64 * 64, per_s = 4 * size_t(N);
   size_t per_g = per_nodes + per_flags + 2 * per_s;

@@ -32,5 +32,16 @@ for cfg in "$@"; do
     full_compose) run full_compose GTNX_FULL_COMPOSE=1 ;;
     sync_compose) run sync_compose GTNX_SYNC_COMPOSE=1 ;;
     no_deep) run no_deep GTNX_NO_DEEP=1 ;;
+    no_wide_compose) run no_wide_compose GTNX_NO_WIDE_COMPOSE=1 ;;
+    force_wide_compose) run force_wide_compose GTNX_FORCE_WIDE_COMPOSE=1 ;;
+    no_pairs_compose) run no_pairs_compose GTNX_NO_PAIRS_COMPOSE=1 ;;
+    trim_fwd_first) run trim_fwd_first GTNX_TRIM_FWD_FIRST=1 ;;
+    trim_fwd_never) run trim_fwd_never GTNX_TRIM_FWD_FIRST=0 ;;
+    grid_replication) run grid_replication GTNX_GRID_REPLICATION=1 ;;
+    inline_replication) run inline_replication GTNX_INLINE_REPLICATION=1 ;;
+    narrow_compose) run narrow_compose GTNX_NARROW_COMPOSE=1 ;;
+    fixed_grad_narrow) run fixed_grad_narrow GTNX_FIXED_GRAD_NARROW=1 ;;
+    mallopt) run mallopt GTNX_MALLOPT=1 ;;
+    args_in_place) run args_in_place GTNX_ARGS_IN_PLACE=1024 ;;
   esac
 done

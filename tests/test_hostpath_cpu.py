@@ -39,3 +39,18 @@ def test_host_path_runs_and_recycles_its_memory(mode):
     if mode == "c2":  # 256 result graphs per repetition out of one cached buffer
         s = re.search(r"graph slabs: (\d+) from the cache, (\d+) fresh", out)
         assert s and int(s.group(1)) >= 300 and int(s.group(1)) >= 8 * int(s.group(2)), out[-1000:]
+
+
+def test_garbage_of_a_thread_that_never_synchronises_is_reachable():
+    """handles destroyed on one thread go home to the list of the thread that made them; a maker that
+    never comes to a reclamation point used to pin every device block behind them.  tools/nullhip/inbox_step.cpp:
+    20 000 graphs made by a sleeping worker and destroyed by the main thread -- the worker's list takes at most 16 384
+    (the sender destroys the rest), and gtnx_empty_cache() takes every thread's list apart: in-use bytes drop to 0."""
+    _build()
+    env = dict(os.environ, LD_PRELOAD=os.path.join(NULLHIP, "_bin", "libnullhip.so"))
+    r = subprocess.run([os.path.join(NULLHIP, "_bin", "inbox_step"), "20000"], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "INBOX_OK" in out, out[-2000:]
+    m = re.search(r"(\d+) after destroying the handles on another thread", out)
+    assert m and int(m.group(1)) == 16384 * 512, out  # bounded: the rest was destroyed by the sender

@@ -54,3 +54,15 @@ def test_garbage_of_a_thread_that_never_synchronises_is_reachable():
     assert r.returncode == 0 and "INBOX_OK" in out, out[-2000:]
     m = re.search(r"(\d+) after destroying the handles on another thread", out)
     assert m and int(m.group(1)) == 16384 * 512, out  # bounded: the rest was destroyed by the sender
+
+
+def test_default_device_is_the_threads_and_is_never_assumed():
+    """with no gtnx_set_device anywhere the engine works on the device the calling thread already has
+    with HIP (eight fake devices, the thread on 5 -- a rank after torch.cuda.set_device(5)), leaves the thread there,
+    and keeps launching on its own device after somebody else's hipSetDevice on the same thread
+    (tools/nullhip/device_step.cpp: per-device launch counters, no launch on a stream whose device is not current)."""
+    _build()
+    env = dict(os.environ, LD_PRELOAD=os.path.join(NULLHIP, "_bin", "libnullhip.so"), NULLHIP_DEVICES="8", NULLHIP_ZERO="1")
+    r = subprocess.run([os.path.join(NULLHIP, "_bin", "device_step")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0 and "DEVICE_OK" in out, out[-2000:]

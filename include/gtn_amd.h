@@ -55,8 +55,11 @@ const char* gtnx_version(void);
 const char* gtnx_backend(void);
 int gtnx_device_count(void);                /* 0 when no GPU is visible */
 /* The device of the CALLING THREAD (hipSetDevice + the engine's per-device context: stream, memory pools).  A thread
- * that never chose is on the process default: the device of the first gtnx_set_device call, else 0 -- one rank per GPU
- * (torch.distributed) sets it once; a host that drives several GPUs gives each its own thread (gtn::parallelMapSharded,
+ * that never chose is on the process default: the device of the first gtnx_set_device call, else the device the
+ * first calling thread ALREADY has with HIP (a rank that only did torch.cuda.set_device(k) works on k and stays on k),
+ * never a silent 0.  Every entry point tells HIP the engine's device again (a hipSetDevice by the host framework on the
+ * same thread is not trusted to have been undone).  One rank per GPU (torch.distributed) sets it once; a host that
+ * drives several GPUs gives each its own thread (gtn::parallelMapSharded,
  * include/gtn/parallel.h; the pool threads of a parallelMap are put on the device of the thread that called it).
  * Graphs live on the device they were made on: using one from a thread on another device is GTNX_INVALID_ARGUMENT. */
 gtnx_status_t gtnx_set_device(int device);
@@ -77,12 +80,16 @@ gtnx_status_t gtnx_synchronize(void);
 gtnx_status_t gtnx_compose_mode(int mode, int* previous);
 /* bytes currently held by the engine's device arena pool / bytes in use */
 gtnx_status_t gtnx_memory_stats(uint64_t* reserved, uint64_t* in_use);
+/* Takes apart EVERY thread's deferred garbage (also that of threads which never come to a reclamation point), waits
+ * for the stream and gives the pooled device and pinned blocks back to the HIP runtime; also what an allocation does
+ * by itself before it reports out-of-memory. */
 gtnx_status_t gtnx_empty_cache(void);
 /* Destroys what the CALLING THREAD has let go of, or built for others and nobody refers to any more, since its last
  * reclamation point (released handles, finished tapes, the recorded calls of a parallelMap region); never waits for
  * the GPU, cheap when nothing is pending.  Every thread takes apart what it allocated: the engine reclaims by itself
- * wherever a thread would wait for the device, and the pool threads of include/gtn/parallel.h call this when their
- * share of a region is done. */
+ * wherever a thread would wait for the device and whenever a thread's own list stands for more than 8 192 graphs
+ * (GTNX_DEFER_FULL); the pool threads of include/gtn/parallel.h call this when their share of a region is done.  A
+ * thread's list takes at most 16 384 objects from OTHER threads: beyond that the thread that lets go destroys. */
 gtnx_status_t gtnx_reclaim(void);
 /* The calling thread is one of several host threads mapping per-graph functions over a batch
  * (gtn::parallelMap, parallel/parallel_map.h:153-188) from here until gtnx_parallel_leave: its

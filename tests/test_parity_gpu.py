@@ -1214,3 +1214,32 @@ def test_deep_thin_dags_vs_oracle(gtn, N, A, hub):
         finally:
             for k in env:
                 os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("N,jump", [(20000, 9000), (20000, 3), (700, 650)])
+def test_viterbi_path_walk_across_lds_windows(gtn, N, jump):
+    """viterbiPath's back-pointer walk (shortest.cpp:239-260 -> shortest.hip: path_pred_kernel + path_chase_kernel) stages
+    windows of 8 192 positions into LDS: a chain of N nodes whose best path takes arcs that jump further than a window
+    (i -> i + 9 000: every step re-stages), arcs that stay inside one (jump 3: ~2 700 steps per window), and a graph
+    smaller than one window -- labels, weights and score as the oracle's"""
+    rng = np.random.default_rng(N + jump)
+    src = list(range(N - 1))
+    dst = list(range(1, N))
+    w = (-np.abs(rng.normal(1.0, 0.3, N - 1))).tolist()           # the chain costs a unit per step
+    il = rng.integers(0, 7, N - 1).tolist()
+    for s in range(0, N - jump, max(1, jump // 2)):                # jumps are almost free: the best path takes them
+        src.append(s)
+        dst.append(s + jump)
+        w.append(float(-0.01 * rng.random()))
+        il.append(int(7 + rng.integers(0, 5)))
+    d = {"start": [1] + [0] * (N - 1), "accept": [0] * (N - 1) + [1], "src": src, "dst": dst, "il": il, "ol": il,
+         "w": gg._f32(w), "sort": None}
+    og = OGraph.from_dict(d)
+    g = gg.to_api(gtn, d)
+    p = gtn.viterbi_path(g)
+    want_score = og.shortest_distance(True)
+    assert float(p.weights_to_numpy().sum()) == pytest.approx(want_score, rel=1e-5)
+    labels = p.labels_to_list()
+    assert any(l >= 7 for l in labels), "the best path takes no jump: the case does not test what it says"
+    arcs, _ = og.shortest_path()
+    assert labels == [il[a] for a in arcs]

@@ -32,6 +32,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <stdexcept>
 #include <type_traits>
 
 #include "kernels.h"
@@ -394,347 +395,17 @@ __device__ __forceinline__ float wave_max_of(const float* v, int n) {
 // ==========================================================================================
 template <int NPL, bool UNIT, int K, bool VEC>
 __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
-  constexpr int RNk = K >= 4 ? 4 : K;  // rows between shifts of a wave's running row
-  constexpr int NP = K / RNk;          // shift periods per block
-  // ticks a staged chunk is in flight: 8 rows ahead, and never less than two ticks -- with one (K = 8) a request had
-  // ~1.5 us to come back and the landing wave waited another 1000 cycles for it every tick (band_bench_tm: land 1056)
-  constexpr int D = 8 / K > GTNX_FWD_DEPTH ? 8 / K : GTNX_FWD_DEPTH;
-  const BandPair P = pairs[blockIdx.x];
-  const int T = P.T, C = P.C, NS = P.NS;
-  extern __shared__ float lds[];
-  const BandLds L = band_lds(C, K, NSmax, false);
-  float* ering = lds + L.o_ering;
-  const BandMisc M = band_misc<K>(lds, L);
-  const int CS = L.CS;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool sweeper = wv < 4;
-  const int l = threadIdx.x & 63;
-  const int nblocks = (T + K - 1) / K;
-  const int nticks = nblocks + 3;
-  GTNX_TM_INIT(0);
-
-  if (sweeper) {
-    __builtin_amdgcn_s_setprio(1);  // the recursion is the critical path; the staging waves of the CU's other workgroup yield (2 %)
-    // ------------------------------------------------------------------ the recursion: no global loads
-    const int w = wv;
-    const int m0 = threadIdx.x * NPL;
-    NodeRegs<NPL> g;
-    load_nodes<NPL, false>(P, m0, g);
-    const bool writer = m0 < NS;
-    float a[NPL];
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) a[j] = g.start[j] ? 0.0f : NEGF;
-    double off = 0.0;  // this wave's shift: true alpha = a + off
-    GTNX_G float* arow = P.alpha + m0;
-    if (writer) {
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) arow[j] = a[j];
-    }
-    // pipeline position s = w: this wave publishes into region s + 1 and reads region s (0: constants)
-    float* bnd_own = M.bndr + (w + 1) * 4 * K * 2;
-    const float* bnd_prev = M.bndr + w * 4 * K * 2;
-    double* off_own = M.offr + (w + 1) * 16;
-    const double* off_prev = M.offr + w * 16;
-    if (threadIdx.x < 8 * K) M.bndr[threadIdx.x] = NEGF;
-    if (threadIdx.x < 16) M.offr[threadIdx.x] = 0.0;
-    if (l == 0) {
-      P.aoff[1 + w] = 0.0;
-      off_own[0] = 0.0;
-    }
-    if (NPL == 1) {
-      if (l >= 62) bnd_own[63 - l] = a[0];
-    } else if (l == 63) {
-      bnd_own[0] = a[NPL - 1];
-      bnd_own[1] = a[0];
-    }
-    lds_barrier();
-    for (int tau = 0; tau < nticks; ++tau) {
-      GTNX_TM(0);
-      const int beta = tau - w;
-      // (every block but the last holds K rows: that one, the common one, is compiled without the per-row tests --
-      //  a wave issues one instruction per four cycles whatever its kind, and the scalar compare / branch / exec-mask
-      //  instructions of `i < rows` were a sixth of the 583 a tick of eight rows took)
-      auto block = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int t0 = beta * K, rows = FULL ? K : min(K, T - t0);
-        const float* eb = ering + (beta % NBE) * K * CS;
-        float ev[K][NPL], bv1[K], bv2[K];
-        double offp[NP + 1];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-#pragma unroll
-          for (int j = 0; j < NPL; ++j) ev[i][j] = eb[i * CS + g.lab[j]];
-          // alpha[t0 + i] of the two nodes below this wave, in the previous wave's frame
-          const float* bp = bnd_prev + ((beta & 3) * K + i) * 2;
-          bv1[i] = bp[0];
-          bv2[i] = bp[1];
-        }
-#pragma unroll
-        for (int q = 0; q <= NP; ++q) offp[q] = off_prev[(beta * NP + q) & 15];
-        float hist[K][NPL];
-        float dconv = 0.0f;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-          if (FULL || i < rows) {
-            if (i % RNk == 0) dconv = float(offp[i / RNk] - off);
-            const float b1 = bv1[i] + dconv, b2 = bv2[i] + dconv;
-            const float p1 = wave_shr1(a[NPL - 1], b1);
-            const float p2 = NPL == 2 ? wave_shr1(a[0], b2) : wave_shr1(p1, b2);
-            float nw[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-              const float s1 = j == 0 ? p1 : a[0];
-              const float s2 = j == 0 ? p2 : p1;
-              float x0, x1, x2;
-              if (UNIT) {  // self-loop and previous-node arc everywhere, weight 0
-                x0 = a[j];
-                x1 = s1;
-                x2 = s2 + g.wi[2][j];
-              } else {
-                x0 = a[j] + g.wi[0][j];
-                x1 = s1 + g.wi[1][j];
-                x2 = s2 + g.wi[2][j];
-              }
-              nw[j] = lse3(x0, x1, x2) + ev[i][j];
-            }
-            if ((i + 1) % RNk == 0) {  // shift this wave's row t0 + i + 1 by its maximum
-              const float mx = wave_max_of(nw, NPL);
-              if (mx > DEADF) {
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) nw[j] -= mx;
-                off += double(mx);
-              } else if (w > 0) {
-                off = offp[(i + 1) / RNk];  // nothing alive here yet: follow the wave below
-              }
-              if (l == 0) {
-                const int p = (t0 + i + 1) / RNk;
-                off_own[p & 15] = off;
-                P.aoff[1 + p * 4 + w] = off;
-              }
-            }
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) hist[i][j] = a[j] = nw[j];
-          }
-        }
-        if (writer) {  // this wave never loads from HBM, so it never waits for these
-#pragma unroll
-          for (int i = 0; i < K; ++i)
-            if (FULL || i < rows) {
-              arow += NS;
-#pragma unroll
-              for (int j = 0; j < NPL; ++j) arow[j] = hist[i][j];
-            }
-        }
-        // boundary values of rows t0 + 1 .. t0 + rows for the wave above
-        if (NPL == 1 ? l >= 62 : l == 63) {
-#pragma unroll
-          for (int i = 0; i < K; ++i)
-            if (FULL || i < rows) {
-              float* bp = bnd_own + ((((beta & 3) * K + i + 1) & (4 * K - 1))) * 2;
-              if (NPL == 1) {
-                bp[63 - l] = hist[i][0];
-              } else {
-                bp[0] = hist[i][NPL - 1];
-                bp[1] = hist[i][0];
-              }
-            }
-        }
-      };
-      if (beta >= 0 && beta < nblocks) {
-        if (beta * K + K <= T) block(std::true_type{});
-        else block(std::false_type{});
-      }
-      GTNX_TM(5);
-      lds_barrier();
-      GTNX_TM(6);
-      GTNX_TM_TICK();
-    }
-    // score = log sum over accept nodes of alpha[T]  (shortest.cpp:153-167)
-    float f = NEGF;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) f = fmaxf(f, g.accept[j] ? a[j] : NEGF);
-    const float mx = wave_max(f);
-    float s = 0.0f;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) s += g.accept[j] ? ex2(a[j] - mx) : 0.0f;
-    s = wave_sum(s);
-    if (l == 0) {
-      M.fin[2 * w] = mx;
-      M.fin[2 * w + 1] = s;
-      M.find[w] = off;
-    }
-  } else {
-    // ------------------------------------------------------------------ helpers: everything else
-    const int hid = threadIdx.x - BW;
-    constexpr bool vec = VEC;  // host: C % 4 == 0 and 16-byte aligned emissions
-    const bool want_lse = P.norm != nullptr || P.rowlse != nullptr;
-    // staging of the emission ring: chunk c = rows [cK, cK + K) = block c
-    Stage<8> st[D];
-    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-    auto issue = [&](Stage<8>& s, int c) { s.template issue<VEC>(P.em + int64_t(c) * K * C, rows_of(c) * C, hid); };
-    GTNX_G float* const em_copy = P.em_copy;  // (uniform; null on every path but a region's first sweep)
-    // COPY is a compile-time choice (the helper's loop is instantiated twice, selected once, below): the copy's stores
-    // and their address arithmetic are not in the loop of the launches that make no copy
-    auto land = [&](const Stage<8>& s, int c, auto copy_tag) {
-      constexpr bool COPY = decltype(copy_tag)::value;
-      float* base = ering + (c % NBE) * K * CS;
-      GTNX_G float* cdst = em_copy + int64_t(c) * K * C;
-      s.template each<VEC>(rows_of(c) * C, C, hid, [&](int, int e, int r, int col, gtnx_f4 q) {
-        float* d = base + r * CS + col;
-        if (vec) *reinterpret_cast<gtnx_f4*>(d) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-        else d[0] = em2(q.x);
-        if (COPY) {  // the values as they came (natural log), where the backward sweep will read them
-          // (non-temporal: 16 bytes per lane that nothing in this launch reads again -- 0.334 -> 0.303 ms at C3; the
-          //  same on the alpha rows and the gradient rows, 4 bytes per lane, measured slower and is not done)
-          if (vec) __builtin_nontemporal_store(q, reinterpret_cast<GTNX_G gtnx_f4*>(cdst + e));
-          else __builtin_nontemporal_store(q.x, cdst + e);
-        }
-      });
-    };
-    // row-wise log2-sum-exp2 of a landed chunk (normaliser): 256 / K lanes per row, pairs
-    // (max, sum) per 16-lane group in phase A, merged per row by one lane in phase B (a tick later)
-    constexpr int LPR = BW / K, G16 = LPR / 16;
-    const int EPL = (C + LPR - 1) / LPR;  // <= 16
-    double normacc = 0.0;
-    // (N = 4 / 8 / 16 elements per lane, chosen once per launch shape: a loop over 16 with a runtime bound costs
-    //  sixteen v_exp_f32 whatever the bound is -- at C = 256 half of the normaliser's transcendentals were wasted)
-    auto lse_a_n = [&](int c, auto nconst) {
-      constexpr int NE = decltype(nconst)::value;
-      const int rows = rows_of(c), rr = hid / LPR, sub = hid - rr * LPR;
-      if (rows <= 0) return;
-      const float* e = ering + ((c % NBE) * K + min(rr, rows - 1)) * CS + sub * EPL;
-      float x[NE];
-      float m = NEGF;
-#pragma unroll
-      for (int i = 0; i < NE; ++i) {
-        x[i] = (i < EPL && sub * EPL + i < C) ? e[i] : NEGF;
-        m = fmaxf(m, x[i]);
-      }
-      m = row16_max(m);
-      float sum = 0.0f;
-#pragma unroll
-      for (int i = 0; i < NE; ++i) sum += (i < EPL) ? ex2(x[i] - m) : 0.0f;
-      sum = row16_sum(sum);
-      if ((hid & 15) == 0 && rr < rows) {
-        float* p = M.lsep + (c & 1) * 256 + (rr * 8 + (sub >> 4)) * 2;
-        p[0] = m;
-        p[1] = sum;
-      }
-    };
-    auto lse_a = [&](int c) {
-      if (EPL <= 4) lse_a_n(c, std::integral_constant<int, 4>{});        // uniform
-      else if (EPL <= 8) lse_a_n(c, std::integral_constant<int, 8>{});
-      else lse_a_n(c, std::integral_constant<int, 16>{});
-    };
-    auto lse_b = [&](int c) {
-      const int rows = rows_of(c);
-      if (hid < rows) {
-        const float* p = M.lsep + (c & 1) * 256 + hid * 16;
-        float Mx = p[0];
-#pragma unroll
-        for (int k = 1; k < G16; ++k) Mx = fmaxf(Mx, p[2 * k]);
-        float S = 0.0f;
-#pragma unroll
-        for (int k = 0; k < G16; ++k) S += p[2 * k + 1] * ex2(p[2 * k] - Mx);
-        const float l2 = Mx + lg2(S);
-        if (P.rowlse) P.rowlse[c * K + hid] = l2;
-        normacc += double(l2);
-      }
-    };
-    auto run = [&](auto copy_tag) {
-      // prologue: chunk 0 landed, chunks 1 .. D requested
-      issue(st[0], 0);
-      land(st[0], 0, copy_tag);
-#pragma unroll
-      for (int c = 1; c <= D; ++c) issue(st[c % D], c);
-      lds_barrier();
-      for (int tau0 = 0; tau0 < nticks; tau0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-          const int tau = tau0 + d;
-          if (tau >= nticks) break;
-          GTNX_TM(0);
-          // chunk tau + 1 lands (its ring block was last read a tick ago), chunk tau + 1 + D is requested
-          land(st[(d + 1) % D], tau + 1, copy_tag);
-          GTNX_TM(1);
-          issue(st[(d + 1) % D], tau + 1 + D);
-          GTNX_TM(2);
-          if (want_lse) {
-            if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
-            if (tau < nblocks) lse_a(tau);
-          }
-          GTNX_TM(4);
-          lds_barrier();
-          GTNX_TM(6);
-          GTNX_TM_TICK();
-        }
-      }
-    };
-    // The copy variant (a region's first sweep: the emissions are also stored where the backward sweep will read
-    // them) with ONE more staging set than chunks in flight, and the request made BEFORE the landing: a request into
-    // the registers a store has just read has to wait for that store (the only counter is vmcnt, and the compiler
-    // waits for all of it) -- the store's whole round trip, every tick.  Here the registers requested into are the
-    // ones landed a tick AGO, so what the wait at the top of a tick covers is a tick old.
-    auto run_copy = [&]() {
-      constexpr int DC = GTNX_FWD_COPY_DEPTH < 8 / K ? 8 / K : GTNX_FWD_COPY_DEPTH;  // ticks a request is in flight
-      constexpr int R = DC + 1;
-      Stage<8> sc[R];
-      issue(sc[0], 0);
-      land(sc[0], 0, std::true_type{});
-#pragma unroll
-      for (int c = 1; c <= DC; ++c) issue(sc[c % R], c);
-      lds_barrier();
-      for (int tau0 = 0; tau0 < nticks; tau0 += R) {
-#pragma unroll
-        for (int d = 0; d < R; ++d) {
-          const int tau = tau0 + d;
-          if (tau >= nticks) break;
-          GTNX_TM(0);
-          // chunk tau + 1 + DC is requested into the set chunk tau left a tick ago ((tau + 1 + DC) % R == tau % R),
-          // then chunk tau + 1 lands (its ring block was last read a tick ago)
-          sc[(d + 1) % R].settle_all();
-          issue(sc[d % R], tau + 1 + DC);
-          GTNX_TM(2);
-          land(sc[(d + 1) % R], tau + 1, std::true_type{});
-          GTNX_TM(1);
-          if (want_lse) {
-            if (tau >= 1 && tau - 1 < nblocks) lse_b(tau - 1);
-            if (tau < nblocks) lse_a(tau);
-          }
-          GTNX_TM(4);
-          lds_barrier();
-          GTNX_TM(6);
-          GTNX_TM_TICK();
-        }
-      }
-    };
-    if (em_copy) {  // (uniform)
-      if (GTNX_FWD_COPY_ROTATE) run_copy();
-      else run(std::true_type{});
-    } else {
-      run(std::false_type{});
-    }
-    if (hid < 16) M.red[hid] = normacc;
-  }
-  GTNX_TM_DUMP();
-  lds_barrier();
-  if (threadIdx.x == 0) {
-    double Mx = double(NEGF);
-    for (int k = 0; k < 4; ++k)
-      if (M.fin[2 * k] > DEADF) Mx = fmax(Mx, M.find[k] + double(M.fin[2 * k]));
-    const bool dead = !(Mx > double(DEADF));
-    float S = 0.0f;
-    for (int k = 0; k < 4; ++k)
-      if (M.fin[2 * k] > DEADF) S += M.fin[2 * k + 1] * ex2(float(M.find[k] + double(M.fin[2 * k]) - Mx));
-    const double z2 = dead ? double(NEGF) : Mx + double(lg2(S));
-    P.aoff[0] = z2;
-    P.score[0] = dead ? -__builtin_inff() : float(z2 * LN2);
-    if (P.norm) {
-      double n2 = 0.0;
-      for (int k = 0; k < 16; ++k) n2 += M.red[k];
-      P.norm[0] = n2 < double(DEADF) ? -__builtin_inff() : float(n2 * LN2);
-    }
-  }
+#define GTNX_BAND_PAIR pairs[blockIdx.x]
+#include "band_forward_body.inc"
+#undef GTNX_BAND_PAIR
+}
+// the same sweep with THE pair as the kernel's own argument: a single utterance through the per-graph functions is a
+// chain of dependent operations, and a 160-byte table copied to the device is one more of them
+template <int NPL, bool UNIT, int K, bool VEC>
+__global__ __launch_bounds__(WG) void band_forward_one_kernel(BandPair one, int NSmax) {
+#define GTNX_BAND_PAIR one
+#include "band_forward_body.inc"
+#undef GTNX_BAND_PAIR
 }
 
 // ==========================================================================================
@@ -752,610 +423,15 @@ __global__ __launch_bounds__(WG) void band_forward_kernel(const BandPair* __rest
 // register budget is 256 there and 128 otherwise
 template <int NPL, bool UNIT, bool GRADG, int K, bool VEC, bool BIG>
 __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
-  constexpr int RNk = K >= 4 ? 4 : K;
-  constexpr int NP = K / RNk;
-  const BandPair P = pairs[blockIdx.x];
-  const int T = P.T, C = P.C, NS = P.NS;
-  extern __shared__ float lds[];
-  const BandLds L = band_lds(C, K, NSmax, true);
-  float* ering = lds + L.o_ering;  // [NBGE blocks][K][CS]   emissions (kept until the block's gradient is out)
-  float* aring = lds + L.o_aring;  // [NBE blocks][K][NSmax] alpha rows
-  float* oring = lds + L.o_oring;  // [NBG blocks][K][NSmax] node posteriors
-  int* snode = reinterpret_cast<int*>(lds + L.o_snode);  // [n_lab] nodes sorted by (label, node)
-  const BandMisc M = band_misc<K>(lds, L);
-  float* lser = M.lsep;            // [NBG blocks][K] row log-sum-exp (softmax term)
-  const int CS = L.CS;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const bool sweeper = wv < 4;
-  const int l = threadIdx.x & 63;
-  const int nblocks = (T + K - 1) / K;
-  const int nticks = nblocks + 5;  // block c: row sums at tick c + 4, gradient rows out at tick c + 5
-  const GTNX_G double* ao = P.aoff;
-  const double z2 = uniform(ao[0]);
-  const bool dead = !(z2 > double(DEADF));
-  const float ds = uniform(P.delta[0]);
-  const bool want_em = P.grad_em != nullptr;
-  GTNX_TM_INIT(128);
-  // ---- who does what besides the recursion.  !SPLIT (the build): the sweepers sum the rows, the draining waves write
-  // every gradient row -- the form of rounds 3-4.  SPLIT (-DGTNX_BWD_SPLIT=1; two workgroups per CU, K >= 2): the row
-  // sums go to the DRAINING waves (wave d sums row d) and a block's gradient rows are written half by them, half by
-  // the STAGING waves, which idle through more than half of every tick (tools/ubench/band_bench_tm: sweepers 2 430
-  // busy cycles per tick with the sums, drainers 2 420, stagers 1 150).  Measured in round 5 and NOT the build:
-  // 0.47 against 0.42 ms -- a drain pass costs ~500 cycles before its first row (label runs, row scalars, addresses,
-  // LDS round trips), so two half passes are 1 250 + 1 250 where one was 2 000, and the sums take 800 cycles in a
-  // wave that is not a sweeper (drainers 2 380 per tick, sweepers idle for 1 100).
-  constexpr bool SPLIT = !BIG && K >= 2 && GTNX_BWD_SPLIT;
-  const float dn_k = P.delta_norm ? uniform(P.delta_norm[0]) : 0.0f;
-  const bool soft_k = P.delta_norm != nullptr && P.rowlse != nullptr;
-  float* const rnorm_k = lser + NBG * K;  // [NBG blocks][K] what makes a row's posteriors sum to one
-  auto rows_of_k = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-  // row sums of block c, row r, by one wave (lane l owns nodes 4l .. 4l+3, + 256 for the second read; the ring holds 0
-  // for nodes past N, so only whole reads past the row are masked).  Posteriors of a time step sum to one; in
-  // float32 the two sweeps and the score drift apart by ~1e-4 over a thousand steps (all nodes of a row alike): the
-  // row is rescaled to its exact total -- and, having the hot label's share in hand as well, the summing wave
-  // stores that gradient element.
-  struct RowSumRegs {
-    float in[NPL];
-    gtnx_f4 hot[NPL];
-  };
-  auto rowsum_init = [&](RowSumRegs& R) {
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-      const int mb = 256 * q + 4 * l;
-      R.in[q] = mb < NSmax ? 1.0f : 0.0f;
-      float hm[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int m = mb + k;
-        int lab = -1;
-        if (m < P.N) lab = P.nodes[m].lab;
-        settle(lab);
-        hm[k] = (P.hot >= 0 && lab == P.hot) ? 1.0f : 0.0f;
-      }
-      R.hot[q] = gtnx_f4{hm[0], hm[1], hm[2], hm[3]};
-    }
-  };
-  auto rowsum_do = [&](const RowSumRegs& R, int c, int r) {
-    const int rows = rows_of_k(c);
-    if (!want_em || r >= rows) return;
-    const float* ob = oring + ((c % NBG) * K + r) * NSmax;
-    gtnx_f4 v[NPL];
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) v[q] = *reinterpret_cast<const gtnx_f4*>(ob + min(256 * q + 4 * l, NSmax - 4));
-    const float em_hot = ering[((c % NBGE) * K + r) * CS + max(P.hot, 0)];
-    const float ls_hot = lser[(c % NBG) * K + r];
-    float all = 0.0f, hotp = 0.0f;
-#pragma unroll
-    for (int q = 0; q < NPL; ++q) {
-      all += (v[q].x * R.in[q] + v[q].y * R.in[q]) + (v[q].z * R.in[q] + v[q].w * R.in[q]);
-      hotp += (v[q].x * R.hot[q].x + v[q].y * R.hot[q].y) + (v[q].z * R.hot[q].z + v[q].w * R.hot[q].w);
-    }
-    if (dead) all = hotp = 0.0f;  // nothing wrote the ring
-    wave_sum63x2(all, hotp);
-    all = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(all), 63));
-    const float f = (all != 0.0f && !dead) ? ds * __builtin_amdgcn_rcpf(all) : 1.0f;
-    if (l == 63 && P.hot >= 0) {
-      float sm = dn_k * ex2(em_hot - ls_hot);
-      sm = soft_k ? sm : 0.0f;
-      P.grad_em[int64_t(T - 1 - c * K - r) * C + P.hot] = (dead ? 0.0f : hotp * f) + sm;
-    }
-    if (l == 0) rnorm_k[(c % NBG) * K + r] = f;
-  };
-  // gradient rows [R0, R1) of block c (every sweeper is through with it, its rows are summed): lane `hid` of a
-  // 256-lane role GATHERS the posteriors of the nodes that carry label hid (+ 256 ...), adds the normaliser's
-  // softmax term and stores the finished element -- coalesced, once.  The label runs come out of the table the
-  // drainers build in the posterior ring before the first tick.
-  constexpr int NCS = 8 / K;  // C <= 2048 / K labels, 256 per round
-  struct DrainRegs {
-    int s[NCS], e[NCS], n0[NCS], n1[NCS];
-    float m0[NCS], m1[NCS];
-    bool more_any;
-  };
-  auto drain_init = [&](DrainRegs& D, int hid) {
-    const int* cls = reinterpret_cast<const int*>(oring);
-#pragma unroll
-    for (int q = 0; q < NCS; ++q) {
-      const int cc = hid + q * BW;
-      D.s[q] = D.e[q] = 0;
-      if (cc < C && cc != P.hot) {
-        D.s[q] = cls[cc];
-        D.e[q] = cls[C + cc];
-      }
-      const int cnt = D.e[q] - D.s[q];
-      D.n0[q] = cnt > 0 ? snode[D.s[q]] : 0;
-      D.n1[q] = cnt > 1 ? snode[D.s[q] + 1] : 0;
-      D.m0[q] = cnt > 0 ? 1.0f : 0.0f;
-      D.m1[q] = cnt > 1 ? 1.0f : 0.0f;
-    }
-    // (does any lane of this wave carry a label that sits on more than two nodes?  Uniform, once: the loop over the
-    //  rest of such a run is a divergent one, and its tests alone cost every tick of every wave)
-    D.more_any = false;
-#pragma unroll
-    for (int q = 0; q < NCS; ++q) D.more_any = D.more_any || __builtin_amdgcn_ballot_w64(D.e[q] - D.s[q] > 2) != 0;
-  };
-  // FULL: a block of K rows (every block but the last): no per-row test
-  auto drain_rows = [&](const DrainRegs& D, int hid, int c, auto full_tag, auto r0_tag, auto r1_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    constexpr int R0 = decltype(r0_tag)::value, R1 = decltype(r1_tag)::value;
-    const int rows = FULL ? K : rows_of_k(c);
-    const float* ob = oring + (c % NBG) * K * NSmax;
-    const float* eb = ering + (c % NBGE) * K * CS;
-    const float* lb = lser + (c % NBG) * K;
-    const float* fb = rnorm_k + (c % NBG) * K;
-    GTNX_G float* dst = P.grad_em + int64_t(T - 1 - c * K) * C;  // row r of the block is t = T-1-cK-r
-#pragma unroll
-    for (int q = 0; q < NCS; ++q) {
-      if (q > 0 && q * BW >= C) break;  // uniform
-      const int cc = hid + q * BW;
-      const bool mine = cc < C && cc != P.hot;
-      // every LDS read of the rows first (addresses are known up front), then the arithmetic
-      float p0[K], p1[K], e[K], ls[K], f[K];
-#pragma unroll
-      for (int r = R0; r < R1; ++r) {
-        p0[r] = ob[r * NSmax + D.n0[q]];
-        p1[r] = ob[r * NSmax + D.n1[q]];
-        e[r] = eb[r * CS + min(cc, C - 1)];
-      }
-      if constexpr (K == 4) {  // the rows' scalars: two 16-byte broadcast reads
-        const gtnx_f4 l4 = *reinterpret_cast<const gtnx_f4*>(lb), f4 = *reinterpret_cast<const gtnx_f4*>(fb);
-        ls[0] = l4.x, ls[1] = l4.y, ls[2] = l4.z, ls[3] = l4.w;
-        f[0] = f4.x, f[1] = f4.y, f[2] = f4.z, f[3] = f4.w;
-      } else {
-#pragma unroll
-        for (int r = R0; r < R1; ++r) {
-          ls[r] = lb[r];
-          f[r] = fb[r];
-        }
-      }
-      float sum[K];
-#pragma unroll
-      for (int r = R0; r < R1; ++r) sum[r] = p0[r] * D.m0[q] + p1[r] * D.m1[q];
-      if (D.more_any) {  // uniform
-        for (int i = D.s[q] + 2; i < D.e[q]; ++i) {  // (a label on more than two nodes)
-          const float* o = ob + snode[i];
-#pragma unroll
-          for (int r = R0; r < R1; ++r) sum[r] += o[r * NSmax];
-        }
-      }
-      float val[K];
-#pragma unroll
-      for (int r = R0; r < R1; ++r) {
-        float sm = dn_k * ex2(e[r] - ls[r]);
-        sm = soft_k ? sm : 0.0f;
-        val[r] = (dead ? 0.0f : sum[r] * f[r]) + sm;
-      }
-      if (mine) {  // one exec mask for the block's stores; a row's address is a uniform base + this lane's label
-#pragma unroll
-        for (int r = R0; r < R1; ++r) {
-          if (FULL || r < rows) {
-            GTNX_G float* row = dst - int64_t(r) * C;
-            row[cc] = val[r];
-          }
-        }
-      }
-    }
-  };
-  auto drain_block = [&](const DrainRegs& D, int hid, int c, auto r0_tag, auto r1_tag) {
-    if (!want_em || c >= nblocks) return;
-    if (c * K + K <= T) drain_rows(D, hid, c, std::true_type{}, r0_tag, r1_tag);
-    else drain_rows(D, hid, c, std::false_type{}, r0_tag, r1_tag);
-  };
-  constexpr int KH = SPLIT ? K / 2 : K;  // rows of a block the draining waves write
-
-  if (sweeper) {
-    __builtin_amdgcn_s_setprio(1);  // the recursion is the critical path; the staging waves of the CU's other workgroup yield (2 %)
-    // ------------------------------------------------------------------ the recursion: no global loads in the loop
-    const int w = wv;
-    const int lag = 3 - w;
-    const int m0 = threadIdx.x * NPL;
-    NodeRegs<NPL> g;
-    load_nodes<NPL, true>(P, m0, g);
-    float b[NPL], post[NPL], acc[3][NPL];
-    // frames: true alpha[r] = stored + ao[1 + (r >> lgrn) * 4 + w] (periods of the FORWARD launch); true beta = b + bsum
-    const double Ahi = uniform(ao[1 + (T >> P.lgrn) * 4 + w]);
-    double bsum = 0.0;
-#pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      b[j] = g.accept[j] ? 0.0f : NEGF;
-      float ahi = m0 < NS ? P.alpha[int64_t(T) * NS + m0 + j] : NEGF;
-      settle(ahi);
-      // posterior of node n at time T (gradient row T-1); every later one comes out of the recursion
-      post[j] = dead ? 0.0f : ex2(ahi + b[j] + float(Ahi - z2));  // (the row scale carries d score)
-      acc[0][j] = acc[1][j] = acc[2][j] = 0.0f;
-      settle(g.lab[j]);
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        settle(g.wo[k][j]);
-        settle(g.ao[k][j]);
-      }
-    }
-    // pipeline position s = 3 - w: this wave publishes into region s + 1 and reads region s (0: constants)
-    float* bnd_own = M.bndr + (4 - w) * 4 * K * 2;
-    const float* bnd_prev = M.bndr + (3 - w) * 4 * K * 2;
-    double* off_own = M.offr + (4 - w) * 16;
-    const double* off_prev = M.offr + (3 - w) * 16;
-    if (threadIdx.x < 8 * K) M.bndr[threadIdx.x] = NEGF;
-    if (threadIdx.x < 16) M.offr[threadIdx.x] = 0.0;
-    if (l == 0) off_own[0] = 0.0;
-    lds_barrier();  // (the helpers sort labels in the posterior ring ...
-    lds_barrier();  //  ... done)
-    RowSumRegs rsr;
-    if constexpr (!SPLIT) rowsum_init(rsr);
-    lds_barrier();  // the label table is in registers: the posterior ring may be written
-    for (int tau = 0; tau < nticks; ++tau) {
-      GTNX_TM(0);
-      // (the last wave left block tau - 4 a tick ago.  SPLIT: the draining waves take the sums, see the head of the kernel)
-      if constexpr (!SPLIT) {
-        if (tau >= 4) rowsum_do(rsr, tau - 4, w);
-      }
-      GTNX_TM(3);
-      const int beta = tau - lag;
-      // (full blocks are compiled without the per-row tests, as in the forward sweep)
-      auto block = [&](auto full_tag) {
-        constexpr bool FULL = decltype(full_tag)::value;
-        const int v0 = beta * K, rows = FULL ? K : min(K, T - v0);
-        const float* eb = ering + (beta % NBGE) * K * CS;
-        const float* ab = aring + (beta % NBE) * K * NSmax;
-        const double* Ab = M.aofr + ((beta % NBE) * K) * 4 + w;
-        float* ob = oring + (beta % NBG) * K * NSmax + m0;
-        float ev[K][NPL], alov[K][NPL], bq1[K], bq2[K];
-        double Acur[K], offp[NP + 1];
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-#pragma unroll
-          for (int j = 0; j < NPL; ++j) {
-            ev[i][j] = eb[i * CS + g.lab[j]];
-            alov[i][j] = ab[i * NSmax + min(m0 + j, NS - 1)];  // (landed data only: lanes past N stay finite)
-          }
-          Acur[i] = Ab[i * 4];
-          // q[v0 + i] of the two nodes above this wave, in the next wave's frame
-          const float* bp = bnd_prev + ((beta & 3) * K + i) * 2;
-          bq1[i] = bp[0];
-          bq2[i] = bp[1];
-        }
-#pragma unroll
-        for (int q = 0; q <= NP; ++q) offp[q] = off_prev[(beta * NP + q) & 15];
-        float qh[K][NPL];
-        float dconv = 0.0f;
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-          if (FULL || i < rows) {
-            if (i % RNk == 0) dconv = float(offp[i / RNk] - bsum);
-            float q[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) qh[i][j] = q[j] = ev[i][j] + b[j];
-            // node posteriors at time t+1 (they belong to gradient row t): carried over from the step before
-            if (want_em && m0 < NSmax) {
-#pragma unroll
-              for (int j = 0; j < NPL; ++j) ob[i * NSmax + j] = post[j];
-            }
-            const float n1 = wave_shl1(q[0], bq1[i] + dconv);
-            const float n2 = NPL == 2 ? wave_shl1(q[NPL - 1], bq2[i] + dconv) : wave_shl1(n1, bq2[i] + dconv);
-            const float dl = float(Acur[i] + (bsum - z2));
-            float nb[NPL];
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) {
-              const float s1 = j + 1 < NPL ? q[NPL - 1] : n1;
-              const float s2 = j + 1 < NPL ? n1 : n2;
-              float y0, y1, y2;
-              if (UNIT) {
-                y0 = q[j];
-                y1 = s1;
-                y2 = s2 + g.wo[2][j];
-              } else {
-                y0 = q[j] + g.wo[0][j];
-                y1 = s1 + g.wo[1][j];
-                y2 = s2 + g.wo[2][j];
-              }
-              // exp(alpha[t][n] + y_k - score) is the posterior of arc k leaving (t, n); their sum is the
-              // posterior of node n at time t -- the NEXT row's gradient term, for one multiply
-              const float mx = fmaxf(fmaxf(y0, y1), y2);
-              const float f = ex2(alov[i][j] + mx + dl);
-              float S;
-              if (GRADG) {
-                const float e0 = ex2(y0 - mx), e1 = ex2(y1 - mx), e2 = ex2(y2 - mx);
-                S = e0 + e1 + e2;
-                acc[0][j] += e0 * f;
-                acc[1][j] += e1 * f;
-                acc[2][j] += e2 * f;
-              } else {  // the largest term is exactly 1
-                const float md = __builtin_amdgcn_fmed3f(y0, y1, y2), mn = fminf(fminf(y0, y1), y2);
-                S = 1.0f + ex2(md - mx) + ex2(mn - mx);
-              }
-              nb[j] = mx + lg2(S);
-              post[j] = f * S;
-            }
-            if ((i + 1) % RNk == 0) {  // shift this wave's beta row v0 + i + 1 by its maximum
-              const float mx = wave_max_of(nb, NPL);
-              if (mx > DEADF) {
-#pragma unroll
-                for (int j = 0; j < NPL; ++j) nb[j] -= mx;
-                bsum += double(mx);
-              } else if (w < 3) {
-                bsum = offp[(i + 1) / RNk];
-              }
-              if (l == 0) off_own[((v0 + i + 1) / RNk) & 15] = bsum;
-            }
-#pragma unroll
-            for (int j = 0; j < NPL; ++j) b[j] = nb[j];
-          }
-        }
-        // q of this wave's first two nodes for the wave below
-        if (NPL == 1 ? l < 2 : l == 0) {
-#pragma unroll
-          for (int i = 0; i < K; ++i)
-            if (FULL || i < rows) {
-              float* bp = bnd_own + ((beta & 3) * K + i) * 2;
-              if (NPL == 1) {
-                bp[l] = qh[i][0];
-              } else {
-                bp[0] = qh[i][0];
-                bp[1] = qh[i][NPL - 1];
-              }
-            }
-        }
-      };
-      if (beta >= 0 && beta < nblocks && !dead) {
-        if (beta * K + K <= T) block(std::true_type{});
-        else block(std::false_type{});
-      }
-      GTNX_TM(5);
-      lds_barrier();
-      GTNX_TM(6);
-      GTNX_TM_TICK();
-    }
-    GTNX_TM_DUMP();
-    if (GRADG && P.grad_fixed && !dead) {
-#pragma unroll
-      for (int j = 0; j < NPL; ++j)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-          if (g.ao[k][j] >= 0) P.grad_fixed[g.ao[k][j]] = acc[k][j] * ds;
-    }
-  } else if (wv < 8) {
-    // ------------------------------------------------------------------ stagers (waves 4-7): emissions and alpha rows into LDS
-    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
-    lds_barrier();  // (the drainers clear the label table ...
-    if constexpr (!BIG) {
-      // One stream per wave: waves 4, 5 stage the emissions of the even / odd chunks, waves 6, 7 the alpha rows and
-      // the rows' scalars.  (Both streams in every staging wave -- 2 x 20 staging registers -- made the kernel need
-      // 96 registers where six waves per SIMD, i.e. two workgroups of twelve waves per CU, leave 80.)  A wave lands
-      // chunk c and requests chunk c + 2 of its stream: a load has two ticks to arrive.
-      // chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; chunk row r (HBM order, ascending t) is row
-      // rows-1-r of its ring block; emissions land during tick c-2 (their ring has a block to spare), alpha rows
-      // and scalars during tick c-1
-      const int h = wv - 4, q = h & 1;
-      auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-      auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
-      // SPLIT: the upper half of every block's gradient rows is written here (lane hid_s of the four staging waves
-      // = label hid_s), after the tick's landing and requests
-      DrainRegs dr_s;
-      const int hid_s = threadIdx.x - BW;
-      auto drain_upper = [&](int tau) {
-        if constexpr (SPLIT) {
-          if (tau >= 5) drain_block(dr_s, hid_s, tau - 5, std::integral_constant<int, KH>{}, std::integral_constant<int, K>{});
-        }
-      };
-      if (h < 2) {
-        Stage<16, 64> se;
-        if constexpr (VEC) se.init_offsets(C, CS, K, l);
-        auto issue_em = [&](int c) { se.template issue<VEC>(P.em + int64_t(tlo_of(c)) * C, rows_of(c) * C, l); };
-        auto land_em = [&](int c) {
-          const int rows = rows_of(c);
-          se.settle_all();
-          GTNX_TM(4);
-          if (rows <= 0) return;
-          float* eb = ering + (c % NBGE) * K * CS;
-          if constexpr (VEC) {
-            se.each_vec(rows * C, (K - rows) * CS, l, [&](int, int o, gtnx_f4 v4) {
-              *reinterpret_cast<gtnx_f4*>(eb + o) = gtnx_f4{em2(v4.x), em2(v4.y), em2(v4.z), em2(v4.w)};
-            });
-          } else {
-            se.template each<false>(rows * C, C, l, [&](int, int, int r, int col, gtnx_f4 v4) {
-              eb[(rows - 1 - r) * CS + col] = em2(v4.x);
-            });
-          }
-        };
-        issue_em(q);  // prologue: the emissions of chunks 0 and 1 landed, 2 and 3 requested
-        land_em(q);
-        issue_em(q + 2);
-        lds_barrier();
-        if constexpr (SPLIT) drain_init(dr_s, hid_s);  // (the table is complete; the sweepers overwrite it after the next barrier)
-        lds_barrier();  // (... and have taken their label runs)
-        for (int tau = 0; tau < nticks; ++tau) {
-          GTNX_TM(0);
-#ifndef GTNX_EXP_NO_STAGE
-          if (((tau + 2) & 1) == q) {  // uniform
-            land_em(tau + 2);
-            GTNX_TM(1);
-            issue_em(tau + 4);
-            GTNX_TM(2);
-          }
-#endif
-          drain_upper(tau);
-          GTNX_TM(3);
-          lds_barrier();
-          GTNX_TM(6);
-          GTNX_TM_TICK();
-        }
-      } else {
-        Stage<16, 64> sa;
-        sa.init_offsets(NS, NSmax, K, l);
-        float lse_s = 0.0f;
-        double af_s = 0.0;
-        auto issue_rest = [&](int c) {
-          const int rows = rows_of(c), tlo = tlo_of(c);
-          sa.template issue<true>(P.alpha + int64_t(tlo) * NS, rows * NS, l);
-          if (rows > 0) {  // uniform; unconditional clamped loads (see Stage::issue)
-            if (soft) lse_s = P.rowlse[tlo + min(l, rows - 1)];
-            // alpha frame of ring row i = l / 4 (t = T-1-cK-i) for sweeper wave l % 4
-            af_s = ao[1 + ((T - 1 - c * K - min(l >> 2, rows - 1)) >> P.lgrn) * 4 + (l & 3)];
-          }
-        };
-        auto land_rest = [&](int c) {
-          const int rows = rows_of(c);
-          sa.settle_all();
-          asm volatile("" : "+v"(lse_s), "+v"(af_s));
-          if (rows <= 0) return;
-          float* ab = aring + (c % NBE) * K * NSmax;
-          sa.each_vec(rows * NS, (K - rows) * NSmax, l, [&](int, int o, gtnx_f4 v4) { *reinterpret_cast<gtnx_f4*>(ab + o) = v4; });
-          if (l < rows) lser[(c % NBG) * K + rows - 1 - l] = lse_s;
-          if (l < 4 * rows) M.aofr[((c % NBE) * K) * 4 + l] = af_s;
-        };
-        issue_rest(q);  // prologue: chunk 0 landed, chunk 1 (lands in tick 0) and chunk 2 requested
-        if (q == 0) {
-          land_rest(0);
-          issue_rest(2);
-        }
-        lds_barrier();
-        if constexpr (SPLIT) drain_init(dr_s, hid_s);
-        lds_barrier();  // (... and have taken their label runs)
-        for (int tau = 0; tau < nticks; ++tau) {
-          GTNX_TM(0);
-#ifndef GTNX_EXP_NO_STAGE
-          if (((tau + 1) & 1) == q) {  // uniform
-            land_rest(tau + 1);
-            GTNX_TM(1);
-            issue_rest(tau + 3);
-            GTNX_TM(2);
-          }
-#endif
-          drain_upper(tau);
-          GTNX_TM(3);
-          lds_barrier();
-          GTNX_TM(6);
-          GTNX_TM_TICK();
-        }
-      }
-      GTNX_TM_DUMP();
-    } else {
-      // BIG shapes (one workgroup per CU, registers to spare, short ticks): both streams in every staging wave,
-      // four ticks for a load to arrive
-    // ---- staging: chunk c = virtual rows [cK, cK + rows), i.e. t from T-1-cK down; HBM rows tlo ..
-    // Helper wave h owns the chunks c = h (mod 4): it lands chunk c during tick c - 1 and then
-    // requests chunk c + 4, so a load has four ticks to arrive and a wave only ever waits for its
-    // OWN loads (vmcnt is per wave) -- with one wave staging every chunk the compiler's counter
-    // made each request wait for the chunk requested a tick earlier.
-    const int h = wv - 4;
-    Stage<BIG ? 32 : 16, 64> se, sa;  // K C and K NS floats over 64 lanes (<= 1024, BIG: <= 2048)
-    if constexpr (VEC) se.init_offsets(C, CS, K, l);
-    sa.init_offsets(NS, NSmax, K, l);
-    float lse_s = 0.0f;
-    double af_s = 0.0;
-    auto rows_of = [&](int c) { return c < nblocks ? min(K, T - c * K) : 0; };
-    auto tlo_of = [&](int c) { return T - c * K - rows_of(c); };
-    auto issue = [&](int c) {
-      const int rows = rows_of(c), tlo = tlo_of(c);
-      se.template issue<VEC>(P.em + int64_t(tlo) * C, rows * C, l);
-      sa.template issue<true>(P.alpha + int64_t(tlo) * NS, rows * NS, l);
-      if (rows > 0) {  // uniform; unconditional clamped loads (see Stage::issue)
-        if (soft) lse_s = P.rowlse[tlo + min(l, rows - 1)];
-        // alpha frame of ring row i = l / 4 (t = T-1-cK-i) for sweeper wave l % 4
-        af_s = ao[1 + ((T - 1 - c * K - min(l >> 2, rows - 1)) >> P.lgrn) * 4 + (l & 3)];
-      }
-    };
-    // chunk row r (HBM order, ascending t) is row rows-1-r of its ring block.  A chunk lands in two
-    // halves a tick apart -- emissions during tick c-2 (their ring has a block to spare), alpha rows and
-    // the rows' scalars during tick c-1 -- so that no wave carries a whole chunk's landing in one tick:
-    // the landing wave was the critical path of a tick
-    auto land_em = [&](int c) {
-      const int rows = rows_of(c);
-      se.settle_all();
-      sa.settle_all();
-      asm volatile("" : "+v"(lse_s), "+v"(af_s));
-      GTNX_TM(4);
-      if (rows <= 0) return;
-      float* eb = ering + (c % NBGE) * K * CS;
-      if constexpr (VEC) {
-        se.each_vec(rows * C, (K - rows) * CS, l, [&](int, int o, gtnx_f4 q) {
-          *reinterpret_cast<gtnx_f4*>(eb + o) = gtnx_f4{em2(q.x), em2(q.y), em2(q.z), em2(q.w)};
-        });
-      } else {
-        se.template each<false>(rows * C, C, l, [&](int, int, int r, int col, gtnx_f4 q) {
-          eb[(rows - 1 - r) * CS + col] = em2(q.x);
-        });
-      }
-    };
-    auto land_rest = [&](int c) {
-      const int rows = rows_of(c);
-      sa.settle_all();
-      asm volatile("" : "+v"(lse_s), "+v"(af_s));
-      if (rows <= 0) return;
-      float* ab = aring + (c % NBE) * K * NSmax;
-      sa.each_vec(rows * NS, (K - rows) * NSmax, l, [&](int, int o, gtnx_f4 q) { *reinterpret_cast<gtnx_f4*>(ab + o) = q; });
-      if (l < rows) lser[(c % NBG) * K + rows - 1 - l] = lse_s;
-      if (l < 4 * rows) M.aofr[((c % NBE) * K) * 4 + l] = af_s;
-    };
-    // prologue: chunk 0 landed, the emissions of chunk 1 too, chunks 1 .. 4 requested
-    issue(h);
-    if (h == 0) {
-      land_em(0);
-      land_rest(0);
-      issue(4);
-    }
-    if (h == 1) land_em(1);
-    lds_barrier();
-    lds_barrier();  // (... and have taken their label runs)
-    for (int tau = 0; tau < nticks; ++tau) {
-      GTNX_TM(0);
-#ifndef GTNX_EXP_NO_STAGE
-      if (((tau + 1) & 3) == h) {  // uniform
-        land_rest(tau + 1);
-        GTNX_TM(1);
-        issue(tau + 5);
-        GTNX_TM(2);
-      }
-      if (((tau + 2) & 3) == h) {  // uniform
-        land_em(tau + 2);
-        GTNX_TM(1);
-      }
-#endif
-      GTNX_TM(3);
-      lds_barrier();
-      GTNX_TM(6);
-      GTNX_TM_TICK();
-    }
-    GTNX_TM_DUMP();
-    }
-  } else {
-    // ------------------------------------------------------------------ drainers (waves 8-11): the gradient rows
-    // (a role of its own since round 3: the staging wave that landed, requested AND drained in one tick was the
-    //  tick's critical path, and one role per code path needs 60-odd registers where the merged helper needed 104)
-    const int hid = threadIdx.x - 2 * BW;
-    const bool soft = P.delta_norm != nullptr && P.rowlse != nullptr;
-    // label -> run of nodes in snode (table built in the posterior ring, which is idle until the first tick)
-    int* cls = reinterpret_cast<int*>(oring);
-    for (int c = hid; c < 2 * C; c += BW) cls[c] = 0;
-    lds_barrier();
-    for (int i = hid; i < P.n_lab; i += BW) {
-      const int lab = P.slab[i];
-      snode[i] = P.snode[i];
-      if (i == 0 || P.slab[i - 1] != lab) cls[lab] = i;
-      if (i == P.n_lab - 1 || P.slab[i + 1] != lab) cls[C + lab] = i + 1;
-    }
-    lds_barrier();  // (the label table is complete; the stagers have landed the first chunks)
-    // this lane's labels (tid, tid + 256, ...): run of nodes, the first two inline
-    DrainRegs dr;
-    drain_init(dr, hid);
-    RowSumRegs rsr;
-    if constexpr (SPLIT) rowsum_init(rsr);
-    const int dw = wv - 8;  // (SPLIT: this wave sums row dw)
-    lds_barrier();  // (label runs are in registers; the posterior ring is the sweepers')
-    for (int tau = 0; tau < nticks; ++tau) {
-      GTNX_TM(0);
-#ifndef GTNX_EXP_NO_DRAIN  // (tools/ubench experiments: what the tick costs without the gradient rows / the staging)
-      if (tau >= 5) drain_block(dr, hid, tau - 5, std::integral_constant<int, 0>{}, std::integral_constant<int, KH>{});
-#endif
-      if constexpr (SPLIT) {  // the last sweeper left block tau - 4 a tick ago; its rows are drained a tick from now
-        if (tau >= 4) rowsum_do(rsr, tau - 4, dw);
-      }
-      GTNX_TM(3);
-      lds_barrier();
-      GTNX_TM(6);
-      GTNX_TM_TICK();
-    }
-    GTNX_TM_DUMP();
-  }
+#define GTNX_BAND_PAIR pairs[blockIdx.x]
+#include "band_backward_body.inc"
+#undef GTNX_BAND_PAIR
+}
+template <int NPL, bool UNIT, bool GRADG, int K, bool VEC, bool BIG>
+__global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_one_kernel(BandPair one, int NSmax) {
+#define GTNX_BAND_PAIR one
+#include "band_backward_body.inc"
+#undef GTNX_BAND_PAIR
 }
 
 
@@ -1857,29 +933,61 @@ void big_lds(K kern) {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
 }
 
+// `one` (host memory, n == 1): the pair goes as the kernel's argument instead of through the table (instantiated for
+// NPL = 1, 16-byte-aligned emissions, not BIG: band_one_ok)
 template <int NPL, int K, bool VEC>
-void launch_fwd2(const BandPair* d, int n, int ns, size_t lds, bool unit, hipStream_t st) {
+void launch_fwd2(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, hipStream_t st) {
   static std::atomic<uint64_t> done{0};
   if (gtnx_first_on_device first{done}) {
     big_lds(band_forward_kernel<NPL, true, K, VEC>);
     big_lds(band_forward_kernel<NPL, false, K, VEC>);
+    if constexpr (NPL == 1 && VEC) {
+      big_lds(band_forward_one_kernel<NPL, true, K, VEC>);
+      big_lds(band_forward_one_kernel<NPL, false, K, VEC>);
+    }
+  }
+  if constexpr (NPL == 1 && VEC) {
+    if (one) {
+      if (unit) hipLaunchKernelGGL((band_forward_one_kernel<NPL, true, K, VEC>), dim3(1), dim3(WG), lds, st, *one, ns);
+      else hipLaunchKernelGGL((band_forward_one_kernel<NPL, false, K, VEC>), dim3(1), dim3(WG), lds, st, *one, ns);
+      return;
+    }
   }
   if (unit) hipLaunchKernelGGL((band_forward_kernel<NPL, true, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
   else hipLaunchKernelGGL((band_forward_kernel<NPL, false, K, VEC>), dim3(n), dim3(WG), lds, st, d, ns);
 }
 template <int NPL, int K>
-void launch_fwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool vec, hipStream_t st) {
-  if (vec) launch_fwd2<NPL, K, true>(d, n, ns, lds, unit, st);
-  else launch_fwd2<NPL, K, false>(d, n, ns, lds, unit, st);
+void launch_fwd(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool vec, hipStream_t st) {
+  if (vec) launch_fwd2<NPL, K, true>(d, one, n, ns, lds, unit, st);
+  else launch_fwd2<NPL, K, false>(d, one, n, ns, lds, unit, st);
 }
 template <int NPL, int K, bool VEC, bool BIG>
-void launch_bwd3(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+void launch_bwd3(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+  constexpr bool ONE = NPL == 1 && VEC && !BIG;
   static std::atomic<uint64_t> done{0};
   if (gtnx_first_on_device first{done}) {
     big_lds(band_backward_kernel<NPL, true, true, K, VEC, BIG>);
     big_lds(band_backward_kernel<NPL, true, false, K, VEC, BIG>);
     big_lds(band_backward_kernel<NPL, false, true, K, VEC, BIG>);
     big_lds(band_backward_kernel<NPL, false, false, K, VEC, BIG>);
+    if constexpr (ONE) {
+      big_lds(band_backward_one_kernel<NPL, true, true, K, VEC, BIG>);
+      big_lds(band_backward_one_kernel<NPL, true, false, K, VEC, BIG>);
+      big_lds(band_backward_one_kernel<NPL, false, true, K, VEC, BIG>);
+      big_lds(band_backward_one_kernel<NPL, false, false, K, VEC, BIG>);
+    }
+  }
+  if constexpr (ONE) {
+    if (one) {
+      if (unit) {
+        if (gradg) hipLaunchKernelGGL((band_backward_one_kernel<NPL, true, true, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
+        else hipLaunchKernelGGL((band_backward_one_kernel<NPL, true, false, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
+      } else {
+        if (gradg) hipLaunchKernelGGL((band_backward_one_kernel<NPL, false, true, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
+        else hipLaunchKernelGGL((band_backward_one_kernel<NPL, false, false, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
+      }
+      return;
+    }
   }
   if (unit) {
     if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
@@ -1890,16 +998,17 @@ void launch_bwd3(const BandPair* d, int n, int ns, size_t lds, bool unit, bool g
   }
 }
 template <int NPL, int K>
-void launch_bwd(const BandPair* d, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, bool big, hipStream_t st) {
+void launch_bwd(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, bool big,
+                hipStream_t st) {
   if constexpr (K == 2) {
     if (big) {
-      if (vec) launch_bwd3<NPL, K, true, true>(d, n, ns, lds, unit, gradg, st);
-      else launch_bwd3<NPL, K, false, true>(d, n, ns, lds, unit, gradg, st);
+      if (vec) launch_bwd3<NPL, K, true, true>(d, one, n, ns, lds, unit, gradg, st);
+      else launch_bwd3<NPL, K, false, true>(d, one, n, ns, lds, unit, gradg, st);
       return;
     }
   }
-  if (vec) launch_bwd3<NPL, K, true, false>(d, n, ns, lds, unit, gradg, st);
-  else launch_bwd3<NPL, K, false, false>(d, n, ns, lds, unit, gradg, st);
+  if (vec) launch_bwd3<NPL, K, true, false>(d, one, n, ns, lds, unit, gradg, st);
+  else launch_bwd3<NPL, K, false, false>(d, one, n, ns, lds, unit, gradg, st);
 }
 
 constexpr size_t LDS_TWO = 78 * 1024;   // two workgroups per CU
@@ -1925,34 +1034,44 @@ int band_block_rows(int C, int max_NS, bool backward) {
   return 0;
 }
 
-void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st) {
+// a launch of ONE pair whose record may travel as the kernel's argument (host pointer `one` of launch_band_*)
+bool band_one_ok(int npl, int C, int max_NS, bool vec, bool backward) {
+  if (npl != 1 || !vec) return false;
+  if (!backward) return true;
+  const int K = band_block_rows(C, max_NS, true);
+  return !(K * C > 1024 || K * max_NS > 1024);
+}
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st,
+                         const BandPair* one) {
   if (n <= 0) return;
+  if (one && (n != 1 || !band_one_ok(npl, C, max_NS, vec, false))) throw std::logic_error("band.hip: not a single-pair launch");
   const int K = band_block_rows(C, 0, false);  // the forward sweep stages no alpha rows
   const size_t lds = 4 * size_t(band_lds(C, K, max_NS, false).total) + 64;
   if (npl == 1) {
-    if (K == 8) launch_fwd<1, 8>(d_pairs, n, max_NS, lds, unit, vec, st);
-    else if (K == 4) launch_fwd<1, 4>(d_pairs, n, max_NS, lds, unit, vec, st);
-    else launch_fwd<1, 2>(d_pairs, n, max_NS, lds, unit, vec, st);
+    if (K == 8) launch_fwd<1, 8>(d_pairs, one, n, max_NS, lds, unit, vec, st);
+    else if (K == 4) launch_fwd<1, 4>(d_pairs, one, n, max_NS, lds, unit, vec, st);
+    else launch_fwd<1, 2>(d_pairs, one, n, max_NS, lds, unit, vec, st);
   } else {
-    if (K == 8) launch_fwd<2, 8>(d_pairs, n, max_NS, lds, unit, vec, st);
-    else if (K == 4) launch_fwd<2, 4>(d_pairs, n, max_NS, lds, unit, vec, st);
-    else launch_fwd<2, 2>(d_pairs, n, max_NS, lds, unit, vec, st);
+    if (K == 8) launch_fwd<2, 8>(d_pairs, one, n, max_NS, lds, unit, vec, st);
+    else if (K == 4) launch_fwd<2, 4>(d_pairs, one, n, max_NS, lds, unit, vec, st);
+    else launch_fwd<2, 2>(d_pairs, one, n, max_NS, lds, unit, vec, st);
   }
 }
 
 // every pair of the launch shares C; max_NS: largest alpha row stride of the launch
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
-                          hipStream_t st) {
+                          hipStream_t st, const BandPair* one) {
   if (n <= 0) return;
+  if (one && (n != 1 || !band_one_ok(npl, C, max_NS, vec, true))) throw std::logic_error("band.hip: not a single-pair launch");
   const int K = band_block_rows(C, max_NS, true);
   const size_t lds = 4 * size_t(band_lds(C, K, max_NS, true).total) + 64;
   const bool big = K * C > 1024 || K * max_NS > 1024;
   if (npl == 1) {
-    if (K == 4) launch_bwd<1, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
-    else launch_bwd<1, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
+    if (K == 4) launch_bwd<1, 4>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
+    else launch_bwd<1, 2>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
   } else {
-    if (K == 4) launch_bwd<2, 4>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
-    else launch_bwd<2, 2>(d_pairs, n, max_NS, lds, unit, gradg, vec, big, st);
+    if (K == 4) launch_bwd<2, 4>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
+    else launch_bwd<2, 2>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
   }
 }
 

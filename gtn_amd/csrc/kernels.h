@@ -620,9 +620,13 @@ int band_row_stride(int N, int npl);       // NS
 int band_forward_lgrn(int C);
 // all pairs of one launch share C and npl; unit: self-loop + previous-node arc at every node, all weights 0;
 // vec: C % 4 == 0 and every pair's emissions are 16-byte aligned (16-byte staging loads)
-void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st);
+// `one` (HOST memory; a launch of one pair for which band_one_ok holds): the record travels as the kernel's own argument
+// and d_pairs is not read
+bool band_one_ok(int npl, int C, int max_NS, bool vec, bool backward);
+void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st,
+                         const BandPair* one = nullptr);
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
-                          hipStream_t st);
+                          hipStream_t st, const BandPair* one = nullptr);
 // dense regime
 void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set
 // backward: vin / vout = the two halves of a [2][nb][N] scratch (vin null on the first step)
@@ -659,6 +663,16 @@ struct ScalarArgs {
   GTNX_G float* out;
 };
 void launch_scalar_combine(const ScalarArgs* d_args, int n, float sa, float sb, hipStream_t st);
+void launch_scalar_combine_one(const ScalarArgs& a, float sa, float sb, hipStream_t st);  // the record as a kernel argument
+// o0[i] = s0 * d[i], o1[i] = s1 * d[i] (o1 may be null); seed != null: d is 1 and is written to *seed
+struct ScalarFanArgs {
+  const GTNX_G float* d;
+  GTNX_G float* seed;
+  GTNX_G float* o0;
+  GTNX_G float* o1;
+};
+void launch_scalar_fan(const ScalarFanArgs* d_args, int n, float s0, float s1, hipStream_t st);
+void launch_scalar_fan_one(const ScalarFanArgs& a, float s0, float s1, hipStream_t st);
 // dst[i] += src[i] for a batch of vectors (atomic when dst's may repeat)
 struct AxpyArgs {
   GTNX_G float* dst;

@@ -244,13 +244,28 @@ __global__ void fill_f32_kernel(float* p, float v, size_t n) {
   for (; i < n; i += stride) p[i] = v;
 }
 
-__global__ void scalar_combine_kernel(const ScalarArgs* __restrict__ args, int n, float sa, float sb) {
+// (args == nullptr: a single record, handed over in the kernel's own argument block -- the per-graph functions on one
+// utterance, where a 24-byte table copied to the device is one more operation of a dependent chain)
+__global__ void scalar_combine_kernel(const ScalarArgs* __restrict__ args, ScalarArgs one, int n, float sa, float sb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const ScalarArgs a = args[i];
+  const ScalarArgs a = args ? args[i] : one;
   float v = sa * (*a.a);
   if (a.b) v += sb * (*a.b);
   *a.out = v;
+}
+// a scalar op's gradient function: o0 = s0 * d, o1 = s1 * d (o1 may be null); seed != null: d is the seed of a
+// backward pass from this result (1, written to *seed: autograd.cpp:57-62) -- seed, and both inputs' gradients, in
+// one launch (what scalar_seed_kernel is to a batch record)
+__global__ void scalar_fan_kernel(const ScalarFanArgs* __restrict__ args, ScalarFanArgs one, int n, float s0, float s1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const ScalarFanArgs a = args ? args[i] : one;
+  float d = 1.0f;
+  if (a.seed) *a.seed = 1.0f;
+  else d = *a.d;
+  *a.o0 = s0 * d;
+  if (a.o1) *a.o1 = s1 * d;
 }
 
 __global__ void axpy_batch_kernel(const AxpyArgs* __restrict__ args, int atomic) {
@@ -371,7 +386,16 @@ void launch_fill_f32(float* p, float v, size_t n, hipStream_t st) {
   if (n) hipLaunchKernelGGL(fill_f32_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, v, n);
 }
 void launch_scalar_combine(const ScalarArgs* d, int n, float sa, float sb, hipStream_t st) {
-  if (n > 0) hipLaunchKernelGGL(scalar_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, n, sa, sb);
+  if (n > 0) hipLaunchKernelGGL(scalar_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, ScalarArgs{}, n, sa, sb);
+}
+void launch_scalar_combine_one(const ScalarArgs& a, float sa, float sb, hipStream_t st) {
+  hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, st, static_cast<const ScalarArgs*>(nullptr), a, 1, sa, sb);
+}
+void launch_scalar_fan(const ScalarFanArgs* d, int n, float s0, float s1, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(scalar_fan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, ScalarFanArgs{}, n, s0, s1);
+}
+void launch_scalar_fan_one(const ScalarFanArgs& a, float s0, float s1, hipStream_t st) {
+  hipLaunchKernelGGL(scalar_fan_kernel, dim3(1), dim3(64), 0, st, static_cast<const ScalarFanArgs*>(nullptr), a, 1, s0, s1);
 }
 void launch_axpy_batch(const AxpyArgs* d, int n, int64_t maxn, int atomic, hipStream_t st) {
   if (n <= 0 || maxn <= 0) return;

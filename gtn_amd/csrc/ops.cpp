@@ -245,31 +245,40 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
 // ======================================================================
 struct ScalarOp : OpRecord {
   ScalarKind kind;
+  bool seeded = false;  // op_backward ran this record's gradient function together with the seed (seed_scalar_root)
+  float scale(int input) const { return kind == SK_NEGATE || (kind == SK_SUBTRACT && input == 1) ? -1.0f : 1.0f; }
+  // the gradient function of member `out`: b0 = s0 d, b1 = s1 d into `buf`, handed to the inputs.  seed != null: d is
+  // the seed of a backward pass from `out` (one launch for seed and function)
   void backward(std::vector<Member>& ms) override {
+    if (seeded) {
+      seeded = false;
+      return;
+    }
+    run(ms, nullptr, nullptr);
+  }
+  void run(std::vector<Member>& ms, const DevMemP& seed_mem, float* seed) {
     Runtime& rt = Runtime::get();
     const int n = int(ms.size());
-    DevMemP buf = rt.alloc(sizeof(float) * 2 * size_t(n));
-    float* b0 = buf->as<float>();
+    DevMemP buf = seed ? seed_mem : rt.alloc(sizeof(float) * 2 * size_t(n));
+    float* b0 = seed ? seed + 1 : buf->as<float>();
     float* b1 = b0 + n;
-    std::vector<ScalarArgs> a0, a1;
+    std::vector<ScalarFanArgs> fan(static_cast<size_t>(n));
     GradSink sink;
     for (int m = 0; m < n; ++m) {
       Graph& out = ms[m].out;
-      float* d = grad_dev_ptr(out);
-      a0.push_back({d, nullptr, b0 + m});
+      fan[size_t(m)] = {seed ? nullptr : grad_dev_ptr(out), seed, b0 + m, nullptr};
       sink.add(out.g->inputs[0], buf, b0 + m);
       if (kind != SK_NEGATE) {
         // subtract only feeds input 1 when it wants a gradient (functions.cpp:55-57)
-        a1.push_back({d, nullptr, b1 + m});
+        fan[size_t(m)].o1 = b1 + m;
         sink.add(out.g->inputs[1], buf, b1 + m);
       }
     }
-    DevMemP d0 = upload_vec(a0);
-    launch_scalar_combine(d0->as<ScalarArgs>(), n, kind == SK_NEGATE ? -1.0f : 1.0f, 0.0f, rt.stream());
-    if (!a1.empty()) {
-      DevMemP d1 = upload_vec(a1);
-      launch_scalar_combine(d1->as<ScalarArgs>(), int(a1.size()), kind == SK_SUBTRACT ? -1.0f : 1.0f, 0.0f,
-                            rt.stream());
+    if (n == 1) {
+      launch_scalar_fan_one(fan[0], scale(0), scale(1), rt.stream());
+    } else {
+      DevMemP d = upload_vec(fan);
+      launch_scalar_fan(d->as<ScalarFanArgs>(), n, scale(0), scale(1), rt.stream());
     }
     sink.flush();
   }
@@ -318,10 +327,31 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
     set_dev_weights(out, res, res->as<float>() + i, 1);
     outs.push_back(std::move(out));
   }
-  DevMemP d = upload_vec(args);
-  launch_scalar_combine(d->as<ScalarArgs>(), int(n), k == SK_NEGATE ? -1.0f : 1.0f,
-                        k == SK_SUBTRACT ? -1.0f : 1.0f, rt.stream());
+  const float sa = k == SK_NEGATE ? -1.0f : 1.0f, sb = k == SK_SUBTRACT ? -1.0f : 1.0f;
+  if (n == 1) {  // one utterance through the per-graph functions: the record travels with the launch
+    launch_scalar_combine_one(args[0], sa, sb, rt.stream());
+  } else {
+    DevMemP d = upload_vec(args);
+    launch_scalar_combine(d->as<ScalarArgs>(), int(n), sa, sb, rt.stream());
+  }
   return outs;
+}
+
+// backward() from the result of a scalar op that holds no gradient yet (the loss of a criterion written with the
+// per-graph functions: subtract(forwardScore(emissions), forwardScore(intersect(...)))): the seed (autograd.cpp:57-62)
+// and the op's own gradient function in one launch instead of a fill, two tables and two launches
+static std::shared_ptr<ScalarOp> seed_scalar_root(Graph& root) {
+  if (!root.calc_grad() || root.is_grad_available() || root.num_arcs() != 1 || !root.g->has_grad_fn) return nullptr;
+  auto op = std::dynamic_pointer_cast<ScalarOp>(root.g->op);
+  if (!op || root.g->inputs.empty() || root.g->inputs.size() != (op->kind == SK_NEGATE ? 1u : 2u)) return nullptr;
+  Runtime& rt = Runtime::get();
+  DevMemP buf = rt.alloc(sizeof(float) * 3);  // [seed, input 0's share, input 1's share]
+  float* seed = buf->as<float>();
+  root.add_grad_device(buf, seed, /*adopt=*/true);
+  std::vector<Member> ms{{root.g->op_idx, root}};
+  op->run(ms, buf, seed);
+  op->seeded = true;
+  return op;
 }
 
 
@@ -465,6 +495,12 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
   GTNX_HOST_T("backward.total");
   Runtime& rt = Runtime::get();
   for (auto& r : roots) realize(r);
+  struct SeededScope {  // (a throw between the seed and the record's turn must not leave the mark behind)
+    std::shared_ptr<ScalarOp> op;
+    ~SeededScope() {
+      if (op) op->seeded = false;
+    }
+  } seeded;
   // ---- seed (autograd.cpp:57-67); seed == false: the roots hold their deltas already (batch.cpp)
   if (!seed) {
   } else if (grad) {
@@ -475,6 +511,7 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
       ensure_weights_device_batch(v);
       r.add_grad_device(grad->w->dev_mem, grad->w->dev, /*adopt=*/false);
     }
+  } else if (roots.size() == 1 && (seeded.op = seed_scalar_root(roots[0]))) {
   } else {
     size_t tot = 0;
     for (auto& r : roots) tot += size_t(r.num_arcs());

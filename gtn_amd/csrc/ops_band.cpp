@@ -12,6 +12,15 @@ void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool back
   bool one_key = true;  // (a criterion step: every pair has the same shape -- nothing to group)
   for (size_t i = 1; i < tab.size() && one_key; ++i) one_key = tab[i].first == tab[0].first;
   if (!one_key) std::stable_sort(tab.begin(), tab.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+  if (tab.size() == 1) {  // one utterance through the per-graph functions: the record travels with the launch
+    const BandLaunchKey& k = tab[0].first;
+    const BandPair& p = tab[0].second;
+    if (band_one_ok(k.npl, k.C, p.NS, k.vec != 0, backward)) {
+      if (backward) launch_band_backward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, k.gradg != 0, true, rt.stream(), &p);
+      else launch_band_forward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, true, rt.stream(), &p);
+      return;
+    }
+  }
   std::vector<BandPair> flat;
   flat.reserve(tab.size());
   for (auto& e : tab) flat.push_back(e.second);

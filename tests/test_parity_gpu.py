@@ -161,6 +161,86 @@ def test_ctc_criterion_known_answers(gtn):
     np.testing.assert_allclose(e.grad().weights_to_numpy(), expected_grad, atol=1e-5)
 
 
+def test_backward_from_a_scalar_op_result(gtn):
+    """autograd.cpp:57-67 through the per-graph functions when the root is the result of a scalar op: the seed and the
+    op's gradient function are one launch (ops.cpp: seed_scalar_root); same answers as the step-by-step form"""
+    def leaves():
+        return gtn.scalar_graph(3.0), gtn.scalar_graph(4.0)
+    a, b = leaves()
+    r = gtn.subtract(a, b)
+    gtn.backward(r)
+    assert (r.grad().item(), a.grad().item(), b.grad().item()) == (1.0, 1.0, -1.0)
+    a, b = leaves()
+    gtn.backward(gtn.add(a, b))
+    assert (a.grad().item(), b.grad().item()) == (1.0, 1.0)
+    a, _ = leaves()
+    gtn.backward(gtn.negate(a))
+    assert a.grad().item() == -1.0
+    a, _ = leaves()
+    gtn.backward(gtn.add(a, a))  # the same input twice: its gradient is the sum of both shares
+    assert a.grad().item() == 2.0
+    a, _ = leaves()
+    gtn.backward(gtn.subtract(a, a))
+    assert a.grad().item() == 0.0
+    a, b = gtn.scalar_graph(3.0), gtn.scalar_graph(4.0, False)  # functions.cpp:55-57: no gradient wanted
+    gtn.backward(gtn.subtract(a, b))
+    assert a.grad().item() == 1.0
+    with pytest.raises(Exception):
+        b.grad()
+    # a chain of scalar ops under the root, and a second backward over a retained tape (the root holds a gradient
+    # then: the general path accumulates onto it)
+    a, b = leaves()
+    r = gtn.negate(gtn.subtract(gtn.add(a, b), a))  # -(a + b - a)
+    gtn.backward(r, True)
+    assert (r.grad().item(), a.grad().item(), b.grad().item()) == (1.0, 0.0, -1.0)
+    gtn.backward(r, True)
+    assert (r.grad().item(), a.grad().item(), b.grad().item()) == (2.0, 0.0, -2.0)
+    # the tape is gone after a backward that did not retain it: the second one throws, and the first one's results stay
+    a, b = leaves()
+    r = gtn.subtract(a, b)
+    gtn.backward(r)
+    with pytest.raises(ValueError, match="Cannot Backward twice"):
+        gtn.backward(r)
+    assert (a.grad().item(), b.grad().item()) == (1.0, -1.0)
+    # a leaf that holds a gradient already accumulates
+    a, b = leaves()
+    gtn.backward(gtn.add(a, b))
+    gtn.backward(gtn.subtract(a, b))
+    assert (a.grad().item(), b.grad().item()) == (2.0, 0.0)
+
+
+@pytest.mark.parametrize("T,C,U", [(100, 28, 20), (37, 8, 5), (64, 256, 30)])
+def test_one_utterance_through_the_per_graph_functions(gtn, T, C, U):
+    """BASELINE C1's loop (benchmarks/ctc.cpp:60-108 at batch 1): a launch of ONE pair carries its record as the
+    kernel's argument (band.hip: band_*_one_kernel) -- same bits as the same utterance inside a table launch of two,
+    and the oracle's loss and gradients"""
+    import torch
+    em, tg = gg.ctc_inputs(4242 + T, 2, T, C, U)
+    dev = torch.from_numpy(em).cuda()
+
+    def run(idx):
+        ems = [gtn.linear_graph(T, C) for _ in idx]
+        for e, b in zip(ems, idx):
+            e.set_weights(dev[b].reshape(-1))
+        ctcs = [gg.to_api(gtn, gg.ctc_target_graph(tg[b].tolist())) for b in idx]
+        if len(idx) == 1:
+            loss = gtn.subtract(gtn.forward_score(ems[0]), gtn.forward_score(gtn.intersect(ctcs[0], ems[0])))
+            gtn.backward(loss)
+            return [loss.item()], [ems[0].grad().weights_to_numpy()], [ctcs[0].grad().weights_to_numpy()]
+        loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(gtn.intersect(ctcs, ems)))
+        gtn.backward(loss)
+        return gtn.items(loss), [e.grad().weights_to_numpy() for e in ems], [c.grad().weights_to_numpy() for c in ctcs]
+
+    l1, ge1, gc1 = run([0])
+    l2, ge2, gc2 = run([0, 1])
+    assert l1[0] == l2[0]
+    assert np.array_equal(ge1[0], ge2[0]) and np.array_equal(gc1[0], gc2[0])
+    want, wgrad = ctc_loss(em[0], tg[0])
+    assert l1[0] == pytest.approx(want, rel=RTOL)
+    z = abs(float(OGraph.linear(T, C, em[0]).shortest_distance()))
+    np.testing.assert_allclose(ge1[0].reshape(T, C), wgrad, rtol=max(RTOL, 8 * 1.2e-7 * z), atol=1e-4)
+
+
 # ---- golden fixtures ----------------------------------------------------------------------
 def test_golden_shortest(gtn, golden):
     for c in golden["shortest"]:

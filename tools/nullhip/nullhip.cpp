@@ -80,6 +80,13 @@ hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
 // NULLHIP_ZERO=1: zero-filled allocations and full-size copies -- deterministic (all-zero) "device"
 // results, for comparing the HOST behaviour of two builds on the same test program
 static const bool g_zero = std::getenv("NULLHIP_ZERO") != nullptr;
+// NULLHIP_TRACE=1: one line per device operation on stderr (copies with kind and bytes, fills, launches by kernel
+// name, synchronisations) -- the dependent chain a small step puts on the stream
+static const bool g_trace = std::getenv("NULLHIP_TRACE") != nullptr;
+static std::map<const void*, const char*>& kernels() {  // (filled by the fat binaries' constructors: before our statics)
+  static auto* m = new std::map<const void*, const char*>();
+  return *m;
+}
 hipError_t hipMalloc(void** p, size_t n) {
   if (posix_memalign(p, 256, n ? n : 256)) return hipErrorOutOfMemory;
   if (g_zero) std::memset(*p, 0, n ? n : 256);
@@ -100,13 +107,19 @@ hipError_t hipFree(void* p) {
 }
 hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return posix_memalign(p, 256, n ? n : 256) ? hipErrorOutOfMemory : hipSuccess; }
 hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
-hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t) {
+  if (g_trace) std::fprintf(stderr, "nullhip: memcpyAsync kind %d bytes %zu\n", int(k), n);
   // big tensor copies are the GPU's job; the host only pays the call
   if (g_zero || n <= (1u << 20)) std::memcpy(d, s, n);
   return hipSuccess;
 }
-hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k) {
+  if (g_trace) std::fprintf(stderr, "nullhip: memcpy kind %d bytes %zu\n", int(k), n);
+  std::memcpy(d, s, n);
+  return hipSuccess;
+}
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) {
+  if (g_trace) std::fprintf(stderr, "nullhip: memsetAsync bytes %zu\n", n);
   if (g_zero || n <= (1u << 20)) std::memset(d, v, n);
   return hipSuccess;
 }
@@ -114,7 +127,10 @@ hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {
   *s = reinterpret_cast<hipStream_t>(new Stream{t_dev});  // (never destroyed: the engine keeps its streams)
   return hipSuccess;
 }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) {
+  if (g_trace) std::fprintf(stderr, "nullhip: streamSynchronize\n");
+  return hipSuccess;
+}
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // the "GPU" is never busy
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(&g_dummy); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(&g_dummy); return hipSuccess; }
@@ -122,18 +138,27 @@ hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) {
+  if (g_trace) std::fprintf(stderr, "nullhip: eventSynchronize\n");
+  return hipSuccess;
+}
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-hipError_t hipLaunchKernel(const void*, dim3, dim3, void**, size_t, hipStream_t st) {
+hipError_t hipLaunchKernel(const void* f, dim3 g, dim3 b, void**, size_t, hipStream_t st) {
   const int d = dev_of_stream(st);
+  if (g_trace) {
+    auto it = kernels().find(f);
+    std::fprintf(stderr, "nullhip: launch %s grid %u block %u\n", it == kernels().end() ? "?" : it->second, g.x * g.y * g.z, b.x);
+  }
   g_launches[d].fetch_add(1);
   if (d != t_dev) g_wrong_device[d].fetch_add(1);  // the real runtime: hipErrorInvalidResourceHandle
   return hipSuccess;
 }
 void** __hipRegisterFatBinary(const void*) { static void* h; return &h; }
 void __hipUnregisterFatBinary(void**) {}
-void __hipRegisterFunction(void**, const void*, char*, const char*, unsigned, void*, void*, void*, void*, int*) {}
+void __hipRegisterFunction(void**, const void* host, char*, const char* name, unsigned, void*, void*, void*, void*, int*) {
+  kernels()[host] = name;
+}
 hipError_t __hipPushCallConfiguration(dim3 g, dim3 b, size_t sh, hipStream_t st) {
   t_grid = g; t_block = b; t_shmem = sh; t_stream = st;
   return hipSuccess;

@@ -193,8 +193,8 @@ def test_backward_from_a_scalar_op_result(gtn):
     r = gtn.negate(gtn.subtract(gtn.add(a, b), a))  # -(a + b - a)
     gtn.backward(r, True)
     assert (r.grad().item(), a.grad().item(), b.grad().item()) == (1.0, 0.0, -1.0)
-    gtn.backward(r, True)
-    assert (r.grad().item(), a.grad().item(), b.grad().item()) == (2.0, 0.0, -2.0)
+    gtn.backward(r, True)  # (autograd.cpp:46-56: every gradient function sees the ACCUMULATED gradient of its output)
+    assert (r.grad().item(), a.grad().item(), b.grad().item()) == (2.0, -1.0, -5.0)
     # the tape is gone after a backward that did not retain it: the second one throws, and the first one's results stay
     a, b = leaves()
     r = gtn.subtract(a, b)

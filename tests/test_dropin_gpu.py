@@ -65,7 +65,10 @@ def test_reference_ctc_benchmark_runs():
     assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
     times = dict(re.findall(r"Timing (\w+) \.\.\.\s+([0-9.e+-]+) msec", r.stdout))
     assert set(times) == {"ctcLoss", "ctcGrad", "ngramCtcLoss", "ngramCtcGrad", "ctcBatched"}, r.stdout
-    assert all(float(v) > 0 for v in times.values())
+    # (time_utils.h:26-44 counts whole milliseconds over 100 calls: a lambda that only ENQUEUES -- ctcLoss reads no
+    # result -- may print 0 when a call costs the host less than 10 us)
+    assert all(float(v) >= 0 for v in times.values()), r.stdout
+    assert float(times["ctcBatched"]) > 0 and float(times["ctcGrad"]) + float(times["ctcLoss"]) > 0, r.stdout
 
 
 @pytest.mark.gpu

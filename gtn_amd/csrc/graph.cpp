@@ -172,7 +172,7 @@ void ensure_band_device_batch(const std::vector<BandInfo*>& bs, const std::vecto
     b->dev_slab = dev->as<int>(os + 4 * nl);
   };
   for (size_t q = 0; q < todo.size(); ++q) body(q);
-  rt.h2d(dev->ptr, pin->ptr, total);
+  rt.h2d_pinned(dev->ptr, pin->ptr, total);
 }
 
 int Structure::max_degree() {
@@ -456,6 +456,13 @@ void Weights::ensure_host() {
     dev_valid = true;
   }
   host.resize(n);
+  float mv;
+  if (n == 1 && mirror.ptr && mirror_version == version && dev_valid && Runtime::get().mirror_read(mirror, &mv)) {
+    host[0] = mv;
+    mirror = {};
+    host_valid = true;
+    return;
+  }
   if (n) Runtime::get().d2h_sync(host.data(), dev, sizeof(float) * size_t(n));
   host_valid = true;
 }

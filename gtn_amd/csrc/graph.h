@@ -228,6 +228,10 @@ struct Weights {
   DevMemP dev_mem;
   float* dev = nullptr;
   bool dev_valid = false;
+  // the kernel that produced this ONE value wrote it to pinned host memory as well (runtime.h: mirror_slot), at
+  // `mirror_version`: ensure_host() waits for the stream and reads it there instead of copying
+  Runtime::MirrorSlot mirror;
+  uint64_t mirror_version = 0;
   void ensure_host();
 };
 

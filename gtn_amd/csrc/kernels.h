@@ -661,8 +661,10 @@ struct ScalarArgs {
   const GTNX_G float* a;
   const GTNX_G float* b; // may be nullptr
   GTNX_G float* out;
+  GTNX_G float* mirror;  // pinned host memory that gets the value too, or nullptr (runtime.h: mirror_slot)
 };
 void launch_scalar_combine(const ScalarArgs* d_args, int n, float sa, float sb, hipStream_t st);
+void launch_copy_small(void* dst, const void* src, size_t bytes, hipStream_t st);  // src: device or pinned host memory
 void launch_scalar_combine_one(const ScalarArgs& a, float sa, float sb, hipStream_t st);  // the record as a kernel argument
 // o0[i] = s0 * d[i], o1[i] = s1 * d[i] (o1 may be null); seed != null: d is 1 and is written to *seed
 struct ScalarFanArgs {

@@ -253,6 +253,20 @@ __global__ void scalar_combine_kernel(const ScalarArgs* __restrict__ args, Scala
   float v = sa * (*a.a);
   if (a.b) v += sb * (*a.b);
   *a.out = v;
+  if (a.mirror) *a.mirror = v;  // (pinned host memory: item() of this result waits for the stream and reads it there)
+}
+// a small copy as a kernel of our own (setWeights from a device pointer, a table out of a pinned block): the runtime's
+// hipMemcpyAsync costs the host twice what a launch does, and a single utterance through the per-graph functions waits
+// for the host at the head of its chain
+__global__ void copy_small_kernel(void* __restrict__ dst, const void* __restrict__ src, size_t bytes, int vec) {
+  const size_t i0 = blockIdx.x * size_t(blockDim.x) + threadIdx.x, stride = size_t(gridDim.x) * blockDim.x;
+  if (vec == 16) {
+    for (size_t i = i0; i < bytes / 16; i += stride) static_cast<uint4*>(dst)[i] = static_cast<const uint4*>(src)[i];
+  } else if (vec == 4) {
+    for (size_t i = i0; i < bytes / 4; i += stride) static_cast<uint32_t*>(dst)[i] = static_cast<const uint32_t*>(src)[i];
+  } else {
+    for (size_t i = i0; i < bytes; i += stride) static_cast<uint8_t*>(dst)[i] = static_cast<const uint8_t*>(src)[i];
+  }
 }
 // a scalar op's gradient function: o0 = s0 * d, o1 = s1 * d (o1 may be null); seed != null: d is the seed of a
 // backward pass from this result (1, written to *seed: autograd.cpp:57-62) -- seed, and both inputs' gradients, in
@@ -390,6 +404,12 @@ void launch_scalar_combine(const ScalarArgs* d, int n, float sa, float sb, hipSt
 }
 void launch_scalar_combine_one(const ScalarArgs& a, float sa, float sb, hipStream_t st) {
   hipLaunchKernelGGL(scalar_combine_kernel, dim3(1), dim3(64), 0, st, static_cast<const ScalarArgs*>(nullptr), a, 1, sa, sb);
+}
+void launch_copy_small(void* dst, const void* src, size_t bytes, hipStream_t st) {
+  if (!bytes) return;
+  const uintptr_t both = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | uintptr_t(bytes);
+  const int vec = both % 16 == 0 ? 16 : both % 4 == 0 ? 4 : 1;
+  hipLaunchKernelGGL(copy_small_kernel, dim3(grid_for(bytes / size_t(vec), 256, 512)), dim3(256), 0, st, dst, src, bytes, vec);
 }
 void launch_scalar_fan(const ScalarFanArgs* d, int n, float s0, float s1, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(scalar_fan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d, ScalarFanArgs{}, n, s0, s1);

@@ -328,7 +328,12 @@ std::vector<Graph> op_scalar(ScalarKind k, std::vector<Graph>& a, std::vector<Gr
     outs.push_back(std::move(out));
   }
   const float sa = k == SK_NEGATE ? -1.0f : 1.0f, sb = k == SK_SUBTRACT ? -1.0f : 1.0f;
-  if (n == 1) {  // one utterance through the per-graph functions: the record travels with the launch
+  if (n == 1) {  // one utterance through the per-graph functions: the record travels with the launch, and the value
+                 // (a loss, as a rule) goes to pinned host memory too: item() will not need a copy
+    Weights& w = *outs[0].w;
+    w.mirror = rt.mirror_slot();
+    w.mirror_version = w.version;
+    args[0].mirror = w.mirror.ptr;
     launch_scalar_combine_one(args[0], sa, sb, rt.stream());
   } else {
     DevMemP d = upload_vec(args);

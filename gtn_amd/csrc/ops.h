@@ -127,7 +127,7 @@ DevMemP upload_vec(const std::vector<T>& v) {
   if (bytes) {
     PinnedMemP p = rt.alloc_pinned(bytes);
     std::memcpy(p->ptr, v.data(), bytes);
-    rt.h2d(d->ptr, p->ptr, bytes);
+    rt.h2d_pinned(d->ptr, p->ptr, bytes);
   }
   return d;
 }

@@ -1,6 +1,8 @@
 // runtime.cpp -- see runtime.h
 #include "runtime.h"
 
+#include "kernels.h"
+
 #include <malloc.h>
 
 #include <atomic>
@@ -458,7 +460,9 @@ DevMemP Runtime::alloc(size_t bytes) {
 
 DevMemP Runtime::alloc_zero(size_t bytes) {
   DevMemP m = alloc(bytes);
-  HIP_CHECK(hipMemsetAsync(m->ptr, 0, bytes ? bytes : 1, stream_));
+  // (blocks are multiples of 256 bytes: whole words.  Small ones by a kernel of ours, like d2d)
+  if (bytes <= (size_t(1) << 20) && m->bytes % 4 == 0) launch_fill_i32(m->as<int>(), 0, (bytes + 3) / 4, stream_);
+  else HIP_CHECK(hipMemsetAsync(m->ptr, 0, bytes ? bytes : 1, stream_));
   return m;
 }
 
@@ -563,8 +567,51 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
   drain_while_busy();
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
+// (up to a megabyte by a kernel of ours -- kernels.h: launch_copy_small; the runtime's copy costs the host about twice
+// a launch, and the copies of this size are the ones at the head of a latency chain: setWeights of one utterance)
 void Runtime::d2d(void* dst, const void* src, size_t bytes) {
-  if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_));
+  if (!bytes) return;
+  if (bytes <= (size_t(1) << 20)) {
+    launch_copy_small(dst, src, bytes, stream_);
+    return;
+  }
+  HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_));
+}
+void Runtime::h2d_pinned(void* dst, const void* pinned_src, size_t bytes) {
+  if (!bytes) return;
+  if (bytes <= 4096) {  // (pinned blocks are mapped into the device's address space: the kernel reads the host's copy)
+    launch_copy_small(dst, pinned_src, bytes, stream_);
+    return;
+  }
+  HIP_CHECK(hipMemcpyAsync(dst, pinned_src, bytes, hipMemcpyHostToDevice, stream_));
+}
+
+Runtime::MirrorSlot Runtime::mirror_slot() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!mirror_ring_) {
+      OnDevice here(device_);
+      void* p = nullptr;
+      HIP_CHECK(hipHostMalloc(&p, sizeof(float) * kMirrorSlots, hipHostMallocDefault));
+      mirror_gen_ = new std::atomic<uint64_t>[kMirrorSlots];
+      for (size_t i = 0; i < kMirrorSlots; ++i) mirror_gen_[i].store(0);
+      mirror_ring_ = static_cast<float*>(p);
+    }
+  }
+  const uint64_t g = mirror_next_.fetch_add(1) + 1;  // (never 0)
+  const size_t i = size_t(g % kMirrorSlots);
+  mirror_gen_[i].store(g);
+  return {mirror_ring_ + i, g};
+}
+bool Runtime::mirror_read(const MirrorSlot& m, float* out) {
+  if (!m.ptr || !mirror_ring_) return false;
+  const size_t i = size_t(m.ptr - mirror_ring_);
+  if (i >= kMirrorSlots || mirror_gen_[i].load() != m.gen) return false;
+  sync();
+  const float v = *static_cast<volatile float*>(m.ptr);
+  if (mirror_gen_[i].load() != m.gen) return false;  // handed out again meanwhile: the value may be the next owner's
+  *out = v;
+  return true;
 }
 
 // ---------------------------------------------------------------- profiler

@@ -124,6 +124,18 @@ class Runtime {
   void h2d(void* dst, const void* src, size_t bytes);
   void d2h_sync(void* dst, const void* src, size_t bytes);  // returns after the data landed
   void d2d(void* dst, const void* src, size_t bytes);
+  void h2d_pinned(void* dst, const void* pinned_src, size_t bytes);  // src from alloc_pinned: small ones by a kernel of ours
+
+  // ---- a ring of pinned floats for kernels that produce ONE scalar (the loss of a criterion written with the
+  // per-graph functions): the kernel writes its value there as well, and item() of that result waits for the stream
+  // instead of putting a copy on it.  A slot is handed out again after kMirrorSlots others: mirror_read says so.
+  struct MirrorSlot {
+    float* ptr = nullptr;
+    uint64_t gen = 0;
+  };
+  static constexpr size_t kMirrorSlots = 1024;
+  MirrorSlot mirror_slot();
+  bool mirror_read(const MirrorSlot& m, float* out);  // waits for the stream; false: the slot has a new owner
 
   // ---- profiler: hipEvent pairs around kernel families on the launch stream
   void prof_enable(bool on);
@@ -143,6 +155,9 @@ class Runtime {
  private:
   explicit Runtime(int device);
   void collect_prof();
+  float* mirror_ring_ = nullptr;
+  std::atomic<uint64_t>* mirror_gen_ = nullptr;
+  std::atomic<uint64_t> mirror_next_{0};
   hipStream_t own_stream_ = nullptr;
   hipStream_t stream_ = nullptr;
   int device_ = 0;

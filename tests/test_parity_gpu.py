@@ -212,8 +212,8 @@ def test_backward_from_a_scalar_op_result(gtn):
 @pytest.mark.parametrize("T,C,U", [(100, 28, 20), (37, 8, 5), (64, 256, 30)])
 def test_one_utterance_through_the_per_graph_functions(gtn, T, C, U):
     """BASELINE C1's loop (benchmarks/ctc.cpp:60-108 at batch 1): a launch of ONE pair carries its record as the
-    kernel's argument (band.hip: band_*_one_kernel) -- same bits as the same utterance inside a table launch of two,
-    and the oracle's loss and gradients"""
+    kernel's argument (band.hip: band_*_one_kernel) -- the same utterance inside a vector call of two agrees, and so do
+    the oracle's loss and gradients"""
     import torch
     em, tg = gg.ctc_inputs(4242 + T, 2, T, C, U)
     dev = torch.from_numpy(em).cuda()
@@ -233,8 +233,11 @@ def test_one_utterance_through_the_per_graph_functions(gtn, T, C, U):
 
     l1, ge1, gc1 = run([0])
     l2, ge2, gc2 = run([0, 1])
-    assert l1[0] == l2[0]
-    assert np.array_equal(ge1[0], ge2[0]) and np.array_equal(gc1[0], gc2[0])
+    # (the vector overloads run as batch records: another route to the same sweeps -- the normaliser's share joins the
+    # emission gradient elsewhere, G's arc gradients are atomic sums -- so last-bit differences, not equal bits)
+    assert l1[0] == pytest.approx(l2[0], rel=1e-6)
+    np.testing.assert_allclose(ge1[0], ge2[0], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(gc1[0], gc2[0], rtol=1e-5, atol=1e-5)
     want, wgrad = ctc_loss(em[0], tg[0])
     assert l1[0] == pytest.approx(want, rel=RTOL)
     z = abs(float(OGraph.linear(T, C, em[0]).shortest_distance()))

@@ -209,6 +209,23 @@ def test_backward_from_a_scalar_op_result(gtn):
     assert (a.grad().item(), b.grad().item()) == (2.0, 0.0)
 
 
+def test_scalar_result_read_through_its_pinned_mirror(gtn):
+    """item() of a scalar op's single result reads the value its kernel also wrote to pinned host memory
+    (runtime.h: mirror_slot) -- also after the ring of slots went round, and not after the weights were replaced"""
+    a = gtn.scalar_graph(1.5)
+    first = gtn.add(a, gtn.scalar_graph(0.25))
+    rs = [gtn.subtract(gtn.scalar_graph(float(i)), a) for i in range(1500)]  # more results than the ring has slots
+    assert rs[-1].item() == 1499.0 - 1.5
+    assert first.item() == 1.75          # its slot has a new owner: read from the device
+    assert rs[700].item() == 700.0 - 1.5  # (a slot of the second lap, still its own)
+    assert rs[3].item() == 3.0 - 1.5      # (first lap: handed out again)
+    r = gtn.negate(a)
+    r.set_weights([42.0])
+    assert r.item() == 42.0
+    r = gtn.negate(a)
+    assert gtn.negate(r).item() == 1.5 and r.item() == -1.5
+
+
 @pytest.mark.parametrize("T,C,U", [(100, 28, 20), (37, 8, 5), (64, 256, 30)])
 def test_one_utterance_through_the_per_graph_functions(gtn, T, C, U):
     """BASELINE C1's loop (benchmarks/ctc.cpp:60-108 at batch 1): a launch of ONE pair carries its record as the

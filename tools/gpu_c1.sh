@@ -17,6 +17,15 @@ for i in (1, 2, 3):
     except Exception as e:
         print("c1 run", i, "failed", e)
 PY
+timeout 200 python tools/bench_configs.py c2 2>$out/c2.err | tail -n 1 > $out/c2.json
+python - <<PY
+import json
+try:
+    d = json.load(open("$out/c2.json"))
+    print("c2", {k: d[k] for k in d if k.startswith("ms") or k.startswith("value")})
+except Exception as e:
+    print("c2 failed", e)
+PY
 root=$(pwd)
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --memory-copy-trace --stats --output-format csv -d $root/$out/prof -o c1 -- python $root/tools/bench_configs.py c1 > $root/$out/prof.log 2>&1)
 find $out/prof -name "*stats*" | head

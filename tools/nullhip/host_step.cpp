@@ -71,6 +71,10 @@ int main(int argc, char** argv) {
     getrusage(RUSAGE_SELF, &ru);
     std::printf("minor page faults per step: %.0f\n", double(ru.ru_minflt - flt0) / (steps - 3));
   }
+  if (all.empty()) {  // (the first three steps are warm-up)
+    std::printf("host ms/step: not measured (steps <= 3)\n");
+    return 0;
+  }
   std::sort(all.begin(), all.end());
   std::printf("host ms/step: best %.2f median %.2f mean %.2f + reclaim %.2f (B=%d T=%d C=%d U=%d)\n", best,
               all[all.size() / 2], sum / (steps - 3), rsum / (steps - 3), B, T, C, U);

@@ -428,14 +428,7 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const B
 #undef GTNX_BAND_PAIR
 }
 template <int NPL, bool UNIT, bool GRADG, int K, bool VEC, bool BIG>
-__global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_one_kernel(BandPair one, int NSmax, int zero_fixed) {
-  // zero_fixed > 0: G's arc gradients (atomic sums below) have not been zero-filled by the host -- one dependent
-  // operation less in front of this launch
-  if (GRADG && zero_fixed > 0) {
-    for (int i = threadIdx.x; i < zero_fixed; i += WGB) one.grad_fixed[i] = 0.0f;
-    __threadfence();
-    __syncthreads();
-  }
+__global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_one_kernel(BandPair one, int NSmax) {
 #define GTNX_BAND_PAIR one
 #include "band_backward_body.inc"
 #undef GTNX_BAND_PAIR
@@ -969,7 +962,7 @@ void launch_fwd(const BandPair* d, const BandPair* one, int n, int ns, size_t ld
   else launch_fwd2<NPL, K, false>(d, one, n, ns, lds, unit, st);
 }
 template <int NPL, int K, bool VEC, bool BIG>
-void launch_bwd3(const BandPair* d, const BandPair* one, int zf, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+void launch_bwd3(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
   constexpr bool ONE = NPL == 1 && VEC && !BIG;
   static std::atomic<uint64_t> done{0};
   if (gtnx_first_on_device first{done}) {
@@ -987,11 +980,11 @@ void launch_bwd3(const BandPair* d, const BandPair* one, int zf, int n, int ns, 
   if constexpr (ONE) {
     if (one) {
       if (unit) {
-        if (gradg) hipLaunchKernelGGL((band_backward_one_kernel<NPL, true, true, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns, zf);
-        else hipLaunchKernelGGL((band_backward_one_kernel<NPL, true, false, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns, zf);
+        if (gradg) hipLaunchKernelGGL((band_backward_one_kernel<NPL, true, true, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
+        else hipLaunchKernelGGL((band_backward_one_kernel<NPL, true, false, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
       } else {
-        if (gradg) hipLaunchKernelGGL((band_backward_one_kernel<NPL, false, true, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns, zf);
-        else hipLaunchKernelGGL((band_backward_one_kernel<NPL, false, false, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns, zf);
+        if (gradg) hipLaunchKernelGGL((band_backward_one_kernel<NPL, false, true, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
+        else hipLaunchKernelGGL((band_backward_one_kernel<NPL, false, false, K, VEC, BIG>), dim3(1), dim3(WGB), lds, st, *one, ns);
       }
       return;
     }
@@ -1005,17 +998,17 @@ void launch_bwd3(const BandPair* d, const BandPair* one, int zf, int n, int ns, 
   }
 }
 template <int NPL, int K>
-void launch_bwd(const BandPair* d, const BandPair* one, int zf, int n, int ns, size_t lds, bool unit, bool gradg, bool vec,
-                bool big, hipStream_t st) {
+void launch_bwd(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, bool big,
+                hipStream_t st) {
   if constexpr (K == 2) {
     if (big) {
-      if (vec) launch_bwd3<NPL, K, true, true>(d, one, zf, n, ns, lds, unit, gradg, st);
-      else launch_bwd3<NPL, K, false, true>(d, one, zf, n, ns, lds, unit, gradg, st);
+      if (vec) launch_bwd3<NPL, K, true, true>(d, one, n, ns, lds, unit, gradg, st);
+      else launch_bwd3<NPL, K, false, true>(d, one, n, ns, lds, unit, gradg, st);
       return;
     }
   }
-  if (vec) launch_bwd3<NPL, K, true, false>(d, one, zf, n, ns, lds, unit, gradg, st);
-  else launch_bwd3<NPL, K, false, false>(d, one, zf, n, ns, lds, unit, gradg, st);
+  if (vec) launch_bwd3<NPL, K, true, false>(d, one, n, ns, lds, unit, gradg, st);
+  else launch_bwd3<NPL, K, false, false>(d, one, n, ns, lds, unit, gradg, st);
 }
 
 constexpr size_t LDS_TWO = 78 * 1024;   // two workgroups per CU
@@ -1067,20 +1060,18 @@ void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max
 
 // every pair of the launch shares C; max_NS: largest alpha row stride of the launch
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
-                          hipStream_t st, const BandPair* one, int one_zero_fixed) {
+                          hipStream_t st, const BandPair* one) {
   if (n <= 0) return;
   if (one && (n != 1 || !band_one_ok(npl, C, max_NS, vec, true))) throw std::logic_error("band.hip: not a single-pair launch");
-  if (!one && one_zero_fixed) throw std::logic_error("band.hip: only a single-pair launch zero-fills G's gradient");
-  const int zf = one_zero_fixed;
   const int K = band_block_rows(C, max_NS, true);
   const size_t lds = 4 * size_t(band_lds(C, K, max_NS, true).total) + 64;
   const bool big = K * C > 1024 || K * max_NS > 1024;
   if (npl == 1) {
-    if (K == 4) launch_bwd<1, 4>(d_pairs, one, zf, n, max_NS, lds, unit, gradg, vec, big, st);
-    else launch_bwd<1, 2>(d_pairs, one, zf, n, max_NS, lds, unit, gradg, vec, big, st);
+    if (K == 4) launch_bwd<1, 4>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
+    else launch_bwd<1, 2>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
   } else {
-    if (K == 4) launch_bwd<2, 4>(d_pairs, one, zf, n, max_NS, lds, unit, gradg, vec, big, st);
-    else launch_bwd<2, 2>(d_pairs, one, zf, n, max_NS, lds, unit, gradg, vec, big, st);
+    if (K == 4) launch_bwd<2, 4>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
+    else launch_bwd<2, 2>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
   }
 }
 

@@ -625,9 +625,8 @@ int band_forward_lgrn(int C);
 bool band_one_ok(int npl, int C, int max_NS, bool vec, bool backward);
 void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st,
                          const BandPair* one = nullptr);
-// one_zero_fixed > 0 (single-pair form only): one->grad_fixed[0, one_zero_fixed) has NOT been zero-filled; the kernel does it
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
-                          hipStream_t st, const BandPair* one = nullptr, int one_zero_fixed = 0);
+                          hipStream_t st, const BandPair* one = nullptr);
 // dense regime
 void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set
 // backward: vin / vout = the two halves of a [2][nb][N] scratch (vin null on the first step)

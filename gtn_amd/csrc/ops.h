@@ -60,9 +60,7 @@ struct BandLaunchKey {
   bool operator==(const BandLaunchKey& o) const { return !(*this < o) && !(o < *this); }
 };
 int band_vec_ok(const BandPair& p);
-// one_zero_fixed (backward, a table of one pair for which band_launch_is_one holds): see launch_band_backward
-void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, int one_zero_fixed = 0);
-bool band_launch_is_one(const std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward);
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward);
 
 enum ScalarKind { SK_NEGATE = 0, SK_ADD = 1, SK_SUBTRACT = 2 };
 

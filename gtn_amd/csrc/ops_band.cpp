@@ -6,10 +6,7 @@ namespace gtnx {
 
 int band_vec_ok(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
 // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
-bool band_launch_is_one(const std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward) {
-  return tab.size() == 1 && band_one_ok(tab[0].first.npl, tab[0].first.C, tab[0].second.NS, tab[0].first.vec != 0, backward);
-}
-void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, int one_zero_fixed) {
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward) {
   Runtime& rt = Runtime::get();
   if (tab.empty()) return;
   bool one_key = true;  // (a criterion step: every pair has the same shape -- nothing to group)
@@ -19,13 +16,11 @@ void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool back
     const BandLaunchKey& k = tab[0].first;
     const BandPair& p = tab[0].second;
     if (band_one_ok(k.npl, k.C, p.NS, k.vec != 0, backward)) {
-      if (backward)
-        launch_band_backward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, k.gradg != 0, true, rt.stream(), &p, one_zero_fixed);
+      if (backward) launch_band_backward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, k.gradg != 0, true, rt.stream(), &p);
       else launch_band_forward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, true, rt.stream(), &p);
       return;
     }
   }
-  if (one_zero_fixed) throw_logic("band_launch: only a single-pair launch zero-fills G's gradient");
   std::vector<BandPair> flat;
   flat.reserve(tab.size());
   for (auto& e : tab) flat.push_back(e.second);
@@ -108,11 +103,10 @@ struct BandSdOp : OpRecord {
         fb = align_up(fb + 4 * size_t(fixed[i].s->A), 256);
       }
     }
-    DevMemP gem = rt.alloc(eb ? eb : 1);  // every row is written by the kernel
-    DevMemP gfx = rt.alloc(fb ? fb : 1);  // arcs that never match stay 0: zero-filled at the launch (plan.zero)
+    DevMemP gem = rt.alloc(eb ? eb : 1);       // every row is written by the kernel
+    DevMemP gfx = rt.alloc_zero(fb ? fb : 1);  // arcs that never match stay 0
     ChainGradPlan local;
     ChainGradPlan& plan = t_chain_plan ? *t_chain_plan : local;
-    if (fb) plan.zero.push_back({gfx->as<float>(), fb});
     plan.keep.push_back(gem);
     plan.keep.push_back(gfx);
     plan.keep.push_back(arena);
@@ -164,18 +158,9 @@ void flush_chain_plan() {
     }
     tab.push_back({BandSdOp::Key{b.C, b.npl, b.unit, b.gradg, b.vec}, b.p});
   }
-  // G's gradient blocks: one fill per record -- or none, when the plan is a single pair whose kernel takes its
-  // record as an argument (it zero-fills its own block: one dependent operation less for one utterance)
-  int one_zero = 0;
-  if (plan->zero.size() == 1 && band_launch_is_one(tab, true) && tab[0].second.grad_fixed == plan->zero[0].first) {
-    one_zero = int(plan->zero[0].second / 4);
-  } else {
-    for (auto& z : plan->zero) launch_fill_i32(reinterpret_cast<int*>(z.first), 0, z.second / 4, Runtime::get().stream());
-  }
-  plan->zero.clear();
   if (!tab.empty()) {
     GTNX_PROF("band_forward_score_grad", plan->bytes);
-    band_launch(tab, true, one_zero);
+    BandSdOp::launch(tab, true);
   }
   plan->sink.flush();
   // normalisers without a sweep: their own kernel

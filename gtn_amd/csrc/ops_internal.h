@@ -74,9 +74,6 @@ struct ChainGradPlan {
   };
   std::unordered_map<Weights*, Lin> lin;  // by chain weights
   std::vector<Band> band;
-  // G's arc-gradient blocks the records allocated WITHOUT zero-filling them (bytes, multiples of 4): flush_chain_plan
-  // fills them -- or, when the whole plan is one single-pair launch, lets that kernel do it
-  std::vector<std::pair<float*, size_t>> zero;
   std::vector<DevMemP> keep;
   GradSink sink;
   double bytes = 0;

@@ -6,7 +6,6 @@
 #include <malloc.h>
 
 #include <atomic>
-#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -251,32 +250,9 @@ void Runtime::side_join(const SideJobP& job) {
   if (job->err) std::rethrow_exception(job->err);
 }
 
-// Wait for the engine stream.  A blocking hipStreamSynchronize wakes the caller through an interrupt, microseconds
-// after the stream ran dry; a caller that waits for a SHORT chain (one utterance through the per-graph functions: a
-// loss every 100 us) pays that every time.  So: poll the stream for up to GTNX_SYNC_SPIN_US microseconds (default
-// 150; 0: never), then block.  A long wait costs the polling thread that bounded spin once.
-void Runtime::wait_stream() {
-  static const long spin_us = [] {
-    const char* e = std::getenv("GTNX_SYNC_SPIN_US");
-    return e ? std::atol(e) : 150L;
-  }();
-  if (spin_us > 0) {
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-      if (hipStreamQuery(stream_) != hipErrorNotReady) {  // done -- or an error, which the call below reports
-        (void)hipGetLastError();
-        break;
-      }
-      (void)hipGetLastError();
-      if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
-    }
-  }
-  HIP_CHECK(hipStreamSynchronize(stream_));
-}
-
 void Runtime::sync() {
   drain_while_busy();  // the GPU is (usually) still busy: reclaim while we would wait
-  wait_stream();
+  HIP_CHECK(hipStreamSynchronize(stream_));
 }
 
 namespace {
@@ -581,7 +557,7 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
     PinnedMemP p = alloc_pinned(bytes);
     HIP_CHECK(hipMemcpyAsync(p->ptr, src, bytes, hipMemcpyDeviceToHost, stream_));
     drain_while_busy();
-    wait_stream();
+    HIP_CHECK(hipStreamSynchronize(stream_));
     std::memcpy(dst, p->ptr, bytes);
     return;
   }
@@ -589,7 +565,7 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
   // call until the stream gets there, so this is the last moment the GPU is busy
   if (bytes) HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream_));
   drain_while_busy();
-  wait_stream();
+  HIP_CHECK(hipStreamSynchronize(stream_));
 }
 // (up to a megabyte by a kernel of ours -- kernels.h: launch_copy_small; the runtime's copy costs the host about twice
 // a launch, and the copies of this size are the ones at the head of a latency chain: setWeights of one utterance)

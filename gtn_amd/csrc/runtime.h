@@ -72,7 +72,6 @@ class Runtime {
   hipStream_t stream() const { return stream_; }
   void set_stream(hipStream_t s);
   void sync();
-  void wait_stream();  // poll for GTNX_SYNC_SPIN_US microseconds (default 150), then hipStreamSynchronize
 
   DevMemP alloc(size_t bytes);            // uninitialised
   DevMemP alloc_zero(size_t bytes);       // + hipMemsetAsync(0)

@@ -8,7 +8,6 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests -m gpu -q > $out/pytest.log 2>&1; echo "pytest exit $?" >> $out/pytest.log
 tail -n 5 $out/pytest.log
 for i in 1 2 3; do timeout 120 python tools/bench_configs.py c1 2>$out/c1_$i.err | tail -n 1 > $out/c1_$i.json; done
-for s in 0 1000; do GTNX_SYNC_SPIN_US=$s timeout 120 python tools/bench_configs.py c1 2>/dev/null | tail -n 1 | python -c "import json,sys; print('c1 with GTNX_SYNC_SPIN_US=$s: ms_per_loss', json.loads(sys.stdin.read())['ms_per_loss'])"; done
 python - <<PY
 import json
 for i in (1, 2, 3):

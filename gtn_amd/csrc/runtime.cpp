@@ -569,9 +569,23 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
 }
 // (up to a megabyte by a kernel of ours -- kernels.h: launch_copy_small; the runtime's copy costs the host about twice
 // a launch, and the copies of this size are the ones at the head of a latency chain: setWeights of one utterance)
+namespace {
+// may a kernel on `dev` touch p?  (A caller's pointer may live on ANOTHER GPU of the process: the runtime's copy
+// handles that with or without peer access, a kernel of ours does not.  One GPU in the process: nothing to ask.)
+bool local_to(const void* p, int dev) {
+  static const int ndev = Runtime::device_count();
+  if (ndev <= 1) return true;
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return a.type == hipMemoryTypeHost || (a.type == hipMemoryTypeDevice && a.device == dev);
+}
+}  // namespace
 void Runtime::d2d(void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
-  if (bytes <= (size_t(1) << 20)) {
+  if (bytes <= (size_t(1) << 20) && local_to(src, device_) && local_to(dst, device_)) {
     launch_copy_small(dst, src, bytes, stream_);
     return;
   }

@@ -362,7 +362,7 @@ BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank
   {
     PinnedMemP pin = rt.alloc_pinned(sizeof(int) * (total ? total : 1));
     std::memcpy(pin->ptr, labels, sizeof(int) * total);
-    rt.h2d(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
+    rt.h2d_pinned(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
   }
   std::vector<CtcTargetArgs> args;
   args.resize(size_t(n));
@@ -439,7 +439,7 @@ BatchP batch_asg_force_align(const int* labels, const int* lengths, int n, Graph
   {
     PinnedMemP pin = rt.alloc_pinned(sizeof(int) * (total ? total : 1));
     std::memcpy(pin->ptr, labels, sizeof(int) * total);
-    rt.h2d(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
+    rt.h2d_pinned(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
   }
   std::vector<AsgFalArgs> args;
   args.resize(size_t(n));
@@ -1084,7 +1084,7 @@ void batch_prefetch_items(const BatchP& x) {
     return;
   }
   x->host_pin = rt.alloc_pinned(sizeof(float) * size_t(x->n));
-  HIP_CHECK(hipMemcpyAsync(x->host_pin->ptr, x->v_dev, sizeof(float) * size_t(x->n), hipMemcpyDeviceToHost, rt.stream()));
+  rt.d2h_pinned_async(x->host_pin->ptr, x->v_dev, sizeof(float) * size_t(x->n));
   HIP_CHECK(hipEventRecord(ev, rt.stream()));
   x->host_ev = ev;
 }

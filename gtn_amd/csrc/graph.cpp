@@ -409,7 +409,7 @@ void PendingCopy::settle() {
     DevMemP d = rt.alloc(bytes);
     PinnedMemP p = rt.alloc_pinned(bytes);
     std::memcpy(p->ptr, segs.data(), bytes);
-    rt.h2d(d->ptr, p->ptr, bytes);
+    rt.h2d_pinned(d->ptr, p->ptr, bytes);
     launch_copy_segments(d->as<CopySeg>(), int(segs.size()), max_bytes, rt.stream());
   }
   done.store(true, std::memory_order_release);
@@ -929,7 +929,7 @@ void Graph::add_grad_device(const DevMemP& owner, float* dev, bool adopt) {
   PinnedMemP pin = rt.alloc_pinned(sizeof(AxpyArgs));
   *pin->as<AxpyArgs>() = a;
   DevMemP d = rt.alloc(sizeof(AxpyArgs));
-  rt.h2d(d->ptr, pin->ptr, sizeof(AxpyArgs));
+  rt.h2d_pinned(d->ptr, pin->ptr, sizeof(AxpyArgs));
   launch_axpy_batch(d->as<AxpyArgs>(), 1, n, 0, rt.stream());
   gw.host_valid = false;
   gw.host_escaped = false;  // the device copy is the live one now
@@ -1058,7 +1058,7 @@ void ensure_device_batch(const std::vector<Structure*>& ss) {
     s->dev_mem = dev;
     s->dev_valid = true;
   });
-  rt.h2d(dev->ptr, pin->ptr, pk.total);
+  rt.h2d_pinned(dev->ptr, pin->ptr, pk.total);
 }
 
 void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
@@ -1108,7 +1108,7 @@ void ensure_weights_device_batch(const std::vector<Weights*>& ws) {
     w->dev = dev->as<float>(offs[i]);
     w->dev_valid = true;
   }
-  rt.h2d(dev->ptr, pin->ptr, pk.total);
+  rt.h2d_pinned(dev->ptr, pin->ptr, pk.total);
 }
 
 DGraph device_view(Graph& gr) {
@@ -1423,7 +1423,7 @@ void ensure_schedule_batch(const std::vector<Structure*>& ss, bool need_rank) {
     v.out_arc = reinterpret_cast<const int*>(db + o.oa);
     todo[i]->sched = sc;
   }
-  rt.h2d(dev->ptr, pin->ptr, pk.total);
+  rt.h2d_pinned(dev->ptr, pin->ptr, pk.total);
 }
 
 // ======================================================================

@@ -271,7 +271,7 @@ std::vector<std::shared_ptr<LazyGroupState>> lazy_forward(std::vector<Graph>& gs
     for (int b = 0; b < nb; ++b) em[b] = st.chains[b].w->dev;
     PinnedMemP pin = rt.alloc_pinned(8 * size_t(nb));
     std::memcpy(pin->ptr, em.data(), 8 * size_t(nb));
-    rt.h2d(st.arena->as<char>(o_em), pin->ptr, 8 * size_t(nb));
+    rt.h2d_pinned(st.arena->as<char>(o_em), pin->ptr, 8 * size_t(nb));
     v.em = reinterpret_cast<const float* const*>(st.arena->as<char>(o_em));
     // slices of one tensor (linearGraphs over a [B][T][C] tensor, the criteria): the kernels' inner loops
     // compute the row address instead of loading it
@@ -484,7 +484,7 @@ struct LazySdOp : OpRecord {
       PinnedMemP pin = rt.alloc_pinned(16 * size_t(nb));
       std::memcpy(pin->as<char>(), delta.data(), 8 * size_t(nb));
       std::memcpy(pin->as<char>(8 * size_t(nb)), gem.data(), 8 * size_t(nb));
-      rt.h2d(tabs->ptr, pin->ptr, 16 * size_t(nb));
+      rt.h2d_pinned(tabs->ptr, pin->ptr, 16 * size_t(nb));
       v.delta = reinterpret_cast<const float* const*>(tabs->as<char>());
       v.grad_em = reinterpret_cast<float* const*>(tabs->as<char>(8 * size_t(nb)));
       if (mode == SD_LOG) {

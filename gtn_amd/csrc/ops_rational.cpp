@@ -392,7 +392,7 @@ Graph op_load_buffer(const void* data, size_t bytes) {
   std::memcpy(pin->as<char>(o_w), w, 4 * size_t(A));
   std::memcpy(pin->as<char>(o_fl), flags.data(), size_t(N));
   DevMemP raw = rt.alloc(in_bytes);
-  rt.h2d(raw->ptr, pin->ptr, in_bytes);
+  rt.h2d_pinned(raw->ptr, pin->ptr, in_bytes);
   // the structure's own arena: arc arrays, weights, flags, lists, adjacency (as op_rational lays it out)
   size_t total = 0;
   auto add = [&](size_t b) {

@@ -461,7 +461,7 @@ DevMemP Runtime::alloc(size_t bytes) {
 DevMemP Runtime::alloc_zero(size_t bytes) {
   DevMemP m = alloc(bytes);
   // (blocks are multiples of 256 bytes: whole words.  Small ones by a kernel of ours, like d2d)
-  if (bytes <= (size_t(1) << 20) && m->bytes % 4 == 0) launch_fill_i32(m->as<int>(), 0, (bytes + 3) / 4, stream_);
+  if (bytes <= (size_t(16) << 20) && m->bytes % 4 == 0) launch_fill_i32(m->as<int>(), 0, (bytes + 3) / 4, stream_);
   else HIP_CHECK(hipMemsetAsync(m->ptr, 0, bytes ? bytes : 1, stream_));
   return m;
 }
@@ -555,7 +555,7 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
   // runtime and blocks inside the call
   if (bytes && bytes <= 4096) {
     PinnedMemP p = alloc_pinned(bytes);
-    HIP_CHECK(hipMemcpyAsync(p->ptr, src, bytes, hipMemcpyDeviceToHost, stream_));
+    d2h_pinned_async(p->ptr, src, bytes);
     drain_while_busy();
     HIP_CHECK(hipStreamSynchronize(stream_));
     std::memcpy(dst, p->ptr, bytes);
@@ -591,9 +591,25 @@ void Runtime::d2d(void* dst, const void* src, size_t bytes) {
   }
   HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream_));
 }
+// device -> pinned host memory, asynchronous: the same way round (the kernel's stores travel over the host link)
+void Runtime::d2h_pinned_async(void* pinned_dst, const void* src, size_t bytes) {
+  if (!bytes) return;
+  if (bytes <= (size_t(1) << 20)) {
+    launch_copy_small(pinned_dst, src, bytes, stream_);
+    return;
+  }
+  HIP_CHECK(hipMemcpyAsync(pinned_dst, src, bytes, hipMemcpyDeviceToHost, stream_));
+}
 void Runtime::h2d_pinned(void* dst, const void* pinned_src, size_t bytes) {
   if (!bytes) return;
-  if (bytes <= 4096) {  // (pinned blocks are mapped into the device's address space: the kernel reads the host's copy)
+  static const size_t lim = [] {  // GTNX_H2D_KERNEL_BYTES: largest pinned block a kernel of ours fetches
+    const char* e = std::getenv("GTNX_H2D_KERNEL_BYTES");
+    return e ? size_t(std::atol(e)) : size_t(1) << 20;
+  }();
+  // (pinned blocks are mapped into the device's address space: the kernel reads the host's copy.  Measured on the
+  //  headline step, whose four table uploads of 28-200 KB were runtime copies: 0.688 -> 0.630 ms per step -- a copy of
+  //  the runtime's is ordered against the compute queue from outside it, a kernel is just the next dispatch)
+  if (bytes <= lim) {
     launch_copy_small(dst, pinned_src, bytes, stream_);
     return;
   }

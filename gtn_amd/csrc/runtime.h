@@ -124,7 +124,10 @@ class Runtime {
   void h2d(void* dst, const void* src, size_t bytes);
   void d2h_sync(void* dst, const void* src, size_t bytes);  // returns after the data landed
   void d2d(void* dst, const void* src, size_t bytes);
-  void h2d_pinned(void* dst, const void* pinned_src, size_t bytes);  // src from alloc_pinned: small ones by a kernel of ours
+  // pinned host memory (alloc_pinned) to / from the device: up to GTNX_H2D_KERNEL_BYTES (default 1 MB) by a kernel of
+  // ours, which is the next dispatch of the compute queue where a copy of the runtime's is ordered against it from outside
+  void h2d_pinned(void* dst, const void* pinned_src, size_t bytes);
+  void d2h_pinned_async(void* pinned_dst, const void* src, size_t bytes);  // ordered on the engine stream
 
   // ---- a ring of pinned floats for kernels that produce ONE scalar (the loss of a criterion written with the
   // per-graph functions): the kernel writes its value there as well, and item() of that result waits for the stream

@@ -1,9 +1,9 @@
 set -u
-O=$PWD/gpurun_out/r4m; mkdir -p $O; rm -f $O/*
+O=$PWD/gpurun_out/${1:-r5v}; mkdir -p $O; rm -f $O/*
 timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -40 > $O/pytest.log
 grep -E "FAILED|passed|failed|ERROR" $O/pytest.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 python - <<PY
 import json
 d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])

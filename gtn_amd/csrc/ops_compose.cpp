@@ -686,7 +686,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       deferred->host = rt.alloc_pinned(hdr.size());
       deferred->hdr_out = hdr_out;
       deferred->hdr_cnt = hdr_cnt;
-      HIP_CHECK(hipMemcpyAsync(deferred->host->ptr, res->ptr, hdr.size(), hipMemcpyDeviceToHost, rt.stream()));
+      rt.d2h_pinned_async(deferred->host->ptr, res->ptr, hdr.size());
       HIP_CHECK(hipEventCreateWithFlags(&deferred->ev, hipEventDisableTiming));
       HIP_CHECK(hipEventRecord(deferred->ev, rt.stream()));
       return;

@@ -479,17 +479,25 @@ PinnedMemP Runtime::alloc_pinned(size_t bytes) {
   void* p = nullptr;
   {
     std::lock_guard<std::mutex> lk(mu_);
-    // recycle blocks whose release event has completed
-    for (size_t i = 0; i < pending_pinned_.size();) {
-      if (hipEventQuery(pending_pinned_[i].ev) == hipSuccess) {
-        free_pinned_.emplace(pending_pinned_[i].bytes, pending_pinned_[i].ptr);
-        ev_pool_.push_back(pending_pinned_[i].ev);
-        pending_pinned_[i] = pending_pinned_.back();
-        pending_pinned_.pop_back();
-      } else {
-        (void)hipGetLastError();
-        ++i;
+    // recycle the groups whose event has completed
+    auto recycle = [&] {
+      for (size_t i = 0; i < pending_pinned_.size();) {
+        if (hipEventQuery(pending_pinned_[i].ev) == hipSuccess) {
+          for (auto& b : pending_pinned_[i].blocks) free_pinned_.emplace(b.second, b.first);
+          ev_pool_.push_back(pending_pinned_[i].ev);
+          if (i + 1 != pending_pinned_.size()) pending_pinned_[i] = std::move(pending_pinned_.back());
+          pending_pinned_.pop_back();
+        } else {
+          (void)hipGetLastError();
+          ++i;
+        }
       }
+    };
+    recycle();
+    {
+      auto hit = free_pinned_.lower_bound(sz);
+      // nothing to offer: whatever waits without an event gets one now, so that it comes back soon
+      if ((hit == free_pinned_.end() || hit->first > sz * 2) && !unstamped_pinned_.empty()) stamp_pinned_locked();
     }
     auto it = free_pinned_.lower_bound(sz);
     if (it != free_pinned_.end() && it->first <= sz * 2) {
@@ -512,6 +520,11 @@ PinnedMemP Runtime::alloc_pinned(size_t bytes) {
 void Runtime::release_pinned(void* p, size_t bytes) {
   OnDevice here(device_);
   std::lock_guard<std::mutex> lk(mu_);
+  unstamped_pinned_.emplace_back(p, bytes);
+  if (unstamped_pinned_.size() >= kPinnedStampEvery) stamp_pinned_locked();
+}
+void Runtime::stamp_pinned_locked() {
+  if (unstamped_pinned_.empty()) return;
   hipEvent_t ev;
   if (!ev_pool_.empty()) {
     ev = ev_pool_.back();
@@ -519,11 +532,13 @@ void Runtime::release_pinned(void* p, size_t bytes) {
   } else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
     (void)hipGetLastError();
     (void)hipStreamSynchronize(stream_);
-    free_pinned_.emplace(bytes, p);
+    for (auto& b : unstamped_pinned_) free_pinned_.emplace(b.second, b.first);
+    unstamped_pinned_.clear();
     return;
   }
   (void)hipEventRecord(ev, stream_);
-  pending_pinned_.push_back({p, bytes, ev});
+  pending_pinned_.push_back({ev, std::move(unstamped_pinned_)});
+  unstamped_pinned_.clear();
 }
 
 void Runtime::empty_cache() {

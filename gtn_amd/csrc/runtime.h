@@ -168,12 +168,18 @@ class Runtime {
   std::mutex mu_;
   std::multimap<size_t, void*> free_dev_;
   std::multimap<size_t, void*> free_pinned_;
-  struct PendingPinned {
-    void* ptr;
-    size_t bytes;
+  // Released pinned blocks wait for the stream in GROUPS: a block let go of joins `unstamped_pinned_` without a HIP
+  // call; one event, recorded after kPinnedStampEvery releases (or when the pool has nothing to offer), stands for
+  // all of them -- the stream is in order, so an event recorded after a block's release covers every operation that
+  // used it.  (One hipEventRecord per block was a marker in the stream and 2-4 us of the host per staged table.)
+  struct PinnedGroup {
     hipEvent_t ev;
+    std::vector<std::pair<void*, size_t>> blocks;
   };
-  std::vector<PendingPinned> pending_pinned_;
+  static constexpr size_t kPinnedStampEvery = 8;
+  std::vector<PinnedGroup> pending_pinned_;
+  std::vector<std::pair<void*, size_t>> unstamped_pinned_;
+  void stamp_pinned_locked();  // mu_ held
   uint64_t reserved_ = 0, in_use_ = 0;
   bool prof_on_ = false;
   struct ProfRec {

@@ -6,6 +6,7 @@
 // the tests, smoke() or bench.py.
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -144,8 +145,23 @@ hipError_t hipEventSynchronize(hipEvent_t) {
 }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
-hipError_t hipLaunchKernel(const void* f, dim3 g, dim3 b, void**, size_t, hipStream_t st) {
+hipError_t hipLaunchKernel(const void* f, dim3 g, dim3 b, void** args, size_t, hipStream_t st) {
   const int d = dev_of_stream(st);
+  // the engine's own small copies and fills (misc.hip: copy_small_kernel, fill_i32_kernel) stand where hipMemcpyAsync /
+  // hipMemsetAsync stood, and those this device carries out: so these two kernels are, too
+  {
+    auto it = kernels().find(f);
+    if (it != kernels().end() && args) {
+      if (std::strstr(it->second, "copy_small_kernel")) {
+        std::memmove(*static_cast<void**>(args[0]), *static_cast<void**>(args[1]), *static_cast<size_t*>(args[2]));
+      } else if (std::strstr(it->second, "fill_i32_kernel")) {
+        int* p = *static_cast<int**>(args[0]);
+        const int v = *static_cast<int*>(args[1]);
+        const size_t n = *static_cast<size_t*>(args[2]);
+        if (g_zero || n <= (1u << 18)) std::fill(p, p + n, v);
+      }
+    }
+  }
   if (g_trace) {
     auto it = kernels().find(f);
     std::fprintf(stderr, "nullhip: launch %s grid %u block %u\n", it == kernels().end() ? "?" : it->second, g.x * g.y * g.z, b.x);

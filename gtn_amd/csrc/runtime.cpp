@@ -520,8 +520,12 @@ PinnedMemP Runtime::alloc_pinned(size_t bytes) {
 void Runtime::release_pinned(void* p, size_t bytes) {
   OnDevice here(device_);
   std::lock_guard<std::mutex> lk(mu_);
+  static const size_t every = [] {  // GTNX_PINNED_STAMP_EVERY: releases per event (1: an event per block, as before)
+    const char* e = std::getenv("GTNX_PINNED_STAMP_EVERY");
+    return e && std::atol(e) > 0 ? size_t(std::atol(e)) : kPinnedStampEvery;
+  }();
   unstamped_pinned_.emplace_back(p, bytes);
-  if (unstamped_pinned_.size() >= kPinnedStampEvery) stamp_pinned_locked();
+  if (unstamped_pinned_.size() >= every) stamp_pinned_locked();
 }
 void Runtime::stamp_pinned_locked() {
   if (unstamped_pinned_.empty()) return;

@@ -245,17 +245,10 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
 // ======================================================================
 struct ScalarOp : OpRecord {
   ScalarKind kind;
-  bool seeded = false;  // op_backward ran this record's gradient function together with the seed (seed_scalar_root)
   float scale(int input) const { return kind == SK_NEGATE || (kind == SK_SUBTRACT && input == 1) ? -1.0f : 1.0f; }
   // the gradient function of member `out`: b0 = s0 d, b1 = s1 d into `buf`, handed to the inputs.  seed != null: d is
   // the seed of a backward pass from `out` (one launch for seed and function)
-  void backward(std::vector<Member>& ms) override {
-    if (seeded) {
-      seeded = false;
-      return;
-    }
-    run(ms, nullptr, nullptr);
-  }
+  void backward(std::vector<Member>& ms) override { run(ms, nullptr, nullptr); }
   void run(std::vector<Member>& ms, const DevMemP& seed_mem, float* seed) {
     Runtime& rt = Runtime::get();
     const int n = int(ms.size());
@@ -355,8 +348,8 @@ static std::shared_ptr<ScalarOp> seed_scalar_root(Graph& root) {
   root.add_grad_device(buf, seed, /*adopt=*/true);
   std::vector<Member> ms{{root.g->op_idx, root}};
   op->run(ms, buf, seed);
-  op->seeded = true;
-  return op;
+  return op;  // (op_backward skips this record's turn for `root`: no mark on the record -- other outputs of a vector
+              //  op may be differentiated by other threads at the same time)
 }
 
 
@@ -500,12 +493,7 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
   GTNX_HOST_T("backward.total");
   Runtime& rt = Runtime::get();
   for (auto& r : roots) realize(r);
-  struct SeededScope {  // (a throw between the seed and the record's turn must not leave the mark behind)
-    std::shared_ptr<ScalarOp> op;
-    ~SeededScope() {
-      if (op) op->seeded = false;
-    }
-  } seeded;
+  std::shared_ptr<ScalarOp> seeded_op;  // the root's record, when its gradient function ran together with the seed
   // ---- seed (autograd.cpp:57-67); seed == false: the roots hold their deltas already (batch.cpp)
   if (!seed) {
   } else if (grad) {
@@ -516,7 +504,7 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
       ensure_weights_device_batch(v);
       r.add_grad_device(grad->w->dev_mem, grad->w->dev, /*adopt=*/false);
     }
-  } else if (roots.size() == 1 && (seeded.op = seed_scalar_root(roots[0]))) {
+  } else if (roots.size() == 1 && (seeded_op = seed_scalar_root(roots[0]))) {
   } else {
     size_t tot = 0;
     for (auto& r : roots) tot += size_t(r.num_arcs());
@@ -559,7 +547,9 @@ void op_backward(std::vector<Graph>& roots, Graph* grad, bool retain, bool seed)
     for (auto& m : members)
       if (!(m.out.s->lazy && m.out.g->grad_propagated))
         (void)m.out.grad();  // throws "Gradient not calculated yet." like autograd.cpp:46
-    if (!members.empty()) kv.second.first->backward(members);
+    const bool ran_with_seed = seeded_op && kv.second.first.get() == seeded_op.get() && members.size() == 1 &&
+                               members[0].out.g == roots[0].g;
+    if (!members.empty() && !ran_with_seed) kv.second.first->backward(members);
     if (!retain) {
       // autograd.cpp:47-50: the tape (inputs, saved forward state) goes away with
       // backward; the objects themselves are reclaimed at the next sync point

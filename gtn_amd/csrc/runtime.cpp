@@ -586,8 +586,6 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
   drain_while_busy();
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
-// (up to a megabyte by a kernel of ours -- kernels.h: launch_copy_small; the runtime's copy costs the host about twice
-// a launch, and the copies of this size are the ones at the head of a latency chain: setWeights of one utterance)
 namespace {
 // may a kernel on `dev` touch p?  (A caller's pointer may live on ANOTHER GPU of the process: the runtime's copy
 // handles that with or without peer access, a kernel of ours does not.  One GPU in the process: nothing to ask.)
@@ -602,6 +600,8 @@ bool local_to(const void* p, int dev) {
   return a.type == hipMemoryTypeHost || (a.type == hipMemoryTypeDevice && a.device == dev);
 }
 }  // namespace
+// (up to a megabyte by a kernel of ours -- kernels.h: launch_copy_small; the runtime's copy costs the host about twice
+// a launch, and the copies of this size are the ones at the head of a latency chain: setWeights of one utterance)
 void Runtime::d2d(void* dst, const void* src, size_t bytes) {
   if (!bytes) return;
   if (bytes <= (size_t(1) << 20) && local_to(src, device_) && local_to(dst, device_)) {

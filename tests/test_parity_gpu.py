@@ -209,6 +209,35 @@ def test_backward_from_a_scalar_op_result(gtn):
     assert (a.grad().item(), b.grad().item()) == (2.0, 0.0)
 
 
+def test_backward_from_single_outputs_of_a_vector_scalar_op(gtn):
+    """one record (a vector subtract), its outputs differentiated one root at a time -- also from several threads at
+    once: the seed-fused gradient function is per root, nothing is marked on the shared record"""
+    import threading
+    n = 16
+    a = [gtn.scalar_graph(float(i)) for i in range(n)]
+    b = [gtn.scalar_graph(2.0 * i) for i in range(n)]
+    r = gtn.subtract(a, b)
+    for i in range(0, n, 2):
+        gtn.backward(r[i])
+    errs = []
+
+    def work(i):
+        try:
+            gtn.backward(r[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(1, n, 2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert gtn.items(r) == [-float(i) for i in range(n)]
+    assert [x.grad().item() for x in a] == [1.0] * n
+    assert [x.grad().item() for x in b] == [-1.0] * n
+    assert [x.grad().item() for x in r] == [1.0] * n
+
+
 def test_scalar_result_read_through_its_pinned_mirror(gtn):
     """item() of a scalar op's single result reads the value its kernel also wrote to pinned host memory
     (runtime.h: mirror_slot) -- also after the ring of slots went round, and not after the weights were replaced"""

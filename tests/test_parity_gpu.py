@@ -232,7 +232,7 @@ def test_backward_from_single_outputs_of_a_vector_scalar_op(gtn):
     for t in ts:
         t.join()
     assert not errs, errs
-    assert gtn.items(r) == [-float(i) for i in range(n)]
+    assert list(gtn.items(r)) == [-float(i) for i in range(n)]
     assert [x.grad().item() for x in a] == [1.0] * n
     assert [x.grad().item() for x in b] == [-1.0] * n
     assert [x.grad().item() for x in r] == [1.0] * n

@@ -136,8 +136,14 @@ hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }  // the "GPU" is n
 hipError_t hipEventCreate(hipEvent_t* e) { *e = reinterpret_cast<hipEvent_t>(&g_dummy); return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(&g_dummy); return hipSuccess; }
 hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) {
+  if (g_trace) std::fprintf(stderr, "nullhip: streamWaitEvent\n");
+  return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t, hipStream_t) {
+  if (g_trace) std::fprintf(stderr, "nullhip: eventRecord\n");
+  return hipSuccess;
+}
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) {
   if (g_trace) std::fprintf(stderr, "nullhip: eventSynchronize\n");

@@ -66,3 +66,51 @@ def test_default_device_is_the_threads_and_is_never_assumed():
     r = subprocess.run([os.path.join(NULLHIP, "_bin", "device_step")], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     out = r.stdout + r.stderr
     assert r.returncode == 0 and "DEVICE_OK" in out, out[-2000:]
+
+
+def _device_ops(cmd, extra_env=None):
+    """the operations the engine puts on its stream during `cmd`, as tools/nullhip's NULLHIP_TRACE prints them"""
+    _build()
+    env = dict(os.environ, LD_PRELOAD=os.path.join(NULLHIP, "_bin", "libnullhip.so"), NULLHIP_TRACE="1")
+    env.update(extra_env or {})
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+    return [ln[len("nullhip: "):] for ln in r.stderr.splitlines() if ln.startswith("nullhip: ")]
+
+
+def _last_period(ops, end):
+    """the operations between the last two `end` lines (one warm repetition)"""
+    idx = [i for i, o in enumerate(ops) if o.startswith(end)]
+    assert len(idx) >= 2, ops[-30:]
+    return ops[idx[-2] + 1: idx[-1]]
+
+
+def test_one_utterance_puts_eight_operations_on_the_stream_and_none_of_the_runtimes():
+    """BASELINE C1: sixteen dependent device operations per loss at the start of round 5, eight
+    of them copies of the HIP runtime.  Now: setWeights and the band records by the engine's copy kernel, the two
+    sweeps with their record as the kernel's argument, subtract, seed + gradient function in one launch, one fill --
+    and item() reads the pinned mirror: nothing but the synchronisation follows the backward sweep."""
+    ops = _last_period(_device_ops([os.path.join(NULLHIP, "_bin", "small_step"), "c1", "60"]), "streamSynchronize")
+    assert not [o for o in ops if o.startswith("memcpy") or o.startswith("memset")], ops
+    launches = [o for o in ops if o.startswith("launch")]
+    assert len(launches) == 7 and len([o for o in ops if not o.startswith("eventRecord")]) == 7, ops
+    names = " | ".join(launches)
+    for k in ("band_forward_one_kernel", "band_backward_one_kernel", "scalar_combine_kernel", "scalar_fan_kernel"):
+        assert k in names, names
+    assert names.count("copy_small_kernel") == 2 and names.rstrip().split(" | ")[-1].find("band_backward_one_kernel") >= 0, names
+
+
+@pytest.mark.parametrize("prog", ["host_step", "region_step"])
+def test_a_training_step_has_no_copy_of_the_runtimes_between_its_kernels(prog):
+    """the tables of the headline step (labels, target arguments, the sweeps' pair tables) and
+    of the reference's loop reach the device by the engine's copy kernel; a hipMemcpyAsync between two kernels cost the
+    step 9 % (0.688 -> 0.630 ms).  GTNX_H2D_KERNEL_BYTES=0 brings the runtime's copies back (the switch works)."""
+    exe = os.path.join(NULLHIP, "_bin", prog)
+    end = "streamSynchronize" if prog == "host_step" else "eventSynchronize"
+    ops = _last_period(_device_ops([exe, "6", "64", "100", "32", "10"] if prog == "host_step" else [exe, "6", "64", "32"]), end)
+    assert [o for o in ops if "band_backward_kernel" in o], ops
+    assert not [o for o in ops if o.startswith("memcpy") or o.startswith("memset")], ops
+    assert len([o for o in ops if o.startswith("eventRecord")]) <= 3, ops
+    old = _last_period(_device_ops([exe, "6", "64", "100", "32", "10"] if prog == "host_step" else [exe, "6", "64", "32"],
+                                   {"GTNX_H2D_KERNEL_BYTES": "0"}), end)
+    assert len([o for o in old if o.startswith("memcpyAsync kind 1")]) >= 3, old

@@ -31,6 +31,23 @@ extern "C" __attribute__((visibility("default"))) int gtn_ctc_loss_n(const void*
   }
 }
 
+// The same, as benchmarks/ctc.cpp:150-165 runs it: target graphs with calcGrad = true, and THEIR gradients too.
+// target_grad: DEVICE float, utterance b's arc gradients (arc ids of benchmarks/ctc.cpp:40-58's addArc order) at
+// target_grad + target_grad_offsets[b]; grad must be non-null.
+extern "C" __attribute__((visibility("default"))) int gtn_ctc_loss_target_grads_n(
+    const void* emissions, const int* targets, const int* lengths, int B, int T, int C, int blank, void* loss,
+    void* grad, void* target_grad, const int64_t* target_grad_offsets) {
+  try {
+    gtn::Batch ctcs;
+    gtn::criteria::ctcLossBatch(emissions, targets, lengths, B, T, C, blank, loss, grad, /*targetGrad=*/true, nullptr, &ctcs);
+    if (target_grad) ctcs.gradsToDevice(target_grad, target_grad_offsets);
+    return 0;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return -1;
+  }
+}
+
 // ASG over a shared transitions graph.  emissions: DEVICE float [B][T][N]; targets / lengths:
 // host int32 (concatenated / [B]); trans_w: DEVICE float [N + N*N] in the arc order of
 // gtn::criteria::asgTransitions BEFORE its arcSort (arc i: <s> -> i; arc N + i*N + j: j -> i);

@@ -61,7 +61,8 @@ inline void ctcLossBatch(
     void* lossDev,
     void* gradDev,
     bool targetGrad = true,  // benchmarks/ctc.cpp builds its targets with calcGrad = true
-    CtcStepTimes* times = nullptr) {
+    CtcStepTimes* times = nullptr,
+    Batch* targetsOut = nullptr) {  // the target acceptors (their gradients populated when targetGrad) handed back
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto t0 = now();
@@ -86,6 +87,7 @@ inline void ctcLossBatch(
   if (times) *times = {ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5)};
   losses.itemsToDevice(lossDev);
   if (gradDev) ems.gradsToDevice(gradDev, off.data());  // (nothing to copy when the rows were written in place)
+  if (targetsOut) *targetsOut = std::move(ctcs);
 }
 
 inline void ctcLossBatch(

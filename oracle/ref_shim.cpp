@@ -557,4 +557,50 @@ double ref_ctc_batch(const float* emissions, const int* targets, int B, int T,
   return secs / (iters > 0 ? iters : 1);
 }
 
+/* ---- the same per-utterance computation (benchmarks/ctc.cpp:40-58,150-160) on RAGGED targets, with the gradient
+ * of the target graph as well: labels back to back, lengths[b] labels each (0 allowed); losses [B]; grads [B*T*C] or
+ * NULL; tgrads or NULL: the target graph's arc gradients (arc ids in benchmarks/ctc.cpp:40-58's addArc order) of
+ * utterance b at tgrads + toff[b]; arcs[b] (or NULL) receives the graph's arc count.  Returns the pool size used. */
+int ref_ctc_ragged(const float* emissions, const int* labels, const int* lengths, int B, int T, int C, int blank,
+                   float* losses, float* grads, float* tgrads, const int64_t* toff, int* arcs) {
+  std::vector<std::vector<int>> tg(B);
+  size_t at = 0;
+  for (int b = 0; b < B; ++b) {
+    tg[b].assign(labels + at, labels + at + lengths[b]);
+    at += (size_t)lengths[b];
+  }
+  std::vector<int> idx(B);
+  for (int b = 0; b < B; ++b) idx[b] = b;
+  std::vector<Graph> ems(B), ctcs(B);
+  auto fwd = [&](int b) {
+    const std::vector<int>& target = tg[b];
+    size_t L = 2 * target.size() + 1;
+    Graph ctc;
+    for (size_t l = 0; l < L; l++) {
+      size_t i = (l - 1) / 2;
+      ctc.addNode(l == 0, l == L - 1 || l == L - 2);
+      int label = l % 2 ? target[i] : blank;
+      ctc.addArc(l, l, label);
+      if (l > 0) ctc.addArc(l - 1, l, label);
+      if (l % 2 && l > 1 && label != target[i - 1]) ctc.addArc(l - 2, l, label);
+    }
+    ctc.arcSort();
+    auto e = gtn::linearGraph(T, C);
+    e.setWeights(emissions + (size_t)b * T * C);
+    ems[b] = e;
+    ctcs[b] = ctc;
+    return gtn::subtract(gtn::forwardScore(e), gtn::forwardScore(gtn::intersect(ctc, e)));
+  };
+  auto bwd = [](const Graph& g) { gtn::backward(g); };
+  auto lossGraphs = gtn::parallelMap(fwd, idx);
+  gtn::parallelMap(bwd, lossGraphs);
+  for (int b = 0; b < B; ++b) {
+    if (losses) losses[b] = lossGraphs[b].item();
+    if (grads) std::memcpy(grads + (size_t)b * T * C, ems[b].grad().weights(), sizeof(float) * (size_t)T * C);
+    if (arcs) arcs[b] = (int)ctcs[b].numArcs();
+    if (tgrads) std::memcpy(tgrads + toff[b], ctcs[b].grad().weights(), sizeof(float) * ctcs[b].numArcs());
+  }
+  return (int)std::min<size_t>((size_t)B, std::thread::hardware_concurrency());
+}
+
 } // extern "C"

@@ -57,7 +57,16 @@ def ctc_loss_fp64(emissions, target, blank=0):
     occ = np.exp(alpha[1:] + beta[1:] - z)  # node posteriors after consuming frame t
     for s in range(S):
         grad[:, lab[s]] -= occ[:, s]
-    return loss, grad, None
+    # d loss / d (weights of the target graph's arcs), arc ids in benchmarks/ctc.cpp:40-58's addArc order: per node
+    # its self loop, the arc from s-1 (s > 0), the arc from s-2 (skip[s]); an arc's posterior summed over the frames
+    q = e + beta[1:]  # [T, S]: consume frame t into node s, then finish
+    tgrad = []
+    for s in range(S):
+        for k in (0, 1, 2):
+            if (k == 1 and s == 0) or (k == 2 and not skip[s]):
+                continue
+            tgrad.append(-np.sum(np.exp(alpha[:T, s - k] + q[:, s] - z)))
+    return loss, grad, np.asarray(tgrad)
 
 
 def asg_fp64(em, tw):

@@ -302,3 +302,89 @@ def test_batch_linear_forward_score_is_one_record(gtn, B, T, C):
     np.testing.assert_allclose(got, gtn.items(fv), rtol=1e-6, atol=1e-5)
     k = B // 2
     np.testing.assert_allclose(g[k], gs[k].grad().weights_to_numpy().reshape(T, C), rtol=1e-6, atol=1e-7)
+
+
+def _ctc_arc_counts(tg):
+    """arcs of benchmarks/ctc.cpp:40-58's graph per target: a self loop per node, a step per node but the first, a
+    skip into a label node whose previous label differs"""
+    return [(2 * len(t) + 1) + 2 * len(t) + sum(1 for i in range(1, len(t)) if t[i] != t[i - 1]) for t in tg]
+
+
+def test_timed_route_at_full_size_against_the_reference(gtn):
+    """The route bench.py TIMES -- criteria::ctcLossBatch itself, through libgtn_criteria.so: gtn::Batch::ctcTargets
+    (ctc_targets_kernel) -> Batch::linear -> batched intersect / forwardScore x2 / subtract / backward (the band sweeps)
+    -- at BASELINE config C3's utterance shape (T = 1000, C = 256, U <= 100), 32 utterances with RAGGED targets
+    (an empty one, repeated labels, a full-length one), against the UNMODIFIED reference running
+    benchmarks/ctc.cpp:40-58,150-160 on the same inputs (oracle/_ref: ref_ctc_ragged): losses, emission gradients
+    AND the target graphs' arc gradients (criterion_test.cpp:56-180 checks emissions only; the reference's
+    benchmark builds its targets with calcGrad = true, so the timed step computes them)."""
+    import ctypes as C
+    import os
+    import torch
+    from ctc_fp64 import ctc_loss_fp64
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref_path = os.path.join(root, "oracle", "_ref", "libgtn_ref.so")
+    if not os.path.exists(ref_path):
+        pytest.skip("oracle/_ref/libgtn_ref.so not built (needs /root/reference at build time)")
+    B, T, Cn, Umax = 32, 1000, 256, 100
+    em, tg = _ragged_inputs(77, B, T, Cn, Umax, Umin=1)
+    tg[0] = tg[0][:0]                                            # empty target
+    tg[1] = np.full(Umax, 7, np.int32)                           # one label repeated: no skip arcs at all
+    tg[2] = np.random.default_rng(5).integers(1, Cn, size=Umax).astype(np.int32)  # full length
+    tg[3] = np.repeat(np.arange(1, 26, dtype=np.int32), 4)       # runs of repeats
+    lens = np.array([len(t) for t in tg], np.int32)
+    flat = np.concatenate(tg).astype(np.int32)
+    narcs = _ctc_arc_counts(tg)
+    toff = np.concatenate([[0], np.cumsum(narcs)]).astype(np.int64)
+
+    # ---- the product: libgtn_criteria.so
+    lib = C.CDLL(os.path.join(root, "gtn_amd", "lib", "libgtn_criteria.so"))
+    lib.gtn_ctc_loss_target_grads_n.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 4
+    lib.gtn_ctc_loss_target_grads_n.restype = C.c_int
+    lib.gtn_criteria_last_error.restype = C.c_char_p
+    em_dev = _dev(em)
+    loss_dev = torch.full((B,), float("nan"), device="cuda:0")
+    grad_dev = torch.full((B, T, Cn), float("nan"), device="cuda:0")
+    tgrad_dev = torch.full((int(toff[-1]),), float("nan"), device="cuda:0")
+    torch.cuda.synchronize()
+    rc = lib.gtn_ctc_loss_target_grads_n(em_dev.data_ptr(), flat.ctypes.data, lens.ctypes.data, B, T, Cn, 0,
+                                         loss_dev.data_ptr(), grad_dev.data_ptr(), tgrad_dev.data_ptr(), toff.ctypes.data)
+    assert rc == 0, lib.gtn_criteria_last_error().decode()
+    gtn.synchronize()
+    got_l, got_g, got_t = loss_dev.cpu().numpy(), grad_dev.cpu().numpy(), tgrad_dev.cpu().numpy()
+
+    # ---- the checker: the reference itself
+    ref = C.CDLL(ref_path)
+    ref.ref_ctc_ragged.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p] * 5
+    ref.ref_ctc_ragged.restype = C.c_int
+    want_l = np.zeros(B, np.float32)
+    want_g = np.zeros((B, T, Cn), np.float32)
+    want_t = np.zeros(int(toff[-1]), np.float32)
+    arcs = np.zeros(B, np.int32)
+    ref.ref_ctc_ragged(em.ctypes.data, flat.ctypes.data, lens.ctypes.data, B, T, Cn, 0, want_l.ctypes.data,
+                       want_g.ctypes.data, want_t.ctypes.data, toff.ctypes.data, arcs.ctypes.data)
+    assert arcs.tolist() == narcs
+
+    # losses: 1e-4 relative (north_star), measured ~1e-6
+    assert np.all(np.isfinite(got_l))
+    np.testing.assert_allclose(got_l, want_l, rtol=1e-4)
+    # gradients.  The float32 reference keeps unnormalised scores ~8.5 T, so ITS gradients are ~1e-3 from exact
+    # arithmetic at T = 1000 (measured below, per utterance); tolerance: <= 1e-4 against float64 (posteriors in
+    # [-1, 1]; target-arc gradients, sums of T posteriors, relative to max(1, |g|)) AND <= 1e-2 against the reference
+    worst = {"em64": 0.0, "emref": 0.0, "t64": 0.0, "tref": 0.0, "ref_em64": 0.0, "ref_t64": 0.0}
+    for b in range(B):
+        l64, g64, t64 = ctc_loss_fp64(em[b], tg[b])
+        assert abs(got_l[b] - l64) <= 1e-4 * abs(l64)
+        sl = slice(int(toff[b]), int(toff[b + 1]))
+        scale = np.maximum(1.0, np.abs(t64))
+        worst["em64"] = max(worst["em64"], np.abs(got_g[b] - g64).max())
+        worst["emref"] = max(worst["emref"], np.abs(got_g[b] - want_g[b]).max())
+        worst["ref_em64"] = max(worst["ref_em64"], np.abs(want_g[b] - g64).max())
+        worst["t64"] = max(worst["t64"], (np.abs(got_t[sl] - t64) / scale).max())
+        worst["tref"] = max(worst["tref"], (np.abs(got_t[sl] - want_t[sl]) / scale).max())
+        worst["ref_t64"] = max(worst["ref_t64"], (np.abs(want_t[sl] - t64) / scale).max())
+    assert worst["em64"] <= 1e-4, worst
+    assert worst["t64"] <= 1e-4, worst
+    assert worst["emref"] <= 1e-2 and worst["tref"] <= 1e-2, worst
+    # (and the engine is the closer of the two to exact arithmetic)
+    assert worst["em64"] <= worst["ref_em64"] and worst["t64"] <= worst["ref_t64"], worst

@@ -90,7 +90,7 @@ def test_asg_shared_transition_grad_all_reduce():
 
 
 @pytest.mark.parametrize("world", [2, 8])
-def test_bench_multi_rank_branch_under_gloo(world):
+def test_bench_multi_rank_branch_under_gloo(world, tmp_path):
     """bench.py's OWN world > 1 branch -- rendezvous from the torchrun environment, all_gather of the
     per-rank losses, barrier-bracketed timing, max over ranks, the per-rank report -- driven as the round
     driver launches it (python -m torch.distributed.run ... bench.py --gpus N), with --dry-run-cpu standing
@@ -102,11 +102,23 @@ def test_bench_multi_rank_branch_under_gloo(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "4",
            "--warmup", "1", "--batch", "8", "--dry-run-cpu"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, GTN_BENCH_OUT=str(tmp_path)))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout      # rank 0 prints ONE line
-    out = json.loads(lines[0])
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0]   # ... and it is the LAST line of stdout
+    line = json.loads(lines[0])
+    # the line the driver parses is short (BENCH_r05.json: a 20 KB line was not parsed); the rest is in the side file
+    assert len(lines[0]) < 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "config", "full_record"):
+        assert k in line, k
+    import hashlib
+    text = open(os.path.join(str(tmp_path), "last_full.json")).read().rstrip("\n")
+    assert hashlib.sha256(text.encode()).hexdigest() == line["full_record"]["sha256"]
+    assert line["rank_seconds"] and len(line["rank_seconds"]) == world
+    out = json.loads(text)
     assert out["n_gpus"] == world and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["dry_run"] is True and out["gather_ok"] is True
     assert [p["rank"] for p in out["per_rank"]] == list(range(world))   # the 8-GPU line: eight per_rank entries
@@ -114,3 +126,31 @@ def test_bench_multi_rank_branch_under_gloo(world):
     assert all(p["host_threads"] >= 1 for p in out["per_rank"])
     # max over ranks: the reported step time is no shorter than any rank's own
     assert out["ms_per_step"] * 4 >= 1e3 * max(p["seconds"] for p in out["per_rank"]) - 1e-6
+
+
+def test_bench_line_is_compact():
+    """bench.py's final line, made from a real full record of round 5 (20 KB: the line the driver could not parse):
+    under 4 KB, parses, and carries the contract's keys, `roofline`, `cpu_baseline` and the parity verdict"""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_v9_c3_bench.json")))
+    full["ms_per_step_cold"], full["value_cold"] = 0.668, 766000.0
+    text = bench.compact_line(full, {"path": "bench_out/last_full.json", "sha256": "0" * 64, "bytes": 20500})
+    assert len(text) < bench.LINE_LIMIT and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "priming_steps", "ms_per_step", "ms_per_step_cold",
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline",
+              "parity_in_run", "full_record"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("BASELINE config C3") and "model" not in line["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert line["parity_in_run"]["ok"] is True
+    assert abs(line["value"] - full["value"]) <= 1e-5 * full["value"]
+    # a record with absurdly long optional parts still fits (they are shed, the contract's keys stay)
+    full["roofline_other"] = {("k%d" % i): {"kernel": "x" * 100, "frac": 0.5, "ms_per_launch": 1.0, "traffic": 1.0} for i in range(40)}
+    text = bench.compact_line(full, None)
+    assert len(text) < bench.LINE_LIMIT and "roofline" in json.loads(text)

@@ -9,24 +9,28 @@
 // creations.cpp:20-33) and the backward launch adds its softmax gradient, so every
 // emission is read once per sweep and every gradient row is written exactly once.
 //
-// One workgroup of 4 waves per utterance; wave w owns nodes [64w NPL, 64(w+1) NPL), NPL = 1
-// or 2 nodes per lane.  The recursion over time is a BLOCK-SKEWED PIPELINE: a node needs
-// values of lower-numbered nodes only (higher-numbered in the backward sweep), so wave w runs
-// one block of K time steps behind wave w-1 and finds the boundary values of a whole block in
-// LDS, written a tick earlier.  Inside a tick a wave runs its K steps with no synchronisation
-// at all (neighbours move by DPP wave shifts; the block's emission gathers, boundary values
-// and alpha rows are fetched from LDS up front); one LDS-only barrier per tick keeps the
-// waves in step.  Nothing on the critical path waits for LDS or HBM latency:
-//   * emission rows live in an LDS ring of 5 blocks, landed a tick ahead from 16-byte loads
-//     issued 8 rows ahead (every wave stages its share; there are no helper waves);
-//   * scores are in log2 units (bare v_exp_f32 / v_log_f32), "minus infinity" is -1e30 so no
-//     step needs an inf / NaN guard, and every RN rows each wave shifts ITS nodes by their
-//     maximum (per-wave shifts summed in fp64; boundary values are re-based when they cross
-//     waves): magnitudes stay O(10) and float32 keeps ~1e-6 relative accuracy on every
-//     posterior for any T;
-//   * the backward sweep adds node posteriors into an LDS ring of gradient rows (pre-filled
-//     with the normaliser's softmax term) which is drained with coalesced stores once the
-//     last wave is through with a block; G's arc gradients are register accumulators.
+// One workgroup per utterance, its waves split into ROLES.  Forward: 8 waves -- 4 SWEEPERS run the recursion (wave
+// w owns nodes [64w NPL, 64(w+1) NPL), NPL = 1 or 2 nodes per lane) and 4 HELPERS stage emission rows HBM -> registers
+// -> LDS, compute the rows' log-sum-exps (the chain's own forwardScore) and, on a region's first sweep, copy the
+// emissions to where the backward sweep reads them.  Backward: 12 waves -- 4 sweepers, 4 STAGERS (waves 4, 5: emission
+// chunks; 6, 7: alpha rows and the rows' scalars) and 4 DRAINERS (gather the node posteriors by label, add the
+// normaliser's softmax term, store each gradient row once, coalesced).  Two workgroups per CU (<= 78 KB of LDS each,
+// <= 80 registers per lane in the backward kernel).
+// The recursion over time is a BLOCK-SKEWED PIPELINE: a node needs values of lower-numbered nodes only (higher-
+// numbered in the backward sweep), so sweeper w runs one block of K time steps (K = 8 forward, 4 backward at C3)
+// behind sweeper w-1 and finds the boundary values of a whole block in LDS, written a tick earlier.  Inside a tick a
+// sweeper runs its K steps with no synchronisation at all (neighbours move by DPP wave shifts; the block's emission
+// gathers, boundary values and alpha rows are fetched from LDS up front); one LDS-only barrier per tick keeps the
+// roles in step.  Nothing on the critical path waits for LDS or HBM latency:
+//   * emission rows live in an LDS ring (NBE = 5 blocks forward, NBGE = 8 backward), landed by the helper / staging
+//     waves from 16-byte loads requested two ticks ahead; the sweepers never issue a global load;
+//   * scores are in log2 units (bare v_exp_f32 / v_log_f32), "minus infinity" is -1e30 so no step needs an inf / NaN
+//     guard, and every RN rows each sweeper shifts ITS nodes by their maximum (per-wave shifts summed in fp64;
+//     boundary values are re-based when they cross waves): magnitudes stay O(10) and float32 keeps ~1e-6 relative
+//     accuracy on every posterior for any T;
+//   * the backward sweepers write node posteriors into an LDS ring with plain stores; when the last sweeper has left a
+//     block its rows are summed (each row's posteriors are rescaled to their exact total) and the drainers write
+//     the gradient rows; G's arc gradients are register accumulators of the sweepers.
 // HBM traffic per utterance: forward 4TC + 4(T+1)NS, backward 8TC + 4(T+1)NS (+ G).
 #include <hip/hip_runtime.h>
 

@@ -501,16 +501,24 @@ struct SlabCache {
 // (null once the thread's destructors have run: buffers that retire later -- the thread's own deferred garbage is
 //  taken apart by a thread-exit destructor too, in unspecified order -- are freed directly)
 SlabCache* slab_cache() {
+  // (the pointer and the flag are trivially destructible thread-locals: they may be read after `h` is gone, which a
+  //  member of `h` may not)
+  static thread_local SlabCache* cache = nullptr;
+  static thread_local bool gone = false;
   struct Holder {
-    SlabCache* c = new SlabCache();
+    Holder() { cache = new SlabCache(); }
     ~Holder() {
-      SlabCache* dead = c;
-      c = nullptr;
+      SlabCache* dead = cache;
+      cache = nullptr;
+      gone = true;
       delete dead;
     }
   };
-  thread_local Holder h;
-  return h.c;
+  if (!cache && !gone) {
+    thread_local Holder h;
+    (void)h;
+  }
+  return cache;
 }
 std::atomic<long> g_slab_hit{0}, g_slab_miss{0}, g_slab_drop{0};
 struct SlabStats {

@@ -587,7 +587,16 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     }
   }
   // The path graphs (a dozen host arrays of T entries per utterance): every element touches only its own objects, so
-  // a large batch is built by a few threads of the caller's pool (idle at a join), as ops_lazy.cpp does for C4
+  // a large batch is built by a few threads of the caller's pool (idle at a join; graph.cpp's ensure_host_batch and
+  // band_prepare above fan out the same way).  Those workers belong to the pool of device 0 and never take the
+  // caller's device: what make_result() stamps on a result there (device, home list) is THEIR thread's, so the
+  // caller's are captured here and written over it -- a result belongs to the thread that asked for it.
+  const int caller_device = Runtime::current_device();
+  const Runtime::InboxP caller_home = Runtime::home();
+  auto stamp = [&](Graph& out) {
+    out.s->device = caller_device;
+    out.s->home = caller_home;
+  };
   std::mutex tied_mu;
   if (want_path)
     for (size_t i = 0; i < n; ++i) gs[i].s->lazy->fixed.s->ensure_host();
@@ -603,6 +612,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     const int chain_first = lp.chain_side == 1;
     if (want_path) {
       Graph out = make_output(pop, int(i), {gs[i]});
+      stamp(out);
       if (len >= 0) {
         const int* harc = reinterpret_cast<const int*>(host.data() + o_pa[i]);
         const int* hlab = harc + (tab[i].T ? tab[i].T : 1);
@@ -627,6 +637,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
       outs[i] = std::move(out);
     } else {
       Graph out = make_output(sop, int(i), {gs[i]});
+      stamp(out);
       init_scalar_result(out);
       set_dev_weights(out, arena, tab[i].score, 1);
       BandViterbiScoreOp::Saved& sv = sop->saved[i];

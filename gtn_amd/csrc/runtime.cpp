@@ -256,9 +256,17 @@ void Runtime::sync() {
 }
 
 namespace {
+// The calling thread's list, reachable through TRIVIALLY DESTRUCTIBLE thread-locals: send() / defer_delete() also run
+// from other thread_local destructors at thread exit (region.cpp's slice deleter, a slab cache), possibly after the
+// holder below is gone -- its members must not be read then.  t_box: the live list; t_box_gone: the holder has been
+// destroyed (whatever arrives now is destroyed by the sender); t_draining: drain_deferred() is on this thread's stack.
+thread_local Runtime::Inbox* t_box = nullptr;
+thread_local bool t_box_gone = false;
+thread_local bool t_draining = false;
 struct InboxHolder {
   Runtime::InboxP box = std::make_shared<Runtime::Inbox>();
   InboxHolder() {
+    t_box = box.get();
     std::lock_guard<std::mutex> lk(g_inbox_mu);
     size_t live = 0;  // (drop the entries of threads that are gone while we are here)
     for (auto& w : g_inboxes)
@@ -280,15 +288,23 @@ struct InboxHolder {
       }
       for (auto& e : batch) e.second(e.first);
     }
+    t_box = nullptr;
+    t_box_gone = true;
   }
 };
 thread_local InboxHolder t_home;
+// the calling thread's list (made on first use), or null once the thread's holder has been destroyed
+Runtime::Inbox* my_box() {
+  if (t_box) return t_box;
+  if (t_box_gone) return nullptr;
+  return t_home.box.get();
+}
 }  // namespace
 
-Runtime::InboxP Runtime::home() { return t_home.box; }
+Runtime::InboxP Runtime::home() { return my_box() ? t_home.box : InboxP(); }
 
 void Runtime::send(const InboxP& to, void* p, void (*del)(void*)) {
-  if (to && to.get() == t_home.box.get()) {  // the caller's own list: counted, and taken apart when it is full
+  if (to && to.get() == my_box()) {  // the caller's own list: counted, and taken apart when it is full
     defer_delete(p, del, 1);
     return;
   }
@@ -339,7 +355,12 @@ static const size_t kDeferFull = [] {
 }();
 
 void Runtime::defer_delete(void* p, void (*del)(void*), size_t weight) {
-  Inbox& b = *t_home.box;
+  Inbox* own = my_box();
+  if (!own) {  // (thread teardown, after the holder: destroyed now)
+    del(p);
+    return;
+  }
+  Inbox& b = *own;
   bool full = false, dead = false;
   {
     std::lock_guard<std::mutex> lk(b.mu);
@@ -352,33 +373,47 @@ void Runtime::defer_delete(void* p, void (*del)(void*), size_t weight) {
     }
   }
   if (dead) del(p);
-  if (full) drain_deferred();
+  // (a destructor run BY a drain may defer more: that lands on the list the drain is emptying -- no nested drain)
+  if (full && !t_draining) drain_deferred();
 }
 
 void Runtime::drain_deferred() {
   GTNX_HOST_T("runtime.drain_deferred");
-  while (drain_some(256)) {
+  if (t_draining) return;
+  t_draining = true;
+  try {
+    while (drain_some(256)) {
+    }
+  } catch (...) {
+    t_draining = false;
+    throw;
   }
+  t_draining = false;
 }
 
 // destroys up to `max_items` of what is waiting on the calling thread's list; false when nothing was
 bool Runtime::drain_some(size_t max_items) {
-  Inbox& b = *t_home.box;
+  Inbox* own = my_box();
+  if (!own) return false;
+  Inbox& b = *own;
   std::vector<std::pair<void*, void (*)(void*)>> batch;
   {
     std::lock_guard<std::mutex> lk(b.mu);
     if (b.items.empty()) return false;
     const size_t n = std::min(max_items, b.items.size());
     batch.assign(b.items.end() - long(n), b.items.end());
+    // (weights are not kept per item: the load shrinks in proportion, and is exact again when the list is empty)
+    b.load = b.items.size() == n ? 0 : b.load - std::min(b.load, b.load * n / b.items.size());
     b.items.resize(b.items.size() - n);
-    if (b.items.empty()) b.load = 0;
   }
   for (auto& e : batch) e.second(e.first);  // (destructors may defer more)
   return true;
 }
 
 size_t Runtime::deferred_count() {
-  Inbox& b = *t_home.box;
+  Inbox* own = my_box();
+  if (!own) return 0;
+  Inbox& b = *own;
   std::lock_guard<std::mutex> lk(b.mu);
   return b.items.size();
 }
@@ -396,7 +431,9 @@ void Runtime::drain_until(void* hip_event) {
 // moment
 void Runtime::drain_while_busy() {
   GTNX_HOST_T("runtime.drain_while_busy");
-  Inbox& b = *t_home.box;
+  Inbox* own = my_box();
+  if (!own) return;
+  Inbox& b = *own;
   for (;;) {
     {
       std::lock_guard<std::mutex> lk(b.mu);
@@ -555,6 +592,14 @@ void Runtime::empty_cache() {
     reserved_ -= kv.first;
   }
   free_dev_.clear();
+  // the stream is idle: every released pinned block is free whether its group has an event yet or not
+  for (auto& b : unstamped_pinned_) free_pinned_.emplace(b.second, b.first);
+  unstamped_pinned_.clear();
+  for (auto& g : pending_pinned_) {
+    for (auto& b : g.blocks) free_pinned_.emplace(b.second, b.first);
+    ev_pool_.push_back(g.ev);
+  }
+  pending_pinned_.clear();
   for (auto& kv : free_pinned_) (void)hipHostFree(kv.second);
   free_pinned_.clear();
 }
@@ -613,7 +658,9 @@ void Runtime::d2d(void* dst, const void* src, size_t bytes) {
 // device -> pinned host memory, asynchronous: the same way round (the kernel's stores travel over the host link)
 void Runtime::d2h_pinned_async(void* pinned_dst, const void* src, size_t bytes) {
   if (!bytes) return;
-  if (bytes <= (size_t(1) << 20)) {
+  // (a source on ANOTHER GPU of the process -- Weights::ensure_host runs on the caller's device, not the owner's -- is
+  //  the runtime's to copy, as in d2d)
+  if (bytes <= (size_t(1) << 20) && local_to(src, device_)) {
     launch_copy_small(pinned_dst, src, bytes, stream_);
     return;
   }
@@ -628,7 +675,7 @@ void Runtime::h2d_pinned(void* dst, const void* pinned_src, size_t bytes) {
   // (pinned blocks are mapped into the device's address space: the kernel reads the host's copy.  Measured on the
   //  headline step, whose four table uploads of 28-200 KB were runtime copies: 0.688 -> 0.630 ms per step -- a copy of
   //  the runtime's is ordered against the compute queue from outside it, a kernel is just the next dispatch)
-  if (bytes <= lim) {
+  if (bytes <= lim && local_to(dst, device_)) {
     launch_copy_small(dst, pinned_src, bytes, stream_);
     return;
   }

@@ -386,6 +386,7 @@ def test_timed_route_at_full_size_against_the_reference(gtn):
         worst["t64"] = max(worst["t64"], (np.abs(got_t[sl] - t64) / scale).max())
         worst["tref"] = max(worst["tref"], (np.abs(got_t[sl] - want_t[sl]) / scale).max())
         worst["ref_t64"] = max(worst["ref_t64"], (np.abs(want_t[sl] - t64) / scale).max())
+    print("timed route vs float64 / reference:", {k: float(v) for k, v in worst.items()})
     assert worst["em64"] <= 1e-4, worst
     # (target-arc gradients are sums of T arc posteriors accumulated in float32 registers by the sweep and are NOT
     #  rescaled per row as the emission gradients are: measured 3.9e-4 on the first run of this test, the reference's

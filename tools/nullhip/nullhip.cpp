@@ -67,15 +67,16 @@ const char* hipGetErrorString(hipError_t) { return "nullhip"; }
 hipError_t hipGetLastError(void) { return hipSuccess; }
 // "device" memory = what hipMalloc handed out (so that the engine's device-pointer detection sees it as such)
 static std::mutex g_range_mu;
-static std::map<uintptr_t, size_t> g_ranges;
+static std::map<uintptr_t, std::pair<size_t, int>> g_ranges;  // start -> (bytes, device current at hipMalloc)
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
   std::lock_guard<std::mutex> lk(g_range_mu);
   auto it = g_ranges.upper_bound(reinterpret_cast<uintptr_t>(p));
   if (it == g_ranges.begin()) return hipErrorInvalidValue;
   --it;
-  if (reinterpret_cast<uintptr_t>(p) >= it->first + it->second) return hipErrorInvalidValue;
+  if (reinterpret_cast<uintptr_t>(p) >= it->first + it->second.first) return hipErrorInvalidValue;
   std::memset(a, 0, sizeof(*a));
   a->type = hipMemoryTypeDevice;
+  a->device = it->second.second;
   return hipSuccess;
 }
 // NULLHIP_ZERO=1: zero-filled allocations and full-size copies -- deterministic (all-zero) "device"
@@ -93,7 +94,7 @@ hipError_t hipMalloc(void** p, size_t n) {
   if (g_zero) std::memset(*p, 0, n ? n : 256);
   {
     std::lock_guard<std::mutex> lk(g_range_mu);
-    g_ranges[reinterpret_cast<uintptr_t>(*p)] = n ? n : 256;
+    g_ranges[reinterpret_cast<uintptr_t>(*p)] = {n ? n : 256, t_dev};
   }
   g_alloc_bytes[t_dev].fetch_add(long(n));
   return hipSuccess;

@@ -3,6 +3,7 @@
 //   tools/ubench/band_bench [B T C U]
 #include "../../gtn_amd/csrc/band.hip"
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <random>
@@ -131,6 +132,58 @@ int main(int argc, char** argv) {
   std::vector<float> sc(B);
   CK(hipMemcpy(sc.data(), d_score, 4 * B, hipMemcpyDeviceToHost));
   printf("score[0..3] %.4f %.4f %.4f %.4f\n", sc[0], sc[1], sc[2], sc[3]);
+  // ---- utterances 0 and B-1 against the same recursion in float64 on the host (delta = -1, FUSE: + softmax term)
+  for (int b : {0, B - 1}) {
+    const BandNode* nd = reinterpret_cast<const BandNode*>(h_g.data() + per_g * b);
+    const float* e = em.data() + size_t(b) * T * C;
+    const double NEG = -1e300;
+    auto lse = [&](double a, double c) { const double m = a > c ? a : c; return m <= NEG ? NEG : m + std::log(std::exp(a - m) + std::exp(c - m)); };
+    std::vector<double> al(size_t(T + 1) * N, NEG), be(size_t(T + 1) * N, NEG);
+    al[0] = 0.0;
+    for (int t = 0; t < T; ++t)
+      for (int m = 0; m < N; ++m) {
+        double v = al[size_t(t) * N + m];
+        if (m > 0) v = lse(v, al[size_t(t) * N + m - 1]);
+        if (nd[m].aid[2] >= 0) v = lse(v, al[size_t(t) * N + m - 2]);
+        al[size_t(t + 1) * N + m] = v <= NEG ? NEG : v + e[size_t(t) * C + nd[m].lab];
+      }
+    be[size_t(T) * N + N - 1] = 0.0;
+    if (N > 1) be[size_t(T) * N + N - 2] = 0.0;
+    for (int t = T - 1; t >= 0; --t)
+      for (int m = 0; m < N; ++m) {
+        auto q = [&](int k) { const double x = be[size_t(t + 1) * N + k]; return x <= NEG ? NEG : x + e[size_t(t) * C + nd[k].lab]; };
+        double v = q(m);
+        if (m + 1 < N) v = lse(v, q(m + 1));
+        if (m + 2 < N && nd[m + 2].aid[2] >= 0) v = lse(v, q(m + 2));
+        be[size_t(t) * N + m] = v;
+      }
+    const double z = lse(al[size_t(T) * N + N - 1], N > 1 ? al[size_t(T) * N + N - 2] : NEG);
+    std::vector<double> g(size_t(T) * C, 0.0), ga(3 * size_t(N), 0.0);
+    const bool fuse = getenv("FUSE") != nullptr;
+    for (int t = 0; t < T; ++t) {
+      if (fuse) {
+        double mx = NEG, s = 0;
+        for (int c = 0; c < C; ++c) mx = e[size_t(t) * C + c] > mx ? e[size_t(t) * C + c] : mx;
+        for (int c = 0; c < C; ++c) s += std::exp(e[size_t(t) * C + c] - mx);
+        for (int c = 0; c < C; ++c) g[size_t(t) * C + c] = -std::exp(e[size_t(t) * C + c] - mx) / s;  // delta_norm = -1
+      }
+      for (int m = 0; m < N; ++m) {
+        g[size_t(t) * C + nd[m].lab] -= std::exp(al[size_t(t + 1) * N + m] + be[size_t(t + 1) * N + m] - z);  // delta = -1
+        for (int k = 0; k < 3; ++k)
+          if (nd[m].aid[k] >= 0 && m - k >= 0)
+            ga[nd[m].aid[k]] -= std::exp(al[size_t(t) * N + m - k] + e[size_t(t) * C + nd[m].lab] + be[size_t(t + 1) * N + m] - z);
+      }
+    }
+    std::vector<float> hg(size_t(T) * C), hga(3 * size_t(N));
+    CK(hipMemcpy(hg.data(), d_grad + size_t(b) * T * C, hg.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hga.data(), d_gfix + size_t(b) * 3 * N, hga.size() * 4, hipMemcpyDeviceToHost));
+    double ge = 0, gae = 0;
+    for (size_t i = 0; i < hg.size(); ++i) ge = std::max(ge, std::fabs(double(hg[i]) - g[i]));
+    if (gradg)
+      for (int a = 0; a < A; ++a) gae = std::max(gae, std::fabs(double(hga[a]) - ga[a]) / std::max(1.0, std::fabs(ga[a])));
+    printf("utterance %d against float64: score %.6f (gpu %.6f), max |d emission| error %.3g, max relative target-arc gradient error %.3g\n", b, z,
+           double(sc[b]), ge, gae);
+  }
 #ifdef GTNX_BAND_TIMING
   long long h[256];
   CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(::g_band_timing), sizeof(h)));

@@ -101,7 +101,7 @@ def compact_line(full, full_ref=None):
 
 def emit(full):
     """write the full record beside the script (bench_out/last_full.json; also under $GRAFT_REPO_ROOT/gpurun_out when
-    that exists, so a gpurun call brings it home) and print the compact line LAST on stdout"""
+    that exists, so a gpurun call brings it home); returns the compact line for say_last()"""
     import hashlib
     text = json.dumps(full)
     ref = None
@@ -116,8 +116,15 @@ def emit(full):
                 ref = {"path": os.path.relpath(os.path.join(d, "last_full.json"), ROOT), "sha256": hashlib.sha256(text.encode()).hexdigest(), "bytes": len(text)}
         except OSError:
             continue
+    return compact_line(full, ref)
+
+
+def say_last(text):
+    """the compact line, as the LAST thing this process writes to stdout (callers tear the process group down first:
+    RCCL prints at teardown)"""
     sys.stdout.flush()
-    print(compact_line(full, ref))
+    sys.stderr.flush()
+    print(text)
     sys.stdout.flush()
 
 
@@ -469,9 +476,10 @@ def dry_run(args, dist, torch, world, rank, dev):
     dt_local = time.perf_counter() - t0
     dt = max_over_ranks(dt_local, dev)
     ranks = per_rank_report(dist, torch, world, dev, {}, dt_local)
+    line = None
     if rank == 0:
         ok = gathered is None or all(float(gathered[r * B]) == float(r) for r in range(world))
-        emit({"metric": "CTC forward+backward losses/sec (T=%d, C=%d)" % (args.T, args.C), "value": None,
+        line = emit({"metric": "CTC forward+backward losses/sec (T=%d, C=%d)" % (args.T, args.C), "value": None,
                           "unit": "losses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / max(args.steps, 1) * 1e3, "higher_is_better": True, "scaling": "weak",
                           "dry_run": True, "data": "none (stand-in step: collectives and timing skeleton only)",
@@ -481,6 +489,8 @@ def dry_run(args, dist, torch, world, rank, dev):
                           "gather_ok": bool(ok), "per_rank": ranks})
     if world > 1:
         dist.destroy_process_group()
+    if line is not None:
+        say_last(line)
 
 
 def main():
@@ -893,18 +903,23 @@ def main():
             out["configs"] = other_configs(args)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, T, Cn, U, 1234, args.cpu_baseline_seconds)
-        emit(out)
-        if parity is not None and not parity.get("ok", False):
-            print("bench.py: the timed batch does NOT match the checker: " + json.dumps(parity), file=sys.stderr)
-            sys.stdout.flush()
-            os._exit(3)
-    # orderly teardown: drop every graph, return pooled memory, then let HIP exit
+        line = emit(out)
+    else:
+        line = None
+    # orderly teardown: drop every graph, return pooled memory, leave the process group -- and only then the line
+    # (RCCL writes to stdout when a group is destroyed; the driver reads the LAST line)
     del keep, ems, comp, e0
     gtn.set_stream(None)
     gtn.synchronize()
     gtn.empty_cache()
     if world_dist:
         dist.destroy_process_group()
+    if line is not None:
+        say_last(line)
+        if parity is not None and not parity.get("ok", False):
+            print("bench.py: the timed batch does NOT match the checker: " + json.dumps(parity), file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(3)
 
 
 if __name__ == "__main__":

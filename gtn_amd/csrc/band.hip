@@ -100,8 +100,13 @@ constexpr int NBGE = 8;  // ... of emissions: they land a tick before the rest o
 #endif
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifdef GTNX_EXP_FAKE_MATH  // (tools/ubench experiment, wrong results: what the sweeps cost with full-rate stand-ins for the transcendentals)
+__device__ __forceinline__ float ex2(float x) { return __builtin_fmaf(x, 0.001f, 1.0f); }
+__device__ __forceinline__ float lg2(float x) { return __builtin_fmaf(x, 0.001f, -0.001f); }
+#else
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float lg2(float x) { return __builtin_amdgcn_logf(x); }
+#endif
 
 // A value that came from a global load and is first used inside the main loop would make the
 // compiler put its `s_waitcnt vmcnt` THERE -- where it also waits for every global store issued

@@ -153,7 +153,9 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
     Runtime& rt = Runtime::get();
     GradTarget ge, gf;
     if (ch.calc_grad) ge = grad_target(ch, false);  // every row is written by the kernel
-    if (fx.calc_grad) gf = grad_target(fx, true);   // arcs that never match stay 0
+    // (device-built CTC targets: every arc lies in the band and the sweep writes them all, zeros included -- no fill;
+    //  force-alignment acceptors keep theirs)
+    if (fx.calc_grad) gf = grad_target(fx, fx.fal);
     Batch* lin_out = nullptr;
     if (t_plan && ch.calc_grad && !ge.scratch) {
       auto it = t_plan->lin.find(&ch);
@@ -349,9 +351,13 @@ BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank
       gs.push_back(ctc_target_graph_host(labels + b->lab_off[size_t(i)], lengths[i], blank, calc_grad));
     return batch_from_graphs(std::move(gs));
   }
-  // records on the device: labels | per element {nodes, flags, snode, slab, n_arcs}
+  // records on the device: labels | the kernel's argument table | per element {nodes, flags, snode, slab, n_arcs}.
+  // Labels and table cross the host link in ONE copy (they were two: a copy is a dependent operation of ~5 us at
+  // the head of every step)
   Runtime& rt = Runtime::get();
-  size_t bytes = align_up(sizeof(int) * (total ? total : 1), 256);
+  const size_t lab_bytes = align_up(sizeof(int) * (total ? total : 1), 256);
+  const size_t arg_bytes = align_up(sizeof(CtcTargetArgs) * size_t(n), 256);
+  size_t bytes = lab_bytes + arg_bytes;
   b->rec_off.resize(size_t(n));
   for (int i = 0; i < n; ++i) {
     const size_t N = size_t(2 * lengths[i] + 1);
@@ -359,13 +365,9 @@ BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank
     bytes += align_up(sizeof(BandNode) * N, 64) + align_up(N, 64) + 2 * align_up(4 * N, 64) + 64;
   }
   b->rec_mem = rt.alloc(bytes);
-  {
-    PinnedMemP pin = rt.alloc_pinned(sizeof(int) * (total ? total : 1));
-    std::memcpy(pin->ptr, labels, sizeof(int) * total);
-    rt.h2d_pinned(b->rec_mem->ptr, pin->ptr, sizeof(int) * total);
-  }
-  std::vector<CtcTargetArgs> args;
-  args.resize(size_t(n));
+  PinnedMemP pin = rt.alloc_pinned(lab_bytes + arg_bytes);
+  std::memcpy(pin->ptr, labels, sizeof(int) * total);
+  CtcTargetArgs* args = reinterpret_cast<CtcTargetArgs*>(static_cast<char*>(pin->ptr) + lab_bytes);
   for (int i = 0; i < n; ++i) {
     const size_t N = size_t(2 * lengths[i] + 1);
     char* base = b->rec_mem->as<char>(b->rec_off[size_t(i)]);
@@ -383,8 +385,8 @@ BatchP batch_ctc_targets(const int* labels, const int* lengths, int n, int blank
     a.N = int(N);
     a.pad = 0;
   }
-  DevMemP d = upload_vec(args);
-  launch_ctc_targets(d->as<CtcTargetArgs>(), n, blank, rt.stream());
+  rt.h2d_pinned(b->rec_mem->ptr, pin->ptr, lab_bytes + arg_bytes);
+  launch_ctc_targets(reinterpret_cast<const CtcTargetArgs*>(b->rec_mem->as<char>(lab_bytes)), n, blank, rt.stream());
   return b;
 }
 

@@ -118,6 +118,7 @@ float* grad_dev_ptr(Graph& out) {
 }
 
 thread_local bool t_backward_retain = false;
+thread_local bool t_reclaim_at_wait = false;
 float* through_delta(Graph& out) {
   float* d = grad_dev_ptr(out);
   GradState& gs = *out.g;

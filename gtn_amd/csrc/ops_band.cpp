@@ -663,7 +663,18 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     };
     build_many(now);
     if (!rerun.empty()) {
-      fetch_results();
+      // only what the second launch rewrote comes back: the reruns' own path blocks and heads (a handful of 12 KB
+      // blocks, not the whole 6 MB arena a second time)
+      if (want_path && rerun.size() * 8 < n) {
+        for (size_t i : rerun) {
+          const size_t T = size_t(tab[i].T ? tab[i].T : 1);
+          rt.d2h_pinned_async(host.data() + o_pa[i], arena->as<char>(o_pa[i]), 12 * T);
+          rt.d2h_pinned_async(host.data() + o_hd[i], arena->as<char>(o_hd[i]), 16);
+        }
+        rt.sync_while_draining();
+      } else {
+        fetch_results();
+      }
       lap("band_viterbi.2c_ranked_rerun_wait");
       build_many(rerun);
     }

@@ -183,7 +183,7 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
       }
       if (ok) {
         ht_phase("compose.0c_shape_ok");
-        rt.drain_deferred();  // the step's reclamation point (see below)
+        if (!t_reclaim_at_wait) rt.drain_deferred();  // the step's reclamation point (see below)
         ht_phase("compose.0d_drain");
         auto lop = make_lazy_compose_op();
         outs.reserve(n);
@@ -316,8 +316,9 @@ std::vector<Graph> op_compose_impl(std::vector<Graph>& av, std::vector<Graph>& b
     if (eligible && (force || pairs || est > budget)) {
       // nothing downstream of a symbolic product waits for the GPU, so this is the step's
       // reclamation point (objects the caller let go of since the last one; cheap while
-      // their memory is still warm for the allocator -- see Runtime::defer_delete)
-      rt.drain_deferred();
+      // their memory is still warm for the allocator -- see Runtime::defer_delete).  A region that goes on to WAIT for
+      // the GPU reclaims there instead (t_reclaim_at_wait).
+      if (!t_reclaim_at_wait) rt.drain_deferred();
       auto lop = make_lazy_compose_op();
       for (size_t i = 0; i < n; ++i) {
         Graph& a = const_cast<Graph&>(bcast(av, n, i));

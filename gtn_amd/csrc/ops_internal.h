@@ -53,6 +53,11 @@ float* grad_dev_ptr(Graph& out);
 // passes, not the current one.  Single pass (every criterion step): grad_dev_ptr(out), nothing else happens.
 float* through_delta(Graph& out);
 extern thread_local bool t_backward_retain;  // the backward pass being run keeps the graph (op_backward)
+// Set by a parallelMap region whose recorded calls end in a function that WAITS for the GPU (viterbiScore /
+// viterbiPath read their results back): compose's reclamation point is skipped and what the caller let go of is
+// taken apart while the host waits for the launch instead (Runtime::d2h_sync -> drain_while_busy) -- in the decode
+// loop of the reference's API that was 1.2 ms per batch in front of the launch.
+extern thread_local bool t_reclaim_at_wait;
 
 // ---- gradient launches of one backward() over the same emission chains, gathered before they go:
 // forwardScore(emissions) contributes dn * softmax(row), forwardScore(target o emissions) the node

@@ -16,6 +16,7 @@
 #include <unordered_map>
 
 namespace gtnx {
+extern thread_local bool t_reclaim_at_wait;  // ops_internal.h: a run that waits for the GPU reclaims at that wait
 
 namespace {
 
@@ -1258,6 +1259,14 @@ struct Run {
       if (prio(a.op) != prio(b.op)) return prio(a.op) < prio(b.op);
       return int(a.op) < int(b.op);
     });
+    // (does this run end in a function that waits for the GPU?  Then the step's reclamation moves to that wait.)
+    bool waits = false;
+    for (auto& g : groups) waits = waits || g.op == RO_VS || g.op == RO_VP;
+    struct ReclaimScope {
+      bool prev;
+      explicit ReclaimScope(bool w) : prev(t_reclaim_at_wait) { t_reclaim_at_wait = w; }
+      ~ReclaimScope() { t_reclaim_at_wait = prev; }
+    } reclaim_scope(waits);
     for (int gi : order) run_group(groups[size_t(gi)]);
     // scalars nobody in this run reads are what the caller will ask for (the losses of a step): their values start
     // for the host now, behind the launches that compute them -- item() then waits for THEM, not for what the

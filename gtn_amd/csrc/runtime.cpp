@@ -631,6 +631,10 @@ void Runtime::d2h_sync(void* dst, const void* src, size_t bytes) {
   drain_while_busy();
   HIP_CHECK(hipStreamSynchronize(stream_));
 }
+void Runtime::sync_while_draining() {
+  drain_while_busy();
+  HIP_CHECK(hipStreamSynchronize(stream_));
+}
 namespace {
 // may a kernel on `dev` touch p?  (A caller's pointer may live on ANOTHER GPU of the process: the runtime's copy
 // handles that with or without peer access, a kernel of ours does not.  One GPU in the process: nothing to ask.)

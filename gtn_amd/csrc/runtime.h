@@ -106,6 +106,7 @@ class Runtime {
   static size_t deferred_count();                                   // entries waiting on the calling thread's list
   void drain_until(void* hip_event);  // reclaim until the event has happened, then wait for it
   void drain_while_busy();
+  void sync_while_draining();  // drain_while_busy(), then wait for the stream (what d2h_sync ends with)
 
   // ---- a SIDE stream with a host thread of its own to feed it.  For a launch chain that does not depend on what
   // the engine stream runs meanwhile (the beta sweep of a dense product next to its alpha sweep, ops_lazy.cpp:

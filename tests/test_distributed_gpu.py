@@ -59,15 +59,22 @@ def test_rccl_collectives_run_on_engine_tensors():
 def test_bench_multi_rank_branch_over_rccl():
     """bench.py's world > 1 code (process group, all_gather of the losses every step, barrier-bracketed timing,
     max over ranks, per-rank report) forced through the nccl branch with WORLD_SIZE = 1"""
+    import tempfile
     env = dict(os.environ, GTN_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(31500 + os.getpid() % 2000),
-               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", GTN_BENCH_OUT=tempfile.mkdtemp(prefix="gtn_bench_"))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2",
                         "--batch", "64", "--no-cpu-baseline", "--no-unmodified-caller", "--no-configs", "--no-reference-api",
                         "--no-built-lattice"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])  # (RCCL prints after it)
+    # the compact line is the LAST line of stdout (bench.py leaves the process group before it prints: RCCL writes to
+    # stdout at teardown), the per-rank report is in the full record beside it
+    last = r.stdout.rstrip().splitlines()[-1]
+    assert last.startswith("{") and len(last) < 4096, r.stdout[-2000:]
+    line = json.loads(last)
     assert line["collectives"] and "RCCL" in line["collectives"]
-    assert line["value"] > 0 and len(line["per_rank"]) == 1
+    assert line["value"] > 0 and line["config"]["rccl_ranks"] == 1
+    full = json.load(open(os.path.join(env["GTN_BENCH_OUT"], "last_full.json")))
+    assert len(full["per_rank"]) == 1 and full["value"] == pytest.approx(line["value"], rel=1e-4)
 
 
 @pytest.mark.gpu

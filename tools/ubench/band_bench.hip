@@ -178,9 +178,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hg.data(), d_grad + size_t(b) * T * C, hg.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(hga.data(), d_gfix + size_t(b) * 3 * N, hga.size() * 4, hipMemcpyDeviceToHost));
     double ge = 0, gae = 0;
+    int worst = -1;
     for (size_t i = 0; i < hg.size(); ++i) ge = std::max(ge, std::fabs(double(hg[i]) - g[i]));
     if (gradg)
-      for (int a = 0; a < A; ++a) gae = std::max(gae, std::fabs(double(hga[a]) - ga[a]) / std::max(1.0, std::fabs(ga[a])));
+      for (int a = 0; a < A; ++a) {
+        const double r = std::fabs(double(hga[a]) - ga[a]) / std::max(1.0, std::fabs(ga[a]));
+        if (r > gae) gae = r, worst = a;
+      }
+    if (worst >= 0) printf("  worst arc %d: gpu %.6f float64 %.6f\n", worst, double(hga[worst]), ga[worst]);
     printf("utterance %d against float64: score %.6f (gpu %.6f), max |d emission| error %.3g, max relative target-arc gradient error %.3g\n", b, z,
            double(sc[b]), ge, gae);
   }

@@ -648,7 +648,10 @@ bool launch_lazy_mfma_chain(const LazyGroup& g, int backward, int* zeroed_sync, 
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st);            // order-preserving integer keys -> floats
 void launch_lazy_mfma_rowmax(const LazyGroup& g, int which, hipStream_t st);   // amaxp -> amax (0) / bmaxp -> bmax (1)
 void launch_lazy_mfma_score(const LazyGroup& g, hipStream_t st);               // score (relative, lazy_final) += sum of amax, float64
-void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x T x nb */, hipStream_t st);  // R zero-filled
+// R zero-filled.  partials: scratch of lazy_mfma_fixed_grad_scratch_bytes(g) bytes or null (then the blocks meet in R by atomics)
+size_t lazy_mfma_fixed_grad_scratch_bytes(const LazyGroup& g);
+void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts /* 16 B x T x nb */, hipStream_t st, void* partials = nullptr,
+                                 size_t partials_bytes = 0);
 
 // ---------------------------------------------------------------------------
 // small elementwise helpers

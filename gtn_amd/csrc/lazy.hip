@@ -24,6 +24,7 @@
 
 #include <climits>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -1376,10 +1377,10 @@ typedef float mf_f4u __attribute__((ext_vector_type(4), aligned(4)));
 constexpr int FG_DEPTH = 6;
 template <bool STRIDED>
 __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad4_kernel(LazyGroup g, const gtnx_f4* __restrict__ pc,
-                                                                   int pairs_per_block) {
+                                                                   int pairs_per_block, int sb_first) {
   __shared__ float part[4][32][64];
   const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 31, hi = l >> 5;
-  const int sb = blockIdx.x, db = blockIdx.y, zb = blockIdx.z;
+  const int sb = blockIdx.x + sb_first, db = blockIdx.y, zb = blockIdx.z;  // (sb_first: the source blocks of a launch start there)
   const int s0 = sb * 128, d0 = db * 64;
   const int N = g.N, C = g.C, nb = g.nb, Nl = g.N - g.rot;
   const int64_t plane = int64_t(nb) * N;
@@ -1499,6 +1500,176 @@ __global__ __launch_bounds__(256) void lazy_mfma_fixed_grad4_kernel(LazyGroup g,
       if (ss < N && dok[c] && a != 0.0f) atomicAdd(&g.R[int64_t(mf_node(g, ss)) * N + dn0 + c], a);
     }
   }
+}
+// ---- The same contraction, one WORKGROUP per 256 x 256 block of R (round 6).  The per-wave kernels above read
+// the planes once per 64 (or 128) destination / source slots: at C4 (512 x 512 live slots) alpha is fetched 8 times and
+// beta 4 times -- 19.5 GB of HBM traffic for 3.1 GB of planes, and that, not the matrix cores, bounded them (4.6 ms).
+// Here sixteen waves (4 x 4, each a 64 x 64 sub-block = 2 x 2 MFMA tiles, 64 accumulator registers) share the
+// operands of a block through LDS: a pair's 256 source values and 256 destination values are loaded and
+// exponentiated ONCE per workgroup (one 16-byte load of alpha and of beta per lane and 16 pairs), double-buffered
+// against the 128 MFMAs a SIMD issues per 16 pairs; every plane is read N / 256 times (twice at C4).  The pairs are
+// split over gridDim.z workgroups per block (split-K); partial blocks meet in R by atomics as before.
+// Floor at C4: 2 T B N^2 = 0.27 TFLOP on v_mfma_f32_32x32x2_f32 (157 TFLOP/s dense) = 1.71 ms.
+// Takes graphs whose live slots come in whole blocks of 256 (Nl % 256 == 0); dead SOURCE slots (an ASG start node:
+// alive at step 0 only) are left to lazy_mfma_fixed_grad4_kernel, launched for those blocks alone.
+constexpr int FGW_KB = 16;  // pairs per staged block
+template <bool STRIDED>
+__global__ __launch_bounds__(1024) void lazy_mfma_fixed_grad_wg_kernel(LazyGroup g, const gtnx_f4* __restrict__ pc,
+                                                                      int pairs_per_block, float* __restrict__ partials) {
+  __shared__ __attribute__((aligned(16))) float As[2][FGW_KB][256];
+  __shared__ __attribute__((aligned(16))) float Qs[2][FGW_KB][256];
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lo = l & 31, hi = l >> 5;
+  const int wi = wv >> 2, wj = wv & 3;
+  const int N = g.N, C = g.C, nb = g.nb, rot = g.rot;
+  const int s0 = blockIdx.x * 256, d0 = blockIdx.y * 256;  // live slots: node = slot + rot
+  const int64_t plane = int64_t(nb) * N;
+  const int64_t npairs = int64_t(g.T) * nb;
+  const int64_t p0 = int64_t(blockIdx.z) * pairs_per_block, p1 = min(npairs, p0 + pairs_per_block);
+  if (p0 >= p1) return;
+  // staging role: pair tid / 64 of the block, columns 4 (tid % 64) .. + 3 of the source AND destination tiles
+  const int sp = tid >> 6, sc = (tid & 63) * 4;
+  const int snode = s0 + rot + sc, dnode = d0 + rot + sc;
+  int lab[4], labc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    lab[k] = g.nlab[dnode + k];
+    labc[k] = lab[k] >= 0 ? lab[k] : 0;
+  }
+  const bool lab_run = lab[0] >= 0 && lab[1] == lab[0] + 1 && lab[2] == lab[0] + 2 && lab[3] == lab[0] + 3;  // (one 16-byte load)
+  int pp = int(p0) + sp;
+  int t = pp / nb, b = pp - t * nb;
+  const int pend = int(p1), plast = int(p1) - 1;
+  const int step_t = FGW_KB / nb, step_b = FGW_KB % nb;
+  struct Round {
+    mf_f4u al, be, ev;
+    gtnx_f4 c;
+    bool in;  // (known when the request is made: nothing LOADED is looked at before the landing)
+  };
+  // exp(-inf) is 0: a dead node or an invalid pair is a select on the ARGUMENT, no branch
+  auto land = [&](const Round& r, int buf) {
+    const bool on = r.in && r.c.w != 0.0f;
+    const float alv[4] = {r.al.x, r.al.y, r.al.z, r.al.w}, bev[4] = {r.be.x, r.be.y, r.be.z, r.be.w},
+                evv[4] = {r.ev.x, r.ev.y, r.ev.z, r.ev.w};
+    float a[4], q[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = __expf(on ? alv[k] + r.c.x : NEG_INF);
+      q[k] = __expf((on && lab[k] >= 0) ? evv[k] + bev[k] + r.c.y : NEG_INF) * r.c.z;
+    }
+    *reinterpret_cast<gtnx_f4*>(&As[buf][sp][sc]) = gtnx_f4{a[0], a[1], a[2], a[3]};
+    *reinterpret_cast<gtnx_f4*>(&Qs[buf][sp][sc]) = gtnx_f4{q[0], q[1], q[2], q[3]};
+  };
+  gtnx_f16v acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = gtnx_f16v{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const int nblk = int((p1 - p0 + FGW_KB - 1) / FGW_KB);
+  auto multiply = [&](int buf) {
+    const float* Ab = &As[buf][0][64 * wi + lo];
+    const float* Qb = &Qs[buf][0][64 * wj + lo];
+#pragma unroll
+    for (int kk = 0; kk < FGW_KB / 2; ++kk) {
+      const float a0 = Ab[(2 * kk + hi) * 256], a1 = Ab[(2 * kk + hi) * 256 + 32];
+      const float q0 = Qb[(2 * kk + hi) * 256], q1 = Qb[(2 * kk + hi) * 256 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, q1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, q1, acc[1][1], 0, 0, 0);
+    }
+  };
+  // One round in flight: block blk + 1 is requested, block blk multiplied out of LDS (128 MFMAs per SIMD, 3.4 us:
+  // the loads arrive under them), block blk + 1 exponentiated into the other buffer -- the only wait for memory is
+  // at that landing, where nothing younger is outstanding.  (A round past the end is a weight-0 re-read of the last
+  // pair: no branch around a request.)  LABRUN: this lane's four labels are consecutive, one 16-byte load.
+  auto sweep = [&](auto labrun_tag) {
+    constexpr bool LABRUN = decltype(labrun_tag)::value;
+    auto req = [&](Round& r) {
+      const bool in = pp < pend;
+      const int tc = in ? t : 0, bc = in ? b : 0;
+      r.in = in;
+      r.c = pc[in ? pp : plast];
+      const float* ar = g.alpha + int64_t(tc) * plane + int64_t(bc) * N;
+      const float* br = g.beta + int64_t(tc + 1) * plane + int64_t(bc) * N;
+      const GTNX_G float* er =
+          (STRIDED ? (const GTNX_G float*)g.em_base + int64_t(bc) * g.em_stride : (const GTNX_G float*)g.em[bc]) + int64_t(tc) * C;
+      r.al = *reinterpret_cast<const mf_f4u*>(ar + snode);
+      r.be = *reinterpret_cast<const mf_f4u*>(br + dnode);
+      if constexpr (LABRUN) {
+        r.ev = *reinterpret_cast<const GTNX_G mf_f4u*>(er + labc[0]);
+      } else {
+        r.ev.x = er[labc[0]];
+        r.ev.y = er[labc[1]];
+        r.ev.z = er[labc[2]];
+        r.ev.w = er[labc[3]];
+      }
+      pp += FGW_KB;
+      b += step_b;
+      t += step_t;
+      const bool wrap = b >= nb;
+      b -= wrap ? nb : 0;
+      t += wrap ? 1 : 0;
+    };
+    Round r;
+    req(r);
+    land(r, 0);
+    __syncthreads();
+    for (int blk = 0; blk < nblk; blk += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (blk + u < nblk) {  // uniform
+          req(r);
+          __builtin_amdgcn_sched_barrier(0);
+          multiply(u);
+          __builtin_amdgcn_sched_barrier(0);
+          land(r, u ^ 1);  // (that buffer was last read a block ago: the barrier below closed that)
+          __syncthreads();
+        }
+      }
+    }
+  };
+  // (every lane of the workgroup has to agree on the form: the loads of a round are counted)
+  __shared__ int s_norun;
+  if (tid == 0) s_norun = 0;
+  __syncthreads();
+  if (!lab_run) s_norun = 1;
+  __syncthreads();
+  if (s_norun == 0) sweep(std::true_type{});
+  else sweep(std::false_type{});
+  // ---- the partial block: tile (i, j) of this wave holds rows 64 wi + 32 i + r(v, hi), columns 64 wj + 32 j + lo.
+  // With `partials` it is STORED (slice-major [z][tile][256][256], 128-byte runs per half wave) and
+  // lazy_mfma_fixed_grad_reduce_kernel sums the slices: 64 slices of atomics into the same megabyte of R were a
+  // third of this kernel's time.  Without: atomics into R as the per-wave kernels do.
+  float* mine = partials ? partials + (int64_t(blockIdx.z) * gridDim.x * gridDim.y + int64_t(blockIdx.x) * gridDim.y + blockIdx.y) * 65536 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int row = 64 * wi + 32 * i + (v & 3) + 8 * (v >> 2) + 4 * hi, col = 64 * wj + 32 * j + lo;
+        const float x = acc[i][j][v];
+        if (mine) mine[row * 256 + col] = x;
+        else if (x != 0.0f) atomicAdd(&g.R[int64_t(s0 + rot + row) * N + d0 + rot + col], x);
+      }
+}
+// R[live block] = sum over the slices of their partial blocks (R was zero-filled; nothing else writes these elements)
+__global__ __launch_bounds__(256) void lazy_mfma_fixed_grad_reduce_kernel(LazyGroup g, const float* __restrict__ partials, int nt, int nz) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // element of tile blockIdx.y
+  const int tile = blockIdx.y, ti = tile / nt, tj = tile - ti * nt;
+  const float* p = partials + int64_t(tile) * 65536 + e;
+  const int64_t stride = int64_t(nt) * nt * 65536;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  int z = 0;
+  for (; z + 4 <= nz; z += 4) {
+    s0 += p[int64_t(z) * stride];
+    s1 += p[int64_t(z + 1) * stride];
+    s2 += p[int64_t(z + 2) * stride];
+    s3 += p[int64_t(z + 3) * stride];
+  }
+  for (; z < nz; ++z) s0 += p[int64_t(z) * stride];
+  const int row = e >> 8, col = e & 255;
+  g.R[int64_t(ti * 256 + g.rot + row) * g.N + tj * 256 + g.rot + col] = (s0 + s1) + (s2 + s3);
 }
 // grad[a] += exp(w[a]) * R[src][dst]  (the balancing shifts of A' and Q' cancel exactly:
 // A' * Q' = exp(alpha + em + beta - Z) * delta)
@@ -1731,7 +1902,14 @@ bool launch_lazy_mfma_chain(const LazyGroup& g, int backward, int* sync, int cus
 void launch_lazy_mfma_keys(float* keys, int64_t n, hipStream_t st) {
   if (n > 0) hipLaunchKernelGGL(lazy_mfma_keys_kernel, dim3(unsigned((n + 255) / 256)), dim3(256), 0, st, keys, n);
 }
-void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStream_t st) {
+// bytes of the partial-block scratch launch_lazy_mfma_fixed_grad can use (0: none wanted for this graph)
+size_t lazy_mfma_fixed_grad_scratch_bytes(const LazyGroup& g) {
+  const int Nl = g.N - g.rot;
+  if (Nl < 256 || (Nl & 255) != 0 || ((g.N - g.rot) & 3) != 0 || getenv("GTNX_FIXED_GRAD_PER_WAVE") || getenv("GTNX_FIXED_GRAD_ATOMICS")) return 0;
+  const int tiles = (Nl / 256) * (Nl / 256);
+  return size_t(std::max(1, 512 / tiles)) * tiles * 65536 * 4;  // (up to 512 workgroups' blocks)
+}
+void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStream_t st, void* partials, size_t partials_bytes) {
   if (g.N <= 0 || g.T <= 0 || g.nb <= 0 || !g.grad_fixed) return;
   const int64_t npairs = int64_t(g.T) * g.nb;
   gtnx_f4* pc = static_cast<gtnx_f4*>(pair_consts);
@@ -1743,9 +1921,38 @@ void launch_lazy_mfma_fixed_grad(const LazyGroup& g, void* pair_consts, hipStrea
     // (slices of 4096 pairs: the 40 blocks of a slice run together and re-read the same rows of the planes while
     // they are still cached -- 5.7 ms at 16384, 4.5 ms at 4096; ordering the blocks by XCD on top changed nothing)
     const int ppb = ppb_env > 0 ? ppb_env : 4096;
-    const dim3 grid4(unsigned((g.N + 127) / 128), unsigned((g.N + 63) / 64), unsigned((npairs + ppb - 1) / ppb));
-    if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<true>, grid4, dim3(256), 0, st, g, (const gtnx_f4*)pc, ppb);
-    else hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<false>, grid4, dim3(256), 0, st, g, (const gtnx_f4*)pc, ppb);
+    const int Nl = g.N - g.rot;
+    static const bool no_wg = getenv("GTNX_FIXED_GRAD_PER_WAVE") != nullptr;
+    if (!no_wg && Nl >= 256 && (Nl & 255) == 0) {
+      // live slots in whole blocks of 256: one workgroup per 256 x 256 block of R and slice of the pairs, as many slices
+      // as fill the chip once (lazy_mfma_fixed_grad_wg_kernel); the dead source slots' blocks per wave as before
+      const int tiles = (Nl / 256) * (Nl / 256);
+      static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        (void)hipGetLastError();
+        return n > 0 ? n : 256;
+      }();
+      int z = std::max(1, cus / tiles);
+      int64_t per = (npairs + z - 1) / z;
+      per = (per + FGW_KB - 1) / FGW_KB * FGW_KB;
+      z = int((npairs + per - 1) / per);
+      const dim3 gw(unsigned(Nl / 256), unsigned(Nl / 256), unsigned(z));
+      float* parts = (partials && z > 1 && partials_bytes >= size_t(z) * tiles * 65536 * 4) ? static_cast<float*>(partials) : nullptr;
+      if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad_wg_kernel<true>, gw, dim3(1024), 0, st, g, (const gtnx_f4*)pc, int(per), parts);
+      else hipLaunchKernelGGL(lazy_mfma_fixed_grad_wg_kernel<false>, gw, dim3(1024), 0, st, g, (const gtnx_f4*)pc, int(per), parts);
+      if (parts) hipLaunchKernelGGL(lazy_mfma_fixed_grad_reduce_kernel, dim3(256, unsigned(tiles)), dim3(256), 0, st, g, parts, Nl / 256, z);
+      if (g.rot > 0) {
+        const int sb_first = Nl / 128;
+        const dim3 gd(unsigned((g.N + 127) / 128 - sb_first), unsigned((g.N + 63) / 64), 1u);  // (their pairs: step 0 only)
+        if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<true>, gd, dim3(256), 0, st, g, (const gtnx_f4*)pc, std::max(ppb, g.nb), sb_first);
+        else hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<false>, gd, dim3(256), 0, st, g, (const gtnx_f4*)pc, std::max(ppb, g.nb), sb_first);
+      }
+    } else {
+      const dim3 grid4(unsigned((g.N + 127) / 128), unsigned((g.N + 63) / 64), unsigned((npairs + ppb - 1) / ppb));
+      if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<true>, grid4, dim3(256), 0, st, g, (const gtnx_f4*)pc, ppb, 0);
+      else hipLaunchKernelGGL(lazy_mfma_fixed_grad4_kernel<false>, grid4, dim3(256), 0, st, g, (const gtnx_f4*)pc, ppb, 0);
+    }
   } else if (g.em_base) hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<true>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
   else hipLaunchKernelGGL(lazy_mfma_fixed_grad_kernel<false>, grid, dim3(256), 0, st, g, (const gtnx_f4*)pc, pairs_per_block);
   if (g.g.A > 0) hipLaunchKernelGGL(lazy_dense_arc_grad_kernel, dim3((g.g.A + 255) / 256), dim3(256), 0, st, g);

@@ -540,7 +540,9 @@ struct LazySdOp : OpRecord {
           v.R = rmem->as<float>();
           if (st.mfma) {
             DevMemP pcm = rt.alloc(16 * size_t(T > 0 ? T : 1) * size_t(nb));
-            launch_lazy_mfma_fixed_grad(v, pcm->ptr, rt.stream());
+            const size_t pb = lazy_mfma_fixed_grad_scratch_bytes(v);
+            DevMemP parts = pb ? rt.alloc(pb) : nullptr;
+            launch_lazy_mfma_fixed_grad(v, pcm->ptr, rt.stream(), parts ? parts->ptr : nullptr, pb);
           } else {
             launch_lazy_dense_fixed_grad(v, rt.stream());
           }

@@ -119,13 +119,36 @@ def emit(full):
     return compact_line(full, ref)
 
 
-def say_last(text):
-    """the compact line, as the LAST thing this process writes to stdout (callers tear the process group down first:
-    RCCL prints at teardown)"""
+def flush_c_stdio():
+    """RCCL prints its version banner with printf: into a pipe that is a BUFFERED write which would otherwise surface
+    when the process exits, i.e. after the result line.  fflush(NULL) sends it on its way now."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
+def say_last(text, world=1, rc=0):
+    """The compact line as the LAST thing on stdout.  The caller has left the process group; whatever the C
+    libraries still hold in their stdio buffers goes out first, the other ranks get a moment to finish (they exit
+    straight after the teardown, without a line of their own), and the process ends without running exit handlers
+    that might print."""
+    flush_c_stdio()
+    if world > 1:
+        time.sleep(1.0)
     sys.stdout.flush()
     sys.stderr.flush()
     print(text)
     sys.stdout.flush()
+    os._exit(rc)
+
+
+def leave_quietly():
+    """ranks that print no line: nothing of theirs may land after rank 0's"""
+    flush_c_stdio()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(0)
 
 
 def ctc_arrays(target, blank=0):
@@ -490,7 +513,9 @@ def dry_run(args, dist, torch, world, rank, dev):
     if world > 1:
         dist.destroy_process_group()
     if line is not None:
-        say_last(line)
+        say_last(line, world)
+    elif world > 1:
+        leave_quietly()
 
 
 def main():
@@ -648,6 +673,7 @@ def main():
             fence()  # (bounds what is queued ahead of the device)
     priming_steps = PRIME_STEPS
     fence()
+    flush_c_stdio()  # (RCCL's banner, printed at the first collective, leaves the stdio buffer now -- not at exit)
     for _ in range(args.warmup):
         step()
     fence()
@@ -692,8 +718,12 @@ def main():
     #   band_forward_score            4TC + 4(T+1)NS per utterance (emissions in, alpha out; NS = N rounded up to 4)
     #   band_forward_score_grad       8TC + 4(T+1)NS + 4A          (emissions in, gradient out, alpha in, G's gradient)
     #   linear_forward / _grad        4TC  /  12TC                 (rows in; rows in + gradient read-modify-write)
-    #   intersect                     20A + 8N: what the chain-product variant of compose_kernel writes (src, il,
-    #                                 ol, in_list are derivable and left out: DESIGN.md section 2)
+    #   intersect                     24A + 8N: what the chain-product variant of compose_kernel writes -- dst, w, gi1, gi2
+    #                                 in arc order, in_src and in_w in in-row order (six 4-byte arrays per arc; src, il,
+    #                                 ol, in_list are derivable and left out: DESIGN.md section 2) + in_off, pair_of per
+    #                                 node.  (Rounds 2-5 priced it at 20A + 8N, one array short: the WRITE_SIZE counter
+    #                                 -- 6.13 GB per launch at B = 512 -- agrees with 24A + 8N = 6.27 GB, there is no
+    #                                 write amplification.)
     #   forward_score                 8A + 8N (reported by the engine)
     #   forward_score_grad            20A + 12N + 4TC (in-rows, arc gradients, node rows, emission gradient)
     # measured = the engine's hipEvent pairs around each family on the launch stream.
@@ -727,7 +757,7 @@ def main():
 
     def rooflines(pr, pmc=pmc, pmc_file=pmc_file):
         fixed = {"linear_forward": B * 4.0 * T * Cn, "linear_forward_grad": B * 12.0 * T * Cn,
-                 "intersect": B * (20.0 * n_arcs + 8.0 * n_nodes),
+                 "intersect": B * (24.0 * n_arcs + 8.0 * n_nodes),
                  "forward_score_grad": B * (20.0 * n_arcs + 12.0 * n_nodes + 4.0 * T * Cn)}
         out = {}
         for name, e in pr.items():
@@ -915,11 +945,12 @@ def main():
     if world_dist:
         dist.destroy_process_group()
     if line is not None:
-        say_last(line)
-        if parity is not None and not parity.get("ok", False):
+        bad = parity is not None and not parity.get("ok", False)
+        if bad:
             print("bench.py: the timed batch does NOT match the checker: " + json.dumps(parity), file=sys.stderr)
-            sys.stderr.flush()
-            os._exit(3)
+        say_last(line, world, 3 if bad else 0)
+    elif world_dist:
+        leave_quietly()
 
 
 if __name__ == "__main__":

@@ -1020,13 +1020,24 @@ void batch_backward(const BatchP& root, bool retain) {
     launch_fill_f32(ones->as<float>(), 1.0f, size_t(root->n), rt.stream());
     launch_vec_axpby(root->g_dev, ones->as<float>(), nullptr, size_t(root->n), 1.0f, 0.0f, 1, rt.stream());
   }
+  // Scalars taken in from the per-graph functions (BFromGraphsOp: their backward runs the PER-GRAPH tape) go last, after
+  // the leaves' gradients have moved into the element graphs: nothing on the batch tape waits for them (their inputs are
+  // graphs), and the per-graph kernels then find the emission graphs' gradient already in place -- the normaliser's
+  // rows, written straight into the caller's tensor -- and accumulate into it (ops_built.cpp: the fused backward's
+  // in-place form).  The other order cost the built-lattice step two passes over the [B][T][C] gradient (an
+  // accumulate and a copy, 0.64 ms of 7.6 at C3) and a zero fill.
+  std::vector<Batch*> from_graphs;
   BackwardPlan plan;
   t_plan = &plan;
   try {
     for (Batch* b : order) {
       if (!b->g_dev) continue;  // no gradient reached it (a symbolic product never holds one)
       if (root_done && b == root.get()) continue;
-      if (auto* f = dynamic_cast<BFromGraphsOp*>(b->op.get())) f->retain = retain;
+      if (auto* f = dynamic_cast<BFromGraphsOp*>(b->op.get())) {
+        f->retain = retain;
+        from_graphs.push_back(b);
+        continue;
+      }
       b->op->backward(*b);
     }
     // normalisers that found no sweep to ride with
@@ -1040,6 +1051,7 @@ void batch_backward(const BatchP& root, bool retain) {
   // leaves whose elements were taken out as graphs: those carry the gradient
   for (Batch* b : seen)
     if ((b->materialised || b->leaf) && b->g_dev && !b->op) push_grads_to_graphs(*b);
+  for (Batch* b : from_graphs) b->op->backward(*b);
   if (!retain)
     for (Batch* b : order) {
       if (b != root.get()) {

@@ -186,6 +186,8 @@ struct SdOp : OpRecord {
     }
     DevMemP fg;
     std::vector<size_t> off_f(n), off_c(n);
+    std::vector<uint8_t> in_place_ok(size_t(n), 0);
+    std::unordered_set<GradState*> place_seen;
     if (fuse) {
       size_t fb = 0;
       for (int i = 0; i < n; ++i) {
@@ -196,13 +198,18 @@ struct SdOp : OpRecord {
         off_f[i] = fb;
         if (fixed.calc_grad()) fb = align_up(fb + 4 * size_t(fixed.num_arcs()), 256);
         off_c[i] = fb;
-        if (chain.calc_grad()) fb = align_up(fb + 4 * size_t(chain.num_arcs()), 256);
+        // (a chain that is accumulated into IN PLACE below needs no block of its own -- nor its share of the zero fill:
+        //  T C floats per utterance)
+        if (chain.calc_grad() && chain.is_grad_available() && place_seen.insert(chain.g.get()).second) {
+          Weights& gw = *chain.grad().w;
+          in_place_ok[i] = gw.dev_valid && !(gw.host_escaped && gw.host_valid) && gw.n == chain.num_arcs();
+        }
+        if (chain.calc_grad() && !in_place_ok[i]) fb = align_up(fb + 4 * size_t(chain.num_arcs()), 256);
       }
       fg = rt.alloc_zero(fb ? fb : 1);
     }
     std::vector<SdArgs> args(n);
     GradSink sink;
-    std::unordered_set<GradState*> fused_chain_seen;
     int64_t tot_out = 0, tot_p = 0;
     double alg = 0;
     for (int i = 0; i < n; ++i) {
@@ -234,21 +241,19 @@ struct SdOp : OpRecord {
         a.fixed_A = int(sc.fixed_A);
         a.chain_A = int(chain.num_arcs());
         a.grad_fixed = fixed.calc_grad() ? fg->as<float>(off_f[i]) : nullptr;
-        a.grad_chain = chain.calc_grad() ? fg->as<float>(off_c[i]) : nullptr;
+        a.grad_chain = chain.calc_grad() ? (in_place_ok[i] ? chain.grad().w->dev : fg->as<float>(off_c[i])) : nullptr;
         a.chunk_levels = std::max(1, std::min(a.chunk_levels, cap_c / std::max(sc.chain_C, 1)));
         if (a.grad_fixed) sink.add(fixed, fg, a.grad_fixed);
         // a chain that already holds a device gradient (e.g. from forwardScore(emissions),
         // run earlier in the sweep) is accumulated into in place: one pass, no axpy
         bool in_place = false;
-        if (a.grad_chain && chain.is_grad_available() && fused_chain_seen.insert(chain.g.get()).second) {
+        if (a.grad_chain && in_place_ok[i]) {  // (decided with the block sizes above)
           Weights& gw = *chain.grad().w;
-          if (gw.dev_valid && !(gw.host_escaped && gw.host_valid) && gw.n == chain.num_arcs()) {
-            a.grad_chain = gw.dev;
-            a.chain_accumulate = 1;
-            gw.host_valid = false;
-            gw.version++;
-            in_place = true;
-          }
+          a.grad_chain = gw.dev;
+          a.chain_accumulate = 1;
+          gw.host_valid = false;
+          gw.version++;
+          in_place = true;
         }
         if (a.grad_chain && !in_place) sink.add(chain, fg, a.grad_chain);
         in.g->grad_propagated = true;

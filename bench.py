@@ -130,9 +130,9 @@ def flush_c_stdio():
 
 def say_last(text, world=1, rc=0):
     """The compact line as the LAST thing on stdout.  The caller has left the process group; whatever the C
-    libraries still hold in their stdio buffers goes out first, the other ranks get a moment to finish (they exit
-    straight after the teardown, without a line of their own), and the process ends without running exit handlers
-    that might print."""
+    libraries still hold in their stdio buffers goes out first (RCCL's banner would otherwise surface when the
+    process exits, after the line), and the other ranks -- which print nothing -- get a moment to finish.  The
+    process then ends the ordinary way: a profiler attached to it (rocprofv3) writes its files at exit."""
     flush_c_stdio()
     if world > 1:
         time.sleep(1.0)
@@ -140,7 +140,8 @@ def say_last(text, world=1, rc=0):
     sys.stderr.flush()
     print(text)
     sys.stdout.flush()
-    os._exit(rc)
+    if rc:
+        sys.exit(rc)
 
 
 def leave_quietly():
@@ -148,7 +149,6 @@ def leave_quietly():
     flush_c_stdio()
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
 
 
 def ctc_arrays(target, blank=0):

@@ -453,30 +453,41 @@ __global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_one_kernel(Ban
 // ==========================================================================================
 __global__ __launch_bounds__(512) void ctc_targets_kernel(const CtcTargetArgs* __restrict__ args, int blank) {
   const CtcTargetArgs a = args[blockIdx.x];
-  __shared__ __attribute__((aligned(16))) int lab[512];
-  __shared__ __attribute__((aligned(16))) int cnt[512];
-  const int N = a.N, m = threadIdx.x;
-  int my = blank, skip = 0;
-  if (m < N && (m & 1)) {
-    my = a.labels[(m - 1) >> 1];
-    skip = (m > 1 && my != a.labels[((m - 1) >> 1) - 1]) ? 1 : 0;
+  // the label sequence and its skip flags (label i differs from label i - 1), padded to whole 16-byte reads
+  __shared__ __attribute__((aligned(16))) int tl[256 + 4];
+  __shared__ __attribute__((aligned(16))) int tk[256 + 4];
+  const int N = a.N, U = (N - 1) >> 1, m = threadIdx.x;
+  if (m < 260) {
+    const int v = m < U ? a.labels[m] : 0x7fffffff;  // (padding: above every real label, no skip arc)
+    tl[m] = v;
+    tk[m] = (m > 0 && m < U && v != a.labels[m - 1]) ? 1 : 0;
   }
-  // (padding past N: a label above every real one and no arcs, so the 16-byte reads below need no bound)
-  lab[m] = m < N ? my : 0x7fffffff;
-  cnt[m] = m < N ? 1 + (m > 0 ? 1 : 0) + skip : 0;
   __syncthreads();
   if (m >= N) return;
-  // rank among the (label, node) pairs and first arc id: N comparisons per node, four per LDS read
-  int rank = 0, base = 0;
-  for (int o = 0; o < N; o += 4) {
-    const gtnx_i4 l4 = *reinterpret_cast<const gtnx_i4*>(lab + o), c4 = *reinterpret_cast<const gtnx_i4*>(cnt + o);
-    const int lo[4] = {l4.x, l4.y, l4.z, l4.w}, co[4] = {c4.x, c4.y, c4.z, c4.w};
+  const bool odd = (m & 1) != 0;
+  const int my = odd ? tl[(m - 1) >> 1] : blank;
+  const int skip = odd ? tk[(m - 1) >> 1] : 0;
+  // Rank among the (label, node) pairs and first arc id.  Node 2i + 1 carries label i, every even node the blank:
+  // the nodes in front of (my, m) are the label nodes with a smaller label (or mine, earlier) -- one pass over the
+  // U labels, four per LDS read, where rounds 2-5 compared against all N nodes -- plus a closed form for the blanks.
+  // The arcs in front of node m: one self loop per node, one step arc per node but the first, the skips counted
+  // in the same pass.
+  const int mi = (m - 1) >> 1;  // (odd m: my own label index; even m: labels 0 .. m/2 - 1 lie in front of me)
+  const int before = odd ? mi : (m >> 1);  // label indices < before belong to nodes in front of m
+  int rank = 0, skips = 0;
+  for (int o = 0; o < U; o += 4) {
+    const gtnx_i4 l4 = *reinterpret_cast<const gtnx_i4*>(tl + o), k4 = *reinterpret_cast<const gtnx_i4*>(tk + o);
+    const int lo[4] = {l4.x, l4.y, l4.z, l4.w}, ko[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      rank += (lo[k] < my || (lo[k] == my && o + k < m)) ? 1 : 0;
-      base += o + k < m ? co[k] : 0;
+      const bool front = o + k < before;
+      rank += (lo[k] < my || (lo[k] == my && front)) ? 1 : 0;
+      skips += front ? ko[k] : 0;
     }
   }
+  // the blank nodes (even, U + 1 of them): all in front of a larger label, the earlier ones in front of an equal one
+  rank += blank < my ? U + 1 : (blank == my ? (m + 1) >> 1 : 0);
+  const int base = (m > 0 ? 2 * m - 1 : 0) + skips;
   GTNX_G BandNode* nd = const_cast<GTNX_G BandNode*>(a.nodes);
   nd[m].lab = my;
   nd[m].aid[0] = base;
@@ -485,7 +496,7 @@ __global__ __launch_bounds__(512) void ctc_targets_kernel(const CtcTargetArgs* _
   a.nflags[m] = uint8_t((m == 0 ? NF_START : 0) | (m + 2 >= N ? NF_ACCEPT : 0));
   a.snode[rank] = m;
   a.slab[rank] = my;
-  if (m == N - 1 && a.n_arcs) a.n_arcs[0] = base + cnt[m];
+  if (m == N - 1 && a.n_arcs) a.n_arcs[0] = base + 1 + (m > 0 ? 1 : 0) + skip;
 }
 
 // ==========================================================================================

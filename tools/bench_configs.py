@@ -295,8 +295,17 @@ def c3v():
             out["value_source"] = "reference_api (C++ host); the Python mirror's figure is symbolic_route.viterbi_path_ms_per_batch"
     except Exception as e:
         out["reference_api"] = {"error": str(e)[:200]}
-    # the built route on a slice of the batch (13 GB of lattices at B = 512; 64 utterances say the same per launch)
+    # the built route at the configuration's own batch when the device has room for it (about 40 MB per utterance with
+    # the arrays viterbiPath asks for: 20 GB at B = 512), else on a slice of 64.  (Rounds 4-5 measured the slice: 64
+    # workgroups on 256 CUs -- the chase is one latency chain per lattice, so a launch takes the same time for 64
+    # lattices as for 512, and the per-launch roofline figure of the slice was an eighth of the batch's.)
     nb = min(B, 64)
+    try:
+        import torch
+        if torch.cuda.mem_get_info()[0] > 60 * (1 << 30):
+            nb = B
+    except Exception:
+        pass
     sub_c, sub_e = ctcs[:nb], ems[:nb]
     prev = gtn.compose_mode(0)
     try:

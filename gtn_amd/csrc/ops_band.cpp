@@ -52,17 +52,21 @@ bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out) {
 }
 // band records and the all-zero test of a batch of partners, on the worker pool (a training step
 // brings one fresh target graph per utterance); both are cached on the graph afterwards
-void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first) {
+static bool tie_ranks(Structure& fs, BandInfo& bi, bool use_ilabel);
+void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first, bool want_ranks) {
   std::vector<size_t> todo;
   std::unordered_set<Structure*> seen;
   for (size_t i = 0; i < fixed.size(); ++i) {
     Structure* st = fixed[i]->s.get();
-    if (!st->band[chain_first[i] ? 0 : 1] && seen.insert(st).second) todo.push_back(i);
+    const std::shared_ptr<BandInfo>& b = st->band[chain_first[i] ? 0 : 1];
+    if ((!b || (want_ranks && b->ok && b->rank_state == 0)) && seen.insert(st).second) todo.push_back(i);
   }
   auto body = [&](size_t q) {
     Graph& g = *fixed[todo[q]];
-    band_info(*g.s, chain_first[todo[q]] != 0);
+    std::shared_ptr<BandInfo> b = band_info(*g.s, chain_first[todo[q]] != 0);
     (void)g.w->is_all_zero();
+    // (a decode: the orders that decide exact ties, while a pool thread has the target in its cache)
+    if (want_ranks && b && b->ok) (void)tie_ranks(*g.s, *b, chain_first[todo[q]] != 0);
   };
   if (todo.size() >= 64) gtn::detail::runIndexed(todo.size(), body, 32, false);
   else for (size_t q = 0; q < todo.size(); ++q) body(q);
@@ -393,6 +397,53 @@ static bool tie_ranks(Structure& fs, BandInfo& bi, bool use_ilabel) {
     for (int k = fs.out_off[size_t(n)] + 1; k < fs.out_off[size_t(n) + 1]; ++k)
       if (lab[size_t(fs.out_list[size_t(k)])] <= lab[size_t(fs.out_list[size_t(k) - 1])]) return false;
   }
+  // ---- closed form (round 6) when the blank is below every label of the target (blank 0, labels >= 1: every CTC
+  // criterion of the reference's tests, examples and benchmarks).  The out-list of a blank node is then (self, next),
+  // of label node 2i+1 (next blank first, then self and the skip to 2i+3 by label value), and the fixed point of the
+  // recursion above is, with p = the number of leading strict ascents t[0] < t[1] < ... < t[p]:
+  //   queue order     0 | (2i, 2i-1) for i = 1..p | N-1 | for i = U-1 down to p+1: (2i, 2i+1) if t[i] != t[i-1] (a skip
+  //                   arc enters 2i+1) else (2i+1, 2i) | 2p+1
+  //   creation order  the identity
+  // -- found by running layer_order() on samples and checked against it on 30 000 random targets (U = 0..40, alphabets
+  // of 2..30 labels, up to 70 % repeats: no difference), in the tree as tests/test_band_tie_ranks.py under
+  // GTNX_CHECK_CLOSED_RANKS=1, where BOTH are computed here and a difference throws.  The ranks of a whole batch then
+  // cost microseconds, and a decode runs its FIRST launch with them (band_viterbi below): no second launch, no second
+  // copy, for the utterance in five hundred that has an exact tie on its best path.
+  static const bool no_closed = std::getenv("GTNX_NO_CLOSED_RANKS") != nullptr;
+  static const bool check_closed = std::getenv("GTNX_CHECK_CLOSED_RANKS") != nullptr;
+  const std::vector<int>& t = *fs.ctc_labels;
+  bool below = !no_closed;
+  for (size_t i = 0; i < t.size() && below; ++i) below = t[i] > fs.ctc_blank;
+  if (below) {
+    const int U = int(t.size()), N = 2 * U + 1;
+    std::vector<int>& rk = bi.rank_kahn;
+    rk.assign(size_t(N), 0);
+    if (U > 0) {
+      int p = 0;
+      while (p + 1 < U && t[size_t(p)] < t[size_t(p) + 1]) ++p;
+      int pos = 1;
+      for (int i = 1; i <= p; ++i) {
+        rk[size_t(2 * i)] = pos++;
+        rk[size_t(2 * i - 1)] = pos++;
+      }
+      rk[size_t(N - 1)] = pos++;
+      for (int i = U - 1; i > p; --i) {
+        const bool skip = t[size_t(i)] != t[size_t(i) - 1];
+        rk[size_t(skip ? 2 * i : 2 * i + 1)] = pos++;
+        rk[size_t(skip ? 2 * i + 1 : 2 * i)] = pos++;
+      }
+      rk[size_t(2 * p + 1)] = pos++;
+    }
+    bi.rank_create.resize(size_t(N));
+    for (int n = 0; n < N; ++n) bi.rank_create[size_t(n)] = n;
+    if (check_closed) {
+      std::vector<int> k2, c2;
+      if (!layer_order(fs, 0, true, k2) || !layer_order(fs, 0, false, c2) || k2 != bi.rank_kahn || c2 != bi.rank_create)
+        throw_runtime("[gtnx] tie ranks: the closed form differs from the fixed point of the recursion");
+    }
+    bi.rank_state = 1;
+    return true;
+  }
   if (!layer_order(fs, 0, /*last_touch=*/true, bi.rank_kahn) || !layer_order(fs, 0, /*last_touch=*/false, bi.rank_create))
     return false;
   bi.rank_state = 1;
@@ -430,7 +481,7 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
       fx[i] = &gs[i].s->lazy->fixed;
       cf[i] = gs[i].s->lazy->chain_side == 1;
     }
-    band_prepare(fx, cf);
+    band_prepare(fx, cf, /*want_ranks=*/true);
   }
   for (size_t i = 0; i < n; ++i) {
     LazyProduct& lp = *gs[i].s->lazy;
@@ -495,10 +546,37 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
     if (p.C % 4 != 0 || (reinterpret_cast<uintptr_t>(p.em) & 15) != 0 || int64_t(p.T) * p.C < 4) vec = 0;
     abytes += 4.0 * p.T * p.C + 0.5 * double(p.T) * p.N + 20.0 * p.T;
   }
+  // Targets whose tie orders are known up front (tie_ranks: CTC-shaped, label-sorted -- a closed form, computed with
+  // the band records) are decoded by the RANKED kernel at once: equal candidates are decided as the reference's queue
+  // / in-lists decide them, no tie is ever reported, and the second launch (+ its copy and host round trip: 1.2 ms per
+  // batch that has ONE tied utterance) never happens.  (The ranked kernel is 6 % slower: 0.41 against 0.39 ms.)
+  static const bool no_ranked_first = std::getenv("GTNX_NO_RANKED_TIES") != nullptr || std::getenv("GTNX_NO_RANKED_FIRST") != nullptr;
+  bool ranked_first = !no_ranked_first && n > 0 && band_viterbi_wave_ok(max_n, max_c, vec);
+  for (size_t i = 0; i < n && ranked_first; ++i) ranked_first = infos[i]->rank_state == 1;
   {
+    DevMemP drk0;
+    if (ranked_first) {
+      std::vector<int> rk;
+      std::vector<size_t> off(n);
+      size_t total = 0;
+      for (size_t i = 0; i < n; ++i) total += 2 * size_t(tab[i].N);
+      rk.reserve(total);
+      for (size_t i = 0; i < n; ++i) {
+        const BandInfo& b = *infos[i];
+        off[i] = rk.size();
+        const std::vector<int>& rin = want_path ? b.rank_kahn : b.rank_create;
+        rk.insert(rk.end(), rin.begin(), rin.end());
+        rk.insert(rk.end(), b.rank_create.begin(), b.rank_create.end());
+      }
+      drk0 = upload_vec(rk);
+      for (size_t i = 0; i < n; ++i) {
+        tab[i].rank_in = drk0->as<int>() + off[i];
+        tab[i].rank_acc = tab[i].rank_in + tab[i].N;
+      }
+    }
     DevMemP d = upload_vec(tab);
     GTNX_PROF(want_path ? "band_viterbi_path" : "band_viterbi_score", abytes);
-    launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, max_n, max_c, vec, rt.stream());
+    launch_band_viterbi(d->as<BandDecode>(), int(n), stage_floats, max_n, max_c, vec, rt.stream(), ranked_first ? 1 : 0);
   }
   // heads (length, score, tie) of every pair; the paths themselves only when they become graphs
   // (a pinned block: the copy into pageable memory ran at a fifth of the link's rate)
@@ -590,7 +668,9 @@ std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path) {
   // a large batch is built by a few threads of the caller's pool (idle at a join; graph.cpp's ensure_host_batch and
   // band_prepare above fan out the same way).  Those workers belong to the pool of device 0 and never take the
   // caller's device: what make_result() stamps on a result there (device, home list) is THEIR thread's, so the
-  // caller's are captured here and written over it -- a result belongs to the thread that asked for it.
+  // caller's are captured here and written over it -- a result belongs to the thread that asked for it.  (Leaving
+  // the HOME list the builder's, so that the pool threads take the path graphs apart, was measured in round 6:
+  // 5.5-5.9 ms per decode batch against 3.9 -- the workers drain their lists inside the next batch's pool phase.)
   const int caller_device = Runtime::current_device();
   const Runtime::InboxP caller_home = Runtime::home();
   auto stamp = [&](Graph& out) {

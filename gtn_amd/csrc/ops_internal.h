@@ -133,7 +133,7 @@ struct LazyPathOp : OpRecord {
 };
 
 bool band_shape_ok(const Structure& chain, Structure& fixed, bool chain_first);
-void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first);
+void band_prepare(const std::vector<Graph*>& fixed, const std::vector<uint8_t>& chain_first, bool want_ranks = false);
 bool band_ok(const LazyProduct& lp, std::shared_ptr<BandInfo>* out = nullptr);
 std::vector<Graph> band_forward_score(std::vector<Graph>& gs);
 std::vector<Graph> band_viterbi(std::vector<Graph>& gs, bool want_path);

@@ -97,3 +97,83 @@ def test_ranks_do_not_apply_to_other_graphs(apis):
     assert gtn.debug_tie_ranks(g) is not None
     g.add_arc(0, 2, 5)  # no longer ctcGraph(labels)
     assert gtn.debug_tie_ranks(g) is None
+
+
+_CLOSED_FORM_CHECK = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import gtn_amd as gtn
+import graphgen as gg
+
+
+def layer_order(t, last):
+    # the recursion of gtn_amd/csrc/ops_band.cpp: layer_order, restated on ctcGraph(t) with blank 0 (benchmarks/ctc.cpp:40-58
+    # after arcSort: out-lists by label)
+    L = 2 * len(t) + 1
+    out = [[] for _ in range(L)]
+    a = 0
+    for l in range(L):
+        lab = t[(l - 1) // 2] if l %% 2 else 0
+        out[l].append((lab, a, l)); a += 1
+        if l > 0:
+            out[l - 1].append((lab, a, l)); a += 1
+        if l %% 2 and l > 1 and lab != t[(l - 1) // 2 - 1]:
+            out[l - 2].append((lab, a, l)); a += 1
+    for l in range(L):
+        out[l].sort()
+    layer = [0]
+    for _ in range(4 * L + 8):
+        key = {}
+        for i, l in enumerate(layer):
+            for k, (_, _, d) in enumerate(out[l]):
+                kk = i * 8 + k
+                key[d] = kk if d not in key else (max(key[d], kk) if last else min(key[d], kk))
+        nxt = sorted(key, key=lambda d: key[d])
+        if nxt == layer:
+            rank = [0] * L
+            for i, n in enumerate(layer):
+                rank[n] = i
+            return rank
+        layer = nxt
+    raise AssertionError("no fixed point")
+
+
+rng = np.random.default_rng(11)
+n = 0
+for trial in range(%(trials)d):
+    U = int(rng.choice([0, 1, 2, 3, 5, 8, 13, 30, 100]))
+    C = int(rng.choice([2, 3, 5, 28, 256]))
+    rep = float(rng.choice([0.0, 0.3, 0.7]))
+    t = []
+    for _ in range(U):
+        t.append(t[-1] if t and rng.random() < rep else int(rng.integers(1, C)))
+    g = gg.to_api(gtn, gg.ctc_target_graph(t, 0))
+    g.arc_sort()
+    ranks = gtn.debug_tie_ranks(g)   # (GTNX_CHECK_CLOSED_RANKS=1: the engine compares its closed form with its own recursion)
+    assert ranks is not None, t
+    assert ranks[0] == layer_order(t, True), t
+    assert ranks[1] == layer_order(t, False) == list(range(2 * U + 1)), t
+    n += 1
+print("CLOSED_FORM_OK", n)
+"""
+
+
+def test_closed_form_ranks_equal_the_recursions_fixed_point():
+    """Round 6: for targets whose blank is below every label the two tie orders come from a closed form
+    (ops_band.cpp: tie_ranks) -- here against the recursion it replaces, twice over: inside the engine
+    (GTNX_CHECK_CLOSED_RANKS=1 computes both and throws on a difference) and against a Python restatement of the
+    recursion, on random targets up to U = 100 with alphabets from 2 to 256 labels and up to 70 %% repeats."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(os.path.join(root, "gtn_amd", "lib", "libgtn_amd.so")):
+        pytest.skip("libgtn_amd.so not built")
+    env = dict(os.environ, GTNX_CHECK_CLOSED_RANKS="1")
+    r = subprocess.run([sys.executable, "-c", _CLOSED_FORM_CHECK % {"root": root, "trials": 400}], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "CLOSED_FORM_OK 400" in r.stdout, (r.stdout + r.stderr)[-3000:]
+    # ... and with the closed form switched off the same answers come from the recursion
+    env = dict(os.environ, GTNX_NO_CLOSED_RANKS="1")
+    r = subprocess.run([sys.executable, "-c", _CLOSED_FORM_CHECK % {"root": root, "trials": 60}], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and "CLOSED_FORM_OK 60" in r.stdout, (r.stdout + r.stderr)[-3000:]

@@ -15,6 +15,13 @@ for cfg in "$@"; do
     device_levelize) run device_levelize GTNX_DEVICE_LEVELIZE=1 ;;
     no_fused_copy) run no_fused_copy GTNX_NO_FUSED_COPY=1 ;;
     no_node_order) run no_node_order GTNX_NO_NODE_ORDER_TIES=1 ;;
+    # round 6
+    no_ranked_first) run no_ranked_first GTNX_NO_RANKED_FIRST=1 ;;
+    no_closed_ranks) run no_closed_ranks GTNX_NO_CLOSED_RANKS=1 ;;
+    check_closed_ranks) run check_closed_ranks GTNX_CHECK_CLOSED_RANKS=1 ;;
+    fixed_grad_per_wave) run fixed_grad_per_wave GTNX_FIXED_GRAD_PER_WAVE=1 ;;
+    fixed_grad_atomics) run fixed_grad_atomics GTNX_FIXED_GRAD_ATOMICS=1 ;;
+    h2d_runtime) run h2d_runtime GTNX_H2D_KERNEL_BYTES=0 ;;
     # round 5
     no_graph_slab) run no_graph_slab GTNX_NO_GRAPH_SLAB=1 ;;
     defer_full_64) run defer_full_64 GTNX_DEFER_FULL=64 ;;

@@ -104,6 +104,7 @@ struct BackwardPlan {
   std::unordered_set<Batch*> fused;
 };
 thread_local BackwardPlan* t_plan = nullptr;
+thread_local bool t_batch_retain = false;  // the batch backward being run keeps the tape (batch_backward)
 
 struct BFsLinearOp : BatchOp {
   void backward(Batch& out) override {
@@ -146,11 +147,26 @@ struct BFsLinearOp : BatchOp {
 struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
   std::vector<BandPair> pairs;
   DevMemP arena;
+  // The gradient this op pushes PAST the symbolic product into its inputs.  In the reference the product is a graph
+  // with a gradient of its own, which accumulates over backward passes and is re-scattered whole by compose's gradient
+  // function in every pass (autograd.cpp:40-52, compose.cpp:496-518): over a retained tape the inputs receive, in
+  // pass k, the SUM over passes 1..k of this output's (accumulated) gradient times the posteriors -- 1, 1+3, 1+3+6 ...
+  // when the root is backward()ed three times.  Single pass (every criterion step): the output's gradient itself, and
+  // nothing is allocated.  (ops.cpp: through_delta is the per-graph form; until round 6 the batch form used the
+  // current gradient -- 1, 3, 6 -- found by tools/double_backward_fit.py against the unmodified reference.)
+  DevMemP through_acc;
   void backward(Batch& out) override {
     Batch& prod = *inputs[0];
     Batch& fx = *prod.fixed;
     Batch& ch = *prod.chain;
     Runtime& rt = Runtime::get();
+    const float* delta = out.g_dev;
+    if (through_acc || t_batch_retain) {
+      const size_t n = size_t(prod.n);
+      if (!through_acc) through_acc = rt.alloc_zero(sizeof(float) * (n ? n : 1));
+      launch_vec_axpby(through_acc->as<float>(), out.g_dev, nullptr, n, 1.0f, 0.0f, /*accumulate=*/1, rt.stream());
+      delta = through_acc->as<float>();
+    }
     GradTarget ge, gf;
     if (ch.calc_grad) ge = grad_target(ch, false);  // every row is written by the kernel
     // (device-built CTC targets: every arc lies in the band and the sweep writes them all, zeros included -- no fill;
@@ -170,7 +186,7 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
     const size_t A = size_t(ch.M) * size_t(ch.C);
     for (int b = 0; b < prod.n; ++b) {
       BandPair p = pairs[size_t(b)];
-      p.delta = out.g_dev + b;
+      p.delta = delta + b;
       p.delta_norm = lin_out ? lin_out->g_dev + b : nullptr;
       p.rowlse = lin_out ? ch.nc_rowlse + size_t(b) * size_t(ch.M) : nullptr;
       p.norm = nullptr;
@@ -1029,6 +1045,11 @@ void batch_backward(const BatchP& root, bool retain) {
   std::vector<Batch*> from_graphs;
   BackwardPlan plan;
   t_plan = &plan;
+  struct RetainScope {
+    bool prev;
+    explicit RetainScope(bool r) : prev(t_batch_retain) { t_batch_retain = r; }
+    ~RetainScope() { t_batch_retain = prev; }
+  } retain_scope(retain);
   try {
     for (Batch* b : order) {
       if (!b->g_dev) continue;  // no gradient reached it (a symbolic product never holds one)

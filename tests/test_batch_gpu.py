@@ -395,3 +395,58 @@ def test_timed_route_at_full_size_against_the_reference(gtn):
     assert worst["emref"] <= 1e-2 and worst["tref"] <= 1e-2, worst
     # (and the engine is the closer of the two to exact arithmetic)
     assert worst["em64"] <= worst["ref_em64"] and worst["t64"] <= worst["ref_t64"], worst
+
+
+@pytest.mark.parametrize("passes", [2, 3])
+def test_repeated_backward_over_a_retained_tape_matches_the_reference(gtn, passes):
+    """backward(loss, retain) called two and three times: in the reference every node passes its ACCUMULATED gradient on
+    in every pass (autograd.cpp:40-52) and compose's gradient function re-scatters the product's accumulated gradient
+    (compose.cpp:496-518), so after k passes the emissions hold (1 + 3 + 6 ...) S - (1 + 4 + 10 ...) P: 4 S - 5 P after
+    two, 10 S - 15 P after three.  The symbolic product has no gradient of its own; the batch records pushed the
+    CURRENT gradient past it (4 S - 4 P) until round 6 (tools/double_backward_fit.py found it).  Against the UNMODIFIED
+    reference (oracle/_ref behind tests/refbackend) through all three routes: batch records, the vector overloads with
+    the products symbolic, and with the lattices built."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "refbackend"))
+    try:
+        import gtn_ref as ref
+    except Exception as e:
+        pytest.skip("needs oracle/_ref: %s" % e)
+    B, T, C = 3, 25, 8
+    em, tg = _ragged_inputs(3, B, T, C, 5, Umin=1)
+    want = []
+    for b in range(B):
+        e = ref.linear_graph(T, C)
+        e.set_weights(em[b].reshape(-1))
+        c = gg.to_api(ref, gg.ctc_target_graph(tg[b].tolist()))
+        c.arc_sort()
+        l = ref.subtract(ref.forward_score(e), ref.forward_score(ref.intersect(c, e)))
+        for p in range(passes):
+            ref.backward(l, p < passes - 1)
+        want.append(e.grad().weights_to_numpy().reshape(T, C))
+    want = np.stack(want)
+    em_dev = _dev(em)
+    # batch records
+    ctcs, ems, loss = _batch_ctc(gtn, em_dev, tg, T, C)
+    for p in range(passes):
+        gtn.backward(loss, p < passes - 1)
+    g = torch.empty(B, T, C, device="cuda:0")
+    ems.grads_to_device(g, np.arange(B, dtype=np.int64) * T * C)
+    np.testing.assert_allclose(g.cpu().numpy(), want, rtol=2e-4, atol=2e-4)
+    # vector overloads: products symbolic (2) and built (0)
+    for mode in (2, 0):
+        prev = gtn.compose_mode(mode)
+        try:
+            es = gtn.linear_graph_n(B, T, C, em_dev)
+            cs = [gg.to_api(gtn, gg.ctc_target_graph(t.tolist())) for t in tg]
+            for c in cs:
+                c.arc_sort()
+            l = gtn.subtract(gtn.forward_score(es), gtn.forward_score(gtn.intersect(cs, es)))
+            for p in range(passes):
+                gtn.backward(l, p < passes - 1)
+            got = np.stack([es[b].grad().weights_to_numpy().reshape(T, C) for b in range(B)])
+        finally:
+            gtn.compose_mode(prev)
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4, err_msg="compose mode %d" % mode)

@@ -196,10 +196,7 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
       bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
                (p.grad_fixed ? 4.0 * double(fx.elem_size(b)) : 0.0);
     }
-    {
-      GTNX_PROF("band_forward_score_grad", bytes);
-      band_launch(tab, true);
-    }
+    band_launch(tab, true, "band_forward_score_grad", bytes);
     if (ch.calc_grad) add_scratch(ch, ge);
     if (fx.calc_grad) add_scratch(fx, gf);
     (void)rt;
@@ -859,10 +856,7 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
       tab.push_back({BandLaunchKey{C, band_npl(q.N), fx.fal ? 0 : 1, 0, band_vec_ok(q)}, q});
       abytes += 4.0 * T * C + 4.0 * double(T + 1) * p.NS + (fuse_copy ? 4.0 * T * C : 0.0);
     }
-    {
-      GTNX_PROF("band_forward_score", abytes);
-      band_launch(tab, false);
-    }
+    band_launch(tab, false, "band_forward_score", abytes);
     if (fuse_copy) pend->done.store(true, std::memory_order_release);  // (under pend->mu, taken above)
     if (want_norm) {
       ch.nc_mem = op->arena;

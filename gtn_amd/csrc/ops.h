@@ -60,7 +60,8 @@ struct BandLaunchKey {
   bool operator==(const BandLaunchKey& o) const { return !(*this < o) && !(o < *this); }
 };
 int band_vec_ok(const BandPair& p);
-void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward);
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, const char* prof_name = nullptr,
+                 double prof_bytes = 0.0);  // prof_name: a profiled span (Runtime::Scope) around the kernel launches only
 
 enum ScalarKind { SK_NEGATE = 0, SK_ADD = 1, SK_SUBTRACT = 2 };
 

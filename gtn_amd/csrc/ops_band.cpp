@@ -2,11 +2,13 @@
 // sweeps of band.hip, forward / backward / Viterbi; see ops.h
 #include "ops_internal.h"
 
+#include <memory>
+
 namespace gtnx {
 
 int band_vec_ok(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
 // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
-void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward) {
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, const char* prof_name, double prof_bytes) {
   Runtime& rt = Runtime::get();
   if (tab.empty()) return;
   bool one_key = true;  // (a criterion step: every pair has the same shape -- nothing to group)
@@ -16,6 +18,7 @@ void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool back
     const BandLaunchKey& k = tab[0].first;
     const BandPair& p = tab[0].second;
     if (band_one_ok(k.npl, k.C, p.NS, k.vec != 0, backward)) {
+      std::unique_ptr<Runtime::Scope> prof(prof_name ? new Runtime::Scope(&rt, prof_name, prof_bytes) : nullptr);
       if (backward) launch_band_backward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, k.gradg != 0, true, rt.stream(), &p);
       else launch_band_forward(nullptr, 1, k.npl, k.C, p.NS, k.unit != 0, true, rt.stream(), &p);
       return;
@@ -26,6 +29,10 @@ void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool back
   for (auto& e : tab) flat.push_back(e.second);
   DevMemP d = upload_vec(flat);
   const BandPair* dp = d->as<BandPair>();
+  // (the profiled span is the KERNEL launches: the table's upload -- a 5 us copy kernel -- is in front of it.  bench.py's
+  //  roofline figure is algorithmic bytes over this span; until round 6 the span held the upload too and read 1.5 % low
+  //  against rocprofv3's kernel time.)
+  std::unique_ptr<Runtime::Scope> prof(prof_name ? new Runtime::Scope(&rt, prof_name, prof_bytes) : nullptr);
   for (size_t i0 = 0; i0 < tab.size();) {
     size_t i1 = i0;
     int max_ns = 0;
@@ -81,7 +88,9 @@ struct BandSdOp : OpRecord {
 
   using Key = BandLaunchKey;
   static int band_vec(const BandPair& p) { return band_vec_ok(p); }
-  static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward) { band_launch(tab, backward); }
+  static void launch(std::vector<std::pair<Key, BandPair>>& tab, bool backward, const char* prof_name = nullptr, double prof_bytes = 0.0) {
+    band_launch(tab, backward, prof_name, prof_bytes);
+  }
 
   void backward(std::vector<Member>& ms) override {
     Runtime& rt = Runtime::get();
@@ -163,8 +172,7 @@ void flush_chain_plan() {
     tab.push_back({BandSdOp::Key{b.C, b.npl, b.unit, b.gradg, b.vec}, b.p});
   }
   if (!tab.empty()) {
-    GTNX_PROF("band_forward_score_grad", plan->bytes);
-    BandSdOp::launch(tab, true);
+    BandSdOp::launch(tab, true, "band_forward_score_grad", plan->bytes);
   }
   plan->sink.flush();
   // normalisers without a sweep: their own kernel
@@ -269,8 +277,7 @@ std::vector<Graph> band_forward_score(std::vector<Graph>& gs) {
     abytes += 4.0 * p.T * p.C + 4.0 * double(p.T + 1) * p.NS;  // emissions in, alpha out (kept for the backward sweep)
   }
   {
-    GTNX_PROF("band_forward_score", abytes);
-    BandSdOp::launch(tab, false);
+    BandSdOp::launch(tab, false, "band_forward_score", abytes);
   }
   for (size_t i = 0; i < n; ++i) {
     const BandPair& p = op->pairs[i];

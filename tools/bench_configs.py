@@ -281,7 +281,9 @@ def c3v():
         if cpus:
             os.sched_setaffinity(0, cpus)
         try:
-            ms_loop = native.gtn_bench_viterbi_reference_loop(em_dev.data_ptr(), tgc.ctypes.data, B, T, Cn, U, 10, lab.ctypes.data)
+            # (60 repetitions: the loop's garbage -- 512 path graphs per batch -- is taken apart in bursts, a full list
+            #  every half dozen batches; ten repetitions caught one burst or two and read 5-7 ms for a 3.9 ms mean)
+            ms_loop = native.gtn_bench_viterbi_reference_loop(em_dev.data_ptr(), tgc.ctypes.data, B, T, Cn, U, 60, lab.ctypes.data)
         finally:
             os.sched_setaffinity(0, before)
         if ms_loop > 0:

@@ -450,3 +450,65 @@ def test_repeated_backward_over_a_retained_tape_matches_the_reference(gtn, passe
         finally:
             gtn.compose_mode(prev)
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4, err_msg="compose mode %d" % mode)
+
+
+def test_batch_route_random_differential_against_the_reference(gtn):
+    """120 random small batches through the batch records (the route bench.py times) against the UNMODIFIED reference
+    run per utterance (benchmarks/ctc.cpp:40-58,150-160): T from 1 to 11, alphabets of 4 to 12 labels, targets of 0 to
+    7 labels -- so empty targets, infeasible ones (more labels than frames: the loss is +inf) and single-frame
+    utterances all occur --, -inf emissions in a third of the batches, calcGrad switched off on either side.  Losses,
+    emission gradients and target-arc gradients must agree wherever the reference's number is finite; where the
+    reference has NaN (a lattice node no finite path enters poisons everything upstream of it, autograd_test.cpp:339-386)
+    the symbolic route has the posteriors the NaN stands for -- the one stated difference."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "refbackend"))
+    try:
+        import gtn_ref as ref
+    except Exception as e:
+        pytest.skip("needs oracle/_ref: %s" % e)
+    rng = np.random.default_rng(5)
+    for trial in range(120):
+        B, T, C = int(rng.integers(1, 5)), int(rng.integers(1, 12)), int(rng.choice([4, 5, 8, 12]))
+        em = (rng.random((B, T, C), dtype=np.float32) * 8 - 4).astype(np.float32)
+        if rng.random() < 0.3:
+            em[rng.random(em.shape) < 0.15] = -np.inf
+        tg = [rng.integers(1, C, size=int(rng.integers(0, 8))).astype(np.int32) for _ in range(B)]
+        cg_t, cg_e = bool(rng.random() < 0.7), bool(rng.random() < 0.9)
+        wl, wg, wt = [], [], []
+        for b in range(B):
+            e = ref.linear_graph(T, C, cg_e)
+            e.set_weights(em[b].reshape(-1))
+            c = gg.to_api(ref, gg.ctc_target_graph(tg[b].tolist()), cg_t)
+            c.arc_sort()
+            l = ref.subtract(ref.forward_score(e), ref.forward_score(ref.intersect(c, e)))
+            if cg_e or cg_t:
+                ref.backward(l)
+            wl.append(np.float32(l.item()))
+            wg.append(e.grad().weights_to_numpy().reshape(T, C) if cg_e else None)
+            wt.append(c.grad().weights_to_numpy() if cg_t else None)
+        em_dev = _dev(em)
+        ctcs = gtn.Batch.ctc_targets(tg, 0, cg_t)
+        ems = gtn.Batch.linear(B, T, C, em_dev, cg_e, True)
+        loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(gtn.intersect(ctcs, ems)))
+        if cg_e or cg_t:
+            gtn.backward(loss)
+        gl = np.array(loss.items(), np.float32)
+        for b in range(B):
+            a, w = gl[b], wl[b]
+            assert (np.isinf(a) and np.isinf(w) and np.sign(a) == np.sign(w)) or (np.isnan(a) and np.isnan(w)) or \
+                abs(a - w) <= 1e-4 * max(1.0, abs(w)), (trial, b, a, w)
+        if cg_e:
+            g = torch.empty(B, T, C, device="cuda:0")
+            ems.grads_to_device(g, np.arange(B, dtype=np.int64) * T * C)
+            g = g.cpu().numpy()
+            for b in range(B):
+                fin = ~np.isnan(wg[b])
+                assert np.all(np.abs(g[b][fin] - wg[b][fin]) <= 2e-4), (trial, b, T, len(tg[b]))
+        if cg_t:
+            for b in range(B):
+                a, w = np.asarray(ctcs[b].grad().weights_to_numpy()), wt[b]
+                assert a.shape == w.shape
+                fin = ~np.isnan(w)
+                assert np.all(np.abs(a[fin] - w[fin]) <= 2e-4 * np.maximum(1.0, np.abs(w[fin]))), (trial, b, T, len(tg[b]))

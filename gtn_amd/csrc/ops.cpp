@@ -214,7 +214,10 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
     arena->bytes = sizeof(float) * size_t(A) * size_t(B);
     arena->borrowed = true;
   } else {
-    arena = rt.alloc(sizeof(float) * size_t(A) * size_t(B > 0 ? B : 1));
+    {
+      GTNX_HOST_T("linear_graphs_device.alloc");
+      arena = rt.alloc(sizeof(float) * size_t(A) * size_t(B > 0 ? B : 1));
+    }
     GTNX_HOST_T("linear_graphs_device.d2d");
     if (dev && A && B) rt.d2d(arena->ptr, dev, sizeof(float) * size_t(A) * size_t(B));
   }
@@ -224,6 +227,7 @@ std::vector<Graph> make_linear_graphs_device(int B, int M, int N, bool calc_grad
   // page faults)
   GraphSlabScope slab_scope(size_t(B > 0 ? B : 0));
   const Runtime::InboxP home = Runtime::home();
+  GTNX_HOST_T("linear_graphs_device.graphs");
   for (int b = 0; b < B; ++b) {
     Graph g = Graph::make_result(calc_grad);
     Structure& s = *g.s;

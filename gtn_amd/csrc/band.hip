@@ -163,6 +163,15 @@ __device__ __forceinline__ void wave_sum63x2(float& a, float& b) {
                GTNX_DPP2("row_bcast:31 row_mask:0xc bank_mask:0xf")
                : "+v"(a), "+v"(b));
 }
+// the same inside every aligned group of 16 lanes (one DPP row): totals in lanes 15, 31, 47, 63
+__device__ __forceinline__ void row_sum15x2(float& a, float& b) {
+  asm volatile("s_nop 1\n\t"
+               GTNX_DPP2("row_shr:1 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_shr:2 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_shr:4 row_mask:0xf bank_mask:0xf")
+               GTNX_DPP2("row_shr:8 row_mask:0xf bank_mask:0xf")
+               : "+v"(a), "+v"(b));
+}
 // all-reduce inside every aligned group of 16 lanes (one DPP row) by rotations
 #define GTNX_ROR4(op)                                                        \
   "s_nop 1\n\t" op " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"    \
@@ -272,7 +281,8 @@ struct Stage {
     for (int i = 0; i < NS / 4; ++i) {
       if (i > 0 && 4 * i * LN >= cnt) break;  // uniform
       const int e = min(4 * (i * LN + tid), cnt - 4);
-      const gtnx_f4 q = *reinterpret_cast<const GTNX_G gtnx_f4*>(src + e);
+      // (e >= 0: a 32-bit BYTE offset beside the uniform base -- no 64-bit lane arithmetic, no register pair per slot)
+      const gtnx_f4 q = *reinterpret_cast<const GTNX_G gtnx_f4*>(reinterpret_cast<const GTNX_G char*>(src) + unsigned(4 * e));
       v[4 * i] = q.x;
       v[4 * i + 1] = q.y;
       v[4 * i + 2] = q.z;
@@ -1037,6 +1047,10 @@ constexpr size_t LDS_ONE = 156 * 1024;  // one
 } // namespace
 
 int band_block_rows(int C, int max_NS, bool backward);
+// The backward sweep's LDS row stride of alpha / posterior rows: with four rows per block one wave sums a block's four
+// posterior rows sixteen lanes per row, sixteen nodes per lane (band_backward_body.inc: ROWSUM4) -- a lane's nodes are
+// inside the row or past it
+static int band_backward_lds_stride(int K, int max_NS) { return K == 4 ? (max_NS + 15) / 16 * 16 : max_NS; }
 int band_max_nodes() { return 512; }
 int band_max_labels() { return 1024; }
 int band_min_labels() { return 4; }  // a chunk of emission rows is fetched with 16-byte loads (Stage::issue)
@@ -1048,7 +1062,8 @@ int band_block_rows(int C, int max_NS, bool backward) {
   for (int k = backward ? 4 : 8; k >= 2; k /= 2) {
     if (k * C > 2048 || k * max_NS > 2048) continue;
     if (backward && k > 2 && (k * C > 1024 || k * max_NS > 1024)) continue;  // 16 staging registers per stream
-    if (4 * size_t(band_lds(C, k, max_NS, backward).total) + 64 <= LDS_TWO) return k;
+    const int ns_lds = backward ? band_backward_lds_stride(k, max_NS) : max_NS;
+    if (4 * size_t(band_lds(C, k, ns_lds, backward).total) + 64 <= LDS_TWO) return k;
   }
   if (4 * size_t(band_lds(C, 2, max_NS, backward).total) + 64 <= LDS_ONE) return 2;
   return 0;
@@ -1084,14 +1099,16 @@ void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int ma
   if (n <= 0) return;
   if (one && (n != 1 || !band_one_ok(npl, C, max_NS, vec, true))) throw std::logic_error("band.hip: not a single-pair launch");
   const int K = band_block_rows(C, max_NS, true);
-  const size_t lds = 4 * size_t(band_lds(C, K, max_NS, true).total) + 64;
   const bool big = K * C > 1024 || K * max_NS > 1024;
+  const int ns_lds = band_backward_lds_stride(K, max_NS);  // (the kernels' NSmax: the stride of rows in LDS, not in HBM)
+  const size_t lds = 4 * size_t(band_lds(C, K, ns_lds, true).total) + 64;
   if (npl == 1) {
-    if (K == 4) launch_bwd<1, 4>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
-    else launch_bwd<1, 2>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
+    if (K == 4) launch_bwd<1, 4>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st);
+    else launch_bwd<1, 2>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st);
   } else {
-    if (K == 4) launch_bwd<2, 4>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
-    else launch_bwd<2, 2>(d_pairs, one, n, max_NS, lds, unit, gradg, vec, big, st);
+    // (four rows per block need K max_NS <= 1024, i.e. at most 256 nodes: one node per lane)
+    if (K == 4) throw std::logic_error("band.hip: four rows per block with two nodes per lane");
+    launch_bwd<2, 2>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st);
   }
 }
 

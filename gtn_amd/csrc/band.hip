@@ -292,14 +292,15 @@ struct Stage {
   // VEC mode: where slot i of a FULL chunk of K rows lands in a ring block whose rows are `stride`
   // floats apart and in reverse order (chunk row r -> block row K-1-r), computed once: a chunk of
   // fewer rows sits (K - rows) block rows lower
+  // (reverse = false: the forward sweep's ring, chunk row r -> block row r)
   int off[NS / 4];
-  __device__ __forceinline__ void init_offsets(int W, int stride, int K, int tid) {
+  __device__ __forceinline__ void init_offsets(int W, int stride, int K, int tid, bool reverse = true) {
     const float invW = 1.0f / float(W);
 #pragma unroll
     for (int i = 0; i < NS / 4; ++i) {
       const int e = 4 * (i * LN + tid);
       const int r = row_of(min(e, 4096), W, invW);
-      off[i] = (K - 1 - r) * stride + (e - r * W);
+      off[i] = (reverse ? K - 1 - r : r) * stride + (e - r * W);
     }
   }
   // f(i, ring offset, values) for the slots of a chunk of `rows` rows of W floats

@@ -28,9 +28,18 @@
 //     guard, and every RN rows each sweeper shifts ITS nodes by their maximum (per-wave shifts summed in fp64;
 //     boundary values are re-based when they cross waves): magnitudes stay O(10) and float32 keeps ~1e-6 relative
 //     accuracy on every posterior for any T;
+//   * the backward recursion works on POSTERIORS: 2^(alpha[t][n] + y_k - score) is the posterior of arc k leaving
+//     (t, n), the three of a node sum to the node's posterior S, and beta[t][n] = log2 S - (alpha[t][n] - score) --
+//     three exponentials and a logarithm per node and step, no shift by a maximum (a posterior is at most 1; one
+//     below 2^-126 is dropped, and with it at most that much of the total mass);
 //   * the backward sweepers write node posteriors into an LDS ring with plain stores; when the last sweeper has left a
-//     block its rows are summed (each row's posteriors are rescaled to their exact total) and the drainers write
-//     the gradient rows; G's arc gradients are register accumulators of the sweepers.
+//     block its rows are summed (each row's posteriors are rescaled to their exact total: at four rows per block by
+//     ONE wave, sixteen lanes per row -- the emission-staging wave that has no chunk to land that tick) and the
+//     drainers write the gradient rows; G's arc gradients are register accumulators of the sweepers.
+// The sweeps are priced in INSTRUCTIONS: a wave alone issues one vector instruction per ~8.5 cycles, a
+// v_cndmask_b32 costs a SIMD 2.6 plain ones, packed float32 arithmetic is free width -- hence no select on a
+// wave-uniform condition in a steady tick, steady ticks compiled without range tests in every role, packed adds and
+// multiplies wherever two values share an instruction.
 // HBM traffic per utterance: forward 4TC + 4(T+1)NS, backward 8TC + 4(T+1)NS (+ G).
 #include <hip/hip_runtime.h>
 

@@ -323,6 +323,37 @@ def test_pair_kernels_ctc_vs_oracle(gtn, B, T, C, U, chain_first, band):
     _ctc_pair_check(gtn, ems, tg, chain_first, band)
 
 
+@pytest.mark.parametrize("B,T,U", [
+    (2, 3, 1),      # fewer rows than one block of four
+    (2, 7, 3),      # a full block and a partial one: no steady tick at all
+    (2, 19, 9),     # the sweepers' first steady tick is the fifth
+    (2, 21, 10),
+    (2, 45, 20),    # a handful of steady ticks, T not a multiple of four
+    (1, 110, 102),  # 205 nodes: LDS row stride 208 (a multiple of 16), the last group of 16 nodes mostly padding
+    (1, 115, 104),  # 209 nodes: four rows per block no longer fit beside a second workgroup (two rows per block)
+])
+def test_band_backward_four_row_blocks_edge_shapes(gtn, B, T, U):
+    """C = 256 (four rows per block, one node per sweeper lane: the timed configuration's kernel instantiation, with a
+    block's four row sums by one staging wave and steady-state ticks in every role) at the sizes where its loops have
+    no steady part, where the rounded LDS row stride differs from the alpha rows' stride in HBM, and where the block
+    size falls back to two rows"""
+    rng = np.random.default_rng(T * 1000 + U)
+    ems = [rng.normal(0, 1, (T, 256)).astype(np.float32) for _ in range(B)]
+    tg = [rng.integers(1, 256, U).tolist() for _ in range(B)]
+    _ctc_pair_check(gtn, ems, tg)
+
+
+def test_band_backward_four_row_blocks_dead_and_live_utterances_in_one_launch(gtn):
+    """one launch at C = 256 with a target that cannot be aligned (more labels than frames), an empty target, a repeated
+    label (needs the blank between: feasible only just) and ordinary ones: the utterance without a path takes the
+    drain path of its own (normaliser's term only), the others the steady ticks"""
+    rng = np.random.default_rng(77)
+    T = 40
+    ems = [rng.normal(0, 1, (T, 256)).astype(np.float32) for _ in range(5)]
+    tg = [rng.integers(1, 256, 12).tolist(), rng.integers(1, 256, 41).tolist(), [], [7] * 20, rng.integers(1, 256, 19).tolist()]
+    _ctc_pair_check(gtn, ems, tg)
+
+
 @pytest.mark.parametrize("band", [True, False])
 def test_pair_kernels_mixed_shapes_in_one_batch(gtn, band):
     """utterances of different length, alphabet and target size in ONE call (launch groups by label

@@ -473,19 +473,56 @@ def per_rank_report(dist, torch, world, dev, host_ms, dt):
     return out
 
 
+class LossGather:
+    """The step's one collective -- all_gather of every rank's losses -- kept OFF the step's critical path: the gather of
+    step s is enqueued asynchronously behind the step's kernels (torch's process group runs it on its own stream) and
+    is waited for when step s + 1 has been enqueued, so it overlaps the next step's sweeps and the ranks are coupled one
+    step apart instead of at every step.  Two loss / result buffers alternate.  (The synchronous form put the
+    collective's latency -- and the slowest rank's jitter -- into every step of every rank.)"""
+
+    def __init__(self, dist, torch, world, B, dev, active):
+        self.dist, self.active = dist, active
+        self.loss = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(2 if active else 1)]
+        self.out = [torch.empty(world * B, dtype=torch.float32, device=dev) for _ in range(2)] if active else None
+        self.work, self.i, self.last = None, 0, 0
+
+    def buffer(self):  # where the step about to run writes its losses
+        return self.loss[self.i]
+
+    def post(self):  # the step has been enqueued: start its gather, wait (on the stream) for the one before
+        self.last = self.i
+        if not self.active:
+            return
+        if self.work is not None:
+            self.work.wait()
+        self.work = self.dist.all_gather_into_tensor(self.out[self.i], self.loss[self.i], async_op=True)
+        self.i ^= 1
+
+    def drain(self):
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+
+    def last_losses(self):
+        return self.loss[self.last]
+
+    def last_gathered(self):
+        return self.out[self.last] if self.active else None
+
+
 def dry_run(args, dist, torch, world, rank, dev):
     """--dry-run-cpu: the collective / timing skeleton of main() over gloo, with a stand-in for the step
     (losses = rank-tagged constants).  Nothing is measured; the line says so."""
     from gtn_amd.distributed import max_over_ranks
     B = args.batch
-    loss_dev = torch.full((B,), float(rank), dtype=torch.float32)
-    gathered = torch.empty(world * B, dtype=torch.float32) if world > 1 else None
+    lg = LossGather(dist, torch, world, B, dev, world > 1)
 
     def step():
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, loss_dev)
+        lg.buffer().fill_(float(rank))
+        lg.post()
 
     def fence():
+        lg.drain()
         if world > 1:
             dist.barrier()
 
@@ -501,6 +538,7 @@ def dry_run(args, dist, torch, world, rank, dev):
     ranks = per_rank_report(dist, torch, world, dev, {}, dt_local)
     line = None
     if rank == 0:
+        gathered = lg.last_gathered()
         ok = gathered is None or all(float(gathered[r * B]) == float(r) for r in range(world))
         line = emit({"metric": "CTC forward+backward losses/sec (T=%d, C=%d)" % (args.T, args.C), "value": None,
                           "unit": "losses/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -590,10 +628,9 @@ def main():
     gtn.set_stream(stream.cuda_stream)
     with torch.cuda.stream(stream):
         em_dev = torch.from_numpy(em).to(dev)
-        loss_dev = torch.empty(B, dtype=torch.float32, device=dev)
-        # ONE flat [world * B] tensor: all_gather_into_tensor writes the ranks' blocks in place (the list form of
-        # all_gather copies world tensors around the collective, host work on every step)
-        gathered = torch.empty(world * B, dtype=torch.float32, device=dev) if world_dist else None
+        # ONE flat [world * B] result tensor per gather: all_gather_into_tensor writes the ranks' blocks in place (the
+        # list form of all_gather copies world tensors around the collective, host work on every step)
+        lg = LossGather(dist, torch, world, B, dev, world_dist)
 
     native = None
     if not args.python_host:
@@ -609,13 +646,12 @@ def main():
         # the step as a gtn user's C++ host code (bench_native/ctc_step.cpp): target
         # graphs built with parallelMap on host threads, graph functions batched
         with torch.cuda.stream(stream):
-            rc = native.gtn_bench_ctc_step(em_dev.data_ptr(), tg.ctypes.data, B, T, Cn, U, loss_dev.data_ptr(),
+            rc = native.gtn_bench_ctc_step(em_dev.data_ptr(), tg.ctypes.data, B, T, Cn, U, lg.buffer().data_ptr(),
                                            grad_dev.data_ptr())
             if rc != 0:
                 native.gtn_bench_last_error.restype = C.c_char_p
                 raise RuntimeError("native step failed: " + native.gtn_bench_last_error().decode())
-            if world_dist:
-                dist.all_gather_into_tensor(gathered, loss_dev)
+            lg.post()
         return None
 
     def vector_step():
@@ -635,13 +671,14 @@ def main():
             comp = gtn.intersect(ctcs, ems)
             loss = gtn.subtract(gtn.forward_score(ems), gtn.forward_score(comp))  # Python: left to right
             gtn.backward(loss)
-            gtn.items_to_device(loss, loss_dev)
-            if world_dist:
-                dist.all_gather_into_tensor(gathered, loss_dev)
+            gtn.items_to_device(loss, lg.buffer())
+            lg.post()
         return ems, comp
 
     def fence():
         if world_dist:
+            with torch.cuda.stream(stream):
+                lg.drain()
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -698,6 +735,7 @@ def main():
                                [round(float(x), 3) for x in buf]))
         except Exception:
             host_ms = None
+    loss_dev = lg.last_losses()  # (what the side legs below write into and read from)
     losses_timed = loss_dev.cpu().numpy().copy()  # of the timed loop's last step
     grad_timed = None
     if native is not None:
@@ -906,8 +944,8 @@ def main():
             # one entry per rank: its own wall time, host phases and host-thread budget (NUMA-pinned when N > 1)
             "per_rank": ranks,
             "numa": numa,
-            "collectives": ("RCCL (nccl backend): all_gather of the losses per step, barrier + all_reduce(MAX) around the timed "
-                            "region" + (" -- forced at world size 1 (GTN_BENCH_FORCE_DIST=1)" if forced and world == 1 else ""))
+            "collectives": ("RCCL (nccl backend): all_gather of the losses per step (asynchronous, overlapping the next step), "
+                            "barrier + all_reduce(MAX) around the timed region" + (" -- forced at world size 1 (GTN_BENCH_FORCE_DIST=1)" if forced and world == 1 else ""))
             if world_dist else None,
             "loss_mean": float(np.mean(losses)),
             # the first utterances of the timed batch, losses and emission gradients, against the reference in this run

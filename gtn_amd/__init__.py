@@ -19,6 +19,7 @@ epsilon = _api.epsilon
 negate = _api.negate
 add = _api.add
 subtract = _api.subtract
+subtract_into = getattr(_api, "subtract_into", None)  # (batches only: the values written into the caller's tensor)
 compose = _api.compose
 intersect = _api.intersect
 forward_score = _api.forward_score

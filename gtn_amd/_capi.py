@@ -117,6 +117,7 @@ _SIGS = {
     "gtnx_batch_negate": [c_graph, c_graph_p],
     "gtnx_batch_add": [c_graph, c_graph, c_graph_p],
     "gtnx_batch_subtract": [c_graph, c_graph, c_graph_p],
+    "gtnx_batch_subtract_into": [c_graph, c_graph, C.c_void_p, c_graph_p],
     "gtnx_batch_compose": [c_graph, c_graph, c_graph_p],
     "gtnx_batch_intersect": [c_graph, c_graph, c_graph_p],
     "gtnx_batch_forward_score": [c_graph, c_graph_p],

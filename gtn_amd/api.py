@@ -637,7 +637,7 @@ def make_api(lib):
         element i as an ordinary Graph.  The module-level functions (intersect, forward_score,
         subtract, backward, ...) accept Batch arguments."""
 
-        __slots__ = ("_h", "__weakref__")
+        __slots__ = ("_h", "_keep", "__weakref__")  # (_keep: a caller's tensor the record borrows, subtract_into)
 
         def __init__(self, graphs=None):
             self._h = None
@@ -739,6 +739,18 @@ def make_api(lib):
         for _name in ("negate", "add", "subtract", "compose", "intersect", "forward_score", "viterbi_score",
                       "viterbi_path"):
             setattr(ns, _name, _with_batches(getattr(ns, _name), getattr(lib, "gtnx_batch_" + _name)))
+
+    def subtract_into(a, b, items_device):
+        """subtract(a, b) of two batches with the values written straight into `items_device` (a torch CUDA tensor or
+        a device address, borrowed: it must outlive the result) -- gtnx_batch_subtract_into"""
+        h = C.c_void_p()
+        check(lib.gtnx_batch_subtract_into(a._h, b._h, _as_dev_ptr(items_device), C.byref(h)))
+        r = Batch._from_handle(h.value)
+        r._keep = items_device
+        return r
+
+    if hasattr(lib, "gtnx_batch_subtract_into"):
+        ns.subtract_into = subtract_into
 
     _plain_backward = ns.backward
 

@@ -80,7 +80,7 @@ inline void ctcLossBatch(
   //  sweep over target o emissions, which reads every emission anyway, leave forwardScore(emissions) behind)
   Batch score = batched::forwardScore(comp);
   Batch norm = batched::forwardScore(ems);
-  Batch losses = batched::subtract(norm, score);
+  Batch losses = batched::subtract(norm, score, lossDev);  // (written where the caller wants them: no copy below)
   auto t4 = now();
   if (gradDev) batched::backward(losses);
   auto t5 = now();

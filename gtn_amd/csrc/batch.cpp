@@ -696,6 +696,12 @@ void batch_materialise(Batch& x) {
       break;
     }
     case Batch::SCALAR: {
+      if (!x.v_mem && x.v_dev) {  // values in the caller's memory (batch_scalar's items_dev): element graphs own theirs
+        Runtime& rt = Runtime::get();
+        x.v_mem = rt.alloc(sizeof(float) * size_t(x.n ? x.n : 1));
+        rt.d2d(x.v_mem->ptr, x.v_dev, sizeof(float) * size_t(x.n));
+        x.v_dev = x.v_mem->as<float>();
+      }
       if (!x.op) {  // the tape is gone (backward without retain): plain values
         gs.reserve(size_t(x.n));
         for (int i = 0; i < x.n; ++i) {
@@ -940,7 +946,7 @@ BatchP scalars_from_graphs(const BatchP& gsb) {
 }
 }  // namespace
 
-BatchP batch_scalar(ScalarKind k, const BatchP& a0, const BatchP& b0) {
+BatchP batch_scalar(ScalarKind k, const BatchP& a0, const BatchP& b0, void* items_dev) {
   BatchP a = a0, b = b0;
   const bool binary = k != SK_NEGATE;
   // one side native, the other the per-graph functions' results: take those in, do not rebuild the native side
@@ -960,8 +966,12 @@ BatchP batch_scalar(ScalarKind k, const BatchP& a0, const BatchP& b0) {
     op->kind = k;
     op->inputs = binary ? std::vector<BatchP>{a, b} : std::vector<BatchP>{a};
     BatchP r = result(Batch::SCALAR, a->n, op);
-    r->v_mem = rt.alloc(sizeof(float) * size_t(a->n ? a->n : 1));
-    r->v_dev = r->v_mem->as<float>();
+    if (items_dev) {  // the values go where the caller wants them (no block of the engine's, no copy afterwards)
+      r->v_dev = static_cast<float*>(items_dev);
+    } else {
+      r->v_mem = rt.alloc(sizeof(float) * size_t(a->n ? a->n : 1));
+      r->v_dev = r->v_mem->as<float>();
+    }
     launch_vec_axpby(r->v_dev, a->v_dev, binary ? b->v_dev : nullptr, size_t(a->n), k == SK_NEGATE ? -1.0f : 1.0f,
                      k == SK_SUBTRACT ? -1.0f : 1.0f, 0, rt.stream());
     return r;
@@ -969,7 +979,9 @@ BatchP batch_scalar(ScalarKind k, const BatchP& a0, const BatchP& b0) {
   batch_materialise(*a);
   std::vector<Graph> none;
   if (binary) batch_materialise(*b);
-  return batch_from_graphs(op_scalar(k, a->graphs, binary ? b->graphs : none));
+  BatchP r = batch_from_graphs(op_scalar(k, a->graphs, binary ? b->graphs : none));
+  if (items_dev) batch_items_device(r, items_dev);
+  return r;
 }
 
 // ---- autograd --------------------------------------------------------------------------------
@@ -1081,6 +1093,7 @@ void batch_backward(const BatchP& root, bool retain) {
 // ---- gathers ---------------------------------------------------------------------------------
 void batch_items_device(const BatchP& x, void* dev_out) {
   if (x->kind == Batch::SCALAR && !x->materialised) {
+    if (static_cast<const void*>(x->v_dev) == dev_out) return;  // (written there in the first place)
     Runtime::get().d2d(dev_out, x->v_dev, sizeof(float) * size_t(x->n));
     return;
   }

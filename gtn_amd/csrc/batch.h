@@ -110,7 +110,9 @@ BatchP batch_linear(int n, int M, int C, bool calc_grad, const void* dev, bool b
 BatchP batch_compose(const BatchP& a, const BatchP& b, bool intersect);
 BatchP batch_shortest_distance(const BatchP& x, bool tropical);
 BatchP batch_viterbi_path(const BatchP& x);
-BatchP batch_scalar(ScalarKind k, const BatchP& a, const BatchP& b);
+// items_dev (optional): device memory of the CALLER's that the n result values are written into directly (borrowed: it
+// must outlive the result); a later batch_items_device to the same address copies nothing
+BatchP batch_scalar(ScalarKind k, const BatchP& a, const BatchP& b, void* items_dev = nullptr);
 void batch_backward(const BatchP& root, bool retain);
 void batch_items_host(const BatchP& x, float* out);
 void batch_items_device(const BatchP& x, void* dev_out);

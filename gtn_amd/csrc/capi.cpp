@@ -840,6 +840,9 @@ GTNX_API gtnx_status_t gtnx_batch_add(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch
 GTNX_API gtnx_status_t gtnx_batch_subtract(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out) {
   return guard([&] { *out = HB(batch_scalar(SK_SUBTRACT, BH(a), BH(b))); });
 }
+GTNX_API gtnx_status_t gtnx_batch_subtract_into(gtnx_batch_t a, gtnx_batch_t b, void* items_device, gtnx_batch_t* out) {
+  return guard([&] { *out = HB(batch_scalar(SK_SUBTRACT, BH(a), BH(b), items_device)); });
+}
 GTNX_API gtnx_status_t gtnx_batch_compose(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out) {
   return guard([&] { *out = HB(batch_compose(BH(a), BH(b), false)); });
 }

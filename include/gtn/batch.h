@@ -128,6 +128,12 @@ namespace batched {
 inline Batch negate(const Batch& a) { return detail::batchUnary(&gtnx_batch_negate, a); }
 inline Batch add(const Batch& a, const Batch& b) { return detail::batchBinary(&gtnx_batch_add, a, b); }
 inline Batch subtract(const Batch& a, const Batch& b) { return detail::batchBinary(&gtnx_batch_subtract, a, b); }
+// ... with the values written straight into device memory of the caller's (which must outlive the result)
+inline Batch subtract(const Batch& a, const Batch& b, void* itemsDevice) {
+  gtnx_batch_t out;
+  detail::check(gtnx_batch_subtract_into(a.handle(), b.handle(), itemsDevice, &out));
+  return Batch::fromHandle(out);
+}
 inline Batch compose(const Batch& a, const Batch& b) { return detail::batchBinary(&gtnx_batch_compose, a, b); }
 inline Batch intersect(const Batch& a, const Batch& b) { return detail::batchBinary(&gtnx_batch_intersect, a, b); }
 inline Batch forwardScore(const Batch& a) { return detail::batchUnary(&gtnx_batch_forward_score, a); }

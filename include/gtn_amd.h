@@ -277,6 +277,10 @@ gtnx_status_t gtnx_batch_get(gtnx_batch_t b, int i, gtnx_graph_t* out);         
 gtnx_status_t gtnx_batch_negate(gtnx_batch_t a, gtnx_batch_t* out);                   /* functions.cpp:18-30 */
 gtnx_status_t gtnx_batch_add(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out);      /* functions.cpp:32-46 */
 gtnx_status_t gtnx_batch_subtract(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out); /* functions.cpp:48-64 */
+/* subtract with the n result values written straight into the caller's device memory (borrowed: it must outlive the
+ * result batch) -- a criterion's losses land where the caller wants them without a copy; gtnx_batch_items_device to the
+ * same address is then a no-op */
+gtnx_status_t gtnx_batch_subtract_into(gtnx_batch_t a, gtnx_batch_t b, void* items_device, gtnx_batch_t* out);
 gtnx_status_t gtnx_batch_compose(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out);  /* functions.cpp:225-237 */
 gtnx_status_t gtnx_batch_intersect(gtnx_batch_t a, gtnx_batch_t b, gtnx_batch_t* out);/* functions.cpp:239-251 */
 gtnx_status_t gtnx_batch_forward_score(gtnx_batch_t a, gtnx_batch_t* out);            /* functions.cpp:320-322 */

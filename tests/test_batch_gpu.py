@@ -38,6 +38,40 @@ def _batch_ctc(gtn, em_dev, tg, T, C, target_grad=True, bind=None):
     return ctcs, ems, loss
 
 
+def test_batch_subtract_into_writes_the_callers_memory(gtn):
+    """gtnx_batch_subtract_into: the losses land in the caller's tensor with no copy (what criteria::ctcLossBatch does);
+    items_to_device to the same tensor is a no-op, to another one a copy; an element taken as a graph owns its value;
+    the gradients are those of subtract"""
+    import torch
+    B, T, C = 6, 50, 20
+    em, tg = _ragged_inputs(3, B, T, C, 8)
+    em_dev = _dev(em)
+    ctcs = gtn.Batch.ctc_targets(tg, 0, True)
+    ems = gtn.Batch.linear(B, T, C, em_dev, True, True)
+    out = torch.full((B,), float("nan"), device="cuda:0")
+    score = gtn.forward_score(gtn.intersect(ctcs, ems))  # (the order of _batch_ctc: the sweep leaves the normaliser behind)
+    loss = gtn.subtract_into(gtn.forward_score(ems), score, out)
+    gtn.backward(loss)
+    gtn.synchronize()
+    got = out.cpu().numpy().copy()
+    want = np.array([ctc_loss(em[b], tg[b])[0] for b in range(B)], np.float32)
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    loss.items_to_device(out)  # (same address: nothing to do)
+    other = torch.zeros(B, device="cuda:0")
+    loss.items_to_device(other)
+    gtn.synchronize()
+    np.testing.assert_array_equal(other.cpu().numpy(), got)
+    np.testing.assert_allclose(np.asarray(loss.items()), got)
+    g0 = loss[2]  # an element as a graph: the batch takes a block of its own
+    out.fill_(0.0)
+    gtn.synchronize()
+    assert g0.item() == pytest.approx(float(got[2]))
+    ctcs2, ems2, loss2 = _batch_ctc(gtn, em_dev, tg, T, C)
+    gtn.backward(loss2)
+    for b in range(B):
+        np.testing.assert_array_equal(ems[b].grad().weights_to_numpy(), ems2[b].grad().weights_to_numpy())
+
+
 @pytest.mark.parametrize("B,T,C,Umax", [(5, 40, 12, 9), (3, 150, 29, 40), (4, 64, 260, 30), (2, 33, 7, 140)])
 def test_batch_ctc_loss_vs_oracle(gtn, B, T, C, Umax):
     """losses and emission gradients of the batch path against the oracle, ragged targets (empty

@@ -447,12 +447,26 @@ __global__ __launch_bounds__(WG) void band_forward_one_kernel(BandPair one, int 
 // block, helper lane c GATHERS the nodes that carry label c (lists sorted by label come with
 // the pair) and stores the finished gradient element -- coalesced, once.
 // ==========================================================================================
+// the pair of a backward launch over the forward launch's table (kernels.h: BandPatch)
+__device__ __forceinline__ BandPair band_patched(BandPair P, const BandPatch& pt) {
+  if (pt.on) {  // (uniform)
+    const int b = P.bidx;
+    P.delta = pt.delta + b;
+    P.delta_norm = pt.delta_norm ? pt.delta_norm + b : nullptr;
+    P.rowlse = pt.rowlse ? pt.rowlse + int64_t(b) * pt.M : nullptr;
+    P.norm = nullptr;
+    P.em_copy = nullptr;
+    P.grad_em = pt.grad_em ? pt.grad_em + int64_t(b) * pt.A : nullptr;
+    P.grad_fixed = pt.grad_fixed ? pt.grad_fixed + P.goff : nullptr;
+  }
+  return P;
+}
 // BIG: a block of K rows holds more than 1024 emissions (K = 2, C > 512): 32 staging registers per
 // helper lane and stream instead of 16 -- such shapes run one workgroup per CU (LDS), so the
 // register budget is 256 there and 128 otherwise
 template <int NPL, bool UNIT, bool GRADG, int K, bool VEC, bool BIG>
-__global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax) {
-#define GTNX_BAND_PAIR pairs[blockIdx.x]
+__global__ __launch_bounds__(WGB, BIG ? 3 : 6) void band_backward_kernel(const BandPair* __restrict__ pairs, int NSmax, BandPatch patch) {
+#define GTNX_BAND_PAIR band_patched(pairs[blockIdx.x], patch)
 #include "band_backward_body.inc"
 #undef GTNX_BAND_PAIR
 }
@@ -1002,7 +1016,8 @@ void launch_fwd(const BandPair* d, const BandPair* one, int n, int ns, size_t ld
   else launch_fwd2<NPL, K, false>(d, one, n, ns, lds, unit, st);
 }
 template <int NPL, int K, bool VEC, bool BIG>
-void launch_bwd3(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st) {
+void launch_bwd3(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, hipStream_t st,
+                 const BandPatch& pt) {
   constexpr bool ONE = NPL == 1 && VEC && !BIG;
   static std::atomic<uint64_t> done{0};
   if (gtnx_first_on_device first{done}) {
@@ -1030,25 +1045,25 @@ void launch_bwd3(const BandPair* d, const BandPair* one, int n, int ns, size_t l
     }
   }
   if (unit) {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, true, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns, pt);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, true, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns, pt);
   } else {
-    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
-    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns);
+    if (gradg) hipLaunchKernelGGL((band_backward_kernel<NPL, false, true, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns, pt);
+    else hipLaunchKernelGGL((band_backward_kernel<NPL, false, false, K, VEC, BIG>), dim3(n), dim3(WGB), lds, st, d, ns, pt);
   }
 }
 template <int NPL, int K>
 void launch_bwd(const BandPair* d, const BandPair* one, int n, int ns, size_t lds, bool unit, bool gradg, bool vec, bool big,
-                hipStream_t st) {
+                hipStream_t st, const BandPatch& pt) {
   if constexpr (K == 2) {
     if (big) {
-      if (vec) launch_bwd3<NPL, K, true, true>(d, one, n, ns, lds, unit, gradg, st);
-      else launch_bwd3<NPL, K, false, true>(d, one, n, ns, lds, unit, gradg, st);
+      if (vec) launch_bwd3<NPL, K, true, true>(d, one, n, ns, lds, unit, gradg, st, pt);
+      else launch_bwd3<NPL, K, false, true>(d, one, n, ns, lds, unit, gradg, st, pt);
       return;
     }
   }
-  if (vec) launch_bwd3<NPL, K, true, false>(d, one, n, ns, lds, unit, gradg, st);
-  else launch_bwd3<NPL, K, false, false>(d, one, n, ns, lds, unit, gradg, st);
+  if (vec) launch_bwd3<NPL, K, true, false>(d, one, n, ns, lds, unit, gradg, st, pt);
+  else launch_bwd3<NPL, K, false, false>(d, one, n, ns, lds, unit, gradg, st, pt);
 }
 
 constexpr size_t LDS_TWO = 78 * 1024;   // two workgroups per CU
@@ -1105,20 +1120,23 @@ void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max
 
 // every pair of the launch shares C; max_NS: largest alpha row stride of the launch
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
-                          hipStream_t st, const BandPair* one) {
+                          hipStream_t st, const BandPair* one, const BandPatch* patch) {
   if (n <= 0) return;
+  if (one && patch) throw std::logic_error("band.hip: a patched launch reads a device table");
+  BandPatch pt{};
+  if (patch) pt = *patch;
   if (one && (n != 1 || !band_one_ok(npl, C, max_NS, vec, true))) throw std::logic_error("band.hip: not a single-pair launch");
   const int K = band_block_rows(C, max_NS, true);
   const bool big = K * C > 1024 || K * max_NS > 1024;
   const int ns_lds = band_backward_lds_stride(K, max_NS);  // (the kernels' NSmax: the stride of rows in LDS, not in HBM)
   const size_t lds = 4 * size_t(band_lds(C, K, ns_lds, true).total) + 64;
   if (npl == 1) {
-    if (K == 4) launch_bwd<1, 4>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st);
-    else launch_bwd<1, 2>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st);
+    if (K == 4) launch_bwd<1, 4>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st, pt);
+    else launch_bwd<1, 2>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st, pt);
   } else {
     // (four rows per block need K max_NS <= 1024, i.e. at most 256 nodes: one node per lane)
     if (K == 4) throw std::logic_error("band.hip: four rows per block with two nodes per lane");
-    launch_bwd<2, 2>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st);
+    launch_bwd<2, 2>(d_pairs, one, n, ns_lds, lds, unit, gradg, vec, big, st, pt);
   }
 }
 

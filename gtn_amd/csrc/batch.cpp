@@ -147,6 +147,8 @@ struct BFsLinearOp : BatchOp {
 struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
   std::vector<BandPair> pairs;
   DevMemP arena;
+  DevMemP fwd_table;  // the forward launch's device table (one launch group, read in place): the backward launch reads
+                      // it again, the pointers that differ travel with the launch (kernels.h: BandPatch)
   // The gradient this op pushes PAST the symbolic product into its inputs.  In the reference the product is a graph
   // with a gradient of its own, which accumulates over backward passes and is re-scattered whole by compose's gradient
   // function in every pass (autograd.cpp:40-52, compose.cpp:496-518): over a retained tape the inputs receive, in
@@ -184,6 +186,8 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
     tab.reserve(pairs.size());
     double bytes = 0;
     const size_t A = size_t(ch.M) * size_t(ch.C);
+    bool one_key = true;
+    int max_ns = 0;
     for (int b = 0; b < prod.n; ++b) {
       BandPair p = pairs[size_t(b)];
       p.delta = delta + b;
@@ -193,10 +197,27 @@ struct BFsBandOp : BatchOp {  // inputs[0]: the PRODUCT
       p.grad_em = ge.ptr ? ge.ptr + size_t(b) * A : nullptr;
       p.grad_fixed = gf.ptr ? gf.ptr + fx.g_off[size_t(b)] : nullptr;
       tab.push_back({BandLaunchKey{p.C, band_npl(p.N), fx.fal ? 0 : 1, p.grad_fixed ? 1 : 0, band_vec_ok(p)}, p});
+      one_key = one_key && tab.back().first == tab.front().first;
+      max_ns = std::max(max_ns, p.NS);
       bytes += 4.0 * p.T * p.C * (p.grad_em ? 2 : 1) + 4.0 * double(p.T + 1) * p.NS +
                (p.grad_fixed ? 4.0 * double(fx.elem_size(b)) : 0.0);
     }
-    band_launch(tab, true, "band_forward_score_grad", bytes);
+    static const bool no_patch = std::getenv("GTNX_NO_BAND_PATCH") != nullptr;
+    if (fwd_table && one_key && prod.n > 1 && !no_patch) {
+      // every field the loop above changed is a base + the pair's index (or the offset the table carries): no upload
+      BandPatch pt{};
+      pt.on = 1;
+      pt.M = ch.M;
+      pt.delta = delta;
+      pt.delta_norm = lin_out ? lin_out->g_dev : nullptr;
+      pt.rowlse = lin_out ? ch.nc_rowlse : nullptr;
+      pt.grad_em = ge.ptr;
+      pt.grad_fixed = gf.ptr;
+      pt.A = int64_t(A);
+      band_launch_patched(fwd_table, prod.n, tab.front().first, max_ns, pt, "band_forward_score_grad", bytes);
+    } else {
+      band_launch(tab, true, "band_forward_score_grad", bytes);
+    }
     if (ch.calc_grad) add_scratch(ch, ge);
     if (fx.calc_grad) add_scratch(fx, gf);
     (void)rt;
@@ -822,6 +843,7 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
         pend->settle();
       }
     }
+    int64_t goff_run = 0;
     for (int b = 0; b < n; ++b) {
       BandPair& p = op->pairs[size_t(b)];
       p = BandPair{};
@@ -851,6 +873,9 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
       }
       p.hot = (!fx.fal && U + 1 >= 8) ? fx.blank : -1;
       p.lgrn = band_forward_lgrn(C);
+      p.bidx = b;
+      p.goff = goff_run;  // (the prefix sums alloc_grad makes at backward time: elements back to back)
+      goff_run += int64_t(fx.elem_size(b));
       // The chain's values may still be in the caller's buffer (staged by the region this sweep belongs to): the
       // sweep reads them THERE and stores them at p.em on its way -- the copy the region owes -- so that the
       // backward sweep, and anybody else later, reads the graph's own copy.  (p, as kept for backward: the copy.)
@@ -862,7 +887,8 @@ BatchP batch_shortest_distance(const BatchP& x, bool tropical) {
       tab.push_back({BandLaunchKey{C, band_npl(q.N), fx.fal ? 0 : 1, 0, band_vec_ok(q)}, q});
       abytes += 4.0 * T * C + 4.0 * double(T + 1) * p.NS + (fuse_copy ? 4.0 * T * C : 0.0);
     }
-    band_launch(tab, false, "band_forward_score", abytes);
+    // (a launch that also makes the region's copy reads the caller's buffer: its table is not the backward sweep's)
+    band_launch(tab, false, "band_forward_score", abytes, fuse_copy ? nullptr : &op->fwd_table);
     if (fuse_copy) pend->done.store(true, std::memory_order_release);  // (under pend->mu, taken above)
     if (want_norm) {
       ch.nc_mem = op->arena;

@@ -503,7 +503,22 @@ struct BandPair {
   int N, T, C, NS;
   int hot;                         // label shared by >= 8 nodes of G (CTC: blank), or -1
   int lgrn;                        // log2 of the rows per shift period of the forward launch
-  int n_lab, pad;
+  int n_lab;
+  int bidx;                        // the pair's index in its batch record (BandPatch)
+  int64_t goff;                    // offset of G's arc gradients inside the batch's gradient block (BandPatch)
+};
+// A backward launch over the table the FORWARD launch left on the device: what differs between the two launches of a
+// batch record -- where the upstream gradients are read and the gradients written -- travels by value with the launch,
+// as bases the kernel offsets by the pair's index (one table upload, a 5 us launch of its own, less per step).
+struct BandPatch {
+  int on;                          // 0: the table is complete (every launch but a batch record's backward)
+  int M;                           // rows of a chain (stride of rowlse)
+  const GTNX_G float* delta;       // [n]
+  const GTNX_G float* delta_norm;  // [n] or null
+  GTNX_G float* rowlse;            // [n][M] or null
+  GTNX_G float* grad_em;           // [n][A] or null
+  GTNX_G float* grad_fixed;        // + goff, or null
+  int64_t A;                       // arcs of a chain (stride of grad_em)
 };
 // viterbiScore / viterbiPath of chain o (banded G): one workgroup per pair (band.hip)
 struct BandDecode {
@@ -625,8 +640,9 @@ int band_forward_lgrn(int C);
 bool band_one_ok(int npl, int C, int max_NS, bool vec, bool backward);
 void launch_band_forward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool vec, hipStream_t st,
                          const BandPair* one = nullptr);
+// patch (optional; not with `one`): d_pairs is the table a FORWARD launch used -- see BandPatch
 void launch_band_backward(const BandPair* d_pairs, int n, int npl, int C, int max_NS, bool unit, bool gradg, bool vec,
-                          hipStream_t st, const BandPair* one = nullptr);
+                          hipStream_t st, const BandPair* one = nullptr, const BandPatch* patch = nullptr);
 // dense regime
 void launch_lazy_dense_prep(const LazyGroup& g, float* E, float* cmax, hipStream_t st);  // nlab must be set
 // backward: vin / vout = the two halves of a [2][nb][N] scratch (vin null on the first step)

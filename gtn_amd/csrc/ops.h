@@ -60,8 +60,13 @@ struct BandLaunchKey {
   bool operator==(const BandLaunchKey& o) const { return !(*this < o) && !(o < *this); }
 };
 int band_vec_ok(const BandPair& p);
+// prof_name: a profiled span (Runtime::Scope) around the kernel launches only.  table_out (forward launches of a batch
+// record): the device table of a launch that was ONE group, kept for the record's backward (kernels.h: BandPatch)
 void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, const char* prof_name = nullptr,
-                 double prof_bytes = 0.0);  // prof_name: a profiled span (Runtime::Scope) around the kernel launches only
+                 double prof_bytes = 0.0, DevMemP* table_out = nullptr);
+// the backward launch of a batch record over its forward launch's table: no upload
+void band_launch_patched(const DevMemP& table, int n, const BandLaunchKey& key, int max_ns, const BandPatch& patch,
+                         const char* prof_name, double prof_bytes);
 
 enum ScalarKind { SK_NEGATE = 0, SK_ADD = 1, SK_SUBTRACT = 2 };
 

@@ -8,8 +8,17 @@ namespace gtnx {
 
 int band_vec_ok(const BandPair& p) { return p.C % 4 == 0 && (reinterpret_cast<uintptr_t>(p.em) & 15) == 0; }
 // launches `tab` grouped by (C, nodes per lane, unit, G wants a gradient, 16-byte staging)
-void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, const char* prof_name, double prof_bytes) {
+void band_launch_patched(const DevMemP& table, int n, const BandLaunchKey& k, int max_ns, const BandPatch& patch,
+                         const char* prof_name, double prof_bytes) {
   Runtime& rt = Runtime::get();
+  std::unique_ptr<Runtime::Scope> prof(prof_name ? new Runtime::Scope(&rt, prof_name, prof_bytes) : nullptr);
+  launch_band_backward(table->as<BandPair>(), n, k.npl, k.C, max_ns, k.unit != 0, k.gradg != 0, k.vec != 0, rt.stream(), nullptr,
+                       &patch);
+}
+void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool backward, const char* prof_name, double prof_bytes,
+                 DevMemP* table_out) {
+  Runtime& rt = Runtime::get();
+  if (table_out) table_out->reset();
   if (tab.empty()) return;
   bool one_key = true;  // (a criterion step: every pair has the same shape -- nothing to group)
   for (size_t i = 1; i < tab.size() && one_key; ++i) one_key = tab[i].first == tab[0].first;
@@ -29,6 +38,7 @@ void band_launch(std::vector<std::pair<BandLaunchKey, BandPair>>& tab, bool back
   for (auto& e : tab) flat.push_back(e.second);
   DevMemP d = upload_vec(flat);
   const BandPair* dp = d->as<BandPair>();
+  if (table_out && one_key) *table_out = d;
   // (the profiled span is the KERNEL launches: the table's upload -- a 5 us copy kernel -- is in front of it.  bench.py's
   //  roofline figure is algorithmic bytes over this span; until round 6 the span held the upload too and read 1.5 % low
   //  against rocprofv3's kernel time.)

@@ -16,6 +16,7 @@ for cfg in "$@"; do
     no_fused_copy) run no_fused_copy GTNX_NO_FUSED_COPY=1 ;;
     no_node_order) run no_node_order GTNX_NO_NODE_ORDER_TIES=1 ;;
     # round 6
+    no_band_patch) run no_band_patch GTNX_NO_BAND_PATCH=1 ;;
     no_ranked_first) run no_ranked_first GTNX_NO_RANKED_FIRST=1 ;;
     no_closed_ranks) run no_closed_ranks GTNX_NO_CLOSED_RANKS=1 ;;
     check_closed_ranks) run check_closed_ranks GTNX_CHECK_CLOSED_RANKS=1 ;;

@@ -103,7 +103,7 @@ def emit(full):
     """write the full record beside the script (bench_out/last_full.json; also under $GRAFT_REPO_ROOT/gpurun_out when
     that exists, so a gpurun call brings it home); returns the compact line for say_last()"""
     import hashlib
-    text = json.dumps(full)
+    text = json.dumps(full) + "\n"  # (sha256 and bytes below are those of the FILE: `sha256sum bench_out/last_full.json`)
     ref = None
     for d in (OUT_DIR, os.path.join(ROOT, "gpurun_out")):
         try:
@@ -111,7 +111,7 @@ def emit(full):
                 continue  # (a child process with its own output directory does not touch the parent's copy)
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, "last_full.json"), "w") as f:
-                f.write(text + "\n")
+                f.write(text)
             if ref is None:
                 ref = {"path": os.path.relpath(os.path.join(d, "last_full.json"), ROOT), "sha256": hashlib.sha256(text.encode()).hexdigest(), "bytes": len(text)}
         except OSError:

@@ -115,8 +115,9 @@ def test_bench_multi_rank_branch_under_gloo(world, tmp_path):
               "config", "full_record"):
         assert k in line, k
     import hashlib
-    text = open(os.path.join(str(tmp_path), "last_full.json")).read().rstrip("\n")
-    assert hashlib.sha256(text.encode()).hexdigest() == line["full_record"]["sha256"]
+    raw = open(os.path.join(str(tmp_path), "last_full.json"), "rb").read()  # (the digest is the FILE's: sha256sum agrees)
+    assert hashlib.sha256(raw).hexdigest() == line["full_record"]["sha256"] and len(raw) == line["full_record"]["bytes"]
+    text = raw.decode()
     assert line["rank_seconds"] and len(line["rank_seconds"]) == world
     out = json.loads(text)
     assert out["n_gpus"] == world and out["steps"] == 4 and out["warmup"] == 1 and out["scaling"] == "weak"

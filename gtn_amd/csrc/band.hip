@@ -1081,7 +1081,14 @@ int band_max_labels() { return 1024; }
 int band_min_labels() { return 4; }  // a chunk of emission rows is fetched with 16-byte loads (Stage::issue)
 int band_npl(int max_nodes) { return max_nodes <= 256 ? 1 : 2; }
 int band_row_stride(int N, int) { return (N + 3) / 4 * 4; }
-int band_forward_lgrn(int C) { return band_block_rows(C, 0, false) >= 4 ? 2 : 1; }
+#ifndef GTNX_FWD_SHIFT_ROWS
+#define GTNX_FWD_SHIFT_ROWS 4
+#endif
+// (log2 of RNk in band_forward_body.inc: the rows between two shifts of a wave's running row)
+int band_forward_lgrn(int C) {
+  const int K = band_block_rows(C, 0, false);
+  return K >= GTNX_FWD_SHIFT_ROWS ? (GTNX_FWD_SHIFT_ROWS == 8 ? 3 : 2) : (K >= 4 ? 2 : 1);
+}
 // rows per tick: the largest block that keeps two workgroups on a CU, else the smallest (one per CU)
 int band_block_rows(int C, int max_NS, bool backward) {
   for (int k = backward ? 4 : 8; k >= 2; k /= 2) {
